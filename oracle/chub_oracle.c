@@ -1113,6 +1113,8 @@ void orc_env_step(orc_env *e, const float *action, const double *exo_z, double *
         used_renew = re_new_power;
     }
     e->used_renew = used_renew;
+    e->ev_list[0] = ev_list[0]; /* self.re_ev_power_list is taken BEFORE the fuel-cell rescale, MGR:212 */
+    e->ev_list[1] = ev_list[1];
     /* MGR:215-227 fuel cell */
     double fc_power;
     if (gen_hy) fc_power = use_cell(e, 0, ev_power_sum);
@@ -1128,8 +1130,6 @@ void orc_env_step(orc_env *e, const float *action, const double *exo_z, double *
         }
     }
     double hy_loss = -6 / 1000.0 * e->hy_to_use;
-    e->ev_list[0] = ev_list[0];
-    e->ev_list[1] = ev_list[1];
     e->hydrogen_power_grid = hydrogen_power;
     /* MGR:233-269 incomes and reward */
     double real_price_dollar = e->price_next / 4;
@@ -1316,3 +1316,24 @@ int orc_env_telemetry(const orc_env *e, double *out) {
     out[i++] = (double) e->wd_day;     /* 23 */
     return i;
 }
+
+/* Reference constructor order with live streams (MGR:25-130): station constructors each run one
+ * evs_reset (CHS:1152,1462), HySystem's 101-step sweep runs real hvs_step()s (HYD:154,168).  The
+ * caller then performs the constructor's own reset() (MGR:120) with that reset's exogenous tape. */
+void orc_env_init_compat_ctor(orc_env *e, const orc_config *cfg, const orc_tables *t, uint32_t glibc_seed,
+                              uint32_t minstd_seed) {
+    orc_env_init(e, cfg, t);
+    orc_rng_seed_compat(&e->rng, glibc_seed, minstd_seed);
+    orc_station_reset(&e->st[0], &e->rng, t);
+    orc_station_reset(&e->st[1], &e->rng, t);
+    e->capacity = cfg->init_soc * e->cap_mass;
+    e->store_soc = cfg->init_soc;
+    e->sys_time = 0;
+    for (int i = 0; i < 101; i++) e->hy_table[i] = hy_step(e, 0.01 * i, NULL);
+    e->hy_table[101] = e->hy_table[100];
+    hy_reset(e);
+}
+
+/* override the action->power table (used when the reference's construction sweep was clamp-bound
+ * and therefore depended on its live random FCEV demand, HYD:154,168,172-173) */
+void orc_env_set_hy_table(orc_env *e, const double *in102) { memcpy(e->hy_table, in102, sizeof e->hy_table); }

@@ -198,6 +198,9 @@ orc_station *orc_env_station(orc_env *e, int k);
 orc_rng *orc_env_rng(orc_env *e);
 void orc_env_hy_table(const orc_env *e, double *out102);
 int orc_env_telemetry(const orc_env *e, double *out24);
+void orc_env_set_hy_table(orc_env *e, const double *in102);
+void orc_env_init_compat_ctor(orc_env *e, const orc_config *cfg, const orc_tables *t, uint32_t glibc_seed,
+                              uint32_t minstd_seed);
 
 #ifdef __cplusplus
 }

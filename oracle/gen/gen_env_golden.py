@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE -- generates tests/golden/env_*.npz from the UNMODIFIED reference.
+
+Runs only in the build container (needs /root/reference and oracle/_ref/libchs_ref.so).  The
+reference's Python host (evcssp_manager.py, Aggregator_Simple.py, hydro_sys.py, renewable.py) is
+imported as it lies; the two module names it needs that the image lacks are bound by
+oracle/gen/stubs/: `pyevstation` (ctypes binding onto the real CHS.hpp build) and `gym` (inert base
+class / Box / seeding names).  All arithmetic runs in reference code.
+
+Each fixture is DATA: constructor kwargs, the two C++ stream seeds installed right before reset(),
+the per-step action tape, the exogenous tape (pv_day, wd_day and every np.random.normal() draw the
+reference made, in order) and the resulting obs / reward / done / telemetry / station outputs.
+"""
+import io
+import contextlib
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("CHUB_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, "stubs"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import pyevstation  # noqa: E402  (the stub binding; registers the real C++ core)
+
+sys.modules["lion_cpp20.pyevstation"] = pyevstation
+sys.path.insert(0, REF)
+with contextlib.redirect_stdout(io.StringIO()):
+    from evcssp_env_cpp.envs.evcssp_manager import EvcsspManagerEnv_v6  # noqa: E402
+import orclib  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+TELEM = ["hy_act", "hy_flow_speed", "all_power_second", "Store_SOC", "capacity", "total_mass_need", "hy_use",
+         "not_meet", "fc_power", "hy_to_use", "re_used_renew", "ev0", "ev1", "re_hydrogen_power", "income",
+         "reward", "re_pv_power", "re_wd_power", "price_next", "arrive_number", "hvs_line", "queue_len"]
+
+
+class Recorder:
+    """Records every np.random.normal() draw and which OU channel consumed it."""
+
+    def __init__(self):
+        self.z = {}
+        self.raw = []
+        self._last = None
+        self._orig = np.random.normal
+
+        def normal(*a, **k):
+            v = self._orig(*a, **k)
+            self._last = float(v)
+            self.raw.append(float(v))
+            return v
+
+        np.random.normal = normal
+
+    def attach(self, env):
+        for name, noise in (("pv", env.renew.pv_noise), ("wd", env.renew.wd_noise), ("price", env.price_noise)):
+            self._wrap(name, noise)
+
+    def _wrap(self, name, noise):
+        orig = noise.sample
+
+        def sample():
+            out = orig()
+            self.z[name] = self._last
+            return out
+
+        noise.sample = sample
+
+    def take(self):
+        z = [self.z.get("pv", np.nan), self.z.get("wd", np.nan), self.z.get("price", np.nan)]
+        self.z = {}
+        return z
+
+    def close(self):
+        np.random.normal = self._orig
+
+
+def telemetry(env):
+    h = env.hy_sys
+    return [env.hy_act, h.hy_flow_speed, h.all_power_second, h.sty.Store_SOC, h.sty.capacity, h.hvs.total_mass_need,
+            h.sty.hy_use, h.sty.not_meet, env.fc_power, env.hfc.hy_to_use, env.re_used_renew,
+            env.re_ev_power_list[0], env.re_ev_power_list[1], env.re_hydrogen_power, env.income, env._last_reward,
+            env.re_pv_power, env.re_wd_power, float(env.real_state[1]), h.hvs.arrive_number, h.hvs.line,
+            len(h.hvs.needed_time_list)]
+
+
+def station_block(env):
+    out = []
+    for st in env.env_aggregator.evcssp_evs_objects:
+        sc = st._sc()
+        out.append(sc[:6])
+    return np.concatenate(out)
+
+
+def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0, reseed_each_episode=False):
+    random.seed(py_seed)
+    np.random.seed(py_seed)
+    rec = Recorder()
+    with contextlib.redirect_stdout(io.StringIO()):
+        env = EvcsspManagerEnv_v6(**kwargs)
+    # the constructor runs one reset() (MGR:120): its exogenous draws shape the OU states we start from
+    ctor_days = [env.renew.pv_day, env.renew.wd_day]
+    raw = list(rec.raw)
+    from evcssp_env_cpp.envs.lion_cpp20.renewable import pv_power_data
+    pv_drawn = pv_power_data[ctor_days[0]][0] > 0 and ctor_days[0] % 2 == 0
+    ctor_z = [raw.pop(0) if pv_drawn else np.nan, raw.pop(0), raw.pop(0)]
+    assert not raw
+    rec.attach(env)
+    rec.take()
+    S = sum(kwargs["station_list"])
+    rs = np.random.RandomState(1234 + S)
+    D = int(env.observation_space.shape[0])
+    hy_table = np.array(env.hy_sys.hy_power_speed_list, dtype=np.float64)
+    data = dict(obs=[], reward=[], done=[], action=[], exo_z=[], telem=[], stations=[], reset_obs=[], reset_days=[],
+                reset_z=[], reset_stations=[], slots0=[], slots1=[], seeds=[])
+    for ep in range(episodes):
+        if seeds is not None and (ep == 0 or reseed_each_episode):
+            g, m = seeds[0] + ep, seeds[1] + ep
+            orclib.ref().ref_seed(g, m)
+            data["seeds"].append([ep, g, m])
+        with contextlib.redirect_stdout(io.StringIO()):
+            o = env.reset()
+        data["reset_obs"].append(np.array(o, dtype=np.float64))
+        data["reset_days"].append([env.renew.pv_day, env.renew.wd_day])
+        data["reset_z"].append(rec.take())
+        data["reset_stations"].append(station_block(env))
+        for t in range(steps_per_episode):
+            if action_kind == "none":
+                act_in = None
+                act = np.append(np.ones(S), [0, 0]).astype(np.float32)
+            else:
+                # dyadic grid (multiples of 2^-10) so f32 and f64 decodes of (a+1)/2 coincide
+                act = (rs.randint(-1024, 1025, size=S + 2) / 1024.0).astype(np.float32)
+                if action_kind == "random_hi":  # bias the electrolyser request high to hit the clamp
+                    act[S] = np.float32(rs.randint(512, 1025) / 1024.0)
+                act_in = act.copy()
+            with contextlib.redirect_stdout(io.StringIO()):
+                o, r, d, _ = env.step(act_in)
+            env._last_reward = r
+            data["action"].append(act)
+            data["obs"].append(np.array(o, dtype=np.float64))
+            data["reward"].append(r)
+            data["done"].append(d)
+            data["exo_z"].append(rec.take())
+            data["telem"].append(telemetry(env))
+            data["stations"].append(station_block(env))
+            sts = env.env_aggregator.evcssp_evs_objects
+            data["slots0"].append(sts[0].slots())
+            data["slots1"].append(sts[1].slots())
+    rec.close()
+    out = {k: np.array(v) for k, v in data.items() if k not in ("slots0", "slots1")}
+    out["slots0"] = np.array(data["slots0"], dtype=np.float32)
+    out["slots1"] = np.array(data["slots1"], dtype=np.float32)
+    out["hy_table"] = hy_table
+    out["ctor_days"] = np.array(ctor_days)
+    out["ctor_z"] = np.array(ctor_z)
+    out["obs_dim"] = np.array(D)
+    kw = dict(kwargs)
+    out["kw_station_list"] = np.array(kw.pop("station_list"))
+    out["kw_station_type"] = np.array([0 if t == "fast" else 1 for t in kw.pop("station_type_list")])
+    for k, v in kw.items():
+        out["kw_" + k] = np.array(float(v))
+    out["episodes"] = np.array(episodes)
+    out["steps_per_episode"] = np.array(steps_per_episode)
+    out["telem_names"] = np.array(TELEM)
+    out["ret"] = np.array(float(np.sum(out["reward"][:steps_per_episode])))
+    os.makedirs(GOLD, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "obs_dim", D, "steps", len(out["reward"]), "return(ep0)", repr(float(out["ret"])),
+          "final SOC", out["telem"][-1][3], "max queue", out["telem"][:, 21].max())
+    return out
+
+
+def base_kwargs(**over):
+    kw = {"station_list": [20, 25], "station_type_list": ["fast", "slow"], "constant_charging": False,
+          "seed_rand": False, "hydro_prod_rate": 100, "hydro_store_vlt": 500 / 20, "init_soc": 0.2,
+          "fc_max_power": 100, "fcev_permeate": 0.01, "use_lagrange": False, "renew_fluctuate": 0.0,
+          "price_fluctuate": 0.0, "hydro_loss": 0.0}
+    kw.update(over)
+    return kw
+
+
+def main():
+    # C1: the reference's own smoke test (test/env_test.py:14-49) -- default C++ seeds, action=None.
+    # Must be first: it relies on the process-default stream state (srand never called, e seed 1).
+    run("env_c1_envtest", base_kwargs(), 1, 96, "none", None, py_seed=0)
+    # C3/C4 hub, random actions, explicit stream seeds, 2 episodes
+    run("env_c3_random", base_kwargs(), 2, 96, "random", (101, 202), py_seed=1)
+    # C2 hub: 16 fast, EV-only
+    run("env_c2_random", base_kwargs(station_list=[16, 0], fcev_permeate=0.0), 2, 96, "random", (303, 404), py_seed=2)
+    # C5 hub with fluctuations and loss
+    run("env_c5_random", base_kwargs(station_list=[32, 32], renew_fluctuate=0.3, price_fluctuate=0.3,
+                                     hydro_loss=0.02), 2, 96, "random", (505, 606), py_seed=3)
+    # slow-only hub, high FCEV permeate (queue carries over), mid-episode reset (40-step episodes)
+    run("env_slow_only_fcev", base_kwargs(station_list=[0, 25], fcev_permeate=0.05), 3, 40, "random", (707, 808),
+        py_seed=4, reseed_each_episode=True)
+    # big electrolyser on a big hub: exercises the grid-limit clamp branch (MGR:164-175)
+    run("env_clamp", base_kwargs(station_list=[64, 64], hydro_prod_rate=2000, hydro_store_vlt=5000, init_soc=0.5),
+        1, 96, "random_hi", (909, 1010), py_seed=5)
+    # nearly full tank: upper_charge clamp (HYD:173-176), slow/fast order swapped
+    run("env_full_tank", base_kwargs(station_list=[12, 10], station_type_list=["slow", "fast"], init_soc=0.95,
+                                     hydro_store_vlt=5), 1, 96, "random", (1111, 1212), py_seed=6)
+    # constant-power fleet mode
+    run("env_constant", base_kwargs(constant_charging=True), 1, 96, "random", (1313, 1414), py_seed=7)
+
+
+if __name__ == "__main__":
+    main()

@@ -77,6 +77,7 @@ void ref_rng_load(const char *buf) {
     memcpy(&v, buf + 128, sizeof v);
     e.seed(v);
 }
+void ref_change_use_seed(int v) { Change_Use_Seed(v != 0); }   // binding of CHS.hpp:27 (main.cpp:21)
 int ref_c_rand() { return rand(); }
 unsigned ref_minstd_next() { return (unsigned) e(); }
 float ref_uniform_rand(float a, float b) { return RandomUtil::uniform_rand(a, b); }

@@ -101,12 +101,14 @@ def _load_oracle():
         "orc_env_alloc": (P, []),
         "orc_env_free": (None, [P]),
         "orc_env_init": (None, [P, P, P]),
+        "orc_env_init_compat_ctor": (None, [P, P, P, C.c_uint32, C.c_uint32]),
         "orc_env_reset": (None, [P, P, P, P]),
         "orc_env_step": (None, [P, P, P, P, P, P]),
         "orc_env_obs_dim": (I, [P]),
         "orc_env_station": (P, [P, I]),
         "orc_env_rng": (P, [P]),
         "orc_env_hy_table": (None, [P, P]),
+        "orc_env_set_hy_table": (None, [P, P]),
         "orc_env_telemetry": (I, [P, P]),
         "orc_vec_create": (P, [P, P, C.c_long, C.c_long, I, C.c_uint64]),
         "orc_vec_destroy": (None, [P]),
@@ -245,5 +247,90 @@ class RefStation:
     def __del__(self):
         try:
             ref().ref_station_free(self.h)
+        except Exception:
+            pass
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+
+
+def golden_config(g):
+    """orc_config from a fixture's recorded constructor kwargs."""
+    sl = [int(x) for x in g["kw_station_list"]]
+    st = ["fast" if int(x) == 0 else "slow" for x in g["kw_station_type"]]
+    return make_config(piles=sl, types=st, constant_charging=bool(g["kw_constant_charging"]),
+                       hydro_prod_rate=float(g["kw_hydro_prod_rate"]), hydro_store_vlt=float(g["kw_hydro_store_vlt"]),
+                       init_soc=float(g["kw_init_soc"]), fc_max_power=float(g["kw_fc_max_power"]),
+                       fcev_permeate=float(g["kw_fcev_permeate"]), renew_fluctuate=float(g["kw_renew_fluctuate"]),
+                       price_fluctuate=float(g["kw_price_fluctuate"]), hydro_loss=float(g["kw_hydro_loss"]))
+
+
+GOLDEN_ENV = ["env_c1_envtest", "env_c3_random", "env_c2_random", "env_c5_random", "env_slow_only_fcev",
+              "env_clamp", "env_full_tank", "env_constant"]
+
+
+class OrcEnv:
+    def __init__(self, cfg, ctor_seeds=None):
+        self.cfg = cfg
+        self.e = orc.orc_env_alloc()
+        if ctor_seeds is None:
+            orc.orc_env_init(self.e, C.byref(cfg), tables())
+        else:
+            orc.orc_env_init_compat_ctor(self.e, C.byref(cfg), tables(), ctor_seeds[0], ctor_seeds[1])
+        self.D = orc.orc_env_obs_dim(C.byref(cfg))
+        self.S = cfg.piles[0] + cfg.piles[1]
+
+    def seed_compat(self, g, m):
+        orc.orc_rng_seed_compat(orc.orc_env_rng(self.e), g, m)
+
+    def seed_philox(self, seed, env_id):
+        orc.orc_rng_seed_philox(orc.orc_env_rng(self.e), seed, env_id)
+
+    def reset(self, days=None, z=None):
+        obs = np.zeros(self.D)
+        d = np.asarray(days, dtype=np.int32) if days is not None else None
+        zz = np.nan_to_num(np.asarray(z, dtype=np.float64)) if z is not None else None
+        orc.orc_env_reset(self.e, ptr(d), ptr(zz), ptr(obs))
+        return obs
+
+    def step(self, action, z=None):
+        obs = np.zeros(self.D)
+        r = C.c_double()
+        d = C.c_int()
+        a = np.ascontiguousarray(action, dtype=np.float32)
+        zz = np.nan_to_num(np.asarray(z, dtype=np.float64)) if z is not None else None
+        orc.orc_env_step(self.e, ptr(a), ptr(zz), ptr(obs), C.byref(r), C.byref(d))
+        return obs, r.value, bool(d.value)
+
+    def telemetry(self):
+        out = np.zeros(24)
+        orc.orc_env_telemetry(self.e, ptr(out))
+        return out
+
+    def hy_table(self):
+        out = np.zeros(102)
+        orc.orc_env_hy_table(self.e, ptr(out))
+        return out
+
+    def set_hy_table(self, tab):
+        t = np.ascontiguousarray(tab, dtype=np.float64)
+        assert t.shape == (102,)
+        orc.orc_env_set_hy_table(self.e, ptr(t))
+
+    def station_scalars(self, k):
+        out = np.zeros(8)
+        orc.orc_station_scalars(orc.orc_env_station(self.e, k), ptr(out))
+        return out
+
+    def station_slots(self, k):
+        n = self.cfg.piles[k]
+        out = np.zeros((9, n), dtype=np.float32)
+        orc.orc_station_slots(orc.orc_env_station(self.e, k), ptr(out))
+        return out
+
+    def __del__(self):
+        try:
+            orc.orc_env_free(self.e)
         except Exception:
             pass

@@ -1,0 +1,77 @@
+"""Oracle (CPU restatement) vs golden trajectories recorded from the unmodified reference
+(tests/golden/env_*.npz, generator oracle/gen/gen_env_golden.py).  No GPU, no reference tree needed."""
+import numpy as np
+import pytest
+
+import orclib
+from orclib import OrcEnv
+
+# fixtures whose construction sweep (HYD:154) hit a tank clamp (loss below 10 % / nearly full tank)
+CLAMP_BOUND_SWEEP = {"env_c5_random", "env_full_tank"}
+RTOL = 1e-12  # f64 host arithmetic restated op-for-op; observed agreement is ~1e-15
+
+
+def _close(a, b, what, rtol=RTOL, atol=1e-12):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert np.allclose(a, b, rtol=rtol, atol=atol), (what, a, b, np.abs(a - b).max())
+
+
+def replay(name, make_env_and_check):
+    g = orclib.load_golden(name)
+    cfg = orclib.golden_config(g)
+    return g, cfg
+
+
+@pytest.mark.parametrize("name", orclib.GOLDEN_ENV)
+def test_env_trajectory_matches_reference(name):
+    g = orclib.load_golden(name)
+    cfg = orclib.golden_config(g)
+    steps = int(g["steps_per_episode"])
+    seeds = {int(ep): (int(a), int(b)) for ep, a, b in g["seeds"]} if g["seeds"].size else {}
+    if name == "env_c1_envtest":
+        # the reference's own smoke test: default C++ seeds (rand() never srand()ed -> 1; e -> 1), so the
+        # constructor's draws matter and are replayed in reference order
+        env = OrcEnv(cfg, ctor_seeds=(1, 1))
+        assert np.array_equal(env.hy_table(), g["hy_table"])
+    else:
+        env = OrcEnv(cfg)
+        env.seed_compat(1, 1)
+        # zero-demand sweep == reference sweep unless a tank clamp binds during construction; with
+        # hydro_loss > 0 the must-charge clamp (HYD:172) binds and the reference's table then depends
+        # on its live random FCEV demand -> take the recorded table
+        if name in CLAMP_BOUND_SWEEP:
+            env.set_hy_table(g["hy_table"])
+        else:
+            _close(env.hy_table(), g["hy_table"], "hy_table", rtol=1e-13)
+    env.reset(g["ctor_days"], g["ctor_z"])  # MGR:120, shapes the persistent OU states
+    S0 = cfg.piles[0]
+    i = 0
+    ret = 0.0
+    for ep in range(int(g["episodes"])):
+        if ep in seeds:
+            env.seed_compat(*seeds[ep])
+        obs = env.reset(g["reset_days"][ep], g["reset_z"][ep])
+        _close(obs, g["reset_obs"][ep], ("reset_obs", ep))
+        st = np.concatenate([env.station_scalars(0)[:6], env.station_scalars(1)[:6]])
+        assert np.array_equal(st, g["reset_stations"][ep]), ("reset stations", ep)
+        for t in range(steps):
+            obs, r, d = env.step(g["action"][i], g["exo_z"][i])
+            # integer / index quantities: exact
+            st = np.concatenate([env.station_scalars(0)[:6], env.station_scalars(1)[:6]])
+            assert np.array_equal(st, g["stations"][i]), (name, ep, t, st, g["stations"][i])
+            assert np.array_equal(env.station_slots(0).view(np.uint32), g["slots0"][i].view(np.uint32)), (ep, t)
+            assert np.array_equal(env.station_slots(1).view(np.uint32), g["slots1"][i].view(np.uint32)), (ep, t)
+            assert d == bool(g["done"][i])
+            tel = env.telemetry()
+            assert tel[19] == g["telem"][i][19] and tel[20] == g["telem"][i][20] and tel[21] == g["telem"][i][21]
+            # floats
+            _close(obs, g["obs"][i], (name, "obs", ep, t))
+            _close(r, g["reward"][i], (name, "reward", ep, t))
+            _close(tel[:19], g["telem"][i][:19], (name, "telem", ep, t), rtol=1e-11, atol=1e-9)
+            if ep == 0:
+                ret += r
+            i += 1
+    if name == "env_c1_envtest":
+        # known answer recorded by the survey: return 34.858789741560585, final SOC 0.1525
+        assert abs(ret - 34.858789741560585) < 1e-9
+        assert abs(env.telemetry()[3] - 0.1525) < 1e-12
