@@ -1,0 +1,20 @@
+"""chub -- MI355X-native vectorised charging-hub environment.
+
+Host side of the drop-in for the reference's ``reset()/step()`` path
+(``evcssp_env_cpp.envs.EvcsspManagerEnv_v6``, evcssp_manager.py:19): a thin ctypes + numpy layer over
+``libchub.so`` (HIP kernels for gfx950 behind the C ABI of ``include/chub.h``).  No PyTorch here; the
+multi-GPU launcher (``sharded.py``) borrows torch only for device buffers and the RCCL gather.
+"""
+from ._lib import ChubError, lib_path, load_library  # noqa: F401
+from .vec_env import VecChargingHub, make_config  # noqa: F401
+from .env import Box, EvcsspManagerEnv_v6  # noqa: F401
+
+__all__ = ["VecChargingHub", "EvcsspManagerEnv_v6", "Box", "make_config", "ChubError", "load_library", "lib_path"]
+
+try:  # same gym id as the reference (evcssp_env_cpp/__init__.py:3-8) when gym is importable
+    from gym.envs.registration import register as _register
+
+    _register(id="charging-hub-v6", entry_point="charginghub_env_amd:EvcsspManagerEnv_v6", max_episode_steps=999,
+              reward_threshold=99)
+except Exception:  # gym absent or id already taken
+    pass

@@ -1,0 +1,81 @@
+"""ctypes binding of include/chub.h.  Fails loudly when libchub.so is missing -- there is no fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DATA_DIR = os.path.join(_HERE, "data")
+
+CHUB_FAST, CHUB_SLOW = 0, 1
+RNG_COMPAT, RNG_PHILOX = 0, 1
+T_COUNT = 24
+TELEMETRY_NAMES = ["hy_act", "hy_flow_speed", "all_power_second", "Store_SOC", "capacity", "total_mass_need", "hy_use",
+                   "not_meet", "fc_power", "hy_to_use", "re_used_renew", "re_ev_power_0", "re_ev_power_1",
+                   "re_hydrogen_power", "income", "reward", "re_pv_power", "re_wd_power", "price_next",
+                   "fcev_arrive_number", "fcev_line", "fcev_queue_len", "pv_day", "wd_day"]
+
+
+class ChubError(RuntimeError):
+    pass
+
+
+class ChubConfig(C.Structure):
+    _fields_ = [("station_list", C.c_int32 * 2), ("station_type_list", C.c_int32 * 2),
+                ("constant_charging", C.c_int32), ("reserved0", C.c_int32),
+                ("hydro_prod_rate", C.c_double), ("hydro_store_vlt", C.c_double), ("init_soc", C.c_double),
+                ("fc_max_power", C.c_double), ("fcev_permeate", C.c_double), ("renew_fluctuate", C.c_double),
+                ("price_fluctuate", C.c_double), ("hydro_loss", C.c_double)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libchub.so")
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ChubError("libchub.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "or `make -C charginghub-env_amd/csrc`; there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    P, I, L = C.c_void_p, C.c_int, C.c_int64
+    sig = {
+        "chub_create": (I, [C.POINTER(ChubConfig), C.c_char_p, L, L, I, C.c_uint64, I, C.POINTER(P)]),
+        "chub_destroy": (I, [P]),
+        "chub_obs_dim": (I, [P]), "chub_act_dim": (I, [P]), "chub_num_envs": (L, [P]), "chub_clock": (I, [P]),
+        "chub_reset": (I, [P, P, P, P]),
+        "chub_step": (I, [P, P, P, P, P, P]),
+        "chub_reset_device": (I, [P, P, P, P, P]),
+        "chub_step_device": (I, [P, P, P, P, P, P, P]),
+        "chub_random_actions_device": (I, [P, C.c_uint64, C.c_uint32, P, P]),
+        "chub_sync": (I, [P]),
+        "chub_get_slots": (I, [P, P]), "chub_get_station_scalars": (I, [P, P]), "chub_get_telemetry": (I, [P, P]),
+        "chub_get_obs_f64": (I, [P, P]), "chub_get_reward_f64": (I, [P, P]), "chub_set_telemetry": (I, [P, I]),
+        "chub_set_rng_compat_seeds": (I, [P, P]), "chub_set_rng_compat_state": (I, [P, P]),
+        "chub_get_rng_compat_state": (I, [P, P]), "chub_set_ou_state": (I, [P, P]),
+        "chub_get_hy_table": (I, [P, P]), "chub_set_hy_table": (I, [P, P]),
+        "chub_last_error": (C.c_char_p, []), "chub_device_count": (I, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI drift between chub.h and the library
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTED = ["chub_create", "chub_destroy", "chub_obs_dim", "chub_act_dim", "chub_num_envs", "chub_clock", "chub_reset",
+            "chub_step", "chub_reset_device", "chub_step_device", "chub_random_actions_device", "chub_sync",
+            "chub_get_slots", "chub_get_station_scalars", "chub_get_telemetry", "chub_get_obs_f64",
+            "chub_get_reward_f64", "chub_set_telemetry", "chub_set_rng_compat_seeds", "chub_set_rng_compat_state", "chub_get_rng_compat_state", "chub_set_ou_state",
+            "chub_get_hy_table", "chub_set_hy_table", "chub_last_error", "chub_device_count"]
+
+
+def check(rc):
+    if rc != 0:
+        msg = load_library().chub_last_error()
+        raise ChubError("libchub error %d: %s" % (rc, msg.decode() if msg else "?"))

@@ -1,0 +1,129 @@
+// chub_device.h -- device-side data layout shared by the kernels (chub_kernels.hip) and the host
+// runtime (chub_runtime.hip).  All state lives in HBM as struct-of-arrays:
+//
+//   per-slot arrays   [station k][env][slot]   (station-major, so that a wave covers one contiguous
+//                                               run of one station type: base_k + env*S_k + slot)
+//   per-station arrays [k][env]                (queue length, arrivals and the three power sums)
+//   per-env arrays     [field][env]            (tank, OU states, exogenous values, price)
+//
+// Envs run in lock-step (one shared clock), so the clock, the price-noise phase and the Philox tick
+// are kernel arguments, not state.
+#pragma once
+
+#include <stdint.h>
+
+#include "chub_curves.h"
+
+namespace chub {
+
+constexpr int kQCap = 16;        // FCEV FIFO capacity (the reference list is unbounded, HYD:264-265)
+constexpr int kMaxLine = 10;     // Station::max_line, CHS.hpp:197
+constexpr int kLevels = 1000;    // RandomUtil::uniform_rand has 1000 levels k/999, CHS.hpp:35-44
+constexpr int kBalkTab = 512;
+constexpr int kPolarMaxTrials = 32;
+constexpr int kTelemCount = 24;
+
+// Philox draw sites (counter word 1 = site << 16 | index)
+enum Site : uint32_t {
+    SITE_ARRIVE = 1,  // index = station; word 0 = arrival level, word 1+j = balk level of arrival j
+    SITE_INIT = 2,    // index = station; polar trials for the initial-occupancy normal (reset)
+    SITE_RENEGE = 3,  // index = station; word w = renege level of queued car w
+    SITE_SOC = 5,     // index = hub slot; polar trials for the arrival SoC normal
+    SITE_TGT = 6,     // index = hub slot; word 0 = target-SoC level
+    SITE_LATE = 7,    // index = hub slot; polar trials for the extra-stay normal
+    SITE_HV = 8,      // word 0 = FCEV arrival level
+    SITE_HVSOC = 9,   // index = FCEV arrival number; polar trials
+    SITE_OU = 10,     // index = 0 pv, 1 wd, 2 price; polar trials
+    SITE_DAY = 11     // word 0 -> pv day, word 1 -> wd day (reset)
+};
+
+struct SlotArrays {          // per-slot state, f32 unless noted; index = base_k + env*S_k + slot
+    float *soc;              // current SoC (introspection; rewritten when a car charges / arrives / leaves)
+    float *target;           // target SoC (written at arrival / departure only)
+    float *init_soc;         // arrival SoC (written at arrival / departure only)
+    float *power;            // kW at the car's current point of the curve (Station::situation["power"])
+    float *t_target;         // soc_to_time(target)   -- cached, constant over a stay
+    float *t_soc;            // soc_to_time(soc)      -- cached, what car_step and calculate_needed both need
+    uint8_t *tl;             // bits 0-6: stay_time - already_stay_time (0 = empty), bit 7: charging this step
+    uint8_t *stay;           // stay_time (introspection)
+};
+
+struct StationArrays {       // index = k*N + env
+    uint8_t *line;           // waiting queue length (Station::line)
+    int8_t *flow_in;         // flow_in_number.back()
+    uint8_t *car_number;
+    float *min_p, *chg_p, *max_p;
+};
+
+struct EnvArrays {           // index = env (or field*N + env)
+    double *cap;             // HyStore.capacity, g
+    double *store_soc;       // HyStore.Store_SOC as last computed by sty_step (stale after the fuel cell, HYD:428)
+    double *ou;              // [3][N] OU states pv, wd, price (REN:56-76), never reset
+    double *price_noise;     // self.price_next noise part (MGR:356)
+    double *re_pv, *re_wd;   // exogenous powers produced by the previous make_state (MGR:349-350)
+    double *price_next;      // real_state[1]
+    int16_t *pv_day, *wd_day;
+    uint8_t *q_len;          // FCEV FIFO length
+    uint8_t *hv_line;        // HyFCEVStation.line
+    uint8_t *q_overflow;
+    double *q_time, *q_mass; // [N][kQCap]
+    double *obs64;           // [N][D]  (telemetry only)
+    double *reward64;        // [N]     (telemetry only)
+    double *telem;           // [kTelemCount][N] (telemetry only)
+};
+
+struct CompatRng {           // reference streams, per env
+    uint32_t *g;             // [N][32]: 31-word glibc TYPE_3 ring + front index in word 31
+    uint32_t *minstd;        // [N]
+};
+
+struct Tables {
+    const uint8_t *cnt[2];   // [96][1000] arrivals per station for level k (already scaled + rounded per type)
+    const uint8_t *cnt_hv;   // [96][1000]
+    const uint16_t *thr_renege;  // [kMaxLine]  queued car w stays iff level >= thr
+    const int16_t *thr_balk;     // [kBalkTab]  arrival stays iff level <= thr[line + j]
+    const double *price;     // [96]
+    const double *pvT;       // [96][100]  (transposed: one row per slot of the day)
+    const double *wdT;       // [96][150]
+    const double *hy_table;  // [102]
+};
+
+struct HubParams {
+    int64_t n_envs;
+    int64_t env_id0;
+    int32_t S[2];
+    int32_t type[2];
+    int32_t H[2];            // lanes per (env, station) unit: pow2 >= max(1, S_k), <= 64
+    int64_t base[2];         // slot-array offset of station k
+    int32_t obs_dim, act_dim;
+    int32_t constant_charging;
+    int32_t rng_mode;
+    int32_t telemetry;
+    uint32_t key[2];
+    CurveConsts cc;
+    float transformer_limit[2];
+    // hydrogen system constants (HYD)
+    double v_h_max, cap_mass, init_soc, hydro_loss, fc_max_power;
+    double cells;            // Electrolyser.cell_number
+    double v_M;              // 0.082 * 298
+    double cpr_w12;          // W_1 + W_2 of the compressor, J/mol
+    double renew_fluct1, price_fluct1;  // 1 + fluctuate
+    double price_mean, price_std;
+    float hv_rate;           // f32(f32(0.3) * f32(permeate))
+};
+
+struct StepArgs {
+    int32_t t;               // clock of the slot being simulated (0..95)
+    uint32_t tick;           // Philox tick (increments on every reset and step)
+    int32_t draw_price;      // price_count % 4 == 0 (MGR:354)
+    int32_t station_filter;  // -1 both stations in one launch, else only station k (COMPAT: serial streams)
+    double price_last;       // env_aggregator.price[-1] seen by this step's make_state
+    const float *actions;    // [N][A]
+    const double *exo_z;     // [N][3] or null
+    const int32_t *exo_days; // [N][2] or null (reset)
+    float *obs;              // [N][D]
+    float *reward;           // [N]
+    uint8_t *done;           // [N]
+};
+
+}  // namespace chub

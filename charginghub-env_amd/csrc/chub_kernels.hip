@@ -1,0 +1,811 @@
+// chub_kernels.hip -- the per-step hot path of the charging-hub environment as CDNA4 (gfx950) kernels.
+//
+//   k_slot  lane = charger slot.  One (env, station) "unit" occupies H = pow2 >= S_k consecutive lanes of a
+//           64-wide wavefront (64/H units per wave); stations are processed station-major so a wave runs
+//           one charge-curve family.  Phases (reference order, CHS.hpp:1188-1207 / 1499-1518):
+//           urgency -> feasibility / on-off -> advance charging cars one slot along the curve -> departures
+//           -> arrivals (lookup, renege, balk) -> admission by wave ballot + prefix rank -> new-car draws
+//           -> urgency + the three station power sums (wave butterfly).
+//   k_env   lane = environment.  The scalar tail of step(): electrolyser clamp against the grid limit,
+//           FCEV arrivals + SAE-J2601 fueling + 15-min FIFO, electrolyser / compressor / tank, renewable
+//           netting, fuel cell, incomes and reward, done, exogenous update (PV / wind / price OU) and the
+//           normalised observation.  The J2601 breakpoints are immediates; the FCEV arrival row, the PV and
+//           wind rows of the current slot and the electrolyser action->power table are staged in LDS.
+//
+// No MFMA: there is no dense contraction anywhere in this path; it is HBM-/FP64-VALU-bound.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "chub_device.h"
+
+namespace chub {
+
+// ------------------------------------------------------------------------------------------ Philox
+struct U4 {
+    uint32_t v[4];
+};
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    U4 r;
+    r.v[0] = c0; r.v[1] = c1; r.v[2] = c2; r.v[3] = c3;
+    return r;
+}
+
+__device__ __forceinline__ uint32_t pick(const U4 &b, int i) {
+    uint32_t r = b.v[0];
+    r = (i == 1) ? b.v[1] : r;
+    r = (i == 2) ? b.v[2] : r;
+    r = (i == 3) ? b.v[3] : r;
+    return r;
+}
+
+struct PhiloxCtx {
+    uint32_t k0, k1, tick, gid;
+    __device__ __forceinline__ U4 block(uint32_t site, uint32_t index, uint32_t blk) const {
+        return philox4x32_10(blk, (site << 16) | index, tick, gid, k0, k1);
+    }
+    // standard normal: Marsaglia polar on 53-bit canonicals, trial i = block i, all f64
+    __device__ double normal(uint32_t site, uint32_t index) const {
+        for (uint32_t trial = 0; trial < (uint32_t) kPolarMaxTrials; trial++) {
+            U4 o = block(site, index, trial);
+            double c1 = ((double) (o.v[0] >> 5) * 67108864.0 + (double) (o.v[1] >> 6)) * (1.0 / 9007199254740992.0);
+            double c2 = ((double) (o.v[2] >> 5) * 67108864.0 + (double) (o.v[3] >> 6)) * (1.0 / 9007199254740992.0);
+            double x = 2.0 * c1 - 1.0, y = 2.0 * c2 - 1.0;
+            double r2 = x * x + y * y;
+            if (r2 > 1.0 || r2 == 0.0) continue;
+            double mult = __dsqrt_rn(-2.0 * log(r2) / r2);
+            return y * mult;
+        }
+        return 0.0;
+    }
+};
+
+// ------------------------------------------------------------- reference streams (COMPAT), one lane
+struct CompatStream {
+    uint32_t *g;  // 32 words: ring[31] + front index
+    uint32_t gf, gr, x;
+    __device__ void load(const CompatRng &cr, int64_t env) {
+        g = cr.g + env * 32;
+        gf = g[31];
+        gr = (gf + 28u) % 31u;
+        x = cr.minstd[env];
+    }
+    __device__ void store(const CompatRng &cr, int64_t env) {
+        g[31] = gf;
+        cr.minstd[env] = x;
+    }
+    // glibc random_r TYPE_3: *f += *r; result = *f >> 1  (rand(), CHS.hpp:41)
+    __device__ uint32_t rand31() {
+        uint32_t v = g[gf] + g[gr];
+        g[gf] = v;
+        gf = (gf + 1u == 31u) ? 0u : gf + 1u;
+        gr = (gr + 1u == 31u) ? 0u : gr + 1u;
+        return v >> 1;
+    }
+    __device__ int level() { return (int) (rand31() % 1000u); }
+    // std::minstd_rand0 (CHS.hpp:25)
+    __device__ uint32_t minstd() {
+        x = (uint32_t) (((uint64_t) x * 16807ull) % 2147483647ull);
+        return x;
+    }
+    // libstdc++ generate_canonical<double,53>: two draws
+    __device__ double canon_d() {
+        const double R = 2147483646.0;
+        double sum = (double) (minstd() - 1u);
+        sum += (double) (minstd() - 1u) * R;
+        double ret = sum / (R * R);
+        if (ret >= 1.0) ret = 0.99999999999999988898;
+        return ret;
+    }
+    // generate_canonical<float,24>: one draw
+    __device__ float canon_f() {
+        float ret = __fdiv_rn((float) (minstd() - 1u), 2147483648.0f);
+        if (ret >= 1.0f) ret = 0.99999994f;
+        return ret;
+    }
+    // std::normal_distribution<double>, fresh per call: polar, y*mult (CHS.hpp:805)
+    __device__ double normal_d(double mean, double sd) {
+        double x_, y_, r2;
+        do {
+            x_ = 2.0 * canon_d() - 1.0;
+            y_ = 2.0 * canon_d() - 1.0;
+            r2 = x_ * x_ + y_ * y_;
+        } while (r2 > 1.0 || r2 == 0.0);
+        double mult = __dsqrt_rn(-2.0 * log(r2) / r2);
+        return (y_ * mult) * sd + mean;
+    }
+    // std::normal_distribution<float> (CHS.hpp:819,833).  logf is evaluated as the f32 rounding of the f64 log.
+    __device__ float normal_f(float mean, float sd) {
+        float x_, y_, r2;
+        do {
+            x_ = __fsub_rn(__fmul_rn(2.0f, canon_f()), 1.0f);
+            y_ = __fsub_rn(__fmul_rn(2.0f, canon_f()), 1.0f);
+            r2 = __fadd_rn(__fmul_rn(x_, x_), __fmul_rn(y_, y_));
+        } while (r2 > 1.0f || r2 == 0.0f);
+        float lg = (float) log((double) r2);
+        float mult = __fsqrt_rn(__fdiv_rn(__fmul_rn(-2.0f, lg), r2));
+        return __fadd_rn(__fmul_rn(__fmul_rn(y_, mult), sd), mean);
+    }
+};
+
+// ------------------------------------------------------------------------------- small arithmetic
+// RandomUtil::uniform_rand(a, b) at level k (CHS.hpp:35-44): two f32 roundings after the division
+__device__ __forceinline__ float uniform_level(int k, float a, float b) {
+    float tr = __fdiv_rn((float) k, 999.0f);
+    return __fadd_rn(__fmul_rn(tr, __fsub_rn(b, a)), a);
+}
+
+// calculate_needed (CHS.hpp:879-898 / 1044-1063) from the cached curve times
+__device__ __forceinline__ float emergency_of(float t_target, float t_soc, int tl) {
+    float need = __fsub_rn(t_target, t_soc);
+    if (need > 0.0f) {
+        if ((float) tl <= ceilf(need)) return 10.0f;
+        float q = __fdiv_rn(need, (float) tl);
+        return (float) ((double) q * (double) q);
+    }
+    return 0.0f;
+}
+
+__device__ __forceinline__ float arrive_soc_from(double normal73) {  // mk_soc, CHS.hpp:804-814
+    float d = (float) normal73;
+    if ((double) d < 1.0) d = 1.0f;
+    else if ((double) d > 10.0) d = 10.0f;
+    return (float) (75.0 - 5.0 * (double) d);
+}
+
+constexpr int MODE_COMPAT = 0, MODE_PHILOX = 1;
+
+// ---------------------------------------------------------------------------------------- k_slot
+template <int TYPE, bool RESET, int MODE>
+__device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
+                          const CompatRng &cr, const Tables &tb, const int k, const int64_t block_local,
+                          float *lds_soc, uint16_t *lds_lev, uint8_t *lds_late) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H = hp.H[k], S = hp.S[k];
+    const int upw = 64 / H;
+    const int uiw = lane / H;
+    const int slot = lane & (H - 1);
+    const int64_t N = hp.n_envs;
+    const int64_t env = block_local * (int64_t) (4 * upw) + wave * upw + uiw;
+    const bool unit_ok = env < N;
+    const bool valid = unit_ok && slot < S;
+    const uint64_t unit_mask = (H == 64) ? ~0ull : (((1ull << H) - 1ull) << (uiw * H));
+    const int64_t idx = hp.base[k] + env * S + slot;
+    const int64_t sidx = (int64_t) k * N + env;
+    const int hub_slot = (k ? hp.S[0] : 0) + slot;
+    const bool cp = hp.constant_charging != 0;
+    const CurveConsts cc = hp.cc;
+
+    float power = 0.0f, t_target = 0.0f, t_soc = 0.0f, soc_new = 0.0f;
+    int tl = 0;
+    bool car = false, charge = false, soc_dirty = false, leave = false;
+
+    if (!RESET && valid) {
+        power = sl.power[idx];
+        t_target = sl.t_target[idx];
+        t_soc = sl.t_soc[idx];
+        tl = sl.tl[idx] & 127;
+        car = tl > 0;
+        // action_to_real (MGR:384-393): (a+1)/2 >= 0.5 on the f32 array
+        const float a = sa.actions[env * hp.act_dim + hub_slot];
+        const bool act_on = __fdiv_rn(__fadd_rn(a, 1.0f), 2.0f) >= 0.5f;
+        // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373)
+        const float em = car ? emergency_of(t_target, t_soc, tl) : 0.0f;
+        const bool on = car && (act_on || (double) em >= 1.01);
+        if (on) {  // car_step (CHS.hpp:900-905 / 1065-1070)
+            const float tt = __fadd_rn(t_soc, 1.0f);
+            soc_new = time_to_soc<TYPE>(tt, cp, cc);
+            power = time_to_power<TYPE>(tt, cp);
+            t_soc = soc_to_time<TYPE>(soc_new, cp);
+            soc_dirty = true;
+        }
+        if (car) {  // remove_car (CHS.hpp:912-923 / 1077-1088)
+            tl -= 1;
+            if (tl <= 0) {
+                car = false;
+                leave = true;
+                tl = 0;
+                power = 0.0f;
+                t_target = 0.0f;
+                t_soc = 0.0f;
+            }
+        }
+        charge = on && car;
+    }
+
+    // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): arrivals, renege, balk, admission
+    const bool empty = valid && !car;
+    const uint64_t be = __ballot(empty) & unit_mask;
+    const int empties = __popcll(be);
+    const int rank = __popcll(be & ((1ull << lane) - 1ull));
+    int line = (!RESET && unit_ok) ? (int) st.line[sidx] : 0;
+    int flow = 0, assign = 0;
+    const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
+
+    float adm_soc = 0.0f;
+    int adm_lev = 0, adm_late = 0;
+
+    if (MODE == MODE_PHILOX) {
+        PhiloxCtx px{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env)};
+        if (unit_ok) {
+            U4 w0 = px.block(SITE_ARRIVE, (uint32_t) k, 0);
+            int n_in;
+            if (RESET) {  // init_station_car_number(mu, 3), CHS.hpp:832-842
+                const float cn = (float) (px.normal(SITE_INIT, (uint32_t) k) * 1.0 + (double) mu);
+                int temp = (int) roundf(cn);
+                temp = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
+                n_in = temp;
+            } else {
+                n_in = (int) tb.cnt[k][sa.t * kLevels + (int) (w0.v[0] % 1000u)];
+            }
+            if (line > 0) {  // queued car w stays iff u > 0.1*logf(w+1)
+                int tline = 0;
+                U4 b = w0;
+                for (int w = 0; w < line; w++) {
+                    if ((w & 3) == 0) b = px.block(SITE_RENEGE, (uint32_t) k, (uint32_t) (w >> 2));
+                    tline += ((int) (pick(b, w & 3) % 1000u) >= (int) tb.thr_renege[w]) ? 1 : 0;
+                }
+                line = tline;
+            }
+            int true_in = 0;
+            {
+                U4 b = w0;
+                for (int j = 0; j < n_in; j++) {  // arrival j stays iff u <= expf(-0.01*(line+j)) and j <= S
+                    const int wi = 1 + j;
+                    if ((wi & 3) == 0) b = px.block(SITE_ARRIVE, (uint32_t) k, (uint32_t) (wi >> 2));
+                    const int m = line + j;
+                    const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
+                    true_in += ((int) (pick(b, wi & 3) % 1000u) <= thr && j <= S) ? 1 : 0;
+                }
+            }
+            flow = (TYPE == 0) ? n_in : true_in;  // fast records the raw count (CHS.hpp:1617), slow the thinned one (1306)
+            assign = (line + flow) < empties ? (line + flow) : empties;  // assign_car, CHS.hpp:417-430
+            line = line + flow - assign;
+            line = line < kMaxLine ? line : kMaxLine;
+        }
+        if (empty && rank < assign) {  // add_car draws, CHS.hpp:864-869 / 1029-1034
+            adm_soc = arrive_soc_from(px.normal(SITE_SOC, (uint32_t) hub_slot) * 3.0 + 7.0);
+            adm_lev = (int) (px.block(SITE_TGT, (uint32_t) hub_slot, 0).v[0] % 1000u);
+            const float cn = (float) (px.normal(SITE_LATE, (uint32_t) hub_slot) * 2.0 + 2.0);
+            adm_late = (int) roundf(cn);
+            adm_late = adm_late < 0 ? 0 : adm_late;
+        }
+    } else {
+        // COMPAT: the unit's first lane walks the two reference streams in the reference's order and
+        // parks the per-admission variates in LDS, indexed by admission rank.
+        const int lbase = wave * 64 + uiw * H;
+        int2 fa = make_int2(0, 0);
+        int new_line = line;
+        if (unit_ok && slot == 0) {
+            CompatStream rs;
+            rs.load(cr, env);
+            int n_in;
+            if (RESET) {
+                const float cn = rs.normal_f((float) mu, 1.0f);
+                int temp = (int) roundf(cn);
+                temp = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
+                n_in = temp;
+            } else {
+                n_in = (int) tb.cnt[k][sa.t * kLevels + rs.level()];
+            }
+            int tline = 0;
+            for (int w = 0; w < line; w++) tline += (rs.level() >= (int) tb.thr_renege[w]) ? 1 : 0;
+            new_line = tline;
+            int true_in = 0;
+            for (int j = 0; j < n_in; j++) {
+                const int m = new_line + j;
+                const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
+                true_in += (rs.level() <= thr && j <= S) ? 1 : 0;
+            }
+            const int fl = (TYPE == 0) ? n_in : true_in;
+            int as = (new_line + fl) < empties ? (new_line + fl) : empties;
+            new_line = new_line + fl - as;
+            new_line = new_line < kMaxLine ? new_line : kMaxLine;
+            for (int r = 0; r < as; r++) {  // ascending slot order == ascending rank
+                lds_soc[lbase + r] = arrive_soc_from(rs.normal_d(7.0, 3.0));
+                lds_lev[lbase + r] = (uint16_t) rs.level();
+                int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
+                lds_late[lbase + r] = (uint8_t) (late < 0 ? 0 : (late > 255 ? 255 : late));
+            }
+            rs.store(cr, env);
+            fa = make_int2(fl, as);
+        }
+        const int leader = uiw * H;
+        flow = __shfl(fa.x, leader);
+        assign = __shfl(fa.y, leader);
+        line = __shfl(new_line, leader);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (empty && rank < assign) {
+            adm_soc = lds_soc[lbase + rank];
+            adm_lev = (int) lds_lev[lbase + rank];
+            adm_late = (int) lds_late[lbase + rank];
+        }
+    }
+
+    const bool adm = empty && rank < assign;
+    float target = 0.0f;
+    int stay = 0;
+    if (adm) {  // add_car, CHS.hpp:864-877 / 1029-1042
+        target = uniform_level(adm_lev, 80.0f, 100.0f);
+        t_target = soc_to_time<TYPE>(target, cp);
+        t_soc = soc_to_time<TYPE>(adm_soc, cp);
+        const float need = __fsub_rn(t_target, t_soc);
+        stay = (int) ceilf(need) + adm_late;
+        stay = stay > 127 ? 127 : stay;
+        tl = stay;
+        power = time_to_power<TYPE>(t_soc, cp);
+        car = tl > 0;
+    }
+
+    // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572)
+    const float em2 = car ? emergency_of(t_target, t_soc, tl) : 0.0f;
+    float r_min, r_max, r_chg;
+    if (MODE == MODE_COMPAT) {
+        // the reference adds slot powers sequentially in f32 (CHS.hpp:1244-1255): same order, same roundings
+        const float v_min = (car && em2 > 8.0f) ? power : 0.0f, v_max = car ? power : 0.0f, v_chg = charge ? power : 0.0f;
+        const int ubase = uiw * H;
+        r_min = r_max = r_chg = 0.0f;
+        for (int i = 0; i < S; i++) {
+            r_max = __fadd_rn(r_max, __shfl(v_max, ubase + i));
+            r_min = __fadd_rn(r_min, __shfl(v_min, ubase + i));
+            r_chg = __fadd_rn(r_chg, __shfl(v_chg, ubase + i));
+        }
+    } else {
+        // production: f64 butterfly == the exact sum, rounded once to f32
+        double s_min = (car && em2 > 8.0f) ? (double) power : 0.0;
+        double s_max = car ? (double) power : 0.0;
+        double s_chg = charge ? (double) power : 0.0;
+        for (int off = H >> 1; off > 0; off >>= 1) {
+            s_min += __shfl_xor(s_min, off);
+            s_max += __shfl_xor(s_max, off);
+            s_chg += __shfl_xor(s_chg, off);
+        }
+        r_min = (float) s_min;
+        r_max = (float) s_max;
+        r_chg = (float) s_chg;
+    }
+    const int cars = __popcll(__ballot(car) & unit_mask);
+
+    if (valid) {
+        sl.power[idx] = power;
+        sl.t_soc[idx] = t_soc;
+        sl.tl[idx] = (uint8_t) (tl | (charge ? 128 : 0));
+        if (adm || leave || RESET) {
+            sl.t_target[idx] = t_target;
+            sl.target[idx] = adm ? target : 0.0f;
+            sl.init_soc[idx] = adm ? adm_soc : 0.0f;
+            sl.stay[idx] = (uint8_t) (adm ? stay : 0);
+            sl.soc[idx] = adm ? adm_soc : 0.0f;
+        } else if (soc_dirty) {
+            sl.soc[idx] = soc_new;
+        }
+    }
+    if (unit_ok && slot == 0) {
+        st.line[sidx] = (uint8_t) line;
+        st.flow_in[sidx] = (int8_t) flow;
+        st.car_number[sidx] = (uint8_t) cars;
+        st.min_p[sidx] = r_min;
+        st.chg_p[sidx] = r_chg;
+        st.max_p[sidx] = r_max;
+    }
+}
+
+template <bool RESET, int MODE>
+__global__ __launch_bounds__(256) void k_slot(HubParams hp, StepArgs sa, SlotArrays sl, StationArrays st, CompatRng cr,
+                                              Tables tb, int64_t nb0) {
+    __shared__ float lds_soc[MODE == MODE_COMPAT ? 256 : 1];
+    __shared__ uint16_t lds_lev[MODE == MODE_COMPAT ? 256 : 1];
+    __shared__ uint8_t lds_late[MODE == MODE_COMPAT ? 256 : 1];
+    int k;
+    int64_t bl;
+    if (sa.station_filter >= 0) {
+        k = sa.station_filter;
+        bl = blockIdx.x;
+    } else {
+        k = ((int64_t) blockIdx.x >= nb0) ? 1 : 0;
+        bl = k ? (int64_t) blockIdx.x - nb0 : (int64_t) blockIdx.x;
+    }
+    if (hp.type[k] == 0) slot_body<0, RESET, MODE>(hp, sa, sl, st, cr, tb, k, bl, lds_soc, lds_lev, lds_late);
+    else slot_body<1, RESET, MODE>(hp, sa, sl, st, cr, tb, k, bl, lds_soc, lds_lev, lds_late);
+}
+
+// ----------------------------------------------------------------------------------------- k_env
+// SAE J2601 target pressure (HYD:338-388 on the table HYD:232-233)
+__device__ __forceinline__ double j2601_target(double p) {
+    const double X[10] = {0.50, 5.00, 10.0, 15.0, 20.0, 30.0, 40.0, 50.0, 60.0, 70.0};
+    const double Y[10] = {87.4, 81.0, 86.8, 86.1, 85.4, 83.8, 82.2, 80.4, 78.5, 76.1};
+    if (p < X[1]) return Y[0];
+    double r = p;
+    bool hit = false;
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        const bool in = (a < 7) ? (X[1 + a] <= p && p < X[2 + a]) : (X[1 + a] <= p && p <= X[2 + a]);
+        if (in && !hit) {
+            r = (Y[2 + a] - Y[1 + a]) / (X[2 + a] - X[1 + a]) * (p - X[1 + a]) + Y[1 + a];
+            hit = true;
+        }
+    }
+    return r;
+}
+__device__ __forceinline__ double pressure_to_mass(double p) { return (6.3 * 1000) * (p / 70); }  // HYD:390-391
+// HYD:308-321
+__device__ __forceinline__ void j2601_time_mass(double p0, double &time_need, double &mass_need) {
+    const double target = j2601_target(p0);
+    if (p0 < 5) time_need = (69 - p0) / 18.5 + (87.4 - 69) / 7.2;
+    else time_need = (target - p0) / ((5 <= p0 && p0 < 70) ? 18.5 : 0.0);
+    mass_need = pressure_to_mass(target) - pressure_to_mass(p0);
+}
+
+__device__ __forceinline__ double ou_sample(double &state, double theta, double sigma, double z) {  // REN:71-76
+    const double dx = theta * (0.0 - state) + sigma * z;
+    state += dx;
+    return state;
+}
+
+template <bool RESET, int MODE>
+__global__ __launch_bounds__(256) void k_env(HubParams hp, StepArgs sa, StationArrays st, EnvArrays ev, CompatRng cr,
+                                             Tables tb) {
+    __shared__ double s_pv[100], s_wd[150], s_hy[102];
+    __shared__ uint8_t s_hv[kLevels];
+    const int t_next = RESET ? 0 : (sa.t + 1) % 96;
+    for (int i = threadIdx.x; i < 100; i += blockDim.x) s_pv[i] = tb.pvT[t_next * 100 + i];
+    for (int i = threadIdx.x; i < 150; i += blockDim.x) s_wd[i] = tb.wdT[t_next * 150 + i];
+    for (int i = threadIdx.x; i < 102; i += blockDim.x) s_hy[i] = tb.hy_table[i];
+    if (!RESET)
+        for (int i = threadIdx.x; i < kLevels; i += blockDim.x) s_hv[i] = tb.cnt_hv[sa.t * kLevels + i];
+    __syncthreads();
+
+    const int64_t N = hp.n_envs;
+    const int64_t env = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    PhiloxCtx px{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env)};
+    CompatStream rs;
+    if (MODE == MODE_COMPAT && !RESET) rs.load(cr, env);
+
+    const double cap_mass = hp.cap_mass;
+    double cap = ev.cap[env];
+    double store_soc = ev.store_soc[env];
+    double reward = 0.0;
+    double tel[kTelemCount];
+    if (hp.telemetry)
+        for (int i = 0; i < kTelemCount; i++) tel[i] = 0.0;
+
+    if (RESET) {
+        // renew_reset (REN:51-53) + hy_reset (HYD:197-208)
+        int pv_day, wd_day;
+        if (MODE == MODE_COMPAT) {
+            pv_day = sa.exo_days[env * 2 + 0];
+            wd_day = sa.exo_days[env * 2 + 1];
+        } else {
+            U4 o = px.block(SITE_DAY, 0, 0);
+            pv_day = (int) (o.v[0] % 100u);
+            wd_day = (int) (o.v[1] % 150u);
+        }
+        ev.pv_day[env] = (int16_t) pv_day;
+        ev.wd_day[env] = (int16_t) wd_day;
+        ev.q_len[env] = 0;
+        ev.hv_line[env] = 0;
+        cap = hp.init_soc * cap_mass;
+        store_soc = hp.init_soc;
+    } else {
+        const int S = hp.S[0] + hp.S[1];
+        const float *act = sa.actions + env * hp.act_dim;
+        const double a_el = ((double) act[S] + 1) / 2;      // action_real[-1] <- action[-2]  (MGR:400-403)
+        const double a_fc = ((double) act[S + 1] + 1) / 2;  // action_real[-2] <- action[-1]  (MGR:395-398)
+        const double P0 = (double) st.chg_p[env], P1 = (double) st.chg_p[N + env];
+        const double F0 = (double) st.flow_in[env], F1 = (double) st.flow_in[N + env];
+        double re_new_power = ev.re_wd[env] + ev.re_pv[env];  // MGR:143
+        const double charging_power = 0.0 + P0 + P1;          // MGR:157
+        // ---- electrolyser request clamp against the grid limit (MGR:160-180)
+        double hy_power_limit = 2000 + re_new_power - charging_power;
+        hy_power_limit = hy_power_limit > 0 ? hy_power_limit : 0.0;
+        double act_el = a_el;
+        int req = (int) ceil(a_el * 100);
+        req = req < 0 ? 0 : (req > 101 ? 101 : req);  // actions outside [-1,1] would index out of the table
+        if (s_hy[req] > hy_power_limit) {
+            int ind = 0;
+            while (ind < 102 && !(s_hy[ind] >= hy_power_limit)) ind++;
+            // hy_power_speed_list_input[ind - 1]; python index -1 wraps to the last entry (1.0)
+            act_el = (ind >= 102 || ind == 0) ? 0.01 * 100 : 0.01 * (ind - 1);
+        }
+        // ---- hvs_step (HYD:253-285): FCEV arrivals -> J2601 -> 15-minute FIFO
+        int q_len = ev.q_len[env];
+        int hv_line = ev.hv_line[env];
+        double *qt = ev.q_time + env * kQCap, *qm = ev.q_mass + env * kQCap;
+        int lev;
+        if (MODE == MODE_COMPAT) lev = rs.level();
+        else lev = (int) (px.block(SITE_HV, 0, 0).v[0] % 1000u);
+        const int arrive = (int) s_hv[lev];
+        double total_time = 0.0, total_mass = 0.0;
+        for (int i = 0; i < q_len; i++) {
+            total_time += qt[i];
+            total_mass += qm[i];
+        }
+        for (int j = 0; j < arrive; j++) {
+            float socf;
+            if (MODE == MODE_COMPAT) socf = arrive_soc_from(rs.normal_d(7.0, 3.0));
+            else socf = arrive_soc_from(px.normal(SITE_HVSOC, (uint32_t) j) * 3.0 + 7.0);
+            double soc = (double) socf;
+            if (soc < 0.5) soc = 0.5;
+            const double p0 = (soc * 0.01) * 70;
+            double tn, mn;
+            j2601_time_mass(p0, tn, mn);
+            if (q_len < kQCap) {
+                qt[q_len] = tn;
+                qm[q_len] = mn;
+                q_len++;
+                total_time += tn;
+                total_mass += mn;
+            } else {
+                ev.q_overflow[env] = 1;
+            }
+        }
+        int hv_num = 0;
+        if (total_time > 15.0) {
+            for (int i = 1; i <= arrive - 1; i++) {
+                int keep = q_len - i;
+                keep = keep < 0 ? 0 : keep;
+                double part = 0.0;
+                for (int j = 0; j < keep; j++) part += qt[j];
+                if (part <= 15.0) {
+                    hv_line = i;
+                    hv_num = keep;
+                    break;
+                }
+            }
+            for (int j = hv_num; j < q_len; j++) {
+                qt[j - hv_num] = qt[j];
+                qm[j - hv_num] = qm[j];
+            }
+            q_len -= hv_num;
+        } else {
+            hv_line = 0;
+            hv_num = q_len;
+            q_len = 0;
+        }
+        const double total_mass_need = total_mass;
+        ev.q_len[env] = (uint8_t) q_len;
+        ev.hv_line[env] = (uint8_t) hv_line;
+        // ---- hy_step (HYD:160-195): production clamp, electrolyser + compressor power, tank
+        double must_charge = cap_mass * 0.1 - cap;
+        must_charge = must_charge > 0 ? must_charge : 0.0;
+        double upper_charge = cap_mass - cap;
+        upper_charge = upper_charge > 0 ? upper_charge : 0.0;
+        double charge_temp = act_el * hp.v_h_max * (15 * 60);
+        charge_temp = charge_temp < upper_charge ? charge_temp : upper_charge;
+        charge_temp = charge_temp > must_charge ? charge_temp : must_charge;
+        double flow = charge_temp / (15 * 60);
+        flow = flow < hp.v_h_max ? flow : hp.v_h_max;
+        double ele_power = 0.0;
+        if (hp.cells != 0.0) {  // Electrolyser.get_power, HYD:38-48
+            const double v_H_mass = flow / hp.cells;
+            const double v_H_mol = v_H_mass / 2.02;
+            const double v_H_L = v_H_mol * hp.v_M;
+            const double v_H = v_H_L * 1000 * 60;
+            const double temp = v_H * 2 * 96487 / (hp.v_M * 1000 * 60);
+            double power = temp * temp * 0.326 + temp * 1.476;
+            ele_power = hp.cells * power / 1000;
+        }
+        const double cpr_power = ((flow / 2.02) * hp.cpr_w12 / 0.8) / 1000;  // Compressor.generate_W, HYD:74-82
+        // sty_step (HYD:104-126)
+        cap += flow * 15 * 60;
+        double lower_change = cap - 0.1 * cap_mass;
+        lower_change = lower_change > 0 ? lower_change : 0.0;
+        const double hy_use = total_mass_need < lower_change ? total_mass_need : lower_change;
+        const double not_meet = total_mass_need - hy_use;
+        cap -= hy_use;
+        cap -= cap * hp.hydro_loss;
+        store_soc = cap / cap_mass;
+        const double all_power_second = ele_power + cpr_power;
+        const bool gen_hy = flow > 0.5;  // MGR:161,173-179
+        // ---- renewable netting (MGR:183-213)
+        double hydrogen_power = all_power_second;
+        double ev_power_sum = charging_power;
+        double e0 = P0, e1 = P1;
+        if (0.0 + P0 + P1 > 0) {
+            const double fc_rate = charging_power / (0.0 + P0 + P1);
+            e0 = fc_rate * P0;
+            e1 = fc_rate * P1;
+        }
+        double used_renew = 0.0;
+        if (re_new_power >= hydrogen_power) {
+            re_new_power -= hydrogen_power;
+            used_renew += hydrogen_power;
+            hydrogen_power = 0.0;
+            const double tmp = ev_power_sum;
+            ev_power_sum = ev_power_sum - re_new_power;
+            ev_power_sum = ev_power_sum > 0 ? ev_power_sum : 0.0;
+            used_renew += tmp - ev_power_sum;
+            const double sl_ = 0.0 + e0 + e1;
+            if (sl_ > 0) {
+                const double rate = ev_power_sum / sl_;
+                e0 = rate * e0;
+                e1 = rate * e1;
+            }
+        } else {
+            hydrogen_power -= re_new_power;
+            used_renew = re_new_power;
+        }
+        const double re_ev0 = e0, re_ev1 = e1;
+        // ---- fuel cell (MGR:215-227, HFC.use_cell HYD:409-430)
+        double fc_power = gen_hy ? 0.0 : hp.fc_max_power * a_fc;
+        if (fc_power > hp.fc_max_power) fc_power = hp.fc_max_power;
+        else if (fc_power < 0) fc_power = 0.0;
+        else if (fc_power > ev_power_sum) fc_power = ev_power_sum;
+        double hy_to_use = fc_power * 1500 / 119.6;
+        hy_to_use = cap < hy_to_use ? cap : hy_to_use;
+        fc_power = fc_power > 0 ? fc_power : 0.0;  // HYD:426 (not H2-limited)
+        cap -= hy_to_use;                          // Store_SOC is not refreshed (HYD:428)
+        ev_power_sum -= fc_power;
+        {
+            const double sl_ = 0.0 + e0 + e1;
+            if (sl_ > 0) {
+                const double rate_ = ev_power_sum / sl_;
+                e0 = rate_ * e0;
+                e1 = rate_ * e1;
+            }
+        }
+        const double hy_loss = -6 / 1000.0 * hy_to_use;
+        // ---- incomes and reward (MGR:233-269)
+        const double real_price_dollar = ev.price_next[env] / 4;
+        const double income_evs_fast = 0.42 / 4 * P0 - real_price_dollar * e0;
+        const double income_evs_slow = 0.21 / 4 * P1 - real_price_dollar * e1;
+        const double income_evs = income_evs_fast + income_evs_slow;
+        const double income_evs_serve = 0.8 * (0.0 + F0 + F1);
+        const double income_hys = 6 / 1000.0 * hy_use;
+        const double not_meet_loss = -10 / 1000.0 * not_meet;
+        const double hy_cost = -real_price_dollar * hydrogen_power;
+        reward = (income_hys + income_evs + income_evs_serve + hy_cost + 1 * hy_loss + not_meet_loss) / 50;
+        if (hp.telemetry) {
+            tel[0] = act_el; tel[1] = flow; tel[2] = all_power_second; tel[3] = store_soc; tel[4] = cap;
+            tel[5] = total_mass_need; tel[6] = hy_use; tel[7] = not_meet; tel[8] = fc_power; tel[9] = hy_to_use;
+            tel[10] = used_renew; tel[11] = re_ev0; tel[12] = re_ev1; tel[13] = hydrogen_power;
+            tel[14] = income_hys + income_evs + income_evs_serve + hy_cost; tel[15] = reward;
+            tel[19] = (double) arrive; tel[20] = (double) hv_line; tel[21] = (double) q_len;
+        }
+    }
+
+    // ---- make_state (MGR:344-373): exogenous update for the NEXT slot, then the observation
+    const int pv_day = ev.pv_day[env], wd_day = ev.wd_day[env];
+    double ou_pv = ev.ou[env], ou_wd = ev.ou[N + env], ou_price = ev.ou[2 * N + env];
+    double temp = s_pv[pv_day];
+    if (temp > 0 && (pv_day % 2) == 0) {  // REN:38-43
+        const double z = (MODE == MODE_COMPAT) ? sa.exo_z[env * 3 + 0] : px.normal(SITE_OU, 0);
+        temp += ou_sample(ou_pv, .01, 1., z) * hp.renew_fluct1;
+    }
+    const double re_pv = (temp > 0 ? temp : 0.0) * 5;
+    temp = s_wd[wd_day];
+    {  // REN:45-49
+        const double z = (MODE == MODE_COMPAT) ? sa.exo_z[env * 3 + 1] : px.normal(SITE_OU, 1);
+        temp += ou_sample(ou_wd, .01, 1.5, z) * hp.renew_fluct1;
+    }
+    const double re_wd = (temp > 0 ? temp : 0.0) * 1;
+    double price_next;
+    if (sa.draw_price) {  // MGR:354-357
+        const double z = (MODE == MODE_COMPAT) ? sa.exo_z[env * 3 + 2] : px.normal(SITE_OU, 2);
+        price_next = ou_sample(ou_price, .1, 0.005, z) * hp.price_fluct1;
+        ev.price_noise[env] = price_next;
+        price_next += sa.price_last;
+    } else {
+        price_next = sa.price_last + ev.price_noise[env];
+    }
+    ev.ou[env] = ou_pv;
+    ev.ou[N + env] = ou_wd;
+    ev.ou[2 * N + env] = ou_price;
+    ev.re_pv[env] = re_pv;
+    ev.re_wd[env] = re_wd;
+    ev.price_next[env] = price_next;
+    ev.cap[env] = cap;
+    ev.store_soc[env] = store_soc;
+    if (MODE == MODE_COMPAT && !RESET) rs.store(cr, env);
+
+    // state_norm (MGR:318-342)
+    double o[16];
+    int n = 0;
+    const double kk = 2 * 3.14159265358979323846 / 96;
+    o[n++] = sin(kk * (double) t_next);
+    o[n++] = (price_next - hp.price_mean) / hp.price_std;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (hp.S[k] > 0) {
+            const int64_t si = (int64_t) k * N + env;
+            const double half_range = (double) hp.transformer_limit[k] / 2;
+            o[n++] = ((double) st.min_p[si] - half_range) / half_range;
+            o[n++] = ((double) st.chg_p[si] - half_range) / half_range;
+            o[n++] = ((double) st.max_p[si] - half_range) / half_range;
+            o[n++] = (double) st.line[si] / 5;
+        }
+    }
+    o[n++] = store_soc;
+    o[n++] = re_pv / (42 * 5);
+    o[n++] = re_wd / (92 * 1);
+    float *obs = sa.obs + env * hp.obs_dim;
+    for (int i = 0; i < n; i++) obs[i] = (float) o[i];
+    if (!RESET) {
+        sa.reward[env] = (float) reward;
+        sa.done[env] = (uint8_t) ((sa.t + 1) >= 96 ? 1 : 0);
+    }
+    if (hp.telemetry) {
+        for (int i = 0; i < n; i++) ev.obs64[env * hp.obs_dim + i] = o[i];
+        ev.reward64[env] = reward;
+        tel[3] = store_soc; tel[16] = re_pv; tel[17] = re_wd; tel[18] = price_next;
+        tel[22] = (double) pv_day; tel[23] = (double) wd_day;
+        if (RESET) tel[4] = cap;
+        for (int i = 0; i < kTelemCount; i++) ev.telem[(int64_t) i * N + env] = tel[i];
+    }
+}
+
+// -------------------------------------------------------------------- random policy (bench / tests)
+__global__ void k_random_actions(int64_t n_envs, int64_t env_id0, int act_dim, uint32_t k0, uint32_t k1, uint32_t batch,
+                                 float *actions) {
+    const int64_t total = n_envs * (int64_t) ((act_dim + 3) / 4);
+    const int per = (act_dim + 3) / 4;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t env = i / per;
+        const int j4 = (int) (i % per);
+        U4 o = philox4x32_10((uint32_t) j4, 0u, batch, (uint32_t) (env_id0 + env), k0, k1);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int j = j4 * 4 + c;
+            if (j < act_dim) actions[env * act_dim + j] = (float) (o.v[c] >> 8) * (2.0f / 16777216.0f) - 1.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------- launchers
+static inline int64_t blocks_for(int64_t n_envs, int H) { return (n_envs + (4 * (64 / H)) - 1) / (4 * (64 / H)); }
+
+void launch_slot(bool reset, const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
+                 const CompatRng &cr, const Tables &tb, hipStream_t stream) {
+    const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0]), nb1 = blocks_for(hp.n_envs, hp.H[1]);
+    if (hp.rng_mode == MODE_PHILOX) {
+        const int64_t nb = nb0 + nb1;
+        if (reset) hipLaunchKernelGGL((k_slot<true, MODE_PHILOX>), dim3((unsigned) nb), dim3(256), 0, stream, hp, sa, sl, st, cr, tb, nb0);
+        else hipLaunchKernelGGL((k_slot<false, MODE_PHILOX>), dim3((unsigned) nb), dim3(256), 0, stream, hp, sa, sl, st, cr, tb, nb0);
+    } else {
+        for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
+            StepArgs s2 = sa;
+            s2.station_filter = k;
+            const int64_t nb = k ? nb1 : nb0;
+            if (reset) hipLaunchKernelGGL((k_slot<true, MODE_COMPAT>), dim3((unsigned) nb), dim3(256), 0, stream, hp, s2, sl, st, cr, tb, nb0);
+            else hipLaunchKernelGGL((k_slot<false, MODE_COMPAT>), dim3((unsigned) nb), dim3(256), 0, stream, hp, s2, sl, st, cr, tb, nb0);
+        }
+    }
+}
+
+void launch_env(bool reset, const HubParams &hp, const StepArgs &sa, const StationArrays &st, const EnvArrays &ev,
+                const CompatRng &cr, const Tables &tb, hipStream_t stream) {
+    const unsigned nb = (unsigned) ((hp.n_envs + 255) / 256);
+    if (hp.rng_mode == MODE_PHILOX) {
+        if (reset) hipLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(256), 0, stream, hp, sa, st, ev, cr, tb);
+        else hipLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(256), 0, stream, hp, sa, st, ev, cr, tb);
+    } else {
+        if (reset) hipLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3(nb), dim3(256), 0, stream, hp, sa, st, ev, cr, tb);
+        else hipLaunchKernelGGL((k_env<false, MODE_COMPAT>), dim3(nb), dim3(256), 0, stream, hp, sa, st, ev, cr, tb);
+    }
+}
+
+void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream) {
+    const int per = (hp.act_dim + 3) / 4;
+    int64_t total = hp.n_envs * per;
+    int64_t nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_random_actions, dim3((unsigned) nb), dim3(256), 0, stream, hp.n_envs, hp.env_id0, hp.act_dim,
+                       (uint32_t) key, (uint32_t) (key >> 32), batch, d_actions);
+}
+
+}  // namespace chub

@@ -1,0 +1,766 @@
+// chub_runtime.hip -- host side of libchub.so: the C ABI of include/chub.h, table construction at
+// create time, HBM state ownership and kernel launches.  No simulation arithmetic of the step runs on
+// the host; what does run here is init-time table building (arrival CDF parsing with the reference's
+// own parser, level thresholds, the electrolyser action->power sweep, price statistics).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/chub.h"
+#include "chub_device.h"
+
+namespace chub {
+void launch_slot(bool reset, const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
+                 const CompatRng &cr, const Tables &tb, hipStream_t stream);
+void launch_env(bool reset, const HubParams &hp, const StepArgs &sa, const StationArrays &st, const EnvArrays &ev,
+                const CompatRng &cr, const Tables &tb, hipStream_t stream);
+void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream);
+}  // namespace chub
+
+using namespace chub;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(CHUB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+struct chub_env {
+    chub_config cfg;
+    HubParams hp;
+    SlotArrays sl;
+    StationArrays st;
+    EnvArrays ev;
+    CompatRng cr;
+    Tables tb;
+    int device;
+    // lock-step clock (MGR:137-140,299; CHS.hpp:1204; AGG:150-151; HYD:192-193 are three copies of it)
+    int t;
+    int price_count;
+    uint32_t tick;
+    double price[96];
+    double hy_table[102];
+    std::vector<void *> allocs;
+    // staging for the host-pointer entry points
+    float *d_actions, *d_obs, *d_reward;
+    uint8_t *d_done;
+    double *d_exo_z;
+    int32_t *d_exo_days;
+    hipStream_t stream;
+};
+
+// ------------------------------------------------------------------------------- data loading
+// Read2Vector::string_to_float (CHS.hpp:138-155): f32 accumulator, `d *= 0.1` is an f64 product narrowed
+// to f32.  Not correctly rounded -- and that changes 79 of the 96 000 arrival-table cells, so it is kept.
+static float parse_cell(const char *s, int len) {
+    int i = 0;
+    float sum = 0;
+    while (i < len && s[i] != '.') {
+        sum = sum * 10.0f + (float) s[i] - 48.0f;
+        ++i;
+    }
+    ++i;
+    float d = 1;
+    while (i < len) {
+        d = (float) ((double) d * 0.1);
+        float t = (float) (s[i] - '0');
+        sum = sum + t * d;
+        ++i;
+    }
+    return sum;
+}
+
+// Read2Vector::read + file_to_string (CHS.hpp:96-136): keep digits and '.', split on ','
+static int load_cdf(const std::string &path, std::vector<float> &cdf) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return fail(CHUB_ERR_DATA, "cannot open " + path);
+    std::string cur;
+    std::vector<float> row;
+    cdf.clear();
+    int rows = 0;
+    int c;
+    auto flush_cell = [&]() {
+        if (!cur.empty()) {
+            row.push_back(parse_cell(cur.data(), (int) cur.size()));
+            cur.clear();
+        }
+    };
+    bool bad = false;
+    auto flush_row = [&]() {
+        flush_cell();
+        if (!row.empty()) {
+            if (row.size() != 301) bad = true;
+            cdf.insert(cdf.end(), row.begin(), row.end());
+            row.clear();
+            rows++;
+        }
+    };
+    while ((c = fgetc(f)) != EOF) {
+        if ((c >= '0' && c <= '9') || c == '.') cur.push_back((char) c);
+        else if (c == ',') flush_cell();
+        else if (c == '\n') flush_row();
+    }
+    flush_row();
+    fclose(f);
+    if (bad || rows != 96) return fail(CHUB_ERR_DATA, path + ": expected 96 rows x 301 columns");
+    return 0;
+}
+
+static int load_f64(const std::string &path, double *dst, size_t count) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return fail(CHUB_ERR_DATA, "cannot open " + path);
+    size_t got = fread(dst, sizeof(double), count, f);
+    int extra = fgetc(f);
+    fclose(f);
+    if (got != count || extra != EOF) return fail(CHUB_ERR_DATA, path + ": wrong size");
+    return 0;
+}
+
+// RandomUtil::uniform_rand(0,1) at level k (CHS.hpp:35-44)
+static float level_value(int k) {
+    float tr = (float) k / 999.0f;
+    tr = tr * (1.0f - 0.0f) + 0.0f;
+    return tr;
+}
+
+// numpy pairwise sum of 96 values (np.mean / np.std, MGR:45-46)
+static double np_sum96(const double *a) {
+    double r[8];
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    for (int i = 8; i < 96; i += 8)
+        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+}
+
+template <typename T>
+static int dev_alloc(chub_env *e, T **p, size_t count, bool zero = true) {
+    void *q = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&q, bytes));
+    e->allocs.push_back(q);
+    if (zero) HIP_TRY(hipMemset(q, 0, bytes));
+    *p = (T *) q;
+    return 0;
+}
+
+template <typename T>
+static int dev_upload(chub_env *e, const T **p, const std::vector<T> &v) {
+    T *q = nullptr;
+    int rc = dev_alloc(e, &q, v.size(), false);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *p = q;
+    return 0;
+}
+
+static int pow2_ge(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// HySystem.__init__ sweep (HYD:154-158) with zero FCEV demand: electrolyser + compressor power of the
+// flow each request level yields while the tank integrates it (see chub_set_hy_table in chub.h).
+static void build_hy_table(const HubParams &hp, double *table) {
+    double cap = hp.init_soc * hp.cap_mass;
+    for (int i = 0; i < 101; i++) {
+        double gen_speed = 0.01 * i;
+        double must_charge = hp.cap_mass * 0.1 - cap;
+        must_charge = must_charge > 0 ? must_charge : 0.0;
+        double upper_charge = hp.cap_mass - cap;
+        upper_charge = upper_charge > 0 ? upper_charge : 0.0;
+        double charge_temp = gen_speed * hp.v_h_max * (15 * 60);
+        charge_temp = charge_temp < upper_charge ? charge_temp : upper_charge;
+        charge_temp = charge_temp > must_charge ? charge_temp : must_charge;
+        double flow = charge_temp / (15 * 60);
+        flow = flow < hp.v_h_max ? flow : hp.v_h_max;
+        double ele = 0.0;
+        if (hp.cells != 0.0) {
+            double v_H_mass = flow / hp.cells;
+            double v_H_mol = v_H_mass / 2.02;
+            double v_H_L = v_H_mol * hp.v_M;
+            double v_H = v_H_L * 1000 * 60;
+            double temp = v_H * 2 * 96487 / (hp.v_M * 1000 * 60);
+            double power = pow(temp, 2) * 0.326 + temp * 1.476;
+            ele = hp.cells * power / 1000;
+        }
+        double cpr = ((flow / 2.02) * hp.cpr_w12 / 0.8) / 1000;
+        cap += flow * 15 * 60;
+        cap -= cap * hp.hydro_loss;
+        table[i] = ele + cpr;
+    }
+    table[101] = table[100];
+}
+
+template <typename T>
+static int fetch(std::vector<T> &dst, const T *src, size_t count) {
+    dst.resize(count);
+    HIP_TRY(hipMemcpy(dst.data(), src, count * sizeof(T), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" {
+
+const char *chub_last_error(void) { return g_err.c_str(); }
+
+int chub_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, int64_t env_id0, int device,
+                uint64_t seed, int rng_mode, chub_env **out) {
+    if (!cfg || !data_dir || !out) return fail(CHUB_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (n_envs <= 0) return fail(CHUB_ERR_ARG, "n_envs must be positive");
+    if (rng_mode != CHUB_RNG_COMPAT && rng_mode != CHUB_RNG_PHILOX) return fail(CHUB_ERR_ARG, "unknown rng_mode");
+    for (int k = 0; k < 2; k++) {
+        if (cfg->station_list[k] < 0) return fail(CHUB_ERR_ARG, "station_list entries must be >= 0");
+        if (cfg->station_list[k] > 64)
+            return fail(CHUB_ERR_UNSUPPORTED, "more than 64 piles per station is not supported yet");
+        if (cfg->station_type_list[k] != CHUB_FAST && cfg->station_type_list[k] != CHUB_SLOW)
+            return fail(CHUB_ERR_ARG, "EVS type must be fast or slow");  // AGG:196
+    }
+    if (cfg->station_list[0] + cfg->station_list[1] < 1)
+        return fail(CHUB_ERR_ARG, "A station must have fast pile or slow pile!");  // MGR:336
+    if (!(cfg->init_soc >= 0.1 && cfg->init_soc <= 1)) return fail(CHUB_ERR_ARG, "init_soc must be in [0.1, 1]");  // HYD:137
+    if (!(cfg->hydro_prod_rate >= 0) || !(cfg->hydro_store_vlt > 0) || !(cfg->fc_max_power >= 0))
+        return fail(CHUB_ERR_ARG, "hydrogen system sizes must be non-negative");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(CHUB_ERR_HIP, "no HIP device available: libchub has no CPU path");
+    if (device < 0 || device >= ndev) return fail(CHUB_ERR_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    chub_env *e = new chub_env();
+    e->cfg = *cfg;
+    e->device = device;
+    e->t = 0;
+    e->price_count = 0;
+    e->tick = 0;
+    e->stream = nullptr;
+    auto bail = [&](int rc) {
+        chub_destroy(e);
+        return rc;
+    };
+
+    // ---- tables from the data files
+    std::string dir(data_dir);
+    std::vector<float> cdf;
+    int rc;
+    if ((rc = load_cdf(dir + "/car_flow_possibility_list_save.csv", cdf))) return bail(rc);
+    std::vector<double> pv(100 * 96), wd(150 * 96);
+    if ((rc = load_f64(dir + "/price_96.f64", e->price, 96))) return bail(rc);
+    if ((rc = load_f64(dir + "/pv_100x96.f64", pv.data(), pv.size()))) return bail(rc);
+    if ((rc = load_f64(dir + "/wd_150x96.f64", wd.data(), wd.size()))) return bail(rc);
+
+    HubParams &hp = e->hp;
+    memset(&hp, 0, sizeof hp);
+    hp.n_envs = n_envs;
+    hp.env_id0 = env_id0;
+    int active = 0;
+    for (int k = 0; k < 2; k++) {
+        hp.S[k] = cfg->station_list[k];
+        hp.type[k] = cfg->station_type_list[k];
+        hp.H[k] = pow2_ge(hp.S[k] > 0 ? hp.S[k] : 1);
+        active += hp.S[k] > 0;
+        // transformer_limit = constant_power * charge_number in f32 (CHS.hpp:1133-1134, 1443-1444)
+        float constant_power = hp.type[k] == CHUB_FAST ? (float) 36.44764034125146 : (float) 5.254973139368931;
+        hp.transformer_limit[k] = constant_power * (float) hp.S[k];
+    }
+    hp.base[0] = 0;
+    hp.base[1] = n_envs * hp.S[0];
+    hp.obs_dim = 2 + 4 * active + 3;
+    hp.act_dim = hp.S[0] + hp.S[1] + 2;
+    hp.constant_charging = cfg->constant_charging ? 1 : 0;
+    hp.rng_mode = rng_mode;
+    hp.telemetry = 0;
+    hp.key[0] = (uint32_t) seed;
+    hp.key[1] = (uint32_t) (seed >> 32);
+    hp.cc = make_curve_consts();
+    // hydrogen system (HYD:94-98, 144, 10-24, 57-72)
+    hp.cap_mass = (0.089 * (200 / 1)) * (cfg->hydro_store_vlt * 1000);
+    hp.v_h_max = 0.089 * cfg->hydro_prod_rate * 1000 / 3600;
+    hp.init_soc = cfg->init_soc;
+    hp.hydro_loss = cfg->hydro_loss;
+    hp.fc_max_power = cfg->fc_max_power;
+    hp.v_M = 0.082 * (273 + 25) / 1;
+    {
+        double v_H_L = (10.0 / 1000) / 60;
+        double v_H_mol = v_H_L / hp.v_M;
+        double v_H_mass = v_H_mol * 2.02;
+        hp.cells = ceil(hp.v_h_max / v_H_mass);
+        double alpha = 1.4, R = 0.082, T = 273 + 25, P_in = 1, P_out = 200;
+        double P_a = sqrt(P_in * P_out);
+        double part1 = alpha / (alpha - 1);
+        double part2 = part1 * R * T;
+        double part3 = (alpha - 1) / alpha;
+        double W_1 = part2 * (-1 + pow(P_a / P_in, part3));
+        double W_2 = part2 * (-1 + pow(P_out / P_a, part3));
+        hp.cpr_w12 = W_1 + W_2;
+    }
+    hp.renew_fluct1 = 1 + cfg->renew_fluctuate;
+    hp.price_fluct1 = 1 + cfg->price_fluctuate;
+    {
+        double mean = np_sum96(e->price) / 96;
+        double dev[96];
+        for (int i = 0; i < 96; i++) {
+            double d = fabs(e->price[i] - mean);
+            dev[i] = d * d;
+        }
+        hp.price_mean = mean;
+        hp.price_std = sqrt(np_sum96(dev) / 96);
+    }
+
+    // arrival index per (slot of day, level): first j with CDF[t][j] >= u_k, else 300 (CHS.hpp:731-743),
+    // then the per-station-type scaling + std::round (CHS.hpp:751-780, HYD:247-251)
+    std::vector<uint8_t> cnt[2], cnt_hv(96 * kLevels);
+    cnt[0].resize(96 * kLevels);
+    cnt[1].resize(96 * kLevels);
+    float hv_pin = (float) 0.3, hv_perm = (float) cfg->fcev_permeate;
+    if (hv_perm > 1) hv_perm = (float) 0.01;
+    for (int t = 0; t < 96; t++) {
+        for (int k = 0; k < kLevels; k++) {
+            float u = level_value(k);
+            int n = 300;
+            for (int j = 0; j < 301; j++) {
+                if ((double) cdf[t * 301 + j] >= (double) u) {
+                    n = j;
+                    break;
+                }
+            }
+            for (int s = 0; s < 2; s++) {
+                float possible_in = hp.type[s] == CHUB_FAST ? (float) 0.15 : (float) 0.1;
+                float permeability = (float) 0.2;
+                float po = possible_in * permeability * (float) n;
+                int c = (int) roundf(po);
+                cnt[s][t * kLevels + k] = (uint8_t) (c < 0 ? 0 : (c > 255 ? 255 : c));
+            }
+            int c = (int) roundf(hv_pin * hv_perm * (float) n);
+            cnt_hv[t * kLevels + k] = (uint8_t) (c < 0 ? 0 : (c > 255 ? 255 : c));
+        }
+    }
+    // level thresholds of the renege / balk tests (CHS.hpp:1286-1303): u > 0.1*logf(w+1), u <= expf(-0.01*m)
+    std::vector<uint16_t> thr_renege(kMaxLine);
+    for (int w = 0; w < kMaxLine; w++) {
+        float leave_possibility = (float) (0.1 * (double) logf((float) (w + 1)));
+        int thr = kLevels;
+        for (int k = 0; k < kLevels; k++)
+            if (level_value(k) > leave_possibility) {
+                thr = k;
+                break;
+            }
+        thr_renege[w] = (uint16_t) thr;
+    }
+    std::vector<int16_t> thr_balk(kBalkTab);
+    for (int m = 0; m < kBalkTab; m++) {
+        float stay = expf((float) (-(0.01 * m)));
+        int thr = -1;
+        for (int k = 0; k < kLevels; k++)
+            if (level_value(k) <= stay) thr = k;
+        thr_balk[m] = (int16_t) thr;
+    }
+    std::vector<double> price_v(e->price, e->price + 96), pvT(96 * 100), wdT(96 * 150);
+    for (int d = 0; d < 100; d++)
+        for (int t = 0; t < 96; t++) pvT[t * 100 + d] = pv[d * 96 + t];
+    for (int d = 0; d < 150; d++)
+        for (int t = 0; t < 96; t++) wdT[t * 150 + d] = wd[d * 96 + t];
+    build_hy_table(hp, e->hy_table);
+    std::vector<double> hy_v(e->hy_table, e->hy_table + 102);
+
+    if ((rc = dev_upload(e, &e->tb.cnt[0], cnt[0]))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.cnt[1], cnt[1]))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.cnt_hv, cnt_hv))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.thr_renege, thr_renege))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.thr_balk, thr_balk))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.price, price_v))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.pvT, pvT))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.wdT, wdT))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.hy_table, hy_v))) return bail(rc);
+
+    // ---- state in HBM
+    const size_t N = (size_t) n_envs, NS = N * (size_t) (hp.S[0] + hp.S[1]);
+#define ALLOC(ptr, count)                                        \
+    if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
+    ALLOC(e->sl.soc, NS); ALLOC(e->sl.target, NS); ALLOC(e->sl.init_soc, NS); ALLOC(e->sl.power, NS);
+    ALLOC(e->sl.t_target, NS); ALLOC(e->sl.t_soc, NS); ALLOC(e->sl.tl, NS); ALLOC(e->sl.stay, NS);
+    ALLOC(e->st.line, 2 * N); ALLOC(e->st.flow_in, 2 * N); ALLOC(e->st.car_number, 2 * N);
+    ALLOC(e->st.min_p, 2 * N); ALLOC(e->st.chg_p, 2 * N); ALLOC(e->st.max_p, 2 * N);
+    ALLOC(e->ev.cap, N); ALLOC(e->ev.store_soc, N); ALLOC(e->ev.ou, 3 * N); ALLOC(e->ev.price_noise, N);
+    ALLOC(e->ev.re_pv, N); ALLOC(e->ev.re_wd, N); ALLOC(e->ev.price_next, N);
+    ALLOC(e->ev.pv_day, N); ALLOC(e->ev.wd_day, N); ALLOC(e->ev.q_len, N); ALLOC(e->ev.hv_line, N);
+    ALLOC(e->ev.q_overflow, N); ALLOC(e->ev.q_time, N * kQCap); ALLOC(e->ev.q_mass, N * kQCap);
+    e->ev.obs64 = nullptr; e->ev.reward64 = nullptr; e->ev.telem = nullptr;
+    e->cr.g = nullptr; e->cr.minstd = nullptr;
+    if (rng_mode == CHUB_RNG_COMPAT) {
+        ALLOC(e->cr.g, N * 32); ALLOC(e->cr.minstd, N);
+    }
+    ALLOC(e->d_actions, N * (size_t) hp.act_dim); ALLOC(e->d_obs, N * (size_t) hp.obs_dim); ALLOC(e->d_reward, N);
+    ALLOC(e->d_done, N); ALLOC(e->d_exo_z, N * 3); ALLOC(e->d_exo_days, N * 2);
+#undef ALLOC
+    {   // tank starts at init_soc (HyStore.__init__, HYD:99-100)
+        std::vector<double> cap(N, hp.init_soc * hp.cap_mass), soc(N, hp.init_soc);
+        HIP_TRY(hipMemcpy(e->ev.cap, cap.data(), N * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->ev.store_soc, soc.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (rng_mode == CHUB_RNG_COMPAT) {
+        // default seeds: env i gets srand(seed + 2*id + 1), e.seed(seed + 2*id + 2)
+        std::vector<uint32_t> seeds(2 * N);
+        for (size_t i = 0; i < N; i++) {
+            uint32_t id = (uint32_t) (env_id0 + (int64_t) i);
+            seeds[2 * i] = (uint32_t) seed + 2u * id + 1u;
+            seeds[2 * i + 1] = (uint32_t) seed + 2u * id + 2u;
+        }
+        *out = e;
+        rc = chub_set_rng_compat_seeds(e, seeds.data());
+        if (rc) {
+            *out = nullptr;
+            return bail(rc);
+        }
+    }
+    *out = e;
+    return CHUB_OK;
+}
+
+int chub_destroy(chub_env *e) {
+    if (!e) return CHUB_OK;
+    (void) hipSetDevice(e->device);
+    (void) hipDeviceSynchronize();
+    for (void *p : e->allocs) (void) hipFree(p);
+    delete e;
+    return CHUB_OK;
+}
+
+int chub_obs_dim(const chub_env *e) { return e ? e->hp.obs_dim : CHUB_ERR_ARG; }
+int chub_act_dim(const chub_env *e) { return e ? e->hp.act_dim : CHUB_ERR_ARG; }
+int64_t chub_num_envs(const chub_env *e) { return e ? e->hp.n_envs : CHUB_ERR_ARG; }
+int chub_clock(const chub_env *e) { return e ? e->t : CHUB_ERR_ARG; }
+
+int chub_sync(chub_env *e) {
+    if (!e) return fail(CHUB_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return CHUB_OK;
+}
+
+int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs, void *stream) {
+    if (!e || !d_obs) return fail(CHUB_ERR_ARG, "null argument");
+    if (e->hp.rng_mode == CHUB_RNG_COMPAT && (!d_exo_days || !d_exo_z))
+        return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_days and exo_z");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t) stream;
+    e->tick += 1;
+    StepArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.t = 0;
+    sa.tick = e->tick;
+    sa.draw_price = (e->price_count % 4 == 0) ? 1 : 0;
+    sa.station_filter = -1;
+    sa.price_last = e->price[95];  // AGG:171: price = [] + mean_for_MAD; price[-1]
+    sa.exo_days = d_exo_days;
+    sa.exo_z = d_exo_z;
+    sa.obs = d_obs;
+    launch_slot(true, e->hp, sa, e->sl, e->st, e->cr, e->tb, s);
+    launch_env(true, e->hp, sa, e->st, e->ev, e->cr, e->tb, s);
+    HIP_TRY(hipGetLastError());
+    e->t = 0;
+    e->price_count = 0;  // MGR:313 (after make_state)
+    return CHUB_OK;
+}
+
+int chub_step_device(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
+                     uint8_t *d_done, void *stream) {
+    if (!e || !d_actions || !d_obs || !d_reward || !d_done) return fail(CHUB_ERR_ARG, "null argument");
+    if (e->tick == 0) return fail(CHUB_ERR_ARG, "step() before reset()");
+    if (e->hp.rng_mode == CHUB_RNG_COMPAT && !d_exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t) stream;
+    e->tick += 1;
+    StepArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.t = e->t;
+    sa.tick = e->tick;
+    sa.draw_price = (e->price_count % 4 == 0) ? 1 : 0;
+    sa.station_filter = -1;
+    sa.price_last = e->price[e->t];  // AGG:147
+    sa.actions = d_actions;
+    sa.exo_z = d_exo_z;
+    sa.obs = d_obs;
+    sa.reward = d_reward;
+    sa.done = d_done;
+    launch_slot(false, e->hp, sa, e->sl, e->st, e->cr, e->tb, s);
+    launch_env(false, e->hp, sa, e->st, e->ev, e->cr, e->tb, s);
+    HIP_TRY(hipGetLastError());
+    e->price_count += 1;
+    e->t = (e->t + 1) % 96;
+    return CHUB_OK;
+}
+
+int chub_reset(chub_env *e, const int32_t *exo_days, const double *exo_z, float *obs) {
+    if (!e || !obs) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t N = (size_t) e->hp.n_envs;
+    if (e->hp.rng_mode == CHUB_RNG_COMPAT) {
+        if (!exo_days || !exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_days and exo_z");
+        for (size_t i = 0; i < N; i++)
+            if (exo_days[2 * i] < 0 || exo_days[2 * i] >= 100 || exo_days[2 * i + 1] < 0 || exo_days[2 * i + 1] >= 150)
+                return fail(CHUB_ERR_ARG, "exo_days out of range");
+        HIP_TRY(hipMemcpy(e->d_exo_days, exo_days, N * 2 * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    int rc = chub_reset_device(e, e->d_exo_days, e->d_exo_z, e->d_obs, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(obs, e->d_obs, N * (size_t) e->hp.obs_dim * sizeof(float), hipMemcpyDeviceToHost));
+    return CHUB_OK;
+}
+
+int chub_step(chub_env *e, const float *actions, const double *exo_z, float *obs, float *reward, uint8_t *done) {
+    if (!e || !actions || !obs || !reward || !done) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t N = (size_t) e->hp.n_envs;
+    HIP_TRY(hipMemcpy(e->d_actions, actions, N * (size_t) e->hp.act_dim * sizeof(float), hipMemcpyHostToDevice));
+    if (e->hp.rng_mode == CHUB_RNG_COMPAT) {
+        if (!exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
+        HIP_TRY(hipMemcpy(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    int rc = chub_step_device(e, e->d_actions, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(obs, e->d_obs, N * (size_t) e->hp.obs_dim * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(done, e->d_done, N, hipMemcpyDeviceToHost));
+    return CHUB_OK;
+}
+
+int chub_random_actions_device(chub_env *e, uint64_t key, uint32_t batch, float *d_actions, void *stream) {
+    if (!e || !d_actions) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    launch_random_actions(e->hp, key, batch, d_actions, (hipStream_t) stream);
+    HIP_TRY(hipGetLastError());
+    return CHUB_OK;
+}
+
+// ------------------------------------------------------------------------------- introspection
+int chub_get_slots(chub_env *e, float *out) {
+    if (!e || !out) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const HubParams &hp = e->hp;
+    const size_t N = (size_t) hp.n_envs, S = (size_t) (hp.S[0] + hp.S[1]), NS = N * S;
+    std::vector<float> soc, target, init_soc, power, t_target, t_soc;
+    std::vector<uint8_t> tl, stay;
+    int rc;
+    if ((rc = fetch(soc, e->sl.soc, NS)) || (rc = fetch(target, e->sl.target, NS)) ||
+        (rc = fetch(init_soc, e->sl.init_soc, NS)) || (rc = fetch(power, e->sl.power, NS)) ||
+        (rc = fetch(t_target, e->sl.t_target, NS)) || (rc = fetch(t_soc, e->sl.t_soc, NS)) ||
+        (rc = fetch(tl, e->sl.tl, NS)) || (rc = fetch(stay, e->sl.stay, NS)))
+        return rc;
+    for (size_t env = 0; env < N; env++) {
+        float *o = out + env * 9 * S;
+        for (int k = 0; k < 2; k++) {
+            const size_t n = (size_t) hp.S[k];
+            for (size_t i = 0; i < n; i++) {
+                const size_t idx = (size_t) hp.base[k] + env * n + i;
+                const int left = tl[idx] & 127;
+                const bool car = left > 0;
+                float em = 0.0f;
+                if (car) {  // Station::situation["emergency"] as calculate_needed leaves it (CHS.hpp:879-898)
+                    float need = t_target[idx] - t_soc[idx];
+                    if (need > 0) em = ((float) left <= ceilf(need)) ? 10.0f : (float) pow((double) (need / (float) left), 2);
+                }
+                o[0 * n + i] = car ? 1.0f : 0.0f;
+                o[1 * n + i] = (tl[idx] & 128) ? 1.0f : 0.0f;
+                o[2 * n + i] = em;
+                o[3 * n + i] = power[idx];
+                o[4 * n + i] = soc[idx];
+                o[5 * n + i] = init_soc[idx];
+                o[6 * n + i] = target[idx];
+                o[7 * n + i] = car ? (float) stay[idx] : -1.0f;
+                o[8 * n + i] = car ? (float) (stay[idx] - left) : -1.0f;
+            }
+            o += 9 * n;
+        }
+    }
+    return CHUB_OK;
+}
+
+int chub_get_station_scalars(chub_env *e, double *out) {
+    if (!e || !out) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t) e->hp.n_envs;
+    std::vector<uint8_t> line, cars;
+    std::vector<int8_t> flow;
+    std::vector<float> mn, ch, mx;
+    int rc;
+    if ((rc = fetch(line, e->st.line, 2 * N)) || (rc = fetch(cars, e->st.car_number, 2 * N)) ||
+        (rc = fetch(flow, e->st.flow_in, 2 * N)) || (rc = fetch(mn, e->st.min_p, 2 * N)) ||
+        (rc = fetch(ch, e->st.chg_p, 2 * N)) || (rc = fetch(mx, e->st.max_p, 2 * N)))
+        return rc;
+    for (size_t env = 0; env < N; env++)
+        for (int k = 0; k < 2; k++) {
+            double *o = out + (env * 2 + k) * 8;
+            const size_t i = (size_t) k * N + env;
+            o[0] = mn[i]; o[1] = ch[i]; o[2] = mx[i]; o[3] = cars[i]; o[4] = line[i]; o[5] = flow[i];
+            o[6] = e->t; o[7] = e->hp.transformer_limit[k];
+        }
+    return CHUB_OK;
+}
+
+int chub_set_telemetry(chub_env *e, int enabled) {
+    if (!e) return fail(CHUB_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    if (enabled && !e->ev.telem) {
+        const size_t N = (size_t) e->hp.n_envs;
+        int rc;
+        if ((rc = dev_alloc(e, &e->ev.telem, N * kTelemCount))) return rc;
+        if ((rc = dev_alloc(e, &e->ev.obs64, N * (size_t) e->hp.obs_dim))) return rc;
+        if ((rc = dev_alloc(e, &e->ev.reward64, N))) return rc;
+    }
+    e->hp.telemetry = enabled ? 1 : 0;
+    return CHUB_OK;
+}
+
+static int need_telemetry(chub_env *e) {
+    if (!e->ev.telem) return fail(CHUB_ERR_ARG, "telemetry is off: call chub_set_telemetry(env, 1) first");
+    return 0;
+}
+
+int chub_get_telemetry(chub_env *e, double *out) {
+    if (!e || !out) return fail(CHUB_ERR_ARG, "null argument");
+    int rc = need_telemetry(e);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t) e->hp.n_envs;
+    std::vector<double> t;
+    if ((rc = fetch(t, e->ev.telem, N * kTelemCount))) return rc;
+    for (size_t env = 0; env < N; env++)
+        for (int i = 0; i < kTelemCount; i++) out[env * kTelemCount + i] = t[(size_t) i * N + env];
+    return CHUB_OK;
+}
+
+int chub_get_obs_f64(chub_env *e, double *out) {
+    if (!e || !out) return fail(CHUB_ERR_ARG, "null argument");
+    int rc = need_telemetry(e);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy(out, e->ev.obs64, (size_t) e->hp.n_envs * e->hp.obs_dim * sizeof(double), hipMemcpyDeviceToHost));
+    return CHUB_OK;
+}
+
+int chub_get_reward_f64(chub_env *e, double *out) {
+    if (!e || !out) return fail(CHUB_ERR_ARG, "null argument");
+    int rc = need_telemetry(e);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy(out, e->ev.reward64, (size_t) e->hp.n_envs * sizeof(double), hipMemcpyDeviceToHost));
+    return CHUB_OK;
+}
+
+int chub_set_rng_compat_seeds(chub_env *e, const uint32_t *seeds) {
+    if (!e || !seeds) return fail(CHUB_ERR_ARG, "null argument");
+    if (e->hp.rng_mode != CHUB_RNG_COMPAT) return fail(CHUB_ERR_ARG, "handle is not in COMPAT mode");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t N = (size_t) e->hp.n_envs;
+    std::vector<uint32_t> g(N * 32), m(N);
+    for (size_t i = 0; i < N; i++) {
+        // glibc srandom_r, TYPE_3: LCG fill of 31 words, front = 3, rear = 0, 310 warm-up draws
+        uint32_t *r = &g[i * 32];
+        uint32_t sd = seeds[2 * i] ? seeds[2 * i] : 1u;
+        int32_t word = (int32_t) sd;
+        r[0] = (uint32_t) word;
+        for (int j = 1; j < 31; j++) {
+            long hi = word / 127773, lo = word % 127773;
+            word = (int32_t) (16807 * lo - 2836 * hi);
+            if (word < 0) word += 2147483647;
+            r[j] = (uint32_t) word;
+        }
+        uint32_t f = 3, b = 0;
+        for (int j = 0; j < 310; j++) {
+            r[f] += r[b];
+            f = (f + 1 == 31) ? 0 : f + 1;
+            b = (b + 1 == 31) ? 0 : b + 1;
+        }
+        r[31] = f;
+        uint32_t x = seeds[2 * i + 1] % 2147483647u;  // minstd_rand0::seed
+        m[i] = x ? x : 1u;
+    }
+    HIP_TRY(hipMemcpy(e->cr.g, g.data(), g.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->cr.minstd, m.data(), m.size() * 4, hipMemcpyHostToDevice));
+    return CHUB_OK;
+}
+
+int chub_set_rng_compat_state(chub_env *e, const uint32_t *state) {
+    if (!e || !state) return fail(CHUB_ERR_ARG, "null argument");
+    if (e->hp.rng_mode != CHUB_RNG_COMPAT) return fail(CHUB_ERR_ARG, "handle is not in COMPAT mode");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t) e->hp.n_envs;
+    std::vector<uint32_t> g(N * 32), m(N);
+    for (size_t i = 0; i < N; i++) {
+        if (state[i * 33 + 31] >= 31u) return fail(CHUB_ERR_ARG, "front index must be < 31");
+        memcpy(&g[i * 32], &state[i * 33], 32 * 4);
+        m[i] = state[i * 33 + 32];
+    }
+    HIP_TRY(hipMemcpy(e->cr.g, g.data(), g.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->cr.minstd, m.data(), m.size() * 4, hipMemcpyHostToDevice));
+    return CHUB_OK;
+}
+
+int chub_get_rng_compat_state(chub_env *e, uint32_t *state) {
+    if (!e || !state) return fail(CHUB_ERR_ARG, "null argument");
+    if (e->hp.rng_mode != CHUB_RNG_COMPAT) return fail(CHUB_ERR_ARG, "handle is not in COMPAT mode");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t) e->hp.n_envs;
+    std::vector<uint32_t> g, m;
+    int rc;
+    if ((rc = fetch(g, (const uint32_t *) e->cr.g, N * 32)) || (rc = fetch(m, (const uint32_t *) e->cr.minstd, N))) return rc;
+    for (size_t i = 0; i < N; i++) {
+        memcpy(&state[i * 33], &g[i * 32], 32 * 4);
+        state[i * 33 + 32] = m[i];
+    }
+    return CHUB_OK;
+}
+
+int chub_set_ou_state(chub_env *e, const double *ou) {
+    if (!e || !ou) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t N = (size_t) e->hp.n_envs;
+    std::vector<double> t(3 * N);
+    for (size_t i = 0; i < N; i++)
+        for (int c = 0; c < 3; c++) t[(size_t) c * N + i] = ou[i * 3 + c];
+    HIP_TRY(hipMemcpy(e->ev.ou, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    return CHUB_OK;
+}
+
+int chub_get_hy_table(const chub_env *e, double *out102) {
+    if (!e || !out102) return fail(CHUB_ERR_ARG, "null argument");
+    memcpy(out102, e->hy_table, sizeof e->hy_table);
+    return CHUB_OK;
+}
+
+int chub_set_hy_table(chub_env *e, const double *in102) {
+    if (!e || !in102) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    memcpy(e->hy_table, in102, sizeof e->hy_table);
+    HIP_TRY(hipMemcpy((void *) e->tb.hy_table, in102, sizeof e->hy_table, hipMemcpyHostToDevice));
+    return CHUB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+"""VecChargingHub -- N lock-step charging-hub environments on one MI355X.
+
+Batched counterpart of ``EvcsspManagerEnv_v6`` (evcssp_manager.py:19-414): same constructor kwargs, same
+observation / action layout per env, arrays of shape ``[N, ...]``.  All simulation runs in libchub's HIP
+kernels; this class only marshals numpy arrays across the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ChubConfig, ChubError, check, load_library
+
+
+def make_config(station_list, station_type_list, constant_charging=False, hydro_prod_rate=None, hydro_store_vlt=None,
+                init_soc=0.5, fc_max_power=None, fcev_permeate=0.01, renew_fluctuate=0, price_fluctuate=0,
+                hydro_loss=0):
+    """Constructor kwargs of the reference (MGR:25-27) -> chub_config, with the reference's defaults
+    (hydro_prod_rate None -> 430 HYD:140-143, hydro_store_vlt None -> 5000 HYD:96, fc_max_power None -> 100 HYD:401-404)."""
+    if not (len(station_list) == len(station_type_list) == 2):  # MGR:37
+        raise AssertionError("station_list and station_type_list must both have 2 entries")
+    cfg = ChubConfig()
+    for k in range(2):
+        cfg.station_list[k] = int(station_list[k])
+        if station_type_list[k] == "fast":
+            cfg.station_type_list[k] = _lib.CHUB_FAST
+        elif station_type_list[k] == "slow":
+            cfg.station_type_list[k] = _lib.CHUB_SLOW
+        else:
+            raise ValueError("EVS type must be fast or slow")  # AGG:196
+    cfg.constant_charging = int(bool(constant_charging))
+    cfg.hydro_prod_rate = 430.0 if hydro_prod_rate is None else float(hydro_prod_rate)
+    cfg.hydro_store_vlt = 5000.0 if hydro_store_vlt is None else float(hydro_store_vlt)
+    cfg.init_soc = float(init_soc)
+    cfg.fc_max_power = 100.0 if fc_max_power is None else float(fc_max_power)
+    cfg.fcev_permeate = float(fcev_permeate)
+    cfg.renew_fluctuate = float(renew_fluctuate)
+    cfg.price_fluctuate = float(price_fluctuate)
+    cfg.hydro_loss = float(hydro_loss)
+    return cfg
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class VecChargingHub(object):
+    def __init__(self, n_envs, station_list, station_type_list, seed=0, rng="philox", device=0, env_id0=0,
+                 data_dir=None, **kwargs):
+        kwargs.pop("seed_rand", None)
+        kwargs.pop("use_lagrange", None)  # ignored by the reference too (MGR:126)
+        self._lib = load_library()
+        self.cfg = make_config(station_list, station_type_list, **kwargs)
+        self.n_envs = int(n_envs)
+        self.rng_mode = _lib.RNG_PHILOX if rng == "philox" else _lib.RNG_COMPAT
+        if rng not in ("philox", "compat"):
+            raise ValueError("rng must be 'philox' or 'compat'")
+        h = C.c_void_p()
+        check(self._lib.chub_create(C.byref(self.cfg), (data_dir or _lib.DATA_DIR).encode(), self.n_envs, int(env_id0),
+                                    int(device), int(seed) & 0xFFFFFFFFFFFFFFFF, self.rng_mode, C.byref(h)))
+        self._h = h
+        self.obs_dim = self._lib.chub_obs_dim(h)
+        self.act_dim = self._lib.chub_act_dim(h)
+        self.n_slots = self.act_dim - 2
+        self.piles = (int(station_list[0]), int(station_list[1]))
+        self._obs = np.zeros((self.n_envs, self.obs_dim), dtype=np.float32)
+        self._reward = np.zeros(self.n_envs, dtype=np.float32)
+        self._done = np.zeros(self.n_envs, dtype=np.uint8)
+
+    # ---- hot path
+    def reset(self, exo_days=None, exo_z=None):
+        d = None if exo_days is None else np.ascontiguousarray(exo_days, dtype=np.int32).reshape(self.n_envs, 2)
+        z = None if exo_z is None else np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)).reshape(self.n_envs, 3)
+        check(self._lib.chub_reset(self._h, _ptr(d), _ptr(z), _ptr(self._obs)))
+        return self._obs.copy()
+
+    def step(self, actions, exo_z=None):
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        if a.shape != (self.n_envs, self.act_dim):  # MGR:148
+            raise AssertionError("actions must have shape (%d, %d)" % (self.n_envs, self.act_dim))
+        z = None if exo_z is None else np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)).reshape(self.n_envs, 3)
+        check(self._lib.chub_step(self._h, _ptr(a), _ptr(z), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
+        return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
+
+    # ---- device-pointer path (ints are raw device addresses, e.g. torch.Tensor.data_ptr())
+    def reset_device(self, d_obs, d_exo_days=0, d_exo_z=0, stream=0):
+        check(self._lib.chub_reset_device(self._h, d_exo_days or None, d_exo_z or None, d_obs, stream or None))
+
+    def step_device(self, d_actions, d_obs, d_reward, d_done, d_exo_z=0, stream=0):
+        check(self._lib.chub_step_device(self._h, d_actions, d_exo_z or None, d_obs, d_reward, d_done, stream or None))
+
+    def random_actions_device(self, d_actions, key, batch, stream=0):
+        check(self._lib.chub_random_actions_device(self._h, int(key), int(batch), d_actions, stream or None))
+
+    def sync(self):
+        check(self._lib.chub_sync(self._h))
+
+    @property
+    def clock(self):
+        return self._lib.chub_clock(self._h)
+
+    # ---- introspection
+    def set_telemetry(self, on=True):
+        check(self._lib.chub_set_telemetry(self._h, int(bool(on))))
+
+    def slots(self):
+        """list over stations of arrays [N, 9, piles_k]: car, charge, emergency, power, soc, init_soc, target_soc,
+        stay_time, already_stay_time."""
+        out = np.zeros((self.n_envs, 9 * self.n_slots), dtype=np.float32)
+        check(self._lib.chub_get_slots(self._h, _ptr(out)))
+        s0 = self.piles[0]
+        a = out[:, :9 * s0].reshape(self.n_envs, 9, s0)
+        b = out[:, 9 * s0:].reshape(self.n_envs, 9, self.piles[1])
+        return [a, b]
+
+    def station_scalars(self):
+        out = np.zeros((self.n_envs, 2, 8), dtype=np.float64)
+        check(self._lib.chub_get_station_scalars(self._h, _ptr(out)))
+        return out
+
+    def telemetry(self):
+        out = np.zeros((self.n_envs, _lib.T_COUNT), dtype=np.float64)
+        check(self._lib.chub_get_telemetry(self._h, _ptr(out)))
+        return out
+
+    def obs_f64(self):
+        out = np.zeros((self.n_envs, self.obs_dim), dtype=np.float64)
+        check(self._lib.chub_get_obs_f64(self._h, _ptr(out)))
+        return out
+
+    def reward_f64(self):
+        out = np.zeros(self.n_envs, dtype=np.float64)
+        check(self._lib.chub_get_reward_f64(self._h, _ptr(out)))
+        return out
+
+    def set_compat_seeds(self, seeds):
+        s = np.ascontiguousarray(seeds, dtype=np.uint32).reshape(self.n_envs, 2)
+        check(self._lib.chub_set_rng_compat_seeds(self._h, _ptr(s)))
+
+    def set_compat_state(self, state):
+        s = np.ascontiguousarray(state, dtype=np.uint32).reshape(self.n_envs, 33)
+        check(self._lib.chub_set_rng_compat_state(self._h, _ptr(s)))
+
+    def compat_state(self):
+        out = np.zeros((self.n_envs, 33), dtype=np.uint32)
+        check(self._lib.chub_get_rng_compat_state(self._h, _ptr(out)))
+        return out
+
+    def set_ou_state(self, ou):
+        o = np.ascontiguousarray(ou, dtype=np.float64).reshape(self.n_envs, 3)
+        check(self._lib.chub_set_ou_state(self._h, _ptr(o)))
+
+    def hy_table(self):
+        out = np.zeros(102, dtype=np.float64)
+        check(self._lib.chub_get_hy_table(self._h, _ptr(out)))
+        return out
+
+    def set_hy_table(self, table):
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        if t.shape != (102,):
+            raise ValueError("table must have 102 entries")
+        check(self._lib.chub_set_hy_table(self._h, _ptr(t)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.chub_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+__all__ = ["VecChargingHub", "make_config", "ChubError"]

@@ -1,0 +1,154 @@
+/* chub.h -- C ABI of the MI355X-native vectorised charging-hub environment runtime (libchub.so).
+ *
+ * Drop-in boundary.  In the reference the Python host (evcssp_env_cpp/envs/evcssp_manager.py:19,
+ * class EvcsspManagerEnv_v6) reaches its native core through the Boost.Python module `pyevstation`
+ * (evcssp_env_cpp/envs/lion_cpp20/main.cpp:19-290).  This header is what replaces that module for
+ * the reset()/step() hot path: plain pointers and sizes, no Python / torch / Boost types.  Each entry
+ * point names the reference interface it stands in for.  Everything behind it runs on the GPU; there
+ * is no CPU fallback -- every call fails with CHUB_ERR_HIP when no device is usable.
+ *
+ * Conventions
+ *   - N = n_envs, S = piles[0] + piles[1], D = chub_obs_dim(), A = S + 2.
+ *   - all arrays are dense row-major; "host" pointers are ordinary CPU memory owned by the caller,
+ *     "device" pointers are HIP device memory on the handle's device, owned by the caller.
+ *   - every function returns 0 on success or a negative CHUB_ERR_* code; chub_last_error() gives the
+ *     message of the calling thread's last failure.  Nothing is printed (the reference prints and
+ *     carries on, CHS.hpp:103,292,825).
+ *   - a handle is not thread-safe; use one host thread per handle (the reference is single-threaded
+ *     with process-global state, CHS.hpp:23-25).
+ */
+#ifndef CHUB_H
+#define CHUB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHUB_VERSION 1
+
+enum {
+    CHUB_OK = 0,
+    CHUB_ERR_ARG = -1,      /* bad argument (the reference: AssertionError / ValueError, MGR:37,148; AGG:196) */
+    CHUB_ERR_DATA = -2,     /* data files missing or malformed (the reference: silent UB, CHS.hpp:102-105,733) */
+    CHUB_ERR_HIP = -3,      /* HIP runtime failure / no GPU */
+    CHUB_ERR_UNSUPPORTED = -4
+};
+
+enum { CHUB_FAST = 0, CHUB_SLOW = 1 };
+
+/* RNG modes.  COMPAT reproduces the reference's two process-global streams per environment (glibc
+ * rand() TYPE_3 + std::minstd_rand0, CHS.hpp:23-45) in the reference's consumption order; exogenous
+ * normals / day indices come from the caller (the reference draws them from numpy / random, REN:25,74).
+ * PHILOX is the production mode: counter-based Philox4x32-10, key = seed, counter = (block,
+ * site<<16|index, tick, global env id); results do not depend on how envs are sharded over GPUs. */
+enum { CHUB_RNG_COMPAT = 0, CHUB_RNG_PHILOX = 1 };
+
+/* Constructor kwargs of EvcsspManagerEnv_v6 (MGR:25-27), same names and meaning.  use_lagrange is
+ * ignored by the reference (MGR:126) and has no field.  seed_rand maps to the seeds given at create. */
+typedef struct chub_config {
+    int32_t station_list[2];      /* piles per station; 0 = station absent from obs but still simulated */
+    int32_t station_type_list[2]; /* CHUB_FAST / CHUB_SLOW */
+    int32_t constant_charging;
+    int32_t reserved0;
+    double hydro_prod_rate;       /* m^3/h  (None -> 430, HYD:140-143) */
+    double hydro_store_vlt;       /* m^3    (None -> 5000, HYD:96) */
+    double init_soc;              /* 0.1 .. 1 (HYD:137) */
+    double fc_max_power;          /* kW     (None -> 100, HYD:401-404) */
+    double fcev_permeate;
+    double renew_fluctuate;
+    double price_fluctuate;
+    double hydro_loss;
+} chub_config;
+
+typedef struct chub_env chub_env;
+
+/* telemetry column indices of chub_get_telemetry (names of the reference attributes, MGR:183-297) */
+enum {
+    CHUB_T_HY_ACT = 0, CHUB_T_HY_FLOW_SPEED, CHUB_T_ALL_POWER_SECOND, CHUB_T_STORE_SOC, CHUB_T_CAPACITY,
+    CHUB_T_TOTAL_MASS_NEED, CHUB_T_HY_USE, CHUB_T_NOT_MEET, CHUB_T_FC_POWER, CHUB_T_HY_TO_USE,
+    CHUB_T_USED_RENEW, CHUB_T_EV0, CHUB_T_EV1, CHUB_T_HYDROGEN_POWER, CHUB_T_INCOME, CHUB_T_REWARD,
+    CHUB_T_RE_PV, CHUB_T_RE_WD, CHUB_T_PRICE_NEXT, CHUB_T_HV_ARRIVE, CHUB_T_HV_LINE, CHUB_T_QUEUE_LEN,
+    CHUB_T_PV_DAY, CHUB_T_WD_DAY, CHUB_T_COUNT
+};
+
+/* ---- lifetime ------------------------------------------------------------------------------
+ * Replaces: EvcsspManagerEnv_v6.__init__ (MGR:25-130) = Change_Use_Seed (main.cpp:21) + 2x
+ * Fast/SlowChargeStation(int,bool,bool) (main.cpp:188,240; AGG:188-196) + HySystem/HFC/ReNew setup.
+ * data_dir holds car_flow_possibility_list_save.csv (parsed with the reference's own float parser,
+ * CHS.hpp:138-155) and price_96.f64 / pv_100x96.f64 / wd_150x96.f64.  env_id0 = global index of this
+ * handle's first env (shard offset); device = HIP device ordinal.  No reset is performed. */
+int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, int64_t env_id0, int device,
+                uint64_t seed, int rng_mode, chub_env **out);
+int chub_destroy(chub_env *env);
+
+int chub_obs_dim(const chub_env *env);  /* 2 + 4*(#stations with piles>0) + 3 (MGR:74-104) */
+int chub_act_dim(const chub_env *env);  /* S + 2 (MGR:108-113) */
+int64_t chub_num_envs(const chub_env *env);
+int chub_clock(const chub_env *env);    /* 0..95, shared by all envs (lock-step) */
+
+/* ---- hot path ------------------------------------------------------------------------------
+ * chub_reset replaces EvcsspManagerEnv_v6.reset (MGR:304-316 -> AGG:157-175 evs_reset main.cpp:199,251,
+ * HYD:197-208, REN:51-53).  chub_step replaces EvcsspManagerEnv_v6.step (MGR:136-302 -> AGG:116-155
+ * evs_step(Vector_float) main.cpp:198,250; hv_car_number_wrt_poisson / mk_soc main.cpp:151,163).
+ *   actions  [N,A] f32 in [-1,1]; pile bit = ((a+1)/2 >= 0.5) in f32; tail is swapped as in MGR:395-403
+ *   exo_days [N,2] i32 (pv_day, wd_day) -- required in COMPAT mode, ignored (may be NULL) in PHILOX
+ *   exo_z    [N,3] f64 standard normals for the (pv, wd, price) OU updates (REN:71-76) -- COMPAT only
+ *   obs      [N,D] f32, reward [N] f32, done [N] u8
+ * Host-pointer forms copy in/out around the device-pointer forms. */
+int chub_reset(chub_env *env, const int32_t *exo_days, const double *exo_z, float *obs);
+int chub_step(chub_env *env, const float *actions, const double *exo_z, float *obs, float *reward, uint8_t *done);
+
+/* Same, all pointers device memory, enqueued on `stream` (a hipStream_t, NULL = default stream);
+ * returns after enqueueing.  This is the form the multi-GPU host and bench.py use. */
+int chub_reset_device(chub_env *env, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs, void *stream);
+int chub_step_device(chub_env *env, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
+                     uint8_t *d_done, void *stream);
+
+/* Random policy on device: fills d_actions [N,A] with i.i.d. uniform(-1,1) f32 from Philox key
+ * `key`, counter (j, 0, batch, global env id).  (test/env_test.py drives the reference with a fixed
+ * policy; RL trainers supply their own.) */
+int chub_random_actions_device(chub_env *env, uint64_t key, uint32_t batch, float *d_actions, void *stream);
+
+int chub_sync(chub_env *env);
+
+/* ---- introspection (parity tests, `re_*` telemetry, show_situation MGR:412-414) ---------------
+ * chub_get_slots: per env, per station k, field-major [9][piles[k]]: car, charge, emergency, power, soc,
+ *   init_soc, target_soc (Station::situation, CHS.hpp:204-231), stay_time, already_stay_time
+ *   (CHS.hpp:245-246); out is [N][9*S] f32 with station 0's block first.  Empty slots report the pile
+ *   defaults of the reference (-1 for the two counters).
+ * chub_get_station_scalars: [N][2][8] f64 = min_power, charge_power, max_power, car_number, line,
+ *   flow_in_number[-1], station_time_hole, transformer_limit (AGG:198-218, MGR:368).
+ * chub_get_telemetry: [N][CHUB_T_COUNT] f64 of the last step.
+ * chub_get_obs_f64 / chub_get_reward_f64: last observation / reward before the f32 narrowing. */
+int chub_get_slots(chub_env *env, float *out);
+int chub_get_station_scalars(chub_env *env, double *out);
+int chub_get_telemetry(chub_env *env, double *out);
+int chub_get_obs_f64(chub_env *env, double *out);
+int chub_get_reward_f64(chub_env *env, double *out);
+int chub_set_telemetry(chub_env *env, int enabled); /* off by default: the hot path then skips those stores */
+
+/* COMPAT streams: seeds [N][2] u32 = (srand seed, e.seed()) per env, i.e. what Change_Use_Seed /
+ * srand / e.seed would install (CHS.hpp:25-44). */
+int chub_set_rng_compat_seeds(chub_env *env, const uint32_t *seeds);
+/* Raw COMPAT stream state per env, [N][33] u32: the 31 words of glibc's TYPE_3 ring, the index of its
+ * front pointer (rear = front - 3 mod 31), and the minstd_rand0 word -- to continue streams mid-sequence. */
+int chub_set_rng_compat_state(chub_env *env, const uint32_t *state);
+int chub_get_rng_compat_state(chub_env *env, uint32_t *state);
+/* Persistent OU states (never reset by the reference, MGR:304-316): [N][3] f64 pv, wd, price. */
+int chub_set_ou_state(chub_env *env, const double *ou);
+
+/* electrolyser action->power table hy_power_speed_list[102] (HYD:154-157).  Built at create by a
+ * zero-demand sweep; the reference's sweep uses live random FCEV demand, which only matters when a
+ * tank clamp binds during construction -- chub_set_hy_table lets a caller install that table. */
+int chub_get_hy_table(const chub_env *env, double *out102);
+int chub_set_hy_table(chub_env *env, const double *in102);
+
+const char *chub_last_error(void);
+int chub_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHUB_H */

@@ -528,6 +528,24 @@ static void calculate_output(orc_station *s) {
         if (s->car[i] > 0.5) calculate_needed(s, i);
     float min_power = 0, max_power = 0, now_power = 0;
     int number = 0;
+    if (s->exact_sums) {
+        /* production semantics (PHILOX mode): the three sums are the f32 rounding of the exact sum, which is
+         * what the GPU's f64 butterfly yields; the reference's sequential f32 sum is within S*2^-24 of it */
+        double dmin = 0, dmax = 0, dnow = 0;
+        for (int i = 0; i < s->n; i++) {
+            if (s->car[i] > 0.5) {
+                number += 1;
+                dmax += s->power[i];
+                if (s->emergency[i] > 8) dmin += s->power[i];
+                if (s->charge[i] <= 1.1 && s->charge[i] >= 0.9) dnow += s->power[i];
+            }
+        }
+        s->min_power = (float) dmin;
+        s->max_power = (float) dmax;
+        s->charge_power = (float) dnow;
+        s->car_number = number;
+        return;
+    }
     for (int i = 0; i < s->n; i++) {
         if (s->car[i] > 0.5) {
             number += 1;
@@ -620,7 +638,7 @@ static void receive_car(orc_station *s, orc_rng *r, const orc_tables *t, int res
     int true_in_car = 0;
     float arrival_stay_possibility;
     for (int arrive_id = 0; arrive_id < in_car; arrive_id++) {
-        a = orc_uniform_level(orc_draw_k(r, ORC_PU_BALK, s->index, arrive_id), 0, 1);
+        a = orc_uniform_level(orc_draw_k(r, ORC_PU_ARRIVE, s->index, 1 + arrive_id), 0, 1); /* philox: word 1+j */
         arrival_stay_possibility = expf(-(0.01 * (s->line + arrive_id)));
         if (a <= arrival_stay_possibility && arrive_id <= s->n) true_in_car += 1;
     }
@@ -1173,6 +1191,8 @@ orc_vec *orc_vec_create(const orc_config *cfg, const orc_tables *t, long n_envs,
             orc_rng_seed_compat(&v->envs[i].rng, (uint32_t) seed + 2u * id + 1u, (uint32_t) seed + 2u * id + 2u);
         } else {
             orc_rng_seed_philox(&v->envs[i].rng, seed, id);
+            v->envs[i].st[0].exact_sums = 1;
+            v->envs[i].st[1].exact_sums = 1;
         }
     }
     return v;
