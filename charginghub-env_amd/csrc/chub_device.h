@@ -49,8 +49,10 @@ struct SlotArrays {          // per-slot state, f32 unless noted; index = base_k
 };
 
 struct StationArrays {       // index = k*N + env
-    uint8_t *line;           // waiting queue length (Station::line)
-    int8_t *flow_in;         // flow_in_number.back()
+    uint8_t *line;           // waiting queue length (Station::line) after the step
+    uint8_t *line_r;         // PHILOX: queue length after the NEXT step's renege pass (drawn ahead by k_env)
+    int8_t *flow_in;         // flow_in_number.back() of the step just simulated
+    int8_t *flow_next;       // PHILOX: the NEXT step's arrivals (drawn ahead by k_env, consumed by k_slot)
     uint8_t *car_number;
     float *min_p, *chg_p, *max_p;
 };
@@ -86,6 +88,12 @@ struct Tables {
     const double *pvT;       // [96][100]  (transposed: one row per slot of the day)
     const double *wdT;       // [96][150]
     const double *hy_table;  // [102]
+    const float *soc_d_icdf; // [4097] inverse CDF of clip(N(7,3),1,10)            (PHILOX mode, tools/gen_tables.py)
+    const uint32_t *late_thr;// [16]   2^32 * CDF of max(0, round(N(2,2)))          (PHILOX mode)
+    const float *normal_icdf;// [4097] inverse CDF of N(0,1), and
+    const float *normal_tail;// [4097] its second level for the lowest / highest cell   (PHILOX mode)
+    const double *sin96;     // [96]   sin(2*pi*t/96), the time feature of the observation (MGR:319-320)
+    const float *ttab[2];    // [1000] soc_to_time(target level k) of station k's curve (target = 80 + 20*k/999)
 };
 
 struct HubParams {
@@ -110,6 +118,7 @@ struct HubParams {
     double renew_fluct1, price_fluct1;  // 1 + fluctuate
     double price_mean, price_std;
     float hv_rate;           // f32(f32(0.3) * f32(permeate))
+    int32_t ablate;          // timing experiments only (env CHUB_ABLATE): skips parts of k_slot, results are WRONG
 };
 
 struct StepArgs {
@@ -121,9 +130,11 @@ struct StepArgs {
     const float *actions;    // [N][A]
     const double *exo_z;     // [N][3] or null
     const int32_t *exo_days; // [N][2] or null (reset)
-    float *obs;              // [N][D]
-    float *reward;           // [N]
-    uint8_t *done;           // [N]
+    float *obs;              // row i at obs + i*obs_stride (dense: stride D; packed: stride D+2)
+    float *reward;           // element i at reward + i*reward_stride
+    uint8_t *done;           // [N] u8, or null when done_f32 is used
+    float *done_f32;         // packed form: element i at done_f32 + i*reward_stride (0.0 / 1.0)
+    int32_t obs_stride, reward_stride;
 };
 
 }  // namespace chub

@@ -55,20 +55,6 @@ struct PhiloxCtx {
     __device__ __forceinline__ U4 block(uint32_t site, uint32_t index, uint32_t blk) const {
         return philox4x32_10(blk, (site << 16) | index, tick, gid, k0, k1);
     }
-    // standard normal: Marsaglia polar on 53-bit canonicals, trial i = block i, all f64
-    __device__ double normal(uint32_t site, uint32_t index) const {
-        for (uint32_t trial = 0; trial < (uint32_t) kPolarMaxTrials; trial++) {
-            U4 o = block(site, index, trial);
-            double c1 = ((double) (o.v[0] >> 5) * 67108864.0 + (double) (o.v[1] >> 6)) * (1.0 / 9007199254740992.0);
-            double c2 = ((double) (o.v[2] >> 5) * 67108864.0 + (double) (o.v[3] >> 6)) * (1.0 / 9007199254740992.0);
-            double x = 2.0 * c1 - 1.0, y = 2.0 * c2 - 1.0;
-            double r2 = x * x + y * y;
-            if (r2 > 1.0 || r2 == 0.0) continue;
-            double mult = __dsqrt_rn(-2.0 * log(r2) / r2);
-            return y * mult;
-        }
-        return 0.0;
-    }
 };
 
 // ------------------------------------------------------------- reference streams (COMPAT), one lane
@@ -166,18 +152,115 @@ __device__ __forceinline__ float arrive_soc_from(double normal73) {  // mk_soc, 
 
 constexpr int MODE_COMPAT = 0, MODE_PHILOX = 1;
 
+// PHILOX mode: mk_soc (CHS.hpp:804-814) from one 32-bit uniform by linear interpolation of the tabulated
+// inverse CDF of clip(N(7,3),1,10): 12 bits pick the cell, 20 bits interpolate (three f32 roundings)
+__device__ __forceinline__ float soc_from_word(const float *icdf, uint32_t w) {
+    const uint32_t idx = w >> 20;
+    const float frac = (float) (w & 0xFFFFFu) * (1.0f / 1048576.0f);
+    const float a = icdf[idx], b = icdf[idx + 1];
+    const float d = __fadd_rn(a, __fmul_rn(__fsub_rn(b, a), frac));
+    return arrive_soc_from((double) d);
+}
+// PHILOX mode: mk_late_time (CHS.hpp:816-830) = #{j : w >= LT[j]} on the tabulated CDF of max(0, round(N(2,2)))
+__device__ __forceinline__ int late_from_word(const uint32_t *thr, uint32_t w) {
+    int late = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) late += (w >= thr[j]) ? 1 : 0;
+    return late;
+}
+
+// PHILOX mode: N(0,1) from one 32-bit uniform by two-level tabulated inverse CDF (tools/gen_tables.py): 4096 cells,
+// linear interpolation inside a cell; the lowest cell is refined by a second table, the highest is its mirror.
+__device__ __forceinline__ float normal_from_word(const float *tz, const float *tl, uint32_t w) {
+    const uint32_t cell = w >> 20;
+    const bool hi = cell == 4095u, lo = cell == 0u;
+    const uint32_t m = hi ? ~w : w;
+    const bool tail = hi || lo;
+    const float *tab = tail ? tl : tz;
+    const uint32_t idx = tail ? (m >> 8) : cell;
+    const float frac = tail ? (float) (m & 0xFFu) * (1.0f / 256.0f) : (float) (w & 0xFFFFFu) * (1.0f / 1048576.0f);
+    const float a = tab[idx], b = tab[idx + 1];
+    const float z = __fadd_rn(a, __fmul_rn(__fsub_rn(b, a), frac));
+    return hi ? -z : z;
+}
+
 // ---------------------------------------------------------------------------------------- k_slot
-template <int TYPE, bool RESET, int MODE>
+// What one lane keeps of its slot across the phases of a step.
+struct SlotRegs {
+    float power, t_target, t_soc, soc_new;
+    int tl;
+    bool car, charge, soc_dirty, leave;
+};
+
+// Phase 1: load, urgency, feasibility / on-off, car_step, departure (CHS.hpp:1188-1202 / 1499-1513)
+template <int TYPE>
+__device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, SlotRegs &r,
+                                             int64_t idx, int64_t env, int hub_slot, bool cp) {
+    r.power = sl.power[idx];
+    r.t_target = sl.t_target[idx];
+    r.t_soc = sl.t_soc[idx];
+    r.tl = sl.tl[idx] & 127;
+    r.car = r.tl > 0;
+    // action_to_real (MGR:384-393): (a+1)/2 >= 0.5 on the f32 array
+    const float a = sa.actions[env * hp.act_dim + hub_slot];
+    const bool act_on = __fdiv_rn(__fadd_rn(a, 1.0f), 2.0f) >= 0.5f;
+    // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373)
+    const float em = r.car ? emergency_of(r.t_target, r.t_soc, r.tl) : 0.0f;
+    const bool on = r.car && (act_on || (double) em >= 1.01);
+    if (on && !(hp.ablate & 2)) {  // car_step (CHS.hpp:900-905 / 1065-1070)
+        const float tt = __fadd_rn(r.t_soc, 1.0f);
+        r.soc_new = time_to_soc<TYPE>(tt, cp, hp.cc);
+        r.power = time_to_power<TYPE>(tt, cp);
+        r.t_soc = soc_to_time<TYPE>(r.soc_new, cp);
+        r.soc_dirty = true;
+    }
+    if (r.car) {  // remove_car (CHS.hpp:912-923 / 1077-1088)
+        r.tl -= 1;
+        if (r.tl <= 0) {
+            r.car = false;
+            r.leave = true;
+            r.tl = 0;
+            r.power = 0.0f;
+            r.t_target = 0.0f;
+            r.t_soc = 0.0f;
+        }
+    }
+    r.charge = on && r.car;
+}
+
+// What add_car (CHS.hpp:864-877 / 1029-1042) produces for one admitted slot.
+struct NewCar {
+    float soc, target, t_target, t_soc, power;
+    int stay;
+};
+
+template <int TYPE>
+__device__ __forceinline__ NewCar make_car(float arrive_soc, float target, float t_target, int late, bool cp) {
+    NewCar c;
+    c.soc = arrive_soc;
+    c.target = target;
+    c.t_target = t_target;
+    c.t_soc = soc_to_time<TYPE>(arrive_soc, cp);
+    const float need = __fsub_rn(c.t_target, c.t_soc);
+    int stay = (int) ceilf(need) + late;  // calculate_min_charging_time + mk_late_time
+    c.stay = stay > 127 ? 127 : stay;
+    c.power = time_to_power<TYPE>(c.t_soc, cp);
+    return c;
+}
+
+template <int TYPE, bool RESET, int MODE, int BLOCK>
 __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
                           const CompatRng &cr, const Tables &tb, const int k, const int64_t block_local,
-                          float *lds_soc, uint16_t *lds_lev, uint8_t *lds_late) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                          float *lds_f, uint32_t *lds_u) {
+    constexpr int WAVES = BLOCK / 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int H = hp.H[k], S = hp.S[k];
     const int upw = 64 / H;
     const int uiw = lane / H;
     const int slot = lane & (H - 1);
     const int64_t N = hp.n_envs;
-    const int64_t env = block_local * (int64_t) (4 * upw) + wave * upw + uiw;
+    const int64_t env = block_local * (int64_t) (WAVES * upw) + wave * upw + uiw;
     const bool unit_ok = env < N;
     const bool valid = unit_ok && slot < S;
     const uint64_t unit_mask = (H == 64) ? ~0ull : (((1ull << H) - 1ull) << (uiw * H));
@@ -185,105 +268,110 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     const int64_t sidx = (int64_t) k * N + env;
     const int hub_slot = (k ? hp.S[0] : 0) + slot;
     const bool cp = hp.constant_charging != 0;
-    const CurveConsts cc = hp.cc;
 
-    float power = 0.0f, t_target = 0.0f, t_soc = 0.0f, soc_new = 0.0f;
-    int tl = 0;
-    bool car = false, charge = false, soc_dirty = false, leave = false;
-
-    if (!RESET && valid) {
-        power = sl.power[idx];
-        t_target = sl.t_target[idx];
-        t_soc = sl.t_soc[idx];
-        tl = sl.tl[idx] & 127;
-        car = tl > 0;
-        // action_to_real (MGR:384-393): (a+1)/2 >= 0.5 on the f32 array
-        const float a = sa.actions[env * hp.act_dim + hub_slot];
-        const bool act_on = __fdiv_rn(__fadd_rn(a, 1.0f), 2.0f) >= 0.5f;
-        // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373)
-        const float em = car ? emergency_of(t_target, t_soc, tl) : 0.0f;
-        const bool on = car && (act_on || (double) em >= 1.01);
-        if (on) {  // car_step (CHS.hpp:900-905 / 1065-1070)
-            const float tt = __fadd_rn(t_soc, 1.0f);
-            soc_new = time_to_soc<TYPE>(tt, cp, cc);
-            power = time_to_power<TYPE>(tt, cp);
-            t_soc = soc_to_time<TYPE>(soc_new, cp);
-            soc_dirty = true;
-        }
-        if (car) {  // remove_car (CHS.hpp:912-923 / 1077-1088)
-            tl -= 1;
-            if (tl <= 0) {
-                car = false;
-                leave = true;
-                tl = 0;
-                power = 0.0f;
-                t_target = 0.0f;
-                t_soc = 0.0f;
-            }
-        }
-        charge = on && car;
-    }
+    SlotRegs r;
+    r.power = r.t_target = r.t_soc = r.soc_new = 0.0f;
+    r.tl = 0;
+    r.car = r.charge = r.soc_dirty = r.leave = false;
+    if (!RESET && valid) slot_advance<TYPE>(hp, sa, sl, r, idx, env, hub_slot, cp);
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): arrivals, renege, balk, admission
-    const bool empty = valid && !car;
+    const bool empty = valid && !r.car;
     const uint64_t be = __ballot(empty) & unit_mask;
     const int empties = __popcll(be);
     const int rank = __popcll(be & ((1ull << lane) - 1ull));
     int line = (!RESET && unit_ok) ? (int) st.line[sidx] : 0;
     int flow = 0, assign = 0;
     const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
-
-    float adm_soc = 0.0f;
-    int adm_lev = 0, adm_late = 0;
+    NewCar nc;
+    nc.soc = nc.target = nc.t_target = nc.t_soc = nc.power = 0.0f;
+    nc.stay = 0;
+    bool adm = false;
 
     if (MODE == MODE_PHILOX) {
         PhiloxCtx px{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env)};
-        if (unit_ok) {
-            U4 w0 = px.block(SITE_ARRIVE, (uint32_t) k, 0);
-            int n_in;
-            if (RESET) {  // init_station_car_number(mu, 3), CHS.hpp:832-842
-                const float cn = (float) (px.normal(SITE_INIT, (uint32_t) k) * 1.0 + (double) mu);
-                int temp = (int) roundf(cn);
-                temp = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
-                n_in = temp;
-            } else {
-                n_in = (int) tb.cnt[k][sa.t * kLevels + (int) (w0.v[0] % 1000u)];
-            }
-            if (line > 0) {  // queued car w stays iff u > 0.1*logf(w+1)
-                int tline = 0;
-                U4 b = w0;
-                for (int w = 0; w < line; w++) {
-                    if ((w & 3) == 0) b = px.block(SITE_RENEGE, (uint32_t) k, (uint32_t) (w >> 2));
-                    tline += ((int) (pick(b, w & 3) % 1000u) >= (int) tb.thr_renege[w]) ? 1 : 0;
-                }
-                line = tline;
-            }
-            int true_in = 0;
-            {
-                U4 b = w0;
+        if (unit_ok && !(hp.ablate & 4)) {
+            if (RESET) {
+                // evs_reset: initial occupancy init_station_car_number(mu, 3) (CHS.hpp:832-842), thinned by the balk test
+                U4 b = px.block(SITE_ARRIVE, (uint32_t) k, 0);
+                const float cn = __fadd_rn(normal_from_word(tb.normal_icdf, tb.normal_tail,
+                                                            px.block(SITE_INIT, (uint32_t) k, 0).v[0]), (float) mu);
+                int n_in = (int) roundf(cn);
+                n_in = n_in > mu + 3 ? mu + 3 : (n_in < mu - 3 ? mu - 3 : n_in);
+                int true_in = 0;
                 for (int j = 0; j < n_in; j++) {  // arrival j stays iff u <= expf(-0.01*(line+j)) and j <= S
                     const int wi = 1 + j;
                     if ((wi & 3) == 0) b = px.block(SITE_ARRIVE, (uint32_t) k, (uint32_t) (wi >> 2));
-                    const int m = line + j;
-                    const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
+                    const int thr = (int) tb.thr_balk[j < kBalkTab ? j : kBalkTab - 1];
                     true_in += ((int) (pick(b, wi & 3) % 1000u) <= thr && j <= S) ? 1 : 0;
                 }
+                flow = (TYPE == 0) ? n_in : true_in;
+            } else {
+                // arrivals, renege and balk of this step were drawn ahead by the previous k_env (lane = env)
+                line = (int) st.line_r[sidx];
+                flow = (int) st.flow_next[sidx];
             }
-            flow = (TYPE == 0) ? n_in : true_in;  // fast records the raw count (CHS.hpp:1617), slow the thinned one (1306)
             assign = (line + flow) < empties ? (line + flow) : empties;  // assign_car, CHS.hpp:417-430
             line = line + flow - assign;
             line = line < kMaxLine ? line : kMaxLine;
         }
-        if (empty && rank < assign) {  // add_car draws, CHS.hpp:864-869 / 1029-1034
-            adm_soc = arrive_soc_from(px.normal(SITE_SOC, (uint32_t) hub_slot) * 3.0 + 7.0);
-            adm_lev = (int) (px.block(SITE_TGT, (uint32_t) hub_slot, 0).v[0] % 1000u);
-            const float cn = (float) (px.normal(SITE_LATE, (uint32_t) hub_slot) * 2.0 + 2.0);
-            adm_late = (int) roundf(cn);
-            adm_late = adm_late < 0 ? 0 : adm_late;
+        if (hp.ablate & 1) assign = 0;
+        adm = empty && rank < assign;
+        // ---- add_car for the admitted slots, compacted over the workgroup: the few admitted lanes of all the
+        // block's units queue up in LDS and are served densely (one lane per new car), instead of every wave
+        // running the whole arrival path for its one or two new cars.
+        uint32_t *q_cnt = lds_u;            // [1]
+        uint32_t *q_item = lds_u + 1;       // [BLOCK]  tid of the admitted lane
+        float *o_soc = lds_f;               // [BLOCK] each, indexed by the admitted lane's tid
+        float *o_target = lds_f + BLOCK;
+        float *o_tt = lds_f + 2 * BLOCK;
+        float *o_ts = lds_f + 3 * BLOCK;
+        float *o_pw = lds_f + 4 * BLOCK;
+        uint32_t *o_stay = lds_u + 1 + BLOCK;  // [BLOCK]
+        if (tid == 0) *q_cnt = 0;
+        __syncthreads();
+        {
+            const uint64_t ba = __ballot(adm);
+            const int na = __popcll(ba);
+            uint32_t base = 0;
+            if (lane == 0 && na) base = atomicAdd(q_cnt, (uint32_t) na);
+            base = __shfl(base, 0);
+            if (adm) q_item[base + __popcll(ba & ((1ull << lane) - 1ull))] = (uint32_t) tid;
+        }
+        __syncthreads();
+        const uint32_t n_adm = *q_cnt;
+        for (uint32_t i = tid; i < n_adm; i += BLOCK) {
+            const int src = (int) q_item[i];
+            const int s_lane = src & 63, s_wave = src >> 6;
+            const int64_t s_env = block_local * (int64_t) (WAVES * upw) + s_wave * upw + s_lane / H;
+            const int s_hub_slot = (k ? hp.S[0] : 0) + (s_lane & (H - 1));
+            PhiloxCtx p2{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + s_env)};
+            const U4 o = p2.block(SITE_SOC, (uint32_t) s_hub_slot, 0);  // word 0 SoC, 1 target level, 2 extra stay
+            const float arrive = soc_from_word(tb.soc_d_icdf, o.v[0]);
+            const int lev = (int) (o.v[1] % 1000u);
+            const int late = late_from_word(tb.late_thr, o.v[2]);
+            const NewCar c = make_car<TYPE>(arrive, uniform_level(lev, 80.0f, 100.0f), tb.ttab[k][lev], late, cp);
+            o_soc[src] = c.soc;
+            o_target[src] = c.target;
+            o_tt[src] = c.t_target;
+            o_ts[src] = c.t_soc;
+            o_pw[src] = c.power;
+            o_stay[src] = (uint32_t) c.stay;
+        }
+        __syncthreads();
+        if (adm) {
+            nc.soc = o_soc[tid];
+            nc.target = o_target[tid];
+            nc.t_target = o_tt[tid];
+            nc.t_soc = o_ts[tid];
+            nc.power = o_pw[tid];
+            nc.stay = (int) o_stay[tid];
         }
     } else {
         // COMPAT: the unit's first lane walks the two reference streams in the reference's order and
         // parks the per-admission variates in LDS, indexed by admission rank.
+        float *lds_soc = lds_f;
+        uint32_t *lds_lev = lds_u, *lds_late = lds_u + BLOCK;
         const int lbase = wave * 64 + uiw * H;
         int2 fa = make_int2(0, 0);
         int new_line = line;
@@ -312,11 +400,11 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
             int as = (new_line + fl) < empties ? (new_line + fl) : empties;
             new_line = new_line + fl - as;
             new_line = new_line < kMaxLine ? new_line : kMaxLine;
-            for (int r = 0; r < as; r++) {  // ascending slot order == ascending rank
-                lds_soc[lbase + r] = arrive_soc_from(rs.normal_d(7.0, 3.0));
-                lds_lev[lbase + r] = (uint16_t) rs.level();
+            for (int rr = 0; rr < as; rr++) {  // ascending slot order == ascending rank
+                lds_soc[lbase + rr] = arrive_soc_from(rs.normal_d(7.0, 3.0));
+                lds_lev[lbase + rr] = (uint32_t) rs.level();
                 int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
-                lds_late[lbase + r] = (uint8_t) (late < 0 ? 0 : (late > 255 ? 255 : late));
+                lds_late[lbase + rr] = (uint32_t) (late < 0 ? 0 : late);
             }
             rs.store(cr, env);
             fa = make_int2(fl, as);
@@ -328,34 +416,29 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (empty && rank < assign) {
-            adm_soc = lds_soc[lbase + rank];
-            adm_lev = (int) lds_lev[lbase + rank];
-            adm_late = (int) lds_late[lbase + rank];
+        adm = empty && rank < assign;
+        if (adm) {
+            const int lev = (int) lds_lev[lbase + rank];
+            const float target = uniform_level(lev, 80.0f, 100.0f);
+            nc = make_car<TYPE>(lds_soc[lbase + rank], target, soc_to_time<TYPE>(target, cp), (int) lds_late[lbase + rank], cp);
         }
     }
 
-    const bool adm = empty && rank < assign;
-    float target = 0.0f;
-    int stay = 0;
-    if (adm) {  // add_car, CHS.hpp:864-877 / 1029-1042
-        target = uniform_level(adm_lev, 80.0f, 100.0f);
-        t_target = soc_to_time<TYPE>(target, cp);
-        t_soc = soc_to_time<TYPE>(adm_soc, cp);
-        const float need = __fsub_rn(t_target, t_soc);
-        stay = (int) ceilf(need) + adm_late;
-        stay = stay > 127 ? 127 : stay;
-        tl = stay;
-        power = time_to_power<TYPE>(t_soc, cp);
-        car = tl > 0;
+    if (adm) {
+        r.t_target = nc.t_target;
+        r.t_soc = nc.t_soc;
+        r.tl = nc.stay;
+        r.power = nc.power;
+        r.car = r.tl > 0;
     }
 
     // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572)
-    const float em2 = car ? emergency_of(t_target, t_soc, tl) : 0.0f;
+    const float em2 = r.car ? emergency_of(r.t_target, r.t_soc, r.tl) : 0.0f;
     float r_min, r_max, r_chg;
     if (MODE == MODE_COMPAT) {
         // the reference adds slot powers sequentially in f32 (CHS.hpp:1244-1255): same order, same roundings
-        const float v_min = (car && em2 > 8.0f) ? power : 0.0f, v_max = car ? power : 0.0f, v_chg = charge ? power : 0.0f;
+        const float v_min = (r.car && em2 > 8.0f) ? r.power : 0.0f, v_max = r.car ? r.power : 0.0f;
+        const float v_chg = r.charge ? r.power : 0.0f;
         const int ubase = uiw * H;
         r_min = r_max = r_chg = 0.0f;
         for (int i = 0; i < S; i++) {
@@ -365,9 +448,9 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         }
     } else {
         // production: f64 butterfly == the exact sum, rounded once to f32
-        double s_min = (car && em2 > 8.0f) ? (double) power : 0.0;
-        double s_max = car ? (double) power : 0.0;
-        double s_chg = charge ? (double) power : 0.0;
+        double s_min = (r.car && em2 > 8.0f) ? (double) r.power : 0.0;
+        double s_max = r.car ? (double) r.power : 0.0;
+        double s_chg = r.charge ? (double) r.power : 0.0;
         for (int off = H >> 1; off > 0; off >>= 1) {
             s_min += __shfl_xor(s_min, off);
             s_max += __shfl_xor(s_max, off);
@@ -377,20 +460,20 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         r_max = (float) s_max;
         r_chg = (float) s_chg;
     }
-    const int cars = __popcll(__ballot(car) & unit_mask);
+    const int cars = __popcll(__ballot(r.car) & unit_mask);
 
     if (valid) {
-        sl.power[idx] = power;
-        sl.t_soc[idx] = t_soc;
-        sl.tl[idx] = (uint8_t) (tl | (charge ? 128 : 0));
-        if (adm || leave || RESET) {
-            sl.t_target[idx] = t_target;
-            sl.target[idx] = adm ? target : 0.0f;
-            sl.init_soc[idx] = adm ? adm_soc : 0.0f;
-            sl.stay[idx] = (uint8_t) (adm ? stay : 0);
-            sl.soc[idx] = adm ? adm_soc : 0.0f;
-        } else if (soc_dirty) {
-            sl.soc[idx] = soc_new;
+        sl.power[idx] = r.power;
+        sl.t_soc[idx] = r.t_soc;
+        sl.tl[idx] = (uint8_t) (r.tl | (r.charge ? 128 : 0));
+        if (adm || r.leave || RESET) {
+            sl.t_target[idx] = r.t_target;
+            sl.target[idx] = adm ? nc.target : 0.0f;
+            sl.init_soc[idx] = adm ? nc.soc : 0.0f;
+            sl.stay[idx] = (uint8_t) (adm ? nc.stay : 0);
+            sl.soc[idx] = adm ? nc.soc : 0.0f;
+        } else if (r.soc_dirty) {
+            sl.soc[idx] = r.soc_new;
         }
     }
     if (unit_ok && slot == 0) {
@@ -403,12 +486,13 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     }
 }
 
+constexpr int kSlotBlock = 256;
+
 template <bool RESET, int MODE>
-__global__ __launch_bounds__(256) void k_slot(HubParams hp, StepArgs sa, SlotArrays sl, StationArrays st, CompatRng cr,
-                                              Tables tb, int64_t nb0) {
-    __shared__ float lds_soc[MODE == MODE_COMPAT ? 256 : 1];
-    __shared__ uint16_t lds_lev[MODE == MODE_COMPAT ? 256 : 1];
-    __shared__ uint8_t lds_late[MODE == MODE_COMPAT ? 256 : 1];
+__global__ __launch_bounds__(kSlotBlock) void k_slot(HubParams hp, StepArgs sa, SlotArrays sl, StationArrays st,
+                                                     CompatRng cr, Tables tb, int64_t nb0) {
+    __shared__ float lds_f[5 * kSlotBlock];
+    __shared__ uint32_t lds_u[2 * kSlotBlock + 1];
     int k;
     int64_t bl;
     if (sa.station_filter >= 0) {
@@ -418,8 +502,8 @@ __global__ __launch_bounds__(256) void k_slot(HubParams hp, StepArgs sa, SlotArr
         k = ((int64_t) blockIdx.x >= nb0) ? 1 : 0;
         bl = k ? (int64_t) blockIdx.x - nb0 : (int64_t) blockIdx.x;
     }
-    if (hp.type[k] == 0) slot_body<0, RESET, MODE>(hp, sa, sl, st, cr, tb, k, bl, lds_soc, lds_lev, lds_late);
-    else slot_body<1, RESET, MODE>(hp, sa, sl, st, cr, tb, k, bl, lds_soc, lds_lev, lds_late);
+    if (hp.type[k] == 0) slot_body<0, RESET, MODE, kSlotBlock>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
+    else slot_body<1, RESET, MODE, kSlotBlock>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
 }
 
 // ----------------------------------------------------------------------------------------- k_env
@@ -455,20 +539,71 @@ __device__ __forceinline__ double ou_sample(double &state, double theta, double 
     return state;
 }
 
+// PHILOX: the station-level draws of receive_car (CHS.hpp:1272-1303 / 1583-1614) for the step that follows --
+// arrival count from the slot-of-day table, renege pass over the queue, balk pass over the arrivals.  They only
+// depend on the queue length, so one lane per (env, station) draws them here, ahead of the next k_slot, instead
+// of every slot lane of a unit repeating them.
+__device__ __forceinline__ void draw_arrivals_ahead(const HubParams &hp, const Tables &tb, const StationArrays &st,
+                                                    uint32_t tick_next, int t_next, int k, int64_t env, int64_t N) {
+    PhiloxCtx px{hp.key[0], hp.key[1], tick_next, (uint32_t) (hp.env_id0 + env)};
+    const int64_t sidx = (int64_t) k * N + env;
+    const int S = hp.S[k];
+    int line = (int) st.line[sidx];
+    const U4 w0 = px.block(SITE_ARRIVE, (uint32_t) k, 0);
+    const int n_in = (int) tb.cnt[k][t_next * kLevels + (int) (w0.v[0] % 1000u)];
+    if (line > 0) {  // queued car w stays iff u > 0.1*logf(w+1)
+        int tline = 0;
+        U4 b = w0;
+        for (int w = 0; w < line; w++) {
+            if ((w & 3) == 0) b = px.block(SITE_RENEGE, (uint32_t) k, (uint32_t) (w >> 2));
+            tline += ((int) (pick(b, w & 3) % 1000u) >= (int) tb.thr_renege[w]) ? 1 : 0;
+        }
+        line = tline;
+    }
+    int true_in = 0;
+    U4 b = w0;
+    for (int j = 0; j < n_in; j++) {  // arrival j stays iff u <= expf(-0.01*(line+j)) and j <= S
+        const int wi = 1 + j;
+        if ((wi & 3) == 0) b = px.block(SITE_ARRIVE, (uint32_t) k, (uint32_t) (wi >> 2));
+        const int m = line + j;
+        const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
+        true_in += ((int) (pick(b, wi & 3) % 1000u) <= thr && j <= S) ? 1 : 0;
+    }
+    // fast records the raw count (CHS.hpp:1617), slow the thinned one (CHS.hpp:1306)
+    st.flow_next[sidx] = (int8_t) (hp.type[k] == 0 ? n_in : true_in);
+    st.line_r[sidx] = (uint8_t) line;
+}
+
+#define CHUB_TEL(i, v)                                        \
+    do {                                                      \
+        if (hp.telemetry) ev.telem[(int64_t) (i) * N + env] = (v); \
+    } while (0)
+
+// Blocks [0, nb_env) run the per-env tail (lane = env); in PHILOX mode blocks [nb_env, ...) draw the next step's
+// station arrivals (lane = (station, env)).  The two parts are independent given k_slot's outputs.
 template <bool RESET, int MODE>
 __global__ __launch_bounds__(256) void k_env(HubParams hp, StepArgs sa, StationArrays st, EnvArrays ev, CompatRng cr,
-                                             Tables tb) {
+                                             Tables tb, int nb_env) {
+    const int64_t N = hp.n_envs;
+    const int t_next = RESET ? 0 : (sa.t + 1) % 96;
+    if ((int) blockIdx.x >= nb_env) {
+        const int64_t u = (int64_t) (blockIdx.x - nb_env) * blockDim.x + threadIdx.x;
+        if (u < 2 * N) {
+            const int k = u >= N ? 1 : 0;
+            draw_arrivals_ahead(hp, tb, st, sa.tick + 1u, t_next, k, u - (int64_t) k * N, N);
+        }
+        return;
+    }
     __shared__ double s_pv[100], s_wd[150], s_hy[102];
     __shared__ uint8_t s_hv[kLevels];
-    const int t_next = RESET ? 0 : (sa.t + 1) % 96;
     for (int i = threadIdx.x; i < 100; i += blockDim.x) s_pv[i] = tb.pvT[t_next * 100 + i];
     for (int i = threadIdx.x; i < 150; i += blockDim.x) s_wd[i] = tb.wdT[t_next * 150 + i];
-    for (int i = threadIdx.x; i < 102; i += blockDim.x) s_hy[i] = tb.hy_table[i];
-    if (!RESET)
+    if (!RESET) {
+        for (int i = threadIdx.x; i < 102; i += blockDim.x) s_hy[i] = tb.hy_table[i];
         for (int i = threadIdx.x; i < kLevels; i += blockDim.x) s_hv[i] = tb.cnt_hv[sa.t * kLevels + i];
+    }
     __syncthreads();
 
-    const int64_t N = hp.n_envs;
     const int64_t env = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= N) return;
     PhiloxCtx px{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env)};
@@ -476,21 +611,16 @@ __global__ __launch_bounds__(256) void k_env(HubParams hp, StepArgs sa, StationA
     if (MODE == MODE_COMPAT && !RESET) rs.load(cr, env);
 
     const double cap_mass = hp.cap_mass;
-    double cap = ev.cap[env];
-    double store_soc = ev.store_soc[env];
-    double reward = 0.0;
-    double tel[kTelemCount];
-    if (hp.telemetry)
-        for (int i = 0; i < kTelemCount; i++) tel[i] = 0.0;
+    double cap, store_soc, reward = 0.0;
+    int pv_day, wd_day;
 
     if (RESET) {
         // renew_reset (REN:51-53) + hy_reset (HYD:197-208)
-        int pv_day, wd_day;
         if (MODE == MODE_COMPAT) {
             pv_day = sa.exo_days[env * 2 + 0];
             wd_day = sa.exo_days[env * 2 + 1];
         } else {
-            U4 o = px.block(SITE_DAY, 0, 0);
+            const U4 o = px.block(SITE_DAY, 0, 0);
             pv_day = (int) (o.v[0] % 100u);
             wd_day = (int) (o.v[1] % 150u);
         }
@@ -500,7 +630,11 @@ __global__ __launch_bounds__(256) void k_env(HubParams hp, StepArgs sa, StationA
         ev.hv_line[env] = 0;
         cap = hp.init_soc * cap_mass;
         store_soc = hp.init_soc;
+        CHUB_TEL(4, cap);
     } else {
+        pv_day = ev.pv_day[env];
+        wd_day = ev.wd_day[env];
+        cap = ev.cap[env];
         const int S = hp.S[0] + hp.S[1];
         const float *act = sa.actions + env * hp.act_dim;
         const double a_el = ((double) act[S] + 1) / 2;      // action_real[-1] <- action[-2]  (MGR:400-403)
@@ -529,56 +663,61 @@ __global__ __launch_bounds__(256) void k_env(HubParams hp, StepArgs sa, StationA
         if (MODE == MODE_COMPAT) lev = rs.level();
         else lev = (int) (px.block(SITE_HV, 0, 0).v[0] % 1000u);
         const int arrive = (int) s_hv[lev];
-        double total_time = 0.0, total_mass = 0.0;
-        for (int i = 0; i < q_len; i++) {
-            total_time += qt[i];
-            total_mass += qm[i];
-        }
-        for (int j = 0; j < arrive; j++) {
-            float socf;
-            if (MODE == MODE_COMPAT) socf = arrive_soc_from(rs.normal_d(7.0, 3.0));
-            else socf = arrive_soc_from(px.normal(SITE_HVSOC, (uint32_t) j) * 3.0 + 7.0);
-            double soc = (double) socf;
-            if (soc < 0.5) soc = 0.5;
-            const double p0 = (soc * 0.01) * 70;
-            double tn, mn;
-            j2601_time_mass(p0, tn, mn);
-            if (q_len < kQCap) {
-                qt[q_len] = tn;
-                qm[q_len] = mn;
-                q_len++;
-                total_time += tn;
-                total_mass += mn;
-            } else {
-                ev.q_overflow[env] = 1;
+        double total_mass = 0.0;
+        if (q_len > 0 || arrive > 0) {
+            double total_time = 0.0;
+            for (int i = 0; i < q_len; i++) {
+                total_time += qt[i];
+                total_mass += qm[i];
             }
-        }
-        int hv_num = 0;
-        if (total_time > 15.0) {
-            for (int i = 1; i <= arrive - 1; i++) {
-                int keep = q_len - i;
-                keep = keep < 0 ? 0 : keep;
-                double part = 0.0;
-                for (int j = 0; j < keep; j++) part += qt[j];
-                if (part <= 15.0) {
-                    hv_line = i;
-                    hv_num = keep;
-                    break;
+            for (int j = 0; j < arrive; j++) {
+                float socf;
+                if (MODE == MODE_COMPAT) socf = arrive_soc_from(rs.normal_d(7.0, 3.0));
+                else socf = soc_from_word(tb.soc_d_icdf, px.block(SITE_HVSOC, (uint32_t) j, 0).v[0]);
+                double soc = (double) socf;
+                if (soc < 0.5) soc = 0.5;
+                const double p0 = (soc * 0.01) * 70;
+                double tn, mn;
+                j2601_time_mass(p0, tn, mn);
+                if (q_len < kQCap) {
+                    qt[q_len] = tn;
+                    qm[q_len] = mn;
+                    q_len++;
+                    total_time += tn;
+                    total_mass += mn;
+                } else {
+                    ev.q_overflow[env] = 1;
                 }
             }
-            for (int j = hv_num; j < q_len; j++) {
-                qt[j - hv_num] = qt[j];
-                qm[j - hv_num] = qm[j];
+            int hv_num = 0;
+            if (total_time > 15.0) {
+                for (int i = 1; i <= arrive - 1; i++) {
+                    int keep = q_len - i;
+                    keep = keep < 0 ? 0 : keep;
+                    double part = 0.0;
+                    for (int j = 0; j < keep; j++) part += qt[j];
+                    if (part <= 15.0) {
+                        hv_line = i;
+                        hv_num = keep;
+                        break;
+                    }
+                }
+                for (int j = hv_num; j < q_len; j++) {
+                    qt[j - hv_num] = qt[j];
+                    qm[j - hv_num] = qm[j];
+                }
+                q_len -= hv_num;
+            } else {
+                hv_line = 0;
+                q_len = 0;
             }
-            q_len -= hv_num;
-        } else {
+            ev.q_len[env] = (uint8_t) q_len;
+            ev.hv_line[env] = (uint8_t) hv_line;
+        } else if (hv_line != 0) {
+            ev.hv_line[env] = 0;  // empty FIFO, no arrivals: total time 0 <= 15 -> line = 0 (HYD:281-283)
             hv_line = 0;
-            hv_num = q_len;
-            q_len = 0;
         }
         const double total_mass_need = total_mass;
-        ev.q_len[env] = (uint8_t) q_len;
-        ev.hv_line[env] = (uint8_t) hv_line;
         // ---- hy_step (HYD:160-195): production clamp, electrolyser + compressor power, tank
         double must_charge = cap_mass * 0.1 - cap;
         must_charge = must_charge > 0 ? must_charge : 0.0;
@@ -639,7 +778,8 @@ __global__ __launch_bounds__(256) void k_env(HubParams hp, StepArgs sa, StationA
             hydrogen_power -= re_new_power;
             used_renew = re_new_power;
         }
-        const double re_ev0 = e0, re_ev1 = e1;
+        CHUB_TEL(11, e0);  // self.re_ev_power_list is taken before the fuel-cell rescale (MGR:212)
+        CHUB_TEL(12, e1);
         // ---- fuel cell (MGR:215-227, HFC.use_cell HYD:409-430)
         double fc_power = gen_hy ? 0.0 : hp.fc_max_power * a_fc;
         if (fc_power > hp.fc_max_power) fc_power = hp.fc_max_power;
@@ -670,81 +810,90 @@ __global__ __launch_bounds__(256) void k_env(HubParams hp, StepArgs sa, StationA
         const double hy_cost = -real_price_dollar * hydrogen_power;
         reward = (income_hys + income_evs + income_evs_serve + hy_cost + 1 * hy_loss + not_meet_loss) / 50;
         if (hp.telemetry) {
-            tel[0] = act_el; tel[1] = flow; tel[2] = all_power_second; tel[3] = store_soc; tel[4] = cap;
-            tel[5] = total_mass_need; tel[6] = hy_use; tel[7] = not_meet; tel[8] = fc_power; tel[9] = hy_to_use;
-            tel[10] = used_renew; tel[11] = re_ev0; tel[12] = re_ev1; tel[13] = hydrogen_power;
-            tel[14] = income_hys + income_evs + income_evs_serve + hy_cost; tel[15] = reward;
-            tel[19] = (double) arrive; tel[20] = (double) hv_line; tel[21] = (double) q_len;
+            CHUB_TEL(0, act_el); CHUB_TEL(1, flow); CHUB_TEL(2, all_power_second); CHUB_TEL(4, cap);
+            CHUB_TEL(5, total_mass_need); CHUB_TEL(6, hy_use); CHUB_TEL(7, not_meet); CHUB_TEL(8, fc_power);
+            CHUB_TEL(9, hy_to_use); CHUB_TEL(10, used_renew); CHUB_TEL(13, hydrogen_power);
+            CHUB_TEL(14, income_hys + income_evs + income_evs_serve + hy_cost); CHUB_TEL(15, reward);
+            CHUB_TEL(19, (double) arrive); CHUB_TEL(20, (double) hv_line); CHUB_TEL(21, (double) q_len);
         }
     }
 
     // ---- make_state (MGR:344-373): exogenous update for the NEXT slot, then the observation
-    const int pv_day = ev.pv_day[env], wd_day = ev.wd_day[env];
     double ou_pv = ev.ou[env], ou_wd = ev.ou[N + env], ou_price = ev.ou[2 * N + env];
+    U4 ow;
+    ow.v[0] = ow.v[1] = ow.v[2] = ow.v[3] = 0u;
+    if (MODE == MODE_PHILOX) ow = px.block(SITE_OU, 0, 0);  // word 0 pv, 1 wind, 2 price
     double temp = s_pv[pv_day];
     if (temp > 0 && (pv_day % 2) == 0) {  // REN:38-43
-        const double z = (MODE == MODE_COMPAT) ? sa.exo_z[env * 3 + 0] : px.normal(SITE_OU, 0);
+        const double z = (MODE == MODE_COMPAT) ? sa.exo_z[env * 3 + 0]
+                                               : (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[0]);
         temp += ou_sample(ou_pv, .01, 1., z) * hp.renew_fluct1;
+        ev.ou[env] = ou_pv;
     }
     const double re_pv = (temp > 0 ? temp : 0.0) * 5;
     temp = s_wd[wd_day];
     {  // REN:45-49
-        const double z = (MODE == MODE_COMPAT) ? sa.exo_z[env * 3 + 1] : px.normal(SITE_OU, 1);
+        const double z = (MODE == MODE_COMPAT) ? sa.exo_z[env * 3 + 1]
+                                               : (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[1]);
         temp += ou_sample(ou_wd, .01, 1.5, z) * hp.renew_fluct1;
+        ev.ou[N + env] = ou_wd;
     }
     const double re_wd = (temp > 0 ? temp : 0.0) * 1;
     double price_next;
     if (sa.draw_price) {  // MGR:354-357
-        const double z = (MODE == MODE_COMPAT) ? sa.exo_z[env * 3 + 2] : px.normal(SITE_OU, 2);
+        const double z = (MODE == MODE_COMPAT) ? sa.exo_z[env * 3 + 2]
+                                               : (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[2]);
         price_next = ou_sample(ou_price, .1, 0.005, z) * hp.price_fluct1;
+        ev.ou[2 * N + env] = ou_price;
         ev.price_noise[env] = price_next;
         price_next += sa.price_last;
     } else {
         price_next = sa.price_last + ev.price_noise[env];
     }
-    ev.ou[env] = ou_pv;
-    ev.ou[N + env] = ou_wd;
-    ev.ou[2 * N + env] = ou_price;
     ev.re_pv[env] = re_pv;
     ev.re_wd[env] = re_wd;
     ev.price_next[env] = price_next;
     ev.cap[env] = cap;
-    ev.store_soc[env] = store_soc;
     if (MODE == MODE_COMPAT && !RESET) rs.store(cr, env);
 
-    // state_norm (MGR:318-342)
-    double o[16];
+    // state_norm (MGR:318-342), written straight to the output row
+    float *obs = sa.obs + env * sa.obs_stride;
+    double *o64 = hp.telemetry ? ev.obs64 + env * hp.obs_dim : nullptr;
     int n = 0;
-    const double kk = 2 * 3.14159265358979323846 / 96;
-    o[n++] = sin(kk * (double) t_next);
-    o[n++] = (price_next - hp.price_mean) / hp.price_std;
+#define CHUB_OBS(v)                    \
+    do {                               \
+        const double v_ = (v);         \
+        obs[n] = (float) v_;           \
+        if (o64) o64[n] = v_;          \
+        n++;                           \
+    } while (0)
+    CHUB_OBS(tb.sin96[t_next]);
+    CHUB_OBS((price_next - hp.price_mean) / hp.price_std);
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         if (hp.S[k] > 0) {
             const int64_t si = (int64_t) k * N + env;
             const double half_range = (double) hp.transformer_limit[k] / 2;
-            o[n++] = ((double) st.min_p[si] - half_range) / half_range;
-            o[n++] = ((double) st.chg_p[si] - half_range) / half_range;
-            o[n++] = ((double) st.max_p[si] - half_range) / half_range;
-            o[n++] = (double) st.line[si] / 5;
+            CHUB_OBS(((double) st.min_p[si] - half_range) / half_range);
+            CHUB_OBS(((double) st.chg_p[si] - half_range) / half_range);
+            CHUB_OBS(((double) st.max_p[si] - half_range) / half_range);
+            CHUB_OBS((double) st.line[si] / 5);
         }
     }
-    o[n++] = store_soc;
-    o[n++] = re_pv / (42 * 5);
-    o[n++] = re_wd / (92 * 1);
-    float *obs = sa.obs + env * hp.obs_dim;
-    for (int i = 0; i < n; i++) obs[i] = (float) o[i];
+    CHUB_OBS(store_soc);
+    CHUB_OBS(re_pv / (42 * 5));
+    CHUB_OBS(re_wd / (92 * 1));
+#undef CHUB_OBS
     if (!RESET) {
-        sa.reward[env] = (float) reward;
-        sa.done[env] = (uint8_t) ((sa.t + 1) >= 96 ? 1 : 0);
+        const bool dn = (sa.t + 1) >= 96;  // MGR:271-273
+        sa.reward[env * sa.reward_stride] = (float) reward;
+        if (sa.done) sa.done[env] = (uint8_t) (dn ? 1 : 0);
+        if (sa.done_f32) sa.done_f32[env * sa.reward_stride] = dn ? 1.0f : 0.0f;
     }
     if (hp.telemetry) {
-        for (int i = 0; i < n; i++) ev.obs64[env * hp.obs_dim + i] = o[i];
         ev.reward64[env] = reward;
-        tel[3] = store_soc; tel[16] = re_pv; tel[17] = re_wd; tel[18] = price_next;
-        tel[22] = (double) pv_day; tel[23] = (double) wd_day;
-        if (RESET) tel[4] = cap;
-        for (int i = 0; i < kTelemCount; i++) ev.telem[(int64_t) i * N + env] = tel[i];
+        CHUB_TEL(3, store_soc); CHUB_TEL(16, re_pv); CHUB_TEL(17, re_wd); CHUB_TEL(18, price_next);
+        CHUB_TEL(22, (double) pv_day); CHUB_TEL(23, (double) wd_day);
     }
 }
 
@@ -766,35 +915,39 @@ __global__ void k_random_actions(int64_t n_envs, int64_t env_id0, int act_dim, u
 }
 
 // ------------------------------------------------------------------------------------- launchers
-static inline int64_t blocks_for(int64_t n_envs, int H) { return (n_envs + (4 * (64 / H)) - 1) / (4 * (64 / H)); }
+static inline int64_t blocks_for(int64_t n_envs, int H) {
+    const int64_t upb = (int64_t) (kSlotBlock / 64) * (64 / H);
+    return (n_envs + upb - 1) / upb;
+}
 
 void launch_slot(bool reset, const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
                  const CompatRng &cr, const Tables &tb, hipStream_t stream) {
     const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0]), nb1 = blocks_for(hp.n_envs, hp.H[1]);
     if (hp.rng_mode == MODE_PHILOX) {
         const int64_t nb = nb0 + nb1;
-        if (reset) hipLaunchKernelGGL((k_slot<true, MODE_PHILOX>), dim3((unsigned) nb), dim3(256), 0, stream, hp, sa, sl, st, cr, tb, nb0);
-        else hipLaunchKernelGGL((k_slot<false, MODE_PHILOX>), dim3((unsigned) nb), dim3(256), 0, stream, hp, sa, sl, st, cr, tb, nb0);
+        if (reset) hipLaunchKernelGGL((k_slot<true, MODE_PHILOX>), dim3((unsigned) nb), dim3(kSlotBlock), 0, stream, hp, sa, sl, st, cr, tb, nb0);
+        else hipLaunchKernelGGL((k_slot<false, MODE_PHILOX>), dim3((unsigned) nb), dim3(kSlotBlock), 0, stream, hp, sa, sl, st, cr, tb, nb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
             StepArgs s2 = sa;
             s2.station_filter = k;
             const int64_t nb = k ? nb1 : nb0;
-            if (reset) hipLaunchKernelGGL((k_slot<true, MODE_COMPAT>), dim3((unsigned) nb), dim3(256), 0, stream, hp, s2, sl, st, cr, tb, nb0);
-            else hipLaunchKernelGGL((k_slot<false, MODE_COMPAT>), dim3((unsigned) nb), dim3(256), 0, stream, hp, s2, sl, st, cr, tb, nb0);
+            if (reset) hipLaunchKernelGGL((k_slot<true, MODE_COMPAT>), dim3((unsigned) nb), dim3(kSlotBlock), 0, stream, hp, s2, sl, st, cr, tb, nb0);
+            else hipLaunchKernelGGL((k_slot<false, MODE_COMPAT>), dim3((unsigned) nb), dim3(kSlotBlock), 0, stream, hp, s2, sl, st, cr, tb, nb0);
         }
     }
 }
 
 void launch_env(bool reset, const HubParams &hp, const StepArgs &sa, const StationArrays &st, const EnvArrays &ev,
                 const CompatRng &cr, const Tables &tb, hipStream_t stream) {
-    const unsigned nb = (unsigned) ((hp.n_envs + 255) / 256);
+    const int nb_env = (int) ((hp.n_envs + 255) / 256);
     if (hp.rng_mode == MODE_PHILOX) {
-        if (reset) hipLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(256), 0, stream, hp, sa, st, ev, cr, tb);
-        else hipLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(256), 0, stream, hp, sa, st, ev, cr, tb);
+        const unsigned nb = (unsigned) (nb_env + (2 * hp.n_envs + 255) / 256);  // + the arrival-draw blocks
+        if (reset) hipLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(256), 0, stream, hp, sa, st, ev, cr, tb, nb_env);
+        else hipLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(256), 0, stream, hp, sa, st, ev, cr, tb, nb_env);
     } else {
-        if (reset) hipLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3(nb), dim3(256), 0, stream, hp, sa, st, ev, cr, tb);
-        else hipLaunchKernelGGL((k_env<false, MODE_COMPAT>), dim3(nb), dim3(256), 0, stream, hp, sa, st, ev, cr, tb);
+        if (reset) hipLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(256), 0, stream, hp, sa, st, ev, cr, tb, nb_env);
+        else hipLaunchKernelGGL((k_env<false, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(256), 0, stream, hp, sa, st, ev, cr, tb, nb_env);
     }
 }
 

@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -60,6 +61,10 @@ struct chub_env {
     double *d_exo_z;
     int32_t *d_exo_days;
     hipStream_t stream;
+    // optional per-kernel timing with HIP events on the launch stream (chub_profile_*)
+    std::vector<hipEvent_t> prof_events;
+    size_t prof_used, prof_cap;
+    bool prof_on;
 };
 
 // ------------------------------------------------------------------------------- data loading
@@ -254,6 +259,8 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     e->price_count = 0;
     e->tick = 0;
     e->stream = nullptr;
+    e->prof_used = e->prof_cap = 0;
+    e->prof_on = false;
     auto bail = [&](int rc) {
         chub_destroy(e);
         return rc;
@@ -290,6 +297,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     hp.constant_charging = cfg->constant_charging ? 1 : 0;
     hp.rng_mode = rng_mode;
     hp.telemetry = 0;
+    hp.ablate = getenv("CHUB_ABLATE") ? atoi(getenv("CHUB_ABLATE")) : 0;
     hp.key[0] = (uint32_t) seed;
     hp.key[1] = (uint32_t) (seed >> 32);
     hp.cc = make_curve_consts();
@@ -380,6 +388,50 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
         for (int t = 0; t < 96; t++) pvT[t * 100 + d] = pv[d * 96 + t];
     for (int d = 0; d < 150; d++)
         for (int t = 0; t < 96; t++) wdT[t * 150 + d] = wd[d * 96 + t];
+    // PHILOX-mode sampling tables + the 1000 possible target SoCs already mapped through each station's curve
+    std::vector<float> icdf(4097);
+    std::vector<uint32_t> late_thr(16);
+    {
+        FILE *f = fopen((dir + "/soc_d_icdf_4097.f32").c_str(), "rb");
+        if (!f || fread(icdf.data(), 4, 4097, f) != 4097) {
+            if (f) fclose(f);
+            return bail(fail(CHUB_ERR_DATA, "cannot read soc_d_icdf_4097.f32"));
+        }
+        fclose(f);
+        f = fopen((dir + "/late_thr_16.u32").c_str(), "rb");
+        if (!f || fread(late_thr.data(), 4, 16, f) != 16) {
+            if (f) fclose(f);
+            return bail(fail(CHUB_ERR_DATA, "cannot read late_thr_16.u32"));
+        }
+        fclose(f);
+    }
+    std::vector<float> nicdf(4097), ntail(4097);
+    {
+        FILE *f = fopen((dir + "/normal_icdf_4097.f32").c_str(), "rb");
+        if (!f || fread(nicdf.data(), 4, 4097, f) != 4097) {
+            if (f) fclose(f);
+            return bail(fail(CHUB_ERR_DATA, "cannot read normal_icdf_4097.f32"));
+        }
+        fclose(f);
+        f = fopen((dir + "/normal_tail_4097.f32").c_str(), "rb");
+        if (!f || fread(ntail.data(), 4, 4097, f) != 4097) {
+            if (f) fclose(f);
+            return bail(fail(CHUB_ERR_DATA, "cannot read normal_tail_4097.f32"));
+        }
+        fclose(f);
+    }
+    std::vector<double> sin96(96);
+    for (int t = 0; t < 96; t++) sin96[t] = sin((2 * M_PI / 96) * (double) t);  // np.sin(k * time), MGR:319-320
+    std::vector<float> ttab[2];
+    for (int s = 0; s < 2; s++) {
+        ttab[s].resize(kLevels);
+        for (int k = 0; k < kLevels; k++) {
+            float tr = (float) k / 999.0f;
+            float target = tr * (100.0f - 80.0f) + 80.0f;  // uniform_rand(80, 100), CHS.hpp:35-44
+            ttab[s][k] = hp.type[s] == CHUB_FAST ? fast_soc_to_time(target, hp.constant_charging != 0)
+                                                 : slow_soc_to_time(target, hp.constant_charging != 0);
+        }
+    }
     build_hy_table(hp, e->hy_table);
     std::vector<double> hy_v(e->hy_table, e->hy_table + 102);
 
@@ -392,6 +444,13 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     if ((rc = dev_upload(e, &e->tb.pvT, pvT))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.wdT, wdT))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.hy_table, hy_v))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.soc_d_icdf, icdf))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.late_thr, late_thr))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.normal_icdf, nicdf))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.normal_tail, ntail))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.sin96, sin96))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.ttab[0], ttab[0]))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.ttab[1], ttab[1]))) return bail(rc);
 
     // ---- state in HBM
     const size_t N = (size_t) n_envs, NS = N * (size_t) (hp.S[0] + hp.S[1]);
@@ -399,7 +458,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
     ALLOC(e->sl.soc, NS); ALLOC(e->sl.target, NS); ALLOC(e->sl.init_soc, NS); ALLOC(e->sl.power, NS);
     ALLOC(e->sl.t_target, NS); ALLOC(e->sl.t_soc, NS); ALLOC(e->sl.tl, NS); ALLOC(e->sl.stay, NS);
-    ALLOC(e->st.line, 2 * N); ALLOC(e->st.flow_in, 2 * N); ALLOC(e->st.car_number, 2 * N);
+    ALLOC(e->st.line, 2 * N); ALLOC(e->st.line_r, 2 * N); ALLOC(e->st.flow_in, 2 * N); ALLOC(e->st.flow_next, 2 * N); ALLOC(e->st.car_number, 2 * N);
     ALLOC(e->st.min_p, 2 * N); ALLOC(e->st.chg_p, 2 * N); ALLOC(e->st.max_p, 2 * N);
     ALLOC(e->ev.cap, N); ALLOC(e->ev.store_soc, N); ALLOC(e->ev.ou, 3 * N); ALLOC(e->ev.price_noise, N);
     ALLOC(e->ev.re_pv, N); ALLOC(e->ev.re_wd, N); ALLOC(e->ev.price_next, N);
@@ -442,6 +501,7 @@ int chub_destroy(chub_env *e) {
     (void) hipSetDevice(e->device);
     (void) hipDeviceSynchronize();
     for (void *p : e->allocs) (void) hipFree(p);
+    for (hipEvent_t ev : e->prof_events) (void) hipEventDestroy(ev);
     delete e;
     return CHUB_OK;
 }
@@ -475,6 +535,7 @@ int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_ex
     sa.exo_days = d_exo_days;
     sa.exo_z = d_exo_z;
     sa.obs = d_obs;
+    sa.obs_stride = e->hp.obs_dim;
     launch_slot(true, e->hp, sa, e->sl, e->st, e->cr, e->tb, s);
     launch_env(true, e->hp, sa, e->st, e->ev, e->cr, e->tb, s);
     HIP_TRY(hipGetLastError());
@@ -483,9 +544,23 @@ int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_ex
     return CHUB_OK;
 }
 
+static int step_common(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, int obs_stride,
+                       float *d_reward, int reward_stride, uint8_t *d_done, float *d_done_f32, void *stream);
+
 int chub_step_device(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
                      uint8_t *d_done, void *stream) {
     if (!e || !d_actions || !d_obs || !d_reward || !d_done) return fail(CHUB_ERR_ARG, "null argument");
+    return step_common(e, d_actions, d_exo_z, d_obs, e->hp.obs_dim, d_reward, 1, d_done, nullptr, stream);
+}
+
+int chub_step_device_packed(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_packed, void *stream) {
+    if (!e || !d_actions || !d_packed) return fail(CHUB_ERR_ARG, "null argument");
+    const int D = e->hp.obs_dim;
+    return step_common(e, d_actions, d_exo_z, d_packed, D + 2, d_packed + D, D + 2, nullptr, d_packed + D + 1, stream);
+}
+
+static int step_common(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, int obs_stride,
+                       float *d_reward, int reward_stride, uint8_t *d_done, float *d_done_f32, void *stream) {
     if (e->tick == 0) return fail(CHUB_ERR_ARG, "step() before reset()");
     if (e->hp.rng_mode == CHUB_RNG_COMPAT && !d_exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
     HIP_TRY(hipSetDevice(e->device));
@@ -501,10 +576,21 @@ int chub_step_device(chub_env *e, const float *d_actions, const double *d_exo_z,
     sa.actions = d_actions;
     sa.exo_z = d_exo_z;
     sa.obs = d_obs;
+    sa.obs_stride = obs_stride;
     sa.reward = d_reward;
+    sa.reward_stride = reward_stride;
     sa.done = d_done;
+    sa.done_f32 = d_done_f32;
+    const bool prof = e->prof_on && e->prof_used < e->prof_cap;
+    hipEvent_t *pe = prof ? &e->prof_events[3 * e->prof_used] : nullptr;
+    if (prof) HIP_TRY(hipEventRecord(pe[0], s));
     launch_slot(false, e->hp, sa, e->sl, e->st, e->cr, e->tb, s);
+    if (prof) HIP_TRY(hipEventRecord(pe[1], s));
     launch_env(false, e->hp, sa, e->st, e->ev, e->cr, e->tb, s);
+    if (prof) {
+        HIP_TRY(hipEventRecord(pe[2], s));
+        e->prof_used++;
+    }
     HIP_TRY(hipGetLastError());
     e->price_count += 1;
     e->t = (e->t + 1) % 96;
@@ -735,6 +821,39 @@ int chub_get_rng_compat_state(chub_env *e, uint32_t *state) {
         memcpy(&state[i * 33], &g[i * 32], 32 * 4);
         state[i * 33 + 32] = m[i];
     }
+    return CHUB_OK;
+}
+
+int chub_profile_begin(chub_env *e, int max_steps) {
+    if (!e || max_steps <= 0) return fail(CHUB_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    while (e->prof_events.size() < (size_t) max_steps * 3) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        e->prof_events.push_back(ev);
+    }
+    e->prof_cap = (size_t) max_steps;
+    e->prof_used = 0;
+    e->prof_on = true;
+    return CHUB_OK;
+}
+
+int chub_profile_end(chub_env *e, double *slot_ms_sum, double *env_ms_sum, int *n_steps) {
+    if (!e || !slot_ms_sum || !env_ms_sum || !n_steps) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    double a = 0, b = 0;
+    for (size_t i = 0; i < e->prof_used; i++) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e->prof_events[3 * i], e->prof_events[3 * i + 1]));
+        a += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, e->prof_events[3 * i + 1], e->prof_events[3 * i + 2]));
+        b += ms;
+    }
+    *slot_ms_sum = a;
+    *env_ms_sum = b;
+    *n_steps = (int) e->prof_used;
+    e->prof_on = false;
     return CHUB_OK;
 }
 

@@ -89,8 +89,21 @@ class VecChargingHub(object):
     def step_device(self, d_actions, d_obs, d_reward, d_done, d_exo_z=0, stream=0):
         check(self._lib.chub_step_device(self._h, d_actions, d_exo_z or None, d_obs, d_reward, d_done, stream or None))
 
+    def step_device_packed(self, d_actions, d_packed, d_exo_z=0, stream=0):
+        """One [N, D+2] f32 output buffer: obs, reward, done -- what a shard sends in the per-step RCCL gather."""
+        check(self._lib.chub_step_device_packed(self._h, d_actions, d_exo_z or None, d_packed, stream or None))
+
     def random_actions_device(self, d_actions, key, batch, stream=0):
         check(self._lib.chub_random_actions_device(self._h, int(key), int(batch), d_actions, stream or None))
+
+    def profile_begin(self, max_steps):
+        check(self._lib.chub_profile_begin(self._h, int(max_steps)))
+
+    def profile_end(self):
+        """-> (slot kernel ms summed, env kernel ms summed, steps covered)"""
+        a, b, n = C.c_double(), C.c_double(), C.c_int()
+        check(self._lib.chub_profile_end(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
 
     def sync(self):
         check(self._lib.chub_sync(self._h))

@@ -106,12 +106,22 @@ int chub_reset_device(chub_env *env, const int32_t *d_exo_days, const double *d_
 int chub_step_device(chub_env *env, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
                      uint8_t *d_done, void *stream);
 
+/* Packed form for the multi-GPU gather: one [N, D+2] f32 buffer, row = obs[D], reward, done (0.0 / 1.0), so that
+ * a shard's whole step output travels in a single RCCL gather. */
+int chub_step_device_packed(chub_env *env, const float *d_actions, const double *d_exo_z, float *d_packed, void *stream);
+
 /* Random policy on device: fills d_actions [N,A] with i.i.d. uniform(-1,1) f32 from Philox key
  * `key`, counter (j, 0, batch, global env id).  (test/env_test.py drives the reference with a fixed
  * policy; RL trainers supply their own.) */
 int chub_random_actions_device(chub_env *env, uint64_t key, uint32_t batch, float *d_actions, void *stream);
 
 int chub_sync(chub_env *env);
+
+/* Per-kernel timing of the step: between chub_profile_begin and chub_profile_end every step (up to max_steps)
+ * records HIP events on the launch stream around the slot kernel and the env kernel; _end synchronises and
+ * returns the summed durations in milliseconds and the number of steps covered. */
+int chub_profile_begin(chub_env *env, int max_steps);
+int chub_profile_end(chub_env *env, double *slot_ms_sum, double *env_ms_sum, int *n_steps);
 
 /* ---- introspection (parity tests, `re_*` telemetry, show_situation MGR:412-414) ---------------
  * chub_get_slots: per env, per station k, field-major [9][piles[k]]: car, charge, emergency, power, soc,

@@ -263,51 +263,72 @@ static float normal_float_compat(orc_rng *r, float mean, float sd) {
     return ret * sd + mean;
 }
 
-/* Philox-mode standard normal: polar method on 53-bit canonicals, trial i = block i of the site's
- * stream, all in f64 (so CPU libm and device ocml agree to 1 ulp of f64 before any narrowing). */
-#define ORC_POLAR_MAX_TRIALS 32
-double orc_normal_std(orc_rng *r, int tag, int index) {
-    for (uint32_t trial = 0; trial < ORC_POLAR_MAX_TRIALS; trial++) {
-        uint32_t o[4];
-        philox_block(r, tag, index, trial, o);
-        double c1 = ((double) (o[0] >> 5) * 67108864.0 + (double) (o[1] >> 6)) * (1.0 / 9007199254740992.0);
-        double c2 = ((double) (o[2] >> 5) * 67108864.0 + (double) (o[3] >> 6)) * (1.0 / 9007199254740992.0);
-        double x = 2.0 * c1 - 1.0, y = 2.0 * c2 - 1.0;
-        double r2 = x * x + y * y;
-        if (r2 > 1.0 || r2 == 0.0) continue;
-        double mult = sqrt(-2.0 * log(r2) / r2);
-        return y * mult;
+/* PHILOX mode: standard normal from one 32-bit uniform by two-level tabulated inverse CDF (tools/gen_tables.py):
+ * 4096 cells, linear interpolation inside a cell; the lowest cell is refined by a second 4096-entry table, the
+ * highest cell is its mirror image. */
+static float icdf_interp(const float *tab, uint32_t idx, float frac) {
+    float a = tab[idx], b = tab[idx + 1];
+    float diff = b - a;
+    float prod = diff * frac;
+    return a + prod;
+}
+float orc_normal_from_word(const orc_tables *t, uint32_t w) {
+    uint32_t cell = w >> 20;
+    if (cell == 4095u) {
+        uint32_t m = ~w; /* < 2^20 */
+        return -icdf_interp(t->normal_tail, m >> 8, (float) (m & 0xFFu) * (1.0f / 256.0f));
     }
-    return 0.0;
+    if (cell == 0u) return icdf_interp(t->normal_tail, w >> 8, (float) (w & 0xFFu) * (1.0f / 256.0f));
+    return icdf_interp(t->normal_icdf, cell, (float) (w & 0xFFFFFu) * (1.0f / 1048576.0f));
 }
 
-/* CHS:804-814 CarArriveRandom::mk_soc */
-float orc_mk_soc(orc_rng *r, int slot, int tag) {
-    float driver_experience;
-    if (r->mode == ORC_RNG_COMPAT) driver_experience = (float) normal_double_compat(r, 7.0, 3.0);
-    else driver_experience = (float) (orc_normal_std(r, tag, slot) * 3.0 + 7.0);
+/* CHS:804-814 CarArriveRandom::mk_soc, given the N(7,3) draw already narrowed to float */
+static float soc_from_experience(float driver_experience) {
     if (driver_experience < 1.0) driver_experience = 1.0;
     else if (driver_experience > 10.0) driver_experience = 10.0;
     float soc = 75.0 - 5.0 * driver_experience;
     return soc;
 }
+float orc_mk_soc(orc_rng *r) { return soc_from_experience((float) normal_double_compat(r, 7.0, 3.0)); }
 
-/* CHS:816-830 mk_late_time -- both pile classes pass "slow" (CHS:869, CHS:1034): N(2,2) */
-int orc_mk_late_time(orc_rng *r, int slot) {
-    float car_number;
-    if (r->mode == ORC_RNG_COMPAT) car_number = normal_float_compat(r, 2.0f, 2.0f);
-    else car_number = (float) (orc_normal_std(r, ORC_PU_LATE, slot) * 2.0 + 2.0);
+/* PHILOX mode: the same variate by inverse-CDF lookup -- 12 bits pick the cell of the tabulated inverse CDF of
+ * clip(N(7,3),1,10), 20 bits interpolate linearly inside it (three f32 roundings) */
+float orc_soc_from_word(const orc_tables *t, uint32_t w) {
+    uint32_t idx = w >> 20;
+    float frac = (float) (w & 0xFFFFFu) * (1.0f / 1048576.0f);
+    float a = t->soc_d_icdf[idx], b = t->soc_d_icdf[idx + 1];
+    float diff = b - a;
+    float prod = diff * frac;
+    float d = a + prod;
+    return soc_from_experience(d);
+}
+
+/* CHS:816-830 mk_late_time -- both pile classes pass "slow" (CHS:869, CHS:1034): max(0, round(N(2,2))) */
+int orc_mk_late_time(orc_rng *r) {
+    float car_number = normal_float_compat(r, 2.0f, 2.0f);
     int duration = (int) roundf(car_number);
     if (duration < 0) duration = 0;
     return duration;
 }
 
+/* PHILOX mode: the same integer law from one 32-bit uniform and the tabulated CDF */
+int orc_late_from_word(const orc_tables *t, uint32_t w) {
+    int late = 0;
+    for (int j = 0; j < 16; j++) late += (w >= t->late_thr[j]) ? 1 : 0;
+    return late;
+}
+
 /* CHS:832-842 init_station_car_number(mu, theta=3) */
-int orc_init_station_car_number(orc_rng *r, int station, int mu) {
+int orc_init_station_car_number(orc_rng *r, const orc_tables *t, int station, int mu) {
     int theta = 3;
     float car_number;
-    if (r->mode == ORC_RNG_COMPAT) car_number = normal_float_compat(r, (float) mu, 1.0f);
-    else car_number = (float) (orc_normal_std(r, ORC_PU_INIT, station) * 1.0 + (double) mu);
+    if (r->mode == ORC_RNG_COMPAT) {
+        car_number = normal_float_compat(r, (float) mu, 1.0f);
+    } else {
+        uint32_t o[4];
+        philox_block(r, ORC_PU_INIT, station, 0, o);
+        car_number = orc_normal_from_word(t, o[0]) + (float) mu;
+    }
     int temp = (int) roundf(car_number);
     if (temp > mu + theta) temp = mu + theta;
     else if (temp < mu - theta) temp = mu - theta;
@@ -578,15 +599,27 @@ static void remove_car(orc_station *s, int i) {
 }
 
 /* CHS:864-877 / 1029-1042 add_car (+ calculate_min_charging_time CHS:933-937 / 1098-1102) */
-static void add_car(orc_station *s, orc_rng *r, int i) {
+static void add_car(orc_station *s, orc_rng *r, const orc_tables *t, int i) {
     int cc = s->constant_charging;
     int slot = s->slot_base + i;
-    s->p_arrive_soc[i] = orc_mk_soc(r, slot, ORC_PU_SOC);
-    s->p_current_soc[i] = s->p_arrive_soc[i];
-    s->p_target_soc[i] = orc_uniform_level(orc_draw_k(r, ORC_PU_TGT, slot, 0), 80, 100);
+    int late;
+    if (r->mode == ORC_RNG_COMPAT) {
+        s->p_arrive_soc[i] = orc_mk_soc(r);
+        s->p_current_soc[i] = s->p_arrive_soc[i];
+        s->p_target_soc[i] = orc_uniform_level((int) (orc_glibc_rand(r) % 1000u), 80, 100);
+    } else {
+        /* PHILOX: one block per admitted slot -- word 0 arrival SoC, word 1 target level, word 2 extra stay */
+        uint32_t o[4];
+        philox_block(r, ORC_PU_SOC, slot, 0, o);
+        s->p_arrive_soc[i] = orc_soc_from_word(t, o[0]);
+        s->p_current_soc[i] = s->p_arrive_soc[i];
+        s->p_target_soc[i] = orc_uniform_level((int) (o[1] % 1000u), 80, 100);
+        late = orc_late_from_word(t, o[2]);
+    }
     float needed_time = soc_to_time(s->type, s->p_target_soc[i], cc) - soc_to_time(s->type, s->p_current_soc[i], cc);
     int must_needed = (int) ceilf(needed_time);
-    s->stay_time[i] = must_needed + orc_mk_late_time(r, slot);
+    if (r->mode == ORC_RNG_COMPAT) late = orc_mk_late_time(r);
+    s->stay_time[i] = must_needed + late;
     s->already[i] = 0;
     s->car[i] = 1; /* occupy_position CHS:314-317 */
     s->assign[i] = 0;
@@ -620,7 +653,7 @@ static void receive_car(orc_station *s, orc_rng *r, const orc_tables *t, int res
     find_empty(s); /* tell_empty CHS:401-407 */
     int in_car;
     if (reset_evs) {
-        in_car = orc_init_station_car_number(r, s->index, (int) round(s->n / 2));
+        in_car = orc_init_station_car_number(r, t, s->index, (int) round(s->n / 2));
     } else {
         int in_car_time = s->time_hole % 96;
         int n = orc_arrival_index(t, in_car_time, orc_draw_k(r, ORC_PU_ARRIVE, s->index, 0));
@@ -647,7 +680,7 @@ static void receive_car(orc_station *s, orc_rng *r, const orc_tables *t, int res
     s->has_flow = 1;
     assign_car(s);
     for (int i = 0; i < s->n; i++)
-        if (s->assign[i] > 0.5) add_car(s, r, i);
+        if (s->assign[i] > 0.5) add_car(s, r, t, i);
     for (int i = 0; i < s->n; i++) s->assign[i] = 0;
 }
 
@@ -826,7 +859,14 @@ static void hvs_step(orc_env *e, int time) {
     int n = orc_arrival_index(e->tab, time, k);
     e->hv_arrive = orc_count_hv(n, (float) 0.3, (float) e->cfg.fcev_permeate); /* HYD:247-251 */
     for (int j = 0; j < e->hv_arrive; j++) {
-        double soc = (double) orc_mk_soc(&e->rng, j, ORC_PU_HVSOC);
+        double soc;
+        if (e->rng.mode == ORC_RNG_COMPAT) {
+            soc = (double) orc_mk_soc(&e->rng);
+        } else {
+            uint32_t o[4];
+            philox_block(&e->rng, ORC_PU_HVSOC, j, 0, o);
+            soc = (double) orc_soc_from_word(e->tab, o[0]);
+        }
         if (soc < 0.5) soc = 0.5;
         double p0 = (soc * 0.01) * 70; /* _soc_to_pressure HYD:302-306 */
         double tn, mn;
@@ -995,21 +1035,23 @@ static double ou_sample(double *state, double theta, double sigma, double z) {
 static void make_state(orc_env *e, int time, const double *exo_z, double *obs) {
     const double scale_pv = 5, scale_wd = 1;
     double z[3];
+    uint32_t ow[4] = {0, 0, 0, 0};
+    if (!exo_z) philox_block(&e->rng, ORC_PU_OU, 0, 0, ow); /* PHILOX: word 0 pv, 1 wind, 2 price */
     /* REN:38-49 */
     double temp = e->tab->pv[e->pv_day][time];
     if (temp > 0 && e->pv_day % 2 == 0) {
-        z[0] = exo_z ? exo_z[0] : orc_normal_std(&e->rng, ORC_PU_OU, 0);
+        z[0] = exo_z ? exo_z[0] : (double) orc_normal_from_word(e->tab, ow[0]);
         temp += ou_sample(&e->ou_pv, .01, 1., z[0]) * (1 + e->cfg.renew_fluctuate);
     }
     e->re_pv = (temp > 0 ? temp : 0) * scale_pv;
     temp = e->tab->wd[e->wd_day][time];
-    z[1] = exo_z ? exo_z[1] : orc_normal_std(&e->rng, ORC_PU_OU, 1);
+    z[1] = exo_z ? exo_z[1] : (double) orc_normal_from_word(e->tab, ow[1]);
     temp += ou_sample(&e->ou_wd, .01, 1.5, z[1]) * (1 + e->cfg.renew_fluctuate);
     e->re_wd = (temp > 0 ? temp : 0) * scale_wd;
     /* MGR:354-360 */
     double price_next;
     if (e->price_count % 4 == 0) {
-        z[2] = exo_z ? exo_z[2] : orc_normal_std(&e->rng, ORC_PU_OU, 2);
+        z[2] = exo_z ? exo_z[2] : (double) orc_normal_from_word(e->tab, ow[2]);
         price_next = ou_sample(&e->ou_price, .1, 0.005, z[2]) * (1 + e->cfg.price_fluctuate);
         e->price_noise_part = price_next;
         price_next += e->price_last;
@@ -1266,6 +1308,22 @@ orc_tables *orc_tables_load(const char *data_dir) {
     if (orc_load_f64(p, &t->pv[0][0], 100 * 96)) { free(t); return NULL; }
     snprintf(p, sizeof p, "%s/wd_150x96.f64", data_dir);
     if (orc_load_f64(p, &t->wd[0][0], 150 * 96)) { free(t); return NULL; }
+    snprintf(p, sizeof p, "%s/soc_d_icdf_4097.f32", data_dir);
+    FILE *f = fopen(p, "rb");
+    if (!f || fread(t->soc_d_icdf, 4, 4097, f) != 4097) { if (f) fclose(f); free(t); return NULL; }
+    fclose(f);
+    snprintf(p, sizeof p, "%s/normal_icdf_4097.f32", data_dir);
+    f = fopen(p, "rb");
+    if (!f || fread(t->normal_icdf, 4, 4097, f) != 4097) { if (f) fclose(f); free(t); return NULL; }
+    fclose(f);
+    snprintf(p, sizeof p, "%s/normal_tail_4097.f32", data_dir);
+    f = fopen(p, "rb");
+    if (!f || fread(t->normal_tail, 4, 4097, f) != 4097) { if (f) fclose(f); free(t); return NULL; }
+    fclose(f);
+    snprintf(p, sizeof p, "%s/late_thr_16.u32", data_dir);
+    f = fopen(p, "rb");
+    if (!f || fread(t->late_thr, 4, 16, f) != 16) { if (f) fclose(f); free(t); return NULL; }
+    fclose(f);
     return t;
 }
 void orc_tables_free(orc_tables *t) { free(t); }

@@ -89,6 +89,10 @@ typedef struct {
     double price[96];
     double pv[100][96];
     double wd[150][96];
+    /* PHILOX-mode sampling tables (tools/gen_tables.py): inverse CDF of clip(N(7,3),1,10), thresholds of mk_late_time */
+    float soc_d_icdf[4097];
+    uint32_t late_thr[16];
+    float normal_icdf[4097], normal_tail[4097]; /* two-level inverse CDF of N(0,1) */
 } orc_tables;
 
 typedef struct {
@@ -140,10 +144,12 @@ uint32_t orc_glibc_rand(orc_rng *r);
 uint32_t orc_minstd_next(orc_rng *r);
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 int orc_draw_k(orc_rng *r, int tag, int index, int j);
-float orc_mk_soc(orc_rng *r, int slot, int tag);                       /* CHS:804-814 */
-int orc_mk_late_time(orc_rng *r, int slot);                            /* CHS:816-830 ("slow" law) */
-int orc_init_station_car_number(orc_rng *r, int station, int mu);      /* CHS:832-842 */
-double orc_normal_std(orc_rng *r, int tag, int index);                 /* Philox-mode OU normal */
+float orc_mk_soc(orc_rng *r);                                          /* CHS:804-814, reference streams */
+int orc_mk_late_time(orc_rng *r);                                      /* CHS:816-830 ("slow" law), reference streams */
+float orc_soc_from_word(const orc_tables *t, uint32_t w);              /* PHILOX mode: mk_soc from one 32-bit uniform */
+int orc_late_from_word(const orc_tables *t, uint32_t w);               /* PHILOX mode: mk_late_time from one uniform */
+int orc_init_station_car_number(orc_rng *r, const orc_tables *t, int station, int mu); /* CHS:832-842 */
+float orc_normal_from_word(const orc_tables *t, uint32_t w);           /* PHILOX mode: N(0,1) from one 32-bit uniform */
 void orc_rng_export_glibc128(const orc_rng *r, unsigned char *buf132); /* glibc initstate layout + minstd */
 void orc_rng_import_glibc128(orc_rng *r, const unsigned char *buf132);
 

@@ -77,10 +77,12 @@ def _load_oracle():
         "orc_minstd_next": (C.c_uint32, [P]),
         "orc_philox4x32_10": (None, [P, P, P]),
         "orc_draw_k": (I, [P, I, I, I]),
-        "orc_mk_soc": (F, [P, I, I]),
-        "orc_mk_late_time": (I, [P, I]),
-        "orc_init_station_car_number": (I, [P, I, I]),
-        "orc_normal_std": (D, [P, I, I]),
+        "orc_mk_soc": (F, [P]),
+        "orc_mk_late_time": (I, [P]),
+        "orc_soc_from_word": (F, [P, C.c_uint32]),
+        "orc_late_from_word": (I, [P, C.c_uint32]),
+        "orc_init_station_car_number": (I, [P, P, I, I]),
+        "orc_normal_from_word": (F, [P, C.c_uint32]),
         "orc_rng_export_glibc128": (None, [P, P]),
         "orc_rng_import_glibc128": (None, [P, P]),
         "orc_curve_slow": (F, [I, F, I]),
