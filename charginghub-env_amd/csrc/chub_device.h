@@ -118,7 +118,19 @@ struct HubParams {
     double renew_fluct1, price_fluct1;  // 1 + fluctuate
     double price_mean, price_std;
     float hv_rate;           // f32(f32(0.3) * f32(permeate))
+    int32_t slot_block;      // workgroup size of the PHILOX slot kernel (256 / 512 / 1024; env CHUB_SLOT_BLOCK)
     int32_t ablate;          // timing experiments only (env CHUB_ABLATE): skips parts of k_slot, results are WRONG
+};
+
+// Everything a kernel needs that does not change from step to step, kept in device memory and passed by pointer
+// (as by-value kernel arguments these ~600 bytes were all loaded into SGPRs up front and spilled).
+struct DevCtx {
+    HubParams hp;
+    SlotArrays sl;
+    StationArrays st;
+    EnvArrays ev;
+    CompatRng cr;
+    Tables tb;
 };
 
 struct StepArgs {

@@ -143,6 +143,14 @@ __device__ __forceinline__ float emergency_of(float t_target, float t_soc, int t
     return 0.0f;
 }
 
+// Both uses the step makes of the emergency -- force-on when emergency >= 1.01 (CHS.hpp:1406) and min_power when
+// emergency > 8 (CHS.hpp:1248) -- reduce to the "must charge" branch: otherwise emergency = (need/left)^2 with
+// left > ceil(need) >= need, i.e. < 1.  So the hot path only needs this predicate, no division.
+__device__ __forceinline__ bool must_charge(float t_target, float t_soc, int tl) {
+    const float need = __fsub_rn(t_target, t_soc);
+    return need > 0.0f && (float) tl <= ceilf(need);
+}
+
 __device__ __forceinline__ float arrive_soc_from(double normal73) {  // mk_soc, CHS.hpp:804-814
     float d = (float) normal73;
     if ((double) d < 1.0) d = 1.0f;
@@ -151,6 +159,21 @@ __device__ __forceinline__ float arrive_soc_from(double normal73) {  // mk_soc, 
 }
 
 constexpr int MODE_COMPAT = 0, MODE_PHILOX = 1;
+
+// DPP lane exchanges for the butterfly sums.  After the xor-1 and xor-2 steps every lane of a quad holds the quad's
+// sum, so the mirror patterns (lane i <-> 7-i, i <-> 15-i) pair the same partial sums as xor 4 / xor 8 would.
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ float dpp_mirror8(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+}
+__device__ __forceinline__ float dpp_mirror16(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+}
 
 // PHILOX mode: mk_soc (CHS.hpp:804-814) from one 32-bit uniform by linear interpolation of the tabulated
 // inverse CDF of clip(N(7,3),1,10): 12 bits pick the cell, 20 bits interpolate (three f32 roundings)
@@ -205,8 +228,7 @@ __device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs
     const float a = sa.actions[env * hp.act_dim + hub_slot];
     const bool act_on = __fdiv_rn(__fadd_rn(a, 1.0f), 2.0f) >= 0.5f;
     // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373)
-    const float em = r.car ? emergency_of(r.t_target, r.t_soc, r.tl) : 0.0f;
-    const bool on = r.car && (act_on || (double) em >= 1.01);
+    const bool on = r.car && (act_on || must_charge(r.t_target, r.t_soc, r.tl));
     if (on && !(hp.ablate & 2)) {  // car_step (CHS.hpp:900-905 / 1065-1070)
         const float tt = __fadd_rn(r.t_soc, 1.0f);
         r.soc_new = time_to_soc<TYPE>(tt, cp, hp.cc);
@@ -433,11 +455,11 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     }
 
     // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572)
-    const float em2 = r.car ? emergency_of(r.t_target, r.t_soc, r.tl) : 0.0f;
+    const bool urgent = r.car && must_charge(r.t_target, r.t_soc, r.tl);
     float r_min, r_max, r_chg;
     if (MODE == MODE_COMPAT) {
         // the reference adds slot powers sequentially in f32 (CHS.hpp:1244-1255): same order, same roundings
-        const float v_min = (r.car && em2 > 8.0f) ? r.power : 0.0f, v_max = r.car ? r.power : 0.0f;
+        const float v_min = urgent ? r.power : 0.0f, v_max = r.car ? r.power : 0.0f;
         const float v_chg = r.charge ? r.power : 0.0f;
         const int ubase = uiw * H;
         r_min = r_max = r_chg = 0.0f;
@@ -447,18 +469,17 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
             r_chg = __fadd_rn(r_chg, __shfl(v_chg, ubase + i));
         }
     } else {
-        // production: f64 butterfly == the exact sum, rounded once to f32
-        double s_min = (r.car && em2 > 8.0f) ? (double) r.power : 0.0;
-        double s_max = r.car ? (double) r.power : 0.0;
-        double s_chg = r.charge ? (double) r.power : 0.0;
-        for (int off = H >> 1; off > 0; off >>= 1) {
-            s_min += __shfl_xor(s_min, off);
-            s_max += __shfl_xor(s_max, off);
-            s_chg += __shfl_xor(s_chg, off);
-        }
-        r_min = (float) s_min;
-        r_max = (float) s_max;
-        r_chg = (float) s_chg;
+        // production: balanced binary-tree sum in f32 over the unit's H lanes (lane i pairs with i^1, i^2, i^4, ...):
+        // DPP lane exchanges inside a 16-lane row, ds_bpermute across rows
+        r_min = urgent ? r.power : 0.0f;
+        r_max = r.car ? r.power : 0.0f;
+        r_chg = r.charge ? r.power : 0.0f;
+        if (H > 1) { r_min += dpp_xor1(r_min); r_max += dpp_xor1(r_max); r_chg += dpp_xor1(r_chg); }
+        if (H > 2) { r_min += dpp_xor2(r_min); r_max += dpp_xor2(r_max); r_chg += dpp_xor2(r_chg); }
+        if (H > 4) { r_min += dpp_mirror8(r_min); r_max += dpp_mirror8(r_max); r_chg += dpp_mirror8(r_chg); }
+        if (H > 8) { r_min += dpp_mirror16(r_min); r_max += dpp_mirror16(r_max); r_chg += dpp_mirror16(r_chg); }
+        if (H > 16) { r_min += __shfl_xor(r_min, 16); r_max += __shfl_xor(r_max, 16); r_chg += __shfl_xor(r_chg, 16); }
+        if (H > 32) { r_min += __shfl_xor(r_min, 32); r_max += __shfl_xor(r_max, 32); r_chg += __shfl_xor(r_chg, 32); }
     }
     const int cars = __popcll(__ballot(r.car) & unit_mask);
 
@@ -486,13 +507,15 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     }
 }
 
-constexpr int kSlotBlock = 256;
-
-template <bool RESET, int MODE>
-__global__ __launch_bounds__(kSlotBlock) void k_slot(HubParams hp, StepArgs sa, SlotArrays sl, StationArrays st,
-                                                     CompatRng cr, Tables tb, int64_t nb0) {
-    __shared__ float lds_f[5 * kSlotBlock];
-    __shared__ uint32_t lds_u[2 * kSlotBlock + 1];
+template <bool RESET, int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_slot(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0) {
+    const HubParams &hp = ctx->hp;
+    const SlotArrays &sl = ctx->sl;
+    const StationArrays &st = ctx->st;
+    const CompatRng &cr = ctx->cr;
+    const Tables &tb = ctx->tb;
+    __shared__ float lds_f[5 * BLOCK];
+    __shared__ uint32_t lds_u[2 * BLOCK + 1];
     int k;
     int64_t bl;
     if (sa.station_filter >= 0) {
@@ -502,8 +525,8 @@ __global__ __launch_bounds__(kSlotBlock) void k_slot(HubParams hp, StepArgs sa, 
         k = ((int64_t) blockIdx.x >= nb0) ? 1 : 0;
         bl = k ? (int64_t) blockIdx.x - nb0 : (int64_t) blockIdx.x;
     }
-    if (hp.type[k] == 0) slot_body<0, RESET, MODE, kSlotBlock>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
-    else slot_body<1, RESET, MODE, kSlotBlock>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
+    if (hp.type[k] == 0) slot_body<0, RESET, MODE, BLOCK>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
+    else slot_body<1, RESET, MODE, BLOCK>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
 }
 
 // ----------------------------------------------------------------------------------------- k_env
@@ -582,8 +605,12 @@ __device__ __forceinline__ void draw_arrivals_ahead(const HubParams &hp, const T
 // Blocks [0, nb_env) run the per-env tail (lane = env); in PHILOX mode blocks [nb_env, ...) draw the next step's
 // station arrivals (lane = (station, env)).  The two parts are independent given k_slot's outputs.
 template <bool RESET, int MODE>
-__global__ __launch_bounds__(256) void k_env(HubParams hp, StepArgs sa, StationArrays st, EnvArrays ev, CompatRng cr,
-                                             Tables tb, int nb_env) {
+__global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, int nb_env) {
+    const HubParams &hp = ctx->hp;
+    const StationArrays &st = ctx->st;
+    const EnvArrays &ev = ctx->ev;
+    const CompatRng &cr = ctx->cr;
+    const Tables &tb = ctx->tb;
     const int64_t N = hp.n_envs;
     const int t_next = RESET ? 0 : (sa.t + 1) % 96;
     if ((int) blockIdx.x >= nb_env) {
@@ -915,39 +942,50 @@ __global__ void k_random_actions(int64_t n_envs, int64_t env_id0, int act_dim, u
 }
 
 // ------------------------------------------------------------------------------------- launchers
-static inline int64_t blocks_for(int64_t n_envs, int H) {
-    const int64_t upb = (int64_t) (kSlotBlock / 64) * (64 / H);
+static inline int64_t blocks_for(int64_t n_envs, int H, int block) {
+    const int64_t upb = (int64_t) (block / 64) * (64 / H);
     return (n_envs + upb - 1) / upb;
 }
 
-void launch_slot(bool reset, const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
-                 const CompatRng &cr, const Tables &tb, hipStream_t stream) {
-    const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0]), nb1 = blocks_for(hp.n_envs, hp.H[1]);
-    if (hp.rng_mode == MODE_PHILOX) {
-        const int64_t nb = nb0 + nb1;
-        if (reset) hipLaunchKernelGGL((k_slot<true, MODE_PHILOX>), dim3((unsigned) nb), dim3(kSlotBlock), 0, stream, hp, sa, sl, st, cr, tb, nb0);
-        else hipLaunchKernelGGL((k_slot<false, MODE_PHILOX>), dim3((unsigned) nb), dim3(kSlotBlock), 0, stream, hp, sa, sl, st, cr, tb, nb0);
+template <bool RESET, int MODE, int BLOCK>
+static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {
+    const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
+    if (MODE == MODE_PHILOX) {
+        hipLaunchKernelGGL((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), 0, stream, ctx, sa, nb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
             StepArgs s2 = sa;
             s2.station_filter = k;
-            const int64_t nb = k ? nb1 : nb0;
-            if (reset) hipLaunchKernelGGL((k_slot<true, MODE_COMPAT>), dim3((unsigned) nb), dim3(kSlotBlock), 0, stream, hp, s2, sl, st, cr, tb, nb0);
-            else hipLaunchKernelGGL((k_slot<false, MODE_COMPAT>), dim3((unsigned) nb), dim3(kSlotBlock), 0, stream, hp, s2, sl, st, cr, tb, nb0);
+            hipLaunchKernelGGL((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), 0, stream, ctx,
+                               s2, nb0);
         }
     }
 }
 
-void launch_env(bool reset, const HubParams &hp, const StepArgs &sa, const StationArrays &st, const EnvArrays &ev,
-                const CompatRng &cr, const Tables &tb, hipStream_t stream) {
+void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {
+    if (hp.rng_mode == MODE_PHILOX) {
+        if (reset) return launch_slot_t<true, MODE_PHILOX, 256>(hp, ctx, sa, stream);
+        switch (hp.slot_block) {
+            case 64: return launch_slot_t<false, MODE_PHILOX, 64>(hp, ctx, sa, stream);
+            case 128: return launch_slot_t<false, MODE_PHILOX, 128>(hp, ctx, sa, stream);
+            case 256: return launch_slot_t<false, MODE_PHILOX, 256>(hp, ctx, sa, stream);
+            case 1024: return launch_slot_t<false, MODE_PHILOX, 1024>(hp, ctx, sa, stream);
+            default: return launch_slot_t<false, MODE_PHILOX, 512>(hp, ctx, sa, stream);
+        }
+    }
+    if (reset) launch_slot_t<true, MODE_COMPAT, 256>(hp, ctx, sa, stream);
+    else launch_slot_t<false, MODE_COMPAT, 256>(hp, ctx, sa, stream);
+}
+
+void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {
     const int nb_env = (int) ((hp.n_envs + 255) / 256);
     if (hp.rng_mode == MODE_PHILOX) {
         const unsigned nb = (unsigned) (nb_env + (2 * hp.n_envs + 255) / 256);  // + the arrival-draw blocks
-        if (reset) hipLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(256), 0, stream, hp, sa, st, ev, cr, tb, nb_env);
-        else hipLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(256), 0, stream, hp, sa, st, ev, cr, tb, nb_env);
+        if (reset) hipLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(256), 0, stream, ctx, sa, nb_env);
+        else hipLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(256), 0, stream, ctx, sa, nb_env);
     } else {
-        if (reset) hipLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(256), 0, stream, hp, sa, st, ev, cr, tb, nb_env);
-        else hipLaunchKernelGGL((k_env<false, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(256), 0, stream, hp, sa, st, ev, cr, tb, nb_env);
+        if (reset) hipLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(256), 0, stream, ctx, sa, nb_env);
+        else hipLaunchKernelGGL((k_env<false, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(256), 0, stream, ctx, sa, nb_env);
     }
 }
 

@@ -16,10 +16,8 @@
 #include "chub_device.h"
 
 namespace chub {
-void launch_slot(bool reset, const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
-                 const CompatRng &cr, const Tables &tb, hipStream_t stream);
-void launch_env(bool reset, const HubParams &hp, const StepArgs &sa, const StationArrays &st, const EnvArrays &ev,
-                const CompatRng &cr, const Tables &tb, hipStream_t stream);
+void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream);
+void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream);
 void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream);
 }  // namespace chub
 
@@ -48,6 +46,8 @@ struct chub_env {
     CompatRng cr;
     Tables tb;
     int device;
+    DevCtx *d_ctx;      // device copy of {hp, sl, st, ev, cr, tb}
+    bool ctx_dirty;
     // lock-step clock (MGR:137-140,299; CHS.hpp:1204; AGG:150-151; HYD:192-193 are three copies of it)
     int t;
     int price_count;
@@ -217,6 +217,17 @@ static int fetch(std::vector<T> &dst, const T *src, size_t count) {
     return 0;
 }
 
+// upload {hp, arrays, tables} when something in them changed (create, telemetry toggle)
+static int sync_ctx(chub_env *e, hipStream_t s) {
+    if (!e->ctx_dirty) return 0;
+    DevCtx h;
+    h.hp = e->hp; h.sl = e->sl; h.st = e->st; h.ev = e->ev; h.cr = e->cr; h.tb = e->tb;
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(e->d_ctx, &h, sizeof h, hipMemcpyHostToDevice));
+    e->ctx_dirty = false;
+    return 0;
+}
+
 extern "C" {
 
 const char *chub_last_error(void) { return g_err.c_str(); }
@@ -297,6 +308,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     hp.constant_charging = cfg->constant_charging ? 1 : 0;
     hp.rng_mode = rng_mode;
     hp.telemetry = 0;
+    hp.slot_block = getenv("CHUB_SLOT_BLOCK") ? atoi(getenv("CHUB_SLOT_BLOCK")) : 256;
     hp.ablate = getenv("CHUB_ABLATE") ? atoi(getenv("CHUB_ABLATE")) : 0;
     hp.key[0] = (uint32_t) seed;
     hp.key[1] = (uint32_t) (seed >> 32);
@@ -469,6 +481,8 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     if (rng_mode == CHUB_RNG_COMPAT) {
         ALLOC(e->cr.g, N * 32); ALLOC(e->cr.minstd, N);
     }
+    ALLOC(e->d_ctx, 1);
+    e->ctx_dirty = true;
     ALLOC(e->d_actions, N * (size_t) hp.act_dim); ALLOC(e->d_obs, N * (size_t) hp.obs_dim); ALLOC(e->d_reward, N);
     ALLOC(e->d_done, N); ALLOC(e->d_exo_z, N * 3); ALLOC(e->d_exo_days, N * 2);
 #undef ALLOC
@@ -536,8 +550,10 @@ int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_ex
     sa.exo_z = d_exo_z;
     sa.obs = d_obs;
     sa.obs_stride = e->hp.obs_dim;
-    launch_slot(true, e->hp, sa, e->sl, e->st, e->cr, e->tb, s);
-    launch_env(true, e->hp, sa, e->st, e->ev, e->cr, e->tb, s);
+    int rc_ = sync_ctx(e, s);
+    if (rc_) return rc_;
+    launch_slot(true, e->hp, e->d_ctx, sa, s);
+    launch_env(true, e->hp, e->d_ctx, sa, s);
     HIP_TRY(hipGetLastError());
     e->t = 0;
     e->price_count = 0;  // MGR:313 (after make_state)
@@ -581,12 +597,14 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
     sa.reward_stride = reward_stride;
     sa.done = d_done;
     sa.done_f32 = d_done_f32;
+    int rc_ = sync_ctx(e, s);
+    if (rc_) return rc_;
     const bool prof = e->prof_on && e->prof_used < e->prof_cap;
     hipEvent_t *pe = prof ? &e->prof_events[3 * e->prof_used] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], s));
-    launch_slot(false, e->hp, sa, e->sl, e->st, e->cr, e->tb, s);
+    launch_slot(false, e->hp, e->d_ctx, sa, s);
     if (prof) HIP_TRY(hipEventRecord(pe[1], s));
-    launch_env(false, e->hp, sa, e->st, e->ev, e->cr, e->tb, s);
+    launch_env(false, e->hp, e->d_ctx, sa, s);
     if (prof) {
         HIP_TRY(hipEventRecord(pe[2], s));
         e->prof_used++;
@@ -718,6 +736,7 @@ int chub_set_telemetry(chub_env *e, int enabled) {
         if ((rc = dev_alloc(e, &e->ev.reward64, N))) return rc;
     }
     e->hp.telemetry = enabled ? 1 : 0;
+    e->ctx_dirty = true;
     return CHUB_OK;
 }
 
