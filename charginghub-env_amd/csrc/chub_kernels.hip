@@ -924,6 +924,26 @@ __global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, Ste
     }
 }
 
+// COMPAT only: the reference's constructor consumes draws of the two streams before the first user-visible
+// reset(): HySystem.__init__ runs 101 real hy_step()s (HYD:154), each drawing the FCEV arrival level and one
+// mk_soc per arrival (HYD:250-259).  This kernel advances the streams by exactly those draws.
+__global__ void k_compat_burn_fcev(const DevCtx *__restrict__ ctx, int n_steps) {
+    const int64_t env = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= ctx->hp.n_envs) return;
+    CompatStream rs;
+    rs.load(ctx->cr, env);
+    for (int i = 0; i < n_steps; i++) {
+        const int t = i % 96;
+        const int arrive = (int) ctx->tb.cnt_hv[t * kLevels + rs.level()];
+        for (int j = 0; j < arrive; j++) (void) rs.normal_d(7.0, 3.0);
+    }
+    rs.store(ctx->cr, env);
+}
+
+void launch_compat_burn_fcev(const HubParams &hp, const DevCtx *ctx, int n_steps, hipStream_t stream) {
+    hipLaunchKernelGGL(k_compat_burn_fcev, dim3((unsigned) ((hp.n_envs + 63) / 64)), dim3(64), 0, stream, ctx, n_steps);
+}
+
 // -------------------------------------------------------------------- random policy (bench / tests)
 __global__ void k_random_actions(int64_t n_envs, int64_t env_id0, int act_dim, uint32_t k0, uint32_t k1, uint32_t batch,
                                  float *actions) {

@@ -19,6 +19,7 @@ namespace chub {
 void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream);
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream);
 void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream);
+void launch_compat_burn_fcev(const HubParams &hp, const DevCtx *ctx, int n_steps, hipStream_t stream);
 }  // namespace chub
 
 using namespace chub;
@@ -257,12 +258,6 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     if (!(cfg->hydro_prod_rate >= 0) || !(cfg->hydro_store_vlt > 0) || !(cfg->fc_max_power >= 0))
         return fail(CHUB_ERR_ARG, "hydrogen system sizes must be non-negative");
 
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(CHUB_ERR_HIP, "no HIP device available: libchub has no CPU path");
-    if (device < 0 || device >= ndev) return fail(CHUB_ERR_ARG, "device ordinal out of range");
-    HIP_TRY(hipSetDevice(device));
-
     chub_env *e = new chub_env();
     e->cfg = *cfg;
     e->device = device;
@@ -286,6 +281,15 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     if ((rc = load_f64(dir + "/price_96.f64", e->price, 96))) return bail(rc);
     if ((rc = load_f64(dir + "/pv_100x96.f64", pv.data(), pv.size()))) return bail(rc);
     if ((rc = load_f64(dir + "/wd_150x96.f64", wd.data(), wd.size()))) return bail(rc);
+
+    {   // data files are validated before the device is touched (so bad data reports CHUB_ERR_DATA everywhere)
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            return bail(fail(CHUB_ERR_HIP, "no HIP device available: libchub has no CPU path"));
+        if (device < 0 || device >= ndev) return bail(fail(CHUB_ERR_ARG, "device ordinal out of range"));
+        hipError_t he = hipSetDevice(device);
+        if (he != hipSuccess) return bail(fail(CHUB_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he)));
+    }
 
     HubParams &hp = e->hp;
     memset(&hp, 0, sizeof hp);
@@ -873,6 +877,24 @@ int chub_profile_end(chub_env *e, double *slot_ms_sum, double *env_ms_sum, int *
     *env_ms_sum = b;
     *n_steps = (int) e->prof_used;
     e->prof_on = false;
+    return CHUB_OK;
+}
+
+int chub_compat_replay_constructor(chub_env *e) {
+    if (!e) return fail(CHUB_ERR_ARG, "null handle");
+    if (e->hp.rng_mode != CHUB_RNG_COMPAT) return fail(CHUB_ERR_ARG, "handle is not in COMPAT mode");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = sync_ctx(e, nullptr);
+    if (rc) return rc;
+    // (1) the two station constructors each run evs_reset (CHS.hpp:1152, 1462; AGG:188-196)
+    StepArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.station_filter = -1;
+    launch_slot(true, e->hp, e->d_ctx, sa, nullptr);
+    // (2) HySystem.__init__: 101 hy_step()s with live FCEV arrivals (HYD:154,168,250-259)
+    launch_compat_burn_fcev(e->hp, e->d_ctx, 101, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
     return CHUB_OK;
 }
 

@@ -78,6 +78,9 @@ class EvcsspManagerEnv_v6(object):
             else:
                 gseed = 1
             self._vec.set_compat_seeds(np.array([[gseed, 1]], dtype=np.uint32))
+            # the reference's constructor consumes stream draws before its reset() (station constructors,
+            # HySystem's sweep): replay them so that an episode after construction matches the reference's
+            self._vec.compat_replay_constructor()
         self.pile_number = [int(station_list[0]), int(station_list[1])]
         data = _lib.DATA_DIR
         self._price = np.fromfile(data + "/price_96.f64", dtype="<f8")
@@ -100,6 +103,11 @@ class EvcsspManagerEnv_v6(object):
         self.viewer = None
         self.action_space = _space(-1.0, 1.0, (sum(self.pile_number) + 2,))
         self.observation_space = _space(self.low_state, self.high_state)
+        if rng == "compat":
+            # side effect of the reference's constructor: each of its three OU_Noise objects calls
+            # random.seed(1) (REN:63 via MGR:30 and REN:34-35), so the first randint() pair of reset()
+            # always starts from that state
+            random.seed(1)
         self._pv_day = 0
         self._wd_day = 0
         self._price_count = 0

@@ -159,6 +159,9 @@ class VecChargingHub(object):
         check(self._lib.chub_get_rng_compat_state(self._h, _ptr(out)))
         return out
 
+    def compat_replay_constructor(self):
+        check(self._lib.chub_compat_replay_constructor(self._h))
+
     def set_ou_state(self, ou):
         o = np.ascontiguousarray(ou, dtype=np.float64).reshape(self.n_envs, 3)
         check(self._lib.chub_set_ou_state(self._h, _ptr(o)))

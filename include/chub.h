@@ -146,6 +146,10 @@ int chub_set_rng_compat_seeds(chub_env *env, const uint32_t *seeds);
  * front pointer (rear = front - 3 mod 31), and the minstd_rand0 word -- to continue streams mid-sequence. */
 int chub_set_rng_compat_state(chub_env *env, const uint32_t *state);
 int chub_get_rng_compat_state(chub_env *env, uint32_t *state);
+/* COMPAT: advance the two streams by what the reference's constructor consumes before its first reset() (MGR:25-119):
+ * one evs_reset per station constructor (CHS.hpp:1152,1462) and the 101-step electrolyser sweep with live FCEV
+ * arrivals (HYD:154).  Call once after chub_create / chub_set_rng_compat_seeds, then chub_reset (= MGR:120). */
+int chub_compat_replay_constructor(chub_env *env);
 /* Persistent OU states (never reset by the reference, MGR:304-316): [N][3] f64 pv, wd, price. */
 int chub_set_ou_state(chub_env *env, const double *ou);
 

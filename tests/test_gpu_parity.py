@@ -61,8 +61,6 @@ def test_compat_matches_reference_golden(name, n_envs):
     chub = hub()
     g = orclib.load_golden(name)
     kw = kwargs_of(g)
-    if name == "env_c1_envtest":
-        pytest.skip("default-seed run needs the constructor replay; covered by test_dropin_env_test_known_answer")
     v = chub.VecChargingHub(n_envs, rng="compat", **kw)
     v.set_telemetry(True)
     S0, S1 = kw["station_list"]
@@ -72,6 +70,9 @@ def test_compat_matches_reference_golden(name, n_envs):
         close(v.hy_table(), g["hy_table"], "hy_table", rtol=1e-13, atol=1e-12)
     rep = lambda a: np.repeat(np.asarray(a)[None, :], n_envs, axis=0)
     v.set_compat_seeds(rep([1, 1]))
+    if name == "env_c1_envtest":
+        # the reference's own smoke test runs on the default seeds, so its constructor's stream draws count
+        v.compat_replay_constructor()
     v.reset(rep(g["ctor_days"]), rep(g["ctor_z"]))  # constructor's reset (MGR:120): shapes the OU states
     seeds = {int(ep): (int(a), int(b)) for ep, a, b in g["seeds"]}
     steps = int(g["steps_per_episode"])
@@ -265,3 +266,33 @@ def test_env_test_known_answer():
     assert abs(ret - 34.858789741560585) < 1e-9
     assert abs(v.telemetry()[0, 3] - 0.1525) < 1e-9
     v.close()
+
+
+def test_dropin_class_reproduces_env_test():
+    """test/env_test.py through the drop-in class, nothing injected: EvcsspManagerEnv_v6(**env_kwargs) with
+    seed_rand=False after random.seed(0); np.random.seed(0), reset(), step(action=None) until done.
+    Reference: return 34.858789741560585, final H2 SOC 0.1525, and the recorded per-step obs / rewards."""
+    import random
+    chub = hub()
+    g = orclib.load_golden("env_c1_envtest")
+    random.seed(0)
+    np.random.seed(0)
+    env = chub.EvcsspManagerEnv_v6(station_list=[20, 25], station_type_list=["fast", "slow"], constant_charging=False,
+                                   seed_rand=False, hydro_prod_rate=100, hydro_store_vlt=500 / 20, init_soc=0.2,
+                                   fc_max_power=100, fcev_permeate=0.01, use_lagrange=False, renew_fluctuate=0.0,
+                                   price_fluctuate=0.0, hydro_loss=0.0)
+    assert env.observation_space.shape == (13,) and env.action_space.shape == (47,)
+    o = env.reset()
+    close(o, g["reset_obs"][0], "drop-in reset obs", rtol=TIGHT, atol=TIGHT)
+    done, ret, i = False, 0.0, 0
+    while not done:
+        s_, r, done, info = env.step(action=None)
+        close(s_, g["obs"][i], ("drop-in obs", i), rtol=TIGHT, atol=TIGHT)
+        close(r, g["reward"][i], ("drop-in reward", i), rtol=TIGHT, atol=TIGHT)
+        assert isinstance(r, float) and isinstance(done, bool) and info == {}
+        ret += r
+        i += 1
+    assert i == 96
+    assert abs(ret - 34.858789741560585) < 1e-9
+    assert abs(env._t_Store_SOC - 0.1525) < 1e-12
+    env.close()
