@@ -14,6 +14,14 @@
 
 #include "chub_curves.h"
 
+// Device pointers kept inside structs that live in memory lose their address space (the compiler then emits flat_*
+// instead of global_* accesses); spell it out for the device pass.  Same size and layout on both sides.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CHUB_G(T) T __attribute__((address_space(1))) *
+#else
+#define CHUB_G(T) T *
+#endif
+
 namespace chub {
 
 constexpr int kQCap = 16;        // FCEV FIFO capacity (the reference list is unbounded, HYD:264-265)
@@ -38,62 +46,67 @@ enum Site : uint32_t {
 };
 
 struct SlotArrays {          // per-slot state, f32 unless noted; index = base_k + env*S_k + slot
-    float *soc;              // current SoC (introspection; rewritten when a car charges / arrives / leaves)
-    float *target;           // target SoC (written at arrival / departure only)
-    float *init_soc;         // arrival SoC (written at arrival / departure only)
-    float *power;            // kW at the car's current point of the curve (Station::situation["power"])
-    float *t_target;         // soc_to_time(target)   -- cached, constant over a stay
-    float *t_soc;            // soc_to_time(soc)      -- cached, what car_step and calculate_needed both need
-    uint8_t *tl;             // bits 0-6: stay_time - already_stay_time (0 = empty), bit 7: charging this step
-    uint8_t *stay;           // stay_time (introspection)
+    CHUB_G(float) soc;       // current SoC (introspection; rewritten when a car charges / arrives / leaves)
+    CHUB_G(float) target;    // target SoC (written at arrival / departure only)
+    CHUB_G(float) init_soc;  // arrival SoC (written at arrival / departure only)
+    CHUB_G(float) power;     // kW at the car's current point of the curve (Station::situation["power"])
+    CHUB_G(float) t_target;  // soc_to_time(target)   -- cached, constant over a stay
+    CHUB_G(float) t_soc;     // soc_to_time(soc)      -- cached, what car_step and calculate_needed both need
+    CHUB_G(uint8_t) tl;      // bits 0-6: stay_time - already_stay_time (0 = empty), bit 7: charging this step
+    CHUB_G(uint8_t) stay;    // stay_time (introspection)
 };
 
 struct StationArrays {       // index = k*N + env
-    uint8_t *line;           // waiting queue length (Station::line) after the step
-    uint8_t *line_r;         // PHILOX: queue length after the NEXT step's renege pass (drawn ahead by k_env)
-    int8_t *flow_in;         // flow_in_number.back() of the step just simulated
-    int8_t *flow_next;       // PHILOX: the NEXT step's arrivals (drawn ahead by k_env, consumed by k_slot)
-    uint8_t *car_number;
-    float *min_p, *chg_p, *max_p;
+    CHUB_G(uint8_t) line;    // waiting queue length (Station::line) after the step
+    CHUB_G(uint8_t) line_r;       // PHILOX: queue length after the NEXT step's renege pass (drawn ahead by k_env)
+    CHUB_G(int8_t) flow_in;  // flow_in_number.back() of the step just simulated
+    CHUB_G(int8_t) flow_next;     // PHILOX: the NEXT step's arrivals (drawn ahead by k_env, consumed by k_slot)
+    CHUB_G(uint8_t) car_number;
+    CHUB_G(float) min_p;
+    CHUB_G(float) chg_p;
+    CHUB_G(float) max_p;
 };
 
 struct EnvArrays {           // index = env (or field*N + env)
-    double *cap;             // HyStore.capacity, g
-    double *store_soc;       // HyStore.Store_SOC as last computed by sty_step (stale after the fuel cell, HYD:428)
-    double *ou;              // [3][N] OU states pv, wd, price (REN:56-76), never reset
-    double *price_noise;     // self.price_next noise part (MGR:356)
-    double *re_pv, *re_wd;   // exogenous powers produced by the previous make_state (MGR:349-350)
-    double *price_next;      // real_state[1]
-    int16_t *pv_day, *wd_day;
-    uint8_t *q_len;          // FCEV FIFO length
-    uint8_t *hv_line;        // HyFCEVStation.line
-    uint8_t *q_overflow;
-    double *q_time, *q_mass; // [N][kQCap]
-    double *obs64;           // [N][D]  (telemetry only)
-    double *reward64;        // [N]     (telemetry only)
-    double *telem;           // [kTelemCount][N] (telemetry only)
+    CHUB_G(double) cap;          // HyStore.capacity, g
+    CHUB_G(double) store_soc;    // HyStore.Store_SOC as last computed by sty_step (stale after the fuel cell, HYD:428)
+    CHUB_G(double) ou;           // [3][N] OU states pv, wd, price (REN:56-76), never reset
+    CHUB_G(double) price_noise;  // self.price_next noise part (MGR:356)
+    CHUB_G(double) re_pv;        // exogenous powers produced by the previous make_state (MGR:349-350)
+    CHUB_G(double) re_wd;
+    CHUB_G(double) price_next;   // real_state[1]
+    CHUB_G(int16_t) pv_day;
+    CHUB_G(int16_t) wd_day;
+    CHUB_G(uint8_t) q_len;       // FCEV FIFO length
+    CHUB_G(uint8_t) hv_line;     // HyFCEVStation.line
+    CHUB_G(uint8_t) q_overflow;
+    CHUB_G(double) q_time;       // [N][kQCap]
+    CHUB_G(double) q_mass;
+    CHUB_G(double) obs64;        // [N][D]  (telemetry only)
+    CHUB_G(double) reward64;     // [N]     (telemetry only)
+    CHUB_G(double) telem;        // [kTelemCount][N] (telemetry only)
 };
 
 struct CompatRng {           // reference streams, per env
-    uint32_t *g;             // [N][32]: 31-word glibc TYPE_3 ring + front index in word 31
-    uint32_t *minstd;        // [N]
+    CHUB_G(uint32_t) g;          // [N][32]: 31-word glibc TYPE_3 ring + front index in word 31
+    CHUB_G(uint32_t) minstd;     // [N]
 };
 
 struct Tables {
-    const uint8_t *cnt[2];   // [96][1000] arrivals per station for level k (already scaled + rounded per type)
-    const uint8_t *cnt_hv;   // [96][1000]
-    const uint16_t *thr_renege;  // [kMaxLine]  queued car w stays iff level >= thr
-    const int16_t *thr_balk;     // [kBalkTab]  arrival stays iff level <= thr[line + j]
-    const double *price;     // [96]
-    const double *pvT;       // [96][100]  (transposed: one row per slot of the day)
-    const double *wdT;       // [96][150]
-    const double *hy_table;  // [102]
-    const float *soc_d_icdf; // [4097] inverse CDF of clip(N(7,3),1,10)            (PHILOX mode, tools/gen_tables.py)
-    const uint32_t *late_thr;// [16]   2^32 * CDF of max(0, round(N(2,2)))          (PHILOX mode)
-    const float *normal_icdf;// [4097] inverse CDF of N(0,1), and
-    const float *normal_tail;// [4097] its second level for the lowest / highest cell   (PHILOX mode)
-    const double *sin96;     // [96]   sin(2*pi*t/96), the time feature of the observation (MGR:319-320)
-    const float *ttab[2];    // [1000] soc_to_time(target level k) of station k's curve (target = 80 + 20*k/999)
+    CHUB_G(const uint8_t) cnt[2];     // [96][1000] arrivals per station for level k (already scaled + rounded per type)
+    CHUB_G(const uint8_t) cnt_hv;     // [96][1000]
+    CHUB_G(const uint16_t) thr_renege;  // [kMaxLine]  queued car w stays iff level >= thr
+    CHUB_G(const int16_t) thr_balk;     // [kBalkTab]  arrival stays iff level <= thr[line + j]
+    CHUB_G(const double) price;       // [96]
+    CHUB_G(const double) pvT;         // [96][100]  (transposed: one row per slot of the day)
+    CHUB_G(const double) wdT;         // [96][150]
+    CHUB_G(const double) hy_table;    // [102]
+    CHUB_G(const float) soc_d_icdf;   // [4097] inverse CDF of clip(N(7,3),1,10)            (PHILOX mode, tools/gen_tables.py)
+    CHUB_G(const uint32_t) late_thr;  // [16]   2^32 * CDF of max(0, round(N(2,2)))          (PHILOX mode)
+    CHUB_G(const float) normal_icdf;  // [4097] inverse CDF of N(0,1), and
+    CHUB_G(const float) normal_tail;  // [4097] its second level for the lowest / highest cell   (PHILOX mode)
+    CHUB_G(const double) sin96;       // [96]   sin(2*pi*t/96), the time feature of the observation (MGR:319-320)
+    CHUB_G(const float) ttab[2];      // [1000] soc_to_time(target level k) of station k's curve (target = 80 + 20*k/999)
 };
 
 struct HubParams {
@@ -102,6 +115,7 @@ struct HubParams {
     int32_t S[2];
     int32_t type[2];
     int32_t H[2];            // lanes per (env, station) unit: pow2 >= max(1, S_k), <= 64
+    int32_t logH[2];
     int64_t base[2];         // slot-array offset of station k
     int32_t obs_dim, act_dim;
     int32_t constant_charging;

@@ -218,15 +218,19 @@ struct SlotRegs {
 // Phase 1: load, urgency, feasibility / on-off, car_step, departure (CHS.hpp:1188-1202 / 1499-1513)
 template <int TYPE>
 __device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, SlotRegs &r,
-                                             int64_t idx, int64_t env, int hub_slot, bool cp) {
+                                             uint32_t idx, uint32_t act_idx, bool cp) {
+    // all five loads go out together (the action is needed only for occupied slots, but waiting for the occupancy
+    // byte first would put two HBM latencies in series)
     r.power = sl.power[idx];
     r.t_target = sl.t_target[idx];
     r.t_soc = sl.t_soc[idx];
-    r.tl = sl.tl[idx] & 127;
+    uint32_t tlb = sl.tl[idx];
+    float a = sa.actions[act_idx];
+    asm volatile("" : "+v"(a), "+v"(tlb));
+    r.tl = (int) (tlb & 127u);
     r.car = r.tl > 0;
     // action_to_real (MGR:384-393): (a+1)/2 >= 0.5 on the f32 array
-    const float a = sa.actions[env * hp.act_dim + hub_slot];
-    const bool act_on = __fdiv_rn(__fadd_rn(a, 1.0f), 2.0f) >= 0.5f;
+    const bool act_on = __fmul_rn(__fadd_rn(a, 1.0f), 0.5f) >= 0.5f;
     // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373)
     const bool on = r.car && (act_on || must_charge(r.t_target, r.t_soc, r.tl));
     if (on && !(hp.ablate & 2)) {  // car_step (CHS.hpp:900-905 / 1065-1070)
@@ -277,17 +281,19 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     constexpr int WAVES = BLOCK / 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int H = hp.H[k], S = hp.S[k];
-    const int upw = 64 / H;
-    const int uiw = lane / H;
+    const int H = hp.H[k], S = hp.S[k], logH = hp.logH[k];
+    const int upw = 64 >> logH;
+    const int uiw = lane >> logH;
     const int slot = lane & (H - 1);
     const int64_t N = hp.n_envs;
-    const int64_t env = block_local * (int64_t) (WAVES * upw) + wave * upw + uiw;
-    const bool unit_ok = env < N;
+    // 32-bit indices: n_envs * (piles + 2) < 2^31 is checked at create
+    const int env_first = (int) block_local * (WAVES * upw);
+    const int env = env_first + wave * upw + uiw;
+    const bool unit_ok = env < (int) N;
     const bool valid = unit_ok && slot < S;
-    const uint64_t unit_mask = (H == 64) ? ~0ull : (((1ull << H) - 1ull) << (uiw * H));
-    const int64_t idx = hp.base[k] + env * S + slot;
-    const int64_t sidx = (int64_t) k * N + env;
+    const uint64_t unit_mask = (H == 64) ? ~0ull : (((1ull << H) - 1ull) << (uiw << logH));
+    const uint32_t idx = (uint32_t) hp.base[k] + (uint32_t) env * (uint32_t) S + (uint32_t) slot;
+    const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
     const int hub_slot = (k ? hp.S[0] : 0) + slot;
     const bool cp = hp.constant_charging != 0;
 
@@ -295,7 +301,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     r.power = r.t_target = r.t_soc = r.soc_new = 0.0f;
     r.tl = 0;
     r.car = r.charge = r.soc_dirty = r.leave = false;
-    if (!RESET && valid) slot_advance<TYPE>(hp, sa, sl, r, idx, env, hub_slot, cp);
+    if (!RESET && valid) slot_advance<TYPE>(hp, sa, sl, r, idx, (uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot, cp);
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): arrivals, renege, balk, admission
     const bool empty = valid && !r.car;
@@ -365,7 +371,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         for (uint32_t i = tid; i < n_adm; i += BLOCK) {
             const int src = (int) q_item[i];
             const int s_lane = src & 63, s_wave = src >> 6;
-            const int64_t s_env = block_local * (int64_t) (WAVES * upw) + s_wave * upw + s_lane / H;
+            const int s_env = env_first + s_wave * upw + (s_lane >> logH);
             const int s_hub_slot = (k ? hp.S[0] : 0) + (s_lane & (H - 1));
             PhiloxCtx p2{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + s_env)};
             const U4 o = p2.block(SITE_SOC, (uint32_t) s_hub_slot, 0);  // word 0 SoC, 1 target level, 2 extra stay
@@ -394,7 +400,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         // parks the per-admission variates in LDS, indexed by admission rank.
         float *lds_soc = lds_f;
         uint32_t *lds_lev = lds_u, *lds_late = lds_u + BLOCK;
-        const int lbase = wave * 64 + uiw * H;
+        const int lbase = wave * 64 + (uiw << logH);
         int2 fa = make_int2(0, 0);
         int new_line = line;
         if (unit_ok && slot == 0) {
@@ -431,7 +437,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
             rs.store(cr, env);
             fa = make_int2(fl, as);
         }
-        const int leader = uiw * H;
+        const int leader = uiw << logH;
         flow = __shfl(fa.x, leader);
         assign = __shfl(fa.y, leader);
         line = __shfl(new_line, leader);
@@ -461,7 +467,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         // the reference adds slot powers sequentially in f32 (CHS.hpp:1244-1255): same order, same roundings
         const float v_min = urgent ? r.power : 0.0f, v_max = r.car ? r.power : 0.0f;
         const float v_chg = r.charge ? r.power : 0.0f;
-        const int ubase = uiw * H;
+        const int ubase = uiw << logH;
         r_min = r_max = r_chg = 0.0f;
         for (int i = 0; i < S; i++) {
             r_max = __fadd_rn(r_max, __shfl(v_max, ubase + i));
@@ -599,7 +605,7 @@ __device__ __forceinline__ void draw_arrivals_ahead(const HubParams &hp, const T
 
 #define CHUB_TEL(i, v)                                        \
     do {                                                      \
-        if (hp.telemetry) ev.telem[(int64_t) (i) * N + env] = (v); \
+        if (hp.telemetry) ev.telem[(size_t) (i) * (size_t) N + (size_t) env] = (v); \
     } while (0)
 
 // Blocks [0, nb_env) run the per-env tail (lane = env); in PHILOX mode blocks [nb_env, ...) draw the next step's
@@ -621,6 +627,53 @@ __global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, Ste
         }
         return;
     }
+    // ---- prefetch: every per-env input is requested before the table staging and its barrier, and the PHILOX
+    // words that do not depend on state (FCEV arrival level, the three OU normals) are drawn here too, so the
+    // memory latencies of this latency-bound kernel overlap instead of queueing behind one another.
+    const int env = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+    const bool live = env < (int) N;
+    const uint32_t e32 = (uint32_t) env, n32 = (uint32_t) N;
+    PhiloxCtx px{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env)};
+    double cap = 0.0, in_re_wd = 0.0, in_re_pv = 0.0, in_price_next = 0.0, in_price_noise = 0.0;
+    double ou_pv = 0.0, ou_wd = 0.0, ou_price = 0.0, z_pv = 0.0, z_wd = 0.0, z_pr = 0.0;
+    float a_el_f = 0.0f, a_fc_f = 0.0f, P0f = 0.0f, P1f = 0.0f, mn0 = 0.0f, mx0 = 0.0f, mn1 = 0.0f, mx1 = 0.0f;
+    int pv_day = 0, wd_day = 0, q_len = 0, hv_line = 0, F0i = 0, F1i = 0, ln0 = 0, ln1 = 0, hv_lev = 0;
+    if (live) {
+        ou_pv = ev.ou[e32];
+        ou_wd = ev.ou[n32 + e32];
+        ou_price = ev.ou[2u * n32 + e32];
+        in_price_noise = ev.price_noise[e32];
+        mn0 = st.min_p[e32]; P0f = st.chg_p[e32]; mx0 = st.max_p[e32]; ln0 = st.line[e32];
+        mn1 = st.min_p[n32 + e32]; P1f = st.chg_p[n32 + e32]; mx1 = st.max_p[n32 + e32]; ln1 = st.line[n32 + e32];
+        if (!RESET) {
+            const int S = hp.S[0] + hp.S[1];
+            const uint32_t ai = e32 * (uint32_t) hp.act_dim + (uint32_t) S;
+            a_el_f = sa.actions[ai];
+            a_fc_f = sa.actions[ai + 1u];
+            cap = ev.cap[e32];
+            in_re_wd = ev.re_wd[e32];
+            in_re_pv = ev.re_pv[e32];
+            in_price_next = ev.price_next[e32];
+            pv_day = ev.pv_day[e32];
+            wd_day = ev.wd_day[e32];
+            q_len = ev.q_len[e32];
+            hv_line = ev.hv_line[e32];
+            F0i = st.flow_in[e32];
+            F1i = st.flow_in[n32 + e32];
+        }
+        if (MODE == MODE_PHILOX) {
+            const U4 ow = px.block(SITE_OU, 0, 0);  // word 0 pv, 1 wind, 2 price
+            z_pv = (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[0]);
+            z_wd = (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[1]);
+            z_pr = (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[2]);
+            if (!RESET) hv_lev = (int) (px.block(SITE_HV, 0, 0).v[0] % 1000u);
+        } else {
+            z_pv = sa.exo_z[e32 * 3u + 0u];
+            z_wd = sa.exo_z[e32 * 3u + 1u];
+            z_pr = sa.exo_z[e32 * 3u + 2u];
+        }
+    }
+
     __shared__ double s_pv[100], s_wd[150], s_hy[102];
     __shared__ uint8_t s_hv[kLevels];
     for (int i = threadIdx.x; i < 100; i += blockDim.x) s_pv[i] = tb.pvT[t_next * 100 + i];
@@ -630,46 +683,38 @@ __global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, Ste
         for (int i = threadIdx.x; i < kLevels; i += blockDim.x) s_hv[i] = tb.cnt_hv[sa.t * kLevels + i];
     }
     __syncthreads();
+    if (!live) return;
 
-    const int64_t env = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= N) return;
-    PhiloxCtx px{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env)};
     CompatStream rs;
     if (MODE == MODE_COMPAT && !RESET) rs.load(cr, env);
 
     const double cap_mass = hp.cap_mass;
-    double cap, store_soc, reward = 0.0;
-    int pv_day, wd_day;
+    double store_soc, reward = 0.0;
 
     if (RESET) {
         // renew_reset (REN:51-53) + hy_reset (HYD:197-208)
         if (MODE == MODE_COMPAT) {
-            pv_day = sa.exo_days[env * 2 + 0];
-            wd_day = sa.exo_days[env * 2 + 1];
+            pv_day = sa.exo_days[e32 * 2u + 0u];
+            wd_day = sa.exo_days[e32 * 2u + 1u];
         } else {
             const U4 o = px.block(SITE_DAY, 0, 0);
             pv_day = (int) (o.v[0] % 100u);
             wd_day = (int) (o.v[1] % 150u);
         }
-        ev.pv_day[env] = (int16_t) pv_day;
-        ev.wd_day[env] = (int16_t) wd_day;
-        ev.q_len[env] = 0;
-        ev.hv_line[env] = 0;
+        ev.pv_day[e32] = (int16_t) pv_day;
+        ev.wd_day[e32] = (int16_t) wd_day;
+        ev.q_len[e32] = 0;
+        ev.hv_line[e32] = 0;
         cap = hp.init_soc * cap_mass;
         store_soc = hp.init_soc;
         CHUB_TEL(4, cap);
     } else {
-        pv_day = ev.pv_day[env];
-        wd_day = ev.wd_day[env];
-        cap = ev.cap[env];
-        const int S = hp.S[0] + hp.S[1];
-        const float *act = sa.actions + env * hp.act_dim;
-        const double a_el = ((double) act[S] + 1) / 2;      // action_real[-1] <- action[-2]  (MGR:400-403)
-        const double a_fc = ((double) act[S + 1] + 1) / 2;  // action_real[-2] <- action[-1]  (MGR:395-398)
-        const double P0 = (double) st.chg_p[env], P1 = (double) st.chg_p[N + env];
-        const double F0 = (double) st.flow_in[env], F1 = (double) st.flow_in[N + env];
-        double re_new_power = ev.re_wd[env] + ev.re_pv[env];  // MGR:143
-        const double charging_power = 0.0 + P0 + P1;          // MGR:157
+        const double a_el = ((double) a_el_f + 1) / 2;  // action_real[-1] <- action[-2]  (MGR:400-403)
+        const double a_fc = ((double) a_fc_f + 1) / 2;  // action_real[-2] <- action[-1]  (MGR:395-398)
+        const double P0 = (double) P0f, P1 = (double) P1f;
+        const double F0 = (double) F0i, F1 = (double) F1i;
+        double re_new_power = in_re_wd + in_re_pv;    // MGR:143
+        const double charging_power = 0.0 + P0 + P1;  // MGR:157
         // ---- electrolyser request clamp against the grid limit (MGR:160-180)
         double hy_power_limit = 2000 + re_new_power - charging_power;
         hy_power_limit = hy_power_limit > 0 ? hy_power_limit : 0.0;
@@ -683,13 +728,9 @@ __global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, Ste
             act_el = (ind >= 102 || ind == 0) ? 0.01 * 100 : 0.01 * (ind - 1);
         }
         // ---- hvs_step (HYD:253-285): FCEV arrivals -> J2601 -> 15-minute FIFO
-        int q_len = ev.q_len[env];
-        int hv_line = ev.hv_line[env];
-        double *qt = ev.q_time + env * kQCap, *qm = ev.q_mass + env * kQCap;
-        int lev;
-        if (MODE == MODE_COMPAT) lev = rs.level();
-        else lev = (int) (px.block(SITE_HV, 0, 0).v[0] % 1000u);
-        const int arrive = (int) s_hv[lev];
+        double *qt = (double *) ev.q_time + (size_t) e32 * kQCap, *qm = (double *) ev.q_mass + (size_t) e32 * kQCap;
+        if (MODE == MODE_COMPAT) hv_lev = rs.level();
+        const int arrive = (int) s_hv[hv_lev];
         double total_mass = 0.0;
         if (q_len > 0 || arrive > 0) {
             double total_time = 0.0;
@@ -713,7 +754,7 @@ __global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, Ste
                     total_time += tn;
                     total_mass += mn;
                 } else {
-                    ev.q_overflow[env] = 1;
+                    ev.q_overflow[e32] = 1;
                 }
             }
             int hv_num = 0;
@@ -738,21 +779,21 @@ __global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, Ste
                 hv_line = 0;
                 q_len = 0;
             }
-            ev.q_len[env] = (uint8_t) q_len;
-            ev.hv_line[env] = (uint8_t) hv_line;
+            ev.q_len[e32] = (uint8_t) q_len;
+            ev.hv_line[e32] = (uint8_t) hv_line;
         } else if (hv_line != 0) {
-            ev.hv_line[env] = 0;  // empty FIFO, no arrivals: total time 0 <= 15 -> line = 0 (HYD:281-283)
+            ev.hv_line[e32] = 0;  // empty FIFO, no arrivals: total time 0 <= 15 -> line = 0 (HYD:281-283)
             hv_line = 0;
         }
         const double total_mass_need = total_mass;
         // ---- hy_step (HYD:160-195): production clamp, electrolyser + compressor power, tank
-        double must_charge = cap_mass * 0.1 - cap;
-        must_charge = must_charge > 0 ? must_charge : 0.0;
+        double must_chg = cap_mass * 0.1 - cap;
+        must_chg = must_chg > 0 ? must_chg : 0.0;
         double upper_charge = cap_mass - cap;
         upper_charge = upper_charge > 0 ? upper_charge : 0.0;
         double charge_temp = act_el * hp.v_h_max * (15 * 60);
         charge_temp = charge_temp < upper_charge ? charge_temp : upper_charge;
-        charge_temp = charge_temp > must_charge ? charge_temp : must_charge;
+        charge_temp = charge_temp > must_chg ? charge_temp : must_chg;
         double flow = charge_temp / (15 * 60);
         flow = flow < hp.v_h_max ? flow : hp.v_h_max;
         double ele_power = 0.0;
@@ -827,7 +868,7 @@ __global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, Ste
         }
         const double hy_loss = -6 / 1000.0 * hy_to_use;
         // ---- incomes and reward (MGR:233-269)
-        const double real_price_dollar = ev.price_next[env] / 4;
+        const double real_price_dollar = in_price_next / 4;
         const double income_evs_fast = 0.42 / 4 * P0 - real_price_dollar * e0;
         const double income_evs_slow = 0.21 / 4 * P1 - real_price_dollar * e1;
         const double income_evs = income_evs_fast + income_evs_slow;
@@ -846,46 +887,34 @@ __global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, Ste
     }
 
     // ---- make_state (MGR:344-373): exogenous update for the NEXT slot, then the observation
-    double ou_pv = ev.ou[env], ou_wd = ev.ou[N + env], ou_price = ev.ou[2 * N + env];
-    U4 ow;
-    ow.v[0] = ow.v[1] = ow.v[2] = ow.v[3] = 0u;
-    if (MODE == MODE_PHILOX) ow = px.block(SITE_OU, 0, 0);  // word 0 pv, 1 wind, 2 price
     double temp = s_pv[pv_day];
     if (temp > 0 && (pv_day % 2) == 0) {  // REN:38-43
-        const double z = (MODE == MODE_COMPAT) ? sa.exo_z[env * 3 + 0]
-                                               : (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[0]);
-        temp += ou_sample(ou_pv, .01, 1., z) * hp.renew_fluct1;
-        ev.ou[env] = ou_pv;
+        temp += ou_sample(ou_pv, .01, 1., z_pv) * hp.renew_fluct1;
+        ev.ou[e32] = ou_pv;
     }
     const double re_pv = (temp > 0 ? temp : 0.0) * 5;
     temp = s_wd[wd_day];
-    {  // REN:45-49
-        const double z = (MODE == MODE_COMPAT) ? sa.exo_z[env * 3 + 1]
-                                               : (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[1]);
-        temp += ou_sample(ou_wd, .01, 1.5, z) * hp.renew_fluct1;
-        ev.ou[N + env] = ou_wd;
-    }
+    temp += ou_sample(ou_wd, .01, 1.5, z_wd) * hp.renew_fluct1;  // REN:45-49
+    ev.ou[n32 + e32] = ou_wd;
     const double re_wd = (temp > 0 ? temp : 0.0) * 1;
     double price_next;
     if (sa.draw_price) {  // MGR:354-357
-        const double z = (MODE == MODE_COMPAT) ? sa.exo_z[env * 3 + 2]
-                                               : (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[2]);
-        price_next = ou_sample(ou_price, .1, 0.005, z) * hp.price_fluct1;
-        ev.ou[2 * N + env] = ou_price;
-        ev.price_noise[env] = price_next;
+        price_next = ou_sample(ou_price, .1, 0.005, z_pr) * hp.price_fluct1;
+        ev.ou[2u * n32 + e32] = ou_price;
+        ev.price_noise[e32] = price_next;
         price_next += sa.price_last;
     } else {
-        price_next = sa.price_last + ev.price_noise[env];
+        price_next = sa.price_last + in_price_noise;
     }
-    ev.re_pv[env] = re_pv;
-    ev.re_wd[env] = re_wd;
-    ev.price_next[env] = price_next;
-    ev.cap[env] = cap;
+    ev.re_pv[e32] = re_pv;
+    ev.re_wd[e32] = re_wd;
+    ev.price_next[e32] = price_next;
+    ev.cap[e32] = cap;
     if (MODE == MODE_COMPAT && !RESET) rs.store(cr, env);
 
     // state_norm (MGR:318-342), written straight to the output row
-    float *obs = sa.obs + env * sa.obs_stride;
-    double *o64 = hp.telemetry ? ev.obs64 + env * hp.obs_dim : nullptr;
+    float *obs = sa.obs + (size_t) e32 * (size_t) sa.obs_stride;
+    double *o64 = hp.telemetry ? (double *) ev.obs64 + (size_t) e32 * hp.obs_dim : nullptr;
     int n = 0;
 #define CHUB_OBS(v)                    \
     do {                               \
@@ -896,16 +925,19 @@ __global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, Ste
     } while (0)
     CHUB_OBS(tb.sin96[t_next]);
     CHUB_OBS((price_next - hp.price_mean) / hp.price_std);
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        if (hp.S[k] > 0) {
-            const int64_t si = (int64_t) k * N + env;
-            const double half_range = (double) hp.transformer_limit[k] / 2;
-            CHUB_OBS(((double) st.min_p[si] - half_range) / half_range);
-            CHUB_OBS(((double) st.chg_p[si] - half_range) / half_range);
-            CHUB_OBS(((double) st.max_p[si] - half_range) / half_range);
-            CHUB_OBS((double) st.line[si] / 5);
-        }
+    if (hp.S[0] > 0) {
+        const double half_range = (double) hp.transformer_limit[0] / 2;
+        CHUB_OBS(((double) mn0 - half_range) / half_range);
+        CHUB_OBS(((double) P0f - half_range) / half_range);
+        CHUB_OBS(((double) mx0 - half_range) / half_range);
+        CHUB_OBS((double) ln0 / 5);
+    }
+    if (hp.S[1] > 0) {
+        const double half_range = (double) hp.transformer_limit[1] / 2;
+        CHUB_OBS(((double) mn1 - half_range) / half_range);
+        CHUB_OBS(((double) P1f - half_range) / half_range);
+        CHUB_OBS(((double) mx1 - half_range) / half_range);
+        CHUB_OBS((double) ln1 / 5);
     }
     CHUB_OBS(store_soc);
     CHUB_OBS(re_pv / (42 * 5));
@@ -913,12 +945,12 @@ __global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, Ste
 #undef CHUB_OBS
     if (!RESET) {
         const bool dn = (sa.t + 1) >= 96;  // MGR:271-273
-        sa.reward[env * sa.reward_stride] = (float) reward;
-        if (sa.done) sa.done[env] = (uint8_t) (dn ? 1 : 0);
-        if (sa.done_f32) sa.done_f32[env * sa.reward_stride] = dn ? 1.0f : 0.0f;
+        sa.reward[(size_t) e32 * sa.reward_stride] = (float) reward;
+        if (sa.done) sa.done[e32] = (uint8_t) (dn ? 1 : 0);
+        if (sa.done_f32) sa.done_f32[(size_t) e32 * sa.reward_stride] = dn ? 1.0f : 0.0f;
     }
     if (hp.telemetry) {
-        ev.reward64[env] = reward;
+        ev.reward64[e32] = reward;
         CHUB_TEL(3, store_soc); CHUB_TEL(16, re_pv); CHUB_TEL(17, re_wd); CHUB_TEL(18, price_next);
         CHUB_TEL(22, (double) pv_day); CHUB_TEL(23, (double) wd_day);
     }

@@ -244,6 +244,8 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     if (!cfg || !data_dir || !out) return fail(CHUB_ERR_ARG, "null argument");
     *out = nullptr;
     if (n_envs <= 0) return fail(CHUB_ERR_ARG, "n_envs must be positive");
+    if (n_envs * (int64_t) (cfg->station_list[0] + cfg->station_list[1] + 2) >= (int64_t) 1 << 31)
+        return fail(CHUB_ERR_UNSUPPORTED, "n_envs * (piles + 2) must stay below 2^31 per handle (32-bit slot indices)");
     if (rng_mode != CHUB_RNG_COMPAT && rng_mode != CHUB_RNG_PHILOX) return fail(CHUB_ERR_ARG, "unknown rng_mode");
     for (int k = 0; k < 2; k++) {
         if (cfg->station_list[k] < 0) return fail(CHUB_ERR_ARG, "station_list entries must be >= 0");
@@ -300,6 +302,8 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
         hp.S[k] = cfg->station_list[k];
         hp.type[k] = cfg->station_type_list[k];
         hp.H[k] = pow2_ge(hp.S[k] > 0 ? hp.S[k] : 1);
+        hp.logH[k] = 0;
+        while ((1 << hp.logH[k]) < hp.H[k]) hp.logH[k]++;
         active += hp.S[k] > 0;
         // transformer_limit = constant_power * charge_number in f32 (CHS.hpp:1133-1134, 1443-1444)
         float constant_power = hp.type[k] == CHUB_FAST ? (float) 36.44764034125146 : (float) 5.254973139368931;
