@@ -24,6 +24,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# kernel arguments in device memory instead of host memory: every wave's first scalar loads then stay on the GPU
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 TOTAL_ENVS = 65536
 HUB = dict(station_list=[20, 25], station_type_list=["fast", "slow"], constant_charging=False, hydro_prod_rate=100.0,

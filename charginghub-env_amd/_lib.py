@@ -2,6 +2,10 @@
 import ctypes as C
 import os
 
+# kernel arguments in device memory (read by every wave's first scalar loads); only effective when set before the
+# HIP runtime initialises, harmless otherwise
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DATA_DIR = os.path.join(_HERE, "data")
 

@@ -58,9 +58,9 @@ struct SlotArrays {          // per-slot state, f32 unless noted; index = base_k
 
 struct StationArrays {       // index = k*N + env
     CHUB_G(uint8_t) line;    // waiting queue length (Station::line) after the step
-    CHUB_G(uint8_t) line_r;       // PHILOX: queue length after the NEXT step's renege pass (drawn ahead by k_env)
+    CHUB_G(uint64_t) pk[2];       // PHILOX: packed state-independent station draws of a step (double-buffered by tick
+                                  // parity): bits 0-9 renege pass per queue position, 10-13 arrivals, 14+4j balk limit of arrival j
     CHUB_G(int8_t) flow_in;  // flow_in_number.back() of the step just simulated
-    CHUB_G(int8_t) flow_next;     // PHILOX: the NEXT step's arrivals (drawn ahead by k_env, consumed by k_slot)
     CHUB_G(uint8_t) car_number;
     CHUB_G(float) min_p;
     CHUB_G(float) chg_p;
@@ -97,6 +97,7 @@ struct Tables {
     CHUB_G(const uint8_t) cnt_hv;     // [96][1000]
     CHUB_G(const uint16_t) thr_renege;  // [kMaxLine]  queued car w stays iff level >= thr
     CHUB_G(const int16_t) thr_balk;     // [kBalkTab]  arrival stays iff level <= thr[line + j]
+    CHUB_G(const int16_t) inv_balk;     // [kLevels]   largest m with thr_balk[m] >= level (-1 if none)
     CHUB_G(const double) price;       // [96]
     CHUB_G(const double) pvT;         // [96][100]  (transposed: one row per slot of the day)
     CHUB_G(const double) wdT;         // [96][150]

@@ -207,6 +207,42 @@ __device__ __forceinline__ float normal_from_word(const float *tz, const float *
     return hi ? -z : z;
 }
 
+// PHILOX: the station-level draws of receive_car (CHS.hpp:1272-1303 / 1583-1614) do not depend on state, only their
+// use does: arrival count = table[slot of day][level]; queued car w stays iff level_w >= thr_renege[w]; arrival j stays
+// iff level_j <= thr_balk[line + j], i.e. iff line <= inv_balk[level_j] - j (thr_balk is non-increasing).  So one lane
+// per (station, env) unit draws them for the NEXT step, in extra blocks of the current k_slot launch (they overlap with
+// the slot work at no latency cost), and packs them into 64 bits:
+//   bits 0-9 renege pass bit per queue position, 10-13 arrivals n (<= 9), 14+4j (j < 9): min(11, max(0, limit_j + 1)).
+__device__ __forceinline__ uint64_t draw_station_levels(const HubParams &hp, const Tables &tb, uint32_t tick_next,
+                                                        int t_next, int k, int64_t env) {
+    // Straight-line on purpose: the six Philox blocks and the ten table look-ups are independent, so issuing them
+    // all up front gives the (few, latency-bound) waves that run this the ILP to overlap them.
+    PhiloxCtx px{hp.key[0], hp.key[1], tick_next, (uint32_t) (hp.env_id0 + env)};
+    const U4 a0 = px.block(SITE_ARRIVE, (uint32_t) k, 0), a1 = px.block(SITE_ARRIVE, (uint32_t) k, 1),
+             a2 = px.block(SITE_ARRIVE, (uint32_t) k, 2);
+    const U4 r0 = px.block(SITE_RENEGE, (uint32_t) k, 0), r1 = px.block(SITE_RENEGE, (uint32_t) k, 1),
+             r2 = px.block(SITE_RENEGE, (uint32_t) k, 2);
+    int n_in = (int) tb.cnt[k][t_next * kLevels + (int) (a0.v[0] % 1000u)];
+    // arrival j uses word 1 + j of the ARRIVE stream
+    const uint32_t bw[9] = {a0.v[1], a0.v[2], a0.v[3], a1.v[0], a1.v[1], a1.v[2], a1.v[3], a2.v[0], a2.v[1]};
+    int lim[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) lim[j] = (int) tb.inv_balk[bw[j] % 1000u];
+    const uint32_t rw[10] = {r0.v[0], r0.v[1], r0.v[2], r0.v[3], r1.v[0], r1.v[1], r1.v[2], r1.v[3], r2.v[0], r2.v[1]};
+    uint32_t lo = 0;
+#pragma unroll
+    for (int w = 0; w < kMaxLine; w++) lo |= ((int) (rw[w] % 1000u) >= (int) tb.thr_renege[w]) ? (1u << w) : 0u;
+    n_in = n_in > 9 ? 9 : n_in;  // the tables top out at round(0.15*0.2*300) = 9
+    uint64_t pk = (uint64_t) (lo | ((uint32_t) n_in << 10));
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        int l = lim[j] - j + 1;  // arrival j stays iff line + 1 <= l
+        l = l < 0 ? 0 : (l > 11 ? 11 : l);
+        pk |= (uint64_t) (j < n_in ? l : 0) << (14 + 4 * j);
+    }
+    return pk;
+}
+
 // ---------------------------------------------------------------------------------------- k_slot
 // What one lane keeps of its slot across the phases of a step.
 struct SlotRegs {
@@ -335,9 +371,19 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
                 }
                 flow = (TYPE == 0) ? n_in : true_in;
             } else {
-                // arrivals, renege and balk of this step were drawn ahead by the previous k_env (lane = env)
-                line = (int) st.line_r[sidx];
-                flow = (int) st.flow_next[sidx];
+                // this step's station-level draws were packed by the previous launch (draw_station_levels)
+                const uint64_t pk = st.pk[sa.tick & 1u][sidx];
+                line = __popc((uint32_t) pk & ((1u << line) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
+                const int n_in = (int) (pk >> 10) & 15;
+                if (TYPE == 0) {
+                    flow = n_in;  // the fast station records the un-thinned count (CHS.hpp:1617)
+                } else {
+                    int true_in = 0;  // balk pass (CHS.hpp:1297-1303): arrival j stays iff line + 1 <= limit_j and j <= S
+#pragma unroll
+                    for (int j = 0; j < 9; j++)
+                        true_in += (j < n_in && j <= S && line + 1 <= (int) ((pk >> (14 + 4 * j)) & 15)) ? 1 : 0;
+                    flow = true_in;
+                }
             }
             assign = (line + flow) < empties ? (line + flow) : empties;  // assign_car, CHS.hpp:417-430
             line = line + flow - assign;
@@ -514,7 +560,8 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
 }
 
 template <bool RESET, int MODE, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_slot(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0) {
+__global__ __launch_bounds__(BLOCK) void k_slot(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0,
+                                                int64_t nb_lev) {
     const HubParams &hp = ctx->hp;
     const SlotArrays &sl = ctx->sl;
     const StationArrays &st = ctx->st;
@@ -522,14 +569,29 @@ __global__ __launch_bounds__(BLOCK) void k_slot(const DevCtx *__restrict__ ctx, 
     const Tables &tb = ctx->tb;
     __shared__ float lds_f[5 * BLOCK];
     __shared__ uint32_t lds_u[2 * BLOCK + 1];
+    if (hp.ablate & 64) return;
     int k;
     int64_t bl;
+    int64_t bid = blockIdx.x;
+    if (MODE == MODE_PHILOX && bid < nb_lev) {
+        // the first blocks of the grid (dispatched first, so their latency hides behind the slot work): next step's
+        // station-level draws, one lane per (station, env)
+        const int64_t u = bid * BLOCK + threadIdx.x;
+        const int64_t N = hp.n_envs;
+        if (u < 2 * N && !(hp.ablate & 16)) {
+            const int kk = u >= N ? 1 : 0;
+            st.pk[(sa.tick + 1u) & 1u][u] =
+                draw_station_levels(hp, tb, sa.tick + 1u, RESET ? 0 : (sa.t + 1) % 96, kk, u - (int64_t) kk * N);
+        }
+        return;
+    }
+    bid -= nb_lev;
     if (sa.station_filter >= 0) {
         k = sa.station_filter;
-        bl = blockIdx.x;
+        bl = bid;
     } else {
-        k = ((int64_t) blockIdx.x >= nb0) ? 1 : 0;
-        bl = k ? (int64_t) blockIdx.x - nb0 : (int64_t) blockIdx.x;
+        k = (bid >= nb0) ? 1 : 0;
+        bl = k ? bid - nb0 : bid;
     }
     if (hp.type[k] == 0) slot_body<0, RESET, MODE, BLOCK>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
     else slot_body<1, RESET, MODE, BLOCK>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
@@ -568,50 +630,16 @@ __device__ __forceinline__ double ou_sample(double &state, double theta, double 
     return state;
 }
 
-// PHILOX: the station-level draws of receive_car (CHS.hpp:1272-1303 / 1583-1614) for the step that follows --
-// arrival count from the slot-of-day table, renege pass over the queue, balk pass over the arrivals.  They only
-// depend on the queue length, so one lane per (env, station) draws them here, ahead of the next k_slot, instead
-// of every slot lane of a unit repeating them.
-__device__ __forceinline__ void draw_arrivals_ahead(const HubParams &hp, const Tables &tb, const StationArrays &st,
-                                                    uint32_t tick_next, int t_next, int k, int64_t env, int64_t N) {
-    PhiloxCtx px{hp.key[0], hp.key[1], tick_next, (uint32_t) (hp.env_id0 + env)};
-    const int64_t sidx = (int64_t) k * N + env;
-    const int S = hp.S[k];
-    int line = (int) st.line[sidx];
-    const U4 w0 = px.block(SITE_ARRIVE, (uint32_t) k, 0);
-    const int n_in = (int) tb.cnt[k][t_next * kLevels + (int) (w0.v[0] % 1000u)];
-    if (line > 0) {  // queued car w stays iff u > 0.1*logf(w+1)
-        int tline = 0;
-        U4 b = w0;
-        for (int w = 0; w < line; w++) {
-            if ((w & 3) == 0) b = px.block(SITE_RENEGE, (uint32_t) k, (uint32_t) (w >> 2));
-            tline += ((int) (pick(b, w & 3) % 1000u) >= (int) tb.thr_renege[w]) ? 1 : 0;
-        }
-        line = tline;
-    }
-    int true_in = 0;
-    U4 b = w0;
-    for (int j = 0; j < n_in; j++) {  // arrival j stays iff u <= expf(-0.01*(line+j)) and j <= S
-        const int wi = 1 + j;
-        if ((wi & 3) == 0) b = px.block(SITE_ARRIVE, (uint32_t) k, (uint32_t) (wi >> 2));
-        const int m = line + j;
-        const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
-        true_in += ((int) (pick(b, wi & 3) % 1000u) <= thr && j <= S) ? 1 : 0;
-    }
-    // fast records the raw count (CHS.hpp:1617), slow the thinned one (CHS.hpp:1306)
-    st.flow_next[sidx] = (int8_t) (hp.type[k] == 0 ? n_in : true_in);
-    st.line_r[sidx] = (uint8_t) line;
-}
-
 #define CHUB_TEL(i, v)                                        \
     do {                                                      \
         if (hp.telemetry) ev.telem[(size_t) (i) * (size_t) N + (size_t) env] = (v); \
     } while (0)
 
-// Blocks [0, nb_env) run the per-env tail (lane = env); in PHILOX mode blocks [nb_env, ...) draw the next step's
-// station arrivals (lane = (station, env)).  The two parts are independent given k_slot's outputs.
+// The per-env tail of step() / reset(), lane = env.
+constexpr int kEnvBlock = 256;  // compile-time (reading blockDim.x fetches the AQL packet)
+
 template <bool RESET, int MODE>
-__global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, int nb_env) {
+__global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, int nb_env) {
     const HubParams &hp = ctx->hp;
     const StationArrays &st = ctx->st;
     const EnvArrays &ev = ctx->ev;
@@ -619,19 +647,11 @@ __global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, Ste
     const Tables &tb = ctx->tb;
     const int64_t N = hp.n_envs;
     const int t_next = RESET ? 0 : (sa.t + 1) % 96;
-    if ((int) blockIdx.x >= nb_env) {
-        const int64_t u = (int64_t) (blockIdx.x - nb_env) * blockDim.x + threadIdx.x;
-        if (u < 2 * N) {
-            const int k = u >= N ? 1 : 0;
-            draw_arrivals_ahead(hp, tb, st, sa.tick + 1u, t_next, k, u - (int64_t) k * N, N);
-        }
-        return;
-    }
     // ---- prefetch: every per-env input is requested before the table staging and its barrier, and the PHILOX
     // words that do not depend on state (FCEV arrival level, the three OU normals) are drawn here too, so the
     // memory latencies of this latency-bound kernel overlap instead of queueing behind one another.
-    const int env = (int) (blockIdx.x * blockDim.x + threadIdx.x);
-    const bool live = env < (int) N;
+    const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
+    const bool live = env < (int) N && !(hp.ablate & 32);
     const uint32_t e32 = (uint32_t) env, n32 = (uint32_t) N;
     PhiloxCtx px{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env)};
     double cap = 0.0, in_re_wd = 0.0, in_re_pv = 0.0, in_price_next = 0.0, in_price_noise = 0.0;
@@ -676,11 +696,11 @@ __global__ __launch_bounds__(256) void k_env(const DevCtx *__restrict__ ctx, Ste
 
     __shared__ double s_pv[100], s_wd[150], s_hy[102];
     __shared__ uint8_t s_hv[kLevels];
-    for (int i = threadIdx.x; i < 100; i += blockDim.x) s_pv[i] = tb.pvT[t_next * 100 + i];
-    for (int i = threadIdx.x; i < 150; i += blockDim.x) s_wd[i] = tb.wdT[t_next * 150 + i];
+    for (int i = threadIdx.x; i < 100; i += kEnvBlock) s_pv[i] = tb.pvT[t_next * 100 + i];
+    for (int i = threadIdx.x; i < 150; i += kEnvBlock) s_wd[i] = tb.wdT[t_next * 150 + i];
     if (!RESET) {
-        for (int i = threadIdx.x; i < 102; i += blockDim.x) s_hy[i] = tb.hy_table[i];
-        for (int i = threadIdx.x; i < kLevels; i += blockDim.x) s_hv[i] = tb.cnt_hv[sa.t * kLevels + i];
+        for (int i = threadIdx.x; i < 102; i += kEnvBlock) s_hy[i] = tb.hy_table[i];
+        for (int i = threadIdx.x; i < kLevels; i += kEnvBlock) s_hv[i] = tb.cnt_hv[sa.t * kLevels + i];
     }
     __syncthreads();
     if (!live) return;
@@ -1003,13 +1023,15 @@ template <bool RESET, int MODE, int BLOCK>
 static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {
     const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
     if (MODE == MODE_PHILOX) {
-        hipLaunchKernelGGL((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), 0, stream, ctx, sa, nb0);
+        const int64_t nbl = (2 * hp.n_envs + BLOCK - 1) / BLOCK;  // + next step's station-level draws
+        hipLaunchKernelGGL((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1 + nbl)), dim3(BLOCK), 0, stream, ctx, sa,
+                           nb0, nbl);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
             StepArgs s2 = sa;
             s2.station_filter = k;
             hipLaunchKernelGGL((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), 0, stream, ctx,
-                               s2, nb0);
+                               s2, nb0, (int64_t) 0);
         }
     }
 }
@@ -1032,12 +1054,12 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {
     const int nb_env = (int) ((hp.n_envs + 255) / 256);
     if (hp.rng_mode == MODE_PHILOX) {
-        const unsigned nb = (unsigned) (nb_env + (2 * hp.n_envs + 255) / 256);  // + the arrival-draw blocks
-        if (reset) hipLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(256), 0, stream, ctx, sa, nb_env);
-        else hipLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(256), 0, stream, ctx, sa, nb_env);
+        const unsigned nb = (unsigned) nb_env;
+        if (reset) hipLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ctx, sa, nb_env);
+        else hipLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ctx, sa, nb_env);
     } else {
-        if (reset) hipLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(256), 0, stream, ctx, sa, nb_env);
-        else hipLaunchKernelGGL((k_env<false, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(256), 0, stream, ctx, sa, nb_env);
+        if (reset) hipLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ctx, sa, nb_env);
+        else hipLaunchKernelGGL((k_env<false, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ctx, sa, nb_env);
     }
 }
 

@@ -56,6 +56,10 @@ struct chub_env {
     double price[96];
     double hy_table[102];
     std::vector<void *> allocs;
+    // all state and tables live in ONE device allocation (carved 256-B aligned): a few large pages instead of ~60
+    // scattered small buffers, so the latency-bound kernels do not start with a TLB miss per array
+    char *arena;
+    size_t arena_size, arena_used;
     // staging for the host-pointer entry points
     float *d_actions, *d_obs, *d_reward;
     uint8_t *d_done;
@@ -153,10 +157,15 @@ static double np_sum96(const double *a) {
 
 template <typename T>
 static int dev_alloc(chub_env *e, T **p, size_t count, bool zero = true) {
+    const size_t bytes = ((count ? count : 1) * sizeof(T) + 255) & ~(size_t) 255;
     void *q = nullptr;
-    size_t bytes = (count ? count : 1) * sizeof(T);
-    HIP_TRY(hipMalloc(&q, bytes));
-    e->allocs.push_back(q);
+    if (e->arena && e->arena_used + bytes <= e->arena_size) {
+        q = e->arena + e->arena_used;
+        e->arena_used += bytes;
+    } else {
+        HIP_TRY(hipMalloc(&q, bytes));
+        e->allocs.push_back(q);
+    }
     if (zero) HIP_TRY(hipMemset(q, 0, bytes));
     *p = (T *) q;
     return 0;
@@ -269,6 +278,8 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     e->stream = nullptr;
     e->prof_used = e->prof_cap = 0;
     e->prof_on = false;
+    e->arena = nullptr;
+    e->arena_size = e->arena_used = 0;
     auto bail = [&](int rc) {
         chub_destroy(e);
         return rc;
@@ -291,6 +302,18 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
         if (device < 0 || device >= ndev) return bail(fail(CHUB_ERR_ARG, "device ordinal out of range"));
         hipError_t he = hipSetDevice(device);
         if (he != hipSuccess) return bail(fail(CHUB_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he)));
+    }
+
+    {   // arena: generous upper bound of everything allocated below (telemetry buffers come later, separately)
+        const size_t S_tot = (size_t) (cfg->station_list[0] + cfg->station_list[1]);
+        const size_t per_env = S_tot * 40 + 2048;
+        const size_t want = (size_t) n_envs * per_env + ((size_t) 4 << 20);
+        void *q = nullptr;
+        if (!getenv("CHUB_NO_ARENA") && hipMalloc(&q, want) == hipSuccess) {
+            e->arena = (char *) q;
+            e->arena_size = want;
+            e->allocs.push_back(q);
+        }
     }
 
     HubParams &hp = e->hp;
@@ -403,6 +426,13 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
             if (level_value(k) <= stay) thr = k;
         thr_balk[m] = (int16_t) thr;
     }
+    std::vector<int16_t> inv_balk(kLevels);
+    for (int v = 0; v < kLevels; v++) {
+        int best = -1;
+        for (int m = 0; m < kBalkTab; m++)
+            if ((int) thr_balk[m] >= v) best = m;
+        inv_balk[v] = (int16_t) best;
+    }
     std::vector<double> price_v(e->price, e->price + 96), pvT(96 * 100), wdT(96 * 150);
     for (int d = 0; d < 100; d++)
         for (int t = 0; t < 96; t++) pvT[t * 100 + d] = pv[d * 96 + t];
@@ -460,6 +490,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     if ((rc = dev_upload(e, &e->tb.cnt_hv, cnt_hv))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.thr_renege, thr_renege))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.thr_balk, thr_balk))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.inv_balk, inv_balk))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.price, price_v))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.pvT, pvT))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.wdT, wdT))) return bail(rc);
@@ -478,7 +509,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
     ALLOC(e->sl.soc, NS); ALLOC(e->sl.target, NS); ALLOC(e->sl.init_soc, NS); ALLOC(e->sl.power, NS);
     ALLOC(e->sl.t_target, NS); ALLOC(e->sl.t_soc, NS); ALLOC(e->sl.tl, NS); ALLOC(e->sl.stay, NS);
-    ALLOC(e->st.line, 2 * N); ALLOC(e->st.line_r, 2 * N); ALLOC(e->st.flow_in, 2 * N); ALLOC(e->st.flow_next, 2 * N); ALLOC(e->st.car_number, 2 * N);
+    ALLOC(e->st.line, 2 * N); ALLOC(e->st.pk[0], 2 * N); ALLOC(e->st.pk[1], 2 * N); ALLOC(e->st.flow_in, 2 * N); ALLOC(e->st.car_number, 2 * N);
     ALLOC(e->st.min_p, 2 * N); ALLOC(e->st.chg_p, 2 * N); ALLOC(e->st.max_p, 2 * N);
     ALLOC(e->ev.cap, N); ALLOC(e->ev.store_soc, N); ALLOC(e->ev.ou, 3 * N); ALLOC(e->ev.price_noise, N);
     ALLOC(e->ev.re_pv, N); ALLOC(e->ev.re_wd, N); ALLOC(e->ev.price_next, N);
