@@ -35,6 +35,7 @@ SEED = 12345
 ACTION_KEY = 0xC0FFEE
 N_ACTION_BATCHES = 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+PROFILE_EVERY = 4      # HIP events around the two kernels on every 4th step of the timed region
 
 
 def algorithmic_bytes(S, D):
@@ -44,6 +45,22 @@ def algorithmic_bytes(S, D):
     slot_kernel = 36 * S + 34
     env_kernel = (36 * S + 269 + 4 * D) - slot_kernel
     return slot_kernel, env_kernel
+
+
+def measured_traffic(envs_per_gpu):
+    """HBM bytes per k_slot launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+    corrected with the calibration kernel of tools/microbench/copy4.hip) -- collected offline with this same command
+    and committed under profiles/; scaled to this run's shard size."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        rec = json.load(open(files[-1]))
+        return rec["k_slot"]["traffic_bytes_per_launch"] * envs_per_gpu / float(TOTAL_ENVS)
+    except Exception:
+        return None
 
 
 def cpu_baseline(target_seconds=12.0):
@@ -131,20 +148,31 @@ def main():
     actions = [torch.empty((per, A), dtype=torch.float32, device=dev) for _ in range(N_ACTION_BATCHES)]
     for b, a in enumerate(actions):
         v.random_actions_device(a.data_ptr(), ACTION_KEY, b, stream)
-    packed = torch.empty((per, D + 2), dtype=torch.float32, device=dev)   # obs, reward, done
+    # packed step output (obs, reward, done); two buffers so that the gather of step i (RCCL's own stream) can
+    # overlap with the kernels of step i+1, which write the other buffer
+    packed = [torch.empty((per, D + 2), dtype=torch.float32, device=dev) for _ in range(2)]
     reset_obs = torch.empty((per, D), dtype=torch.float32, device=dev)
-    gathered = None
+    gathered = [None, None]
     if world > 1 and rank == 0:
-        gathered = [torch.empty_like(packed) for _ in range(world)]
+        gathered = [[torch.empty_like(packed[0]) for _ in range(world)] for _ in range(2)]
+    pending = [None, None]
 
     def one_step(i):
+        b = i & 1
+        if pending[b] is not None:
+            pending[b].wait()  # stream-level: the step that reuses this buffer waits for its previous gather
+            pending[b] = None
         if i % 96 == 0:
             v.reset_device(reset_obs.data_ptr(), stream=stream)
-        v.step_device_packed(actions[i % N_ACTION_BATCHES].data_ptr(), packed.data_ptr(), stream=stream)
+        v.step_device_packed(actions[i % N_ACTION_BATCHES].data_ptr(), packed[b].data_ptr(), stream=stream)
         if world > 1:
-            dist.gather(packed, gather_list=gathered, dst=0)
+            pending[b] = dist.gather(packed[b], gather_list=gathered[b], dst=0, async_op=True)
 
     def fence():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -155,7 +183,7 @@ def main():
     fence()
     use_events = not args.no_events
     if use_events:
-        v.profile_begin(args.steps)
+        v.profile_begin(args.steps, every=PROFILE_EVERY)
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
@@ -171,7 +199,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     # sanity on the last outputs (rank-local): finite, done flag consistent with the clock
-    last = packed.cpu()
+    last = packed[(args.warmup + args.steps - 1) & 1].cpu()
     assert bool(torch.isfinite(last).all()), "non-finite step output"
 
     if rank == 0:
@@ -182,7 +210,7 @@ def main():
             slot_s = slot_ms / 1e3 / n_prof
             achieved = slot_b * per / slot_s / 1e9
             roofline = {"bound": "hbm", "kernel": "k_slot", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(per),
                         "algorithmic_bytes_per_launch": slot_b * per, "avg_launch_us": slot_s * 1e6,
                         "env_kernel_avg_launch_us": env_ms / n_prof * 1e3,
                         "env_kernel_algorithmic_bytes_per_launch": env_b * per}

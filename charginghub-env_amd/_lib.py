@@ -58,7 +58,7 @@ def load_library():
         "chub_step_device_packed": (I, [P, P, P, P, P]),
         "chub_random_actions_device": (I, [P, C.c_uint64, C.c_uint32, P, P]),
         "chub_sync": (I, [P]),
-        "chub_profile_begin": (I, [P, I]), "chub_profile_end": (I, [P, P, P, P]),
+        "chub_profile_begin": (I, [P, I, I]), "chub_profile_end": (I, [P, P, P, P]),
         "chub_get_slots": (I, [P, P]), "chub_get_station_scalars": (I, [P, P]), "chub_get_telemetry": (I, [P, P]),
         "chub_get_obs_f64": (I, [P, P]), "chub_get_reward_f64": (I, [P, P]), "chub_set_telemetry": (I, [P, I]),
         "chub_set_rng_compat_seeds": (I, [P, P]), "chub_set_rng_compat_state": (I, [P, P]),

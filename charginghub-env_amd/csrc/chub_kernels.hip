@@ -696,6 +696,11 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
 
     __shared__ double s_pv[100], s_wd[150], s_hy[102];
     __shared__ uint8_t s_hv[kLevels];
+    if (hp.ablate & 16384) {
+        if (live) sa.obs[(size_t) e32 * sa.obs_stride] = (float) (cap + in_re_wd + in_re_pv + in_price_next + ou_pv + ou_wd + ou_price + z_pv + z_wd + z_pr + a_el_f + a_fc_f + P0f + P1f + mn0 + mx0 + mn1 + mx1 + pv_day + wd_day + q_len + hv_line + F0i + F1i + ln0 + ln1 + hv_lev + in_price_noise);
+        return;
+    }
+    if (!(hp.ablate & 4096))
     for (int i = threadIdx.x; i < 100; i += kEnvBlock) s_pv[i] = tb.pvT[t_next * 100 + i];
     for (int i = threadIdx.x; i < 150; i += kEnvBlock) s_wd[i] = tb.wdT[t_next * 150 + i];
     if (!RESET) {
@@ -932,6 +937,10 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     ev.cap[e32] = cap;
     if (MODE == MODE_COMPAT && !RESET) rs.store(cr, env);
 
+    if (hp.ablate & 8192) {
+        sa.reward[(size_t) e32 * sa.reward_stride] = (float) (reward + store_soc + re_pv + re_wd + price_next);
+        return;
+    }
     // state_norm (MGR:318-342), written straight to the output row
     float *obs = sa.obs + (size_t) e32 * (size_t) sa.obs_stride;
     double *o64 = hp.telemetry ? (double *) ev.obs64 + (size_t) e32 * hp.obs_dim : nullptr;

@@ -69,6 +69,7 @@ struct chub_env {
     // optional per-kernel timing with HIP events on the launch stream (chub_profile_*)
     std::vector<hipEvent_t> prof_events;
     size_t prof_used, prof_cap;
+    int prof_every, prof_phase;
     bool prof_on;
 };
 
@@ -638,7 +639,11 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
     sa.done_f32 = d_done_f32;
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
-    const bool prof = e->prof_on && e->prof_used < e->prof_cap;
+    bool prof = e->prof_on && e->prof_used < e->prof_cap;
+    if (prof) {
+        prof = (e->prof_phase % e->prof_every) == 0;  // sample: the event records are not free
+        e->prof_phase++;
+    }
     hipEvent_t *pe = prof ? &e->prof_events[3 * e->prof_used] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], s));
     launch_slot(false, e->hp, e->d_ctx, sa, s);
@@ -882,8 +887,10 @@ int chub_get_rng_compat_state(chub_env *e, uint32_t *state) {
     return CHUB_OK;
 }
 
-int chub_profile_begin(chub_env *e, int max_steps) {
-    if (!e || max_steps <= 0) return fail(CHUB_ERR_ARG, "bad argument");
+int chub_profile_begin(chub_env *e, int max_steps, int every) {
+    if (!e || max_steps <= 0 || every <= 0) return fail(CHUB_ERR_ARG, "bad argument");
+    e->prof_every = every;
+    e->prof_phase = 0;
     HIP_TRY(hipSetDevice(e->device));
     while (e->prof_events.size() < (size_t) max_steps * 3) {
         hipEvent_t ev;

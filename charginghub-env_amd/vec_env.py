@@ -96,8 +96,8 @@ class VecChargingHub(object):
     def random_actions_device(self, d_actions, key, batch, stream=0):
         check(self._lib.chub_random_actions_device(self._h, int(key), int(batch), d_actions, stream or None))
 
-    def profile_begin(self, max_steps):
-        check(self._lib.chub_profile_begin(self._h, int(max_steps)))
+    def profile_begin(self, max_steps, every=1):
+        check(self._lib.chub_profile_begin(self._h, int(max_steps), int(every)))
 
     def profile_end(self):
         """-> (slot kernel ms summed, env kernel ms summed, steps covered)"""

@@ -117,10 +117,10 @@ int chub_random_actions_device(chub_env *env, uint64_t key, uint32_t batch, floa
 
 int chub_sync(chub_env *env);
 
-/* Per-kernel timing of the step: between chub_profile_begin and chub_profile_end every step (up to max_steps)
- * records HIP events on the launch stream around the slot kernel and the env kernel; _end synchronises and
- * returns the summed durations in milliseconds and the number of steps covered. */
-int chub_profile_begin(chub_env *env, int max_steps);
+/* Per-kernel timing of the step: between chub_profile_begin and chub_profile_end every `every`-th step (up to
+ * max_steps samples) records HIP events on the launch stream around the slot kernel and the env kernel; _end
+ * synchronises and returns the summed durations in milliseconds and the number of steps sampled. */
+int chub_profile_begin(chub_env *env, int max_steps, int every);
 int chub_profile_end(chub_env *env, double *slot_ms_sum, double *env_ms_sum, int *n_steps);
 
 /* ---- introspection (parity tests, `re_*` telemetry, show_situation MGR:412-414) ---------------
