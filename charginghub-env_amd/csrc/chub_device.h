@@ -56,15 +56,12 @@ struct SlotArrays {          // per-slot state, f32 unless noted; index = base_k
     CHUB_G(uint8_t) stay;    // stay_time (introspection)
 };
 
-struct StationArrays {       // index = k*N + env
-    CHUB_G(uint8_t) line;    // waiting queue length (Station::line) after the step
-    CHUB_G(uint64_t) pk[2];       // PHILOX: packed state-independent station draws of a step (double-buffered by tick
-                                  // parity): bits 0-9 renege pass per queue position, 10-13 arrivals, 14+4j balk limit of arrival j
-    CHUB_G(int8_t) flow_in;  // flow_in_number.back() of the step just simulated
-    CHUB_G(uint8_t) car_number;
-    CHUB_G(float) min_p;
-    CHUB_G(float) chg_p;
-    CHUB_G(float) max_p;
+struct StationArrays {       // unit index u = k*N + env
+    CHUB_G(uint32_t) rec;        // [2N][4] per-unit record written by k_slot: min_power, charge_power, max_power (f32 bits),
+                                 // line | flow_in << 8 | car_number << 16  (Station::line, flow_in_number.back(), car_number)
+    CHUB_G(uint64_t) pk[2];      // PHILOX: packed state-independent station draws of a step (double-buffered by tick
+                                 // parity): bits 0-9 renege pass per queue position, 10-13 arrivals, 14+4j balk limit of arrival j
+    CHUB_G(uint32_t) grp_cnt;    // [ceil(N/64)] fused tail: finished slot workgroups per 64-env group (returns to 0)
 };
 
 struct EnvArrays {           // index = env (or field*N + env)
@@ -133,7 +130,7 @@ struct HubParams {
     double renew_fluct1, price_fluct1;  // 1 + fluctuate
     double price_mean, price_std;
     float hv_rate;           // f32(f32(0.3) * f32(permeate))
-    int32_t slot_block;      // workgroup size of the PHILOX slot kernel (256 / 512 / 1024; env CHUB_SLOT_BLOCK)
+    int32_t fused;           // PHILOX: run the per-env tail inside the slot launch (env CHUB_FUSED=0 turns it off)
     int32_t ablate;          // timing experiments only (env CHUB_ABLATE): skips parts of k_slot, results are WRONG
 };
 

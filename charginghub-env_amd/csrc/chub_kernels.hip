@@ -160,6 +160,42 @@ __device__ __forceinline__ float arrive_soc_from(double normal73) {  // mk_soc, 
 
 constexpr int MODE_COMPAT = 0, MODE_PHILOX = 1;
 
+// What k_slot hands to the per-env tail for one (station, env) unit: one 16-byte record.
+struct StationRec {
+    float mn, chg, mx;  // min_power, charge_power, max_power (CHS.hpp:1257-1259)
+    uint32_t pkd;       // line | flow_in << 8 | car_number << 16
+};
+// COHERENT = the record crosses workgroups inside one launch (fused tail): relaxed agent-scope atomics compile to
+// sc1 (write-through / L1-bypassing) accesses, the form MI355X_MICROARCH.md prescribes for in-launch hand-offs.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool COHERENT>
+__device__ __forceinline__ void rec_store(CHUB_G(uint32_t) rec, uint32_t u, float mn, float chg, float mx, uint32_t pkd) {
+    u32x4 v = {__float_as_uint(mn), __float_as_uint(chg), __float_as_uint(mx), pkd};
+    CHUB_G(u32x4) p = (CHUB_G(u32x4)) (rec + 4u * u);
+    if (COHERENT) {
+        // one 16-byte write-through store (sc1).  The compiler does not count it: the caller drains vmcnt itself
+        // before signalling (fused tail hand-off).
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    } else {
+        *p = v;
+    }
+}
+template <bool COHERENT>
+__device__ __forceinline__ StationRec rec_load(CHUB_G(uint32_t) rec, uint32_t u) {
+    CHUB_G(u32x4) p = (CHUB_G(u32x4)) (rec + 4u * u);
+    u32x4 v;
+    if (COHERENT) {
+        // one 16-byte L1-bypassing load (sc1), waited for inside the statement
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    } else {
+        v = *p;
+    }
+    StationRec r;
+    r.mn = __uint_as_float(v.x); r.chg = __uint_as_float(v.y); r.mx = __uint_as_float(v.z); r.pkd = v.w;
+    return r;
+}
+
 // DPP lane exchanges for the butterfly sums.  After the xor-1 and xor-2 steps every lane of a quad holds the quad's
 // sum, so the mirror patterns (lane i <-> 7-i, i <-> 15-i) pair the same partial sums as xor 4 / xor 8 would.
 __device__ __forceinline__ float dpp_xor1(float v) {
@@ -251,6 +287,59 @@ struct SlotRegs {
     bool car, charge, soc_dirty, leave;
 };
 
+// car_step (CHS.hpp:900-905 / 1065-1070): soc and power one slot further along the curve, evaluated together.  Same
+// expressions as time_to_soc / time_to_power (chub_curves.h), but the powers of x are shared between the two
+// polynomials and each transcendental branch is skipped when no lane of the wave is in its regime.
+template <int TYPE>
+__device__ __forceinline__ void car_step_curves(float tt, bool cp, const CurveConsts &cc, float &soc, float &power) {
+    if (cp) {
+        soc = time_to_soc<TYPE>(tt, cp, cc);
+        power = time_to_power<TYPE>(tt, cp);
+        return;
+    }
+    if (TYPE == 0) {
+        const float xf = tt * 15.0f;
+        const double x = xf, t = tt;
+        const bool p1 = tt >= 0 && t < (28.7 / 15), p2 = tt >= 0 && t < (51.2 / 15);  // fast_time_to_power
+        const bool s0 = tt <= 0, s1 = t <= 28.7 / 15, s2 = t <= 51.2 / 15;            // fast_time_to_soc
+        float pw = 0.0f, sc = 100.0f;
+        if (__any(p1 || (!s0 && s1))) {
+            const double e = exp(0.053 * x);
+            if (p1) pw = (float) (0.7194 * e + 47.78);
+            if (!s0 && s1) sc = (float) ((0.7194 / 0.053) * e + 50.15 * x - (double) cc.fast_aa1_c) * cc.fast_soc_scale;
+        }
+        if (__any((!p1 && p2) || (!s0 && !s1 && s2))) {
+            const double x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x;
+            if (!p1 && p2) pw = (float) (0.0002253 * x4 - 0.03572 * x3 + 2.016 * x2 - 48.76 * x + 457.7);
+            if (!s0 && !s1 && s2)
+                sc = (float) ((0.0002253 / 5) * x5 - (0.03572 / 4) * x4 + (2.016 / 3) * x3 - (48.76 / 2) * x2 + 457.7 * x +
+                              (double) cc.fast_aa2_c) * cc.fast_soc_scale;
+        }
+        if (s0) sc = 0.0f;
+        soc = sc;
+        power = pw;
+    } else {
+        const float xf = tt / 4.0f;
+        const double x = xf, t = tt;
+        const bool p1 = t < 2.33 * 4, p2 = t < 3.67 * 4;                 // slow_time_to_power
+        const bool c0 = tt <= 0, c1 = t <= 2.33 * 4, c2 = t <= 3.67 * 4; // slow_c_hole
+        float pw = 0.0f, ch = cc.slow_c2_end;
+        if (__any(p1 || (!c0 && c1))) {
+            const double x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x;
+            if (p1) pw = (float) (-0.002056 * x4 + 0.00921 * x3 + 0.03562 * x2 + 0.02379 * x + 6.007);
+            if (!c0 && c1)
+                ch = (float) (-0.0004112 * x5 + 0.0023025 * x4 + (0.03562 / 3) * x3 + 0.011895 * x2 + 6.007 * x);
+        }
+        if (__any((!p1 && p2) || (!c0 && !c1 && c2))) {
+            if (!p1 && p2) pw = (float) ((-4.041 * x + 21.1) / (x - 0.485));
+            if (!c0 && !c1 && c2) ch = (float) (-4.041 * x + 19.140115 * log(fabs(x - 0.485)) + 11.943306312699628);
+        }
+        if (c0) ch = 0.0f;
+        soc = (float) ((double) (100.0f * ch) / 19.285746346634653);
+        power = pw;
+    }
+}
+
 // Phase 1: load, urgency, feasibility / on-off, car_step, departure (CHS.hpp:1188-1202 / 1499-1513)
 template <int TYPE>
 __device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, SlotRegs &r,
@@ -271,8 +360,7 @@ __device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs
     const bool on = r.car && (act_on || must_charge(r.t_target, r.t_soc, r.tl));
     if (on && !(hp.ablate & 2)) {  // car_step (CHS.hpp:900-905 / 1065-1070)
         const float tt = __fadd_rn(r.t_soc, 1.0f);
-        r.soc_new = time_to_soc<TYPE>(tt, cp, hp.cc);
-        r.power = time_to_power<TYPE>(tt, cp);
+        car_step_curves<TYPE>(tt, cp, hp.cc, r.soc_new, r.power);
         r.t_soc = soc_to_time<TYPE>(r.soc_new, cp);
         r.soc_dirty = true;
     }
@@ -310,7 +398,7 @@ __device__ __forceinline__ NewCar make_car(float arrive_soc, float target, float
     return c;
 }
 
-template <int TYPE, bool RESET, int MODE, int BLOCK>
+template <int TYPE, bool RESET, int MODE, int BLOCK, bool FUSED>
 __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
                           const CompatRng &cr, const Tables &tb, const int k, const int64_t block_local,
                           float *lds_f, uint32_t *lds_u) {
@@ -333,6 +421,14 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     const int hub_slot = (k ? hp.S[0] : 0) + slot;
     const bool cp = hp.constant_charging != 0;
 
+    // the unit's queue length and this step's packed station draws: requested now, together with the slot loads
+    // below, so that the wave pays one memory round trip instead of three
+    uint32_t line_in = 0;
+    uint64_t pk_in = 0;
+    if (!RESET && unit_ok) {
+        line_in = st.rec[4u * sidx + 3u] & 0xFFu;
+        if (MODE == MODE_PHILOX) pk_in = st.pk[sa.tick & 1u][sidx];
+    }
     SlotRegs r;
     r.power = r.t_target = r.t_soc = r.soc_new = 0.0f;
     r.tl = 0;
@@ -344,7 +440,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     const uint64_t be = __ballot(empty) & unit_mask;
     const int empties = __popcll(be);
     const int rank = __popcll(be & ((1ull << lane) - 1ull));
-    int line = (!RESET && unit_ok) ? (int) st.line[sidx] : 0;
+    int line = (int) line_in;
     int flow = 0, assign = 0;
     const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
     NewCar nc;
@@ -372,7 +468,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
                 flow = (TYPE == 0) ? n_in : true_in;
             } else {
                 // this step's station-level draws were packed by the previous launch (draw_station_levels)
-                const uint64_t pk = st.pk[sa.tick & 1u][sidx];
+                const uint64_t pk = pk_in;
                 line = __popc((uint32_t) pk & ((1u << line) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
                 const int n_in = (int) (pk >> 10) & 15;
                 if (TYPE == 0) {
@@ -550,16 +646,24 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         }
     }
     if (unit_ok && slot == 0) {
-        st.line[sidx] = (uint8_t) line;
-        st.flow_in[sidx] = (int8_t) flow;
-        st.car_number[sidx] = (uint8_t) cars;
-        st.min_p[sidx] = r_min;
-        st.chg_p[sidx] = r_chg;
-        st.max_p[sidx] = r_max;
+        const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) cars << 16);
+        rec_store<FUSED>(st.rec, sidx, r_min, r_chg, r_max, pkd);
     }
 }
 
-template <bool RESET, int MODE, int BLOCK>
+template <bool RESET, int MODE, bool FUSED>
+__device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
+                                         const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
+                                         const bool staged_phase_done);
+
+// FUSED (PHILOX mode): the per-env tail runs inside this launch.  Envs are grouped by 64; every slot workgroup, once
+// all its waves have drained their stores, adds 1 to the counter of each group it covers; the workgroup whose add
+// completes a group (both stations, all their workgroups) runs the tail for those 64 envs on one wave while the rest
+// of the grid is still busy with slot work -- no second launch, no kernel boundary, and the tail's latency is hidden.
+// Hand-off per MI355X_MICROARCH.md (in-launch producer -> consumer): records are written with sc1 stores, every
+// storing wave waits vmcnt(0), workgroup barrier, ONE lane does the agent-scope atomic add; the last arriver (told by
+// the value its add returned) takes an agent acquire and reads the records with sc1 loads.
+template <bool RESET, int MODE, int BLOCK, bool FUSED>
 __global__ __launch_bounds__(BLOCK) void k_slot(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0,
                                                 int64_t nb_lev) {
     const HubParams &hp = ctx->hp;
@@ -567,8 +671,10 @@ __global__ __launch_bounds__(BLOCK) void k_slot(const DevCtx *__restrict__ ctx, 
     const StationArrays &st = ctx->st;
     const CompatRng &cr = ctx->cr;
     const Tables &tb = ctx->tb;
+    constexpr int WAVES = BLOCK / 64;
     __shared__ float lds_f[5 * BLOCK];
     __shared__ uint32_t lds_u[2 * BLOCK + 1];
+    __shared__ int s_last[WAVES];
     if (hp.ablate & 64) return;
     int k;
     int64_t bl;
@@ -593,8 +699,45 @@ __global__ __launch_bounds__(BLOCK) void k_slot(const DevCtx *__restrict__ ctx, 
         k = (bid >= nb0) ? 1 : 0;
         bl = k ? bid - nb0 : bid;
     }
-    if (hp.type[k] == 0) slot_body<0, RESET, MODE, BLOCK>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
-    else slot_body<1, RESET, MODE, BLOCK>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
+    if (hp.type[k] == 0) slot_body<0, RESET, MODE, BLOCK, FUSED>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
+    else slot_body<1, RESET, MODE, BLOCK, FUSED>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
+
+    if (FUSED) {
+        const int N = (int) hp.n_envs;
+        const int upb = WAVES * (64 >> hp.logH[k]);  // envs per workgroup of this station
+        const int e0 = (int) bl * upb;
+        const int g0 = e0 >> 6;
+        const int n_groups = (N + 63) >> 6;
+        const int ng = upb >= 64 ? upb >> 6 : 1;     // groups this workgroup covers (<= WAVES)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores (incl. the sc1 records) have landed
+        __syncthreads();
+        if ((int) threadIdx.x < ng) {
+            const int g = g0 + (int) threadIdx.x;
+            int last = 0;
+            if (g < n_groups) {
+                const int envs = N - (g << 6) < 64 ? N - (g << 6) : 64;
+                int expected = 0;
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) {
+                    const int upb_k = WAVES * (64 >> hp.logH[kk]);
+                    expected += upb_k >= 64 ? 1 : (envs + upb_k - 1) / upb_k;
+                }
+                const uint32_t old = __hip_atomic_fetch_add(st.grp_cnt + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = (int) old == expected - 1;
+                if (last) __hip_atomic_store(st.grp_cnt + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_last[threadIdx.x] = last;
+        }
+        __syncthreads();
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int gi = wave; gi < ng; gi += WAVES) {
+            if (s_last[gi]) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const int env = ((g0 + gi) << 6) + lane;
+                env_tail<RESET, MODE, true>(ctx, sa, env, env < N, nullptr, nullptr, nullptr, nullptr, true);
+            }
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------- k_env
@@ -638,8 +781,13 @@ __device__ __forceinline__ double ou_sample(double &state, double theta, double 
 // The per-env tail of step() / reset(), lane = env.
 constexpr int kEnvBlock = 256;  // compile-time (reading blockDim.x fetches the AQL packet)
 
-template <bool RESET, int MODE>
-__global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, int nb_env) {
+// ---- the per-env tail of step() / reset() for one env per lane.  FUSED = run at the end of k_slot by the last
+// workgroup to finish a 64-env group (station records come through sc1 loads, tables straight from L2); otherwise it is
+// the body of the stand-alone k_env (tables staged in LDS by the caller between the two phases).
+template <bool RESET, int MODE, bool FUSED>
+__device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
+                                         const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
+                                         const bool staged_phase_done) {
     const HubParams &hp = ctx->hp;
     const StationArrays &st = ctx->st;
     const EnvArrays &ev = ctx->ev;
@@ -647,11 +795,13 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     const Tables &tb = ctx->tb;
     const int64_t N = hp.n_envs;
     const int t_next = RESET ? 0 : (sa.t + 1) % 96;
+#define TAB_PV(d) (FUSED ? tb.pvT[t_next * 100 + (d)] : s_pv[d])
+#define TAB_WD(d) (FUSED ? tb.wdT[t_next * 150 + (d)] : s_wd[d])
+#define TAB_HY(i) (FUSED ? tb.hy_table[i] : s_hy[i])
+#define TAB_HV(l) (FUSED ? tb.cnt_hv[sa.t * kLevels + (l)] : s_hv[l])
     // ---- prefetch: every per-env input is requested before the table staging and its barrier, and the PHILOX
     // words that do not depend on state (FCEV arrival level, the three OU normals) are drawn here too, so the
     // memory latencies of this latency-bound kernel overlap instead of queueing behind one another.
-    const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
-    const bool live = env < (int) N && !(hp.ablate & 32);
     const uint32_t e32 = (uint32_t) env, n32 = (uint32_t) N;
     PhiloxCtx px{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env)};
     double cap = 0.0, in_re_wd = 0.0, in_re_pv = 0.0, in_price_next = 0.0, in_price_noise = 0.0;
@@ -663,8 +813,9 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
         ou_wd = ev.ou[n32 + e32];
         ou_price = ev.ou[2u * n32 + e32];
         in_price_noise = ev.price_noise[e32];
-        mn0 = st.min_p[e32]; P0f = st.chg_p[e32]; mx0 = st.max_p[e32]; ln0 = st.line[e32];
-        mn1 = st.min_p[n32 + e32]; P1f = st.chg_p[n32 + e32]; mx1 = st.max_p[n32 + e32]; ln1 = st.line[n32 + e32];
+        const StationRec r0 = rec_load<FUSED>(st.rec, e32), r1 = rec_load<FUSED>(st.rec, n32 + e32);
+        mn0 = r0.mn; P0f = r0.chg; mx0 = r0.mx; ln0 = (int) (r0.pkd & 0xFFu); F0i = (int) (int8_t) ((r0.pkd >> 8) & 0xFFu);
+        mn1 = r1.mn; P1f = r1.chg; mx1 = r1.mx; ln1 = (int) (r1.pkd & 0xFFu); F1i = (int) (int8_t) ((r1.pkd >> 8) & 0xFFu);
         if (!RESET) {
             const int S = hp.S[0] + hp.S[1];
             const uint32_t ai = e32 * (uint32_t) hp.act_dim + (uint32_t) S;
@@ -678,8 +829,6 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
             wd_day = ev.wd_day[e32];
             q_len = ev.q_len[e32];
             hv_line = ev.hv_line[e32];
-            F0i = st.flow_in[e32];
-            F1i = st.flow_in[n32 + e32];
         }
         if (MODE == MODE_PHILOX) {
             const U4 ow = px.block(SITE_OU, 0, 0);  // word 0 pv, 1 wind, 2 price
@@ -694,20 +843,17 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
         }
     }
 
-    __shared__ double s_pv[100], s_wd[150], s_hy[102];
-    __shared__ uint8_t s_hv[kLevels];
-    if (hp.ablate & 16384) {
-        if (live) sa.obs[(size_t) e32 * sa.obs_stride] = (float) (cap + in_re_wd + in_re_pv + in_price_next + ou_pv + ou_wd + ou_price + z_pv + z_wd + z_pr + a_el_f + a_fc_f + P0f + P1f + mn0 + mx0 + mn1 + mx1 + pv_day + wd_day + q_len + hv_line + F0i + F1i + ln0 + ln1 + hv_lev + in_price_noise);
-        return;
+
+    if (!FUSED) {
+        // stand-alone kernel: the caller staged the tables while the loads above were in flight
+        for (int i = threadIdx.x; i < 100; i += kEnvBlock) ((double *) s_pv)[i] = tb.pvT[t_next * 100 + i];
+        for (int i = threadIdx.x; i < 150; i += kEnvBlock) ((double *) s_wd)[i] = tb.wdT[t_next * 150 + i];
+        if (!RESET) {
+            for (int i = threadIdx.x; i < 102; i += kEnvBlock) ((double *) s_hy)[i] = tb.hy_table[i];
+            for (int i = threadIdx.x; i < kLevels; i += kEnvBlock) ((uint8_t *) s_hv)[i] = tb.cnt_hv[sa.t * kLevels + i];
+        }
+        __syncthreads();
     }
-    if (!(hp.ablate & 4096))
-    for (int i = threadIdx.x; i < 100; i += kEnvBlock) s_pv[i] = tb.pvT[t_next * 100 + i];
-    for (int i = threadIdx.x; i < 150; i += kEnvBlock) s_wd[i] = tb.wdT[t_next * 150 + i];
-    if (!RESET) {
-        for (int i = threadIdx.x; i < 102; i += kEnvBlock) s_hy[i] = tb.hy_table[i];
-        for (int i = threadIdx.x; i < kLevels; i += kEnvBlock) s_hv[i] = tb.cnt_hv[sa.t * kLevels + i];
-    }
-    __syncthreads();
     if (!live) return;
 
     CompatStream rs;
@@ -746,16 +892,16 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
         double act_el = a_el;
         int req = (int) ceil(a_el * 100);
         req = req < 0 ? 0 : (req > 101 ? 101 : req);  // actions outside [-1,1] would index out of the table
-        if (s_hy[req] > hy_power_limit) {
+        if (TAB_HY(req) > hy_power_limit) {
             int ind = 0;
-            while (ind < 102 && !(s_hy[ind] >= hy_power_limit)) ind++;
+            while (ind < 102 && !(TAB_HY(ind) >= hy_power_limit)) ind++;
             // hy_power_speed_list_input[ind - 1]; python index -1 wraps to the last entry (1.0)
             act_el = (ind >= 102 || ind == 0) ? 0.01 * 100 : 0.01 * (ind - 1);
         }
         // ---- hvs_step (HYD:253-285): FCEV arrivals -> J2601 -> 15-minute FIFO
         double *qt = (double *) ev.q_time + (size_t) e32 * kQCap, *qm = (double *) ev.q_mass + (size_t) e32 * kQCap;
         if (MODE == MODE_COMPAT) hv_lev = rs.level();
-        const int arrive = (int) s_hv[hv_lev];
+        const int arrive = (int) TAB_HV(hv_lev);
         double total_mass = 0.0;
         if (q_len > 0 || arrive > 0) {
             double total_time = 0.0;
@@ -912,13 +1058,13 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     }
 
     // ---- make_state (MGR:344-373): exogenous update for the NEXT slot, then the observation
-    double temp = s_pv[pv_day];
+    double temp = TAB_PV(pv_day);
     if (temp > 0 && (pv_day % 2) == 0) {  // REN:38-43
         temp += ou_sample(ou_pv, .01, 1., z_pv) * hp.renew_fluct1;
         ev.ou[e32] = ou_pv;
     }
     const double re_pv = (temp > 0 ? temp : 0.0) * 5;
-    temp = s_wd[wd_day];
+    temp = TAB_WD(wd_day);
     temp += ou_sample(ou_wd, .01, 1.5, z_wd) * hp.renew_fluct1;  // REN:45-49
     ev.ou[n32 + e32] = ou_wd;
     const double re_wd = (temp > 0 ? temp : 0.0) * 1;
@@ -937,10 +1083,6 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     ev.cap[e32] = cap;
     if (MODE == MODE_COMPAT && !RESET) rs.store(cr, env);
 
-    if (hp.ablate & 8192) {
-        sa.reward[(size_t) e32 * sa.reward_stride] = (float) (reward + store_soc + re_pv + re_wd + price_next);
-        return;
-    }
     // state_norm (MGR:318-342), written straight to the output row
     float *obs = sa.obs + (size_t) e32 * (size_t) sa.obs_stride;
     double *o64 = hp.telemetry ? (double *) ev.obs64 + (size_t) e32 * hp.obs_dim : nullptr;
@@ -983,6 +1125,18 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
         CHUB_TEL(3, store_soc); CHUB_TEL(16, re_pv); CHUB_TEL(17, re_wd); CHUB_TEL(18, price_next);
         CHUB_TEL(22, (double) pv_day); CHUB_TEL(23, (double) wd_day);
     }
+#undef TAB_PV
+#undef TAB_WD
+#undef TAB_HY
+#undef TAB_HV
+}
+
+template <bool RESET, int MODE>
+__global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, int nb_env) {
+    __shared__ double s_pv[100], s_wd[150], s_hy[102];
+    __shared__ uint8_t s_hv[kLevels];
+    const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
+    env_tail<RESET, MODE, false>(ctx, sa, env, env < (int) ctx->hp.n_envs, s_pv, s_wd, s_hy, s_hv, false);
 }
 
 // COMPAT only: the reference's constructor consumes draws of the two streams before the first user-visible
@@ -1028,36 +1182,38 @@ static inline int64_t blocks_for(int64_t n_envs, int H, int block) {
     return (n_envs + upb - 1) / upb;
 }
 
-template <bool RESET, int MODE, int BLOCK>
+template <bool RESET, int MODE, int BLOCK, bool FUSED>
 static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {
     const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
     if (MODE == MODE_PHILOX) {
         const int64_t nbl = (2 * hp.n_envs + BLOCK - 1) / BLOCK;  // + next step's station-level draws
-        hipLaunchKernelGGL((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1 + nbl)), dim3(BLOCK), 0, stream, ctx, sa,
-                           nb0, nbl);
+        hipLaunchKernelGGL((k_slot<RESET, MODE, BLOCK, FUSED>), dim3((unsigned) (nb0 + nb1 + nbl)), dim3(BLOCK), 0, stream,
+                           ctx, sa, nb0, nbl);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
             StepArgs s2 = sa;
             s2.station_filter = k;
-            hipLaunchKernelGGL((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), 0, stream, ctx,
-                               s2, nb0, (int64_t) 0);
+            hipLaunchKernelGGL((k_slot<RESET, MODE, BLOCK, false>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), 0, stream,
+                               ctx, s2, nb0, (int64_t) 0);
         }
     }
 }
 
-void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {
+// returns true when the per-env tail ran inside the slot launch (no k_env needed)
+bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {
     if (hp.rng_mode == MODE_PHILOX) {
-        if (reset) return launch_slot_t<true, MODE_PHILOX, 256>(hp, ctx, sa, stream);
-        switch (hp.slot_block) {
-            case 64: return launch_slot_t<false, MODE_PHILOX, 64>(hp, ctx, sa, stream);
-            case 128: return launch_slot_t<false, MODE_PHILOX, 128>(hp, ctx, sa, stream);
-            case 256: return launch_slot_t<false, MODE_PHILOX, 256>(hp, ctx, sa, stream);
-            case 1024: return launch_slot_t<false, MODE_PHILOX, 1024>(hp, ctx, sa, stream);
-            default: return launch_slot_t<false, MODE_PHILOX, 512>(hp, ctx, sa, stream);
+        if (hp.fused) {
+            if (reset) launch_slot_t<true, MODE_PHILOX, 256, true>(hp, ctx, sa, stream);
+            else launch_slot_t<false, MODE_PHILOX, 256, true>(hp, ctx, sa, stream);
+            return true;
         }
+        if (reset) launch_slot_t<true, MODE_PHILOX, 256, false>(hp, ctx, sa, stream);
+        else launch_slot_t<false, MODE_PHILOX, 256, false>(hp, ctx, sa, stream);
+        return false;
     }
-    if (reset) launch_slot_t<true, MODE_COMPAT, 256>(hp, ctx, sa, stream);
-    else launch_slot_t<false, MODE_COMPAT, 256>(hp, ctx, sa, stream);
+    if (reset) launch_slot_t<true, MODE_COMPAT, 256, false>(hp, ctx, sa, stream);
+    else launch_slot_t<false, MODE_COMPAT, 256, false>(hp, ctx, sa, stream);
+    return false;
 }
 
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {

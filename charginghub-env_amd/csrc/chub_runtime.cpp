@@ -16,7 +16,7 @@
 #include "chub_device.h"
 
 namespace chub {
-void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream);
+bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream);
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream);
 void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream);
 void launch_compat_burn_fcev(const HubParams &hp, const DevCtx *ctx, int n_steps, hipStream_t stream);
@@ -340,7 +340,9 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     hp.constant_charging = cfg->constant_charging ? 1 : 0;
     hp.rng_mode = rng_mode;
     hp.telemetry = 0;
-    hp.slot_block = getenv("CHUB_SLOT_BLOCK") ? atoi(getenv("CHUB_SLOT_BLOCK")) : 256;
+    // fused tail: measured slower at every size tried (each producer workgroup pays a store drain + a returning
+    // atomic on its critical path) -- kept as an option for experiments, off by default
+    hp.fused = (rng_mode == CHUB_RNG_PHILOX && getenv("CHUB_FUSED") && atoi(getenv("CHUB_FUSED")) == 1) ? 1 : 0;
     hp.ablate = getenv("CHUB_ABLATE") ? atoi(getenv("CHUB_ABLATE")) : 0;
     hp.key[0] = (uint32_t) seed;
     hp.key[1] = (uint32_t) (seed >> 32);
@@ -510,8 +512,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
     ALLOC(e->sl.soc, NS); ALLOC(e->sl.target, NS); ALLOC(e->sl.init_soc, NS); ALLOC(e->sl.power, NS);
     ALLOC(e->sl.t_target, NS); ALLOC(e->sl.t_soc, NS); ALLOC(e->sl.tl, NS); ALLOC(e->sl.stay, NS);
-    ALLOC(e->st.line, 2 * N); ALLOC(e->st.pk[0], 2 * N); ALLOC(e->st.pk[1], 2 * N); ALLOC(e->st.flow_in, 2 * N); ALLOC(e->st.car_number, 2 * N);
-    ALLOC(e->st.min_p, 2 * N); ALLOC(e->st.chg_p, 2 * N); ALLOC(e->st.max_p, 2 * N);
+    ALLOC(e->st.rec, 8 * N); ALLOC(e->st.pk[0], 2 * N); ALLOC(e->st.pk[1], 2 * N); ALLOC(e->st.grp_cnt, (N + 63) / 64);
     ALLOC(e->ev.cap, N); ALLOC(e->ev.store_soc, N); ALLOC(e->ev.ou, 3 * N); ALLOC(e->ev.price_noise, N);
     ALLOC(e->ev.re_pv, N); ALLOC(e->ev.re_wd, N); ALLOC(e->ev.price_next, N);
     ALLOC(e->ev.pv_day, N); ALLOC(e->ev.wd_day, N); ALLOC(e->ev.q_len, N); ALLOC(e->ev.hv_line, N);
@@ -592,8 +593,7 @@ int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_ex
     sa.obs_stride = e->hp.obs_dim;
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
-    launch_slot(true, e->hp, e->d_ctx, sa, s);
-    launch_env(true, e->hp, e->d_ctx, sa, s);
+    if (!launch_slot(true, e->hp, e->d_ctx, sa, s)) launch_env(true, e->hp, e->d_ctx, sa, s);
     HIP_TRY(hipGetLastError());
     e->t = 0;
     e->price_count = 0;  // MGR:313 (after make_state)
@@ -646,9 +646,9 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
     }
     hipEvent_t *pe = prof ? &e->prof_events[3 * e->prof_used] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], s));
-    launch_slot(false, e->hp, e->d_ctx, sa, s);
+    const bool tail_done = launch_slot(false, e->hp, e->d_ctx, sa, s);
     if (prof) HIP_TRY(hipEventRecord(pe[1], s));
-    launch_env(false, e->hp, e->d_ctx, sa, s);
+    if (!tail_done) launch_env(false, e->hp, e->d_ctx, sa, s);
     if (prof) {
         HIP_TRY(hipEventRecord(pe[2], s));
         e->prof_used++;
@@ -751,19 +751,19 @@ int chub_get_station_scalars(chub_env *e, double *out) {
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t) e->hp.n_envs;
-    std::vector<uint8_t> line, cars;
-    std::vector<int8_t> flow;
-    std::vector<float> mn, ch, mx;
+    std::vector<uint32_t> rec;
     int rc;
-    if ((rc = fetch(line, e->st.line, 2 * N)) || (rc = fetch(cars, e->st.car_number, 2 * N)) ||
-        (rc = fetch(flow, e->st.flow_in, 2 * N)) || (rc = fetch(mn, e->st.min_p, 2 * N)) ||
-        (rc = fetch(ch, e->st.chg_p, 2 * N)) || (rc = fetch(mx, e->st.max_p, 2 * N)))
-        return rc;
+    if ((rc = fetch(rec, (const uint32_t *) e->st.rec, 8 * N))) return rc;
     for (size_t env = 0; env < N; env++)
         for (int k = 0; k < 2; k++) {
             double *o = out + (env * 2 + k) * 8;
-            const size_t i = (size_t) k * N + env;
-            o[0] = mn[i]; o[1] = ch[i]; o[2] = mx[i]; o[3] = cars[i]; o[4] = line[i]; o[5] = flow[i];
+            const uint32_t *r = &rec[4 * ((size_t) k * N + env)];
+            float mn, ch, mx;
+            memcpy(&mn, &r[0], 4); memcpy(&ch, &r[1], 4); memcpy(&mx, &r[2], 4);
+            o[0] = mn; o[1] = ch; o[2] = mx;
+            o[3] = (double) ((r[3] >> 16) & 0xFFu);          // car_number
+            o[4] = (double) (r[3] & 0xFFu);                  // line
+            o[5] = (double) (int8_t) ((r[3] >> 8) & 0xFFu);  // flow_in_number[-1] (can be negative right after reset)
             o[6] = e->t; o[7] = e->hp.transformer_limit[k];
         }
     return CHUB_OK;
