@@ -664,7 +664,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 // storing wave waits vmcnt(0), workgroup barrier, ONE lane does the agent-scope atomic add; the last arriver (told by
 // the value its add returned) takes an agent acquire and reads the records with sc1 loads.
 template <bool RESET, int MODE, int BLOCK, bool FUSED>
-__global__ __launch_bounds__(BLOCK) void k_slot(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0,
+__global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 7 : 1) void k_slot(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0,
                                                 int64_t nb_lev) {
     const HubParams &hp = ctx->hp;
     const SlotArrays &sl = ctx->sl;
