@@ -130,6 +130,7 @@ struct HubParams {
     double renew_fluct1, price_fluct1;  // 1 + fluctuate
     double price_mean, price_std;
     float hv_rate;           // f32(f32(0.3) * f32(permeate))
+    int32_t slot_block;      // experiments: workgroup size of the PHILOX slot kernel (128 / 256 / 512; env CHUB_SLOT_BLOCK)
     int32_t fused;           // PHILOX: run the per-env tail inside the slot launch (env CHUB_FUSED=0 turns it off)
     int32_t ablate;          // timing experiments only (env CHUB_ABLATE): skips parts of k_slot, results are WRONG
 };

@@ -283,8 +283,10 @@ __device__ __forceinline__ uint64_t draw_station_levels(const HubParams &hp, con
 // What one lane keeps of its slot across the phases of a step.
 struct SlotRegs {
     float power, t_target, t_soc, soc_new;
+    float step_tt;    // DEFER: curve time at which car_step has to be evaluated
     int tl;
     bool car, charge, soc_dirty, leave;
+    bool needs_step;  // DEFER: charging this step and still here afterwards
 };
 
 // car_step (CHS.hpp:900-905 / 1065-1070): soc and power one slot further along the curve, evaluated together.  Same
@@ -341,7 +343,10 @@ __device__ __forceinline__ void car_step_curves(float tt, bool cp, const CurveCo
 }
 
 // Phase 1: load, urgency, feasibility / on-off, car_step, departure (CHS.hpp:1188-1202 / 1499-1513)
-template <int TYPE>
+// DEFER: do not evaluate the curves here, only record that (and where) they are needed -- the caller compacts the
+// charging cars of the whole workgroup and evaluates them densely.  A car that leaves this step is wiped by
+// reset_position right after its car_step (CHS.hpp:1196-1201), so its curve evaluation is skipped altogether.
+template <int TYPE, bool DEFER>
 __device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, SlotRegs &r,
                                              uint32_t idx, uint32_t act_idx, bool cp) {
     // all five loads go out together (the action is needed only for occupied slots, but waiting for the occupancy
@@ -358,7 +363,10 @@ __device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs
     const bool act_on = __fmul_rn(__fadd_rn(a, 1.0f), 0.5f) >= 0.5f;
     // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373)
     const bool on = r.car && (act_on || must_charge(r.t_target, r.t_soc, r.tl));
-    if (on && !(hp.ablate & 2)) {  // car_step (CHS.hpp:900-905 / 1065-1070)
+    if (DEFER) {
+        r.step_tt = __fadd_rn(r.t_soc, 1.0f);
+        r.needs_step = on && r.tl > 1;
+    } else if (on) {  // car_step (CHS.hpp:900-905 / 1065-1070)
         const float tt = __fadd_rn(r.t_soc, 1.0f);
         car_step_curves<TYPE>(tt, cp, hp.cc, r.soc_new, r.power);
         r.t_soc = soc_to_time<TYPE>(r.soc_new, cp);
@@ -431,9 +439,11 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     }
     SlotRegs r;
     r.power = r.t_target = r.t_soc = r.soc_new = 0.0f;
+    r.step_tt = 0.0f;
     r.tl = 0;
-    r.car = r.charge = r.soc_dirty = r.leave = false;
-    if (!RESET && valid) slot_advance<TYPE>(hp, sa, sl, r, idx, (uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot, cp);
+    r.car = r.charge = r.soc_dirty = r.leave = r.needs_step = false;
+    if (!RESET && valid)
+        slot_advance<TYPE, MODE == MODE_PHILOX>(hp, sa, sl, r, idx, (uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot, cp);
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): arrivals, renege, balk, admission
     const bool empty = valid && !r.car;
@@ -487,31 +497,50 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         }
         if (hp.ablate & 1) assign = 0;
         adm = empty && rank < assign;
-        // ---- add_car for the admitted slots, compacted over the workgroup: the few admitted lanes of all the
-        // block's units queue up in LDS and are served densely (one lane per new car), instead of every wave
-        // running the whole arrival path for its one or two new cars.
-        uint32_t *q_cnt = lds_u;            // [1]
-        uint32_t *q_item = lds_u + 1;       // [BLOCK]  tid of the admitted lane
-        float *o_soc = lds_f;               // [BLOCK] each, indexed by the admitted lane's tid
+        // ---- the two expensive per-car jobs, compacted over the workgroup through LDS: car_step for the cars that
+        // charge this step, add_car for the newly admitted ones.  Their lanes queue up and the queues are served
+        // densely (one lane per car) instead of every wave running both curve paths for a handful of active lanes.
+        uint32_t *q_cnt = lds_u;                   // [2]  0: new cars, 1: charging cars
+        uint32_t *q_new = lds_u + 2;               // [BLOCK]  tid of the admitted lane
+        uint32_t *q_chg = lds_u + 2 + BLOCK;       // [BLOCK]  tid of the charging lane
+        uint32_t *o_stay = lds_u + 2 + 2 * BLOCK;  // [BLOCK]
+        float *o_soc = lds_f;                      // [BLOCK] each, indexed by the owning lane's tid
         float *o_target = lds_f + BLOCK;
         float *o_tt = lds_f + 2 * BLOCK;
         float *o_ts = lds_f + 3 * BLOCK;
         float *o_pw = lds_f + 4 * BLOCK;
-        uint32_t *o_stay = lds_u + 1 + BLOCK;  // [BLOCK]
-        if (tid == 0) *q_cnt = 0;
+        float *in_tt = lds_f + 5 * BLOCK;          // [BLOCK] curve time of a charging car
+        if (tid < 2) q_cnt[tid] = 0;
         __syncthreads();
         {
-            const uint64_t ba = __ballot(adm);
-            const int na = __popcll(ba);
-            uint32_t base = 0;
-            if (lane == 0 && na) base = atomicAdd(q_cnt, (uint32_t) na);
-            base = __shfl(base, 0);
-            if (adm) q_item[base + __popcll(ba & ((1ull << lane) - 1ull))] = (uint32_t) tid;
+            const uint64_t ba = __ballot(adm), bc = __ballot(r.needs_step);
+            const int na = __popcll(ba), nc_ = __popcll(bc);
+            uint32_t base_a = 0, base_c = 0;
+            if (lane == 0) {
+                if (na) base_a = atomicAdd(&q_cnt[0], (uint32_t) na);
+                if (nc_) base_c = atomicAdd(&q_cnt[1], (uint32_t) nc_);
+            }
+            base_a = __shfl(base_a, 0);
+            base_c = __shfl(base_c, 0);
+            const uint64_t below = (1ull << lane) - 1ull;
+            if (adm) q_new[base_a + __popcll(ba & below)] = (uint32_t) tid;
+            if (r.needs_step) {
+                q_chg[base_c + __popcll(bc & below)] = (uint32_t) tid;
+                in_tt[tid] = r.step_tt;
+            }
         }
         __syncthreads();
-        const uint32_t n_adm = *q_cnt;
-        for (uint32_t i = tid; i < n_adm; i += BLOCK) {
-            const int src = (int) q_item[i];
+        const uint32_t n_adm = q_cnt[0], n_chg = q_cnt[1];
+        for (uint32_t i = tid; i < n_chg; i += BLOCK) {  // car_step (CHS.hpp:900-905 / 1065-1070), from the low waves
+            const int src = (int) q_chg[i];
+            float soc_c, pw_c;
+            car_step_curves<TYPE>(in_tt[src], cp, hp.cc, soc_c, pw_c);
+            o_soc[src] = soc_c;
+            o_pw[src] = pw_c;
+            o_ts[src] = soc_to_time<TYPE>(soc_c, cp);
+        }
+        for (uint32_t i = (uint32_t) (BLOCK - 1 - tid); i < n_adm; i += BLOCK) {  // add_car, from the high waves
+            const int src = (int) q_new[i];
             const int s_lane = src & 63, s_wave = src >> 6;
             const int s_env = env_first + s_wave * upw + (s_lane >> logH);
             const int s_hub_slot = (k ? hp.S[0] : 0) + (s_lane & (H - 1));
@@ -536,6 +565,12 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
             nc.t_soc = o_ts[tid];
             nc.power = o_pw[tid];
             nc.stay = (int) o_stay[tid];
+        }
+        if (r.needs_step) {
+            r.soc_new = o_soc[tid];
+            r.power = o_pw[tid];
+            r.t_soc = o_ts[tid];
+            r.soc_dirty = true;
         }
     } else {
         // COMPAT: the unit's first lane walks the two reference streams in the reference's order and
@@ -664,7 +699,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 // storing wave waits vmcnt(0), workgroup barrier, ONE lane does the agent-scope atomic add; the last arriver (told by
 // the value its add returned) takes an agent acquire and reads the records with sc1 loads.
 template <bool RESET, int MODE, int BLOCK, bool FUSED>
-__global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 7 : 1) void k_slot(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0,
+__global__ __launch_bounds__(BLOCK, BLOCK <= 256 ? 7 : (BLOCK == 512 ? 6 : 1)) void k_slot(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0,
                                                 int64_t nb_lev) {
     const HubParams &hp = ctx->hp;
     const SlotArrays &sl = ctx->sl;
@@ -672,8 +707,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 7 : 1) void k_slot(const DevC
     const CompatRng &cr = ctx->cr;
     const Tables &tb = ctx->tb;
     constexpr int WAVES = BLOCK / 64;
-    __shared__ float lds_f[5 * BLOCK];
-    __shared__ uint32_t lds_u[2 * BLOCK + 1];
+    __shared__ float lds_f[6 * BLOCK];
+    __shared__ uint32_t lds_u[3 * BLOCK + 2];
     __shared__ int s_last[WAVES];
     if (hp.ablate & 64) return;
     int k;
@@ -1208,6 +1243,8 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             return true;
         }
         if (reset) launch_slot_t<true, MODE_PHILOX, 256, false>(hp, ctx, sa, stream);
+        else if (hp.slot_block == 512) launch_slot_t<false, MODE_PHILOX, 512, false>(hp, ctx, sa, stream);
+        else if (hp.slot_block == 128) launch_slot_t<false, MODE_PHILOX, 128, false>(hp, ctx, sa, stream);
         else launch_slot_t<false, MODE_PHILOX, 256, false>(hp, ctx, sa, stream);
         return false;
     }

@@ -340,6 +340,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     hp.constant_charging = cfg->constant_charging ? 1 : 0;
     hp.rng_mode = rng_mode;
     hp.telemetry = 0;
+    hp.slot_block = getenv("CHUB_SLOT_BLOCK") ? atoi(getenv("CHUB_SLOT_BLOCK")) : 256;
     // fused tail: measured slower at every size tried (each producer workgroup pays a store drain + a returning
     // atomic on its critical path) -- kept as an option for experiments, off by default
     hp.fused = (rng_mode == CHUB_RNG_PHILOX && getenv("CHUB_FUSED") && atoi(getenv("CHUB_FUSED")) == 1) ? 1 : 0;
