@@ -248,7 +248,8 @@ __device__ __forceinline__ float normal_from_word(const float *tz, const float *
 // iff level_j <= thr_balk[line + j], i.e. iff line <= inv_balk[level_j] - j (thr_balk is non-increasing).  So one lane
 // per (station, env) unit draws them for the NEXT step, in extra blocks of the current k_slot launch (they overlap with
 // the slot work at no latency cost), and packs them into 64 bits:
-//   bits 0-9 renege pass bit per queue position, 10-13 arrivals n (<= 9), 14+4j (j < 9): min(11, max(0, limit_j + 1)).
+//   bits 0-9 renege pass bit per queue position, 10-13 arrivals n (<= 9), 14+4l (l = 0..10): how many of the n
+//   arrivals stay (balk pass, incl. the j <= S guard) if the queue holds l cars after the renege pass.
 __device__ __forceinline__ uint64_t draw_station_levels(const HubParams &hp, const Tables &tb, uint32_t tick_next,
                                                         int t_next, int k, int64_t env) {
     // Straight-line on purpose: the six Philox blocks and the ten table look-ups are independent, so issuing them
@@ -270,12 +271,19 @@ __device__ __forceinline__ uint64_t draw_station_levels(const HubParams &hp, con
     for (int w = 0; w < kMaxLine; w++) lo |= ((int) (rw[w] % 1000u) >= (int) tb.thr_renege[w]) ? (1u << w) : 0u;
     n_in = n_in > 9 ? 9 : n_in;  // the tables top out at round(0.15*0.2*300) = 9
     uint64_t pk = (uint64_t) (lo | ((uint32_t) n_in << 10));
+    const int S = hp.S[k];
+    int stay[kMaxLine + 1];
+#pragma unroll
+    for (int l = 0; l <= kMaxLine; l++) stay[l] = 0;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
-        int l = lim[j] - j + 1;  // arrival j stays iff line + 1 <= l
-        l = l < 0 ? 0 : (l > 11 ? 11 : l);
-        pk |= (uint64_t) (j < n_in ? l : 0) << (14 + 4 * j);
+        const int top = lim[j] - j;  // arrival j stays iff line <= top (thr_balk is non-increasing)
+        const bool counts = j < n_in && j <= S;
+#pragma unroll
+        for (int l = 0; l <= kMaxLine; l++) stay[l] += (counts && l <= top) ? 1 : 0;
     }
+#pragma unroll
+    for (int l = 0; l <= kMaxLine; l++) pk |= (uint64_t) stay[l] << (14 + 4 * l);
     return pk;
 }
 
@@ -434,7 +442,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     uint32_t line_in = 0;
     uint64_t pk_in = 0;
     if (!RESET && unit_ok) {
-        line_in = st.rec[4u * sidx + 3u] & 0xFFu;
+        line_in = st.rec[4u * sidx + 3u];  // masked after the slot loads have been issued (see slot_advance)
         if (MODE == MODE_PHILOX) pk_in = st.pk[sa.tick & 1u][sidx];
     }
     SlotRegs r;
@@ -450,7 +458,8 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     const uint64_t be = __ballot(empty) & unit_mask;
     const int empties = __popcll(be);
     const int rank = __popcll(be & ((1ull << lane) - 1ull));
-    int line = (int) line_in;
+    asm volatile("" : "+v"(line_in));
+    int line = (int) (line_in & 0xFFu);
     int flow = 0, assign = 0;
     const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
     NewCar nc;
@@ -481,15 +490,9 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
                 const uint64_t pk = pk_in;
                 line = __popc((uint32_t) pk & ((1u << line) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
                 const int n_in = (int) (pk >> 10) & 15;
-                if (TYPE == 0) {
-                    flow = n_in;  // the fast station records the un-thinned count (CHS.hpp:1617)
-                } else {
-                    int true_in = 0;  // balk pass (CHS.hpp:1297-1303): arrival j stays iff line + 1 <= limit_j and j <= S
-#pragma unroll
-                    for (int j = 0; j < 9; j++)
-                        true_in += (j < n_in && j <= S && line + 1 <= (int) ((pk >> (14 + 4 * j)) & 15)) ? 1 : 0;
-                    flow = true_in;
-                }
+                // the fast station records the un-thinned count (CHS.hpp:1617), the slow one what survives the balk
+                // pass given the queue length just computed (CHS.hpp:1297-1306)
+                flow = (TYPE == 0) ? n_in : (int) ((pk >> (14 + 4 * line)) & 15);
             }
             assign = (line + flow) < empties ? (line + flow) : empties;  // assign_car, CHS.hpp:417-430
             line = line + flow - assign;
