@@ -99,6 +99,8 @@ def cpu_baseline(target_seconds=12.0):
     steps = 96
     n = int(max(64 * cores, min(TOTAL_ENVS, rate * target_seconds / steps)))
     n -= n % cores
+    if n == TOTAL_ENVS:  # whole workload fits: add whole episodes until the sample is ~target_seconds long
+        steps = 96 * max(1, min(4, int(round(rate * target_seconds / (n * 96.0)))))
     rate = run(n, steps)
     return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs x %d steps of the same hub (oracle/chub_oracle.c, Philox streams, %d pthreads)"

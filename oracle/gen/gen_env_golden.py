@@ -206,6 +206,9 @@ def main():
     # nearly full tank: upper_charge clamp (HYD:173-176), slow/fast order swapped
     run("env_full_tank", base_kwargs(station_list=[12, 10], station_type_list=["slow", "fast"], init_soc=0.95,
                                      hydro_store_vlt=5), 1, 96, "random", (1111, 1212), py_seed=6)
+    # busy FCEV forecourt: several arrivals per step, the 15-minute FIFO carries cars over (HYD:266-279)
+    run("env_fcev_queue", base_kwargs(fcev_permeate=0.06, hydro_store_vlt=200, init_soc=0.6), 1, 45, "random",
+        (1515, 1616), py_seed=8)
     # constant-power fleet mode
     run("env_constant", base_kwargs(constant_charging=True), 1, 96, "random", (1313, 1414), py_seed=7)
 

@@ -269,7 +269,7 @@ def golden_config(g):
 
 
 GOLDEN_ENV = ["env_c1_envtest", "env_c3_random", "env_c2_random", "env_c5_random", "env_slow_only_fcev",
-              "env_clamp", "env_full_tank", "env_constant"]
+              "env_clamp", "env_full_tank", "env_constant", "env_fcev_queue"]
 
 
 class OrcEnv:
