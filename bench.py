@@ -130,13 +130,21 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # Rehearsal switch (never used by the driver): CHUB_BENCH_REHEARSE=1 runs all ranks on GPU 0 with the gloo
+    # backend (host-staged gather), to exercise the multi-rank orchestration on a one-GPU box.
+    rehearse = os.environ.get("CHUB_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL
 
     import charginghub_env_amd as chub
 
@@ -155,8 +163,9 @@ def main():
     packed = [torch.empty((per, D + 2), dtype=torch.float32, device=dev) for _ in range(2)]
     reset_obs = torch.empty((per, D), dtype=torch.float32, device=dev)
     gathered = [None, None]
+    gdev = "cpu" if rehearse else dev
     if world > 1 and rank == 0:
-        gathered = [[torch.empty_like(packed[0]) for _ in range(world)] for _ in range(2)]
+        gathered = [[torch.empty((per, D + 2), dtype=torch.float32, device=gdev) for _ in range(world)] for _ in range(2)]
     pending = [None, None]
 
     def one_step(i):
@@ -168,7 +177,8 @@ def main():
             v.reset_device(reset_obs.data_ptr(), stream=stream)
         v.step_device_packed(actions[i % N_ACTION_BATCHES].data_ptr(), packed[b].data_ptr(), stream=stream)
         if world > 1:
-            pending[b] = dist.gather(packed[b], gather_list=gathered[b], dst=0, async_op=True)
+            src = packed[b].cpu() if rehearse else packed[b]
+            pending[b] = dist.gather(src, gather_list=gathered[b], dst=0, async_op=True)
 
     def fence():
         for b in (0, 1):
@@ -197,7 +207,7 @@ def main():
         slot_ms, env_ms, n_prof = v.profile_end()
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     # sanity on the last outputs (rank-local): finite, done flag consistent with the clock
