@@ -692,7 +692,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
 template <bool RESET, int MODE, bool FUSED>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
-                                         const bool staged_phase_done);
+                                         float *s_out);
 
 // FUSED (PHILOX mode): the per-env tail runs inside this launch.  Envs are grouped by 64; every slot workgroup, once
 // all its waves have drained their stores, adds 1 to the counter of each group it covers; the workgroup whose add
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 256 ? 7 : (BLOCK == 512 ? 6 : 1)) v
             if (s_last[gi]) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 const int env = ((g0 + gi) << 6) + lane;
-                env_tail<RESET, MODE, true>(ctx, sa, env, env < N, nullptr, nullptr, nullptr, nullptr, true);
+                env_tail<RESET, MODE, true>(ctx, sa, env, env < N, nullptr, nullptr, nullptr, nullptr, nullptr);
             }
         }
     }
@@ -825,7 +825,7 @@ constexpr int kEnvBlock = 256;  // compile-time (reading blockDim.x fetches the 
 template <bool RESET, int MODE, bool FUSED>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
-                                         const bool staged_phase_done) {
+                                         float *s_out) {
     const HubParams &hp = ctx->hp;
     const StationArrays &st = ctx->st;
     const EnvArrays &ev = ctx->ev;
@@ -892,7 +892,20 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         }
         __syncthreads();
     }
-    if (!live) return;
+    // stand-alone kernel: output rows go through LDS so that the workgroup writes its kEnvBlock consecutive rows (one
+    // contiguous run of memory) with coalesced stores instead of 15 scattered 4-byte stores per lane
+    const int row_w = sa.obs_stride;  // D (dense) or D + 2 (packed: obs, reward, done)
+    auto flush_rows = [&]() {
+        __syncthreads();
+        const int env0 = (int) blockIdx.x * kEnvBlock;
+        const int rows = (int) N - env0 < kEnvBlock ? (int) N - env0 : kEnvBlock;
+        float *dst = sa.obs + (size_t) env0 * (size_t) row_w;
+        for (int i = threadIdx.x; i < rows * row_w; i += kEnvBlock) dst[i] = s_out[i];
+    };
+    // one pass of a do/while so that lanes without an env skip the work but still reach the workgroup barrier of
+    // flush_rows() at the same program point as everybody else
+    do {
+    if (!live) break;
 
     CompatStream rs;
     if (MODE == MODE_COMPAT && !RESET) rs.load(cr, env);
@@ -995,6 +1008,10 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             hv_line = 0;
         }
         const double total_mass_need = total_mass;
+        if (hp.ablate & 4096) {  // experiment: skip the H2 / money chain
+            store_soc = cap / cap_mass;
+            reward = total_mass + act_el;
+        } else {
         // ---- hy_step (HYD:160-195): production clamp, electrolyser + compressor power, tank
         double must_chg = cap_mass * 0.1 - cap;
         must_chg = must_chg > 0 ? must_chg : 0.0;
@@ -1093,6 +1110,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             CHUB_TEL(14, income_hys + income_evs + income_evs_serve + hy_cost); CHUB_TEL(15, reward);
             CHUB_TEL(19, (double) arrive); CHUB_TEL(20, (double) hv_line); CHUB_TEL(21, (double) q_len);
         }
+        }
     }
 
     // ---- make_state (MGR:344-373): exogenous update for the NEXT slot, then the observation
@@ -1122,7 +1140,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     if (MODE == MODE_COMPAT && !RESET) rs.store(cr, env);
 
     // state_norm (MGR:318-342), written straight to the output row
-    float *obs = sa.obs + (size_t) e32 * (size_t) sa.obs_stride;
+    float *obs = FUSED ? sa.obs + (size_t) e32 * (size_t) sa.obs_stride : s_out + (int) threadIdx.x * row_w;
     double *o64 = hp.telemetry ? (double *) ev.obs64 + (size_t) e32 * hp.obs_dim : nullptr;
     int n = 0;
 #define CHUB_OBS(v)                    \
@@ -1154,15 +1172,22 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 #undef CHUB_OBS
     if (!RESET) {
         const bool dn = (sa.t + 1) >= 96;  // MGR:271-273
-        sa.reward[(size_t) e32 * sa.reward_stride] = (float) reward;
-        if (sa.done) sa.done[e32] = (uint8_t) (dn ? 1 : 0);
-        if (sa.done_f32) sa.done_f32[(size_t) e32 * sa.reward_stride] = dn ? 1.0f : 0.0f;
+        if (!FUSED && sa.done_f32) {  // packed row: reward and done ride in the same LDS row
+            obs[n] = (float) reward;
+            obs[n + 1] = dn ? 1.0f : 0.0f;
+        } else {
+            sa.reward[(size_t) e32 * sa.reward_stride] = (float) reward;
+            if (sa.done) sa.done[e32] = (uint8_t) (dn ? 1 : 0);
+            if (sa.done_f32) sa.done_f32[(size_t) e32 * sa.reward_stride] = dn ? 1.0f : 0.0f;
+        }
     }
     if (hp.telemetry) {
         ev.reward64[e32] = reward;
         CHUB_TEL(3, store_soc); CHUB_TEL(16, re_pv); CHUB_TEL(17, re_wd); CHUB_TEL(18, price_next);
         CHUB_TEL(22, (double) pv_day); CHUB_TEL(23, (double) wd_day);
     }
+    } while (0);
+    if (!FUSED) flush_rows();
 #undef TAB_PV
 #undef TAB_WD
 #undef TAB_HY
@@ -1173,8 +1198,9 @@ template <bool RESET, int MODE>
 __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, int nb_env) {
     __shared__ double s_pv[100], s_wd[150], s_hy[102];
     __shared__ uint8_t s_hv[kLevels];
+    __shared__ float s_out[kEnvBlock * 16];  // output rows: obs_dim + 2 <= 15 floats
     const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
-    env_tail<RESET, MODE, false>(ctx, sa, env, env < (int) ctx->hp.n_envs, s_pv, s_wd, s_hy, s_hv, false);
+    env_tail<RESET, MODE, false>(ctx, sa, env, env < (int) ctx->hp.n_envs && !(ctx->hp.ablate & 32), s_pv, s_wd, s_hy, s_hv, s_out);
 }
 
 // COMPAT only: the reference's constructor consumes draws of the two streams before the first user-visible
