@@ -941,6 +941,73 @@ int chub_compat_replay_constructor(chub_env *e) {
     return CHUB_OK;
 }
 
+// ---- snapshot / restore (the reference cannot be pickled or deep-copied, MAIN:234) -----------
+// Blob = header + the device arena (all state arrays; the tables in it are constant and simply ride along).
+struct SnapshotHeader {
+    uint64_t magic;
+    int64_t n_envs, env_id0;
+    chub_config cfg;
+    int32_t rng_mode, t, price_count;
+    uint32_t tick;
+    uint64_t arena_used;
+    double hy_table[102];
+};
+static const uint64_t kSnapMagic = 0x43485542534e4150ull;  // "CHUBSNAP"
+
+int64_t chub_state_size(const chub_env *e) {
+    if (!e) return fail(CHUB_ERR_ARG, "null handle");
+    if (!e->arena) return fail(CHUB_ERR_UNSUPPORTED, "snapshot needs the single-arena allocation (CHUB_NO_ARENA is set)");
+    return (int64_t) (sizeof(SnapshotHeader) + e->arena_used);
+}
+
+int chub_get_state(chub_env *e, void *buf, int64_t size) {
+    if (!e || !buf) return fail(CHUB_ERR_ARG, "null argument");
+    const int64_t need = chub_state_size(e);
+    if (need < 0) return (int) need;
+    if (size < need) return fail(CHUB_ERR_ARG, "buffer too small for the snapshot");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    SnapshotHeader h;
+    memset(&h, 0, sizeof h);
+    h.magic = kSnapMagic;
+    h.n_envs = e->hp.n_envs;
+    h.env_id0 = e->hp.env_id0;
+    h.cfg = e->cfg;
+    h.rng_mode = e->hp.rng_mode;
+    h.t = e->t;
+    h.price_count = e->price_count;
+    h.tick = e->tick;
+    h.arena_used = e->arena_used;
+    memcpy(h.hy_table, e->hy_table, sizeof h.hy_table);
+    memcpy(buf, &h, sizeof h);
+    HIP_TRY(hipMemcpy((char *) buf + sizeof h, e->arena, e->arena_used, hipMemcpyDeviceToHost));
+    return CHUB_OK;
+}
+
+int chub_set_state(chub_env *e, const void *buf, int64_t size) {
+    if (!e || !buf) return fail(CHUB_ERR_ARG, "null argument");
+    const int64_t need = chub_state_size(e);
+    if (need < 0) return (int) need;
+    SnapshotHeader h;
+    if (size < (int64_t) sizeof h) return fail(CHUB_ERR_ARG, "snapshot truncated");
+    memcpy(&h, buf, sizeof h);
+    if (h.magic != kSnapMagic) return fail(CHUB_ERR_ARG, "not a chub snapshot");
+    if (h.n_envs != e->hp.n_envs || h.env_id0 != e->hp.env_id0 || h.rng_mode != e->hp.rng_mode ||
+        memcmp(&h.cfg, &e->cfg, sizeof h.cfg) != 0 || h.arena_used != e->arena_used || size < need)
+        return fail(CHUB_ERR_ARG, "snapshot was taken from a handle with a different configuration");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    // device pointers inside the arena are position-dependent: restore only into the handle's own layout, which the
+    // checks above guarantee is the same; the DevCtx block (pointers, flags) is rewritten from the host copy
+    HIP_TRY(hipMemcpy(e->arena, (const char *) buf + sizeof h, e->arena_used, hipMemcpyHostToDevice));
+    e->t = h.t;
+    e->price_count = h.price_count;
+    e->tick = h.tick;
+    memcpy(e->hy_table, h.hy_table, sizeof h.hy_table);
+    e->ctx_dirty = true;
+    return CHUB_OK;
+}
+
 int chub_set_ou_state(chub_env *e, const double *ou) {
     if (!e || !ou) return fail(CHUB_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));

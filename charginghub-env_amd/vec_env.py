@@ -166,6 +166,19 @@ class VecChargingHub(object):
         o = np.ascontiguousarray(ou, dtype=np.float64).reshape(self.n_envs, 3)
         check(self._lib.chub_set_ou_state(self._h, _ptr(o)))
 
+    def get_state(self):
+        """Snapshot of the whole simulation state as bytes (see chub_get_state)."""
+        n = self._lib.chub_state_size(self._h)
+        if n < 0:
+            check(int(n))
+        buf = np.empty(n, dtype=np.uint8)
+        check(self._lib.chub_get_state(self._h, _ptr(buf), n))
+        return buf
+
+    def set_state(self, blob):
+        b = np.ascontiguousarray(blob, dtype=np.uint8)
+        check(self._lib.chub_set_state(self._h, _ptr(b), b.size))
+
     def hy_table(self):
         out = np.zeros(102, dtype=np.float64)
         check(self._lib.chub_get_hy_table(self._h, _ptr(out)))

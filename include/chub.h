@@ -153,6 +153,13 @@ int chub_compat_replay_constructor(chub_env *env);
 /* Persistent OU states (never reset by the reference, MGR:304-316): [N][3] f64 pv, wd, price. */
 int chub_set_ou_state(chub_env *env, const double *ou);
 
+/* Snapshot / restore of the whole simulation state (clock, streams, every slot and env variable): checkpoint /
+ * resume, planners that branch from a state.  The reference cannot do this (pickling disabled, main.cpp:234; raw
+ * back-pointers, CHS.hpp:238).  A snapshot restores only into a handle created with the same arguments. */
+int64_t chub_state_size(const chub_env *env);
+int chub_get_state(chub_env *env, void *buf, int64_t size);
+int chub_set_state(chub_env *env, const void *buf, int64_t size);
+
 /* electrolyser action->power table hy_power_speed_list[102] (HYD:154-157).  Built at create by a
  * zero-demand sweep; the reference's sweep uses live random FCEV demand, which only matters when a
  * tank clamp binds during construction -- chub_set_hy_table lets a caller install that table. */

@@ -296,3 +296,36 @@ def test_dropin_class_reproduces_env_test():
     assert abs(ret - 34.858789741560585) < 1e-9
     assert abs(env._t_Store_SOC - 0.1525) < 1e-12
     env.close()
+
+
+@pytest.mark.parametrize("rng", ["philox", "compat"])
+def test_snapshot_restore_roundtrip(rng):
+    """chub_get_state / chub_set_state: branching from a snapshot replays the same future bit for bit."""
+    chub = hub()
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.05)
+    n = 96
+    v = chub.VecChargingHub(n, seed=5, rng=rng, **kw)
+    rs = np.random.RandomState(0)
+    days = np.stack([rs.randint(0, 100, n), rs.randint(0, 150, n)], axis=1) if rng == "compat" else None
+    z = (lambda: rs.normal(size=(n, 3))) if rng == "compat" else (lambda: None)
+    v.reset(days, z())
+    acts = [rs.uniform(-1, 1, size=(n, v.act_dim)).astype(np.float32) for _ in range(40)]
+    zs = [z() for _ in range(40)]
+    for t in range(10):
+        v.step(acts[t], zs[t])
+    snap = v.get_state()
+    first = [v.step(acts[t], zs[t]) for t in range(10, 40)]
+    slots_a = v.slots()
+    v.set_state(snap)
+    assert v.clock == 10
+    second = [v.step(acts[t], zs[t]) for t in range(10, 40)]
+    slots_b = v.slots()
+    for a, b in zip(first, second):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert all(np.array_equal(x, y) for x, y in zip(slots_a, slots_b))
+    other = chub.VecChargingHub(n + 1, seed=5, rng=rng, **kw)
+    with pytest.raises(chub.ChubError):
+        other.set_state(snap)
+    other.close()
+    v.close()
