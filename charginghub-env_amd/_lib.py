@@ -56,6 +56,7 @@ def load_library():
         "chub_reset_device": (I, [P, P, P, P, P]),
         "chub_step_device": (I, [P, P, P, P, P, P, P]),
         "chub_step_device_packed": (I, [P, P, P, P, P]),
+        "chub_step_load": (I, [P, P, P, P, P, P]), "chub_step_load_device": (I, [P, P, P, P, P, P, P]),
         "chub_random_actions_device": (I, [P, C.c_uint64, C.c_uint32, P, P]),
         "chub_sync": (I, [P]),
         "chub_profile_begin": (I, [P, I, I]), "chub_profile_end": (I, [P, P, P, P]),
@@ -76,7 +77,7 @@ def load_library():
 
 
 EXPORTED = ["chub_create", "chub_destroy", "chub_obs_dim", "chub_act_dim", "chub_num_envs", "chub_clock", "chub_reset",
-            "chub_step", "chub_reset_device", "chub_step_device", "chub_step_device_packed", "chub_random_actions_device", "chub_sync", "chub_profile_begin", "chub_profile_end",
+            "chub_step", "chub_reset_device", "chub_step_device", "chub_step_device_packed", "chub_step_load", "chub_step_load_device", "chub_random_actions_device", "chub_sync", "chub_profile_begin", "chub_profile_end",
             "chub_get_slots", "chub_get_station_scalars", "chub_get_telemetry", "chub_get_obs_f64",
             "chub_get_reward_f64", "chub_set_telemetry", "chub_set_rng_compat_seeds", "chub_set_rng_compat_state", "chub_get_rng_compat_state", "chub_compat_replay_constructor", "chub_set_ou_state",
             "chub_state_size", "chub_get_state", "chub_set_state", "chub_get_hy_table", "chub_set_hy_table", "chub_last_error", "chub_device_count"]

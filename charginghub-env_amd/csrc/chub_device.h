@@ -160,6 +160,7 @@ struct StepArgs {
     uint8_t *done;           // [N] u8, or null when done_f32 is used
     float *done_f32;         // packed form: element i at done_f32 + i*reward_stride (0.0 / 1.0)
     int32_t obs_stride, reward_stride;
+    int32_t load_mode;       // scalar-load control (evs_step(float)): actions[.][0] / [.][S0] carry one kW target per station
 };
 
 }  // namespace chub

@@ -356,7 +356,7 @@ __device__ __forceinline__ void car_step_curves(float tt, bool cp, const CurveCo
 // reset_position right after its car_step (CHS.hpp:1196-1201), so its curve evaluation is skipped altogether.
 template <int TYPE, bool DEFER>
 __device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, SlotRegs &r,
-                                             uint32_t idx, uint32_t act_idx, bool cp) {
+                                             uint32_t idx, uint32_t act_idx, bool cp, int on_override) {
     // all five loads go out together (the action is needed only for occupied slots, but waiting for the occupancy
     // byte first would put two HBM latencies in series)
     r.power = sl.power[idx];
@@ -370,7 +370,8 @@ __device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs
     // action_to_real (MGR:384-393): (a+1)/2 >= 0.5 on the f32 array
     const bool act_on = __fmul_rn(__fadd_rn(a, 1.0f), 0.5f) >= 0.5f;
     // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373)
-    const bool on = r.car && (act_on || must_charge(r.t_target, r.t_soc, r.tl));
+    const bool on = on_override >= 0 ? (r.car && on_override != 0)
+                                     : (r.car && (act_on || must_charge(r.t_target, r.t_soc, r.tl)));
     if (DEFER) {
         r.step_tt = __fadd_rn(r.t_soc, 1.0f);
         r.needs_step = on && r.tl > 1;
@@ -450,8 +451,66 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     r.step_tt = 0.0f;
     r.tl = 0;
     r.car = r.charge = r.soc_dirty = r.leave = r.needs_step = false;
+    // ---- scalar-load control mode, evs_step(float) (CHS.hpp:1169-1186 / 1480-1497): one kW target per station; the
+    // piles are switched on in urgency order until the target is met (assign_on_off, CHS.hpp:1318-1362 / 1629-1674)
+    int on_override = -1;
+    if (!RESET && sa.load_mode) {
+        float pw0 = 0.0f, em0 = 0.0f;
+        bool car0 = false;
+        if (valid) {
+            pw0 = sl.power[idx];
+            const int tl0 = sl.tl[idx] & 127;
+            car0 = tl0 > 0;
+            if (car0) em0 = emergency_of(sl.t_target[idx], sl.t_soc[idx], tl0);
+        }
+        // catch_load (CHS.hpp:358-366): clamp to [min_power, max_power] of the previous calculate_output
+        float load = 0.0f;
+        if (unit_ok) {
+            const StationRec pr = rec_load<false>(st.rec, sidx);
+            load = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) (k ? hp.S[0] : 0)];
+            if (load > pr.mx) load = pr.mx;
+            else if (load < pr.mn) load = pr.mn;
+        }
+        // std::multimap keyed by -emergency (CHS.hpp:1324-1336): emergency descending, ties by slot index
+        const int ubase = uiw << logH;
+        int rk = 0;
+        for (int j = 0; j < S; j++) {
+            const float ej = __shfl(em0, ubase + j);
+            rk += (ej > em0 || (ej == em0 && j < slot)) ? 1 : 0;
+        }
+        // rank_power_add (CHS.hpp:1375-1402): cumulative power of the cars in that order, added sequentially in f32
+        float *by_rank = lds_f + wave * 64 + ubase;          // this unit's H floats
+        uint32_t *car_by_rank = lds_u + wave * 64 + ubase;
+        if (valid) {
+            by_rank[rk] = car0 ? pw0 : 0.0f;
+            car_by_rank[rk] = car0 ? 1u : 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float cum = 0.0f, mine = 0.0f;
+        int cars_before = 0, mine_before = 0;
+        for (int q = 0; q < S; q++) {
+            if (q == rk) mine_before = cars_before;
+            cum = __fadd_rn(cum, valid ? by_rank[q] : 0.0f);
+            cars_before += valid ? (int) car_by_rank[q] : 0;
+            if (q == rk) mine = cum;
+        }
+        bool chg;
+        if (cp) {  // constant-power fleet: the first round(load / constant_power) cars in order
+            const float constant_power = TYPE == 0 ? (float) 36.44764034125146 : (float) 5.254973139368931;
+            const int n_on = (int) roundf(__fdiv_rn(load, constant_power));
+            chg = car0 && mine_before < n_on;
+        } else {
+            chg = car0 && ((double) load + 0.0001 >= (double) mine);
+        }
+        on_override = chg ? 1 : 0;
+        __builtin_amdgcn_wave_barrier();
+        __syncthreads();  // the scratch areas are reused by the queues below
+    }
     if (!RESET && valid)
-        slot_advance<TYPE, MODE == MODE_PHILOX>(hp, sa, sl, r, idx, (uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot, cp);
+        slot_advance<TYPE, MODE == MODE_PHILOX>(hp, sa, sl, r, idx, (uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot, cp,
+                                                on_override);
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): arrivals, renege, balk, admission
     const bool empty = valid && !r.car;

@@ -602,7 +602,8 @@ int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_ex
 }
 
 static int step_common(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, int obs_stride,
-                       float *d_reward, int reward_stride, uint8_t *d_done, float *d_done_f32, void *stream);
+                       float *d_reward, int reward_stride, uint8_t *d_done, float *d_done_f32, void *stream,
+                       int load_mode = 0);
 
 int chub_step_device(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
                      uint8_t *d_done, void *stream) {
@@ -616,8 +617,32 @@ int chub_step_device_packed(chub_env *e, const float *d_actions, const double *d
     return step_common(e, d_actions, d_exo_z, d_packed, D + 2, d_packed + D, D + 2, nullptr, d_packed + D + 1, stream);
 }
 
+int chub_step_load_device(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
+                          uint8_t *d_done, void *stream) {
+    if (!e || !d_actions || !d_obs || !d_reward || !d_done) return fail(CHUB_ERR_ARG, "null argument");
+    return step_common(e, d_actions, d_exo_z, d_obs, e->hp.obs_dim, d_reward, 1, d_done, nullptr, stream, 1);
+}
+
+int chub_step_load(chub_env *e, const float *actions, const double *exo_z, float *obs, float *reward, uint8_t *done) {
+    if (!e || !actions || !obs || !reward || !done) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t N = (size_t) e->hp.n_envs;
+    HIP_TRY(hipMemcpy(e->d_actions, actions, N * (size_t) e->hp.act_dim * sizeof(float), hipMemcpyHostToDevice));
+    if (e->hp.rng_mode == CHUB_RNG_COMPAT) {
+        if (!exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
+        HIP_TRY(hipMemcpy(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    int rc = chub_step_load_device(e, e->d_actions, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(obs, e->d_obs, N * (size_t) e->hp.obs_dim * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(done, e->d_done, N, hipMemcpyDeviceToHost));
+    return CHUB_OK;
+}
+
 static int step_common(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, int obs_stride,
-                       float *d_reward, int reward_stride, uint8_t *d_done, float *d_done_f32, void *stream) {
+                       float *d_reward, int reward_stride, uint8_t *d_done, float *d_done_f32, void *stream,
+                       int load_mode) {
     if (e->tick == 0) return fail(CHUB_ERR_ARG, "step() before reset()");
     if (e->hp.rng_mode == CHUB_RNG_COMPAT && !d_exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
     HIP_TRY(hipSetDevice(e->device));
@@ -638,6 +663,7 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
     sa.reward_stride = reward_stride;
     sa.done = d_done;
     sa.done_f32 = d_done_f32;
+    sa.load_mode = load_mode;
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
     bool prof = e->prof_on && e->prof_used < e->prof_cap;

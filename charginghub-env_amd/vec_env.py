@@ -82,6 +82,24 @@ class VecChargingHub(object):
         check(self._lib.chub_step(self._h, _ptr(a), _ptr(z), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
         return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
 
+    def load_actions(self, loads, tail):
+        """[N, A] action array of the scalar-load mode: loads [N, 2] in kW (one per station), tail [N, 2] as in step()."""
+        a = np.zeros((self.n_envs, self.act_dim), dtype=np.float32)
+        loads = np.asarray(loads, dtype=np.float32).reshape(self.n_envs, 2)
+        if self.piles[0] > 0:
+            a[:, 0] = loads[:, 0]
+        if self.piles[1] > 0:
+            a[:, self.piles[0]] = loads[:, 1]
+        a[:, self.n_slots:] = np.asarray(tail, dtype=np.float32).reshape(self.n_envs, 2)
+        return a
+
+    def step_load(self, loads, tail, exo_z=None):
+        """Scalar-load control (the reference's evs_step(float), CHS.hpp:1169-1186 / 1480-1497): one kW target per station."""
+        a = self.load_actions(loads, tail)
+        z = None if exo_z is None else np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)).reshape(self.n_envs, 3)
+        check(self._lib.chub_step_load(self._h, _ptr(a), _ptr(z), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
+        return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
+
     # ---- device-pointer path (ints are raw device addresses, e.g. torch.Tensor.data_ptr())
     def reset_device(self, d_obs, d_exo_days=0, d_exo_z=0, stream=0):
         check(self._lib.chub_reset_device(self._h, d_exo_days or None, d_exo_z or None, d_obs, stream or None))

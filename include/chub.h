@@ -106,6 +106,15 @@ int chub_reset_device(chub_env *env, const int32_t *d_exo_days, const double *d_
 int chub_step_device(chub_env *env, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
                      uint8_t *d_done, void *stream);
 
+/* Scalar-load control mode: replaces EvcsspManagerEnv-level use of Fast/SlowChargeStation.evs_step(float)
+ * (CHS.hpp:1169-1186 / 1480-1497, bound at main.cpp:196-197,248-249): one kW target per station instead of one bit per
+ * pile; the piles are switched on in urgency order until the (clamped) target is met.  Same array layout as chub_step,
+ * with actions[i][0] = load of station 0 and actions[i][station_list[0]] = load of station 1 (kW, not normalised; the
+ * other pile entries are ignored; a station without piles has no load entry); the two tail entries keep their meaning. */
+int chub_step_load(chub_env *env, const float *actions, const double *exo_z, float *obs, float *reward, uint8_t *done);
+int chub_step_load_device(chub_env *env, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
+                          uint8_t *d_done, void *stream);
+
 /* Packed form for the multi-GPU gather: one [N, D+2] f32 buffer, row = obs[D], reward, done (0.0 / 1.0), so that
  * a shard's whole step output travels in a single RCCL gather. */
 int chub_step_device_packed(chub_env *env, const float *d_actions, const double *d_exo_z, float *d_packed, void *stream);

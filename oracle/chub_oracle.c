@@ -1112,7 +1112,23 @@ void orc_env_reset(orc_env *e, const int *exo_days, const double *exo_z, double 
 }
 
 /* MGR:136-302 step */
+static void env_step_impl(orc_env *e, const float *action, const double *exo_z, double *obs, double *reward, int *done,
+                          int load_mode);
+
 void orc_env_step(orc_env *e, const float *action, const double *exo_z, double *obs, double *reward, int *done) {
+    env_step_impl(e, action, exo_z, obs, reward, done, 0);
+}
+
+/* Scalar-load control mode: instead of one bit per pile the hub is driven with one kW target per
+ * station, evs_step(float) (CHS:1169-1186 / 1480-1497; bound at MAIN:196-197,248-249).  action[0] and
+ * action[piles[0]] carry the two loads; the tail entries keep their meaning.  The reference's gym host never takes
+ * this path (AGG:141-142 always passes a Vector_float); the rest of step() is unchanged. */
+void orc_env_step_load(orc_env *e, const float *action, const double *exo_z, double *obs, double *reward, int *done) {
+    env_step_impl(e, action, exo_z, obs, reward, done, 1);
+}
+
+static void env_step_impl(orc_env *e, const float *action, const double *exo_z, double *obs, double *reward, int *done,
+                          int load_mode) {
     e->rng.tick += 1;
     int S0 = e->cfg.piles[0], S1 = e->cfg.piles[1], S = S0 + S1;
     int time_real_next = (int) e->time_now + 1;
@@ -1126,8 +1142,13 @@ void orc_env_step(orc_env *e, const float *action, const double *exo_z, double *
     double a_fc = ((double) action[S + 1] + 1) / 2; /* action_real[-2] */
     double a_el = ((double) action[S] + 1) / 2;     /* action_real[-1] */
     /* AGG:116-155 ag_step */
-    orc_station_step(&e->st[0], &e->rng, e->tab, bits);
-    orc_station_step(&e->st[1], &e->rng, e->tab, bits + S0);
+    if (load_mode) {
+        orc_station_step_load(&e->st[0], &e->rng, e->tab, action[0]);
+        orc_station_step_load(&e->st[1], &e->rng, e->tab, action[S0]);
+    } else {
+        orc_station_step(&e->st[0], &e->rng, e->tab, bits);
+        orc_station_step(&e->st[1], &e->rng, e->tab, bits + S0);
+    }
     e->price_last = e->tab->price[e->agg_time];
     e->agg_time = (e->agg_time + 1) % 96;
     double P[2] = {(double) e->st[0].charge_power, (double) e->st[1].charge_power};
@@ -1263,6 +1284,7 @@ void orc_vec_reset(orc_vec *v, const int *exo_days, const double *exo_z, double 
 
 typedef struct {
     orc_vec *v;
+    int load_mode;
     const float *actions;
     const double *exo_z;
     double *obs, *reward;
@@ -1275,15 +1297,27 @@ static void *vec_worker(void *p) {
     orc_vec *v = j->v;
     for (long i = j->lo; i < j->hi; i++) {
         int d;
-        orc_env_step(&v->envs[i], j->actions + (long) v->act_dim * i, j->exo_z ? j->exo_z + 3 * i : NULL,
-                     j->obs + (long) v->obs_dim * i, &j->reward[i], &d);
+        env_step_impl(&v->envs[i], j->actions + (long) v->act_dim * i, j->exo_z ? j->exo_z + 3 * i : NULL,
+                      j->obs + (long) v->obs_dim * i, &j->reward[i], &d, j->load_mode);
         j->done[i] = (unsigned char) d;
     }
     return NULL;
 }
 
+static void vec_step_impl(orc_vec *v, const float *actions, const double *exo_z, double *obs, double *reward,
+                          unsigned char *done, int n_threads, int load_mode);
+
 void orc_vec_step(orc_vec *v, const float *actions, const double *exo_z, double *obs, double *reward,
                   unsigned char *done, int n_threads) {
+    vec_step_impl(v, actions, exo_z, obs, reward, done, n_threads, 0);
+}
+void orc_vec_step_load(orc_vec *v, const float *actions, const double *exo_z, double *obs, double *reward,
+                       unsigned char *done, int n_threads) {
+    vec_step_impl(v, actions, exo_z, obs, reward, done, n_threads, 1);
+}
+
+static void vec_step_impl(orc_vec *v, const float *actions, const double *exo_z, double *obs, double *reward,
+                          unsigned char *done, int n_threads, int load_mode) {
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
     if ((long) n_threads > v->n) n_threads = (int) (v->n > 0 ? v->n : 1);
@@ -1294,7 +1328,7 @@ void orc_vec_step(orc_vec *v, const float *actions, const double *exo_z, double 
         long lo = chunk * k, hi = lo + chunk;
         if (hi > v->n) hi = v->n;
         if (lo > hi) lo = hi;
-        jobs[k] = (vec_job){v, actions, exo_z, obs, reward, done, lo, hi};
+        jobs[k] = (vec_job){v, load_mode, actions, exo_z, obs, reward, done, lo, hi};
     }
     if (n_threads == 1) {
         vec_worker(&jobs[0]);

@@ -175,6 +175,7 @@ void orc_env_init(orc_env *e, const orc_config *cfg, const orc_tables *t);
 /* exo_days: {pv_day, wd_day} or NULL (Philox mode draws them); exo_z: {z_pv, z_wd, z_price} or NULL */
 void orc_env_reset(orc_env *e, const int *exo_days, const double *exo_z, double *obs);
 void orc_env_step(orc_env *e, const float *action, const double *exo_z, double *obs, double *reward, int *done);
+void orc_env_step_load(orc_env *e, const float *action, const double *exo_z, double *obs, double *reward, int *done);
 int orc_env_obs_dim(const orc_config *cfg);
 
 /* ---- vector front-end used by tests and by bench.py's cpu_baseline ---- */
@@ -186,6 +187,8 @@ orc_env *orc_vec_env(orc_vec *v, long i);
 void orc_vec_reset(orc_vec *v, const int *exo_days, const double *exo_z, double *obs);
 void orc_vec_step(orc_vec *v, const float *actions, const double *exo_z, double *obs, double *reward,
                   unsigned char *done, int n_threads);
+void orc_vec_step_load(orc_vec *v, const float *actions, const double *exo_z, double *obs, double *reward,
+                       unsigned char *done, int n_threads);
 long orc_sizeof_env(void);
 
 /* ---- accessors for the ctypes tests ---- */

@@ -117,6 +117,8 @@ def _load_oracle():
         "orc_vec_env": (P, [P, C.c_long]),
         "orc_vec_reset": (None, [P, P, P, P]),
         "orc_vec_step": (None, [P, P, P, P, P, P, I]),
+        "orc_vec_step_load": (None, [P, P, P, P, P, P, I]),
+        "orc_env_step_load": (None, [P, P, P, P, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -329,3 +329,62 @@ def test_snapshot_restore_roundtrip(rng):
         other.set_state(snap)
     other.close()
     v.close()
+
+
+@pytest.mark.parametrize("cc", [False, True])
+@pytest.mark.parametrize("rng", ["philox", "compat"])
+def test_scalar_load_mode_matches_oracle(rng, cc):
+    """evs_step(float) on the GPU against the oracle, whose station code for this mode is pinned
+    bit for bit against the reference (tests/test_oracle_vs_ref.py::test_station_scalar_load_mode)."""
+    chub = hub()
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01, constant_charging=cc, renew_fluctuate=0.0,
+              price_fluctuate=0.0, hydro_loss=0.0)
+    n, seed = 70, 99
+    v = chub.VecChargingHub(n, seed=seed, rng=rng, **kw)
+    v.set_telemetry(True)
+    cfg = orclib.make_config(piles=kw["station_list"], types=kw["station_type_list"], constant_charging=cc,
+                             hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
+    mode = orclib.PHILOX if rng == "philox" else orclib.COMPAT
+    h = orc.orc_vec_create(C.byref(cfg), orclib.tables(), n, 0, mode, seed)
+    rs = np.random.RandomState(4)
+    o_obs, o_rew, o_done = np.zeros((n, v.obs_dim)), np.zeros(n), np.zeros(n, dtype=np.uint8)
+    if rng == "compat":
+        days = np.stack([rs.randint(0, 100, n), rs.randint(0, 150, n)], axis=1).astype(np.int32)
+        z = rs.normal(size=(n, 3))
+        v.reset(days, z)
+        orc.orc_vec_reset(h, ptr(days), ptr(z), ptr(o_obs))
+    else:
+        v.reset()
+        orc.orc_vec_reset(h, None, None, ptr(o_obs))
+    for t in range(120):
+        sc = v.station_scalars()
+        loads = np.stack([rs.uniform(0, 1.2, n) * (sc[:, 0, 2] + 1.0), rs.uniform(0, 1.2, n) * (sc[:, 1, 2] + 1.0)], axis=1)
+        loads = loads.astype(np.float32)
+        tail = rs.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+        z = rs.normal(size=(n, 3)) if rng == "compat" else None
+        act = v.load_actions(loads, tail)
+        obs, rew, done, _ = v.step_load(loads, tail, z)
+        orc.orc_vec_step_load(h, ptr(act), ptr(z) if z is not None else None, ptr(o_obs), ptr(o_rew), ptr(o_done), 2)
+        sl = v.slots()
+        sc = v.station_scalars()
+        for e in range(n):
+            env = orc.orc_vec_env(h, e)
+            for k, nk in ((0, 20), (1, 25)):
+                want = np.zeros((9, nk), dtype=np.float32)
+                orc.orc_station_slots(orc.orc_env_station(env, k), ptr(want))
+                check_slots(sl[k][e], want, ("load mode", rng, cc, t, e, k))
+                ws = np.zeros(8)
+                orc.orc_station_scalars(orc.orc_env_station(env, k), ptr(ws))
+                assert np.array_equal(sc[e, k, :6], ws[:6]), (t, e, k, sc[e, k], ws)
+        close(v.obs_f64(), o_obs, ("load mode obs", t), rtol=TIGHT, atol=TIGHT)
+        close(v.reward_f64(), o_rew, ("load mode reward", t), rtol=TIGHT, atol=TIGHT)
+        if t == 95:
+            if rng == "compat":
+                v.reset(days, np.zeros((n, 3)))
+                orc.orc_vec_reset(h, ptr(days), ptr(np.zeros((n, 3))), ptr(o_obs))
+            else:
+                v.reset()
+                orc.orc_vec_reset(h, None, None, ptr(o_obs))
+    orc.orc_vec_destroy(h)
+    v.close()
