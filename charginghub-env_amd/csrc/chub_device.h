@@ -45,15 +45,17 @@ enum Site : uint32_t {
     SITE_DAY = 11     // word 0 -> pv day, word 1 -> wd day (reset)
 };
 
-struct SlotArrays {          // per-slot state, f32 unless noted; index = base_k + env*S_k + slot
-    CHUB_G(float) soc;       // current SoC (introspection; rewritten when a car charges / arrives / leaves)
-    CHUB_G(float) target;    // target SoC (written at arrival / departure only)
-    CHUB_G(float) init_soc;  // arrival SoC (written at arrival / departure only)
-    CHUB_G(float) power;     // kW at the car's current point of the curve (Station::situation["power"])
-    CHUB_G(float) t_target;  // soc_to_time(target)   -- cached, constant over a stay
-    CHUB_G(float) t_soc;     // soc_to_time(soc)      -- cached, what car_step and calculate_needed both need
-    CHUB_G(uint8_t) tl;      // bits 0-6: stay_time - already_stay_time (0 = empty), bit 7: charging this step
-    CHUB_G(uint8_t) stay;    // stay_time (introspection)
+struct SlotArrays {          // index = base_k + env*S_k + slot  (station-major)
+    // the hot record, one 16-byte load and one 16-byte store per slot and step:
+    //   .x power     kW at the car's current point of the curve (Station::situation["power"])
+    //   .y t_target  soc_to_time(target)   -- cached, constant over a stay
+    //   .z t_soc     soc_to_time(soc)      -- cached, what car_step and calculate_needed both need
+    //   .w bits 0-6 stay_time - already_stay_time (0 = empty), bit 7 charging this step, bits 8-15 stay_time
+    CHUB_G(uint32_t) hot;    // [NS][4]
+    // cold: written when a car arrives / leaves / charges, read only by introspection
+    CHUB_G(float) soc;       // current SoC
+    CHUB_G(float) target;    // target SoC
+    CHUB_G(float) init_soc;  // arrival SoC
 };
 
 struct StationArrays {       // unit index u = k*N + env

@@ -21,6 +21,8 @@
 
 namespace chub {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 // ------------------------------------------------------------------------------------------ Philox
 struct U4 {
     uint32_t v[4];
@@ -167,8 +169,6 @@ struct StationRec {
 };
 // COHERENT = the record crosses workgroups inside one launch (fused tail): relaxed agent-scope atomics compile to
 // sc1 (write-through / L1-bypassing) accesses, the form MI355X_MICROARCH.md prescribes for in-launch hand-offs.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
 template <bool COHERENT>
 __device__ __forceinline__ void rec_store(CHUB_G(uint32_t) rec, uint32_t u, float mn, float chg, float mx, uint32_t pkd) {
     u32x4 v = {__float_as_uint(mn), __float_as_uint(chg), __float_as_uint(mx), pkd};
@@ -292,7 +292,7 @@ __device__ __forceinline__ uint64_t draw_station_levels(const HubParams &hp, con
 struct SlotRegs {
     float power, t_target, t_soc, soc_new;
     float step_tt;    // DEFER: curve time at which car_step has to be evaluated
-    int tl;
+    int tl, stay;
     bool car, charge, soc_dirty, leave;
     bool needs_step;  // DEFER: charging this step and still here afterwards
 };
@@ -357,15 +357,17 @@ __device__ __forceinline__ void car_step_curves(float tt, bool cp, const CurveCo
 template <int TYPE, bool DEFER>
 __device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, SlotRegs &r,
                                              uint32_t idx, uint32_t act_idx, bool cp, int on_override) {
-    // all five loads go out together (the action is needed only for occupied slots, but waiting for the occupancy
+    // the slot's hot record and its action go out together (the action is needed only for occupied slots, but waiting for the occupancy
     // byte first would put two HBM latencies in series)
-    r.power = sl.power[idx];
-    r.t_target = sl.t_target[idx];
-    r.t_soc = sl.t_soc[idx];
-    uint32_t tlb = sl.tl[idx];
+    const u32x4 hot = ((CHUB_G(u32x4)) sl.hot)[idx];
+    r.power = __uint_as_float(hot.x);
+    r.t_target = __uint_as_float(hot.y);
+    r.t_soc = __uint_as_float(hot.z);
+    uint32_t tlb = hot.w;
     float a = sa.actions[act_idx];
     asm volatile("" : "+v"(a), "+v"(tlb));
     r.tl = (int) (tlb & 127u);
+    r.stay = (int) ((tlb >> 8) & 255u);
     r.car = r.tl > 0;
     // action_to_real (MGR:384-393): (a+1)/2 >= 0.5 on the f32 array
     const bool act_on = __fmul_rn(__fadd_rn(a, 1.0f), 0.5f) >= 0.5f;
@@ -449,7 +451,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     SlotRegs r;
     r.power = r.t_target = r.t_soc = r.soc_new = 0.0f;
     r.step_tt = 0.0f;
-    r.tl = 0;
+    r.tl = r.stay = 0;
     r.car = r.charge = r.soc_dirty = r.leave = r.needs_step = false;
     // ---- scalar-load control mode, evs_step(float) (CHS.hpp:1169-1186 / 1480-1497): one kW target per station; the
     // piles are switched on in urgency order until the target is met (assign_on_off, CHS.hpp:1318-1362 / 1629-1674)
@@ -458,10 +460,11 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         float pw0 = 0.0f, em0 = 0.0f;
         bool car0 = false;
         if (valid) {
-            pw0 = sl.power[idx];
-            const int tl0 = sl.tl[idx] & 127;
+            const u32x4 hot = ((CHUB_G(u32x4)) sl.hot)[idx];
+            pw0 = __uint_as_float(hot.x);
+            const int tl0 = (int) (hot.w & 127u);
             car0 = tl0 > 0;
-            if (car0) em0 = emergency_of(sl.t_target[idx], sl.t_soc[idx], tl0);
+            if (car0) em0 = emergency_of(__uint_as_float(hot.y), __uint_as_float(hot.z), tl0);
         }
         // catch_load (CHS.hpp:358-366): clamp to [min_power, max_power] of the previous calculate_output
         float load = 0.0f;
@@ -729,14 +732,17 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     const int cars = __popcll(__ballot(r.car) & unit_mask);
 
     if (valid) {
-        sl.power[idx] = r.power;
-        sl.t_soc[idx] = r.t_soc;
-        sl.tl[idx] = (uint8_t) (r.tl | (r.charge ? 128 : 0));
+        if (adm) r.stay = nc.stay;
+        else if (r.leave || RESET) r.stay = 0;
+        u32x4 hot;
+        hot.x = __float_as_uint(r.power);
+        hot.y = __float_as_uint(r.t_target);
+        hot.z = __float_as_uint(r.t_soc);
+        hot.w = (uint32_t) r.tl | (r.charge ? 128u : 0u) | ((uint32_t) r.stay << 8);
+        ((CHUB_G(u32x4)) sl.hot)[idx] = hot;
         if (adm || r.leave || RESET) {
-            sl.t_target[idx] = r.t_target;
             sl.target[idx] = adm ? nc.target : 0.0f;
             sl.init_soc[idx] = adm ? nc.soc : 0.0f;
-            sl.stay[idx] = (uint8_t) (adm ? nc.stay : 0);
             sl.soc[idx] = adm ? nc.soc : 0.0f;
         } else if (r.soc_dirty) {
             sl.soc[idx] = r.soc_new;

@@ -511,8 +511,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     const size_t N = (size_t) n_envs, NS = N * (size_t) (hp.S[0] + hp.S[1]);
 #define ALLOC(ptr, count)                                        \
     if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
-    ALLOC(e->sl.soc, NS); ALLOC(e->sl.target, NS); ALLOC(e->sl.init_soc, NS); ALLOC(e->sl.power, NS);
-    ALLOC(e->sl.t_target, NS); ALLOC(e->sl.t_soc, NS); ALLOC(e->sl.tl, NS); ALLOC(e->sl.stay, NS);
+    ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.soc, NS); ALLOC(e->sl.target, NS); ALLOC(e->sl.init_soc, NS);
     ALLOC(e->st.rec, 8 * N); ALLOC(e->st.pk[0], 2 * N); ALLOC(e->st.pk[1], 2 * N); ALLOC(e->st.grp_cnt, (N + 63) / 64);
     ALLOC(e->ev.cap, N); ALLOC(e->ev.store_soc, N); ALLOC(e->ev.ou, 3 * N); ALLOC(e->ev.price_noise, N);
     ALLOC(e->ev.re_pv, N); ALLOC(e->ev.re_wd, N); ALLOC(e->ev.price_next, N);
@@ -736,13 +735,11 @@ int chub_get_slots(chub_env *e, float *out) {
     HIP_TRY(hipDeviceSynchronize());
     const HubParams &hp = e->hp;
     const size_t N = (size_t) hp.n_envs, S = (size_t) (hp.S[0] + hp.S[1]), NS = N * S;
-    std::vector<float> soc, target, init_soc, power, t_target, t_soc;
-    std::vector<uint8_t> tl, stay;
+    std::vector<float> soc, target, init_soc;
+    std::vector<uint32_t> hot;
     int rc;
-    if ((rc = fetch(soc, e->sl.soc, NS)) || (rc = fetch(target, e->sl.target, NS)) ||
-        (rc = fetch(init_soc, e->sl.init_soc, NS)) || (rc = fetch(power, e->sl.power, NS)) ||
-        (rc = fetch(t_target, e->sl.t_target, NS)) || (rc = fetch(t_soc, e->sl.t_soc, NS)) ||
-        (rc = fetch(tl, e->sl.tl, NS)) || (rc = fetch(stay, e->sl.stay, NS)))
+    if ((rc = fetch(soc, (const float *) e->sl.soc, NS)) || (rc = fetch(target, (const float *) e->sl.target, NS)) ||
+        (rc = fetch(init_soc, (const float *) e->sl.init_soc, NS)) || (rc = fetch(hot, (const uint32_t *) e->sl.hot, 4 * NS)))
         return rc;
     for (size_t env = 0; env < N; env++) {
         float *o = out + env * 9 * S;
@@ -750,22 +747,27 @@ int chub_get_slots(chub_env *e, float *out) {
             const size_t n = (size_t) hp.S[k];
             for (size_t i = 0; i < n; i++) {
                 const size_t idx = (size_t) hp.base[k] + env * n + i;
-                const int left = tl[idx] & 127;
+                float power, t_target, t_soc;
+                memcpy(&power, &hot[4 * idx + 0], 4);
+                memcpy(&t_target, &hot[4 * idx + 1], 4);
+                memcpy(&t_soc, &hot[4 * idx + 2], 4);
+                const uint32_t w = hot[4 * idx + 3];
+                const int left = (int) (w & 127u), stay = (int) ((w >> 8) & 255u);
                 const bool car = left > 0;
                 float em = 0.0f;
                 if (car) {  // Station::situation["emergency"] as calculate_needed leaves it (CHS.hpp:879-898)
-                    float need = t_target[idx] - t_soc[idx];
+                    float need = t_target - t_soc;
                     if (need > 0) em = ((float) left <= ceilf(need)) ? 10.0f : (float) pow((double) (need / (float) left), 2);
                 }
                 o[0 * n + i] = car ? 1.0f : 0.0f;
-                o[1 * n + i] = (tl[idx] & 128) ? 1.0f : 0.0f;
+                o[1 * n + i] = (w & 128u) ? 1.0f : 0.0f;
                 o[2 * n + i] = em;
-                o[3 * n + i] = power[idx];
+                o[3 * n + i] = power;
                 o[4 * n + i] = soc[idx];
                 o[5 * n + i] = init_soc[idx];
                 o[6 * n + i] = target[idx];
-                o[7 * n + i] = car ? (float) stay[idx] : -1.0f;
-                o[8 * n + i] = car ? (float) (stay[idx] - left) : -1.0f;
+                o[7 * n + i] = car ? (float) stay : -1.0f;
+                o[8 * n + i] = car ? (float) (stay - left) : -1.0f;
             }
             o += 9 * n;
         }
