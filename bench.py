@@ -53,7 +53,13 @@ def measured_traffic(envs_per_gpu):
     and committed under profiles/; scaled to this run's shard size."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")))
+    import re
+
+    def version(path):
+        m = re.search(r"round(\d+)_v(\d+)_pmc_traffic", path)
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")), key=version)
     if not files:
         return None
     try:
