@@ -31,6 +31,13 @@ TOTAL_ENVS = 65536
 HUB = dict(station_list=[20, 25], station_type_list=["fast", "slow"], constant_charging=False, hydro_prod_rate=100.0,
            hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01, renew_fluctuate=0.0,
            price_fluctuate=0.0, hydro_loss=0.0)
+# the other BASELINE.json configs (parity-test sizes; selectable with --config for the results table, not the headline)
+CONFIGS = {
+    "c2": (4096, dict(HUB, station_list=[16, 0], fcev_permeate=0.0)),
+    "c3": (32768, dict(HUB)),
+    "c4": (65536, dict(HUB)),
+    "c5": (262144, dict(HUB, station_list=[32, 32], renew_fluctuate=0.3, price_fluctuate=0.3)),
+}
 SEED = 12345
 ACTION_KEY = 0xC0FFEE
 N_ACTION_BATCHES = 8
@@ -64,7 +71,7 @@ def measured_traffic(envs_per_gpu):
         return None
     try:
         rec = json.load(open(files[-1]))
-        return rec["k_slot"]["traffic_bytes_per_launch"] * envs_per_gpu / float(TOTAL_ENVS)
+        return rec["k_slot"]["traffic_bytes_per_launch"] * envs_per_gpu / float(TOTAL_ENVS)  # measured on the c4 hub
     except Exception:
         return None
 
@@ -118,7 +125,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=960)
     ap.add_argument("--warmup", type=int, default=96)
-    ap.add_argument("--envs", type=int, default=TOTAL_ENVS)
+    ap.add_argument("--envs", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events in the timed region")
     args = ap.parse_args()
@@ -154,10 +162,11 @@ def main():
 
     import charginghub_env_amd as chub
 
-    total = args.envs
+    cfg_envs, hub_kw = CONFIGS[args.config]
+    total = args.envs if args.envs is not None else cfg_envs
     assert total % world == 0
     per = total // world
-    v = chub.VecChargingHub(per, seed=SEED, rng="philox", device=local_rank, env_id0=rank * per, **HUB)
+    v = chub.VecChargingHub(per, seed=SEED, rng="philox", device=local_rank, env_id0=rank * per, **hub_kw)
     D, A, S = v.obs_dim, v.act_dim, v.n_slots
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -228,7 +237,7 @@ def main():
             slot_s = slot_ms / 1e3 / n_prof
             achieved = slot_b * per / slot_s / 1e9
             roofline = {"bound": "hbm", "kernel": "k_slot", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(per),
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(per) if args.config in ("c3", "c4") else None,
                         "algorithmic_bytes_per_launch": slot_b * per, "avg_launch_us": slot_s * 1e6,
                         "env_kernel_avg_launch_us": env_ms / n_prof * 1e3,
                         "env_kernel_algorithmic_bytes_per_launch": env_b * per}
@@ -237,13 +246,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%d envs x hub [20 fast, 25 slow] (BASELINE.json configs[3]), fcev_permeate 0.01, "
-                                   "random policy resident in HBM, reset every 96 steps, Philox streams" % total,
+            "config": {"workload": "%d envs x hub [%d fast, %d slow] (BASELINE.json %s), fcev_permeate %g, "
+                                   "random policy resident in HBM, reset every 96 steps, Philox streams"
+                                   % (total, hub_kw["station_list"][0], hub_kw["station_list"][1],
+                                      "configs[3]" if args.config == "c4" else args.config, hub_kw["fcev_permeate"]),
                        "envs_per_gpu": per, "obs_dim": D, "act_dim": A,
                        "collective": "none" if world == 1 else "one RCCL gather of [envs_per_gpu, %d] f32 per step" % (D + 2)},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config == "c4":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     v.close()
