@@ -61,7 +61,7 @@ def load_library():
         "chub_sync": (I, [P]),
         "chub_profile_begin": (I, [P, I, I]), "chub_profile_end": (I, [P, P, P, P]),
         "chub_get_slots": (I, [P, P]), "chub_get_station_scalars": (I, [P, P]), "chub_get_telemetry": (I, [P, P]),
-        "chub_get_obs_f64": (I, [P, P]), "chub_get_reward_f64": (I, [P, P]), "chub_set_telemetry": (I, [P, I]),
+        "chub_get_obs_f64": (I, [P, P]), "chub_get_reward_f64": (I, [P, P]), "chub_set_telemetry": (I, [P, I]), "chub_fcev_overflow_count": (I, [P, P]),
         "chub_set_rng_compat_seeds": (I, [P, P]), "chub_set_rng_compat_state": (I, [P, P]),
         "chub_get_rng_compat_state": (I, [P, P]), "chub_compat_replay_constructor": (I, [P]), "chub_set_ou_state": (I, [P, P]),
         "chub_state_size": (L, [P]), "chub_get_state": (I, [P, P, L]), "chub_set_state": (I, [P, P, L]),
@@ -79,7 +79,7 @@ def load_library():
 EXPORTED = ["chub_create", "chub_destroy", "chub_obs_dim", "chub_act_dim", "chub_num_envs", "chub_clock", "chub_reset",
             "chub_step", "chub_reset_device", "chub_step_device", "chub_step_device_packed", "chub_step_load", "chub_step_load_device", "chub_random_actions_device", "chub_sync", "chub_profile_begin", "chub_profile_end",
             "chub_get_slots", "chub_get_station_scalars", "chub_get_telemetry", "chub_get_obs_f64",
-            "chub_get_reward_f64", "chub_set_telemetry", "chub_set_rng_compat_seeds", "chub_set_rng_compat_state", "chub_get_rng_compat_state", "chub_compat_replay_constructor", "chub_set_ou_state",
+            "chub_get_reward_f64", "chub_set_telemetry", "chub_fcev_overflow_count", "chub_set_rng_compat_seeds", "chub_set_rng_compat_state", "chub_get_rng_compat_state", "chub_compat_replay_constructor", "chub_set_ou_state",
             "chub_state_size", "chub_get_state", "chub_set_state", "chub_get_hy_table", "chub_set_hy_table", "chub_last_error", "chub_device_count"]
 
 

@@ -410,6 +410,14 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
             cnt_hv[t * kLevels + k] = (uint8_t) (c < 0 ? 0 : (c > 255 ? 255 : c));
         }
     }
+    if (rng_mode == CHUB_RNG_PHILOX) {
+        // the packed per-step station draws (draw_station_levels) hold up to 9 arrivals per station and step
+        int top = 0;
+        for (int sidx = 0; sidx < 2; sidx++)
+            for (uint8_t c : cnt[sidx]) top = c > top ? c : top;
+        if (top > 9)
+            return bail(fail(CHUB_ERR_UNSUPPORTED, "arrival table yields more than 9 EV arrivals per station and step"));
+    }
     // level thresholds of the renege / balk tests (CHS.hpp:1286-1303): u > 0.1*logf(w+1), u <= expf(-0.01*m)
     std::vector<uint16_t> thr_renege(kMaxLine);
     for (int w = 0; w < kMaxLine; w++) {
@@ -1033,6 +1041,19 @@ int chub_set_state(chub_env *e, const void *buf, int64_t size) {
     e->tick = h.tick;
     memcpy(e->hy_table, h.hy_table, sizeof h.hy_table);
     e->ctx_dirty = true;
+    return CHUB_OK;
+}
+
+int chub_fcev_overflow_count(chub_env *e, int64_t *out) {
+    if (!e || !out) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint8_t> f;
+    int rc = fetch(f, (const uint8_t *) e->ev.q_overflow, (size_t) e->hp.n_envs);
+    if (rc) return rc;
+    int64_t n = 0;
+    for (uint8_t b : f) n += b ? 1 : 0;
+    *out = n;
     return CHUB_OK;
 }
 

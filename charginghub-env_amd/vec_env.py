@@ -164,6 +164,12 @@ class VecChargingHub(object):
         check(self._lib.chub_get_reward_f64(self._h, _ptr(out)))
         return out
 
+    def fcev_overflow_count(self):
+        """envs whose FCEV waiting list outgrew its 16-car capacity (parity with the reference is lost for them)"""
+        n = C.c_int64()
+        check(self._lib.chub_fcev_overflow_count(self._h, C.byref(n)))
+        return n.value
+
     def set_compat_seeds(self, seeds):
         s = np.ascontiguousarray(seeds, dtype=np.uint32).reshape(self.n_envs, 2)
         check(self._lib.chub_set_rng_compat_seeds(self._h, _ptr(s)))

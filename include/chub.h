@@ -148,6 +148,10 @@ int chub_get_obs_f64(chub_env *env, double *out);
 int chub_get_reward_f64(chub_env *env, double *out);
 int chub_set_telemetry(chub_env *env, int enabled); /* off by default: the hot path then skips those stores */
 
+/* Number of envs whose FCEV waiting list ever exceeded its fixed capacity (16 cars; the reference's list is unbounded,
+ * HYD:264-265, and only grows that long once its queue is stuck): for those envs parity with the reference is lost. */
+int chub_fcev_overflow_count(chub_env *env, int64_t *out);
+
 /* COMPAT streams: seeds [N][2] u32 = (srand seed, e.seed()) per env, i.e. what Change_Use_Seed /
  * srand / e.seed would install (CHS.hpp:25-44). */
 int chub_set_rng_compat_seeds(chub_env *env, const uint32_t *seeds);

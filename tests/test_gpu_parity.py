@@ -225,6 +225,7 @@ def test_full_size_properties():
                 assert np.all(sl[k][:, 4, :][occ] >= 25.0 - 1e-3) and np.all(sl[k][:, 4, :][occ] <= 100.0)
                 assert np.all(sl[k][:, 4, :][~occ] == 0)
             assert np.all(o[:, -3] >= 0.1 - 1e-6) and np.all(o[:, -3] <= 1.0 + 1e-6)  # tank SOC bounds (HYD:111-112)
+    assert whole.fcev_overflow_count() == 0
     # random policy, this hub: mean episode return is O(10); guards against silently dead dynamics
     assert 0 < ret.mean() < 100 and ret.std() > 0.1
     whole.close(); a.close(); b.close()

@@ -140,3 +140,43 @@ def test_oracle_philox_streams_are_shard_independent():
                 orc.orc_vec_reset(h, None, None, ptr(o))
     for h in (whole, a, b):
         orc.orc_vec_destroy(h)
+
+
+def test_philox_mode_is_statistically_the_reference_process():
+    """The production RNG mode draws from different streams (Philox + tabulated inverse CDFs) than the reference
+    (glibc rand + minstd + polar normals).  It must still simulate the same stochastic process: compare episode-level
+    statistics of the two modes of the oracle over many envs under the same policy."""
+    cfg = orclib.make_config(piles=(20, 25), types=("fast", "slow"), fcev_permeate=0.05)
+    n, D, A = 384, 13, 47
+    rs = np.random.RandomState(3)
+    stats = {}
+    for mode in (orclib.COMPAT, orclib.PHILOX):
+        h = orc.orc_vec_create(C.byref(cfg), orclib.tables(), n, 0, mode, 2024)
+        obs, rew, done = np.zeros((n, D)), np.zeros(n), np.zeros(n, dtype=np.uint8)
+        rs_a = np.random.RandomState(11)
+        days = np.stack([rs.randint(0, 100, n), rs.randint(0, 150, n)], axis=1).astype(np.int32)
+        ret = np.zeros(n)
+        cars, line, flow, soc_new = [], [], [], []
+        if mode == orclib.COMPAT:
+            orc.orc_vec_reset(h, ptr(days), ptr(rs.normal(size=(n, 3))), ptr(obs))
+        else:
+            orc.orc_vec_reset(h, None, None, ptr(obs))
+        for t in range(96):
+            act = rs_a.uniform(-1, 1, size=(n, A)).astype(np.float32)
+            z = rs.normal(size=(n, 3)) if mode == orclib.COMPAT else None
+            orc.orc_vec_step(h, ptr(act), ptr(z) if z is not None else None, ptr(obs), ptr(rew), ptr(done), 4)
+            ret += rew
+            for e in range(0, n, 8):
+                for k in (0, 1):
+                    sc = np.zeros(8)
+                    orc.orc_station_scalars(orc.orc_env_station(orc.orc_vec_env(h, e), k), ptr(sc))
+                    cars.append(sc[3]); line.append(sc[4]); flow.append(sc[5])
+        stats[mode] = dict(ret=ret, cars=np.array(cars), line=np.array(line), flow=np.array(flow))
+        orc.orc_vec_destroy(h)
+    a, b = stats[orclib.COMPAT], stats[orclib.PHILOX]
+    # PV / wind days and OU noise differ between the two runs as well, so compare with sampling error in mind
+    se = np.sqrt(a["ret"].var() / n + b["ret"].var() / n)
+    assert abs(a["ret"].mean() - b["ret"].mean()) < 5 * se + 0.5, (a["ret"].mean(), b["ret"].mean(), se)
+    for key, tol in (("cars", 0.35), ("line", 0.25), ("flow", 0.15)):
+        assert abs(a[key].mean() - b[key].mean()) < tol, (key, a[key].mean(), b[key].mean())
+    assert abs(a["cars"].std() - b["cars"].std()) < 0.4
