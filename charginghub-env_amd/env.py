@@ -53,7 +53,7 @@ class EvcsspManagerEnv_v6(object):
     def __init__(self, station_list, station_type_list, constant_charging=False, hydro_prod_rate=None,
                  hydro_store_vlt=None, seed_rand=True, init_soc=0.5, fc_max_power=None, fcev_permeate=0.01,
                  use_lagrange=False, renew_fluctuate=0, price_fluctuate=0, hydro_loss=0, rng="compat", device=0,
-                 seed=None):
+                 seed=None, data_dir=None):
         assert len(station_list) == len(station_type_list) == 2  # MGR:37
         self.fcev_permeate = fcev_permeate
         self.init_soc = init_soc
@@ -62,7 +62,7 @@ class EvcsspManagerEnv_v6(object):
         self.simulate = False
         self._rng = rng
         self._vec = VecChargingHub(1, station_list, station_type_list, seed=0 if seed is None else seed, rng=rng,
-                                   device=device, constant_charging=constant_charging,
+                                   device=device, data_dir=data_dir, constant_charging=constant_charging,
                                    hydro_prod_rate=hydro_prod_rate, hydro_store_vlt=hydro_store_vlt,
                                    init_soc=init_soc, fc_max_power=fc_max_power, fcev_permeate=fcev_permeate,
                                    renew_fluctuate=renew_fluctuate, price_fluctuate=price_fluctuate,
@@ -82,7 +82,7 @@ class EvcsspManagerEnv_v6(object):
             # HySystem's sweep): replay them so that an episode after construction matches the reference's
             self._vec.compat_replay_constructor()
         self.pile_number = [int(station_list[0]), int(station_list[1])]
-        data = _lib.DATA_DIR
+        data = data_dir or _lib.DATA_DIR
         self._price = np.fromfile(data + "/price_96.f64", dtype="<f8")
         self._pv = np.fromfile(data + "/pv_100x96.f64", dtype="<f8").reshape(100, 96)
         self._wd = np.fromfile(data + "/wd_150x96.f64", dtype="<f8").reshape(150, 96)

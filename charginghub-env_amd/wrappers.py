@@ -1,0 +1,241 @@
+"""What RL trainers put around the hub: registration, time limit, vector-env adapters, telemetry in ``info``.
+
+The reference registers one id with gym (``evcssp_env_cpp/__init__.py:3-8``: ``charging-hub-v6``,
+``max_episode_steps=999``) and returns an empty ``info`` (``MGR:302``) while keeping the step's accounting on
+attributes (``re_used_renew``, ``re_ev_power_list``, ``income`` ... ``MGR:183-297``).  Neither gym nor Gymnasium is a
+dependency here: the adapters are duck-typed to the three calling conventions in use --
+
+* ``make()``            -- ``gym.make('evcssp_env_cpp:charging-hub-v6', **kwargs)`` of the reference: the single drop-in
+                           env inside a ``TimeLimit(999)``;
+* ``HubVecEnv``         -- the stable-baselines ``VecEnv`` convention (``reset() -> obs``, ``step_async / step_wait``,
+                           ``dones`` with automatic reset and ``terminal_observation`` in the per-env ``infos``);
+* ``HubVectorEnv``      -- the Gymnasium ``VectorEnv`` convention (``reset(seed=, options=) -> (obs, info)``,
+                           ``step -> (obs, reward, terminated, truncated, info)`` with dict-of-arrays ``info``).
+
+All N envs of a ``VecChargingHub`` run in lock-step (one clock), so an episode end is an all-env event and automatic
+reset is one ``chub_reset``.
+"""
+import numpy as np
+
+from . import _lib
+from .env import Box, EvcsspManagerEnv_v6, _space
+from .vec_env import VecChargingHub
+
+ENV_ID = "charging-hub-v6"
+MAX_EPISODE_STEPS = 999   # evcssp_env_cpp/__init__.py:6
+REWARD_THRESHOLD = 99     # evcssp_env_cpp/__init__.py:7
+
+# reference attribute name (MGR:175-297) -> telemetry column of chub_get_telemetry
+_T = {n: i for i, n in enumerate(_lib.TELEMETRY_NAMES)}
+INFO_COLUMNS = {
+    "hy_act": _T["hy_act"], "re_hydrogen_power_init": _T["all_power_second"], "Store_SOC": _T["Store_SOC"],
+    "fc_power": _T["fc_power"], "re_hy_for_fc": _T["hy_to_use"], "re_used_renew": _T["re_used_renew"],
+    "re_hydrogen_power": _T["re_hydrogen_power"], "income": _T["income"], "re_pv_power": _T["re_pv_power"],
+    "re_wd_power": _T["re_wd_power"], "hy_use": _T["hy_use"], "not_meet": _T["not_meet"],
+    "price_next": _T["price_next"], "fcev_arrive_number": _T["fcev_arrive_number"],
+}
+
+
+def telemetry_info(tel):
+    """[N, T_COUNT] telemetry block -> dict of [N] arrays under the reference's attribute names"""
+    info = {name: tel[:, col].copy() for name, col in INFO_COLUMNS.items()}
+    info["re_hy_gen"] = 900.0 * tel[:, _T["hy_flow_speed"]]                                    # MGR:183
+    info["re_ev_power_list"] = tel[:, [_T["re_ev_power_0"], _T["re_ev_power_1"]]].copy()       # MGR:212
+    return info
+
+
+class TimeLimit(object):
+    """``gym.wrappers.TimeLimit`` as the reference's registration applies it (old 4-tuple step API): after
+    ``max_episode_steps`` steps without a reset, ``done`` is forced and ``info['TimeLimit.truncated']`` says whether the
+    env itself had not ended.  The hub's own ``done`` fires every 96 steps (MGR:271-273); it may be stepped on without a
+    reset (infinite horizon), which is when this limit matters."""
+
+    def __init__(self, env, max_episode_steps=MAX_EPISODE_STEPS):
+        self.env = env
+        self._max_episode_steps = int(max_episode_steps)
+        self._elapsed_steps = None
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    @property
+    def unwrapped(self):
+        return self.env
+
+    def reset(self, **kwargs):
+        self._elapsed_steps = 0
+        return self.env.reset(**kwargs)
+
+    def step(self, action=None):
+        assert self._elapsed_steps is not None, "Cannot call env.step() before calling reset()"
+        obs, reward, done, info = self.env.step(action)
+        self._elapsed_steps += 1
+        if self._elapsed_steps >= self._max_episode_steps:
+            info = dict(info)
+            info["TimeLimit.truncated"] = not done
+            done = True
+        return obs, reward, done, info
+
+
+def make(id=ENV_ID, **kwargs):
+    """The reference's ``gym.make('evcssp_env_cpp:charging-hub-v6', **env_kwargs)`` (test/env_test.py:36)."""
+    if id.split(":")[-1] != ENV_ID:
+        raise ValueError("unknown environment id %r (have %r)" % (id, ENV_ID))
+    return TimeLimit(EvcsspManagerEnv_v6(**kwargs), MAX_EPISODE_STEPS)
+
+
+def register():
+    """Register ``charging-hub-v6`` with whichever of gym / gymnasium is importable; returns the module names done."""
+    done = []
+    for modname in ("gym", "gymnasium"):
+        try:
+            mod = __import__(modname + ".envs.registration", fromlist=["register"])
+        except Exception:
+            continue
+        mod.register(id=ENV_ID, entry_point="charginghub_env_amd:EvcsspManagerEnv_v6",
+                     max_episode_steps=MAX_EPISODE_STEPS, reward_threshold=REWARD_THRESHOLD)
+        done.append(modname)
+    return done
+
+
+def _spaces(vec, data_dir=None):
+    price = np.fromfile((data_dir or _lib.DATA_DIR) + "/price_96.f64", dtype="<f8")
+    obs_price = (price - np.mean(price)) / np.std(price)
+    lo, hi = [-1.0, min(obs_price)], [1.0, max(obs_price)]           # MGR:51-104
+    for k in range(2):
+        if vec.piles[k] > 0:
+            lo += [-1.0, -1.0, -1.0, 0]
+            hi += [1.0, 1.0, 1.0, 2]
+    lo += [0, 0, 0]
+    hi += [1, 1, 1]
+    return (_space(np.array(lo, dtype=np.float32), np.array(hi, dtype=np.float32)),
+            _space(-1.0, 1.0, (vec.act_dim,)))
+
+
+class _HubBatch(object):
+    """shared by the two vector conventions: owns (or borrows) a VecChargingHub, counts steps, applies the limit"""
+
+    def __init__(self, vec=None, n_envs=None, max_episode_steps=None, telemetry=False, data_dir=None, **hub_kwargs):
+        if vec is None:
+            if n_envs is None:
+                raise ValueError("give either vec= or n_envs= and the hub kwargs")
+            vec = VecChargingHub(n_envs, data_dir=data_dir, **hub_kwargs)
+        self.vec = vec
+        self.num_envs = vec.n_envs
+        self.single_observation_space, self.single_action_space = _spaces(vec, data_dir)
+        self.observation_space, self.action_space = self.single_observation_space, self.single_action_space
+        self.max_episode_steps = None if max_episode_steps is None else int(max_episode_steps)
+        self.telemetry = bool(telemetry)
+        if self.telemetry:
+            vec.set_telemetry(True)
+        self._elapsed = 0
+        self.metadata = EvcsspManagerEnv_v6.metadata
+        self.reward_range = (-float("inf"), float("inf"))
+        self.spec = None
+
+    def _step(self, actions):
+        obs, reward, done, _ = self.vec.step(actions)
+        self._elapsed += 1
+        truncated = np.zeros(self.num_envs, dtype=bool)
+        if self.max_episode_steps is not None and self._elapsed >= self.max_episode_steps:
+            truncated = ~done
+        tel = telemetry_info(self.vec.telemetry()) if self.telemetry else {}
+        return obs, reward, done, truncated, tel
+
+    def _reset(self):
+        self._elapsed = 0
+        return self.vec.reset()
+
+    def close(self):
+        self.vec.close()
+
+    def render(self, mode="human"):
+        return None
+
+
+class HubVecEnv(_HubBatch):
+    """stable-baselines ``VecEnv`` convention over one VecChargingHub.
+
+    ``step_wait`` returns ``(obs, rewards, dones, infos)``; when the episode ends (all envs at once) the envs are reset,
+    the returned ``obs`` is the first observation of the next episode and ``infos[i]['terminal_observation']`` holds the
+    last one of the finished episode; ``infos[i]['TimeLimit.truncated']`` marks an end forced by ``max_episode_steps``.
+    """
+
+    def __init__(self, vec=None, n_envs=None, max_episode_steps=None, telemetry=False, **hub_kwargs):
+        _HubBatch.__init__(self, vec, n_envs, max_episode_steps, telemetry, **hub_kwargs)
+        self._pending = None
+
+    def reset(self):
+        return self._reset()
+
+    def step_async(self, actions):
+        self._pending = np.asarray(actions, dtype=np.float32)
+
+    def step_wait(self):
+        obs, reward, done, truncated, tel = self._step(self._pending)
+        self._pending = None
+        dones = done | truncated
+        infos = [dict() for _ in range(self.num_envs)]
+        if tel:
+            for name, col in tel.items():
+                for i in range(self.num_envs):
+                    infos[i][name] = col[i]
+        if dones.any():
+            # lock-step clock: the episode ends for every env in the same step
+            for i in range(self.num_envs):
+                infos[i]["terminal_observation"] = obs[i]
+                infos[i]["TimeLimit.truncated"] = bool(truncated[i])
+            obs = self._reset()
+            dones = np.ones(self.num_envs, dtype=bool)
+        return obs, reward, dones, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def seed(self, seed=None):
+        return [None] * self.num_envs  # streams are fixed by the hub's constructor seed (Philox key)
+
+    def get_attr(self, attr_name, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [getattr(self, attr_name)] * n
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [False] * n
+
+
+class HubVectorEnv(_HubBatch):
+    """Gymnasium ``VectorEnv`` convention over one VecChargingHub (autoreset mode "next step": the step after an
+    episode end ignores its actions, resets and returns the first observation with zero reward)."""
+
+    def __init__(self, vec=None, n_envs=None, max_episode_steps=None, telemetry=False, autoreset=True, **hub_kwargs):
+        _HubBatch.__init__(self, vec, n_envs, max_episode_steps, telemetry, **hub_kwargs)
+        self.autoreset = bool(autoreset)
+        self._needs_reset = True
+        self.closed = False
+
+    def reset(self, seed=None, options=None):
+        self._needs_reset = False
+        return self._reset(), {}
+
+    def step(self, actions):
+        if self._needs_reset:
+            if not self.autoreset:
+                raise RuntimeError("episode has ended: call reset()")
+            obs, info = self.reset()
+            z = np.zeros(self.num_envs, dtype=bool)
+            return obs, np.zeros(self.num_envs, dtype=np.float32), z, z.copy(), info
+        obs, reward, done, truncated, info = self._step(actions)
+        if (done | truncated).any():
+            self._needs_reset = True
+        return obs, reward, done, truncated, info
+
+    def close(self, **kwargs):
+        if not self.closed:
+            self.closed = True
+            _HubBatch.close(self)
+
+
+__all__ = ["ENV_ID", "MAX_EPISODE_STEPS", "TimeLimit", "make", "register", "HubVecEnv", "HubVectorEnv",
+           "telemetry_info", "Box"]

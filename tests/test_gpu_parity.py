@@ -109,10 +109,10 @@ def test_compat_matches_reference_golden(name, n_envs):
     v.close()
 
 
-def _oracle_vec(cfg_kw, n, env_id0, seed):
+def _oracle_vec(cfg_kw, n, env_id0, seed, tables=None):
     cfg = orclib.make_config(piles=cfg_kw["station_list"], types=cfg_kw["station_type_list"],
                              **{k: cfg_kw[k] for k in cfg_kw if k not in ("station_list", "station_type_list")})
-    h = orc.orc_vec_create(C.byref(cfg), orclib.tables(), n, env_id0, orclib.PHILOX, seed)
+    h = orc.orc_vec_create(C.byref(cfg), tables or orclib.tables(), n, env_id0, orclib.PHILOX, seed)
     return cfg, h
 
 
@@ -139,21 +139,40 @@ PHILOX_CASES = [
 @pytest.mark.parametrize("label,kw,n", PHILOX_CASES, ids=[c[0] for c in PHILOX_CASES])
 def test_philox_matches_oracle(label, kw, n):
     """PHILOX streams: GPU == CPU oracle on identical seeds / actions, 2 episodes + a cut-short one."""
+    _philox_parity(label, kw, n)
+
+
+def test_philox_user_series(tmp_path):
+    """user-supplied arrival CDFs / price / PV / wind through a data directory: same parity bar"""
+    from charginghub_env_amd import data_io
+    rs = np.random.RandomState(11)
+    rates = 45 + 35 * np.sin(np.arange(96) * 2 * np.pi / 96 + 1.0)
+    price = 0.12 + 0.08 * np.sin(np.arange(96) * 2 * np.pi / 96) + rs.uniform(0, 0.02, 96)
+    pv = np.maximum(0, 30 * np.sin((np.arange(96) - 24) * np.pi / 48))[None, :] * rs.uniform(0.2, 1.2, (9, 1))
+    wd = rs.uniform(0, 80, (150, 96))
+    d = data_io.write_data_dir(str(tmp_path / "hub"), arrival_cdf=data_io.cdf_from_rates(rates), price=price, pv=pv, wd=wd)
+    tables = orc.orc_tables_load(d.encode())
+    assert tables
+    kw = dict(station_list=[12, 20], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.02, renew_fluctuate=0.2, price_fluctuate=0.1)
+    _philox_parity("user_series", kw, 96, data_dir=d, tables=tables, plan=[96, 20])
+
+
+def _philox_parity(label, kw, n, data_dir=None, tables=None, plan=(96, 96, 10, 30)):
     chub = hub()
     kw = dict(kw)
     for k, d in (("constant_charging", False), ("renew_fluctuate", 0.0), ("price_fluctuate", 0.0), ("hydro_loss", 0.0)):
         kw.setdefault(k, d)
     seed, env_id0 = 0xC0FFEE12345, 1000
-    v = chub.VecChargingHub(n, seed=seed, rng="philox", env_id0=env_id0, **kw)
+    v = chub.VecChargingHub(n, seed=seed, rng="philox", env_id0=env_id0, data_dir=data_dir, **kw)
     v.set_telemetry(True)
-    cfg, h = _oracle_vec(kw, n, env_id0, seed)
+    cfg, h = _oracle_vec(kw, n, env_id0, seed, tables)
     D, A = v.obs_dim, v.act_dim
     S0, S1 = kw["station_list"]
     rs = np.random.RandomState(7)
     o_obs = np.zeros((n, D))
     o_rew = np.zeros(n)
     o_done = np.zeros(n, dtype=np.uint8)
-    plan = [96, 96, 10, 30]
     for ep, steps in enumerate(plan):
         g_obs = v.reset()
         orc.orc_vec_reset(h, None, None, ptr(o_obs))
@@ -389,3 +408,64 @@ def test_scalar_load_mode_matches_oracle(rng, cc):
                 orc.orc_vec_reset(h, None, None, ptr(o_obs))
     orc.orc_vec_destroy(h)
     v.close()
+
+
+def test_vector_adapters_and_info_telemetry():
+    """the stable-baselines / Gymnasium conventions over the HIP hub give the same trajectory as the
+    plain VecChargingHub loop, with the reference's re_* accounting in info"""
+    chub = hub()
+    from charginghub_env_amd import wrappers
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
+    n, seed = 64, 99
+    plain = chub.VecChargingHub(n, seed=seed, **kw)
+    plain.set_telemetry(True)
+    sb3 = wrappers.HubVecEnv(n_envs=n, seed=seed, telemetry=True, **kw)
+    gym = wrappers.HubVectorEnv(n_envs=n, seed=seed, telemetry=True, **kw)
+    assert sb3.observation_space.shape == (13,) and sb3.action_space.shape == (47,)
+    o0 = plain.reset()
+    assert np.array_equal(o0, sb3.reset()) and np.array_equal(o0, gym.reset()[0])
+    rs = np.random.RandomState(5)
+    for t in range(100):
+        a = rs.uniform(-1, 1, (n, 47)).astype(np.float32)
+        if t == 96:
+            g = gym.step(a)                      # Gymnasium "next step" autoreset consumes one call
+            assert np.array_equal(g[0], o_reset) and not g[2].any()
+        o, r, d, _ = plain.step(a)
+        so, sr, sd, si = sb3.step(a)
+        go, gr, gt, gtr, gi = gym.step(a)
+        assert np.array_equal(r, sr) and np.array_equal(r, gr) and np.array_equal(d, sd) and np.array_equal(d, gt)
+        assert np.array_equal(o, go)
+        tel = plain.telemetry()
+        assert np.array_equal(gi["re_used_renew"], tel[:, 10]) and np.array_equal(gi["income"], tel[:, 14])
+        assert si[3]["income"] == tel[3, 14] and np.array_equal(si[3]["re_ev_power_list"], tel[3, 11:13])
+        if d.all():
+            assert t == 95
+            assert np.array_equal(si[0]["terminal_observation"], o[0]) and si[0]["TimeLimit.truncated"] is False
+            o_reset = plain.reset()
+            assert np.array_equal(so, o_reset)
+        else:
+            assert np.array_equal(o, so)
+    for x in (plain, sb3, gym):
+        x.close()
+
+
+def test_make_time_limit_on_dropin():
+    """gym.make('evcssp_env_cpp:charging-hub-v6', **env_kwargs) of test/env_test.py:36 without gym"""
+    import random
+    chub = hub()
+    random.seed(0)
+    np.random.seed(0)
+    env = chub.make("evcssp_env_cpp:charging-hub-v6", station_list=[20, 25], station_type_list=["fast", "slow"],
+                    constant_charging=False, seed_rand=False, hydro_prod_rate=100, hydro_store_vlt=25, init_soc=0.2,
+                    fc_max_power=100, fcev_permeate=0.01, use_lagrange=False, renew_fluctuate=0, price_fluctuate=0,
+                    hydro_loss=0)
+    env.reset()
+    done, ret, steps = False, 0.0, 0
+    while not done:
+        s_, r, done, info = env.step(action=None)
+        ret += r
+        steps += 1
+    assert steps == 96 and info == {}
+    assert abs(ret - 34.858789741560585) < 1e-9       # the reference's own smoke run (SURVEY 6)
+    env.close()

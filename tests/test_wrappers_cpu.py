@@ -1,0 +1,185 @@
+"""Host-side logic around the path that needs no GPU: time limit, vector-env conventions (against a stand-in hub
+with the VecChargingHub surface), user-supplied series -> data directory -> tables as the oracle parses them."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import charginghub_env_amd as chub
+from charginghub_env_amd import data_io, wrappers
+
+import orclib
+from orclib import orc
+
+
+class FakeSingle(object):
+    def __init__(self, horizon=96):
+        self.t, self.h = 0, horizon
+
+    def reset(self):
+        self.t = 0
+        return np.zeros(3)
+
+    def step(self, action=None):
+        self.t += 1
+        return np.full(3, self.t), 1.0, self.t % self.h == 0, {}
+
+
+class FakeHub(object):
+    """the part of VecChargingHub the adapters use; obs[:, 0] = clock, obs[:, 1] = episode number"""
+
+    def __init__(self, n=4, piles=(2, 3)):
+        self.n_envs, self.piles = n, piles
+        self.act_dim, self.obs_dim = sum(piles) + 2, 13
+        self.t, self.ep, self.tel_on, self.closed = 0, 0, False, False
+
+    def _obs(self):
+        o = np.zeros((self.n_envs, self.obs_dim), dtype=np.float32)
+        o[:, 0], o[:, 1] = self.t, self.ep
+        return o
+
+    def reset(self):
+        self.t = 0
+        self.ep += 1
+        return self._obs()
+
+    def step(self, actions):
+        assert np.asarray(actions).shape == (self.n_envs, self.act_dim)
+        self.t = (self.t + 1) % 96
+        done = np.full(self.n_envs, self.t == 0)
+        return self._obs(), np.ones(self.n_envs, dtype=np.float32), done, {}
+
+    def set_telemetry(self, on=True):
+        self.tel_on = on
+
+    def telemetry(self):
+        assert self.tel_on
+        return np.tile(np.arange(24, dtype=np.float64), (self.n_envs, 1))
+
+    def close(self):
+        self.closed = True
+
+
+def test_time_limit_semantics():
+    env = wrappers.TimeLimit(FakeSingle(), 10)
+    with pytest.raises(AssertionError):
+        env.step(None)
+    env.reset()
+    for i in range(9):
+        _, _, done, info = env.step(None)
+        assert not done and info == {}
+    _, _, done, info = env.step(None)
+    assert done and info["TimeLimit.truncated"] is True
+    # the hub's own done inside the limit is passed through untouched (96 < 999, the reference's registration)
+    env = wrappers.TimeLimit(FakeSingle(), wrappers.MAX_EPISODE_STEPS)
+    env.reset()
+    dones = [env.step(None)[2] for _ in range(96)]
+    assert dones == [False] * 95 + [True]
+    assert env.unwrapped.t == 96 and env.h == 96  # attribute passthrough
+
+
+def test_make_rejects_unknown_id():
+    with pytest.raises(ValueError):
+        wrappers.make("evcssp_env_cpp:charging-hub-v5")
+    assert wrappers.ENV_ID == "charging-hub-v6" and wrappers.MAX_EPISODE_STEPS == 999
+
+
+def test_sb3_convention_autoreset_and_info():
+    hub = FakeHub()
+    env = wrappers.HubVecEnv(vec=hub, telemetry=True)
+    assert env.num_envs == 4 and env.action_space.shape == (7,) and env.observation_space.shape == (13,)
+    obs = env.reset()
+    assert obs.shape == (4, 13) and hub.ep == 1
+    a = np.zeros((4, 7), dtype=np.float32)
+    for t in range(95):
+        obs, rew, dones, infos = env.step(a)
+        assert not dones.any() and obs[0, 0] == t + 1 and "terminal_observation" not in infos[0]
+    env.step_async(a)
+    obs, rew, dones, infos = env.step_wait()
+    assert dones.all() and hub.ep == 2 and obs[0, 1] == 2 and obs[0, 0] == 0       # first obs of the next episode
+    assert infos[2]["terminal_observation"][1] == 1 and infos[2]["TimeLimit.truncated"] is False
+    assert infos[0]["re_used_renew"] == 10.0 and list(infos[0]["re_ev_power_list"]) == [11.0, 12.0]
+    assert infos[0]["re_hy_gen"] == 900.0
+    env.close()
+    assert hub.closed
+
+
+def test_sb3_convention_time_limit():
+    env = wrappers.HubVecEnv(vec=FakeHub(), max_episode_steps=10)
+    env.reset()
+    a = np.zeros((4, 7), dtype=np.float32)
+    for t in range(9):
+        assert not env.step(a)[2].any()
+    obs, _, dones, infos = env.step(a)
+    assert dones.all() and infos[0]["TimeLimit.truncated"] is True and infos[0]["terminal_observation"][0] == 10
+    assert obs[0, 0] == 0
+
+
+def test_gymnasium_convention():
+    hub = FakeHub()
+    env = wrappers.HubVectorEnv(vec=hub)
+    obs, info = env.reset(seed=3)
+    assert info == {} and obs.shape == (4, 13)
+    a = np.zeros((4, 7), dtype=np.float32)
+    for t in range(95):
+        obs, rew, term, trunc, info = env.step(a)
+        assert not term.any() and not trunc.any()
+    obs, rew, term, trunc, info = env.step(a)
+    assert term.all() and not trunc.any() and obs[0, 1] == 1      # last observation of the episode, no reset yet
+    obs, rew, term, trunc, info = env.step(a)                      # "next step" autoreset
+    assert hub.ep == 2 and obs[0, 0] == 0 and not term.any() and (rew == 0).all()
+    obs, rew, term, trunc, info = env.step(a)
+    assert obs[0, 0] == 1 and (rew == 1).all()
+    strict = wrappers.HubVectorEnv(vec=FakeHub(), autoreset=False, max_episode_steps=5)
+    strict.reset()
+    for t in range(4):
+        strict.step(a)
+    _, _, term, trunc, _ = strict.step(a)
+    assert trunc.all() and not term.any()
+    with pytest.raises(RuntimeError):
+        strict.step(a)
+
+
+def test_series_loaders(tmp_path):
+    rs = np.random.RandomState(0)
+    pv = rs.uniform(0, 40, size=(7, 96))
+    np.save(tmp_path / "pv.npy", pv)
+    np.savetxt(tmp_path / "wd.csv", rs.uniform(0, 90, size=(150, 96)), delimiter=",")
+    price = rs.uniform(0.05, 0.3, size=96)
+    price.astype("<f8").tofile(tmp_path / "price.f64")
+    d = data_io.write_data_dir(str(tmp_path / "hub"), price=str(tmp_path / "price.f64"), pv=str(tmp_path / "pv.npy"),
+                               wd=str(tmp_path / "wd.csv"))
+    got_pv = np.fromfile(d + "/pv_100x96.f64").reshape(100, 96)
+    assert np.array_equal(got_pv[:7], pv) and np.array_equal(got_pv[7:14], pv) and np.array_equal(got_pv[98], pv[0])
+    assert np.array_equal(np.fromfile(d + "/price_96.f64"), price)
+    assert np.fromfile(d + "/wd_150x96.f64").shape == (150 * 96,)
+    default = os.path.join(orclib.DATA_DIR, "car_flow_possibility_list_save.csv")
+    assert open(d + "/car_flow_possibility_list_save.csv", "rb").read() == open(default, "rb").read()
+    for bad in (dict(price=np.ones(96)), dict(price=np.ones(95)), dict(pv=np.ones((101, 96))), dict(wd=np.ones((3, 95))),
+                dict(pv=np.full((2, 96), np.nan)), dict(arrival_cdf=np.ones((96, 300)))):
+        with pytest.raises(ValueError):
+            data_io.write_data_dir(str(tmp_path / "bad"), **bad)
+    with pytest.raises(ValueError):
+        c = np.tile(np.linspace(0, 1, 301), (96, 1))
+        c[5, 100] = 0.9
+        data_io.check_cdf(c)
+
+
+def test_user_arrival_cdf_through_the_oracle_parser(tmp_path):
+    """a Poisson table written by write_data_dir, parsed with the reference's float parser (CHS.hpp:138-155 as
+    restated in the oracle), gives the Poisson quantiles back through the arrival lookup (CHS.hpp:731-743)"""
+    rates = 40 + 30 * np.sin(np.arange(96) * 2 * np.pi / 96)
+    cdf = data_io.cdf_from_rates(rates)
+    assert cdf.shape == (96, 301) and np.all(np.diff(cdf, axis=1) >= 0) and abs(cdf[:, -1] - 1).max() < 1e-9
+    d = data_io.write_data_dir(str(tmp_path / "hub"), arrival_cdf=cdf)
+    t = orc.orc_tables_load(d.encode())
+    assert t
+    for time in (0, 17, 48, 95):
+        for k in (0, 1, 250, 500, 900, 998, 999):
+            u = np.float32(np.float32(k) / np.float32(999.0))
+            want = int(np.argmax(np.round(cdf[time], 8).astype(np.float32).astype(np.float64) >= float(u))) \
+                if np.round(cdf[time], 8).astype(np.float32).max() >= u else 300
+            got = orc.orc_arrival_index(t, time, k)
+            assert abs(got - want) <= 1, (time, k, got, want)     # 1-ulp parser effects may move a boundary cell
+            assert abs(got - rates[time]) < 6 * np.sqrt(rates[time]) + 2 or k in (0, 999)
