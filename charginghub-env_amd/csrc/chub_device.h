@@ -28,6 +28,7 @@ constexpr int kQCap = 16;        // FCEV FIFO capacity (the reference list is un
 constexpr int kMaxLine = 10;     // Station::max_line, CHS.hpp:197
 constexpr int kLevels = 1000;    // RandomUtil::uniform_rand has 1000 levels k/999, CHS.hpp:35-44
 constexpr int kBalkTab = 512;
+constexpr int kSocLevels = 16384;  // PHILOX: equiprobable levels of the EV arrival SoC (top 14 bits of a Philox word)
 constexpr int kPolarMaxTrials = 32;
 constexpr int kTelemCount = 24;
 
@@ -106,7 +107,9 @@ struct Tables {
     CHUB_G(const float) normal_icdf;  // [4097] inverse CDF of N(0,1), and
     CHUB_G(const float) normal_tail;  // [4097] its second level for the lowest / highest cell   (PHILOX mode)
     CHUB_G(const double) sin96;       // [96]   sin(2*pi*t/96), the time feature of the observation (MGR:319-320)
-    CHUB_G(const float) ttab[2];      // [1000] soc_to_time(target level k) of station k's curve (target = 80 + 20*k/999)
+    CHUB_G(const float) ttab[2];      // [1000][2] per target level k of station k: target SoC (= 80 + 20*k/999), soc_to_time(target)
+    CHUB_G(const float) newcar[2];    // [kSocLevels][4] PHILOX: per arrival-SoC level of station k: soc, soc_to_time(soc),
+                                      //                 time_to_power(soc_to_time(soc)), 0 -- what add_car derives from it
 };
 
 struct HubParams {

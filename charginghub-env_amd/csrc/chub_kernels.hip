@@ -611,10 +611,20 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
             const int s_hub_slot = (k ? hp.S[0] : 0) + (s_lane & (H - 1));
             PhiloxCtx p2{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + s_env)};
             const U4 o = p2.block(SITE_SOC, (uint32_t) s_hub_slot, 0);  // word 0 SoC, 1 target level, 2 extra stay
-            const float arrive = soc_from_word(tb.soc_d_icdf, o.v[0]);
-            const int lev = (int) (o.v[1] % 1000u);
+            // everything add_car derives from the arrival SoC is tabulated per SoC level (Tables::newcar)
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x4 nw = ((CHUB_G(const f32x4)) tb.newcar[k])[o.v[0] >> 18];
+            const f32x2 tg = ((CHUB_G(const f32x2)) tb.ttab[k])[o.v[1] % 1000u];
             const int late = late_from_word(tb.late_thr, o.v[2]);
-            const NewCar c = make_car<TYPE>(arrive, uniform_level(lev, 80.0f, 100.0f), tb.ttab[k][lev], late, cp);
+            NewCar c;
+            c.soc = nw.x;
+            c.t_soc = nw.y;
+            c.power = nw.z;
+            c.target = tg.x;
+            c.t_target = tg.y;
+            const int stay = (int) ceilf(__fsub_rn(c.t_target, c.t_soc)) + late;  // calculate_min_charging_time + mk_late_time
+            c.stay = stay > 127 ? 127 : stay;
             o_soc[src] = c.soc;
             o_target[src] = c.target;
             o_tt[src] = c.t_target;

@@ -308,7 +308,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     {   // arena: generous upper bound of everything allocated below (telemetry buffers come later, separately)
         const size_t S_tot = (size_t) (cfg->station_list[0] + cfg->station_list[1]);
         const size_t per_env = S_tot * 40 + 2048;
-        const size_t want = (size_t) n_envs * per_env + ((size_t) 4 << 20);
+        const size_t want = (size_t) n_envs * per_env + ((size_t) 8 << 20);
         void *q = nullptr;
         if (!getenv("CHUB_NO_ARENA") && hipMalloc(&q, want) == hipSuccess) {
             e->arena = (char *) q;
@@ -484,14 +484,33 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     }
     std::vector<double> sin96(96);
     for (int t = 0; t < 96; t++) sin96[t] = sin((2 * M_PI / 96) * (double) t);  // np.sin(k * time), MGR:319-320
-    std::vector<float> ttab[2];
+    std::vector<float> ttab[2], newcar[2];
     for (int s = 0; s < 2; s++) {
-        ttab[s].resize(kLevels);
+        const bool fast = hp.type[s] == CHUB_FAST, cpw = hp.constant_charging != 0;
+        ttab[s].resize(2 * kLevels);
         for (int k = 0; k < kLevels; k++) {
             float tr = (float) k / 999.0f;
             float target = tr * (100.0f - 80.0f) + 80.0f;  // uniform_rand(80, 100), CHS.hpp:35-44
-            ttab[s][k] = hp.type[s] == CHUB_FAST ? fast_soc_to_time(target, hp.constant_charging != 0)
-                                                 : slow_soc_to_time(target, hp.constant_charging != 0);
+            ttab[s][2 * k] = target;
+            ttab[s][2 * k + 1] = fast ? fast_soc_to_time(target, cpw) : slow_soc_to_time(target, cpw);
+        }
+        // PHILOX: what add_car (CHS.hpp:864-877 / 1029-1042) derives from the arrival SoC, per SoC level: level l sits at
+        // probability (l + 0.5) / kSocLevels of the tabulated inverse CDF (cell l >> 2, fraction ((l & 3) + 0.5) / 4)
+        newcar[s].assign(4 * (size_t) kSocLevels, 0.0f);
+        for (int l = 0; l < kSocLevels; l++) {
+            const int idx = l >> 2;
+            const float frac = ((float) (l & 3) + 0.5f) * 0.25f;
+            const float a = icdf[idx], b = icdf[idx + 1];
+            const float diff = b - a;
+            const float prod = diff * frac;
+            float d = a + prod;
+            if ((double) d < 1.0) d = 1.0f;  // mk_soc, CHS.hpp:804-814
+            else if ((double) d > 10.0) d = 10.0f;
+            const float soc = (float) (75.0 - 5.0 * (double) d);
+            const float t_soc = fast ? fast_soc_to_time(soc, cpw) : slow_soc_to_time(soc, cpw);
+            newcar[s][4 * l] = soc;
+            newcar[s][4 * l + 1] = t_soc;
+            newcar[s][4 * l + 2] = fast ? fast_time_to_power(t_soc, cpw) : slow_time_to_power(t_soc, cpw);
         }
     }
     build_hy_table(hp, e->hy_table);
@@ -514,6 +533,8 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     if ((rc = dev_upload(e, &e->tb.sin96, sin96))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.ttab[0], ttab[0]))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.ttab[1], ttab[1]))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.newcar[0], newcar[0]))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.newcar[1], newcar[1]))) return bail(rc);
 
     // ---- state in HBM
     const size_t N = (size_t) n_envs, NS = N * (size_t) (hp.S[0] + hp.S[1]);

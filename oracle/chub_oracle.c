@@ -303,6 +303,21 @@ float orc_soc_from_word(const orc_tables *t, uint32_t w) {
     return soc_from_experience(d);
 }
 
+/* PHILOX mode, EV arrivals: the arrival SoC takes one of 16384 equiprobable levels (the top 14 bits of the word):
+ * level l sits at probability (l + 0.5) / 16384 of the same tabulated inverse CDF -- cell l >> 2, fraction
+ * ((l & 3) + 0.5) / 4.  A finite level set lets an implementation tabulate everything add_car derives from the
+ * arrival SoC (curve time, initial power) once per station. */
+float orc_soc_level_value(const orc_tables *t, uint32_t level) {
+    uint32_t idx = level >> 2;
+    float frac = ((float) (level & 3u) + 0.5f) * 0.25f;
+    float a = t->soc_d_icdf[idx], b = t->soc_d_icdf[idx + 1];
+    float diff = b - a;
+    float prod = diff * frac;
+    float d = a + prod;
+    return soc_from_experience(d);
+}
+float orc_soc_level_from_word(const orc_tables *t, uint32_t w) { return orc_soc_level_value(t, w >> 18); }
+
 /* CHS:816-830 mk_late_time -- both pile classes pass "slow" (CHS:869, CHS:1034): max(0, round(N(2,2))) */
 int orc_mk_late_time(orc_rng *r) {
     float car_number = normal_float_compat(r, 2.0f, 2.0f);
@@ -620,7 +635,7 @@ static void add_car(orc_station *s, orc_rng *r, const orc_tables *t, int i) {
         /* PHILOX: one block per admitted slot -- word 0 arrival SoC, word 1 target level, word 2 extra stay */
         uint32_t o[4];
         philox_block(r, ORC_PU_SOC, slot, 0, o);
-        s->p_arrive_soc[i] = orc_soc_from_word(t, o[0]);
+        s->p_arrive_soc[i] = orc_soc_level_from_word(t, o[0]);
         s->p_current_soc[i] = s->p_arrive_soc[i];
         s->p_target_soc[i] = orc_uniform_level((int) (o[1] % 1000u), 80, 100);
         late = orc_late_from_word(t, o[2]);

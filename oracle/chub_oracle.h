@@ -146,7 +146,9 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 int orc_draw_k(orc_rng *r, int tag, int index, int j);
 float orc_mk_soc(orc_rng *r);                                          /* CHS:804-814, reference streams */
 int orc_mk_late_time(orc_rng *r);                                      /* CHS:816-830 ("slow" law), reference streams */
-float orc_soc_from_word(const orc_tables *t, uint32_t w);              /* PHILOX mode: mk_soc from one 32-bit uniform */
+float orc_soc_from_word(const orc_tables *t, uint32_t w);              /* PHILOX mode: mk_soc from one 32-bit uniform (FCEV) */
+float orc_soc_level_value(const orc_tables *t, uint32_t level);       /* PHILOX mode: EV arrival SoC of level 0..16383 */
+float orc_soc_level_from_word(const orc_tables *t, uint32_t w);       /* PHILOX mode: EV arrival SoC from one uniform */
 int orc_late_from_word(const orc_tables *t, uint32_t w);               /* PHILOX mode: mk_late_time from one uniform */
 int orc_init_station_car_number(orc_rng *r, const orc_tables *t, int station, int mu); /* CHS:832-842 */
 float orc_normal_from_word(const orc_tables *t, uint32_t w);           /* PHILOX mode: N(0,1) from one 32-bit uniform */

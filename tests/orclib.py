@@ -80,6 +80,8 @@ def _load_oracle():
         "orc_mk_soc": (F, [P]),
         "orc_mk_late_time": (I, [P]),
         "orc_soc_from_word": (F, [P, C.c_uint32]),
+        "orc_soc_level_from_word": (F, [P, C.c_uint32]),
+        "orc_soc_level_value": (F, [P, C.c_uint32]),
         "orc_late_from_word": (I, [P, C.c_uint32]),
         "orc_init_station_car_number": (I, [P, P, I, I]),
         "orc_normal_from_word": (F, [P, C.c_uint32]),
