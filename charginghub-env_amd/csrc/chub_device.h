@@ -134,6 +134,8 @@ struct HubParams {
     double cpr_w12;          // W_1 + W_2 of the compressor, J/mol
     double renew_fluct1, price_fluct1;  // 1 + fluctuate
     double price_mean, price_std;
+    // correctly rounded reciprocals of the tail's run-time constant divisors (div_c in chub_kernels.hip)
+    double rc_cells, rc_cap_mass, rc_vm60k, rc_price_std, rc_half_range[2];
     float hv_rate;           // f32(f32(0.3) * f32(permeate))
     int32_t slot_block;      // experiments: workgroup size of the PHILOX slot kernel (128 / 256 / 512; env CHUB_SLOT_BLOCK)
     int32_t fused;           // PHILOX: run the per-env tail inside the slot launch (env CHUB_FUSED=0 turns it off)

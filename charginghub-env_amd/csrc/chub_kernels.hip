@@ -514,6 +514,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     if (!RESET && valid)
         slot_advance<TYPE, MODE == MODE_PHILOX>(hp, sa, sl, r, idx, (uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot, cp,
                                                 on_override);
+    if (hp.ablate & 2) r.needs_step = false;  // experiment: no car_step
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): arrivals, renege, balk, admission
     const bool empty = valid && !r.car;
@@ -610,7 +611,15 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
             const int s_env = env_first + s_wave * upw + (s_lane >> logH);
             const int s_hub_slot = (k ? hp.S[0] : 0) + (s_lane & (H - 1));
             PhiloxCtx p2{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + s_env)};
-            const U4 o = p2.block(SITE_SOC, (uint32_t) s_hub_slot, 0);  // word 0 SoC, 1 target level, 2 extra stay
+            U4 o;
+            if (hp.ablate & 128) {  // experiment: no Philox block per new car
+                o.v[0] = (uint32_t) src * 2654435761u;
+                o.v[1] = o.v[0] >> 7;
+                o.v[2] = o.v[0] ^ 0x55555555u;
+                o.v[3] = 0;
+            } else {
+                o = p2.block(SITE_SOC, (uint32_t) s_hub_slot, 0);  // word 0 SoC, 1 target level, 2 extra stay
+            }
             // everything add_car derives from the arrival SoC is tabulated per SoC level (Tables::newcar)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -750,7 +759,8 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         hot.z = __float_as_uint(r.t_soc);
         hot.w = (uint32_t) r.tl | (r.charge ? 128u : 0u) | ((uint32_t) r.stay << 8);
         ((CHUB_G(u32x4)) sl.hot)[idx] = hot;
-        if (adm || r.leave || RESET) {
+        if (hp.ablate & 8) {  // experiment: no cold-array stores
+        } else if (adm || r.leave || RESET) {
             sl.target[idx] = adm ? nc.target : 0.0f;
             sl.init_soc[idx] = adm ? nc.soc : 0.0f;
             sl.soc[idx] = adm ? nc.soc : 0.0f;
@@ -871,12 +881,23 @@ __device__ __forceinline__ double j2601_target(double p) {
     }
     return r;
 }
-__device__ __forceinline__ double pressure_to_mass(double p) { return (6.3 * 1000) * (p / 70); }  // HYD:390-391
+// x / c for a divisor known ahead of time, without the ~35-instruction division sequence on the tail's dependent chain:
+// q = x * RN(1/c), one exact residual, one correction (Markstein; Brisebarre, Muller, Raina 2004).  The result is the
+// correctly rounded quotient except for isolated (divisor-specific) x where it is one ulp off -- 1e-16 relative on f64
+// values whose parity bar is 1e-5.
+__device__ __forceinline__ double div_c(double x, double c, double rc) {
+    const double q = x * rc;
+    const double r = __fma_rn(-q, c, x);
+    return __fma_rn(r, rc, q);
+}
+#define DIV_K(x, c) div_c((x), (double) (c), 1.0 / (double) (c))  // literal divisor: reciprocal folded at compile time
+
+__device__ __forceinline__ double pressure_to_mass(double p) { return (6.3 * 1000) * DIV_K(p, 70); }  // HYD:390-391
 // HYD:308-321
 __device__ __forceinline__ void j2601_time_mass(double p0, double &time_need, double &mass_need) {
     const double target = j2601_target(p0);
-    if (p0 < 5) time_need = (69 - p0) / 18.5 + (87.4 - 69) / 7.2;
-    else time_need = (target - p0) / ((5 <= p0 && p0 < 70) ? 18.5 : 0.0);
+    if (p0 < 5) time_need = DIV_K(69 - p0, 18.5) + (87.4 - 69) / 7.2;
+    else time_need = (5 <= p0 && p0 < 70) ? DIV_K(target - p0, 18.5) : (target - p0) / 0.0;
     mass_need = pressure_to_mass(target) - pressure_to_mass(p0);
 }
 
@@ -1084,7 +1105,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         }
         const double total_mass_need = total_mass;
         if (hp.ablate & 4096) {  // experiment: skip the H2 / money chain
-            store_soc = cap / cap_mass;
+            store_soc = div_c(cap, cap_mass, hp.rc_cap_mass);
             reward = total_mass + act_el;
         } else {
         // ---- hy_step (HYD:160-195): production clamp, electrolyser + compressor power, tank
@@ -1095,19 +1116,19 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         double charge_temp = act_el * hp.v_h_max * (15 * 60);
         charge_temp = charge_temp < upper_charge ? charge_temp : upper_charge;
         charge_temp = charge_temp > must_chg ? charge_temp : must_chg;
-        double flow = charge_temp / (15 * 60);
+        double flow = DIV_K(charge_temp, 15 * 60);
         flow = flow < hp.v_h_max ? flow : hp.v_h_max;
         double ele_power = 0.0;
         if (hp.cells != 0.0) {  // Electrolyser.get_power, HYD:38-48
-            const double v_H_mass = flow / hp.cells;
-            const double v_H_mol = v_H_mass / 2.02;
+            const double v_H_mass = div_c(flow, hp.cells, hp.rc_cells);
+            const double v_H_mol = DIV_K(v_H_mass, 2.02);
             const double v_H_L = v_H_mol * hp.v_M;
             const double v_H = v_H_L * 1000 * 60;
-            const double temp = v_H * 2 * 96487 / (hp.v_M * 1000 * 60);
+            const double temp = div_c(v_H * 2 * 96487, hp.v_M * 1000 * 60, hp.rc_vm60k);
             double power = temp * temp * 0.326 + temp * 1.476;
-            ele_power = hp.cells * power / 1000;
+            ele_power = DIV_K(hp.cells * power, 1000);
         }
-        const double cpr_power = ((flow / 2.02) * hp.cpr_w12 / 0.8) / 1000;  // Compressor.generate_W, HYD:74-82
+        const double cpr_power = DIV_K(DIV_K(DIV_K(flow, 2.02) * hp.cpr_w12, 0.8), 1000);  // Compressor.generate_W, HYD:74-82
         // sty_step (HYD:104-126)
         cap += flow * 15 * 60;
         double lower_change = cap - 0.1 * cap_mass;
@@ -1116,18 +1137,14 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         const double not_meet = total_mass_need - hy_use;
         cap -= hy_use;
         cap -= cap * hp.hydro_loss;
-        store_soc = cap / cap_mass;
+        store_soc = div_c(cap, cap_mass, hp.rc_cap_mass);
         const double all_power_second = ele_power + cpr_power;
         const bool gen_hy = flow > 0.5;  // MGR:161,173-179
         // ---- renewable netting (MGR:183-213)
         double hydrogen_power = all_power_second;
         double ev_power_sum = charging_power;
         double e0 = P0, e1 = P1;
-        if (0.0 + P0 + P1 > 0) {
-            const double fc_rate = charging_power / (0.0 + P0 + P1);
-            e0 = fc_rate * P0;
-            e1 = fc_rate * P1;
-        }
+        // fc_rate = charging_power / (0 + P0 + P1) (MGR:187-191) divides a positive finite number by itself: exactly 1
         double used_renew = 0.0;
         if (re_new_power >= hydrogen_power) {
             re_new_power -= hydrogen_power;
@@ -1154,7 +1171,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         if (fc_power > hp.fc_max_power) fc_power = hp.fc_max_power;
         else if (fc_power < 0) fc_power = 0.0;
         else if (fc_power > ev_power_sum) fc_power = ev_power_sum;
-        double hy_to_use = fc_power * 1500 / 119.6;
+        double hy_to_use = DIV_K(fc_power * 1500, 119.6);
         hy_to_use = cap < hy_to_use ? cap : hy_to_use;
         fc_power = fc_power > 0 ? fc_power : 0.0;  // HYD:426 (not H2-limited)
         cap -= hy_to_use;                          // Store_SOC is not refreshed (HYD:428)
@@ -1177,7 +1194,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         const double income_hys = 6 / 1000.0 * hy_use;
         const double not_meet_loss = -10 / 1000.0 * not_meet;
         const double hy_cost = -real_price_dollar * hydrogen_power;
-        reward = (income_hys + income_evs + income_evs_serve + hy_cost + 1 * hy_loss + not_meet_loss) / 50;
+        reward = DIV_K(income_hys + income_evs + income_evs_serve + hy_cost + 1 * hy_loss + not_meet_loss, 50);
         if (hp.telemetry) {
             CHUB_TEL(0, act_el); CHUB_TEL(1, flow); CHUB_TEL(2, all_power_second); CHUB_TEL(4, cap);
             CHUB_TEL(5, total_mass_need); CHUB_TEL(6, hy_use); CHUB_TEL(7, not_meet); CHUB_TEL(8, fc_power);
@@ -1226,24 +1243,24 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         n++;                           \
     } while (0)
     CHUB_OBS(tb.sin96[t_next]);
-    CHUB_OBS((price_next - hp.price_mean) / hp.price_std);
+    CHUB_OBS(div_c(price_next - hp.price_mean, hp.price_std, hp.rc_price_std));
     if (hp.S[0] > 0) {
-        const double half_range = (double) hp.transformer_limit[0] / 2;
-        CHUB_OBS(((double) mn0 - half_range) / half_range);
-        CHUB_OBS(((double) P0f - half_range) / half_range);
-        CHUB_OBS(((double) mx0 - half_range) / half_range);
-        CHUB_OBS((double) ln0 / 5);
+        const double half_range = (double) hp.transformer_limit[0] / 2, rc_hr = hp.rc_half_range[0];
+        CHUB_OBS(div_c((double) mn0 - half_range, half_range, rc_hr));
+        CHUB_OBS(div_c((double) P0f - half_range, half_range, rc_hr));
+        CHUB_OBS(div_c((double) mx0 - half_range, half_range, rc_hr));
+        CHUB_OBS(DIV_K((double) ln0, 5));
     }
     if (hp.S[1] > 0) {
-        const double half_range = (double) hp.transformer_limit[1] / 2;
-        CHUB_OBS(((double) mn1 - half_range) / half_range);
-        CHUB_OBS(((double) P1f - half_range) / half_range);
-        CHUB_OBS(((double) mx1 - half_range) / half_range);
-        CHUB_OBS((double) ln1 / 5);
+        const double half_range = (double) hp.transformer_limit[1] / 2, rc_hr = hp.rc_half_range[1];
+        CHUB_OBS(div_c((double) mn1 - half_range, half_range, rc_hr));
+        CHUB_OBS(div_c((double) P1f - half_range, half_range, rc_hr));
+        CHUB_OBS(div_c((double) mx1 - half_range, half_range, rc_hr));
+        CHUB_OBS(DIV_K((double) ln1, 5));
     }
     CHUB_OBS(store_soc);
-    CHUB_OBS(re_pv / (42 * 5));
-    CHUB_OBS(re_wd / (92 * 1));
+    CHUB_OBS(DIV_K(re_pv, 42 * 5));
+    CHUB_OBS(DIV_K(re_wd, 92 * 1));
 #undef CHUB_OBS
     if (!RESET) {
         const bool dn = (sa.t + 1) >= 96;  // MGR:271-273

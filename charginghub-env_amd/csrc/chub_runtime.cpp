@@ -369,6 +369,13 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
         double W_2 = part2 * (-1 + pow(P_out / P_a, part3));
         hp.cpr_w12 = W_1 + W_2;
     }
+    hp.rc_cells = hp.cells != 0.0 ? 1.0 / hp.cells : 0.0;
+    hp.rc_cap_mass = 1.0 / hp.cap_mass;
+    hp.rc_vm60k = 1.0 / (hp.v_M * 1000 * 60);
+    for (int k = 0; k < 2; k++) {
+        const double half_range = (double) hp.transformer_limit[k] / 2;
+        hp.rc_half_range[k] = half_range != 0.0 ? 1.0 / half_range : 0.0;
+    }
     hp.renew_fluct1 = 1 + cfg->renew_fluctuate;
     hp.price_fluct1 = 1 + cfg->price_fluctuate;
     {
@@ -380,6 +387,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
         }
         hp.price_mean = mean;
         hp.price_std = sqrt(np_sum96(dev) / 96);
+        hp.rc_price_std = 1.0 / hp.price_std;
     }
 
     // arrival index per (slot of day, level): first j with CDF[t][j] >= u_k, else 300 (CHS.hpp:731-743),

@@ -237,5 +237,84 @@ class HubVectorEnv(_HubBatch):
             _HubBatch.close(self)
 
 
-__all__ = ["ENV_ID", "MAX_EPISODE_STEPS", "TimeLimit", "make", "register", "HubVecEnv", "HubVectorEnv",
+class StaggeredHub(object):
+    """Non-lock-step episodes: G groups of envs whose days are offset against each other by 96/G slots.
+
+    The N envs of one VecChargingHub share one clock, so all N episodes end in the same step -- convenient for the
+    kernels, but a learner then sees every env at the same time of day.  This front splits the env range into G
+    contiguous groups (one hub each, global env ids and therefore Philox streams unchanged: group g covers
+    ``[g*N/G, (g+1)*N/G)``), and keeps group g ``g * 96 // G`` slots ahead: ``reset()`` resets all groups and then walks
+    group g through its head start with the all-on action (the reference's ``step(None)``, MGR:146-147).  ``step()`` steps
+    every group, and a group whose day has ended (its own ``done``) is reset on the spot (``autoreset=True``): the
+    returned observation rows of that group are the first of its next episode, ``info['terminal_observation']`` keeps
+    the last ones and ``info['reset_groups']`` lists the groups reset in this step.
+    """
+
+    def __init__(self, n_envs, groups, station_list, station_type_list, seed=0, env_id0=0, autoreset=True,
+                 hub_factory=None, **hub_kwargs):
+        groups = int(groups)
+        if groups < 1 or n_envs % groups:
+            raise ValueError("n_envs must split evenly over the groups")
+        if groups > 96:
+            raise ValueError("at most 96 groups (one per slot of the day)")
+        make = hub_factory or VecChargingHub
+        self.n_envs, self.groups, self.per = int(n_envs), groups, int(n_envs) // groups
+        self.offsets = [g * 96 // groups for g in range(groups)]
+        self.hubs = [make(self.per, station_list, station_type_list, seed=seed, env_id0=env_id0 + g * self.per,
+                          **hub_kwargs) for g in range(groups)]
+        self.obs_dim, self.act_dim = self.hubs[0].obs_dim, self.hubs[0].act_dim
+        self.piles, self.n_slots = self.hubs[0].piles, self.act_dim - 2
+        self.autoreset = bool(autoreset)
+
+    def _rows(self, g):
+        return slice(g * self.per, (g + 1) * self.per)
+
+    @property
+    def clocks(self):
+        """slot of day of every group"""
+        return [h.clock for h in self.hubs]
+
+    def reset(self):
+        obs = np.zeros((self.n_envs, self.obs_dim), dtype=np.float32)
+        head = np.zeros((self.per, self.act_dim), dtype=np.float32)
+        head[:, :self.n_slots] = 1.0  # step(None): every pile on, fuel cell and electrolyser at 0 (MGR:146-147, 384-404)
+        for g, h in enumerate(self.hubs):
+            o = h.reset()
+            for _ in range(self.offsets[g]):
+                o = h.step(head)[0]
+            obs[self._rows(g)] = o
+        return obs
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        if a.shape != (self.n_envs, self.act_dim):  # MGR:148
+            raise AssertionError("actions must have shape (%d, %d)" % (self.n_envs, self.act_dim))
+        obs = np.zeros((self.n_envs, self.obs_dim), dtype=np.float32)
+        reward = np.zeros(self.n_envs, dtype=np.float32)
+        done = np.zeros(self.n_envs, dtype=bool)
+        info = {}
+        for g, h in enumerate(self.hubs):
+            rows = self._rows(g)
+            o, r, d, _ = h.step(a[rows])
+            reward[rows], done[rows] = r, d
+            if d.all() and self.autoreset:
+                info.setdefault("terminal_observation", np.zeros_like(obs))[rows] = o
+                info.setdefault("reset_groups", []).append(g)
+                o = h.reset()
+            obs[rows] = o
+        return obs, reward, done, info
+
+    def set_telemetry(self, on=True):
+        for h in self.hubs:
+            h.set_telemetry(on)
+
+    def telemetry(self):
+        return np.concatenate([h.telemetry() for h in self.hubs], axis=0)
+
+    def close(self):
+        for h in self.hubs:
+            h.close()
+
+
+__all__ = ["ENV_ID", "StaggeredHub", "MAX_EPISODE_STEPS", "TimeLimit", "make", "register", "HubVecEnv", "HubVectorEnv",
            "telemetry_info", "Box"]

@@ -469,3 +469,40 @@ def test_make_time_limit_on_dropin():
     assert steps == 96 and info == {}
     assert abs(ret - 34.858789741560585) < 1e-9       # the reference's own smoke run
     env.close()
+
+
+def test_staggered_groups_on_gpu():
+    """non-lock-step episodes: 4 groups a quarter day apart; every group is bit-identical to a plain
+    hub over the same global env range that got the same head start"""
+    chub = hub()
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
+    n, G, seed = 64, 4, 31
+    st = chub.StaggeredHub(n, G, seed=seed, env_id0=500, **kw)
+    obs = st.reset()
+    assert st.clocks == [0, 24, 48, 72]
+    g = 2
+    ref = chub.VecChargingHub(n // G, seed=seed, env_id0=500 + g * (n // G), **kw)
+    o = ref.reset()
+    head = np.zeros((n // G, 47), dtype=np.float32)
+    head[:, :45] = 1.0
+    for _ in range(48):
+        o = ref.step(head)[0]
+    rows = slice(g * (n // G), (g + 1) * (n // G))
+    assert np.array_equal(obs[rows], o)
+    rs = np.random.RandomState(3)
+    ends = []
+    for t in range(1, 110):
+        a = rs.uniform(-1, 1, (n, 47)).astype(np.float32)
+        obs, rew, done, info = st.step(a)
+        o, r, d, _ = ref.step(a[rows])
+        assert np.array_equal(rew[rows], r) and np.array_equal(done[rows], d)
+        if d.all():
+            assert np.array_equal(info["terminal_observation"][rows], o) and g in info["reset_groups"]
+            o = ref.reset()
+        assert np.array_equal(obs[rows], o)
+        ends.append(sorted(set(np.nonzero(done)[0] // (n // G))))
+    assert [t + 1 for t, e in enumerate(ends) if e] == [24, 48, 72, 96]
+    assert [e for e in ends if e] == [[3], [2], [1], [0]]
+    st.close()
+    ref.close()

@@ -141,6 +141,44 @@ def test_gymnasium_convention():
         strict.step(a)
 
 
+class ClockHub(FakeHub):
+    def __init__(self, n, station_list, station_type_list, seed=0, env_id0=0, **kw):
+        FakeHub.__init__(self, n, tuple(station_list))
+        self.env_id0 = env_id0
+
+    @property
+    def clock(self):
+        return self.t
+
+
+def test_staggered_groups():
+    st = wrappers.StaggeredHub(8, 4, [2, 3], ["fast", "slow"], seed=1, env_id0=100, hub_factory=ClockHub)
+    assert [h.env_id0 for h in st.hubs] == [100, 102, 104, 106] and st.offsets == [0, 24, 48, 72]
+    obs = st.reset()
+    assert list(obs[::2, 0]) == [0, 24, 48, 72] and st.clocks == [0, 24, 48, 72]
+    a = np.zeros((8, 7), dtype=np.float32)
+    seen = []
+    for t in range(1, 100):
+        obs, rew, done, info = st.step(a)
+        for g in range(4):
+            ended = (t + st.offsets[g]) % 96 == 0
+            assert done[2 * g] == ended and done[2 * g + 1] == ended
+            if ended:
+                seen.append((t, g))
+                assert g in info["reset_groups"] and obs[2 * g, 0] == 0
+                assert info["terminal_observation"][2 * g, 0] == 0 and info["terminal_observation"][2 * g, 1] == 1
+                assert obs[2 * g, 1] == 2     # next episode
+            else:
+                assert obs[2 * g, 0] == (t + st.offsets[g]) % 96
+    assert seen == [(24, 3), (48, 2), (72, 1), (96, 0)]
+    with pytest.raises(ValueError):
+        wrappers.StaggeredHub(10, 4, [2, 3], ["fast", "slow"], hub_factory=ClockHub)
+    with pytest.raises(AssertionError):
+        st.step(np.zeros((8, 6), dtype=np.float32))
+    st.close()
+    assert all(h.closed for h in st.hubs)
+
+
 def test_series_loaders(tmp_path):
     rs = np.random.RandomState(0)
     pv = rs.uniform(0, 40, size=(7, 96))
