@@ -941,7 +941,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     double cap = 0.0, in_re_wd = 0.0, in_re_pv = 0.0, in_price_next = 0.0, in_price_noise = 0.0;
     double ou_pv = 0.0, ou_wd = 0.0, ou_price = 0.0, z_pv = 0.0, z_wd = 0.0, z_pr = 0.0;
     float a_el_f = 0.0f, a_fc_f = 0.0f, P0f = 0.0f, P1f = 0.0f, mn0 = 0.0f, mx0 = 0.0f, mn1 = 0.0f, mx1 = 0.0f;
-    int pv_day = 0, wd_day = 0, q_len = 0, hv_line = 0, F0i = 0, F1i = 0, ln0 = 0, ln1 = 0, hv_lev = 0;
+    int pv_day = 0, wd_day = 0, q_len = 0, hv_line = 0, F0i = 0, F1i = 0, ln0 = 0, ln1 = 0, hv_lev = 0, hv_arrive = 0;
     if (live) {
         ou_pv = ev.ou[e32];
         ou_wd = ev.ou[n32 + e32];
@@ -969,7 +969,11 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             z_pv = (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[0]);
             z_wd = (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[1]);
             z_pr = (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[2]);
-            if (!RESET) hv_lev = (int) (px.block(SITE_HV, 0, 0).v[0] % 1000u);
+            if (!RESET) {
+                // the FCEV arrival level is state-independent: look its count up now, one byte straight from the table
+                hv_lev = (int) (px.block(SITE_HV, 0, 0).v[0] % 1000u);
+                hv_arrive = (int) tb.cnt_hv[(uint32_t) sa.t * (uint32_t) kLevels + (uint32_t) hv_lev];
+            }
         } else {
             z_pv = sa.exo_z[e32 * 3u + 0u];
             z_wd = sa.exo_z[e32 * 3u + 1u];
@@ -984,7 +988,9 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         for (int i = threadIdx.x; i < 150; i += kEnvBlock) ((double *) s_wd)[i] = tb.wdT[t_next * 150 + i];
         if (!RESET) {
             for (int i = threadIdx.x; i < 102; i += kEnvBlock) ((double *) s_hy)[i] = tb.hy_table[i];
-            for (int i = threadIdx.x; i < kLevels; i += kEnvBlock) ((uint8_t *) s_hv)[i] = tb.cnt_hv[sa.t * kLevels + i];
+            if (MODE == MODE_COMPAT)  // the level comes out of the env's stream later: stage the row (250 dwords)
+                for (int i = threadIdx.x; i < kLevels / 4; i += kEnvBlock)
+                    ((uint32_t *) s_hv)[i] = ((CHUB_G(const uint32_t)) tb.cnt_hv)[sa.t * (kLevels / 4) + i];
         }
         __syncthreads();
     }
@@ -1048,7 +1054,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         // ---- hvs_step (HYD:253-285): FCEV arrivals -> J2601 -> 15-minute FIFO
         double *qt = (double *) ev.q_time + (size_t) e32 * kQCap, *qm = (double *) ev.q_mass + (size_t) e32 * kQCap;
         if (MODE == MODE_COMPAT) hv_lev = rs.level();
-        const int arrive = (int) TAB_HV(hv_lev);
+        const int arrive = MODE == MODE_COMPAT ? (int) TAB_HV(hv_lev) : hv_arrive;
         double total_mass = 0.0;
         if (q_len > 0 || arrive > 0) {
             double total_time = 0.0;
@@ -1289,7 +1295,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 template <bool RESET, int MODE>
 __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, int nb_env) {
     __shared__ double s_pv[100], s_wd[150], s_hy[102];
-    __shared__ uint8_t s_hv[kLevels];
+    __shared__ __attribute__((aligned(16))) uint8_t s_hv[kLevels];
     __shared__ float s_out[kEnvBlock * 16];  // output rows: obs_dim + 2 <= 15 floats
     const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
     env_tail<RESET, MODE, false>(ctx, sa, env, env < (int) ctx->hp.n_envs && !(ctx->hp.ablate & 32), s_pv, s_wd, s_hy, s_hv, s_out);
