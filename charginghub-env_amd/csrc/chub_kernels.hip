@@ -198,18 +198,12 @@ __device__ __forceinline__ StationRec rec_load(CHUB_G(uint32_t) rec, uint32_t u)
 
 // DPP lane exchanges for the butterfly sums.  After the xor-1 and xor-2 steps every lane of a quad holds the quad's
 // sum, so the mirror patterns (lane i <-> 7-i, i <-> 15-i) pair the same partial sums as xor 4 / xor 8 would.
-__device__ __forceinline__ float dpp_xor1(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
-}
-__device__ __forceinline__ float dpp_xor2(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
-}
-__device__ __forceinline__ float dpp_mirror8(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-}
-__device__ __forceinline__ float dpp_mirror16(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
-}
+__device__ __forceinline__ int dppi_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }      // quad_perm [1,0,3,2]
+__device__ __forceinline__ int dppi_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); }      // quad_perm [2,3,0,1]
+__device__ __forceinline__ int dppi_mirror8(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true); }  // row_half_mirror
+__device__ __forceinline__ int dppi_mirror16(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true); } // row_mirror
+// PHILOX-mode station sums are integer sums of slot powers in units of 2^-19 kW (see slot_body); back to kW in f32
+__device__ __forceinline__ float fixed_to_kw(int v) { return (float) v * (1.0f / 524288.0f); }
 
 // PHILOX mode: mk_soc (CHS.hpp:804-814) from one 32-bit uniform by linear interpolation of the tabulated
 // inverse CDF of clip(N(7,3),1,10): 12 bits pick the cell, 20 bits interpolate (three f32 roundings)
@@ -736,17 +730,19 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
             r_chg = __fadd_rn(r_chg, __shfl(v_chg, ubase + i));
         }
     } else {
-        // production: balanced binary-tree sum in f32 over the unit's H lanes (lane i pairs with i^1, i^2, i^4, ...):
-        // DPP lane exchanges inside a 16-lane row, ds_bpermute across rows
-        r_min = urgent ? r.power : 0.0f;
-        r_max = r.car ? r.power : 0.0f;
-        r_chg = r.charge ? r.power : 0.0f;
-        if (H > 1) { r_min += dpp_xor1(r_min); r_max += dpp_xor1(r_max); r_chg += dpp_xor1(r_chg); }
-        if (H > 2) { r_min += dpp_xor2(r_min); r_max += dpp_xor2(r_max); r_chg += dpp_xor2(r_chg); }
-        if (H > 4) { r_min += dpp_mirror8(r_min); r_max += dpp_mirror8(r_max); r_chg += dpp_mirror8(r_chg); }
-        if (H > 8) { r_min += dpp_mirror16(r_min); r_max += dpp_mirror16(r_max); r_chg += dpp_mirror16(r_chg); }
-        if (H > 16) { r_min += __shfl_xor(r_min, 16); r_max += __shfl_xor(r_max, 16); r_chg += __shfl_xor(r_chg, 16); }
-        if (H > 32) { r_min += __shfl_xor(r_min, 32); r_max += __shfl_xor(r_max, 32); r_chg += __shfl_xor(r_chg, 32); }
+        // production: order-independent sums -- every slot power truncated to a multiple of 2^-19 kW, integer butterfly
+        // over the unit's H lanes (DPP lane exchanges inside a 16-lane row, ds_bpermute across rows), one rounding to f32
+        const int q = (int) (r.power * 524288.0f);
+        int i_min = urgent ? q : 0, i_max = r.car ? q : 0, i_chg = r.charge ? q : 0;
+        if (H > 1) { i_min += dppi_xor1(i_min); i_max += dppi_xor1(i_max); i_chg += dppi_xor1(i_chg); }
+        if (H > 2) { i_min += dppi_xor2(i_min); i_max += dppi_xor2(i_max); i_chg += dppi_xor2(i_chg); }
+        if (H > 4) { i_min += dppi_mirror8(i_min); i_max += dppi_mirror8(i_max); i_chg += dppi_mirror8(i_chg); }
+        if (H > 8) { i_min += dppi_mirror16(i_min); i_max += dppi_mirror16(i_max); i_chg += dppi_mirror16(i_chg); }
+        if (H > 16) { i_min += __shfl_xor(i_min, 16); i_max += __shfl_xor(i_max, 16); i_chg += __shfl_xor(i_chg, 16); }
+        if (H > 32) { i_min += __shfl_xor(i_min, 32); i_max += __shfl_xor(i_max, 32); i_chg += __shfl_xor(i_chg, 32); }
+        r_min = fixed_to_kw(i_min);
+        r_max = fixed_to_kw(i_max);
+        r_chg = fixed_to_kw(i_chg);
     }
     const int cars = __popcll(__ballot(r.car) & unit_mask);
 

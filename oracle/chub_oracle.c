@@ -565,29 +565,23 @@ static void calculate_output(orc_station *s) {
     float min_power = 0, max_power = 0, now_power = 0;
     int number = 0;
     if (s->exact_sums) {
-        /* production semantics (PHILOX mode): the three sums are balanced binary-tree sums in f32 over the station's
-         * slots padded with zeros to H = pow2 >= n lanes -- the association of the GPU's wave butterfly
-         * (slot i pairs with i^1, then i^2, i^4, ...).  Within log2(H)*2^-24 of the exact sum; the reference's
-         * sequential f32 sum (CHS:1244-1255) is within n*2^-24 of it. */
-        float vmin[ORC_MAX_PILES], vmax[ORC_MAX_PILES], vnow[ORC_MAX_PILES];
-        int H = 1;
-        while (H < s->n) H <<= 1;
-        for (int i = 0; i < H; i++) {
-            int car = i < s->n && s->car[i] > 0.5;
-            if (car) number += 1;
-            vmax[i] = car ? s->power[i] : 0.0f;
-            vmin[i] = (car && s->emergency[i] > 8) ? s->power[i] : 0.0f;
-            vnow[i] = (car && s->charge[i] <= 1.1 && s->charge[i] >= 0.9) ? s->power[i] : 0.0f;
+        /* production semantics (PHILOX mode): the three sums are order-independent -- every slot power is truncated to
+         * a multiple of 2^-19 kW (C cast of power * 2^19 to int32: |power| < 64 kW, at most 64 slots, so the int32 sum
+         * cannot overflow), the integers are added, and the total is rounded once to f32.  Within n * 2^-19 kW of the
+         * exact sum; the reference's sequential f32 sum (CHS:1244-1255) is within n * 2^-24 relative of it.  An
+         * implementation may add the terms in any order and with any grouping (wave butterflies, LDS atomics). */
+        int32_t amin = 0, amax = 0, anow = 0;
+        for (int i = 0; i < s->n; i++) {
+            if (!(s->car[i] > 0.5)) continue;
+            number += 1;
+            int32_t q = (int32_t) (s->power[i] * 524288.0f);
+            amax += q;
+            if (s->emergency[i] > 8) amin += q;
+            if (s->charge[i] <= 1.1 && s->charge[i] >= 0.9) anow += q;
         }
-        for (int off = 1; off < H; off <<= 1)
-            for (int i = 0; i < H; i += 2 * off) {
-                vmin[i] = vmin[i] + vmin[i + off];
-                vmax[i] = vmax[i] + vmax[i + off];
-                vnow[i] = vnow[i] + vnow[i + off];
-            }
-        s->min_power = vmin[0];
-        s->max_power = vmax[0];
-        s->charge_power = vnow[0];
+        s->min_power = (float) amin * (1.0f / 524288.0f);
+        s->max_power = (float) amax * (1.0f / 524288.0f);
+        s->charge_power = (float) anow * (1.0f / 524288.0f);
         s->car_number = number;
         return;
     }
