@@ -108,6 +108,8 @@ struct Tables {
     CHUB_G(const float) normal_tail;  // [4097] its second level for the lowest / highest cell   (PHILOX mode)
     CHUB_G(const double) sin96;       // [96]   sin(2*pi*t/96), the time feature of the observation (MGR:319-320)
     CHUB_G(const float) ttab[2];      // [1000][2] per target level k of station k: target SoC (= 80 + 20*k/999), soc_to_time(target)
+    CHUB_G(const uint32_t) lane_map[2];  // [slot_block][4] packed slot kernel, per workgroup lane of station k: ballot mask of
+                                      // its unit's lanes in its own wave (2 words) and in the neighbouring wave (2 words)
     CHUB_G(const float) newcar[2];    // [kSocLevels][4] PHILOX: per arrival-SoC level of station k: soc, soc_to_time(soc),
                                       //                 time_to_power(soc_to_time(soc)), 0 -- what add_car derives from it
 };
@@ -137,6 +139,8 @@ struct HubParams {
     // correctly rounded reciprocals of the tail's run-time constant divisors (div_c in chub_kernels.hip)
     double rc_cells, rc_cap_mass, rc_vm60k, rc_price_std, rc_half_range[2];
     float hv_rate;           // f32(f32(0.3) * f32(permeate))
+    int32_t upb[2];          // packed slot kernel: whole units per workgroup = slot_block / S_k
+    int32_t packed;          // PHILOX steps run k_slot_packed (both stations non-empty and at least one packs tighter)
     int32_t slot_block;      // experiments: workgroup size of the PHILOX slot kernel (128 / 256 / 512; env CHUB_SLOT_BLOCK)
     int32_t fused;           // PHILOX: run the per-env tail inside the slot launch (env CHUB_FUSED=0 turns it off)
     int32_t ablate;          // timing experiments only (env CHUB_ABLATE): skips parts of k_slot, results are WRONG
@@ -151,6 +155,13 @@ struct DevCtx {
     EnvArrays ev;
     CompatRng cr;
     Tables tb;
+};
+
+// host-side copies of the device pointers the packed slot kernel takes as kernel arguments (launch_slot)
+struct PackedPtrs {
+    uint32_t *hot, *rec;
+    uint64_t *pk[2];
+    const uint32_t *lane_map[2];
 };
 
 struct StepArgs {

@@ -770,6 +770,252 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Packed variant of the PHILOX step (no reset, no scalar-load mode): the workgroup's lanes map onto upb = BLOCK / S whole
+// units laid end to end (lane l <-> unit l / S, slot l % S), so a station of 20 piles fills 240 of 256 lanes instead of 160
+// and the workgroup's loads and stores are one contiguous run of memory.  Units may straddle a wave boundary, so what the
+// wave-local variant gets from ballots and butterflies goes through LDS here: every wave publishes its ballot of empty
+// slots (admission rank = empties of the unit in the previous wave + empties below the lane in its own wave, masks from
+// Tables::lane_map), and the station sums are integer LDS atomics (order-independent by definition, see slot_body): lanes
+// whose state is final after phase A add their share at once, the dense loops add the shares of the cars they process,
+// so the unit leaders can emit the station records right after the last barrier.  Same results as slot_body bit for bit.
+//
+// PackedArgs: what the first loads of a wave need, by value in the kernel arguments (one scalar load) instead of
+// behind the context pointer (three dependent ones) -- this kernel's waves spend most of their life waiting, not issuing.
+struct PackedArgs {
+    uint32_t S[2], upb[2], magic[2], base[2], type[2];
+    uint32_t n_envs, act_dim;
+    CHUB_G(uint32_t) hot;
+    CHUB_G(uint32_t) rec;
+    CHUB_G(uint64_t) pk;             // this step's packed station draws
+    CHUB_G(const uint32_t) lane_map[2];
+};
+
+template <int TYPE, int BLOCK>
+__device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const PackedArgs &pa, const SlotArrays &sl,
+                                 const Tables &tb, const int k, const uint32_t block_local, float *lds_f, uint32_t *lds_u,
+                                 uint64_t *s_ball, int *s_acc) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int S = (int) pa.S[k], upb = (int) pa.upb[k];
+    const int N = (int) pa.n_envs;
+    const int u = (int) (((uint32_t) tid * pa.magic[k]) >> 16);  // tid / S (magic = 65536 / S + 1, checked on the host)
+    const int slot = tid - u * S;
+    const int env_first = (int) block_local * upb;
+    const int env = env_first + u;
+    const bool valid = u < upb && env < N;
+    const uint32_t idx = pa.base[k] + (uint32_t) env_first * (uint32_t) S + (uint32_t) tid;  // == base + env * S + slot
+    const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
+    const int S0 = k ? (int) pa.S[0] : 0;
+    const bool cp = hp.constant_charging != 0;
+
+    // phase A loads: hot record, action, the unit's queue length and packed draws, the lane's ballot masks
+    u32x4 hot = {0u, 0u, 0u, 0u}, lm = {0u, 0u, 0u, 0u};
+    float act = 0.0f;
+    uint32_t line_in = 0;
+    uint64_t pk_in = 0;
+    if (valid) {
+        hot = ((CHUB_G(u32x4)) pa.hot)[idx];
+        act = sa.actions[(uint32_t) env * pa.act_dim + (uint32_t) (S0 + slot)];
+        line_in = pa.rec[4u * sidx + 3u];
+        pk_in = pa.pk[sidx];
+        lm = ((CHUB_G(const u32x4)) pa.lane_map[k])[tid];
+    }
+    uint32_t *q_cnt = lds_u;                   // [1]  new cars | charging cars << 16
+    uint32_t *q_new = lds_u + 2;               // [BLOCK]  tid of the admitted lane
+    uint32_t *q_chg = lds_u + 2 + BLOCK;       // [BLOCK]  tid of the charging lane
+    uint32_t *o_stay = lds_u + 2 + 2 * BLOCK;  // [BLOCK]  in: stay left of a charging car; out: stay of a new car
+    float *o_soc = lds_f;                      // [BLOCK] each, indexed by the owning lane's tid
+    float *o_target = lds_f + BLOCK;
+    float *o_tt = lds_f + 2 * BLOCK;           // in: t_target of a charging car; out: t_target of a new car
+    float *o_ts = lds_f + 3 * BLOCK;
+    float *o_pw = lds_f + 4 * BLOCK;
+    float *in_tt = lds_f + 5 * BLOCK;          // [BLOCK] curve time of a charging car
+    if (tid == 0) q_cnt[0] = 0;
+    for (int i = tid; i < 4 * upb; i += BLOCK) s_acc[i] = 0;
+
+    // ---- slot_advance (deferred form): urgency, feasibility / on-off, departure (CHS.hpp:1188-1202 / 1499-1513)
+    float power = __uint_as_float(hot.x), t_target = __uint_as_float(hot.y), t_soc = __uint_as_float(hot.z);
+    uint32_t tlb = hot.w;
+    asm volatile("" : "+v"(act), "+v"(tlb));
+    int tl = (int) (tlb & 127u), stay = (int) ((tlb >> 8) & 255u);
+    bool car = tl > 0;
+    const bool act_on = __fmul_rn(__fadd_rn(act, 1.0f), 0.5f) >= 0.5f;  // action_to_real (MGR:384-393)
+    const bool on = car && (act_on || must_charge(t_target, t_soc, tl));
+    const float step_tt = __fadd_rn(t_soc, 1.0f);
+    bool needs_step = on && tl > 1;
+    bool leave = false;
+    if (car) {  // remove_car (CHS.hpp:912-923 / 1077-1088)
+        tl -= 1;
+        if (tl <= 0) {
+            car = false;
+            leave = true;
+            tl = 0;
+            stay = 0;
+            power = t_target = t_soc = 0.0f;
+        }
+    }
+    const bool charge = on && car;
+    if (hp.ablate & 2) needs_step = false;  // experiment: no car_step
+
+    // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): arrivals, renege, balk, admission
+    const bool empty = valid && !car;
+    const uint64_t be = __ballot(empty);
+    if (lane == 0) s_ball[wave] = be;
+    __syncthreads();
+    const uint64_t mA = (uint64_t) lm.x | ((uint64_t) lm.y << 32), mB = (uint64_t) lm.z | ((uint64_t) lm.w << 32);
+    const bool b_prev = u * S < wave * 64;                       // the unit began in the previous wave
+    const int cntB = __popcll(s_ball[b_prev ? wave - 1 : wave + 1] & mB);  // its empties there (mB = 0: no lanes there)
+    const int empties = __popcll(be & mA) + cntB;
+    const int rank = __popcll(be & mA & ((1ull << lane) - 1ull)) + (b_prev ? cntB : 0);
+    asm volatile("" : "+v"(line_in));
+    int line = (int) (line_in & 0xFFu);
+    int flow = 0, assign = 0;
+    if (valid && !(hp.ablate & 4)) {
+        const uint64_t pk = pk_in;
+        line = __popc((uint32_t) pk & ((1u << line) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
+        const int n_in = (int) (pk >> 10) & 15;
+        flow = (TYPE == 0) ? n_in : (int) ((pk >> (14 + 4 * line)) & 15);
+        assign = (line + flow) < empties ? (line + flow) : empties;  // assign_car, CHS.hpp:417-430
+        line = line + flow - assign;
+        line = line < kMaxLine ? line : kMaxLine;
+    }
+    if (hp.ablate & 1) assign = 0;
+    const bool adm = empty && rank < assign;
+    int *acc = s_acc + 4 * u;  // the unit's {min, charge, max power in 2^-19 kW, cars}
+    if (car && !needs_step) {  // state final: calculate_output share (CHS.hpp:1233-1261 / 1544-1572) goes in now
+        const int q = (int) (power * 524288.0f);
+        atomicAdd(acc + 2, q);
+        atomicAdd(acc + 3, 1);
+        if (must_charge(t_target, t_soc, tl)) atomicAdd(acc + 0, q);
+        if (charge) atomicAdd(acc + 1, q);
+    }
+    {
+        const uint64_t ba = __ballot(adm), bc = __ballot(needs_step);
+        const uint32_t both = (uint32_t) __popcll(ba) | ((uint32_t) __popcll(bc) << 16);
+        uint32_t base = 0;
+        if (lane == 0 && both) base = atomicAdd(&q_cnt[0], both);
+        base = __shfl(base, 0);
+        const uint64_t below = (1ull << lane) - 1ull;
+        if (adm) q_new[(base & 0xFFFFu) + __popcll(ba & below)] = (uint32_t) tid;
+        if (needs_step) {
+            q_chg[(base >> 16) + __popcll(bc & below)] = (uint32_t) tid;
+            in_tt[tid] = step_tt;
+            o_tt[tid] = t_target;
+            o_stay[tid] = (uint32_t) tl;
+        }
+    }
+    __syncthreads();
+    const uint32_t qc = q_cnt[0];
+    const uint32_t n_adm = qc & 0xFFFFu, n_chg = qc >> 16;
+    for (uint32_t i = tid; i < n_chg; i += BLOCK) {  // car_step (CHS.hpp:900-905 / 1065-1070), from the low waves
+        const int src = (int) q_chg[i];
+        float soc_c, pw_c;
+        car_step_curves<TYPE>(in_tt[src], cp, hp.cc, soc_c, pw_c);
+        const float ts_c = soc_to_time<TYPE>(soc_c, cp);
+        o_soc[src] = soc_c;
+        o_pw[src] = pw_c;
+        o_ts[src] = ts_c;
+        int *ac = s_acc + 4 * (int) (((uint32_t) src * pa.magic[k]) >> 16);
+        const int q = (int) (pw_c * 524288.0f);
+        atomicAdd(ac + 2, q);
+        atomicAdd(ac + 3, 1);
+        atomicAdd(ac + 1, q);  // a car that was stepped is charging
+        if (must_charge(o_tt[src], ts_c, (int) o_stay[src])) atomicAdd(ac + 0, q);
+    }
+    for (uint32_t i = (uint32_t) (BLOCK - 1 - tid); i < n_adm; i += BLOCK) {  // add_car, from the high waves
+        const int src = (int) q_new[i];
+        const int s_u = (int) (((uint32_t) src * pa.magic[k]) >> 16);
+        const int s_env = env_first + s_u;
+        const int s_hub_slot = S0 + (src - s_u * S);
+        PhiloxCtx p2{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + s_env)};
+        const U4 o = p2.block(SITE_SOC, (uint32_t) s_hub_slot, 0);  // word 0 SoC, 1 target level, 2 extra stay
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x4 nw = ((CHUB_G(const f32x4)) tb.newcar[k])[o.v[0] >> 18];
+        const f32x2 tg = ((CHUB_G(const f32x2)) tb.ttab[k])[o.v[1] % 1000u];
+        const int late = late_from_word(tb.late_thr, o.v[2]);
+        int st_ = (int) ceilf(__fsub_rn(tg.y, nw.y)) + late;  // calculate_min_charging_time + mk_late_time
+        st_ = st_ > 127 ? 127 : st_;
+        o_soc[src] = nw.x;
+        o_target[src] = tg.x;
+        o_tt[src] = tg.y;
+        o_ts[src] = nw.y;
+        o_pw[src] = nw.z;
+        o_stay[src] = (uint32_t) st_;
+        if (st_ > 0) {
+            int *ac = s_acc + 4 * s_u;
+            const int q = (int) (nw.z * 524288.0f);
+            atomicAdd(ac + 2, q);
+            atomicAdd(ac + 3, 1);
+            if (must_charge(tg.y, nw.y, st_)) atomicAdd(ac + 0, q);
+        }
+    }
+    __syncthreads();
+    float nc_soc = 0.0f, nc_target = 0.0f, soc_new = 0.0f;
+    if (adm) {
+        nc_soc = o_soc[tid];
+        nc_target = o_target[tid];
+        t_target = o_tt[tid];
+        t_soc = o_ts[tid];
+        power = o_pw[tid];
+        tl = (int) o_stay[tid];
+        stay = tl;
+    }
+    if (needs_step) {
+        soc_new = o_soc[tid];
+        power = o_pw[tid];
+        t_soc = o_ts[tid];
+    }
+    if (valid) {
+        u32x4 h2;
+        h2.x = __float_as_uint(power);
+        h2.y = __float_as_uint(t_target);
+        h2.z = __float_as_uint(t_soc);
+        h2.w = (uint32_t) tl | (charge ? 128u : 0u) | ((uint32_t) stay << 8);
+        ((CHUB_G(u32x4)) pa.hot)[idx] = h2;
+        if (hp.ablate & 8) {  // experiment: no cold-array stores
+        } else if (adm || leave) {
+            sl.target[idx] = adm ? nc_target : 0.0f;
+            sl.init_soc[idx] = adm ? nc_soc : 0.0f;
+            sl.soc[idx] = adm ? nc_soc : 0.0f;
+        } else if (needs_step) {
+            sl.soc[idx] = soc_new;
+        }
+        if (slot == 0) {
+            const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) acc[3] << 16);
+            rec_store<false>(pa.rec, sidx, fixed_to_kw(acc[0]), fixed_to_kw(acc[1]), fixed_to_kw(acc[2]), pkd);
+        }
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa, uint32_t nb0,
+                                                          uint32_t nb_lev) {
+    __shared__ float lds_f[6 * BLOCK];
+    __shared__ uint32_t lds_u[3 * BLOCK + 2];
+    __shared__ uint64_t s_ball[BLOCK / 64 + 2];  // [1 + wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
+    __shared__ int s_acc[BLOCK];                 // upb <= BLOCK / 4 units x {min, charge, max power, cars}
+    const HubParams &hp = ctx->hp;
+    if (hp.ablate & 64) return;
+    uint32_t bid = blockIdx.x;
+    if (bid < nb_lev) {  // next step's station-level draws, one lane per (station, env): see k_slot
+        const int64_t u = (int64_t) bid * BLOCK + threadIdx.x;
+        const int64_t N = hp.n_envs;
+        if (u < 2 * N && !(hp.ablate & 16)) {
+            const int kk = u >= N ? 1 : 0;
+            ctx->st.pk[(sa.tick + 1u) & 1u][u] =
+                draw_station_levels(hp, ctx->tb, sa.tick + 1u, (sa.t + 1) % 96, kk, u - (int64_t) kk * N);
+        }
+        return;
+    }
+    bid -= nb_lev;
+    const int k = (bid >= nb0) ? 1 : 0;
+    const uint32_t bl = k ? bid - nb0 : bid;
+    if (pa.type[k] == 0) slot_body_packed<0, BLOCK>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
+    else slot_body_packed<1, BLOCK>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
+}
+
 template <bool RESET, int MODE, bool FUSED>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
@@ -1358,7 +1604,8 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
 }
 
 // returns true when the per-env tail ran inside the slot launch (no k_env needed)
-bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {
+bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
+                 const PackedPtrs &pp) {
     if (hp.rng_mode == MODE_PHILOX) {
         if (hp.fused) {
             if (reset) launch_slot_t<true, MODE_PHILOX, 256, true>(hp, ctx, sa, stream);
@@ -1366,7 +1613,30 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             return true;
         }
         if (reset) launch_slot_t<true, MODE_PHILOX, 256, false>(hp, ctx, sa, stream);
-        else if (hp.slot_block == 512) launch_slot_t<false, MODE_PHILOX, 512, false>(hp, ctx, sa, stream);
+        else if (hp.packed && !sa.load_mode) {
+            PackedArgs pa;
+            for (int k = 0; k < 2; k++) {
+                pa.S[k] = (uint32_t) hp.S[k];
+                pa.upb[k] = (uint32_t) hp.upb[k];
+                pa.magic[k] = 65536u / (uint32_t) hp.S[k] + 1u;
+                pa.base[k] = (uint32_t) hp.base[k];
+                pa.type[k] = (uint32_t) hp.type[k];
+                pa.lane_map[k] = (CHUB_G(const uint32_t)) pp.lane_map[k];
+            }
+            pa.n_envs = (uint32_t) hp.n_envs;
+            pa.act_dim = (uint32_t) hp.act_dim;
+            pa.hot = (CHUB_G(uint32_t)) pp.hot;
+            pa.rec = (CHUB_G(uint32_t)) pp.rec;
+            pa.pk = (CHUB_G(uint64_t)) pp.pk[sa.tick & 1u];
+            const uint32_t nb0 = (uint32_t) ((hp.n_envs + hp.upb[0] - 1) / hp.upb[0]);
+            const uint32_t nb1 = (uint32_t) ((hp.n_envs + hp.upb[1] - 1) / hp.upb[1]);
+            const uint32_t nbl = (uint32_t) ((2 * hp.n_envs + hp.slot_block - 1) / hp.slot_block);
+            const dim3 grid(nb0 + nb1 + nbl);
+            if (hp.slot_block == 192) hipLaunchKernelGGL((k_slot_packed<192>), grid, dim3(192), 0, stream, ctx, sa, pa, nb0, nbl);
+            else if (hp.slot_block == 128) hipLaunchKernelGGL((k_slot_packed<128>), grid, dim3(128), 0, stream, ctx, sa, pa, nb0, nbl);
+            else if (hp.slot_block == 512) hipLaunchKernelGGL((k_slot_packed<512>), grid, dim3(512), 0, stream, ctx, sa, pa, nb0, nbl);
+            else hipLaunchKernelGGL((k_slot_packed<256>), grid, dim3(256), 0, stream, ctx, sa, pa, nb0, nbl);
+        } else if (hp.slot_block == 512) launch_slot_t<false, MODE_PHILOX, 512, false>(hp, ctx, sa, stream);
         else if (hp.slot_block == 128) launch_slot_t<false, MODE_PHILOX, 128, false>(hp, ctx, sa, stream);
         else launch_slot_t<false, MODE_PHILOX, 256, false>(hp, ctx, sa, stream);
         return false;

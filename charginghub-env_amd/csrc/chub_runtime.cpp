@@ -16,7 +16,8 @@
 #include "chub_device.h"
 
 namespace chub {
-bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream);
+bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
+                 const PackedPtrs &pp);
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream);
 void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream);
 void launch_compat_burn_fcev(const HubParams &hp, const DevCtx *ctx, int n_steps, hipStream_t stream);
@@ -229,6 +230,17 @@ static int fetch(std::vector<T> &dst, const T *src, size_t count) {
 }
 
 // upload {hp, arrays, tables} when something in them changed (create, telemetry toggle)
+static PackedPtrs packed_ptrs(const chub_env *e) {
+    PackedPtrs p;
+    p.hot = (uint32_t *) e->sl.hot;
+    p.rec = (uint32_t *) e->st.rec;
+    p.pk[0] = (uint64_t *) e->st.pk[0];
+    p.pk[1] = (uint64_t *) e->st.pk[1];
+    p.lane_map[0] = e->tb.lane_map[0];
+    p.lane_map[1] = e->tb.lane_map[1];
+    return p;
+}
+
 static int sync_ctx(chub_env *e, hipStream_t s) {
     if (!e->ctx_dirty) return 0;
     DevCtx h;
@@ -341,6 +353,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     hp.rng_mode = rng_mode;
     hp.telemetry = 0;
     hp.slot_block = getenv("CHUB_SLOT_BLOCK") ? atoi(getenv("CHUB_SLOT_BLOCK")) : 256;
+    if (hp.slot_block != 128 && hp.slot_block != 192 && hp.slot_block != 256 && hp.slot_block != 512) hp.slot_block = 256;
     // fused tail: measured slower at every size tried (each producer workgroup pays a store drain + a returning
     // atomic on its critical path) -- kept as an option for experiments, off by default
     hp.fused = (rng_mode == CHUB_RNG_PHILOX && getenv("CHUB_FUSED") && atoi(getenv("CHUB_FUSED")) == 1) ? 1 : 0;
@@ -521,6 +534,42 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
             newcar[s][4 * l + 2] = fast ? fast_time_to_power(t_soc, cpw) : slow_time_to_power(t_soc, cpw);
         }
     }
+    // packed slot kernel (k_slot_packed): lanes of a workgroup laid over whole units end to end
+    std::vector<uint32_t> lane_map[2];
+    {
+        const int pb = hp.slot_block;
+        bool tighter = false;
+        for (int s = 0; s < 2; s++) {
+            const int S = hp.S[s];
+            hp.upb[s] = S > 0 ? pb / S : 1;
+            if (S > 0 && hp.upb[s] > (pb / 64) * (64 / hp.H[s])) tighter = true;
+            lane_map[s].assign((size_t) pb * 4, 0u);
+            for (int l = 0; l < pb && S > 0; l++) {
+                const int u = l / S, slot = l % S, w = l / 64;
+                if (u >= hp.upb[s]) continue;
+                const int ub = u * S, ue = ub + S;  // the unit's lanes [ub, ue) of the workgroup
+                auto mask_in = [&](int wv) -> uint64_t {
+                    const int lo = ub > wv * 64 ? ub : wv * 64, hi = ue < wv * 64 + 64 ? ue : wv * 64 + 64;
+                    if (hi <= lo) return 0;
+                    const int n = hi - lo;
+                    return (n == 64 ? ~0ull : ((1ull << n) - 1ull)) << (lo - wv * 64);
+                };
+                const int w_first = ub / 64, w_last = (ue - 1) / 64;
+                const int wb = (w_first == w_last) ? w : (w == w_first ? w_last : w_first);
+                const uint64_t mA = mask_in(w), mB = (wb == w) ? 0 : mask_in(wb);
+                uint32_t *m = &lane_map[s][(size_t) l * 4];
+                m[0] = (uint32_t) mA; m[1] = (uint32_t) (mA >> 32); m[2] = (uint32_t) mB; m[3] = (uint32_t) (mB >> 32);
+                (void) slot;
+            }
+        }
+        bool magic_ok = true;  // the kernel divides lane numbers by S with a 16-bit reciprocal
+        for (int s = 0; s < 2 && magic_ok; s++)
+            for (int l = 0; l < pb && hp.S[s] > 0; l++)
+                if ((((uint32_t) l * (65536u / (uint32_t) hp.S[s] + 1u)) >> 16) != (uint32_t) (l / hp.S[s])) magic_ok = false;
+        const char *pe = getenv("CHUB_PACKED");
+        hp.packed = (rng_mode == CHUB_RNG_PHILOX && !hp.fused && hp.S[0] >= 4 && hp.S[1] >= 4 && magic_ok && 
+                     (pe ? atoi(pe) != 0 : tighter)) ? 1 : 0;
+    }
     build_hy_table(hp, e->hy_table);
     std::vector<double> hy_v(e->hy_table, e->hy_table + 102);
 
@@ -541,6 +590,8 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     if ((rc = dev_upload(e, &e->tb.sin96, sin96))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.ttab[0], ttab[0]))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.ttab[1], ttab[1]))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.lane_map[0], lane_map[0]))) return bail(rc);
+    if ((rc = dev_upload(e, &e->tb.lane_map[1], lane_map[1]))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.newcar[0], newcar[0]))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.newcar[1], newcar[1]))) return bail(rc);
 
@@ -630,7 +681,7 @@ int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_ex
     sa.obs_stride = e->hp.obs_dim;
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
-    if (!launch_slot(true, e->hp, e->d_ctx, sa, s)) launch_env(true, e->hp, e->d_ctx, sa, s);
+    if (!launch_slot(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e))) launch_env(true, e->hp, e->d_ctx, sa, s);
     HIP_TRY(hipGetLastError());
     e->t = 0;
     e->price_count = 0;  // MGR:313 (after make_state)
@@ -709,7 +760,7 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
     }
     hipEvent_t *pe = prof ? &e->prof_events[3 * e->prof_used] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], s));
-    const bool tail_done = launch_slot(false, e->hp, e->d_ctx, sa, s);
+    const bool tail_done = launch_slot(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e));
     if (prof) HIP_TRY(hipEventRecord(pe[1], s));
     if (!tail_done) launch_env(false, e->hp, e->d_ctx, sa, s);
     if (prof) {
@@ -998,7 +1049,7 @@ int chub_compat_replay_constructor(chub_env *e) {
     StepArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.station_filter = -1;
-    launch_slot(true, e->hp, e->d_ctx, sa, nullptr);
+    launch_slot(true, e->hp, e->d_ctx, sa, nullptr, packed_ptrs(e));
     // (2) HySystem.__init__: 101 hy_step()s with live FCEV arrivals (HYD:154,168,250-259)
     launch_compat_burn_fcev(e->hp, e->d_ctx, 101, nullptr);
     HIP_TRY(hipGetLastError());
