@@ -236,7 +236,7 @@ def main():
         if n_prof:
             slot_s = slot_ms / 1e3 / n_prof
             achieved = slot_b * per / slot_s / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_slot", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"bound": "hbm", "kernel": "k_slot_packed (k_slot for hub shapes it does not cover)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(per) if args.config in ("c3", "c4") else None,
                         "algorithmic_bytes_per_launch": slot_b * per, "avg_launch_us": slot_s * 1e6,
                         "env_kernel_avg_launch_us": env_ms / n_prof * 1e3,

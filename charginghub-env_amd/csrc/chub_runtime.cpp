@@ -568,7 +568,8 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
                 if ((((uint32_t) l * (65536u / (uint32_t) hp.S[s] + 1u)) >> 16) != (uint32_t) (l / hp.S[s])) magic_ok = false;
         const char *pe = getenv("CHUB_PACKED");
         hp.packed = (rng_mode == CHUB_RNG_PHILOX && !hp.fused && hp.S[0] >= 4 && hp.S[1] >= 4 && magic_ok && 
-                     (pe ? atoi(pe) != 0 : tighter)) ? 1 : 0;
+                     (pe ? atoi(pe) != 0 : true)) ? 1 : 0;
+        (void) tighter;
     }
     build_hy_table(hp, e->hy_table);
     std::vector<double> hy_v(e->hy_table, e->hy_table + 102);

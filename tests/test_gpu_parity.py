@@ -142,6 +142,15 @@ def test_philox_matches_oracle(label, kw, n):
     _philox_parity(label, kw, n)
 
 
+@pytest.mark.parametrize("label,packed", [("c3", "0"), ("constant", "0"), ("c5", "1"), ("max64", "1"), ("c2", "1")])
+def test_philox_other_slot_kernel(label, packed, monkeypatch):
+    """PHILOX steps have two slot kernels (wave-local units / units packed end to end over the workgroup) and the
+    library picks one per hub shape: force the other one (CHUB_PACKED) through the same parity check"""
+    monkeypatch.setenv("CHUB_PACKED", packed)
+    kw, n = next((c[1], c[2]) for c in PHILOX_CASES if c[0] == label)
+    _philox_parity(label + "_packed" + packed, kw, n, plan=(96, 30))
+
+
 def test_philox_user_series(tmp_path):
     """user-supplied arrival CDFs / price / PV / wind through a data directory: same parity bar"""
     from charginghub_env_amd import data_io

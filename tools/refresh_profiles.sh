@@ -32,7 +32,7 @@ def collect(d):
     return acc
 def pick(acc, key):
     for name in acc:
-        if key in name:
+        if any(k in name for k in key):
             return {c: sum(v) / len(v) for c, v in acc[name].items()}
     return {}
 fe, wr, sq = collect(out + "/pmc_fetch"), collect(out + "/pmc_write"), collect(out + "/pmc_sq")
@@ -42,7 +42,7 @@ FETCH_FACTOR, WRITE_FACTOR = 1.9998847180168786, 1.0
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes), mean per dispatch over the step kernels of "
                "bench.py --steps 96 at 65536 envs x [20,25]; KiB; corrections from tools/microbench/copy4.hip",
        "calibration": {"fetch_factor": FETCH_FACTOR, "write_factor": WRITE_FACTOR}}
-for label, key in (("k_slot", "k_slot<false"), ("k_env", "k_env<false")):
+for label, key in (("k_slot", ("k_slot_packed", "k_slot<false")), ("k_env", ("k_env<false",))):
     f, w = pick(fe, key).get("FETCH_SIZE", 0.0), pick(wr, key).get("WRITE_SIZE", 0.0)
     res[label] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                   "traffic_bytes_per_launch": (f * FETCH_FACTOR + w * WRITE_FACTOR) * 1024.0}
