@@ -617,8 +617,9 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
             // everything add_car derives from the arrival SoC is tabulated per SoC level (Tables::newcar)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             typedef float f32x2 __attribute__((ext_vector_type(2)));
-            const f32x4 nw = ((CHUB_G(const f32x4)) tb.newcar[k])[o.v[0] >> 18];
-            const f32x2 tg = ((CHUB_G(const f32x2)) tb.ttab[k])[o.v[1] % 1000u];
+            f32x4 nw = ((CHUB_G(const f32x4)) tb.newcar[k])[o.v[0] >> 18];
+            f32x2 tg = ((CHUB_G(const f32x2)) tb.ttab[k])[o.v[1] % 1000u];
+            asm volatile("" : "+v"(nw), "+v"(tg));  // both lookups in flight together
             const int late = late_from_word(tb.late_thr, o.v[2]);
             NewCar c;
             c.soc = nw.x;
@@ -821,6 +822,8 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         pk_in = pa.pk[sidx];
         lm = ((CHUB_G(const u32x4)) pa.lane_map[k])[tid];
     }
+    // all five requests are out before the first use of any of them (one memory round trip, not two)
+    asm volatile("" : "+v"(hot), "+v"(act), "+v"(line_in), "+v"(pk_in), "+v"(lm));
     uint32_t *q_cnt = lds_u;                   // [1]  new cars | charging cars << 16
     uint32_t *q_new = lds_u + 2;               // [BLOCK]  tid of the admitted lane
     uint32_t *q_chg = lds_u + 2 + BLOCK;       // [BLOCK]  tid of the charging lane
@@ -836,8 +839,7 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
 
     // ---- slot_advance (deferred form): urgency, feasibility / on-off, departure (CHS.hpp:1188-1202 / 1499-1513)
     float power = __uint_as_float(hot.x), t_target = __uint_as_float(hot.y), t_soc = __uint_as_float(hot.z);
-    uint32_t tlb = hot.w;
-    asm volatile("" : "+v"(act), "+v"(tlb));
+    const uint32_t tlb = hot.w;
     int tl = (int) (tlb & 127u), stay = (int) ((tlb >> 8) & 255u);
     bool car = tl > 0;
     const bool act_on = __fmul_rn(__fadd_rn(act, 1.0f), 0.5f) >= 0.5f;  // action_to_real (MGR:384-393)
@@ -868,7 +870,6 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
     const int cntB = __popcll(s_ball[b_prev ? wave - 1 : wave + 1] & mB);  // its empties there (mB = 0: no lanes there)
     const int empties = __popcll(be & mA) + cntB;
     const int rank = __popcll(be & mA & ((1ull << lane) - 1ull)) + (b_prev ? cntB : 0);
-    asm volatile("" : "+v"(line_in));
     int line = (int) (line_in & 0xFFu);
     int flow = 0, assign = 0;
     if (valid && !(hp.ablate & 4)) {
@@ -932,8 +933,9 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         const U4 o = p2.block(SITE_SOC, (uint32_t) s_hub_slot, 0);  // word 0 SoC, 1 target level, 2 extra stay
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x4 nw = ((CHUB_G(const f32x4)) tb.newcar[k])[o.v[0] >> 18];
-        const f32x2 tg = ((CHUB_G(const f32x2)) tb.ttab[k])[o.v[1] % 1000u];
+        f32x4 nw = ((CHUB_G(const f32x4)) tb.newcar[k])[o.v[0] >> 18];
+        f32x2 tg = ((CHUB_G(const f32x2)) tb.ttab[k])[o.v[1] % 1000u];
+        asm volatile("" : "+v"(nw), "+v"(tg));  // both lookups in flight together
         const int late = late_from_word(tb.late_thr, o.v[2]);
         int st_ = (int) ceilf(__fsub_rn(tg.y, nw.y)) + late;  // calculate_min_charging_time + mk_late_time
         st_ = st_ > 127 ? 127 : st_;
@@ -997,7 +999,6 @@ __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restri
     __shared__ uint64_t s_ball[BLOCK / 64 + 2];  // [1 + wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
     __shared__ int s_acc[BLOCK];                 // upb <= BLOCK / 4 units x {min, charge, max power, cars}
     const HubParams &hp = ctx->hp;
-    if (hp.ablate & 64) return;
     uint32_t bid = blockIdx.x;
     if (bid < nb_lev) {  // next step's station-level draws, one lane per (station, env): see k_slot
         const int64_t u = (int64_t) bid * BLOCK + threadIdx.x;
@@ -1539,6 +1540,19 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     __shared__ double s_pv[100], s_wd[150], s_hy[102];
     __shared__ __attribute__((aligned(16))) uint8_t s_hv[kLevels];
     __shared__ float s_out[kEnvBlock * 16];  // output rows: obs_dim + 2 <= 15 floats
+    if (MODE == MODE_PHILOX && (int) blockIdx.x >= nb_env) {
+        // the last blocks of the grid (HubParams::lev_in_env): next step's station-level draws, one lane per (station, env).
+        // They are pure VALU work and fill the issue slots the latency-bound tail waves leave empty.
+        const HubParams &hp = ctx->hp;
+        const int64_t u = (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x;
+        const int64_t N = hp.n_envs;
+        if (u < 2 * N) {
+            const int kk = u >= N ? 1 : 0;
+            ctx->st.pk[(sa.tick + 1u) & 1u][u] =
+                draw_station_levels(hp, ctx->tb, sa.tick + 1u, RESET ? 0 : (sa.t + 1) % 96, kk, u - (int64_t) kk * N);
+        }
+        return;
+    }
     const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
     env_tail<RESET, MODE, false>(ctx, sa, env, env < (int) ctx->hp.n_envs && !(ctx->hp.ablate & 32), s_pv, s_wd, s_hy, s_hv, s_out);
 }
@@ -1590,7 +1604,7 @@ template <bool RESET, int MODE, int BLOCK, bool FUSED>
 static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {
     const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
     if (MODE == MODE_PHILOX) {
-        const int64_t nbl = (2 * hp.n_envs + BLOCK - 1) / BLOCK;  // + next step's station-level draws
+        const int64_t nbl = (hp.lev_in_env && !FUSED) ? 0 : (2 * hp.n_envs + BLOCK - 1) / BLOCK;  // + next step's station-level draws
         hipLaunchKernelGGL((k_slot<RESET, MODE, BLOCK, FUSED>), dim3((unsigned) (nb0 + nb1 + nbl)), dim3(BLOCK), 0, stream,
                            ctx, sa, nb0, nbl);
     } else {
@@ -1630,7 +1644,7 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             pa.pk = (CHUB_G(uint64_t)) pp.pk[sa.tick & 1u];
             const uint32_t nb0 = (uint32_t) ((hp.n_envs + hp.upb[0] - 1) / hp.upb[0]);
             const uint32_t nb1 = (uint32_t) ((hp.n_envs + hp.upb[1] - 1) / hp.upb[1]);
-            const uint32_t nbl = (uint32_t) ((2 * hp.n_envs + hp.slot_block - 1) / hp.slot_block);
+            const uint32_t nbl = hp.lev_in_env ? 0u : (uint32_t) ((2 * hp.n_envs + hp.slot_block - 1) / hp.slot_block);
             const dim3 grid(nb0 + nb1 + nbl);
             if (hp.slot_block == 192) hipLaunchKernelGGL((k_slot_packed<192>), grid, dim3(192), 0, stream, ctx, sa, pa, nb0, nbl);
             else if (hp.slot_block == 128) hipLaunchKernelGGL((k_slot_packed<128>), grid, dim3(128), 0, stream, ctx, sa, pa, nb0, nbl);
@@ -1649,7 +1663,7 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {
     const int nb_env = (int) ((hp.n_envs + 255) / 256);
     if (hp.rng_mode == MODE_PHILOX) {
-        const unsigned nb = (unsigned) nb_env;
+        const unsigned nb = (unsigned) nb_env + ((hp.lev_in_env && !hp.fused) ? (unsigned) ((2 * hp.n_envs + kEnvBlock - 1) / kEnvBlock) : 0u);
         if (reset) hipLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ctx, sa, nb_env);
         else hipLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ctx, sa, nb_env);
     } else {

@@ -358,6 +358,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     // atomic on its critical path) -- kept as an option for experiments, off by default
     hp.fused = (rng_mode == CHUB_RNG_PHILOX && getenv("CHUB_FUSED") && atoi(getenv("CHUB_FUSED")) == 1) ? 1 : 0;
     hp.ablate = getenv("CHUB_ABLATE") ? atoi(getenv("CHUB_ABLATE")) : 0;
+    hp.lev_in_env = (rng_mode == CHUB_RNG_PHILOX && !hp.fused && !(getenv("CHUB_LEV_IN_ENV") && atoi(getenv("CHUB_LEV_IN_ENV")) == 0)) ? 1 : 0;
     hp.key[0] = (uint32_t) seed;
     hp.key[1] = (uint32_t) (seed >> 32);
     hp.cc = make_curve_consts();
