@@ -15,6 +15,7 @@
 // No MFMA: there is no dense contraction anywhere in this path; it is HBM-/FP64-VALU-bound.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "chub_device.h"
@@ -1600,33 +1601,36 @@ static inline int64_t blocks_for(int64_t n_envs, int H, int block) {
     return (n_envs + upb - 1) / upb;
 }
 
+// ev0 / ev1 (may be null): kernel start / stop timestamps of the dispatch itself (hipExtLaunchKernelGGL), what
+// chub_profile_* reports -- plain hipEventRecord pairs around a launch also count the gap in front of it
 template <bool RESET, int MODE, int BLOCK, bool FUSED>
-static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {
+static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
+                          hipEvent_t ev1) {
     const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
     if (MODE == MODE_PHILOX) {
         const int64_t nbl = (hp.lev_in_env && !FUSED) ? 0 : (2 * hp.n_envs + BLOCK - 1) / BLOCK;  // + next step's station-level draws
-        hipLaunchKernelGGL((k_slot<RESET, MODE, BLOCK, FUSED>), dim3((unsigned) (nb0 + nb1 + nbl)), dim3(BLOCK), 0, stream,
-                           ctx, sa, nb0, nbl);
+        hipExtLaunchKernelGGL((k_slot<RESET, MODE, BLOCK, FUSED>), dim3((unsigned) (nb0 + nb1 + nbl)), dim3(BLOCK), 0, stream,
+                              ev0, ev1, 0, ctx, sa, nb0, nbl);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
             StepArgs s2 = sa;
             s2.station_filter = k;
-            hipLaunchKernelGGL((k_slot<RESET, MODE, BLOCK, false>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), 0, stream,
-                               ctx, s2, nb0, (int64_t) 0);
+            hipExtLaunchKernelGGL((k_slot<RESET, MODE, BLOCK, false>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), 0, stream,
+                                  k == 0 ? ev0 : nullptr, k == 1 ? ev1 : nullptr, 0, ctx, s2, nb0, (int64_t) 0);
         }
     }
 }
 
 // returns true when the per-env tail ran inside the slot launch (no k_env needed)
 bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
-                 const PackedPtrs &pp) {
+                 const PackedPtrs &pp, hipEvent_t ev0, hipEvent_t ev1) {
     if (hp.rng_mode == MODE_PHILOX) {
         if (hp.fused) {
-            if (reset) launch_slot_t<true, MODE_PHILOX, 256, true>(hp, ctx, sa, stream);
-            else launch_slot_t<false, MODE_PHILOX, 256, true>(hp, ctx, sa, stream);
+            if (reset) launch_slot_t<true, MODE_PHILOX, 256, true>(hp, ctx, sa, stream, ev0, ev1);
+            else launch_slot_t<false, MODE_PHILOX, 256, true>(hp, ctx, sa, stream, ev0, ev1);
             return true;
         }
-        if (reset) launch_slot_t<true, MODE_PHILOX, 256, false>(hp, ctx, sa, stream);
+        if (reset) launch_slot_t<true, MODE_PHILOX, 256, false>(hp, ctx, sa, stream, ev0, ev1);
         else if (hp.packed && !sa.load_mode) {
             PackedArgs pa;
             for (int k = 0; k < 2; k++) {
@@ -1646,29 +1650,30 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             const uint32_t nb1 = (uint32_t) ((hp.n_envs + hp.upb[1] - 1) / hp.upb[1]);
             const uint32_t nbl = hp.lev_in_env ? 0u : (uint32_t) ((2 * hp.n_envs + hp.slot_block - 1) / hp.slot_block);
             const dim3 grid(nb0 + nb1 + nbl);
-            if (hp.slot_block == 192) hipLaunchKernelGGL((k_slot_packed<192>), grid, dim3(192), 0, stream, ctx, sa, pa, nb0, nbl);
-            else if (hp.slot_block == 128) hipLaunchKernelGGL((k_slot_packed<128>), grid, dim3(128), 0, stream, ctx, sa, pa, nb0, nbl);
-            else if (hp.slot_block == 512) hipLaunchKernelGGL((k_slot_packed<512>), grid, dim3(512), 0, stream, ctx, sa, pa, nb0, nbl);
-            else hipLaunchKernelGGL((k_slot_packed<256>), grid, dim3(256), 0, stream, ctx, sa, pa, nb0, nbl);
-        } else if (hp.slot_block == 512) launch_slot_t<false, MODE_PHILOX, 512, false>(hp, ctx, sa, stream);
-        else if (hp.slot_block == 128) launch_slot_t<false, MODE_PHILOX, 128, false>(hp, ctx, sa, stream);
-        else launch_slot_t<false, MODE_PHILOX, 256, false>(hp, ctx, sa, stream);
+            if (hp.slot_block == 192) hipExtLaunchKernelGGL((k_slot_packed<192>), grid, dim3(192), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
+            else if (hp.slot_block == 128) hipExtLaunchKernelGGL((k_slot_packed<128>), grid, dim3(128), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
+            else if (hp.slot_block == 512) hipExtLaunchKernelGGL((k_slot_packed<512>), grid, dim3(512), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
+            else hipExtLaunchKernelGGL((k_slot_packed<256>), grid, dim3(256), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
+        } else if (hp.slot_block == 512) launch_slot_t<false, MODE_PHILOX, 512, false>(hp, ctx, sa, stream, ev0, ev1);
+        else if (hp.slot_block == 128) launch_slot_t<false, MODE_PHILOX, 128, false>(hp, ctx, sa, stream, ev0, ev1);
+        else launch_slot_t<false, MODE_PHILOX, 256, false>(hp, ctx, sa, stream, ev0, ev1);
         return false;
     }
-    if (reset) launch_slot_t<true, MODE_COMPAT, 256, false>(hp, ctx, sa, stream);
-    else launch_slot_t<false, MODE_COMPAT, 256, false>(hp, ctx, sa, stream);
+    if (reset) launch_slot_t<true, MODE_COMPAT, 256, false>(hp, ctx, sa, stream, ev0, ev1);
+    else launch_slot_t<false, MODE_COMPAT, 256, false>(hp, ctx, sa, stream, ev0, ev1);
     return false;
 }
 
-void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream) {
+void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
+                hipEvent_t ev1) {
     const int nb_env = (int) ((hp.n_envs + 255) / 256);
     if (hp.rng_mode == MODE_PHILOX) {
         const unsigned nb = (unsigned) nb_env + ((hp.lev_in_env && !hp.fused) ? (unsigned) ((2 * hp.n_envs + kEnvBlock - 1) / kEnvBlock) : 0u);
-        if (reset) hipLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ctx, sa, nb_env);
-        else hipLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ctx, sa, nb_env);
+        if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, nb_env);
+        else hipExtLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, nb_env);
     } else {
-        if (reset) hipLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ctx, sa, nb_env);
-        else hipLaunchKernelGGL((k_env<false, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ctx, sa, nb_env);
+        if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, nb_env);
+        else hipExtLaunchKernelGGL((k_env<false, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, nb_env);
     }
 }
 

@@ -17,8 +17,9 @@
 
 namespace chub {
 bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
-                 const PackedPtrs &pp);
-void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream);
+                 const PackedPtrs &pp, hipEvent_t ev0, hipEvent_t ev1);
+void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
+                hipEvent_t ev1);
 void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream);
 void launch_compat_burn_fcev(const HubParams &hp, const DevCtx *ctx, int n_steps, hipStream_t stream);
 }  // namespace chub
@@ -69,6 +70,7 @@ struct chub_env {
     hipStream_t stream;
     // optional per-kernel timing with HIP events on the launch stream (chub_profile_*)
     std::vector<hipEvent_t> prof_events;
+    std::vector<bool> prof_tail;
     size_t prof_used, prof_cap;
     int prof_every, prof_phase;
     bool prof_on;
@@ -683,7 +685,8 @@ int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_ex
     sa.obs_stride = e->hp.obs_dim;
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
-    if (!launch_slot(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e))) launch_env(true, e->hp, e->d_ctx, sa, s);
+    if (!launch_slot(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e), nullptr, nullptr))
+        launch_env(true, e->hp, e->d_ctx, sa, s, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     e->t = 0;
     e->price_count = 0;  // MGR:313 (after make_state)
@@ -760,13 +763,12 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
         prof = (e->prof_phase % e->prof_every) == 0;  // sample: the event records are not free
         e->prof_phase++;
     }
-    hipEvent_t *pe = prof ? &e->prof_events[3 * e->prof_used] : nullptr;
-    if (prof) HIP_TRY(hipEventRecord(pe[0], s));
-    const bool tail_done = launch_slot(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e));
-    if (prof) HIP_TRY(hipEventRecord(pe[1], s));
-    if (!tail_done) launch_env(false, e->hp, e->d_ctx, sa, s);
+    // four events per profiled step: start / stop of the slot kernel, start / stop of the tail kernel
+    hipEvent_t *pe = prof ? &e->prof_events[4 * e->prof_used] : nullptr;
+    const bool tail_done = launch_slot(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e), prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
+    if (!tail_done) launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr);
     if (prof) {
-        HIP_TRY(hipEventRecord(pe[2], s));
+        e->prof_tail[e->prof_used] = !tail_done;
         e->prof_used++;
     }
     HIP_TRY(hipGetLastError());
@@ -1011,7 +1013,8 @@ int chub_profile_begin(chub_env *e, int max_steps, int every) {
     e->prof_every = every;
     e->prof_phase = 0;
     HIP_TRY(hipSetDevice(e->device));
-    while (e->prof_events.size() < (size_t) max_steps * 3) {
+    e->prof_tail.assign((size_t) max_steps, false);
+    while (e->prof_events.size() < (size_t) max_steps * 4) {
         hipEvent_t ev;
         HIP_TRY(hipEventCreate(&ev));
         e->prof_events.push_back(ev);
@@ -1029,9 +1032,10 @@ int chub_profile_end(chub_env *e, double *slot_ms_sum, double *env_ms_sum, int *
     double a = 0, b = 0;
     for (size_t i = 0; i < e->prof_used; i++) {
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, e->prof_events[3 * i], e->prof_events[3 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, e->prof_events[4 * i], e->prof_events[4 * i + 1]));
         a += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, e->prof_events[3 * i + 1], e->prof_events[3 * i + 2]));
+        if (!e->prof_tail[i]) continue;
+        HIP_TRY(hipEventElapsedTime(&ms, e->prof_events[4 * i + 2], e->prof_events[4 * i + 3]));
         b += ms;
     }
     *slot_ms_sum = a;
@@ -1051,7 +1055,7 @@ int chub_compat_replay_constructor(chub_env *e) {
     StepArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.station_filter = -1;
-    launch_slot(true, e->hp, e->d_ctx, sa, nullptr, packed_ptrs(e));
+    launch_slot(true, e->hp, e->d_ctx, sa, nullptr, packed_ptrs(e), nullptr, nullptr);
     // (2) HySystem.__init__: 101 hy_step()s with live FCEV arrivals (HYD:154,168,250-259)
     launch_compat_burn_fcev(e->hp, e->d_ctx, 101, nullptr);
     HIP_TRY(hipGetLastError());
