@@ -51,11 +51,11 @@ struct SlotArrays {          // index = base_k + env*S_k + slot  (station-major)
     //   .x power     kW at the car's current point of the curve (Station::situation["power"])
     //   .y t_target  soc_to_time(target)   -- cached, constant over a stay
     //   .z t_soc     soc_to_time(soc)      -- cached, what car_step and calculate_needed both need
-    //   .w bits 0-6 stay_time - already_stay_time (0 = empty), bit 7 charging this step, bits 8-15 stay_time
+    //   .w bits 0-6 stay_time - already_stay_time (0 = empty), bit 7 charging this step, bits 8-14 stay_time,
+    //      bits 15-24 target-SoC level l (target = 80 + 20 * l / 999, CHS.hpp:35-44), bits 25-31 car_steps taken since arrival
     CHUB_G(uint32_t) hot;    // [NS][4]
-    // cold: written when a car arrives / leaves / charges, read only by introspection
-    CHUB_G(float) soc;       // current SoC
-    CHUB_G(float) target;    // target SoC
+    // cold: written once per arriving car, read only by introspection.  Current SoC = arrival SoC advanced by the
+    // recorded number of car_steps (k_replay_soc), target SoC from its level; slots without a car read as zeros.
     CHUB_G(float) init_soc;  // arrival SoC
 };
 
@@ -107,7 +107,7 @@ struct Tables {
     CHUB_G(const float) normal_icdf;  // [4097] inverse CDF of N(0,1), and
     CHUB_G(const float) normal_tail;  // [4097] its second level for the lowest / highest cell   (PHILOX mode)
     CHUB_G(const double) sin96;       // [96]   sin(2*pi*t/96), the time feature of the observation (MGR:319-320)
-    CHUB_G(const float) ttab[2];      // [1000][2] per target level k of station k: target SoC (= 80 + 20*k/999), soc_to_time(target)
+    CHUB_G(const float) ttab[2];      // [1000] soc_to_time(target level k) of station k's curve (target = 80 + 20*k/999)
     CHUB_G(const uint32_t) lane_map[2];  // [slot_block][4] packed slot kernel, per workgroup lane of station k: ballot mask of
                                       // its unit's lanes in its own wave (2 words) and in the neighbouring wave (2 words)
     CHUB_G(const float) newcar[2];    // [kSocLevels][4] PHILOX: per arrival-SoC level of station k: soc, soc_to_time(soc),

@@ -362,13 +362,14 @@ __device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs
     float a = sa.actions[act_idx];
     asm volatile("" : "+v"(a), "+v"(tlb));
     r.tl = (int) (tlb & 127u);
-    r.stay = (int) ((tlb >> 8) & 255u);
+    r.stay = (int) (tlb >> 8);  // all of the meta bits above the flag: stay_time | target level << 7 | car_steps << 17
     r.car = r.tl > 0;
     // action_to_real (MGR:384-393): (a+1)/2 >= 0.5 on the f32 array
     const bool act_on = __fmul_rn(__fadd_rn(a, 1.0f), 0.5f) >= 0.5f;
     // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373)
     const bool on = on_override >= 0 ? (r.car && on_override != 0)
                                      : (r.car && (act_on || must_charge(r.t_target, r.t_soc, r.tl)));
+    if (on) r.stay += 1 << 17;  // one more car_step on this car's account (its SoC is replayed from it on demand)
     if (DEFER) {
         r.step_tt = __fadd_rn(r.t_soc, 1.0f);
         r.needs_step = on && r.tl > 1;
@@ -387,6 +388,7 @@ __device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs
             r.power = 0.0f;
             r.t_target = 0.0f;
             r.t_soc = 0.0f;
+            r.stay = 0;
         }
     }
     r.charge = on && r.car;
@@ -394,15 +396,15 @@ __device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs
 
 // What add_car (CHS.hpp:864-877 / 1029-1042) produces for one admitted slot.
 struct NewCar {
-    float soc, target, t_target, t_soc, power;
-    int stay;
+    float soc, t_target, t_soc, power;
+    int stay, lev;  // lev: target-SoC level, target = 80 + 20 * lev / 999 (CHS.hpp:35-44)
 };
 
 template <int TYPE>
-__device__ __forceinline__ NewCar make_car(float arrive_soc, float target, float t_target, int late, bool cp) {
+__device__ __forceinline__ NewCar make_car(float arrive_soc, int lev, float t_target, int late, bool cp) {
     NewCar c;
     c.soc = arrive_soc;
-    c.target = target;
+    c.lev = lev;
     c.t_target = t_target;
     c.t_soc = soc_to_time<TYPE>(arrive_soc, cp);
     const float need = __fsub_rn(c.t_target, c.t_soc);
@@ -521,8 +523,8 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     int flow = 0, assign = 0;
     const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
     NewCar nc;
-    nc.soc = nc.target = nc.t_target = nc.t_soc = nc.power = 0.0f;
-    nc.stay = 0;
+    nc.soc = nc.t_target = nc.t_soc = nc.power = 0.0f;
+    nc.stay = nc.lev = 0;
     bool adm = false;
 
     if (MODE == MODE_PHILOX) {
@@ -566,11 +568,10 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         uint32_t *q_chg = lds_u + 2 + BLOCK;       // [BLOCK]  tid of the charging lane
         uint32_t *o_stay = lds_u + 2 + 2 * BLOCK;  // [BLOCK]
         float *o_soc = lds_f;                      // [BLOCK] each, indexed by the owning lane's tid
-        float *o_target = lds_f + BLOCK;
-        float *o_tt = lds_f + 2 * BLOCK;
-        float *o_ts = lds_f + 3 * BLOCK;
-        float *o_pw = lds_f + 4 * BLOCK;
-        float *in_tt = lds_f + 5 * BLOCK;          // [BLOCK] curve time of a charging car
+        float *o_tt = lds_f + BLOCK;
+        float *o_ts = lds_f + 2 * BLOCK;
+        float *o_pw = lds_f + 3 * BLOCK;
+        float *in_tt = lds_f + 4 * BLOCK;          // [BLOCK] curve time of a charging car
         if (tid < 2) q_cnt[tid] = 0;
         __syncthreads();
         {
@@ -617,34 +618,27 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
             }
             // everything add_car derives from the arrival SoC is tabulated per SoC level (Tables::newcar)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const uint32_t lev = o.v[1] % 1000u;
             f32x4 nw = ((CHUB_G(const f32x4)) tb.newcar[k])[o.v[0] >> 18];
-            f32x2 tg = ((CHUB_G(const f32x2)) tb.ttab[k])[o.v[1] % 1000u];
-            asm volatile("" : "+v"(nw), "+v"(tg));  // both lookups in flight together
+            float tt_ = tb.ttab[k][lev];
+            asm volatile("" : "+v"(nw), "+v"(tt_));  // both lookups in flight together
             const int late = late_from_word(tb.late_thr, o.v[2]);
-            NewCar c;
-            c.soc = nw.x;
-            c.t_soc = nw.y;
-            c.power = nw.z;
-            c.target = tg.x;
-            c.t_target = tg.y;
-            const int stay = (int) ceilf(__fsub_rn(c.t_target, c.t_soc)) + late;  // calculate_min_charging_time + mk_late_time
-            c.stay = stay > 127 ? 127 : stay;
-            o_soc[src] = c.soc;
-            o_target[src] = c.target;
-            o_tt[src] = c.t_target;
-            o_ts[src] = c.t_soc;
-            o_pw[src] = c.power;
-            o_stay[src] = (uint32_t) c.stay;
+            int stay = (int) ceilf(__fsub_rn(tt_, nw.y)) + late;  // calculate_min_charging_time + mk_late_time
+            stay = stay > 127 ? 127 : stay;
+            o_soc[src] = nw.x;
+            o_tt[src] = tt_;
+            o_ts[src] = nw.y;
+            o_pw[src] = nw.z;
+            o_stay[src] = (uint32_t) stay | (lev << 7);
         }
         __syncthreads();
         if (adm) {
             nc.soc = o_soc[tid];
-            nc.target = o_target[tid];
             nc.t_target = o_tt[tid];
             nc.t_soc = o_ts[tid];
             nc.power = o_pw[tid];
-            nc.stay = (int) o_stay[tid];
+            nc.stay = (int) (o_stay[tid] & 127u);
+            nc.lev = (int) (o_stay[tid] >> 7);
         }
         if (r.needs_step) {
             r.soc_new = o_soc[tid];
@@ -705,7 +699,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         if (adm) {
             const int lev = (int) lds_lev[lbase + rank];
             const float target = uniform_level(lev, 80.0f, 100.0f);
-            nc = make_car<TYPE>(lds_soc[lbase + rank], target, soc_to_time<TYPE>(target, cp), (int) lds_late[lbase + rank], cp);
+            nc = make_car<TYPE>(lds_soc[lbase + rank], lev, soc_to_time<TYPE>(target, cp), (int) lds_late[lbase + rank], cp);
         }
     }
 
@@ -749,7 +743,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     const int cars = __popcll(__ballot(r.car) & unit_mask);
 
     if (valid) {
-        if (adm) r.stay = nc.stay;
+        if (adm) r.stay = nc.stay | (nc.lev << 7);
         else if (r.leave || RESET) r.stay = 0;
         u32x4 hot;
         hot.x = __float_as_uint(r.power);
@@ -757,14 +751,8 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         hot.z = __float_as_uint(r.t_soc);
         hot.w = (uint32_t) r.tl | (r.charge ? 128u : 0u) | ((uint32_t) r.stay << 8);
         ((CHUB_G(u32x4)) sl.hot)[idx] = hot;
-        if (hp.ablate & 8) {  // experiment: no cold-array stores
-        } else if (adm || r.leave || RESET) {
-            sl.target[idx] = adm ? nc.target : 0.0f;
-            sl.init_soc[idx] = adm ? nc.soc : 0.0f;
-            sl.soc[idx] = adm ? nc.soc : 0.0f;
-        } else if (r.soc_dirty) {
-            sl.soc[idx] = r.soc_new;
-        }
+        // the only cold store: the arrival SoC of a new car (current SoC and target SoC are derived on demand)
+        if (adm && !(hp.ablate & 8)) sl.init_soc[idx] = nc.soc;
     }
     if (unit_ok && slot == 0) {
         const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) cars << 16);
@@ -830,29 +818,27 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
     uint32_t *q_chg = lds_u + 2 + BLOCK;       // [BLOCK]  tid of the charging lane
     uint32_t *o_stay = lds_u + 2 + 2 * BLOCK;  // [BLOCK]  in: stay left of a charging car; out: stay of a new car
     float *o_soc = lds_f;                      // [BLOCK] each, indexed by the owning lane's tid
-    float *o_target = lds_f + BLOCK;
-    float *o_tt = lds_f + 2 * BLOCK;           // in: t_target of a charging car; out: t_target of a new car
-    float *o_ts = lds_f + 3 * BLOCK;
-    float *o_pw = lds_f + 4 * BLOCK;
-    float *in_tt = lds_f + 5 * BLOCK;          // [BLOCK] curve time of a charging car
+    float *o_tt = lds_f + BLOCK;               // in: t_target of a charging car; out: t_target of a new car
+    float *o_ts = lds_f + 2 * BLOCK;
+    float *o_pw = lds_f + 3 * BLOCK;
+    float *in_tt = lds_f + 4 * BLOCK;          // [BLOCK] curve time of a charging car
     if (tid == 0) q_cnt[0] = 0;
     for (int i = tid; i < 4 * upb; i += BLOCK) s_acc[i] = 0;
 
     // ---- slot_advance (deferred form): urgency, feasibility / on-off, departure (CHS.hpp:1188-1202 / 1499-1513)
     float power = __uint_as_float(hot.x), t_target = __uint_as_float(hot.y), t_soc = __uint_as_float(hot.z);
     const uint32_t tlb = hot.w;
-    int tl = (int) (tlb & 127u), stay = (int) ((tlb >> 8) & 255u);
+    int tl = (int) (tlb & 127u), stay = (int) (tlb >> 8);  // stay: the meta bits (stay_time | target level << 7 | car_steps << 17)
     bool car = tl > 0;
     const bool act_on = __fmul_rn(__fadd_rn(act, 1.0f), 0.5f) >= 0.5f;  // action_to_real (MGR:384-393)
     const bool on = car && (act_on || must_charge(t_target, t_soc, tl));
     const float step_tt = __fadd_rn(t_soc, 1.0f);
     bool needs_step = on && tl > 1;
-    bool leave = false;
+    if (needs_step) stay += 1 << 17;  // one more car_step on this car's account
     if (car) {  // remove_car (CHS.hpp:912-923 / 1077-1088)
         tl -= 1;
         if (tl <= 0) {
             car = false;
-            leave = true;
             tl = 0;
             stay = 0;
             power = t_target = t_soc = 0.0f;
@@ -915,7 +901,6 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         float soc_c, pw_c;
         car_step_curves<TYPE>(in_tt[src], cp, hp.cc, soc_c, pw_c);
         const float ts_c = soc_to_time<TYPE>(soc_c, cp);
-        o_soc[src] = soc_c;
         o_pw[src] = pw_c;
         o_ts[src] = ts_c;
         int *ac = s_acc + 4 * (int) (((uint32_t) src * pa.magic[k]) >> 16);
@@ -933,40 +918,37 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         PhiloxCtx p2{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + s_env)};
         const U4 o = p2.block(SITE_SOC, (uint32_t) s_hub_slot, 0);  // word 0 SoC, 1 target level, 2 extra stay
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const uint32_t lev = o.v[1] % 1000u;
         f32x4 nw = ((CHUB_G(const f32x4)) tb.newcar[k])[o.v[0] >> 18];
-        f32x2 tg = ((CHUB_G(const f32x2)) tb.ttab[k])[o.v[1] % 1000u];
-        asm volatile("" : "+v"(nw), "+v"(tg));  // both lookups in flight together
+        float tt_ = tb.ttab[k][lev];
+        asm volatile("" : "+v"(nw), "+v"(tt_));  // both lookups in flight together
         const int late = late_from_word(tb.late_thr, o.v[2]);
-        int st_ = (int) ceilf(__fsub_rn(tg.y, nw.y)) + late;  // calculate_min_charging_time + mk_late_time
+        int st_ = (int) ceilf(__fsub_rn(tt_, nw.y)) + late;  // calculate_min_charging_time + mk_late_time
         st_ = st_ > 127 ? 127 : st_;
         o_soc[src] = nw.x;
-        o_target[src] = tg.x;
-        o_tt[src] = tg.y;
+        o_tt[src] = tt_;
         o_ts[src] = nw.y;
         o_pw[src] = nw.z;
-        o_stay[src] = (uint32_t) st_;
+        o_stay[src] = (uint32_t) st_ | (lev << 7);
         if (st_ > 0) {
             int *ac = s_acc + 4 * s_u;
             const int q = (int) (nw.z * 524288.0f);
             atomicAdd(ac + 2, q);
             atomicAdd(ac + 3, 1);
-            if (must_charge(tg.y, nw.y, st_)) atomicAdd(ac + 0, q);
+            if (must_charge(tt_, nw.y, st_)) atomicAdd(ac + 0, q);
         }
     }
     __syncthreads();
-    float nc_soc = 0.0f, nc_target = 0.0f, soc_new = 0.0f;
+    float nc_soc = 0.0f;
     if (adm) {
         nc_soc = o_soc[tid];
-        nc_target = o_target[tid];
         t_target = o_tt[tid];
         t_soc = o_ts[tid];
         power = o_pw[tid];
-        tl = (int) o_stay[tid];
-        stay = tl;
+        stay = (int) o_stay[tid];  // stay_time | target level << 7, no car_steps yet
+        tl = stay & 127;
     }
     if (needs_step) {
-        soc_new = o_soc[tid];
         power = o_pw[tid];
         t_soc = o_ts[tid];
     }
@@ -977,14 +959,8 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         h2.z = __float_as_uint(t_soc);
         h2.w = (uint32_t) tl | (charge ? 128u : 0u) | ((uint32_t) stay << 8);
         ((CHUB_G(u32x4)) pa.hot)[idx] = h2;
-        if (hp.ablate & 8) {  // experiment: no cold-array stores
-        } else if (adm || leave) {
-            sl.target[idx] = adm ? nc_target : 0.0f;
-            sl.init_soc[idx] = adm ? nc_soc : 0.0f;
-            sl.soc[idx] = adm ? nc_soc : 0.0f;
-        } else if (needs_step) {
-            sl.soc[idx] = soc_new;
-        }
+        // the only cold store: the arrival SoC of a new car (current SoC and target SoC are derived on demand)
+        if (adm && !(hp.ablate & 8)) sl.init_soc[idx] = nc_soc;
         if (slot == 0) {
             const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) acc[3] << 16);
             rec_store<false>(pa.rec, sidx, fixed_to_kw(acc[0]), fixed_to_kw(acc[1]), fixed_to_kw(acc[2]), pkd);
@@ -995,7 +971,7 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa, uint32_t nb0,
                                                           uint32_t nb_lev) {
-    __shared__ float lds_f[6 * BLOCK];
+    __shared__ float lds_f[5 * BLOCK];
     __shared__ uint32_t lds_u[3 * BLOCK + 2];
     __shared__ uint64_t s_ball[BLOCK / 64 + 2];  // [1 + wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
     __shared__ int s_acc[BLOCK];                 // upb <= BLOCK / 4 units x {min, charge, max power, cars}
@@ -1039,7 +1015,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 256 ? 7 : (BLOCK == 512 ? 6 : 1)) v
     const CompatRng &cr = ctx->cr;
     const Tables &tb = ctx->tb;
     constexpr int WAVES = BLOCK / 64;
-    __shared__ float lds_f[6 * BLOCK];
+    __shared__ float lds_f[5 * BLOCK];
     __shared__ uint32_t lds_u[3 * BLOCK + 2];
     __shared__ int s_last[WAVES];
     if (hp.ablate & 64) return;
@@ -1595,6 +1571,32 @@ __global__ void k_random_actions(int64_t n_envs, int64_t env_id0, int act_dim, u
     }
 }
 
+// -------------------------------------------------------------------- introspection: current SoC on demand
+// The step kernels keep, per occupied slot, the arrival SoC (SlotArrays::init_soc) and the number of car_steps taken since
+// (hot.w bits 25-31) instead of storing the SoC every step: the SoC after n steps is the same deterministic chain
+// soc -> soc_to_time -> +1 slot -> time_to_soc the step evaluated (CHS.hpp:900-905 / 1065-1070), replayed here with the
+// same device functions, so the value is bit for bit the one the step produced.
+__global__ void k_replay_soc(const DevCtx *__restrict__ ctx, float *out) {
+    const HubParams &hp = ctx->hp;
+    const int64_t NS = hp.n_envs * (int64_t) (hp.S[0] + hp.S[1]);
+    const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NS) return;
+    const int k = idx >= hp.base[1] ? 1 : 0;
+    const bool cp = hp.constant_charging != 0;
+    const uint32_t w = ctx->sl.hot[4 * idx + 3];
+    float soc = 0.0f;
+    if ((w & 127u) != 0u) {
+        soc = ctx->sl.init_soc[idx];
+        const int n = (int) (w >> 25);
+        for (int i = 0; i < n; i++) {
+            float pw;
+            if (hp.type[k] == 0) car_step_curves<0>(__fadd_rn(soc_to_time<0>(soc, cp), 1.0f), cp, hp.cc, soc, pw);
+            else car_step_curves<1>(__fadd_rn(soc_to_time<1>(soc, cp), 1.0f), cp, hp.cc, soc, pw);
+        }
+    }
+    out[idx] = soc;
+}
+
 // ------------------------------------------------------------------------------------- launchers
 static inline int64_t blocks_for(int64_t n_envs, int H, int block) {
     const int64_t upb = (int64_t) (block / 64) * (64 / H);
@@ -1675,6 +1677,11 @@ void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepAr
         if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, nb_env);
         else hipExtLaunchKernelGGL((k_env<false, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, nb_env);
     }
+}
+
+void launch_replay_soc(const HubParams &hp, const DevCtx *ctx, float *d_out, hipStream_t stream) {
+    const int64_t NS = hp.n_envs * (int64_t) (hp.S[0] + hp.S[1]);
+    hipLaunchKernelGGL(k_replay_soc, dim3((unsigned) ((NS + 255) / 256)), dim3(256), 0, stream, ctx, d_out);
 }
 
 void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream) {

@@ -18,6 +18,7 @@
 namespace chub {
 bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
                  const PackedPtrs &pp, hipEvent_t ev0, hipEvent_t ev1);
+void launch_replay_soc(const HubParams &hp, const DevCtx *ctx, float *d_out, hipStream_t stream);
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
                 hipEvent_t ev1);
 void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream);
@@ -511,12 +512,11 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     std::vector<float> ttab[2], newcar[2];
     for (int s = 0; s < 2; s++) {
         const bool fast = hp.type[s] == CHUB_FAST, cpw = hp.constant_charging != 0;
-        ttab[s].resize(2 * kLevels);
+        ttab[s].resize(kLevels);
         for (int k = 0; k < kLevels; k++) {
             float tr = (float) k / 999.0f;
             float target = tr * (100.0f - 80.0f) + 80.0f;  // uniform_rand(80, 100), CHS.hpp:35-44
-            ttab[s][2 * k] = target;
-            ttab[s][2 * k + 1] = fast ? fast_soc_to_time(target, cpw) : slow_soc_to_time(target, cpw);
+            ttab[s][k] = fast ? fast_soc_to_time(target, cpw) : slow_soc_to_time(target, cpw);
         }
         // PHILOX: what add_car (CHS.hpp:864-877 / 1029-1042) derives from the arrival SoC, per SoC level: level l sits at
         // probability (l + 0.5) / kSocLevels of the tabulated inverse CDF (cell l >> 2, fraction ((l & 3) + 0.5) / 4)
@@ -603,7 +603,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     const size_t N = (size_t) n_envs, NS = N * (size_t) (hp.S[0] + hp.S[1]);
 #define ALLOC(ptr, count)                                        \
     if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
-    ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.soc, NS); ALLOC(e->sl.target, NS); ALLOC(e->sl.init_soc, NS);
+    ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.init_soc, NS);
     ALLOC(e->st.rec, 8 * N); ALLOC(e->st.pk[0], 2 * N); ALLOC(e->st.pk[1], 2 * N); ALLOC(e->st.grp_cnt, (N + 63) / 64);
     ALLOC(e->ev.cap, N); ALLOC(e->ev.store_soc, N); ALLOC(e->ev.ou, 3 * N); ALLOC(e->ev.price_noise, N);
     ALLOC(e->ev.re_pv, N); ALLOC(e->ev.re_wd, N); ALLOC(e->ev.price_next, N);
@@ -827,11 +827,19 @@ int chub_get_slots(chub_env *e, float *out) {
     HIP_TRY(hipDeviceSynchronize());
     const HubParams &hp = e->hp;
     const size_t N = (size_t) hp.n_envs, S = (size_t) (hp.S[0] + hp.S[1]), NS = N * S;
-    std::vector<float> soc, target, init_soc;
+    std::vector<float> soc, init_soc;
     std::vector<uint32_t> hot;
     int rc;
-    if ((rc = fetch(soc, (const float *) e->sl.soc, NS)) || (rc = fetch(target, (const float *) e->sl.target, NS)) ||
-        (rc = fetch(init_soc, (const float *) e->sl.init_soc, NS)) || (rc = fetch(hot, (const uint32_t *) e->sl.hot, 4 * NS)))
+    if ((rc = sync_ctx(e, nullptr))) return rc;
+    {   // current SoC: the arrival SoC advanced by the recorded number of car_steps, on the device (k_replay_soc)
+        float *d_soc = nullptr;
+        HIP_TRY(hipMalloc((void **) &d_soc, NS * sizeof(float)));
+        launch_replay_soc(hp, e->d_ctx, d_soc, nullptr);
+        rc = fetch(soc, (const float *) d_soc, NS);
+        (void) hipFree(d_soc);
+        if (rc) return rc;
+    }
+    if ((rc = fetch(init_soc, (const float *) e->sl.init_soc, NS)) || (rc = fetch(hot, (const uint32_t *) e->sl.hot, 4 * NS)))
         return rc;
     for (size_t env = 0; env < N; env++) {
         float *o = out + env * 9 * S;
@@ -844,8 +852,10 @@ int chub_get_slots(chub_env *e, float *out) {
                 memcpy(&t_target, &hot[4 * idx + 1], 4);
                 memcpy(&t_soc, &hot[4 * idx + 2], 4);
                 const uint32_t w = hot[4 * idx + 3];
-                const int left = (int) (w & 127u), stay = (int) ((w >> 8) & 255u);
+                const int left = (int) (w & 127u), stay = (int) ((w >> 8) & 127u), lev = (int) ((w >> 15) & 1023u);
                 const bool car = left > 0;
+                const float tr = (float) lev / 999.0f;
+                const float target = tr * (100.0f - 80.0f) + 80.0f;  // uniform_rand(80, 100) at level lev, CHS.hpp:35-44
                 float em = 0.0f;
                 if (car) {  // Station::situation["emergency"] as calculate_needed leaves it (CHS.hpp:879-898)
                     float need = t_target - t_soc;
@@ -855,9 +865,9 @@ int chub_get_slots(chub_env *e, float *out) {
                 o[1 * n + i] = (w & 128u) ? 1.0f : 0.0f;
                 o[2 * n + i] = em;
                 o[3 * n + i] = power;
-                o[4 * n + i] = soc[idx];
-                o[5 * n + i] = init_soc[idx];
-                o[6 * n + i] = target[idx];
+                o[4 * n + i] = car ? soc[idx] : 0.0f;
+                o[5 * n + i] = car ? init_soc[idx] : 0.0f;
+                o[6 * n + i] = car ? target : 0.0f;
                 o[7 * n + i] = car ? (float) stay : -1.0f;
                 o[8 * n + i] = car ? (float) (stay - left) : -1.0f;
             }
