@@ -219,7 +219,11 @@ __device__ __forceinline__ float soc_from_word(const float *icdf, uint32_t w) {
 __device__ __forceinline__ int late_from_word(const uint32_t *thr, uint32_t w) {
     int late = 0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) late += (w >= thr[j]) ? 1 : 0;
+    for (int j = 0; j < 8; j++) late += (w >= thr[j]) ? 1 : 0;
+    if (__any(w >= thr[7])) {  // the thresholds increase: beyond the 8th only with probability 0.3 %
+#pragma unroll
+        for (int j = 8; j < 16; j++) late += (w >= thr[j]) ? 1 : 0;
+    }
     return late;
 }
 
@@ -340,7 +344,7 @@ __device__ __forceinline__ void car_step_curves(float tt, bool cp, const CurveCo
             if (!c0 && !c1 && c2) ch = (float) (-4.041 * x + 19.140115 * log(fabs(x - 0.485)) + 11.943306312699628);
         }
         if (c0) ch = 0.0f;
-        soc = (float) ((double) (100.0f * ch) / 19.285746346634653);
+        soc = (float) CHUB_DIV_K64((double) (100.0f * ch), 19.285746346634653);
         power = pw;
     }
 }
