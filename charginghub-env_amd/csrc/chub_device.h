@@ -161,6 +161,7 @@ struct DevCtx {
 // host-side copies of the device pointers the packed slot kernel takes as kernel arguments (launch_slot)
 struct PackedPtrs {
     uint32_t *hot, *rec;
+    float *init_soc;
     uint64_t *pk[2];
     const uint32_t *lane_map[2];
 };

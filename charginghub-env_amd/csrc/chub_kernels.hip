@@ -782,6 +782,8 @@ struct PackedArgs {
     CHUB_G(uint32_t) hot;
     CHUB_G(uint32_t) rec;
     CHUB_G(uint64_t) pk;             // this step's packed station draws
+    CHUB_G(const float) actions;
+    CHUB_G(float) init_soc;
     CHUB_G(const uint32_t) lane_map[2];
 };
 
@@ -808,12 +810,15 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
     float act = 0.0f;
     uint32_t line_in = 0;
     uint64_t pk_in = 0;
+    // every array reached from here is < 4 GiB (checked at create), so addresses are a uniform base + a 32-bit byte offset
+    // per lane: the loads and stores take the base from SGPRs and need no 64-bit address arithmetic
+#define CHUB_AT(T, base, byte_off) (*(CHUB_G(T)) ((CHUB_G(char)) (base) + (uint32_t) (byte_off)))
     if (valid) {
-        hot = ((CHUB_G(u32x4)) pa.hot)[idx];
-        act = sa.actions[(uint32_t) env * pa.act_dim + (uint32_t) (S0 + slot)];
-        line_in = pa.rec[4u * sidx + 3u];
-        pk_in = pa.pk[sidx];
-        lm = ((CHUB_G(const u32x4)) pa.lane_map[k])[tid];
+        hot = CHUB_AT(u32x4, pa.hot, idx << 4);
+        act = CHUB_AT(const float, pa.actions, ((uint32_t) env * pa.act_dim + (uint32_t) (S0 + slot)) << 2);
+        line_in = CHUB_AT(uint32_t, pa.rec, (sidx << 4) + 12u);
+        pk_in = CHUB_AT(uint64_t, pa.pk, sidx << 3);
+        lm = CHUB_AT(const u32x4, pa.lane_map[k], (uint32_t) tid << 4);
     }
     // all five requests are out before the first use of any of them (one memory round trip, not two)
     asm volatile("" : "+v"(hot), "+v"(act), "+v"(line_in), "+v"(pk_in), "+v"(lm));
@@ -962,14 +967,17 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         h2.y = __float_as_uint(t_target);
         h2.z = __float_as_uint(t_soc);
         h2.w = (uint32_t) tl | (charge ? 128u : 0u) | ((uint32_t) stay << 8);
-        ((CHUB_G(u32x4)) pa.hot)[idx] = h2;
+        CHUB_AT(u32x4, pa.hot, idx << 4) = h2;
         // the only cold store: the arrival SoC of a new car (current SoC and target SoC are derived on demand)
-        if (adm && !(hp.ablate & 8)) sl.init_soc[idx] = nc_soc;
+        if (adm && !(hp.ablate & 8)) CHUB_AT(float, pa.init_soc, idx << 2) = nc_soc;
         if (slot == 0) {
             const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) acc[3] << 16);
-            rec_store<false>(pa.rec, sidx, fixed_to_kw(acc[0]), fixed_to_kw(acc[1]), fixed_to_kw(acc[2]), pkd);
+            const u32x4 rv = {__float_as_uint(fixed_to_kw(acc[0])), __float_as_uint(fixed_to_kw(acc[1])),
+                              __float_as_uint(fixed_to_kw(acc[2])), pkd};
+            CHUB_AT(u32x4, pa.rec, sidx << 4) = rv;
         }
     }
+#undef CHUB_AT
 }
 
 template <int BLOCK>
@@ -1652,6 +1660,8 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             pa.hot = (CHUB_G(uint32_t)) pp.hot;
             pa.rec = (CHUB_G(uint32_t)) pp.rec;
             pa.pk = (CHUB_G(uint64_t)) pp.pk[sa.tick & 1u];
+            pa.actions = (CHUB_G(const float)) sa.actions;
+            pa.init_soc = (CHUB_G(float)) pp.init_soc;
             const uint32_t nb0 = (uint32_t) ((hp.n_envs + hp.upb[0] - 1) / hp.upb[0]);
             const uint32_t nb1 = (uint32_t) ((hp.n_envs + hp.upb[1] - 1) / hp.upb[1]);
             const uint32_t nbl = hp.lev_in_env ? 0u : (uint32_t) ((2 * hp.n_envs + hp.slot_block - 1) / hp.slot_block);

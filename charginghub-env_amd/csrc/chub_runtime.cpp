@@ -237,6 +237,7 @@ static PackedPtrs packed_ptrs(const chub_env *e) {
     PackedPtrs p;
     p.hot = (uint32_t *) e->sl.hot;
     p.rec = (uint32_t *) e->st.rec;
+    p.init_soc = (float *) e->sl.init_soc;
     p.pk[0] = (uint64_t *) e->st.pk[0];
     p.pk[1] = (uint64_t *) e->st.pk[1];
     p.lane_map[0] = e->tb.lane_map[0];
@@ -570,7 +571,9 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
             for (int l = 0; l < pb && hp.S[s] > 0; l++)
                 if ((((uint32_t) l * (65536u / (uint32_t) hp.S[s] + 1u)) >> 16) != (uint32_t) (l / hp.S[s])) magic_ok = false;
         const char *pe = getenv("CHUB_PACKED");
-        hp.packed = (rng_mode == CHUB_RNG_PHILOX && !hp.fused && hp.S[0] >= 4 && hp.S[1] >= 4 && magic_ok && 
+        hp.packed = (rng_mode == CHUB_RNG_PHILOX && !hp.fused && hp.S[0] >= 4 && hp.S[1] >= 4 && magic_ok &&
+                     (uint64_t) n_envs * (uint64_t) (hp.S[0] + hp.S[1] + 2) * 16u < ((uint64_t) 1 << 32) &&  // 32-bit byte offsets
+                     
                      (pe ? atoi(pe) != 0 : true)) ? 1 : 0;
         (void) tighter;
     }
