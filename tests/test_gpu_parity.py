@@ -151,6 +151,17 @@ def test_philox_other_slot_kernel(label, packed, monkeypatch):
     _philox_parity(label + "_packed" + packed, kw, n, plan=(96, 30))
 
 
+@pytest.mark.parametrize("piles,types", [((4, 5), ("fast", "slow")), ((7, 13), ("slow", "fast")), ((33, 45), ("fast", "slow")),
+                                         ((63, 64), ("slow", "fast")), ((5, 64), ("fast", "fast")), ((21, 4), ("slow", "slow")),
+                                         ((10, 6), ("fast", "slow"))])
+def test_packed_kernel_shape_sweep(piles, types):
+    """the packed slot kernel lays whole units end to end over the workgroup, so where a unit meets a wave boundary
+    depends on the pile count: sweep awkward counts (and an env count that fills no workgroup evenly)"""
+    kw = dict(station_list=list(piles), station_type_list=list(types), hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.03)
+    _philox_parity("sweep_%d_%d" % piles, kw, 37, plan=(40,))
+
+
 def test_philox_user_series(tmp_path):
     """user-supplied arrival CDFs / price / PV / wind through a data directory: same parity bar"""
     from charginghub_env_amd import data_io
