@@ -806,10 +806,13 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
     const bool cp = hp.constant_charging != 0;
 
     // phase A loads: hot record, action, the unit's queue length and packed draws, the lane's ballot masks
-    u32x4 hot = {0u, 0u, 0u, 0u}, lm = {0u, 0u, 0u, 0u};
-    float act = 0.0f;
-    uint32_t line_in = 0;
-    uint64_t pk_in = 0;
+    // no zero fill for the lanes without a slot: what they hold is never used (their occupancy is forced to 0 below,
+    // their ballot masks to empty), and the fill would cost a dozen moves per wave
+    u32x4 hot, lm;
+    float act;
+    uint32_t line_in;
+    uint64_t pk_in;
+    asm volatile("" : "=v"(hot), "=v"(lm), "=v"(act), "=v"(line_in), "=v"(pk_in));
     // every array reached from here is < 4 GiB (checked at create), so addresses are a uniform base + a 32-bit byte offset
     // per lane: the loads and stores take the base from SGPRs and need no 64-bit address arithmetic
 #define CHUB_AT(T, base, byte_off) (*(CHUB_G(T)) ((CHUB_G(char)) (base) + (uint32_t) (byte_off)))
@@ -836,7 +839,7 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
 
     // ---- slot_advance (deferred form): urgency, feasibility / on-off, departure (CHS.hpp:1188-1202 / 1499-1513)
     float power = __uint_as_float(hot.x), t_target = __uint_as_float(hot.y), t_soc = __uint_as_float(hot.z);
-    const uint32_t tlb = hot.w;
+    const uint32_t tlb = valid ? hot.w : 0u;
     int tl = (int) (tlb & 127u), stay = (int) (tlb >> 8);  // stay: the meta bits (stay_time | target level << 7 | car_steps << 17)
     bool car = tl > 0;
     const bool act_on = __fmul_rn(__fadd_rn(act, 1.0f), 0.5f) >= 0.5f;  // action_to_real (MGR:384-393)
