@@ -1,0 +1,49 @@
+"""The multi-GPU orchestration of bench.py / sharded.py on the one GPU a test box has: a world of ONE rank over the
+`nccl` (= RCCL) backend, in a child process.  It cannot show scaling, but it runs the very calls the N > 1 bench makes
+(process group with device_id, async gather into a gather list, wait, barrier, all_reduce of the timing) against the real
+RCCL of the image, with the HIP engine writing the packed step output that is gathered."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r'''
+import os, sys
+sys.path.insert(0, os.environ["CHUB_ROOT"])
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group(backend="nccl", device_id=dev)
+from charginghub_env_amd.sharded import ShardedChargingHub
+kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+          init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
+hub = ShardedChargingHub(256, kw, seed=5, engine="hip")
+obs0 = hub.reset()
+eng = hub.engine
+gathered = [torch.empty_like(eng.packed)]
+a = torch.rand((256, hub.act_dim), device=dev) * 2 - 1
+for i in range(4):
+    eng.step(a)
+    work = dist.gather(eng.packed, gather_list=gathered, dst=0, async_op=True)   # bench.py's per-step collective
+    work.wait()
+torch.cuda.synchronize()
+dist.barrier()
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t.item()) == 1.5
+assert torch.equal(gathered[0], eng.packed) and bool(torch.isfinite(gathered[0]).all())
+assert obs0.shape == (256, hub.obs_dim)
+dist.destroy_process_group()
+print("RCCL_SINGLE_OK")
+'''
+
+
+def test_rccl_world_of_one():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CHUB_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_SINGLE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
