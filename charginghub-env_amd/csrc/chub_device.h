@@ -80,6 +80,8 @@ struct EnvArrays {           // index = env (or field*N + env)
     CHUB_G(uint8_t) q_len;       // FCEV FIFO length
     CHUB_G(uint8_t) hv_line;     // HyFCEVStation.line
     CHUB_G(uint8_t) q_overflow;
+    CHUB_G(uint32_t) drw[2];     // [N][4] PHILOX: a step's state-independent env draws, made one launch ahead (double-buffered by
+                                 // tick parity): three OU normals (f32 bits: pv, wind, price) and the FCEV arrival count
     CHUB_G(double) q_time;       // [N][kQCap]
     CHUB_G(double) q_mass;
     CHUB_G(double) obs64;        // [N][D]  (telemetry only)

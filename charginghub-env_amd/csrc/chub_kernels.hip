@@ -1199,7 +1199,15 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             q_len = ev.q_len[e32];
             hv_line = ev.hv_line[e32];
         }
-        if (MODE == MODE_PHILOX) {
+        if (MODE == MODE_PHILOX && !RESET && !FUSED && hp.lev_in_env) {
+            // this step's state-independent env draws (three OU normals, FCEV arrival count) were made one launch ahead by
+            // the level blocks of k_env (draw_env_levels): 350 dependent instructions less on this latency-bound chain
+            const u32x4 d = ((CHUB_G(const u32x4)) ev.drw[sa.tick & 1u])[e32];
+            z_pv = (double) __uint_as_float(d.x);
+            z_wd = (double) __uint_as_float(d.y);
+            z_pr = (double) __uint_as_float(d.z);
+            hv_arrive = (int) d.w;
+        } else if (MODE == MODE_PHILOX) {
             const U4 ow = px.block(SITE_OU, 0, 0);  // word 0 pv, 1 wind, 2 price
             z_pv = (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[0]);
             z_wd = (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[1]);
@@ -1538,10 +1546,23 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
         const HubParams &hp = ctx->hp;
         const int64_t u = (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x;
         const int64_t N = hp.n_envs;
+        const int t_next = RESET ? 0 : (sa.t + 1) % 96;
         if (u < 2 * N) {
             const int kk = u >= N ? 1 : 0;
-            ctx->st.pk[(sa.tick + 1u) & 1u][u] =
-                draw_station_levels(hp, ctx->tb, sa.tick + 1u, RESET ? 0 : (sa.t + 1) % 96, kk, u - (int64_t) kk * N);
+            ctx->st.pk[(sa.tick + 1u) & 1u][u] = draw_station_levels(hp, ctx->tb, sa.tick + 1u, t_next, kk, u - (int64_t) kk * N);
+        } else if (u < 3 * N) {
+            // ... and the next step's per-env draws (same Philox sites and counters the tail would use itself)
+            const uint32_t e = (uint32_t) (u - 2 * N);
+            const Tables &tb = ctx->tb;
+            PhiloxCtx px{hp.key[0], hp.key[1], sa.tick + 1u, (uint32_t) (hp.env_id0 + e)};
+            const U4 ow = px.block(SITE_OU, 0, 0);  // word 0 pv, 1 wind, 2 price
+            const uint32_t hv_lev = px.block(SITE_HV, 0, 0).v[0] % 1000u;
+            u32x4 d;
+            d.x = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[0]));
+            d.y = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[1]));
+            d.z = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[2]));
+            d.w = (uint32_t) tb.cnt_hv[(uint32_t) t_next * (uint32_t) kLevels + hv_lev];
+            ((CHUB_G(u32x4)) ctx->ev.drw[(sa.tick + 1u) & 1u])[e] = d;
         }
         return;
     }
@@ -1687,7 +1708,7 @@ void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepAr
                 hipEvent_t ev1) {
     const int nb_env = (int) ((hp.n_envs + 255) / 256);
     if (hp.rng_mode == MODE_PHILOX) {
-        const unsigned nb = (unsigned) nb_env + ((hp.lev_in_env && !hp.fused) ? (unsigned) ((2 * hp.n_envs + kEnvBlock - 1) / kEnvBlock) : 0u);
+        const unsigned nb = (unsigned) nb_env + ((hp.lev_in_env && !hp.fused) ? (unsigned) ((3 * hp.n_envs + kEnvBlock - 1) / kEnvBlock) : 0u);
         if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, nb_env);
         else hipExtLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, nb_env);
     } else {

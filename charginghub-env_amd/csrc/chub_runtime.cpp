@@ -612,6 +612,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     ALLOC(e->ev.re_pv, N); ALLOC(e->ev.re_wd, N); ALLOC(e->ev.price_next, N);
     ALLOC(e->ev.pv_day, N); ALLOC(e->ev.wd_day, N); ALLOC(e->ev.q_len, N); ALLOC(e->ev.hv_line, N);
     ALLOC(e->ev.q_overflow, N); ALLOC(e->ev.q_time, N * kQCap); ALLOC(e->ev.q_mass, N * kQCap);
+    ALLOC(e->ev.drw[0], 4 * N); ALLOC(e->ev.drw[1], 4 * N);
     e->ev.obs64 = nullptr; e->ev.reward64 = nullptr; e->ev.telem = nullptr;
     e->cr.g = nullptr; e->cr.minstd = nullptr;
     if (rng_mode == CHUB_RNG_COMPAT) {
