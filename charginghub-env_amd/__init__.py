@@ -8,11 +8,11 @@ multi-GPU launcher (``sharded.py``) borrows torch only for device buffers and th
 from ._lib import ChubError, lib_path, load_library  # noqa: F401
 from .vec_env import VecChargingHub, make_config  # noqa: F401
 from .env import Box, EvcsspManagerEnv_v6  # noqa: F401
-from .wrappers import HubVecEnv, HubVectorEnv, StaggeredHub, TimeLimit, make, register  # noqa: F401
+from .wrappers import HubVecEnv, HubVectorEnv, StaggeredHub, TimeLimit, TorchHubVecEnv, make, register  # noqa: F401
 from .data_io import write_data_dir  # noqa: F401
 
 __all__ = ["VecChargingHub", "EvcsspManagerEnv_v6", "Box", "make_config", "ChubError", "load_library", "lib_path",
-           "HubVecEnv", "HubVectorEnv", "StaggeredHub", "TimeLimit", "make", "register", "write_data_dir"]
+           "HubVecEnv", "HubVectorEnv", "StaggeredHub", "TimeLimit", "TorchHubVecEnv", "make", "register", "write_data_dir"]
 
 try:  # same gym id as the reference (evcssp_env_cpp/__init__.py:3-8) when gym / gymnasium is importable
     register()

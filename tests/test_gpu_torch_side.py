@@ -1,4 +1,4 @@
-"""The multi-GPU orchestration of bench.py / sharded.py on the one GPU a test box has: a world of ONE rank over the
+"""The multi-GPU orchestration of bench.py / sharded.py on the one GPU a test box has (plus the device-resident torch adapter): a world of ONE rank over the
 `nccl` (= RCCL) backend, in a child process.  It cannot show scaling, but it runs the very calls the N > 1 bench makes
 (process group with device_id, async gather into a gather list, wait, barrier, all_reduce of the timing) against the real
 RCCL of the image, with the HIP engine writing the packed step output that is gathered."""
@@ -47,3 +47,42 @@ def test_rccl_world_of_one():
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_SINGLE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+TORCH_CHILD = r'''
+import os, sys
+sys.path.insert(0, os.environ["CHUB_ROOT"])
+import numpy as np, torch
+import charginghub_env_amd as chub
+kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+          init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
+n = 128
+tv = chub.TorchHubVecEnv(n, seed=3, **kw)
+ref = chub.VecChargingHub(n, seed=3, **kw)
+o = tv.reset()
+assert o.is_cuda and np.array_equal(o.cpu().numpy(), ref.reset())
+g = torch.Generator(device="cuda").manual_seed(1)
+for t in range(100):
+    a = torch.rand((n, 47), device="cuda", generator=g) * 2 - 1
+    obs, rew, done, info = tv.step(a)
+    ro, rr, rd, _ = ref.step(a.cpu().numpy())
+    assert np.array_equal(rew.cpu().numpy(), rr) and np.array_equal(done.cpu().numpy(), rd), t
+    if rd.all():
+        assert t == 95 and np.array_equal(tv.last_obs.cpu().numpy(), ro)
+        ro = ref.reset()
+    assert np.array_equal(obs.cpu().numpy(), ro), t
+try:
+    tv.step(torch.zeros((n, 46), device="cuda"))
+    raise SystemExit("shape check missing")
+except AssertionError:
+    pass
+print("TORCH_VEC_OK")
+'''
+
+
+def test_torch_device_resident_adapter():
+    """TorchHubVecEnv: CUDA tensors in / out through the device-pointer entry points == the host-pointer path"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", TORCH_CHILD], env=dict(os.environ, CHUB_ROOT=root), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "TORCH_VEC_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
