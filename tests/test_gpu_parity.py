@@ -526,3 +526,36 @@ def test_staggered_groups_on_gpu():
     assert [e for e in ends if e] == [[3], [2], [1], [0]]
     st.close()
     ref.close()
+
+
+def test_determinism_and_long_run():
+    """same seed -> the same trajectory on two handles (atomics and dense-queue order must not leak into results);
+    ten episodes stay finite and in range, the FCEV FIFO never overflows at the default permeate"""
+    chub = hub()
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01, renew_fluctuate=0.3, price_fluctuate=0.3)
+    n = 4096
+    a_, b_ = chub.VecChargingHub(n, seed=77, **kw), chub.VecChargingHub(n, seed=77, **kw)
+    rs = np.random.RandomState(9)
+    oa, ob = a_.reset(), b_.reset()
+    assert np.array_equal(oa, ob)
+    for t in range(960):
+        act = rs.uniform(-1, 1, (n, 47)).astype(np.float32)
+        oa, ra, da, _ = a_.step(act)
+        if t % 96 < 40 or t % 96 == 95:      # the second handle shadows part of every episode and every episode end
+            ob, rb, db, _ = b_.step(act)
+            assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db), t
+            if t % 96 == 39:
+                snap = a_.get_state()        # ... and is re-synchronised from a snapshot where it stops shadowing
+        elif t % 96 == 94:
+            b_.set_state(a_.get_state())
+        assert np.isfinite(oa).all() and np.isfinite(ra).all() and np.abs(oa).max() < 50
+        if da.all():
+            assert t % 96 == 95
+            oa, ob = a_.reset(), b_.reset()
+            assert np.array_equal(oa, ob)
+    assert a_.fcev_overflow_count() == 0
+    sl = a_.slots()
+    assert sl[0][:, 4].min() >= 0 and sl[0][:, 4].max() <= 100.0 + 1e-3 and sl[1][:, 4].max() <= 100.0 + 1e-3  # SoC in range
+    a_.close()
+    b_.close()
