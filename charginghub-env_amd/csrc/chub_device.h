@@ -143,6 +143,8 @@ struct HubParams {
     float hv_rate;           // f32(f32(0.3) * f32(permeate))
     int32_t upb[2];          // packed slot kernel: whole units per workgroup = slot_block / S_k
     int32_t lev_in_env;      // PHILOX: next step's station-level draws ride in the k_env launch instead of the slot launch
+    int32_t tail_lead;       // k_step: how many slot workgroups are dispatched after the tail workgroups
+    int32_t one_launch;      // PHILOX steps on the packed kernel: slot, tail and level-draw workgroups in ONE launch (k_step)
     int32_t packed;          // PHILOX steps run k_slot_packed (both stations non-empty and at least one packs tighter)
     int32_t slot_block;      // experiments: workgroup size of the PHILOX slot kernel (128 / 256 / 512; env CHUB_SLOT_BLOCK)
     int32_t fused;           // PHILOX: run the per-env tail inside the slot launch (env CHUB_FUSED=0 turns it off)

@@ -166,8 +166,13 @@ constexpr int MODE_COMPAT = 0, MODE_PHILOX = 1;
 // What k_slot hands to the per-env tail for one (station, env) unit: one 16-byte record.
 struct StationRec {
     float mn, chg, mx;  // min_power, charge_power, max_power (CHS.hpp:1257-1259)
-    uint32_t pkd;       // line | flow_in << 8 | car_number << 16
+    uint32_t pkd;       // line | flow_in << 8 | car_number << 16 | (tick & 255) << 24
 };
+// The tick tag makes the record a self-announcing granule: written by ONE 16-byte store, a reader that polls it with
+// sc1 loads knows from the tag alone that it holds this step's record (MI355X_MICROARCH.md, granule hand-off: no
+// drain, no flag, no fence on the producer's side) -- what the one-launch step (k_step) uses between its slot workgroups
+// and its tail workgroups.  The record of the step before carries the previous tag, so a stale read cannot pass.
+__device__ __forceinline__ uint32_t rec_tag(uint32_t tick) { return (tick & 255u) << 24; }
 // COHERENT = the record crosses workgroups inside one launch (fused tail): relaxed agent-scope atomics compile to
 // sc1 (write-through / L1-bypassing) accesses, the form MI355X_MICROARCH.md prescribes for in-launch hand-offs.
 template <bool COHERENT>
@@ -759,7 +764,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         if (adm && !(hp.ablate & 8)) sl.init_soc[idx] = nc.soc;
     }
     if (unit_ok && slot == 0) {
-        const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) cars << 16);
+        const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) cars << 16) | rec_tag(sa.tick);
         rec_store<FUSED>(st.rec, sidx, r_min, r_chg, r_max, pkd);
     }
 }
@@ -787,7 +792,7 @@ struct PackedArgs {
     CHUB_G(const uint32_t) lane_map[2];
 };
 
-template <int TYPE, int BLOCK>
+template <int TYPE, int BLOCK, bool ONE>
 __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const PackedArgs &pa, const SlotArrays &sl,
                                  const Tables &tb, const int k, const uint32_t block_local, float *lds_f, uint32_t *lds_u,
                                  uint64_t *s_ball, int *s_acc) {
@@ -974,10 +979,15 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         // the only cold store: the arrival SoC of a new car (current SoC and target SoC are derived on demand)
         if (adm && !(hp.ablate & 8)) CHUB_AT(float, pa.init_soc, idx << 2) = nc_soc;
         if (slot == 0) {
-            const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) acc[3] << 16);
+            const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) acc[3] << 16) | rec_tag(sa.tick);
             const u32x4 rv = {__float_as_uint(fixed_to_kw(acc[0])), __float_as_uint(fixed_to_kw(acc[1])),
                               __float_as_uint(fixed_to_kw(acc[2])), pkd};
-            CHUB_AT(u32x4, pa.rec, sidx << 4) = rv;
+            if (ONE) {  // read by a tail workgroup of this same launch: write-through granule
+                CHUB_G(u32x4) rp = (CHUB_G(u32x4)) ((CHUB_G(char)) pa.rec + (sidx << 4));
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(rp), "v"(rv) : "memory");
+            } else {
+                CHUB_AT(u32x4, pa.rec, sidx << 4) = rv;
+            }
         }
     }
 #undef CHUB_AT
@@ -1005,14 +1015,14 @@ __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restri
     bid -= nb_lev;
     const int k = (bid >= nb0) ? 1 : 0;
     const uint32_t bl = k ? bid - nb0 : bid;
-    if (pa.type[k] == 0) slot_body_packed<0, BLOCK>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
-    else slot_body_packed<1, BLOCK>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
+    if (pa.type[k] == 0) slot_body_packed<0, BLOCK, false>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
+    else slot_body_packed<1, BLOCK, false>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
 }
 
-template <bool RESET, int MODE, bool FUSED>
+template <bool RESET, int MODE, bool FUSED, bool WAIT = false>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
-                                         float *s_out);
+                                         float *s_out, const int env_block);
 
 // FUSED (PHILOX mode): the per-env tail runs inside this launch.  Envs are grouped by 64; every slot workgroup, once
 // all its waves have drained their stores, adds 1 to the counter of each group it covers; the workgroup whose add
@@ -1092,7 +1102,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 256 ? 7 : (BLOCK == 512 ? 6 : 1)) v
             if (s_last[gi]) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 const int env = ((g0 + gi) << 6) + lane;
-                env_tail<RESET, MODE, true>(ctx, sa, env, env < N, nullptr, nullptr, nullptr, nullptr, nullptr);
+                env_tail<RESET, MODE, true>(ctx, sa, env, env < N, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
             }
         }
     }
@@ -1153,10 +1163,12 @@ constexpr int kEnvBlock = 256;  // compile-time (reading blockDim.x fetches the 
 // ---- the per-env tail of step() / reset() for one env per lane.  FUSED = run at the end of k_slot by the last
 // workgroup to finish a 64-env group (station records come through sc1 loads, tables straight from L2); otherwise it is
 // the body of the stand-alone k_env (tables staged in LDS by the caller between the two phases).
-template <bool RESET, int MODE, bool FUSED>
+// WAIT = the tail runs in the same launch as the slot workgroups (k_step): everything that does not come from them is
+// requested up front as usual, the two station records are polled (sc1 loads) until they carry this step's tag.
+template <bool RESET, int MODE, bool FUSED, bool WAIT>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
-                                         float *s_out) {
+                                         float *s_out, const int env_block) {
     const HubParams &hp = ctx->hp;
     const StationArrays &st = ctx->st;
     const EnvArrays &ev = ctx->ev;
@@ -1182,9 +1194,11 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         ou_wd = ev.ou[n32 + e32];
         ou_price = ev.ou[2u * n32 + e32];
         in_price_noise = ev.price_noise[e32];
-        const StationRec r0 = rec_load<FUSED>(st.rec, e32), r1 = rec_load<FUSED>(st.rec, n32 + e32);
-        mn0 = r0.mn; P0f = r0.chg; mx0 = r0.mx; ln0 = (int) (r0.pkd & 0xFFu); F0i = (int) (int8_t) ((r0.pkd >> 8) & 0xFFu);
-        mn1 = r1.mn; P1f = r1.chg; mx1 = r1.mx; ln1 = (int) (r1.pkd & 0xFFu); F1i = (int) (int8_t) ((r1.pkd >> 8) & 0xFFu);
+        if (!WAIT) {
+            const StationRec r0 = rec_load<FUSED>(st.rec, e32), r1 = rec_load<FUSED>(st.rec, n32 + e32);
+            mn0 = r0.mn; P0f = r0.chg; mx0 = r0.mx; ln0 = (int) (r0.pkd & 0xFFu); F0i = (int) (int8_t) ((r0.pkd >> 8) & 0xFFu);
+            mn1 = r1.mn; P1f = r1.chg; mx1 = r1.mx; ln1 = (int) (r1.pkd & 0xFFu); F1i = (int) (int8_t) ((r1.pkd >> 8) & 0xFFu);
+        }
         if (!RESET) {
             const int S = hp.S[0] + hp.S[1];
             const uint32_t ai = e32 * (uint32_t) hp.act_dim + (uint32_t) S;
@@ -1237,12 +1251,27 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         }
         __syncthreads();
     }
+    if (WAIT && live) {
+        // the slot workgroups of this launch write each station record with one 16-byte sc1 store that carries the step's tag
+        const uint32_t want = rec_tag(sa.tick);
+        StationRec r0, r1;
+        int spins = 0;
+        for (;;) {
+            r0 = rec_load<true>(st.rec, e32);
+            r1 = rec_load<true>(st.rec, n32 + e32);
+            if (((r0.pkd & 0xFF000000u) == want && (r1.pkd & 0xFF000000u) == want) || ++spins > (1 << 22)) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (spins > (1 << 22)) ev.q_overflow[e32] = 2;  // never seen: gives up loudly (chub_fcev_overflow_count counts it) instead of hanging
+        mn0 = r0.mn; P0f = r0.chg; mx0 = r0.mx; ln0 = (int) (r0.pkd & 0xFFu); F0i = (int) (int8_t) ((r0.pkd >> 8) & 0xFFu);
+        mn1 = r1.mn; P1f = r1.chg; mx1 = r1.mx; ln1 = (int) (r1.pkd & 0xFFu); F1i = (int) (int8_t) ((r1.pkd >> 8) & 0xFFu);
+    }
     // stand-alone kernel: output rows go through LDS so that the workgroup writes its kEnvBlock consecutive rows (one
     // contiguous run of memory) with coalesced stores instead of 15 scattered 4-byte stores per lane
     const int row_w = sa.obs_stride;  // D (dense) or D + 2 (packed: obs, reward, done)
     auto flush_rows = [&]() {
         __syncthreads();
-        const int env0 = (int) blockIdx.x * kEnvBlock;
+        const int env0 = env_block * kEnvBlock;
         const int rows = (int) N - env0 < kEnvBlock ? (int) N - env0 : kEnvBlock;
         float *dst = sa.obs + (size_t) env0 * (size_t) row_w;
         for (int i = threadIdx.x; i < rows * row_w; i += kEnvBlock) dst[i] = s_out[i];
@@ -1535,6 +1564,29 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 #undef TAB_HV
 }
 
+// Next step's state-independent draws, lane u: [0, 2N) the station-level variates of unit u, [2N, 3N) the per-env draws
+__device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int64_t u, const int t_next) {
+    const HubParams &hp = ctx->hp;
+    const int64_t N = hp.n_envs;
+    if (u < 2 * N) {
+        const int kk = u >= N ? 1 : 0;
+        ctx->st.pk[(sa.tick + 1u) & 1u][u] = draw_station_levels(hp, ctx->tb, sa.tick + 1u, t_next, kk, u - (int64_t) kk * N);
+    } else if (u < 3 * N) {
+        // the per-env draws (same Philox sites and counters the tail would use itself)
+        const uint32_t e = (uint32_t) (u - 2 * N);
+        const Tables &tb = ctx->tb;
+        PhiloxCtx px{hp.key[0], hp.key[1], sa.tick + 1u, (uint32_t) (hp.env_id0 + e)};
+        const U4 ow = px.block(SITE_OU, 0, 0);  // word 0 pv, 1 wind, 2 price
+        const uint32_t hv_lev = px.block(SITE_HV, 0, 0).v[0] % 1000u;
+        u32x4 d;
+        d.x = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[0]));
+        d.y = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[1]));
+        d.z = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[2]));
+        d.w = (uint32_t) tb.cnt_hv[(uint32_t) t_next * (uint32_t) kLevels + hv_lev];
+        ((CHUB_G(u32x4)) ctx->ev.drw[(sa.tick + 1u) & 1u])[e] = d;
+    }
+}
+
 template <bool RESET, int MODE>
 __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, int nb_env) {
     __shared__ double s_pv[100], s_wd[150], s_hy[102];
@@ -1543,31 +1595,61 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     if (MODE == MODE_PHILOX && (int) blockIdx.x >= nb_env) {
         // the last blocks of the grid (HubParams::lev_in_env): next step's station-level draws, one lane per (station, env).
         // They are pure VALU work and fill the issue slots the latency-bound tail waves leave empty.
-        const HubParams &hp = ctx->hp;
-        const int64_t u = (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x;
-        const int64_t N = hp.n_envs;
-        const int t_next = RESET ? 0 : (sa.t + 1) % 96;
-        if (u < 2 * N) {
-            const int kk = u >= N ? 1 : 0;
-            ctx->st.pk[(sa.tick + 1u) & 1u][u] = draw_station_levels(hp, ctx->tb, sa.tick + 1u, t_next, kk, u - (int64_t) kk * N);
-        } else if (u < 3 * N) {
-            // ... and the next step's per-env draws (same Philox sites and counters the tail would use itself)
-            const uint32_t e = (uint32_t) (u - 2 * N);
-            const Tables &tb = ctx->tb;
-            PhiloxCtx px{hp.key[0], hp.key[1], sa.tick + 1u, (uint32_t) (hp.env_id0 + e)};
-            const U4 ow = px.block(SITE_OU, 0, 0);  // word 0 pv, 1 wind, 2 price
-            const uint32_t hv_lev = px.block(SITE_HV, 0, 0).v[0] % 1000u;
-            u32x4 d;
-            d.x = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[0]));
-            d.y = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[1]));
-            d.z = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[2]));
-            d.w = (uint32_t) tb.cnt_hv[(uint32_t) t_next * (uint32_t) kLevels + hv_lev];
-            ((CHUB_G(u32x4)) ctx->ev.drw[(sa.tick + 1u) & 1u])[e] = d;
-        }
+        level_block(ctx, sa, (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x, RESET ? 0 : (sa.t + 1) % 96);
         return;
     }
     const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
-    env_tail<RESET, MODE, false>(ctx, sa, env, env < (int) ctx->hp.n_envs && !(ctx->hp.ablate & 32), s_pv, s_wd, s_hy, s_hv, s_out);
+    env_tail<RESET, MODE, false>(ctx, sa, env, env < (int) ctx->hp.n_envs && !(ctx->hp.ablate & 32), s_pv, s_wd, s_hy, s_hv, s_out,
+                                 (int) blockIdx.x);
+}
+
+// One launch per PHILOX step (HubParams::one_launch): [slot workgroups | tail workgroups | level-draw workgroups].  The tail
+// workgroups sit behind all slot workgroups in the grid; each requests its envs' state, stages the tables, and then
+// polls its envs' two station records until they carry this step's tag (the slot workgroups write them as 16-byte sc1
+// granules), so the tail's load burst and the kernel boundary in front of it disappear behind the slot work.  The
+// level-draw workgroups come last and fill the issue slots of the tail phase.  Tail workgroups are a small fraction of
+// the chip's wave slots and every poll loop is bounded, so no dispatch order can stall the grid.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void k_step(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa, uint32_t nb0,
+                                                   uint32_t nb_slot, uint32_t nb_env, uint32_t tail_at) {
+    static_assert(BLOCK == kEnvBlock, "tail rows are flushed per kEnvBlock envs");
+    // the two roles' LDS needs overlap (a workgroup has one role)
+    __shared__ __attribute__((aligned(16))) char lds_raw[(kEnvBlock * 16) * 4 + (100 + 150 + 102) * 8];
+    const HubParams &hp = ctx->hp;
+    // grid order: slot workgroups [0, tail_at) | tail workgroups | the remaining slot workgroups | level-draw workgroups.
+    // The tail workgroups are dispatched a few microseconds of slot work before the end, so their requests are back
+    // and their tables staged when the last station records arrive.
+    uint32_t bid = blockIdx.x;
+    bool tail_role = false;
+    if (bid >= tail_at && bid < tail_at + nb_env) {
+        tail_role = true;
+        bid -= tail_at;
+    } else if (bid >= tail_at + nb_env && bid < nb_slot + nb_env) {
+        bid -= nb_env;
+    }
+    if (!tail_role && bid < nb_slot) {
+        float *lds_f = (float *) lds_raw;                              // [5 * BLOCK]
+        uint32_t *lds_u = (uint32_t *) (lds_raw + 5 * BLOCK * 4);      // [3 * BLOCK + 2]
+        uint64_t *s_ball = (uint64_t *) (lds_raw + 8 * BLOCK * 4 + 16);  // [BLOCK / 64 + 2]
+        int *s_acc = (int *) (lds_raw + 8 * BLOCK * 4 + 16 + (BLOCK / 64 + 2) * 8);  // [BLOCK]
+        const int k = (bid >= nb0) ? 1 : 0;
+        const uint32_t bl = k ? bid - nb0 : bid;
+        if (pa.type[k] == 0) slot_body_packed<0, BLOCK, true>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
+        else slot_body_packed<1, BLOCK, true>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
+        return;
+    }
+    if (tail_role) {
+        __builtin_amdgcn_s_setprio(3);  // the launch ends with this chain: ahead of the level-draw waves at the issue ports
+        float *s_out = (float *) lds_raw;                              // [kEnvBlock * 16]
+        double *s_pv = (double *) (lds_raw + kEnvBlock * 16 * 4);      // [100], then wd [150], hy [102]
+        double *s_wd = s_pv + 100, *s_hy = s_wd + 150;
+        const int eb = (int) bid;
+        const int env = eb * kEnvBlock + (int) threadIdx.x;
+        env_tail<false, MODE_PHILOX, false, true>(ctx, sa, env, env < (int) hp.n_envs, s_pv, s_wd, s_hy, nullptr, s_out, eb);
+        return;
+    }
+    if (hp.ablate & 16) return;  // experiment: no level draws
+    level_block(ctx, sa, (int64_t) (bid - nb_slot - nb_env) * kEnvBlock + threadIdx.x, (sa.t + 1) % 96);
 }
 
 // COMPAT only: the reference's constructor consumes draws of the two streams before the first user-visible
@@ -1689,6 +1771,16 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             const uint32_t nb0 = (uint32_t) ((hp.n_envs + hp.upb[0] - 1) / hp.upb[0]);
             const uint32_t nb1 = (uint32_t) ((hp.n_envs + hp.upb[1] - 1) / hp.upb[1]);
             const uint32_t nbl = hp.lev_in_env ? 0u : (uint32_t) ((2 * hp.n_envs + hp.slot_block - 1) / hp.slot_block);
+            if (hp.one_launch && hp.slot_block == kEnvBlock) {
+                const uint32_t nb_env = (uint32_t) ((hp.n_envs + kEnvBlock - 1) / kEnvBlock);
+                const uint32_t nb_lev3 = (uint32_t) ((3 * hp.n_envs + kEnvBlock - 1) / kEnvBlock);
+                const uint32_t nb_slot = nb0 + nb1;
+                const uint32_t lead = (uint32_t) hp.tail_lead;  // slot workgroups dispatched after the tail workgroups
+                const uint32_t tail_at = nb_slot > lead ? nb_slot - lead : 0u;
+                hipExtLaunchKernelGGL((k_step<kEnvBlock>), dim3(nb_slot + nb_env + nb_lev3), dim3(kEnvBlock), 0, stream, ev0, ev1,
+                                      0, ctx, sa, pa, nb0, nb_slot, nb_env, tail_at);
+                return true;  // the tail ran in this launch
+            }
             const dim3 grid(nb0 + nb1 + nbl);
             if (hp.slot_block == 192) hipExtLaunchKernelGGL((k_slot_packed<192>), grid, dim3(192), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
             else if (hp.slot_block == 128) hipExtLaunchKernelGGL((k_slot_packed<128>), grid, dim3(128), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);

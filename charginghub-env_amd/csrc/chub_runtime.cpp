@@ -575,6 +575,10 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
                      (uint64_t) n_envs * (uint64_t) (hp.S[0] + hp.S[1] + 2) * 16u < ((uint64_t) 1 << 32) &&  // 32-bit byte offsets
                      
                      (pe ? atoi(pe) != 0 : true)) ? 1 : 0;
+        hp.tail_lead = getenv("CHUB_TAIL_LEAD") ? atoi(getenv("CHUB_TAIL_LEAD")) : 2048;
+        if (hp.tail_lead < 0) hp.tail_lead = 0;
+        hp.one_launch = (hp.packed && hp.lev_in_env && hp.slot_block == 256 && getenv("CHUB_ONE_LAUNCH") &&
+                         atoi(getenv("CHUB_ONE_LAUNCH")) == 1) ? 1 : 0;
         (void) tighter;
     }
     build_hy_table(hp, e->hy_table);
