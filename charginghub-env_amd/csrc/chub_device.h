@@ -164,6 +164,8 @@ struct DevCtx {
 
 // host-side copies of the device pointers the packed slot kernel takes as kernel arguments (launch_slot)
 struct PackedPtrs {
+    const EnvArrays *ev;      // host copies of the array tables (launch_env / k_step build TailArgs from them)
+    const StationArrays *st;
     uint32_t *hot, *rec;
     float *init_soc;
     uint64_t *pk[2];

@@ -1019,10 +1019,50 @@ __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restri
     else slot_body_packed<1, BLOCK, false>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
 }
 
+// What the tail's first loads need, by value in the kernel arguments: one scalar load at the start of the wave instead
+// of a dozen dependent hops through the context pointer in front of the load burst of this latency-bound kernel.
+struct TailArgs {
+    CHUB_G(const double) ou;
+    CHUB_G(const double) price_noise;
+    CHUB_G(const double) cap;
+    CHUB_G(const double) re_wd;
+    CHUB_G(const double) re_pv;
+    CHUB_G(const double) price_next;
+    CHUB_G(const int16_t) pv_day;
+    CHUB_G(const int16_t) wd_day;
+    CHUB_G(const uint8_t) q_len;
+    CHUB_G(const uint8_t) hv_line;
+    CHUB_G(const uint32_t) drw;   // this step's pre-drawn env variates
+    CHUB_G(uint32_t) rec;
+    CHUB_G(const float) actions;
+    uint32_t n_envs, act_dim, s_tot, pad;
+};
+__host__ __device__ inline TailArgs make_tail_args(const EnvArrays &ev, const StationArrays &st, const HubParams &hp, const StepArgs &sa) {
+    TailArgs ta;
+    ta.ou = (CHUB_G(const double)) ev.ou;
+    ta.price_noise = (CHUB_G(const double)) ev.price_noise;
+    ta.cap = (CHUB_G(const double)) ev.cap;
+    ta.re_wd = (CHUB_G(const double)) ev.re_wd;
+    ta.re_pv = (CHUB_G(const double)) ev.re_pv;
+    ta.price_next = (CHUB_G(const double)) ev.price_next;
+    ta.pv_day = (CHUB_G(const int16_t)) ev.pv_day;
+    ta.wd_day = (CHUB_G(const int16_t)) ev.wd_day;
+    ta.q_len = (CHUB_G(const uint8_t)) ev.q_len;
+    ta.hv_line = (CHUB_G(const uint8_t)) ev.hv_line;
+    ta.drw = (CHUB_G(const uint32_t)) ev.drw[sa.tick & 1u];
+    ta.rec = (CHUB_G(uint32_t)) st.rec;
+    ta.actions = (CHUB_G(const float)) sa.actions;
+    ta.n_envs = (uint32_t) hp.n_envs;
+    ta.act_dim = (uint32_t) hp.act_dim;
+    ta.s_tot = (uint32_t) (hp.S[0] + hp.S[1]);
+    ta.pad = 0;
+    return ta;
+}
+
 template <bool RESET, int MODE, bool FUSED, bool WAIT = false>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
-                                         float *s_out, const int env_block);
+                                         float *s_out, const int env_block, const TailArgs &ta);
 
 // FUSED (PHILOX mode): the per-env tail runs inside this launch.  Envs are grouped by 64; every slot workgroup, once
 // all its waves have drained their stores, adds 1 to the counter of each group it covers; the workgroup whose add
@@ -1102,7 +1142,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 256 ? 7 : (BLOCK == 512 ? 6 : 1)) v
             if (s_last[gi]) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 const int env = ((g0 + gi) << 6) + lane;
-                env_tail<RESET, MODE, true>(ctx, sa, env, env < N, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+                env_tail<RESET, MODE, true>(ctx, sa, env, env < N, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                                            make_tail_args(ctx->ev, ctx->st, ctx->hp, sa));
             }
         }
     }
@@ -1154,7 +1195,7 @@ __device__ __forceinline__ double ou_sample(double &state, double theta, double 
 
 #define CHUB_TEL(i, v)                                        \
     do {                                                      \
-        if (hp.telemetry) ev.telem[(size_t) (i) * (size_t) N + (size_t) env] = (v); \
+        if (tel_on) ev.telem[(size_t) (i) * (size_t) N + (size_t) env] = (v); \
     } while (0)
 
 // The per-env tail of step() / reset(), lane = env.
@@ -1168,9 +1209,8 @@ constexpr int kEnvBlock = 256;  // compile-time (reading blockDim.x fetches the 
 template <bool RESET, int MODE, bool FUSED, bool WAIT>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
-                                         float *s_out, const int env_block) {
+                                         float *s_out, const int env_block, const TailArgs &ta) {
     const HubParams &hp = ctx->hp;
-    const StationArrays &st = ctx->st;
     const EnvArrays &ev = ctx->ev;
     const CompatRng &cr = ctx->cr;
     const Tables &tb = ctx->tb;
@@ -1183,44 +1223,56 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     // ---- prefetch: every per-env input is requested before the table staging and its barrier, and the PHILOX
     // words that do not depend on state (FCEV arrival level, the three OU normals) are drawn here too, so the
     // memory latencies of this latency-bound kernel overlap instead of queueing behind one another.
-    const uint32_t e32 = (uint32_t) env, n32 = (uint32_t) N;
+    const uint32_t e32 = (uint32_t) env, n32 = ta.n_envs;
+    // the table rows of this slot of the day (PV, wind, hy_table; COMPAT: FCEV counts) go out first, one element per lane, in
+    // the same burst as the state loads: one memory round trip for everything (they are parked in LDS further down)
+    double st_pv = 0.0, st_wd = 0.0, st_hy = 0.0;
+    uint32_t st_hv = 0;
+    double sin_t = tb.sin96[t_next];  // the observation's time feature: requested here, used at the very end
+    asm volatile("" : "+v"(sin_t));
+    const bool tel_on = hp.telemetry != 0;
+    if (!FUSED) {
+        const int i = threadIdx.x;
+        if (i < 100) st_pv = tb.pvT[t_next * 100 + i];
+        if (i < 150) st_wd = tb.wdT[t_next * 150 + i];
+        if (!RESET) {
+            if (i < 102) st_hy = tb.hy_table[i];
+            if (MODE == MODE_COMPAT && i < kLevels / 4) st_hv = ((CHUB_G(const uint32_t)) tb.cnt_hv)[sa.t * (kLevels / 4) + i];
+        }
+    }
     PhiloxCtx px{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env)};
     double cap = 0.0, in_re_wd = 0.0, in_re_pv = 0.0, in_price_next = 0.0, in_price_noise = 0.0;
     double ou_pv = 0.0, ou_wd = 0.0, ou_price = 0.0, z_pv = 0.0, z_wd = 0.0, z_pr = 0.0;
     float a_el_f = 0.0f, a_fc_f = 0.0f, P0f = 0.0f, P1f = 0.0f, mn0 = 0.0f, mx0 = 0.0f, mn1 = 0.0f, mx1 = 0.0f;
     int pv_day = 0, wd_day = 0, q_len = 0, hv_line = 0, F0i = 0, F1i = 0, ln0 = 0, ln1 = 0, hv_lev = 0, hv_arrive = 0;
+    u32x4 drw_raw = {0u, 0u, 0u, 0u};
     if (live) {
-        ou_pv = ev.ou[e32];
-        ou_wd = ev.ou[n32 + e32];
-        ou_price = ev.ou[2u * n32 + e32];
-        in_price_noise = ev.price_noise[e32];
+        ou_pv = ta.ou[e32];
+        ou_wd = ta.ou[n32 + e32];
+        ou_price = ta.ou[2u * n32 + e32];
+        in_price_noise = ta.price_noise[e32];
         if (!WAIT) {
-            const StationRec r0 = rec_load<FUSED>(st.rec, e32), r1 = rec_load<FUSED>(st.rec, n32 + e32);
+            const StationRec r0 = rec_load<FUSED>(ta.rec, e32), r1 = rec_load<FUSED>(ta.rec, n32 + e32);
             mn0 = r0.mn; P0f = r0.chg; mx0 = r0.mx; ln0 = (int) (r0.pkd & 0xFFu); F0i = (int) (int8_t) ((r0.pkd >> 8) & 0xFFu);
             mn1 = r1.mn; P1f = r1.chg; mx1 = r1.mx; ln1 = (int) (r1.pkd & 0xFFu); F1i = (int) (int8_t) ((r1.pkd >> 8) & 0xFFu);
         }
         if (!RESET) {
-            const int S = hp.S[0] + hp.S[1];
-            const uint32_t ai = e32 * (uint32_t) hp.act_dim + (uint32_t) S;
-            a_el_f = sa.actions[ai];
-            a_fc_f = sa.actions[ai + 1u];
-            cap = ev.cap[e32];
-            in_re_wd = ev.re_wd[e32];
-            in_re_pv = ev.re_pv[e32];
-            in_price_next = ev.price_next[e32];
-            pv_day = ev.pv_day[e32];
-            wd_day = ev.wd_day[e32];
-            q_len = ev.q_len[e32];
-            hv_line = ev.hv_line[e32];
+            const uint32_t ai = e32 * ta.act_dim + ta.s_tot;
+            a_el_f = ta.actions[ai];
+            a_fc_f = ta.actions[ai + 1u];
+            cap = ta.cap[e32];
+            in_re_wd = ta.re_wd[e32];
+            in_re_pv = ta.re_pv[e32];
+            in_price_next = ta.price_next[e32];
+            pv_day = ta.pv_day[e32];
+            wd_day = ta.wd_day[e32];
+            q_len = ta.q_len[e32];
+            hv_line = ta.hv_line[e32];
         }
         if (MODE == MODE_PHILOX && !RESET && !FUSED && hp.lev_in_env) {
             // this step's state-independent env draws (three OU normals, FCEV arrival count) were made one launch ahead by
             // the level blocks of k_env (draw_env_levels): 350 dependent instructions less on this latency-bound chain
-            const u32x4 d = ((CHUB_G(const u32x4)) ev.drw[sa.tick & 1u])[e32];
-            z_pv = (double) __uint_as_float(d.x);
-            z_wd = (double) __uint_as_float(d.y);
-            z_pr = (double) __uint_as_float(d.z);
-            hv_arrive = (int) d.w;
+            drw_raw = ((CHUB_G(const u32x4)) ta.drw)[e32];  // unpacked behind the table staging: no wait for it here
         } else if (MODE == MODE_PHILOX) {
             const U4 ow = px.block(SITE_OU, 0, 0);  // word 0 pv, 1 wind, 2 price
             z_pv = (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[0]);
@@ -1240,16 +1292,22 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 
 
     if (!FUSED) {
-        // stand-alone kernel: the caller staged the tables while the loads above were in flight
-        for (int i = threadIdx.x; i < 100; i += kEnvBlock) ((double *) s_pv)[i] = tb.pvT[t_next * 100 + i];
-        for (int i = threadIdx.x; i < 150; i += kEnvBlock) ((double *) s_wd)[i] = tb.wdT[t_next * 150 + i];
+        // stand-alone kernel: the table rows requested at the top arrive with the state loads; park them in LDS
+        static_assert(kEnvBlock >= 150, "one table element per lane");
+        const int i = threadIdx.x;
+        if (i < 100) ((double *) s_pv)[i] = st_pv;
+        if (i < 150) ((double *) s_wd)[i] = st_wd;
         if (!RESET) {
-            for (int i = threadIdx.x; i < 102; i += kEnvBlock) ((double *) s_hy)[i] = tb.hy_table[i];
-            if (MODE == MODE_COMPAT)  // the level comes out of the env's stream later: stage the row (250 dwords)
-                for (int i = threadIdx.x; i < kLevels / 4; i += kEnvBlock)
-                    ((uint32_t *) s_hv)[i] = ((CHUB_G(const uint32_t)) tb.cnt_hv)[sa.t * (kLevels / 4) + i];
+            if (i < 102) ((double *) s_hy)[i] = st_hy;
+            if (MODE == MODE_COMPAT && i < kLevels / 4) ((uint32_t *) s_hv)[i] = st_hv;
         }
         __syncthreads();
+    }
+    if (MODE == MODE_PHILOX && !RESET && !FUSED && hp.lev_in_env) {
+        z_pv = (double) __uint_as_float(drw_raw.x);
+        z_wd = (double) __uint_as_float(drw_raw.y);
+        z_pr = (double) __uint_as_float(drw_raw.z);
+        hv_arrive = (int) drw_raw.w;
     }
     if (WAIT && live) {
         // the slot workgroups of this launch write each station record with one 16-byte sc1 store that carries the step's tag
@@ -1257,8 +1315,8 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         StationRec r0, r1;
         int spins = 0;
         for (;;) {
-            r0 = rec_load<true>(st.rec, e32);
-            r1 = rec_load<true>(st.rec, n32 + e32);
+            r0 = rec_load<true>(ta.rec, e32);
+            r1 = rec_load<true>(ta.rec, n32 + e32);
             if (((r0.pkd & 0xFF000000u) == want && (r1.pkd & 0xFF000000u) == want) || ++spins > (1 << 22)) break;
             __builtin_amdgcn_s_sleep(8);
         }
@@ -1473,7 +1531,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         const double not_meet_loss = -10 / 1000.0 * not_meet;
         const double hy_cost = -real_price_dollar * hydrogen_power;
         reward = DIV_K(income_hys + income_evs + income_evs_serve + hy_cost + 1 * hy_loss + not_meet_loss, 50);
-        if (hp.telemetry) {
+        if (tel_on) {
             CHUB_TEL(0, act_el); CHUB_TEL(1, flow); CHUB_TEL(2, all_power_second); CHUB_TEL(4, cap);
             CHUB_TEL(5, total_mass_need); CHUB_TEL(6, hy_use); CHUB_TEL(7, not_meet); CHUB_TEL(8, fc_power);
             CHUB_TEL(9, hy_to_use); CHUB_TEL(10, used_renew); CHUB_TEL(13, hydrogen_power);
@@ -1511,7 +1569,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 
     // state_norm (MGR:318-342), written straight to the output row
     float *obs = FUSED ? sa.obs + (size_t) e32 * (size_t) sa.obs_stride : s_out + (int) threadIdx.x * row_w;
-    double *o64 = hp.telemetry ? (double *) ev.obs64 + (size_t) e32 * hp.obs_dim : nullptr;
+    double *o64 = tel_on ? (double *) ev.obs64 + (size_t) e32 * hp.obs_dim : nullptr;
     int n = 0;
 #define CHUB_OBS(v)                    \
     do {                               \
@@ -1520,7 +1578,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         if (o64) o64[n] = v_;          \
         n++;                           \
     } while (0)
-    CHUB_OBS(tb.sin96[t_next]);
+    CHUB_OBS(sin_t);
     CHUB_OBS(div_c(price_next - hp.price_mean, hp.price_std, hp.rc_price_std));
     if (hp.S[0] > 0) {
         const double half_range = (double) hp.transformer_limit[0] / 2, rc_hr = hp.rc_half_range[0];
@@ -1551,7 +1609,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             if (sa.done_f32) sa.done_f32[(size_t) e32 * sa.reward_stride] = dn ? 1.0f : 0.0f;
         }
     }
-    if (hp.telemetry) {
+    if (tel_on) {
         ev.reward64[e32] = reward;
         CHUB_TEL(3, store_soc); CHUB_TEL(16, re_pv); CHUB_TEL(17, re_wd); CHUB_TEL(18, price_next);
         CHUB_TEL(22, (double) pv_day); CHUB_TEL(23, (double) wd_day);
@@ -1588,7 +1646,7 @@ __device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, cons
 }
 
 template <bool RESET, int MODE>
-__global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, int nb_env) {
+__global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, TailArgs ta, int nb_env) {
     __shared__ double s_pv[100], s_wd[150], s_hy[102];
     __shared__ __attribute__((aligned(16))) uint8_t s_hv[kLevels];
     __shared__ float s_out[kEnvBlock * 16];  // output rows: obs_dim + 2 <= 15 floats
@@ -1600,7 +1658,7 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     }
     const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
     env_tail<RESET, MODE, false>(ctx, sa, env, env < (int) ctx->hp.n_envs && !(ctx->hp.ablate & 32), s_pv, s_wd, s_hy, s_hv, s_out,
-                                 (int) blockIdx.x);
+                                 (int) blockIdx.x, ta);
 }
 
 // One launch per PHILOX step (HubParams::one_launch): [slot workgroups | tail workgroups | level-draw workgroups].  The tail
@@ -1610,7 +1668,7 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
 // level-draw workgroups come last and fill the issue slots of the tail phase.  Tail workgroups are a small fraction of
 // the chip's wave slots and every poll loop is bounded, so no dispatch order can stall the grid.
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 8) void k_step(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa, uint32_t nb0,
+__global__ __launch_bounds__(BLOCK, 8) void k_step(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa, TailArgs ta, uint32_t nb0,
                                                    uint32_t nb_slot, uint32_t nb_env, uint32_t tail_at) {
     static_assert(BLOCK == kEnvBlock, "tail rows are flushed per kEnvBlock envs");
     // the two roles' LDS needs overlap (a workgroup has one role)
@@ -1645,7 +1703,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_step(const DevCtx *__restrict__ ct
         double *s_wd = s_pv + 100, *s_hy = s_wd + 150;
         const int eb = (int) bid;
         const int env = eb * kEnvBlock + (int) threadIdx.x;
-        env_tail<false, MODE_PHILOX, false, true>(ctx, sa, env, env < (int) hp.n_envs, s_pv, s_wd, s_hy, nullptr, s_out, eb);
+        env_tail<false, MODE_PHILOX, false, true>(ctx, sa, env, env < (int) hp.n_envs, s_pv, s_wd, s_hy, nullptr, s_out, eb, ta);
         return;
     }
     if (hp.ablate & 16) return;  // experiment: no level draws
@@ -1778,7 +1836,7 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
                 const uint32_t lead = (uint32_t) hp.tail_lead;  // slot workgroups dispatched after the tail workgroups
                 const uint32_t tail_at = nb_slot > lead ? nb_slot - lead : 0u;
                 hipExtLaunchKernelGGL((k_step<kEnvBlock>), dim3(nb_slot + nb_env + nb_lev3), dim3(kEnvBlock), 0, stream, ev0, ev1,
-                                      0, ctx, sa, pa, nb0, nb_slot, nb_env, tail_at);
+                                      0, ctx, sa, pa, make_tail_args(*pp.ev, *pp.st, hp, sa), nb0, nb_slot, nb_env, tail_at);
                 return true;  // the tail ran in this launch
             }
             const dim3 grid(nb0 + nb1 + nbl);
@@ -1797,15 +1855,16 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
 }
 
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
-                hipEvent_t ev1) {
+                hipEvent_t ev1, const PackedPtrs &pp) {
+    const TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa);
     const int nb_env = (int) ((hp.n_envs + 255) / 256);
     if (hp.rng_mode == MODE_PHILOX) {
         const unsigned nb = (unsigned) nb_env + ((hp.lev_in_env && !hp.fused) ? (unsigned) ((3 * hp.n_envs + kEnvBlock - 1) / kEnvBlock) : 0u);
-        if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, nb_env);
-        else hipExtLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, nb_env);
+        if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
+        else hipExtLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
     } else {
-        if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, nb_env);
-        else hipExtLaunchKernelGGL((k_env<false, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, nb_env);
+        if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
+        else hipExtLaunchKernelGGL((k_env<false, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
     }
 }
 

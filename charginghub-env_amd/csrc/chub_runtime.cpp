@@ -20,7 +20,7 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
                  const PackedPtrs &pp, hipEvent_t ev0, hipEvent_t ev1);
 void launch_replay_soc(const HubParams &hp, const DevCtx *ctx, float *d_out, hipStream_t stream);
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
-                hipEvent_t ev1);
+                hipEvent_t ev1, const PackedPtrs &pp);
 void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream);
 void launch_compat_burn_fcev(const HubParams &hp, const DevCtx *ctx, int n_steps, hipStream_t stream);
 }  // namespace chub
@@ -235,6 +235,8 @@ static int fetch(std::vector<T> &dst, const T *src, size_t count) {
 // upload {hp, arrays, tables} when something in them changed (create, telemetry toggle)
 static PackedPtrs packed_ptrs(const chub_env *e) {
     PackedPtrs p;
+    p.ev = &e->ev;
+    p.st = &e->st;
     p.hot = (uint32_t *) e->sl.hot;
     p.rec = (uint32_t *) e->st.rec;
     p.init_soc = (float *) e->sl.init_soc;
@@ -694,7 +696,7 @@ int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_ex
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
     if (!launch_slot(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e), nullptr, nullptr))
-        launch_env(true, e->hp, e->d_ctx, sa, s, nullptr, nullptr);
+        launch_env(true, e->hp, e->d_ctx, sa, s, nullptr, nullptr, packed_ptrs(e));
     HIP_TRY(hipGetLastError());
     e->t = 0;
     e->price_count = 0;  // MGR:313 (after make_state)
@@ -774,7 +776,7 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
     // four events per profiled step: start / stop of the slot kernel, start / stop of the tail kernel
     hipEvent_t *pe = prof ? &e->prof_events[4 * e->prof_used] : nullptr;
     const bool tail_done = launch_slot(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e), prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
-    if (!tail_done) launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr);
+    if (!tail_done) launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
     if (prof) {
         e->prof_tail[e->prof_used] = !tail_done;
         e->prof_used++;
