@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""env-steps/s through the HOST-pointer entry point chub_step (numpy in / numpy out: PCIe copies and a sync per step),
+for the note in DESIGN.md.  bench.py's `value` is the device-resident rate; this one is never reported as `value`."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import charginghub_env_amd as chub  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+          init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
+v = chub.VecChargingHub(n, seed=12345, **kw)
+a = np.random.RandomState(0).uniform(-1, 1, (n, v.act_dim)).astype(np.float32)
+v.reset()
+for _ in range(20):
+    v.step(a)
+t0 = time.perf_counter()
+steps = 192
+for i in range(steps):
+    if i % 96 == 0:
+        v.reset()
+    v.step(a)
+dt = time.perf_counter() - t0
+print("host-pointer path: %d envs, %.3f ms/step, %.1f M env-steps/s" % (n, dt / steps * 1e3, n * steps / dt / 1e6))
