@@ -162,6 +162,22 @@ def test_packed_kernel_shape_sweep(piles, types):
     _philox_parity("sweep_%d_%d" % piles, kw, 37, plan=(40,))
 
 
+@pytest.mark.parametrize("label", ["c3", "c5"])
+def test_philox_one_launch_step(label, monkeypatch):
+    """the optional one-launch step (CHUB_ONE_LAUNCH=1: slot, tail and level-draw workgroups in one grid, station records
+    handed over as tagged sc1 granules) must give the same results as the two-launch default"""
+    monkeypatch.setenv("CHUB_ONE_LAUNCH", "1")
+    kw, n = next((c[1], c[2]) for c in PHILOX_CASES if c[0] == label)
+    _philox_parity(label + "_one_launch", kw, n, plan=(96, 30))
+    chub = hub()
+    v = chub.VecChargingHub(n, seed=1, **kw)          # the give-up flag of a bounded poll would show up here
+    v.reset()
+    for _ in range(20):
+        v.step(np.zeros((n, v.act_dim), dtype=np.float32))
+    assert v.fcev_overflow_count() == 0
+    v.close()
+
+
 def test_philox_user_series(tmp_path):
     """user-supplied arrival CDFs / price / PV / wind through a data directory: same parity bar"""
     from charginghub_env_amd import data_io
