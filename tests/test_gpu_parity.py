@@ -575,3 +575,35 @@ def test_determinism_and_long_run():
     assert sl[0][:, 4].min() >= 0 and sl[0][:, 4].max() <= 100.0 + 1e-3 and sl[1][:, 4].max() <= 100.0 + 1e-3  # SoC in range
     a_.close()
     b_.close()
+
+
+def test_error_paths_on_gpu():
+    """error behaviour of the ABI with a device present: codes + messages, nothing crashes, the handle stays usable"""
+    chub = hub()
+    from charginghub_env_amd import ChubError
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
+    v = chub.VecChargingHub(8, seed=1, **kw)
+    a = np.zeros((8, 47), dtype=np.float32)
+    with pytest.raises(ChubError, match="before reset"):
+        v.step(a)                                       # MGR would fail on its unset state too
+    v.reset()
+    with pytest.raises(AssertionError):
+        v.step(a[:, :46])                               # MGR:148
+    blob = v.get_state()
+    with pytest.raises(ChubError):
+        v.set_state(blob[:-8])                          # truncated snapshot
+    other = chub.VecChargingHub(16, seed=1, **kw)
+    with pytest.raises(ChubError):
+        other.set_state(blob)                           # snapshot of a different batch size
+    other.close()
+    o1 = v.step(a)[0]
+    v.set_state(blob)
+    assert np.array_equal(v.step(a)[0], o1)             # still consistent after the failed calls
+    c = chub.VecChargingHub(4, seed=1, rng="compat", **kw)
+    with pytest.raises(ChubError, match="COMPAT"):
+        c.reset()                                       # the reference's host draws must be supplied in this mode
+    c.close()
+    with pytest.raises(ChubError):
+        chub.VecChargingHub(8, seed=1, device=99, **kw)
+    v.close()
