@@ -450,8 +450,8 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     // below, so that the wave pays one memory round trip instead of three
     uint32_t line_in = 0;
     uint64_t pk_in = 0;
-    if (!RESET && unit_ok) {
-        line_in = st.rec[4u * sidx + 3u];  // masked after the slot loads have been issued (see slot_advance)
+    if (unit_ok) {
+        if (!RESET) line_in = st.rec[4u * sidx + 3u];  // masked after the slot loads have been issued (see slot_advance)
         if (MODE == MODE_PHILOX) pk_in = st.pk[sa.tick & 1u][sidx];
     }
     SlotRegs r;
@@ -537,23 +537,10 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     bool adm = false;
 
     if (MODE == MODE_PHILOX) {
-        PhiloxCtx px{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env)};
         if (unit_ok && !(hp.ablate & 4)) {
             if (RESET) {
-                // evs_reset: initial occupancy init_station_car_number(mu, 3) (CHS.hpp:832-842), thinned by the balk test
-                U4 b = px.block(SITE_ARRIVE, (uint32_t) k, 0);
-                const float cn = __fadd_rn(normal_from_word(tb.normal_icdf, tb.normal_tail,
-                                                            px.block(SITE_INIT, (uint32_t) k, 0).v[0]), (float) mu);
-                int n_in = (int) roundf(cn);
-                n_in = n_in > mu + 3 ? mu + 3 : (n_in < mu - 3 ? mu - 3 : n_in);
-                int true_in = 0;
-                for (int j = 0; j < n_in; j++) {  // arrival j stays iff u <= expf(-0.01*(line+j)) and j <= S
-                    const int wi = 1 + j;
-                    if ((wi & 3) == 0) b = px.block(SITE_ARRIVE, (uint32_t) k, (uint32_t) (wi >> 2));
-                    const int thr = (int) tb.thr_balk[j < kBalkTab ? j : kBalkTab - 1];
-                    true_in += ((int) (pick(b, wi & 3) % 1000u) <= thr && j <= S) ? 1 : 0;
-                }
-                flow = (TYPE == 0) ? n_in : true_in;
+                // evs_reset: the unit's initial occupancy was drawn by k_reset_levels, one lane per unit, just before
+                flow = (TYPE == 0) ? (int) (pk_in & 0xFFu) : (int) ((pk_in >> 8) & 0xFFu);
             } else {
                 // this step's station-level draws were packed by the previous launch (draw_station_levels)
                 const uint64_t pk = pk_in;
@@ -1653,6 +1640,7 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     if (MODE == MODE_PHILOX && (int) blockIdx.x >= nb_env) {
         // the last blocks of the grid (HubParams::lev_in_env): next step's station-level draws, one lane per (station, env).
         // They are pure VALU work and fill the issue slots the latency-bound tail waves leave empty.
+        if (ctx->hp.ablate & 16) return;  // experiment: no level draws
         level_block(ctx, sa, (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x, RESET ? 0 : (sa.t + 1) % 96);
         return;
     }
@@ -1773,6 +1761,33 @@ __global__ void k_replay_soc(const DevCtx *__restrict__ ctx, float *out) {
     out[idx] = soc;
 }
 
+// PHILOX reset: evs_reset's initial occupancy per (station, env) unit -- init_station_car_number(mu, 3) (CHS.hpp:832-842)
+// thinned by the balk test of an empty queue -- drawn once per unit here (every lane of the unit used to redo it),
+// handed to k_slot<RESET> through this tick's pk word: arrivals | arrivals that stay << 8.
+__global__ void k_reset_levels(const DevCtx *__restrict__ ctx, uint32_t tick) {
+    const HubParams &hp = ctx->hp;
+    const Tables &tb = ctx->tb;
+    const int64_t N = hp.n_envs;
+    const int64_t u = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= 2 * N) return;
+    const int k = u >= N ? 1 : 0;
+    const int64_t env = u - (int64_t) k * N;
+    const int S = hp.S[k], mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
+    PhiloxCtx px{hp.key[0], hp.key[1], tick, (uint32_t) (hp.env_id0 + env)};
+    U4 b = px.block(SITE_ARRIVE, (uint32_t) k, 0);
+    const float cn = __fadd_rn(normal_from_word(tb.normal_icdf, tb.normal_tail, px.block(SITE_INIT, (uint32_t) k, 0).v[0]), (float) mu);
+    int n_in = (int) roundf(cn);
+    n_in = n_in > mu + 3 ? mu + 3 : (n_in < mu - 3 ? mu - 3 : n_in);
+    int true_in = 0;
+    for (int j = 0; j < n_in; j++) {  // arrival j stays iff u <= expf(-0.01*(line+j)) and j <= S
+        const int wi = 1 + j;
+        if ((wi & 3) == 0) b = px.block(SITE_ARRIVE, (uint32_t) k, (uint32_t) (wi >> 2));
+        const int thr = (int) tb.thr_balk[j < kBalkTab ? j : kBalkTab - 1];
+        true_in += ((int) (pick(b, wi & 3) % 1000u) <= thr && j <= S) ? 1 : 0;
+    }
+    ctx->st.pk[tick & 1u][u] = (uint64_t) ((uint32_t) (n_in < 0 ? 0 : n_in) | ((uint32_t) true_in << 8));
+}
+
 // ------------------------------------------------------------------------------------- launchers
 static inline int64_t blocks_for(int64_t n_envs, int H, int block) {
     const int64_t upb = (int64_t) (block / 64) * (64 / H);
@@ -1786,6 +1801,7 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
                           hipEvent_t ev1) {
     const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
     if (MODE == MODE_PHILOX) {
+        if (RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa.tick);
         const int64_t nbl = (hp.lev_in_env && !FUSED) ? 0 : (2 * hp.n_envs + BLOCK - 1) / BLOCK;  // + next step's station-level draws
         hipExtLaunchKernelGGL((k_slot<RESET, MODE, BLOCK, FUSED>), dim3((unsigned) (nb0 + nb1 + nbl)), dim3(BLOCK), 0, stream,
                               ev0, ev1, 0, ctx, sa, nb0, nbl);
