@@ -162,6 +162,10 @@ __device__ __forceinline__ float arrive_soc_from(double normal73) {  // mk_soc, 
 }
 
 constexpr int MODE_COMPAT = 0, MODE_PHILOX = 1;
+// action_to_real (MGR:384-393) switches a pile on iff (a + 1) / 2 >= 0.5 on the f32 array.  In round-to-nearest-even f32
+// that is exactly a >= -2^-25 (a + 1 rounds to 1 from -2^-25 upwards, the tie going to the even 1.0; checked against the
+// two-step form on every f32 around the threshold and a stride over all others), so one compare replaces add, mul, compare.
+constexpr float kActOnThreshold = -2.98023223876953125e-8f;
 
 // What k_slot hands to the per-env tail for one (station, env) unit: one 16-byte record.
 struct StationRec {
@@ -374,7 +378,7 @@ __device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs
     r.stay = (int) (tlb >> 8);  // all of the meta bits above the flag: stay_time | target level << 7 | car_steps << 17
     r.car = r.tl > 0;
     // action_to_real (MGR:384-393): (a+1)/2 >= 0.5 on the f32 array
-    const bool act_on = __fmul_rn(__fadd_rn(a, 1.0f), 0.5f) >= 0.5f;
+    const bool act_on = a >= kActOnThreshold;
     // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373)
     const bool on = on_override >= 0 ? (r.car && on_override != 0)
                                      : (r.car && (act_on || must_charge(r.t_target, r.t_soc, r.tl)));
@@ -834,7 +838,7 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
     const uint32_t tlb = valid ? hot.w : 0u;
     int tl = (int) (tlb & 127u), stay = (int) (tlb >> 8);  // stay: the meta bits (stay_time | target level << 7 | car_steps << 17)
     bool car = tl > 0;
-    const bool act_on = __fmul_rn(__fadd_rn(act, 1.0f), 0.5f) >= 0.5f;  // action_to_real (MGR:384-393)
+    const bool act_on = act >= kActOnThreshold;  // action_to_real (MGR:384-393)
     const bool on = car && (act_on || must_charge(t_target, t_soc, tl));
     const float step_tt = __fadd_rn(t_soc, 1.0f);
     bool needs_step = on && tl > 1;
