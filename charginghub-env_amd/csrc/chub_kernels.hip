@@ -161,6 +161,11 @@ __device__ __forceinline__ float arrive_soc_from(double normal73) {  // mk_soc, 
     return (float) (75.0 - 5.0 * (double) d);
 }
 
+// popcount of the bits of m below this lane: two mbcnt instructions (no lane mask to build, no 64-bit and)
+__device__ __forceinline__ int prefix_count(uint64_t m) {
+    return (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+}
+
 constexpr int MODE_COMPAT = 0, MODE_PHILOX = 1;
 // action_to_real (MGR:384-393) switches a pile on iff (a + 1) / 2 >= 0.5 on the f32 array.  In round-to-nearest-even f32
 // that is exactly a >= -2^-25 (a + 1 rounds to 1 from -2^-25 upwards, the tie going to the even 1.0; checked against the
@@ -530,7 +535,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     const bool empty = valid && !r.car;
     const uint64_t be = __ballot(empty) & unit_mask;
     const int empties = __popcll(be);
-    const int rank = __popcll(be & ((1ull << lane) - 1ull));
+    const int rank = prefix_count(be);
     asm volatile("" : "+v"(line_in));
     int line = (int) (line_in & 0xFFu);
     int flow = 0, assign = 0;
@@ -584,10 +589,9 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
             }
             base_a = __shfl(base_a, 0);
             base_c = __shfl(base_c, 0);
-            const uint64_t below = (1ull << lane) - 1ull;
-            if (adm) q_new[base_a + __popcll(ba & below)] = (uint32_t) tid;
+            if (adm) q_new[base_a + prefix_count(ba)] = (uint32_t) tid;
             if (r.needs_step) {
-                q_chg[base_c + __popcll(bc & below)] = (uint32_t) tid;
+                q_chg[base_c + prefix_count(bc)] = (uint32_t) tid;
                 in_tt[tid] = r.step_tt;
             }
         }
@@ -864,7 +868,7 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
     const bool b_prev = u * S < wave * 64;                       // the unit began in the previous wave
     const int cntB = __popcll(s_ball[b_prev ? wave - 1 : wave + 1] & mB);  // its empties there (mB = 0: no lanes there)
     const int empties = __popcll(be & mA) + cntB;
-    const int rank = __popcll(be & mA & ((1ull << lane) - 1ull)) + (b_prev ? cntB : 0);
+    const int rank = prefix_count(be & mA) + (b_prev ? cntB : 0);
     int line = (int) (line_in & 0xFFu);
     int flow = 0, assign = 0;
     if (valid && !(hp.ablate & 4)) {
@@ -892,10 +896,9 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         uint32_t base = 0;
         if (lane == 0 && both) base = atomicAdd(&q_cnt[0], both);
         base = __shfl(base, 0);
-        const uint64_t below = (1ull << lane) - 1ull;
-        if (adm) q_new[(base & 0xFFFFu) + __popcll(ba & below)] = (uint32_t) tid;
+        if (adm) q_new[(base & 0xFFFFu) + prefix_count(ba)] = (uint32_t) tid;
         if (needs_step) {
-            q_chg[(base >> 16) + __popcll(bc & below)] = (uint32_t) tid;
+            q_chg[(base >> 16) + prefix_count(bc)] = (uint32_t) tid;
             in_tt[tid] = step_tt;
             o_tt[tid] = t_target;
             o_stay[tid] = (uint32_t) tl;
