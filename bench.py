@@ -123,8 +123,8 @@ def cpu_baseline(target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=960)
-    ap.add_argument("--warmup", type=int, default=96)
+    ap.add_argument("--steps", type=int, default=4800)
+    ap.add_argument("--warmup", type=int, default=960)
     ap.add_argument("--envs", type=int, default=None)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
