@@ -787,10 +787,11 @@ struct PackedArgs {
     CHUB_G(const uint32_t) lane_map[2];
 };
 
-template <int TYPE, int BLOCK, bool ONE>
+template <int TYPE, int BLOCK, bool ONE, bool ABL = false>
 __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const PackedArgs &pa, const SlotArrays &sl,
                                  const Tables &tb, const int k, const uint32_t block_local, float *lds_f, uint32_t *lds_u,
                                  uint64_t *s_ball, int *s_acc) {
+    const int abl = ABL ? hp.ablate : 0;  // timing experiments (CHUB_ABLATE) run a separate instantiation
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int S = (int) pa.S[k], upb = (int) pa.upb[k];
@@ -857,7 +858,7 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         }
     }
     const bool charge = on && car;
-    if (hp.ablate & 2) needs_step = false;  // experiment: no car_step
+    if (abl & 2) needs_step = false;  // experiment: no car_step
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): arrivals, renege, balk, admission
     const bool empty = valid && !car;
@@ -871,7 +872,7 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
     const int rank = prefix_count(be & mA) + (b_prev ? cntB : 0);
     int line = (int) (line_in & 0xFFu);
     int flow = 0, assign = 0;
-    if (valid && !(hp.ablate & 4)) {
+    if (valid && !(abl & 4)) {
         const uint64_t pk = pk_in;
         line = __popc((uint32_t) pk & ((1u << line) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
         const int n_in = (int) (pk >> 10) & 15;
@@ -880,7 +881,7 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         line = line + flow - assign;
         line = line < kMaxLine ? line : kMaxLine;
     }
-    if (hp.ablate & 1) assign = 0;
+    if (abl & 1) assign = 0;
     const bool adm = empty && rank < assign;
     int *acc = s_acc + 4 * u;  // the unit's {min, charge, max power in 2^-19 kW, cars}
     if (car && !needs_step) {  // state final: calculate_output share (CHS.hpp:1233-1261 / 1544-1572) goes in now
@@ -971,7 +972,7 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         h2.w = (uint32_t) tl | (charge ? 128u : 0u) | ((uint32_t) stay << 8);
         CHUB_AT(u32x4, pa.hot, idx << 4) = h2;
         // the only cold store: the arrival SoC of a new car (current SoC and target SoC are derived on demand)
-        if (adm && !(hp.ablate & 8)) CHUB_AT(float, pa.init_soc, idx << 2) = nc_soc;
+        if (adm && !(abl & 8)) CHUB_AT(float, pa.init_soc, idx << 2) = nc_soc;
         if (slot == 0) {
             const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) acc[3] << 16) | rec_tag(sa.tick);
             const u32x4 rv = {__float_as_uint(fixed_to_kw(acc[0])), __float_as_uint(fixed_to_kw(acc[1])),
@@ -987,7 +988,7 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
 #undef CHUB_AT
 }
 
-template <int BLOCK>
+template <int BLOCK, bool ABL = false>
 __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa, uint32_t nb0,
                                                           uint32_t nb_lev) {
     __shared__ float lds_f[5 * BLOCK];
@@ -1009,8 +1010,8 @@ __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restri
     bid -= nb_lev;
     const int k = (bid >= nb0) ? 1 : 0;
     const uint32_t bl = k ? bid - nb0 : bid;
-    if (pa.type[k] == 0) slot_body_packed<0, BLOCK, false>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
-    else slot_body_packed<1, BLOCK, false>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
+    if (pa.type[k] == 0) slot_body_packed<0, BLOCK, false, ABL>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
+    else slot_body_packed<1, BLOCK, false, ABL>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
 }
 
 // What the tail's first loads need, by value in the kernel arguments: one scalar load at the start of the wave instead
@@ -1866,6 +1867,7 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             if (hp.slot_block == 192) hipExtLaunchKernelGGL((k_slot_packed<192>), grid, dim3(192), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
             else if (hp.slot_block == 128) hipExtLaunchKernelGGL((k_slot_packed<128>), grid, dim3(128), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
             else if (hp.slot_block == 512) hipExtLaunchKernelGGL((k_slot_packed<512>), grid, dim3(512), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
+            else if (hp.ablate) hipExtLaunchKernelGGL((k_slot_packed<256, true>), grid, dim3(256), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
             else hipExtLaunchKernelGGL((k_slot_packed<256>), grid, dim3(256), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
         } else if (hp.slot_block == 512) launch_slot_t<false, MODE_PHILOX, 512, false>(hp, ctx, sa, stream, ev0, ev1);
         else if (hp.slot_block == 128) launch_slot_t<false, MODE_PHILOX, 128, false>(hp, ctx, sa, stream, ev0, ev1);
