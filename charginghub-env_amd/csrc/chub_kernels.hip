@@ -1054,7 +1054,7 @@ __host__ __device__ inline TailArgs make_tail_args(const EnvArrays &ev, const St
     return ta;
 }
 
-template <bool RESET, int MODE, bool FUSED, bool WAIT = false>
+template <bool RESET, int MODE, bool FUSED, bool WAIT = false, bool ABL = false>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
                                          float *s_out, const int env_block, const TailArgs &ta);
@@ -1201,7 +1201,7 @@ constexpr int kEnvBlock = 256;  // compile-time (reading blockDim.x fetches the 
 // the body of the stand-alone k_env (tables staged in LDS by the caller between the two phases).
 // WAIT = the tail runs in the same launch as the slot workgroups (k_step): everything that does not come from them is
 // requested up front as usual, the two station records are polled (sc1 loads) until they carry this step's tag.
-template <bool RESET, int MODE, bool FUSED, bool WAIT>
+template <bool RESET, int MODE, bool FUSED, bool WAIT, bool ABL>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
                                          float *s_out, const int env_block, const TailArgs &ta) {
@@ -1435,7 +1435,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             hv_line = 0;
         }
         const double total_mass_need = total_mass;
-        if (hp.ablate & 4096) {  // experiment: skip the H2 / money chain
+        if (ABL && (hp.ablate & 4096)) {  // experiment: skip the H2 / money chain
             store_soc = div_c(cap, cap_mass, hp.rc_cap_mass);
             reward = total_mass + act_el;
         } else {
@@ -1640,7 +1640,7 @@ __device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, cons
     }
 }
 
-template <bool RESET, int MODE>
+template <bool RESET, int MODE, bool ABL = false>
 __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, TailArgs ta, int nb_env) {
     __shared__ double s_pv[100], s_wd[150], s_hy[102];
     __shared__ __attribute__((aligned(16))) uint8_t s_hv[kLevels];
@@ -1648,13 +1648,13 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     if (MODE == MODE_PHILOX && (int) blockIdx.x >= nb_env) {
         // the last blocks of the grid (HubParams::lev_in_env): next step's station-level draws, one lane per (station, env).
         // They are pure VALU work and fill the issue slots the latency-bound tail waves leave empty.
-        if (ctx->hp.ablate & 16) return;  // experiment: no level draws
+        if (ABL && (ctx->hp.ablate & 16)) return;  // experiment: no level draws
         level_block(ctx, sa, (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x, RESET ? 0 : (sa.t + 1) % 96);
         return;
     }
     const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
-    env_tail<RESET, MODE, false>(ctx, sa, env, env < (int) ctx->hp.n_envs && !(ctx->hp.ablate & 32), s_pv, s_wd, s_hy, s_hv, s_out,
-                                 (int) blockIdx.x, ta);
+    env_tail<RESET, MODE, false, false, ABL>(ctx, sa, env, env < (int) ta.n_envs && !(ABL && (ctx->hp.ablate & 32)), s_pv, s_wd, s_hy,
+                                             s_hv, s_out, (int) blockIdx.x, ta);
 }
 
 // One launch per PHILOX step (HubParams::one_launch): [slot workgroups | tail workgroups | level-draw workgroups].  The tail
@@ -1886,6 +1886,7 @@ void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepAr
     if (hp.rng_mode == MODE_PHILOX) {
         const unsigned nb = (unsigned) nb_env + ((hp.lev_in_env && !hp.fused) ? (unsigned) ((3 * hp.n_envs + kEnvBlock - 1) / kEnvBlock) : 0u);
         if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
+        else if (hp.ablate) hipExtLaunchKernelGGL((k_env<false, MODE_PHILOX, true>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
         else hipExtLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
     } else {
         if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
