@@ -31,7 +31,8 @@ class ChubConfig(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libchub.so")
+    """libchub.so next to this file; CHUB_LIB names another build of it (compiler-flag experiments)"""
+    return os.environ.get("CHUB_LIB") or os.path.join(_HERE, "libchub.so")
 
 
 _lib = None
