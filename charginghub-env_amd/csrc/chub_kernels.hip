@@ -988,6 +988,28 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
 #undef CHUB_AT
 }
 
+// A station without piles still queues, reneges and balks (receive_car runs on it as on any other, CHS.hpp:1272-1316 /
+// 1583-1627; nobody is ever admitted): one lane per env advances its queue length and arrival count and writes the station
+// record (power sums and car count 0).
+template <int BLOCK, bool ONE>
+__device__ __forceinline__ void empty_station_body(const StepArgs &sa, const PackedArgs &pa, const int k, const uint32_t block_local) {
+    const uint32_t env = block_local * BLOCK + threadIdx.x;
+    if (env >= pa.n_envs) return;
+    const uint32_t sidx = (uint32_t) k * pa.n_envs + env;
+    const uint32_t line_in = pa.rec[4u * sidx + 3u];
+    const uint64_t pk = pa.pk[sidx];
+    int line = (int) (line_in & 0xFFu);
+    line = __popc((uint32_t) pk & ((1u << line) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
+    const int n_in = (int) (pk >> 10) & 15;
+    const int flow = (pa.type[k] == 0) ? n_in : (int) ((pk >> (14 + 4 * line)) & 15);
+    line = line + flow;
+    line = line < kMaxLine ? line : kMaxLine;
+    const u32x4 rv = {0u, 0u, 0u, (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | rec_tag(sa.tick)};
+    CHUB_G(u32x4) rp = (CHUB_G(u32x4)) pa.rec + sidx;
+    if (ONE) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(rp), "v"(rv) : "memory");
+    else *rp = rv;
+}
+
 template <int BLOCK, bool ABL = false>
 __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa, uint32_t nb0,
                                                           uint32_t nb_lev) {
@@ -1010,6 +1032,10 @@ __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restri
     bid -= nb_lev;
     const int k = (bid >= nb0) ? 1 : 0;
     const uint32_t bl = k ? bid - nb0 : bid;
+    if (pa.S[k] == 0) {
+        empty_station_body<BLOCK, false>(sa, pa, k, bl);
+        return;
+    }
     if (pa.type[k] == 0) slot_body_packed<0, BLOCK, false, ABL>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
     else slot_body_packed<1, BLOCK, false, ABL>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
 }
@@ -1688,6 +1714,10 @@ __global__ __launch_bounds__(BLOCK, 8) void k_step(const DevCtx *__restrict__ ct
         int *s_acc = (int *) (lds_raw + 8 * BLOCK * 4 + 16 + (BLOCK / 64 + 2) * 8);  // [BLOCK]
         const int k = (bid >= nb0) ? 1 : 0;
         const uint32_t bl = k ? bid - nb0 : bid;
+        if (pa.S[k] == 0) {
+            empty_station_body<BLOCK, true>(sa, pa, k, bl);
+            return;
+        }
         if (pa.type[k] == 0) slot_body_packed<0, BLOCK, true>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
         else slot_body_packed<1, BLOCK, true>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
         return;
@@ -1838,7 +1868,7 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             for (int k = 0; k < 2; k++) {
                 pa.S[k] = (uint32_t) hp.S[k];
                 pa.upb[k] = (uint32_t) hp.upb[k];
-                pa.magic[k] = 65536u / (uint32_t) hp.S[k] + 1u;
+                pa.magic[k] = hp.S[k] > 0 ? 65536u / (uint32_t) hp.S[k] + 1u : 0u;
                 pa.base[k] = (uint32_t) hp.base[k];
                 pa.type[k] = (uint32_t) hp.type[k];
                 pa.lane_map[k] = (CHUB_G(const uint32_t)) pp.lane_map[k];

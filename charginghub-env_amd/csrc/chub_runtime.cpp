@@ -547,7 +547,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
         bool tighter = false;
         for (int s = 0; s < 2; s++) {
             const int S = hp.S[s];
-            hp.upb[s] = S > 0 ? pb / S : 1;
+            hp.upb[s] = S > 0 ? pb / S : pb;  // a station without piles: one lane per env (empty_station_body)
             if (S > 0 && hp.upb[s] > (pb / 64) * (64 / hp.H[s])) tighter = true;
             lane_map[s].assign((size_t) pb * 4, 0u);
             for (int l = 0; l < pb && S > 0; l++) {
@@ -573,7 +573,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
             for (int l = 0; l < pb && hp.S[s] > 0; l++)
                 if ((((uint32_t) l * (65536u / (uint32_t) hp.S[s] + 1u)) >> 16) != (uint32_t) (l / hp.S[s])) magic_ok = false;
         const char *pe = getenv("CHUB_PACKED");
-        hp.packed = (rng_mode == CHUB_RNG_PHILOX && !hp.fused && hp.S[0] >= 4 && hp.S[1] >= 4 && magic_ok &&
+        hp.packed = (rng_mode == CHUB_RNG_PHILOX && !hp.fused && (hp.S[0] >= 4 || hp.S[0] == 0) && (hp.S[1] >= 4 || hp.S[1] == 0) && magic_ok &&
                      (uint64_t) n_envs * (uint64_t) (hp.S[0] + hp.S[1] + 2) * 16u < ((uint64_t) 1 << 32) &&  // 32-bit byte offsets
                      
                      (pe ? atoi(pe) != 0 : true)) ? 1 : 0;
