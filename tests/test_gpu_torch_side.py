@@ -43,9 +43,13 @@ print("RCCL_SINGLE_OK")
 
 def test_rccl_world_of_one():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CHUB_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1",
+    import socket
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, CHUB_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_SINGLE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
@@ -84,5 +88,5 @@ def test_torch_device_resident_adapter():
     """TorchHubVecEnv: CUDA tensors in / out through the device-pointer entry points == the host-pointer path"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", TORCH_CHILD], env=dict(os.environ, CHUB_ROOT=root), capture_output=True,
-                       text=True, timeout=300)
+                       text=True, timeout=600)
     assert r.returncode == 0 and "TORCH_VEC_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
