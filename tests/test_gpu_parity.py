@@ -607,3 +607,44 @@ def test_error_paths_on_gpu():
     with pytest.raises(ChubError):
         chub.VecChargingHub(8, seed=1, device=99, **kw)
     v.close()
+
+
+def test_philox_is_statistically_the_reference_process_on_gpu():
+    """PHILOX (production streams) against COMPAT (the reference's own streams, which reproduce the reference bit for
+    bit) on the device, 8192 envs x one episode each under the same random policy: episode returns, occupancy, queue
+    and arrival statistics agree within sampling error -- the two modes simulate the same stochastic process"""
+    chub = hub()
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.02)
+    n = 8192
+    rs = np.random.RandomState(5)
+    acts = [rs.uniform(-1, 1, (n, 47)).astype(np.float32) for _ in range(96)]
+    out = {}
+    for mode in ("compat", "philox"):
+        v = chub.VecChargingHub(n, seed=4242, rng=mode, **kw)
+        rz = np.random.RandomState(17)
+        if mode == "compat":
+            days = np.stack([rz.randint(0, 100, n), rz.randint(0, 150, n)], axis=1).astype(np.int32)
+            v.reset(days, rz.normal(size=(n, 3)))
+        else:
+            v.reset()
+        ret = np.zeros(n)
+        cars, line, flow, soc = [], [], [], []
+        for t in range(96):
+            o, r, d, _ = v.step(acts[t], rz.normal(size=(n, 3)) if mode == "compat" else None)
+            ret += r
+            if t % 8 == 7:
+                sc = v.station_scalars()
+                cars.append(sc[:, :, 3].mean()); line.append(sc[:, :, 4].mean()); flow.append(sc[:, :, 5].mean())
+                soc.append(o[:, 10].mean())
+        out[mode] = dict(ret=ret, cars=np.mean(cars), line=np.mean(line), flow=np.mean(flow), soc=np.mean(soc))
+        v.close()
+    a, b = out["compat"], out["philox"]
+    se = np.sqrt(a["ret"].var() / n + b["ret"].var() / n)
+    print("compat vs philox: return %.4f / %.4f (se %.4f), std %.3f / %.3f, cars %.3f / %.3f, line %.4f / %.4f, flow %.4f / %.4f, H2 SOC %.4f / %.4f"
+          % (a["ret"].mean(), b["ret"].mean(), se, a["ret"].std(), b["ret"].std(), a["cars"], b["cars"], a["line"], b["line"],
+             a["flow"], b["flow"], a["soc"], b["soc"]))
+    assert abs(a["ret"].mean() - b["ret"].mean()) < 5 * se + 0.05, (a["ret"].mean(), b["ret"].mean(), se)
+    assert abs(a["ret"].std() - b["ret"].std()) < 0.1 * a["ret"].std()
+    for key, tol in (("cars", 0.1), ("line", 0.05), ("flow", 0.05), ("soc", 0.01)):
+        assert abs(a[key] - b[key]) < tol, (key, a[key], b[key])
