@@ -1208,6 +1208,13 @@ __device__ __forceinline__ void j2601_time_mass(double p0, double &time_need, do
     mass_need = pressure_to_mass(target) - pressure_to_mass(p0);
 }
 
+__device__ __forceinline__ void fcev_time_mass(float socf, double &tn, double &mn) {
+    double soc = (double) socf;
+    if (soc < 0.5) soc = 0.5;
+    const double p0 = (soc * 0.01) * 70;  // _soc_to_pressure HYD:302-306
+    j2601_time_mass(p0, tn, mn);
+}
+
 __device__ __forceinline__ double ou_sample(double &state, double theta, double sigma, double z) {  // REN:71-76
     const double dx = theta * (0.0 - state) + sigma * z;
     state += dx;
@@ -1266,7 +1273,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     double ou_pv = 0.0, ou_wd = 0.0, ou_price = 0.0, z_pv = 0.0, z_wd = 0.0, z_pr = 0.0;
     float a_el_f = 0.0f, a_fc_f = 0.0f, P0f = 0.0f, P1f = 0.0f, mn0 = 0.0f, mx0 = 0.0f, mn1 = 0.0f, mx1 = 0.0f;
     int pv_day = 0, wd_day = 0, q_len = 0, hv_line = 0, F0i = 0, F1i = 0, ln0 = 0, ln1 = 0, hv_lev = 0, hv_arrive = 0;
-    u32x4 drw_raw = {0u, 0u, 0u, 0u};
+    u32x4 drw_raw = {0u, 0u, 0u, 0u}, drw_fcev = {0u, 0u, 0u, 0u};
     if (live) {
         ou_pv = ta.ou[e32];
         ou_wd = ta.ou[n32 + e32];
@@ -1293,7 +1300,8 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         if (MODE == MODE_PHILOX && !RESET && !FUSED && hp.lev_in_env) {
             // this step's state-independent env draws (three OU normals, FCEV arrival count) were made one launch ahead by
             // the level blocks of k_env (draw_env_levels): 350 dependent instructions less on this latency-bound chain
-            drw_raw = ((CHUB_G(const u32x4)) ta.drw)[e32];  // unpacked behind the table staging: no wait for it here
+            drw_raw = ((CHUB_G(const u32x4)) ta.drw)[2u * e32];  // unpacked behind the table staging: no wait for it here
+            drw_fcev = ((CHUB_G(const u32x4)) ta.drw)[2u * e32 + 1u];
         } else if (MODE == MODE_PHILOX) {
             const U4 ow = px.block(SITE_OU, 0, 0);  // word 0 pv, 1 wind, 2 price
             z_pv = (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[0]);
@@ -1407,21 +1415,36 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         if (MODE == MODE_COMPAT) hv_lev = rs.level();
         const int arrive = MODE == MODE_COMPAT ? (int) TAB_HV(hv_lev) : hv_arrive;
         double total_mass = 0.0;
-        if (q_len > 0 || arrive > 0) {
+        const bool fcev_pre = MODE == MODE_PHILOX && !RESET && !FUSED && hp.lev_in_env;
+        const double pre_tn = __hiloint2double((int) drw_fcev.y, (int) drw_fcev.x);
+        const double pre_mn = __hiloint2double((int) drw_fcev.w, (int) drw_fcev.z);
+        if (fcev_pre && q_len == 0 && arrive == 1 && pre_tn <= 15.0) {
+            // the common case by far: an empty FIFO, one arrival, served within the slot (hvs_step leaves the FIFO empty and
+            // the line at 0, HYD:281-283) -- nothing to read from or write to the queue arrays
+            total_mass = pre_mn;
+            if (hv_line != 0) {
+                ev.hv_line[e32] = 0;
+                hv_line = 0;
+            }
+        } else if (q_len > 0 || arrive > 0) {
             double total_time = 0.0;
             for (int i = 0; i < q_len; i++) {
                 total_time += qt[i];
                 total_mass += qm[i];
             }
             for (int j = 0; j < arrive; j++) {
-                float socf;
-                if (MODE == MODE_COMPAT) socf = arrive_soc_from(rs.normal_d(7.0, 3.0));
-                else socf = soc_from_word(tb.soc_d_icdf, px.block(SITE_HVSOC, (uint32_t) j, 0).v[0]);
-                double soc = (double) socf;
-                if (soc < 0.5) soc = 0.5;
-                const double p0 = (soc * 0.01) * 70;
                 double tn, mn;
-                j2601_time_mass(p0, tn, mn);
+                if (fcev_pre && j == 0) {
+                    // the first arrival's fueling time and mass depend on its drawn SoC only: made one launch ahead with the
+                    // other env draws (level_block), same functions, same Philox counter
+                    tn = pre_tn;
+                    mn = pre_mn;
+                } else {
+                    float socf;
+                    if (MODE == MODE_COMPAT) socf = arrive_soc_from(rs.normal_d(7.0, 3.0));
+                    else socf = soc_from_word(tb.soc_d_icdf, px.block(SITE_HVSOC, (uint32_t) j, 0).v[0]);
+                    fcev_time_mass(socf, tn, mn);
+                }
                 if (q_len < kQCap) {
                     qt[q_len] = tn;
                     qm[q_len] = mn;
@@ -1662,7 +1685,16 @@ __device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, cons
         d.y = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[1]));
         d.z = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[2]));
         d.w = (uint32_t) tb.cnt_hv[(uint32_t) t_next * (uint32_t) kLevels + hv_lev];
-        ((CHUB_G(u32x4)) ctx->ev.drw[(sa.tick + 1u) & 1u])[e] = d;
+        u32x4 f = {0u, 0u, 0u, 0u};
+        if (d.w != 0u) {
+            double tn, mn;
+            fcev_time_mass(soc_from_word(tb.soc_d_icdf, px.block(SITE_HVSOC, 0, 0).v[0]), tn, mn);
+            f.x = (uint32_t) __double2loint(tn); f.y = (uint32_t) __double2hiint(tn);
+            f.z = (uint32_t) __double2loint(mn); f.w = (uint32_t) __double2hiint(mn);
+        }
+        CHUB_G(u32x4) dst = (CHUB_G(u32x4)) ctx->ev.drw[(sa.tick + 1u) & 1u] + 2u * e;
+        dst[0] = d;
+        dst[1] = f;
     }
 }
 

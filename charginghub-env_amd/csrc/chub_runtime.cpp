@@ -618,7 +618,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     ALLOC(e->ev.re_pv, N); ALLOC(e->ev.re_wd, N); ALLOC(e->ev.price_next, N);
     ALLOC(e->ev.pv_day, N); ALLOC(e->ev.wd_day, N); ALLOC(e->ev.q_len, N); ALLOC(e->ev.hv_line, N);
     ALLOC(e->ev.q_overflow, N); ALLOC(e->ev.q_time, N * kQCap); ALLOC(e->ev.q_mass, N * kQCap);
-    ALLOC(e->ev.drw[0], 4 * N); ALLOC(e->ev.drw[1], 4 * N);
+    ALLOC(e->ev.drw[0], 8 * N); ALLOC(e->ev.drw[1], 8 * N);
     e->ev.obs64 = nullptr; e->ev.reward64 = nullptr; e->ev.telem = nullptr;
     e->cr.g = nullptr; e->cr.minstd = nullptr;
     if (rng_mode == CHUB_RNG_COMPAT) {
@@ -655,10 +655,13 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
 
 int chub_destroy(chub_env *e) {
     if (!e) return CHUB_OK;
-    (void) hipSetDevice(e->device);
-    (void) hipDeviceSynchronize();
-    for (void *p : e->allocs) (void) hipFree(p);
-    for (hipEvent_t ev : e->prof_events) (void) hipEventDestroy(ev);
+    if (!e->allocs.empty() || !e->prof_events.empty()) {  // a handle that never reached the device owns nothing there
+        (void) hipSetDevice(e->device);
+        (void) hipDeviceSynchronize();
+        for (void *p : e->allocs) (void) hipFree(p);
+        for (hipEvent_t ev : e->prof_events) (void) hipEventDestroy(ev);
+    }
+    (void) hipGetLastError();  // HIP's last-error slot is per thread and sticky: do not leave ours for the next handle's checks
     delete e;
     return CHUB_OK;
 }
@@ -680,6 +683,7 @@ int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_ex
     if (e->hp.rng_mode == CHUB_RNG_COMPAT && (!d_exo_days || !d_exo_z))
         return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_days and exo_z");
     HIP_TRY(hipSetDevice(e->device));
+    (void) hipGetLastError();  // a stale error of an earlier, unrelated call must not be reported as this step's
     hipStream_t s = (hipStream_t) stream;
     e->tick += 1;
     StepArgs sa;
@@ -748,6 +752,7 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
     if (e->tick == 0) return fail(CHUB_ERR_ARG, "step() before reset()");
     if (e->hp.rng_mode == CHUB_RNG_COMPAT && !d_exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
     HIP_TRY(hipSetDevice(e->device));
+    (void) hipGetLastError();  // a stale error of an earlier, unrelated call must not be reported as this step's
     hipStream_t s = (hipStream_t) stream;
     e->tick += 1;
     StepArgs sa;
