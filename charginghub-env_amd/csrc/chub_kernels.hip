@@ -1010,7 +1010,9 @@ __device__ __forceinline__ void empty_station_body(const StepArgs &sa, const Pac
     else *rp = rv;
 }
 
-template <int BLOCK, bool ABL = false>
+// LEV = the launch carries level-draw workgroups in front (HubParams::lev_in_env off).  The production instantiation is
+// without them: the mere presence of that path costs the slot path 2 % (register allocation is per kernel).
+template <int BLOCK, bool ABL = false, bool LEV = true>
 __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa, uint32_t nb0,
                                                           uint32_t nb_lev) {
     __shared__ float lds_f[5 * BLOCK];
@@ -1019,7 +1021,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restri
     __shared__ int s_acc[BLOCK];                 // upb <= BLOCK / 4 units x {min, charge, max power, cars}
     const HubParams &hp = ctx->hp;
     uint32_t bid = blockIdx.x;
-    if (bid < nb_lev) {  // next step's station-level draws, one lane per (station, env): see k_slot
+    if (LEV && bid < nb_lev) {  // next step's station-level draws, one lane per (station, env): see k_slot
         const int64_t u = (int64_t) bid * BLOCK + threadIdx.x;
         const int64_t N = hp.n_envs;
         if (u < 2 * N && !(hp.ablate & 16)) {
@@ -1029,7 +1031,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restri
         }
         return;
     }
-    bid -= nb_lev;
+    if (LEV) bid -= nb_lev;
     const int k = (bid >= nb0) ? 1 : 0;
     const uint32_t bl = k ? bid - nb0 : bid;
     if (pa.S[k] == 0) {
@@ -1930,6 +1932,7 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             else if (hp.slot_block == 128) hipExtLaunchKernelGGL((k_slot_packed<128>), grid, dim3(128), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
             else if (hp.slot_block == 512) hipExtLaunchKernelGGL((k_slot_packed<512>), grid, dim3(512), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
             else if (hp.ablate) hipExtLaunchKernelGGL((k_slot_packed<256, true>), grid, dim3(256), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
+            else if (nbl == 0) hipExtLaunchKernelGGL((k_slot_packed<256, false, false>), grid, dim3(256), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
             else hipExtLaunchKernelGGL((k_slot_packed<256>), grid, dim3(256), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
         } else if (hp.slot_block == 512) launch_slot_t<false, MODE_PHILOX, 512, false>(hp, ctx, sa, stream, ev0, ev1);
         else if (hp.slot_block == 128) launch_slot_t<false, MODE_PHILOX, 128, false>(hp, ctx, sa, stream, ev0, ev1);

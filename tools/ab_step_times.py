@@ -7,7 +7,7 @@ sys.path.insert(0, ".")
 import torch
 import charginghub_env_amd as chub
 n=65536
-for perm in (0.01, 0.05):
+for perm in (0.01,):
     kw = dict(station_list=[20,25], station_type_list=["fast","slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=perm)
     v = chub.VecChargingHub(n, seed=1, **kw)
     dev = torch.device("cuda", 0)
