@@ -824,8 +824,6 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         pk_in = CHUB_AT(uint64_t, pa.pk, sidx << 3);
         lm = CHUB_AT(const u32x4, pa.lane_map[k], (uint32_t) tid << 4);
     }
-    // all five requests are out before the first use of any of them (one memory round trip, not two)
-    asm volatile("" : "+v"(hot), "+v"(act), "+v"(line_in), "+v"(pk_in), "+v"(lm));
     uint32_t *q_cnt = lds_u;                   // [1]  new cars | charging cars << 16
     uint32_t *q_new = lds_u + 2;               // [BLOCK]  tid of the admitted lane
     uint32_t *q_chg = lds_u + 2 + BLOCK;       // [BLOCK]  tid of the charging lane
@@ -837,6 +835,9 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
     float *in_tt = lds_f + 4 * BLOCK;          // [BLOCK] curve time of a charging car
     if (tid == 0) q_cnt[0] = 0;
     for (int i = tid; i < 4 * upb; i += BLOCK) s_acc[i] = 0;
+    // all five requests are out before the first use of any of them (one memory round trip, not two); the LDS clearing
+    // above sits in front of this point, i.e. inside that round trip
+    asm volatile("" : "+v"(hot), "+v"(act), "+v"(line_in), "+v"(pk_in), "+v"(lm));
 
     // ---- slot_advance (deferred form): urgency, feasibility / on-off, departure (CHS.hpp:1188-1202 / 1499-1513)
     float power = __uint_as_float(hot.x), t_target = __uint_as_float(hot.y), t_soc = __uint_as_float(hot.z);
