@@ -1,5 +1,5 @@
 // chub_device.h -- device-side data layout shared by the kernels (chub_kernels.hip) and the host
-// runtime (chub_runtime.hip).  All state lives in HBM as struct-of-arrays:
+// runtime (chub_runtime.cpp).  All state lives in HBM as struct-of-arrays:
 //
 //   per-slot arrays   [station k][env][slot]   (station-major, so that a wave covers one contiguous
 //                                               run of one station type: base_k + env*S_k + slot)

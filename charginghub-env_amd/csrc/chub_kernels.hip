@@ -1,18 +1,22 @@
 // chub_kernels.hip -- the per-step hot path of the charging-hub environment as CDNA4 (gfx950) kernels.
 //
-//   k_slot  lane = charger slot.  One (env, station) "unit" occupies H = pow2 >= S_k consecutive lanes of a
-//           64-wide wavefront (64/H units per wave); stations are processed station-major so a wave runs
-//           one charge-curve family.  Phases (reference order, CHS.hpp:1188-1207 / 1499-1518):
-//           urgency -> feasibility / on-off -> advance charging cars one slot along the curve -> departures
-//           -> arrivals (lookup, renege, balk) -> admission by wave ballot + prefix rank -> new-car draws
-//           -> urgency + the three station power sums (wave butterfly).
-//   k_env   lane = environment.  The scalar tail of step(): electrolyser clamp against the grid limit,
-//           FCEV arrivals + SAE-J2601 fueling + 15-min FIFO, electrolyser / compressor / tank, renewable
-//           netting, fuel cell, incomes and reward, done, exogenous update (PV / wind / price OU) and the
-//           normalised observation.  The J2601 breakpoints are immediates; the FCEV arrival row, the PV and
-//           wind rows of the current slot and the electrolyser action->power table are staged in LDS.
+//   k_slot_packed   lane = charger slot, PHILOX steps (production).  The workgroup's 256 lanes are laid over whole
+//           (env, station) units end to end; phases in the reference's order (CHS.hpp:1188-1207 / 1499-1518):
+//           urgency -> feasibility / on-off -> departures -> arrivals (pre-drawn levels, renege, balk) -> admission by
+//           ballot + prefix rank (across waves through LDS) -> dense car_step / add_car over LDS queues -> station sums
+//           (integer LDS atomics) -> one 16-byte station record per unit.
+//   k_slot  the same phases with wave-local units (H = pow2 >= S_k lanes each): reset, COMPAT streams, scalar-load
+//           control, stations with 1-3 piles.
+//   k_env   lane = environment.  The scalar tail of step(): electrolyser clamp against the grid limit, FCEV arrivals +
+//           SAE-J2601 fueling + 15-min FIFO, electrolyser / compressor / tank, renewable netting, fuel cell, incomes and
+//           reward, done, exogenous update (PV / wind / price OU) and the normalised observation.  The J2601 breakpoints
+//           are immediates; the PV and wind rows of the current slot and the electrolyser action->power table are staged
+//           in LDS; its last workgroups draw the next step's state-independent variates.
+//   k_step  optional: all of a PHILOX step in one launch (tail workgroups poll tagged station records).
+//   k_reset_levels, k_replay_soc, k_random_actions, k_compat_burn_fcev: small helpers (reset draws, SoC introspection,
+//           bench policy, COMPAT constructor replay).
 //
-// No MFMA: there is no dense contraction anywhere in this path; it is HBM-/FP64-VALU-bound.
+// No MFMA: there is no dense contraction anywhere in this path; by bytes it is HBM-bound, measured it is VALU-issue bound.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -211,7 +215,7 @@ __device__ __forceinline__ StationRec rec_load(CHUB_G(uint32_t) rec, uint32_t u)
     return r;
 }
 
-// DPP lane exchanges for the butterfly sums.  After the xor-1 and xor-2 steps every lane of a quad holds the quad's
+// DPP lane exchanges for the (integer) butterfly sums of the wave-local kernel.  After the xor-1 and xor-2 steps every lane of a quad holds the quad's
 // sum, so the mirror patterns (lane i <-> 7-i, i <-> 15-i) pair the same partial sums as xor 4 / xor 8 would.
 __device__ __forceinline__ int dppi_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }      // quad_perm [1,0,3,2]
 __device__ __forceinline__ int dppi_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); }      // quad_perm [2,3,0,1]

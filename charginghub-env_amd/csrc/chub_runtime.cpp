@@ -1,4 +1,4 @@
-// chub_runtime.hip -- host side of libchub.so: the C ABI of include/chub.h, table construction at
+// chub_runtime.cpp -- host side of libchub.so: the C ABI of include/chub.h, table construction at
 // create time, HBM state ownership and kernel launches.  No simulation arithmetic of the step runs on
 // the host; what does run here is init-time table building (arrival CDF parsing with the reference's
 // own parser, level thresholds, the electrolyser action->power sweep, price statistics).

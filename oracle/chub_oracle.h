@@ -68,7 +68,7 @@ typedef struct {
     float constant_power, transformer_limit;
     int slot_base; /* hub-global index of slot 0 (Philox tags) */
     int index;     /* 0/1 within the hub */
-    int exact_sums; /* 0: reference's sequential f32 sums (CHS:1244-1255); 1: f32 balanced-tree sums (PHILOX mode) */
+    int exact_sums; /* 0: reference's sequential f32 sums (CHS:1244-1255); 1: order-independent integer sums in 2^-19 kW (PHILOX mode) */
 } orc_station;
 
 typedef struct {
