@@ -18,6 +18,14 @@ TELEMETRY_NAMES = ["hy_act", "hy_flow_speed", "all_power_second", "Store_SOC", "
                    "fcev_arrive_number", "fcev_line", "fcev_queue_len", "pv_day", "wd_day"]
 
 
+class ChubOptions(C.Structure):
+    """chub_options of include/chub.h (all zero = defaults; the library reads no environment variables)"""
+    _fields_ = [("slot_kernel", C.c_int32), ("no_arena", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
+SLOT_KERNELS = {"auto": 0, "wave": 1, "packed": 2}
+
+
 class ChubError(RuntimeError):
     pass
 
@@ -35,6 +43,18 @@ def lib_path():
     return os.environ.get("CHUB_LIB") or os.path.join(_HERE, "libchub.so")
 
 
+def source_hash():
+    """the hash the Makefile compiles into chub_build_id(): sha256 over the sources, first 16 hex digits"""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    for name in ("chub_kernels.hip", "chub_runtime.cpp", "chub_comm.cpp", "chub_device.h", "chub_curves.h"):
+        h.update(open(os.path.join(csrc, name), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(_HERE), "include", "chub.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 
 
@@ -47,9 +67,17 @@ def load_library():
         raise ChubError("libchub.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "or `make -C charginghub-env_amd/csrc`; there is no CPU fallback" % path)
     lib = C.CDLL(path)
+    if not os.environ.get("CHUB_LIB"):
+        # a prebuilt library must match the sources next to it: no silent reuse of a stale build
+        lib.chub_build_id.restype = C.c_char_p
+        have, want = lib.chub_build_id().decode(), source_hash()
+        if have != want:
+            raise ChubError("libchub.so (build id %s) is older than its sources (%s): rebuild with "
+                            "`make -C charginghub-env_amd/csrc`" % (have, want))
     P, I, L = C.c_void_p, C.c_int, C.c_int64
     sig = {
         "chub_create": (I, [C.POINTER(ChubConfig), C.c_char_p, L, L, I, C.c_uint64, I, C.POINTER(P)]),
+        "chub_create_ex": (I, [C.POINTER(ChubConfig), C.c_char_p, L, L, I, C.c_uint64, I, C.POINTER(ChubOptions), C.POINTER(P)]),
         "chub_destroy": (I, [P]),
         "chub_obs_dim": (I, [P]), "chub_act_dim": (I, [P]), "chub_num_envs": (L, [P]), "chub_clock": (I, [P]),
         "chub_reset": (I, [P, P, P, P]),
@@ -62,12 +90,16 @@ def load_library():
         "chub_sync": (I, [P]),
         "chub_profile_begin": (I, [P, I, I]), "chub_profile_end": (I, [P, P, P, P]),
         "chub_get_slots": (I, [P, P]), "chub_get_station_scalars": (I, [P, P]), "chub_get_telemetry": (I, [P, P]),
-        "chub_get_obs_f64": (I, [P, P]), "chub_get_reward_f64": (I, [P, P]), "chub_set_telemetry": (I, [P, I]), "chub_fcev_overflow_count": (I, [P, P]),
+        "chub_get_obs_f64": (I, [P, P]), "chub_get_reward_f64": (I, [P, P]), "chub_set_telemetry": (I, [P, I]), "chub_fcev_stuck_count": (I, [P, P]),
         "chub_set_rng_compat_seeds": (I, [P, P]), "chub_set_rng_compat_state": (I, [P, P]),
         "chub_get_rng_compat_state": (I, [P, P]), "chub_compat_replay_constructor": (I, [P]), "chub_set_ou_state": (I, [P, P]),
         "chub_state_size": (L, [P]), "chub_get_state": (I, [P, P, L]), "chub_set_state": (I, [P, P, L]),
-        "chub_get_hy_table": (I, [P, P]), "chub_set_hy_table": (I, [P, P]),
-        "chub_last_error": (C.c_char_p, []), "chub_device_count": (I, []),
+        "chub_get_hy_table": (I, [P, P]), "chub_get_hy_table_env": (I, [P, L, P]), "chub_set_hy_table": (I, [P, P]),
+        "chub_last_error": (C.c_char_p, []), "chub_device_count": (I, []), "chub_build_id": (C.c_char_p, []),
+        "chub_comm_unique_id": (I, [P]), "chub_comm_create": (I, [P, I, I, I, C.POINTER(P)]), "chub_comm_destroy": (I, [P]),
+        "chub_comm_world": (I, [P]), "chub_comm_rank": (I, [P]), "chub_comm_gather": (I, [P, P, P, L, P]),
+        "chub_comm_max_f64": (I, [P, C.POINTER(C.c_double), P]), "chub_comm_barrier": (I, [P, P]),
+        "chub_step_gather": (I, [P, P, P, P, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here == ABI drift between chub.h and the library
@@ -77,11 +109,13 @@ def load_library():
     return lib
 
 
-EXPORTED = ["chub_create", "chub_destroy", "chub_obs_dim", "chub_act_dim", "chub_num_envs", "chub_clock", "chub_reset",
+EXPORTED = ["chub_create", "chub_create_ex", "chub_destroy", "chub_obs_dim", "chub_act_dim", "chub_num_envs", "chub_clock", "chub_reset",
             "chub_step", "chub_reset_device", "chub_step_device", "chub_step_device_packed", "chub_step_load", "chub_step_load_device", "chub_random_actions_device", "chub_sync", "chub_profile_begin", "chub_profile_end",
             "chub_get_slots", "chub_get_station_scalars", "chub_get_telemetry", "chub_get_obs_f64",
-            "chub_get_reward_f64", "chub_set_telemetry", "chub_fcev_overflow_count", "chub_set_rng_compat_seeds", "chub_set_rng_compat_state", "chub_get_rng_compat_state", "chub_compat_replay_constructor", "chub_set_ou_state",
-            "chub_state_size", "chub_get_state", "chub_set_state", "chub_get_hy_table", "chub_set_hy_table", "chub_last_error", "chub_device_count"]
+            "chub_get_reward_f64", "chub_set_telemetry", "chub_fcev_stuck_count", "chub_set_rng_compat_seeds", "chub_set_rng_compat_state", "chub_get_rng_compat_state", "chub_compat_replay_constructor", "chub_set_ou_state",
+            "chub_state_size", "chub_get_state", "chub_set_state", "chub_get_hy_table", "chub_get_hy_table_env", "chub_set_hy_table", "chub_last_error", "chub_device_count", "chub_build_id",
+            "chub_comm_unique_id", "chub_comm_create", "chub_comm_destroy", "chub_comm_world", "chub_comm_rank", "chub_comm_gather",
+            "chub_comm_max_f64", "chub_comm_barrier", "chub_step_gather"]
 
 
 def check(rc):

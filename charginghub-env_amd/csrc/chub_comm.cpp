@@ -1,0 +1,194 @@
+// chub_comm.cpp -- the multi-GPU leg of libchub.so: ONE collective per step, issued by the runtime itself.
+//
+// Environments are independent, so the path shards by contiguous global env ranges, one process per GPU, and the only
+// thing that crosses GPUs is each shard's packed step output [n_local, D+2] f32 (obs, reward, done) travelling to rank 0.
+// On the 8-GPU xGMI full mesh every peer has its own direct link into the root, so the gather is one grouped
+// ncclSend (peers) / ncclRecv x (world-1) (root): bound by one link per peer, not by a ring.  It is enqueued on the SAME
+// HIP stream as the step kernels (stream order is the only synchronisation: no host wait per step), and can be captured
+// into a hipGraph together with them.
+//
+// RCCL is loaded with dlopen when the first communicator is made: a single-GPU user of libchub never maps it, and when a
+// process already carries an RCCL (PyTorch bundles one) that copy is the one used.  The reference has no counterpart
+// (it has no distributed anything): this is the build's own design (BASELINE.json north_star).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/chub.h"
+
+// the slice of rccl.h this file uses (declared here so that the library builds without the RCCL headers in its include path
+// and binds at run time; layouts and enum values are RCCL's ABI: /opt/rocm/include/rccl/rccl.h:40-43,450,459-467)
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId;
+typedef int ncclResult_t;
+}
+enum { kNcclSuccess = 0, kNcclUint8 = 1, kNcclFloat64 = 8, kNcclMax = 2 };
+
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+Rccl g_rccl;
+
+int comm_fail(int code, const std::string &msg);
+
+bool load_rccl() {
+    if (g_rccl.handle) return true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) {
+        g_rccl.why = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "?");
+        return false;
+    }
+#define BIND(field, sym)                                                   \
+    g_rccl.field = (decltype(g_rccl.field)) dlsym(h, sym);                 \
+    if (!g_rccl.field) {                                                   \
+        g_rccl.why = std::string("RCCL lacks ") + sym;                     \
+        return false;                                                      \
+    }
+    BIND(GetUniqueId, "ncclGetUniqueId");
+    BIND(CommInitRank, "ncclCommInitRank");
+    BIND(CommDestroy, "ncclCommDestroy");
+    BIND(Send, "ncclSend");
+    BIND(Recv, "ncclRecv");
+    BIND(GroupStart, "ncclGroupStart");
+    BIND(GroupEnd, "ncclGroupEnd");
+    BIND(AllReduce, "ncclAllReduce");
+    BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+    g_rccl.handle = h;
+    return true;
+}
+}  // namespace
+
+struct chub_comm {
+    ncclComm_t comm;
+    int world, rank, device;
+    double *d_scratch;  // 1 f64 for barrier / max
+};
+
+// chub_runtime.cpp owns the thread-local error string behind chub_last_error()
+extern "C" __attribute__((visibility("hidden"))) int chub_set_last_error_(int code, const char *msg);
+namespace {
+int comm_fail(int code, const std::string &msg) { return chub_set_last_error_(code, msg.c_str()); }
+}  // namespace
+
+#define NCCL_TRY(expr)                                                                                          \
+    do {                                                                                                        \
+        ncclResult_t r_ = (expr);                                                                               \
+        if (r_ != kNcclSuccess) return comm_fail(CHUB_ERR_COMM, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+    } while (0)
+#define HIPC_TRY(expr)                                                                                 \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return comm_fail(CHUB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" {
+
+int chub_comm_unique_id(void *id128) {
+    if (!id128) return comm_fail(CHUB_ERR_ARG, "null argument");
+    if (!load_rccl()) return comm_fail(CHUB_ERR_COMM, g_rccl.why);
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(id128, id.internal, sizeof id.internal);
+    return CHUB_OK;
+}
+
+int chub_comm_create(const void *id128, int world, int rank, int device, chub_comm **out) {
+    if (!id128 || !out) return comm_fail(CHUB_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return comm_fail(CHUB_ERR_ARG, "bad world / rank");
+    if (!load_rccl()) return comm_fail(CHUB_ERR_COMM, g_rccl.why);
+    HIPC_TRY(hipSetDevice(device));
+    ncclUniqueId id;
+    memcpy(id.internal, id128, sizeof id.internal);
+    chub_comm *c = new chub_comm();
+    c->world = world;
+    c->rank = rank;
+    c->device = device;
+    c->comm = nullptr;
+    c->d_scratch = nullptr;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != kNcclSuccess) {
+        delete c;
+        return comm_fail(CHUB_ERR_COMM, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+    }
+    hipError_t he = hipMalloc((void **) &c->d_scratch, 2 * sizeof(double));
+    if (he != hipSuccess) {
+        g_rccl.CommDestroy(c->comm);
+        delete c;
+        return comm_fail(CHUB_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(he));
+    }
+    *out = c;
+    return CHUB_OK;
+}
+
+int chub_comm_destroy(chub_comm *c) {
+    if (!c) return CHUB_OK;
+    (void) hipSetDevice(c->device);
+    (void) hipDeviceSynchronize();
+    if (c->d_scratch) (void) hipFree(c->d_scratch);
+    if (c->comm) (void) g_rccl.CommDestroy(c->comm);
+    delete c;
+    return CHUB_OK;
+}
+
+int chub_comm_world(const chub_comm *c) { return c ? c->world : CHUB_ERR_ARG; }
+int chub_comm_rank(const chub_comm *c) { return c ? c->rank : CHUB_ERR_ARG; }
+
+// every rank's `bytes` at d_send -> rank 0's d_recv[rank * bytes ...]; enqueued on `stream`, returns at once
+int chub_comm_gather(chub_comm *c, const void *d_send, void *d_recv, int64_t bytes, void *stream) {
+    if (!c || !d_send || bytes <= 0) return comm_fail(CHUB_ERR_ARG, "bad argument");
+    if (c->rank == 0 && !d_recv) return comm_fail(CHUB_ERR_ARG, "rank 0 needs a receive buffer");
+    hipStream_t s = (hipStream_t) stream;
+    NCCL_TRY(g_rccl.GroupStart());
+    ncclResult_t r = g_rccl.Send(d_send, (size_t) bytes, kNcclUint8, 0, c->comm, s);
+    if (r == kNcclSuccess && c->rank == 0)
+        for (int p = 0; p < c->world && r == kNcclSuccess; p++)
+            r = g_rccl.Recv((char *) d_recv + (size_t) p * (size_t) bytes, (size_t) bytes, kNcclUint8, p, c->comm, s);
+    ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r != kNcclSuccess) return comm_fail(CHUB_ERR_COMM, std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(r));
+    NCCL_TRY(r2);
+    return CHUB_OK;
+}
+
+// max over ranks of one host double (bench timing: max-over-ranks of the timed region); synchronises the stream
+int chub_comm_max_f64(chub_comm *c, double *value, void *stream) {
+    if (!c || !value) return comm_fail(CHUB_ERR_ARG, "null argument");
+    hipStream_t s = (hipStream_t) stream;
+    HIPC_TRY(hipSetDevice(c->device));
+    HIPC_TRY(hipMemcpyAsync(c->d_scratch, value, sizeof(double), hipMemcpyHostToDevice, s));
+    NCCL_TRY(g_rccl.AllReduce(c->d_scratch, c->d_scratch + 1, 1, kNcclFloat64, kNcclMax, c->comm, s));
+    HIPC_TRY(hipMemcpyAsync(value, c->d_scratch + 1, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPC_TRY(hipStreamSynchronize(s));
+    return CHUB_OK;
+}
+
+// all ranks have reached this point and their streams have drained
+int chub_comm_barrier(chub_comm *c, void *stream) {
+    double v = 0.0;
+    return chub_comm_max_f64(c, &v, stream);
+}
+
+}  // extern "C"

@@ -24,7 +24,6 @@
 
 namespace chub {
 
-constexpr int kQCap = 16;        // FCEV FIFO capacity (the reference list is unbounded, HYD:264-265)
 constexpr int kMaxLine = 10;     // Station::max_line, CHS.hpp:197
 constexpr int kLevels = 1000;    // RandomUtil::uniform_rand has 1000 levels k/999, CHS.hpp:35-44
 constexpr int kBalkTab = 512;
@@ -64,7 +63,6 @@ struct StationArrays {       // unit index u = k*N + env
                                  // line | flow_in << 8 | car_number << 16  (Station::line, flow_in_number.back(), car_number)
     CHUB_G(uint64_t) pk[2];      // PHILOX: packed state-independent station draws of a step (double-buffered by tick
                                  // parity): bits 0-9 renege pass per queue position, 10-13 arrivals, 14+4j balk limit of arrival j
-    CHUB_G(uint32_t) grp_cnt;    // [ceil(N/64)] fused tail: finished slot workgroups per 64-env group (returns to 0)
 };
 
 struct EnvArrays {           // index = env (or field*N + env)
@@ -77,12 +75,16 @@ struct EnvArrays {           // index = env (or field*N + env)
     CHUB_G(double) price_next;   // real_state[1]
     CHUB_G(int16_t) pv_day;
     CHUB_G(int16_t) wd_day;
-    CHUB_G(uint8_t) q_len;       // FCEV FIFO length
-    CHUB_G(uint8_t) hv_line;     // HyFCEVStation.line
-    CHUB_G(uint8_t) q_overflow;
+    CHUB_G(uint8_t) q_len;       // FCEV waiting list: explicit entries (<= HubParams::qcap)
+    CHUB_G(uint8_t) hv_line;     // bits 0-6 HyFCEVStation.line, bit 7: the list is stuck (no prefix fits in 15 minutes any more,
+                                 // HYD:270-276) and its entries are folded into q_fold / q_fold_cnt
+    CHUB_G(double) q_fold;       // [N][2] folded list: sum of its times, sum of its masses, in the reference's left-to-right order
+    CHUB_G(uint32_t) q_fold_cnt; // [N]    folded list: number of entries
+    CHUB_G(double) hy_env;       // [N][102] COMPAT only: per-env hy_power_speed_list (the reference builds it with live random
+                                 // FCEV demand at construction, HYD:154-157, so it depends on the env's streams)
     CHUB_G(uint32_t) drw[2];     // [N][4] PHILOX: a step's state-independent env draws, made one launch ahead (double-buffered by
                                  // tick parity): three OU normals (f32 bits: pv, wind, price) and the FCEV arrival count
-    CHUB_G(double) q_time;       // [N][kQCap]
+    CHUB_G(double) q_time;       // [N][qcap]
     CHUB_G(double) q_mass;
     CHUB_G(double) obs64;        // [N][D]  (telemetry only)
     CHUB_G(double) reward64;     // [N]     (telemetry only)
@@ -141,14 +143,9 @@ struct HubParams {
     // correctly rounded reciprocals of the tail's run-time constant divisors (div_c in chub_kernels.hip)
     double rc_cells, rc_cap_mass, rc_vm60k, rc_price_std, rc_half_range[2];
     float hv_rate;           // f32(f32(0.3) * f32(permeate))
+    int32_t qcap;            // explicit FCEV waiting-list entries per env = max(1, 2 * (max arrivals per step) - 1)
     int32_t upb[2];          // packed slot kernel: whole units per workgroup = slot_block / S_k
-    int32_t lev_in_env;      // PHILOX: next step's station-level draws ride in the k_env launch instead of the slot launch
-    int32_t tail_lead;       // k_step: how many slot workgroups are dispatched after the tail workgroups
-    int32_t one_launch;      // PHILOX steps on the packed kernel: slot, tail and level-draw workgroups in ONE launch (k_step)
-    int32_t packed;          // PHILOX steps run k_slot_packed (both stations non-empty and at least one packs tighter)
-    int32_t slot_block;      // experiments: workgroup size of the PHILOX slot kernel (128 / 256 / 512; env CHUB_SLOT_BLOCK)
-    int32_t fused;           // PHILOX: run the per-env tail inside the slot launch (env CHUB_FUSED=0 turns it off)
-    int32_t ablate;          // timing experiments only (env CHUB_ABLATE): skips parts of k_slot, results are WRONG
+    int32_t packed;          // PHILOX steps run k_slot_packed (every station has 0 or >= 4 piles)
 };
 
 // Everything a kernel needs that does not change from step to step, kept in device memory and passed by pointer

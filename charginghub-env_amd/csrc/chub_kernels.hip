@@ -12,7 +12,6 @@
 //           reward, done, exogenous update (PV / wind / price OU) and the normalised observation.  The J2601 breakpoints
 //           are immediates; the PV and wind rows of the current slot and the electrolyser action->power table are staged
 //           in LDS; its last workgroups draw the next step's state-independent variates.
-//   k_step  optional: all of a PHILOX step in one launch (tail workgroups poll tagged station records).
 //   k_reset_levels, k_replay_soc, k_random_actions, k_compat_burn_fcev: small helpers (reset draws, SoC introspection,
 //           bench policy, COMPAT constructor replay).
 //
@@ -171,6 +170,7 @@ __device__ __forceinline__ int prefix_count(uint64_t m) {
 }
 
 constexpr int MODE_COMPAT = 0, MODE_PHILOX = 1;
+constexpr int kSlotBlock = 256;  // workgroup size of the slot kernels (the host builds lane_map for it)
 // action_to_real (MGR:384-393) switches a pile on iff (a + 1) / 2 >= 0.5 on the f32 array.  In round-to-nearest-even f32
 // that is exactly a >= -2^-25 (a + 1 rounds to 1 from -2^-25 upwards, the tie going to the even 1.0; checked against the
 // two-step form on every f32 around the threshold and a stride over all others), so one compare replaces add, mul, compare.
@@ -179,37 +179,14 @@ constexpr float kActOnThreshold = -2.98023223876953125e-8f;
 // What k_slot hands to the per-env tail for one (station, env) unit: one 16-byte record.
 struct StationRec {
     float mn, chg, mx;  // min_power, charge_power, max_power (CHS.hpp:1257-1259)
-    uint32_t pkd;       // line | flow_in << 8 | car_number << 16 | (tick & 255) << 24
+    uint32_t pkd;       // line | (flow_in & 255) << 8 | car_number << 16
 };
-// The tick tag makes the record a self-announcing granule: written by ONE 16-byte store, a reader that polls it with
-// sc1 loads knows from the tag alone that it holds this step's record (MI355X_MICROARCH.md, granule hand-off: no
-// drain, no flag, no fence on the producer's side) -- what the one-launch step (k_step) uses between its slot workgroups
-// and its tail workgroups.  The record of the step before carries the previous tag, so a stale read cannot pass.
-__device__ __forceinline__ uint32_t rec_tag(uint32_t tick) { return (tick & 255u) << 24; }
-// COHERENT = the record crosses workgroups inside one launch (fused tail): relaxed agent-scope atomics compile to
-// sc1 (write-through / L1-bypassing) accesses, the form MI355X_MICROARCH.md prescribes for in-launch hand-offs.
-template <bool COHERENT>
 __device__ __forceinline__ void rec_store(CHUB_G(uint32_t) rec, uint32_t u, float mn, float chg, float mx, uint32_t pkd) {
     u32x4 v = {__float_as_uint(mn), __float_as_uint(chg), __float_as_uint(mx), pkd};
-    CHUB_G(u32x4) p = (CHUB_G(u32x4)) (rec + 4u * u);
-    if (COHERENT) {
-        // one 16-byte write-through store (sc1).  The compiler does not count it: the caller drains vmcnt itself
-        // before signalling (fused tail hand-off).
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-    } else {
-        *p = v;
-    }
+    *((CHUB_G(u32x4)) (rec + 4u * u)) = v;
 }
-template <bool COHERENT>
 __device__ __forceinline__ StationRec rec_load(CHUB_G(uint32_t) rec, uint32_t u) {
-    CHUB_G(u32x4) p = (CHUB_G(u32x4)) (rec + 4u * u);
-    u32x4 v;
-    if (COHERENT) {
-        // one 16-byte L1-bypassing load (sc1), waited for inside the statement
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    } else {
-        v = *p;
-    }
+    const u32x4 v = *((CHUB_G(u32x4)) (rec + 4u * u));
     StationRec r;
     r.mn = __uint_as_float(v.x); r.chg = __uint_as_float(v.y); r.mx = __uint_as_float(v.z); r.pkd = v.w;
     return r;
@@ -436,7 +413,7 @@ __device__ __forceinline__ NewCar make_car(float arrive_soc, int lev, float t_ta
     return c;
 }
 
-template <int TYPE, bool RESET, int MODE, int BLOCK, bool FUSED>
+template <int TYPE, bool RESET, int MODE, int BLOCK>
 __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
                           const CompatRng &cr, const Tables &tb, const int k, const int64_t block_local,
                           float *lds_f, uint32_t *lds_u) {
@@ -488,7 +465,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         // catch_load (CHS.hpp:358-366): clamp to [min_power, max_power] of the previous calculate_output
         float load = 0.0f;
         if (unit_ok) {
-            const StationRec pr = rec_load<false>(st.rec, sidx);
+            const StationRec pr = rec_load(st.rec, sidx);
             load = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) (k ? hp.S[0] : 0)];
             if (load > pr.mx) load = pr.mx;
             else if (load < pr.mn) load = pr.mn;
@@ -533,7 +510,6 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     if (!RESET && valid)
         slot_advance<TYPE, MODE == MODE_PHILOX>(hp, sa, sl, r, idx, (uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot, cp,
                                                 on_override);
-    if (hp.ablate & 2) r.needs_step = false;  // experiment: no car_step
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): arrivals, renege, balk, admission
     const bool empty = valid && !r.car;
@@ -550,10 +526,12 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     bool adm = false;
 
     if (MODE == MODE_PHILOX) {
-        if (unit_ok && !(hp.ablate & 4)) {
+        if (unit_ok) {
             if (RESET) {
                 // evs_reset: the unit's initial occupancy was drawn by k_reset_levels, one lane per unit, just before
-                flow = (TYPE == 0) ? (int) (pk_in & 0xFFu) : (int) ((pk_in >> 8) & 0xFFu);
+                // the fast station records the raw draw, which is negative for small stations (mu - 3 < 0, CHS.hpp:1617,
+                // 832-842): assign_car then admits nobody and the queue stays empty
+                flow = (TYPE == 0) ? (int) (int8_t) (pk_in & 0xFFu) : (int) ((pk_in >> 8) & 0xFFu);
             } else {
                 // this step's station-level draws were packed by the previous launch (draw_station_levels)
                 const uint64_t pk = pk_in;
@@ -567,7 +545,6 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
             line = line + flow - assign;
             line = line < kMaxLine ? line : kMaxLine;
         }
-        if (hp.ablate & 1) assign = 0;
         adm = empty && rank < assign;
         // ---- the two expensive per-car jobs, compacted over the workgroup through LDS: car_step for the cars that
         // charge this step, add_car for the newly admitted ones.  Their lanes queue up and the queues are served
@@ -615,15 +592,7 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
             const int s_env = env_first + s_wave * upw + (s_lane >> logH);
             const int s_hub_slot = (k ? hp.S[0] : 0) + (s_lane & (H - 1));
             PhiloxCtx p2{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + s_env)};
-            U4 o;
-            if (hp.ablate & 128) {  // experiment: no Philox block per new car
-                o.v[0] = (uint32_t) src * 2654435761u;
-                o.v[1] = o.v[0] >> 7;
-                o.v[2] = o.v[0] ^ 0x55555555u;
-                o.v[3] = 0;
-            } else {
-                o = p2.block(SITE_SOC, (uint32_t) s_hub_slot, 0);  // word 0 SoC, 1 target level, 2 extra stay
-            }
+            const U4 o = p2.block(SITE_SOC, (uint32_t) s_hub_slot, 0);  // word 0 SoC, 1 target level, 2 extra stay
             // everything add_car derives from the arrival SoC is tabulated per SoC level (Tables::newcar)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const uint32_t lev = o.v[1] % 1000u;
@@ -760,11 +729,11 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
         hot.w = (uint32_t) r.tl | (r.charge ? 128u : 0u) | ((uint32_t) r.stay << 8);
         ((CHUB_G(u32x4)) sl.hot)[idx] = hot;
         // the only cold store: the arrival SoC of a new car (current SoC and target SoC are derived on demand)
-        if (adm && !(hp.ablate & 8)) sl.init_soc[idx] = nc.soc;
+        if (adm) sl.init_soc[idx] = nc.soc;
     }
     if (unit_ok && slot == 0) {
-        const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) cars << 16) | rec_tag(sa.tick);
-        rec_store<FUSED>(st.rec, sidx, r_min, r_chg, r_max, pkd);
+        const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) cars << 16);
+        rec_store(st.rec, sidx, r_min, r_chg, r_max, pkd);
     }
 }
 
@@ -791,11 +760,10 @@ struct PackedArgs {
     CHUB_G(const uint32_t) lane_map[2];
 };
 
-template <int TYPE, int BLOCK, bool ONE, bool ABL = false>
+template <int TYPE, int BLOCK>
 __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const PackedArgs &pa, const SlotArrays &sl,
                                  const Tables &tb, const int k, const uint32_t block_local, float *lds_f, uint32_t *lds_u,
                                  uint64_t *s_ball, int *s_acc) {
-    const int abl = ABL ? hp.ablate : 0;  // timing experiments (CHUB_ABLATE) run a separate instantiation
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int S = (int) pa.S[k], upb = (int) pa.upb[k];
@@ -863,7 +831,6 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         }
     }
     const bool charge = on && car;
-    if (abl & 2) needs_step = false;  // experiment: no car_step
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): arrivals, renege, balk, admission
     const bool empty = valid && !car;
@@ -877,7 +844,7 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
     const int rank = prefix_count(be & mA) + (b_prev ? cntB : 0);
     int line = (int) (line_in & 0xFFu);
     int flow = 0, assign = 0;
-    if (valid && !(abl & 4)) {
+    if (valid) {
         const uint64_t pk = pk_in;
         line = __popc((uint32_t) pk & ((1u << line) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
         const int n_in = (int) (pk >> 10) & 15;
@@ -886,7 +853,6 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         line = line + flow - assign;
         line = line < kMaxLine ? line : kMaxLine;
     }
-    if (abl & 1) assign = 0;
     const bool adm = empty && rank < assign;
     int *acc = s_acc + 4 * u;  // the unit's {min, charge, max power in 2^-19 kW, cars}
     if (car && !needs_step) {  // state final: calculate_output share (CHS.hpp:1233-1261 / 1544-1572) goes in now
@@ -977,17 +943,12 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
         h2.w = (uint32_t) tl | (charge ? 128u : 0u) | ((uint32_t) stay << 8);
         CHUB_AT(u32x4, pa.hot, idx << 4) = h2;
         // the only cold store: the arrival SoC of a new car (current SoC and target SoC are derived on demand)
-        if (adm && !(abl & 8)) CHUB_AT(float, pa.init_soc, idx << 2) = nc_soc;
+        if (adm) CHUB_AT(float, pa.init_soc, idx << 2) = nc_soc;
         if (slot == 0) {
-            const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) acc[3] << 16) | rec_tag(sa.tick);
+            const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) acc[3] << 16);
             const u32x4 rv = {__float_as_uint(fixed_to_kw(acc[0])), __float_as_uint(fixed_to_kw(acc[1])),
                               __float_as_uint(fixed_to_kw(acc[2])), pkd};
-            if (ONE) {  // read by a tail workgroup of this same launch: write-through granule
-                CHUB_G(u32x4) rp = (CHUB_G(u32x4)) ((CHUB_G(char)) pa.rec + (sidx << 4));
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(rp), "v"(rv) : "memory");
-            } else {
-                CHUB_AT(u32x4, pa.rec, sidx << 4) = rv;
-            }
+            CHUB_AT(u32x4, pa.rec, sidx << 4) = rv;
         }
     }
 #undef CHUB_AT
@@ -996,7 +957,7 @@ __device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const 
 // A station without piles still queues, reneges and balks (receive_car runs on it as on any other, CHS.hpp:1272-1316 /
 // 1583-1627; nobody is ever admitted): one lane per env advances its queue length and arrival count and writes the station
 // record (power sums and car count 0).
-template <int BLOCK, bool ONE>
+template <int BLOCK>
 __device__ __forceinline__ void empty_station_body(const StepArgs &sa, const PackedArgs &pa, const int k, const uint32_t block_local) {
     const uint32_t env = block_local * BLOCK + threadIdx.x;
     if (env >= pa.n_envs) return;
@@ -1009,42 +970,26 @@ __device__ __forceinline__ void empty_station_body(const StepArgs &sa, const Pac
     const int flow = (pa.type[k] == 0) ? n_in : (int) ((pk >> (14 + 4 * line)) & 15);
     line = line + flow;
     line = line < kMaxLine ? line : kMaxLine;
-    const u32x4 rv = {0u, 0u, 0u, (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | rec_tag(sa.tick)};
-    CHUB_G(u32x4) rp = (CHUB_G(u32x4)) pa.rec + sidx;
-    if (ONE) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(rp), "v"(rv) : "memory");
-    else *rp = rv;
+    const u32x4 rv = {0u, 0u, 0u, (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8)};
+    *((CHUB_G(u32x4)) pa.rec + sidx) = rv;
 }
 
-// LEV = the launch carries level-draw workgroups in front (HubParams::lev_in_env off).  The production instantiation is
-// without them: the mere presence of that path costs the slot path 2 % (register allocation is per kernel).
-template <int BLOCK, bool ABL = false, bool LEV = true>
-__global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa, uint32_t nb0,
-                                                          uint32_t nb_lev) {
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa, uint32_t nb0) {
     __shared__ float lds_f[5 * BLOCK];
     __shared__ uint32_t lds_u[3 * BLOCK + 2];
     __shared__ uint64_t s_ball[BLOCK / 64 + 2];  // [1 + wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
     __shared__ int s_acc[BLOCK];                 // upb <= BLOCK / 4 units x {min, charge, max power, cars}
     const HubParams &hp = ctx->hp;
-    uint32_t bid = blockIdx.x;
-    if (LEV && bid < nb_lev) {  // next step's station-level draws, one lane per (station, env): see k_slot
-        const int64_t u = (int64_t) bid * BLOCK + threadIdx.x;
-        const int64_t N = hp.n_envs;
-        if (u < 2 * N && !(hp.ablate & 16)) {
-            const int kk = u >= N ? 1 : 0;
-            ctx->st.pk[(sa.tick + 1u) & 1u][u] =
-                draw_station_levels(hp, ctx->tb, sa.tick + 1u, (sa.t + 1) % 96, kk, u - (int64_t) kk * N);
-        }
-        return;
-    }
-    if (LEV) bid -= nb_lev;
+    const uint32_t bid = blockIdx.x;
     const int k = (bid >= nb0) ? 1 : 0;
     const uint32_t bl = k ? bid - nb0 : bid;
     if (pa.S[k] == 0) {
-        empty_station_body<BLOCK, false>(sa, pa, k, bl);
+        empty_station_body<BLOCK>(sa, pa, k, bl);
         return;
     }
-    if (pa.type[k] == 0) slot_body_packed<0, BLOCK, false, ABL>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
-    else slot_body_packed<1, BLOCK, false, ABL>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
+    if (pa.type[k] == 0) slot_body_packed<0, BLOCK>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
+    else slot_body_packed<1, BLOCK>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
 }
 
 // What the tail's first loads need, by value in the kernel arguments: one scalar load at the start of the wave instead
@@ -1087,47 +1032,14 @@ __host__ __device__ inline TailArgs make_tail_args(const EnvArrays &ev, const St
     return ta;
 }
 
-template <bool RESET, int MODE, bool FUSED, bool WAIT = false, bool ABL = false>
-__device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
-                                         const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
-                                         float *s_out, const int env_block, const TailArgs &ta);
-
-// FUSED (PHILOX mode): the per-env tail runs inside this launch.  Envs are grouped by 64; every slot workgroup, once
-// all its waves have drained their stores, adds 1 to the counter of each group it covers; the workgroup whose add
-// completes a group (both stations, all their workgroups) runs the tail for those 64 envs on one wave while the rest
-// of the grid is still busy with slot work -- no second launch, no kernel boundary, and the tail's latency is hidden.
-// Hand-off per MI355X_MICROARCH.md (in-launch producer -> consumer): records are written with sc1 stores, every
-// storing wave waits vmcnt(0), workgroup barrier, ONE lane does the agent-scope atomic add; the last arriver (told by
-// the value its add returned) takes an agent acquire and reads the records with sc1 loads.
-template <bool RESET, int MODE, int BLOCK, bool FUSED>
-__global__ __launch_bounds__(BLOCK, BLOCK <= 256 ? 7 : (BLOCK == 512 ? 6 : 1)) void k_slot(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0,
-                                                int64_t nb_lev) {
+template <bool RESET, int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 7) void k_slot(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0) {
     const HubParams &hp = ctx->hp;
-    const SlotArrays &sl = ctx->sl;
-    const StationArrays &st = ctx->st;
-    const CompatRng &cr = ctx->cr;
-    const Tables &tb = ctx->tb;
-    constexpr int WAVES = BLOCK / 64;
     __shared__ float lds_f[5 * BLOCK];
     __shared__ uint32_t lds_u[3 * BLOCK + 2];
-    __shared__ int s_last[WAVES];
-    if (hp.ablate & 64) return;
     int k;
     int64_t bl;
-    int64_t bid = blockIdx.x;
-    if (MODE == MODE_PHILOX && bid < nb_lev) {
-        // the first blocks of the grid (dispatched first, so their latency hides behind the slot work): next step's
-        // station-level draws, one lane per (station, env)
-        const int64_t u = bid * BLOCK + threadIdx.x;
-        const int64_t N = hp.n_envs;
-        if (u < 2 * N && !(hp.ablate & 16)) {
-            const int kk = u >= N ? 1 : 0;
-            st.pk[(sa.tick + 1u) & 1u][u] =
-                draw_station_levels(hp, tb, sa.tick + 1u, RESET ? 0 : (sa.t + 1) % 96, kk, u - (int64_t) kk * N);
-        }
-        return;
-    }
-    bid -= nb_lev;
+    const int64_t bid = blockIdx.x;
     if (sa.station_filter >= 0) {
         k = sa.station_filter;
         bl = bid;
@@ -1135,46 +1047,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 256 ? 7 : (BLOCK == 512 ? 6 : 1)) v
         k = (bid >= nb0) ? 1 : 0;
         bl = k ? bid - nb0 : bid;
     }
-    if (hp.type[k] == 0) slot_body<0, RESET, MODE, BLOCK, FUSED>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
-    else slot_body<1, RESET, MODE, BLOCK, FUSED>(hp, sa, sl, st, cr, tb, k, bl, lds_f, lds_u);
-
-    if (FUSED) {
-        const int N = (int) hp.n_envs;
-        const int upb = WAVES * (64 >> hp.logH[k]);  // envs per workgroup of this station
-        const int e0 = (int) bl * upb;
-        const int g0 = e0 >> 6;
-        const int n_groups = (N + 63) >> 6;
-        const int ng = upb >= 64 ? upb >> 6 : 1;     // groups this workgroup covers (<= WAVES)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores (incl. the sc1 records) have landed
-        __syncthreads();
-        if ((int) threadIdx.x < ng) {
-            const int g = g0 + (int) threadIdx.x;
-            int last = 0;
-            if (g < n_groups) {
-                const int envs = N - (g << 6) < 64 ? N - (g << 6) : 64;
-                int expected = 0;
-#pragma unroll
-                for (int kk = 0; kk < 2; kk++) {
-                    const int upb_k = WAVES * (64 >> hp.logH[kk]);
-                    expected += upb_k >= 64 ? 1 : (envs + upb_k - 1) / upb_k;
-                }
-                const uint32_t old = __hip_atomic_fetch_add(st.grp_cnt + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = (int) old == expected - 1;
-                if (last) __hip_atomic_store(st.grp_cnt + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            s_last[threadIdx.x] = last;
-        }
-        __syncthreads();
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        for (int gi = wave; gi < ng; gi += WAVES) {
-            if (s_last[gi]) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const int env = ((g0 + gi) << 6) + lane;
-                env_tail<RESET, MODE, true>(ctx, sa, env, env < N, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
-                                            make_tail_args(ctx->ev, ctx->st, ctx->hp, sa));
-            }
-        }
-    }
+    if (hp.type[k] == 0) slot_body<0, RESET, MODE, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
+    else slot_body<1, RESET, MODE, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
 }
 
 // ----------------------------------------------------------------------------------------- k_env
@@ -1236,12 +1110,9 @@ __device__ __forceinline__ double ou_sample(double &state, double theta, double 
 // The per-env tail of step() / reset(), lane = env.
 constexpr int kEnvBlock = 256;  // compile-time (reading blockDim.x fetches the AQL packet)
 
-// ---- the per-env tail of step() / reset() for one env per lane.  FUSED = run at the end of k_slot by the last
-// workgroup to finish a 64-env group (station records come through sc1 loads, tables straight from L2); otherwise it is
-// the body of the stand-alone k_env (tables staged in LDS by the caller between the two phases).
-// WAIT = the tail runs in the same launch as the slot workgroups (k_step): everything that does not come from them is
-// requested up front as usual, the two station records are polled (sc1 loads) until they carry this step's tag.
-template <bool RESET, int MODE, bool FUSED, bool WAIT, bool ABL>
+// ---- the per-env tail of step() / reset() for one env per lane: the body of k_env (tables staged in LDS between the
+// load burst and the arithmetic).
+template <bool RESET, int MODE>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
                                          float *s_out, const int env_block, const TailArgs &ta) {
@@ -1251,10 +1122,10 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     const Tables &tb = ctx->tb;
     const int64_t N = hp.n_envs;
     const int t_next = RESET ? 0 : (sa.t + 1) % 96;
-#define TAB_PV(d) (FUSED ? tb.pvT[t_next * 100 + (d)] : s_pv[d])
-#define TAB_WD(d) (FUSED ? tb.wdT[t_next * 150 + (d)] : s_wd[d])
-#define TAB_HY(i) (FUSED ? tb.hy_table[i] : s_hy[i])
-#define TAB_HV(l) (FUSED ? tb.cnt_hv[sa.t * kLevels + (l)] : s_hv[l])
+#define TAB_PV(d) (s_pv[d])
+#define TAB_WD(d) (s_wd[d])
+#define TAB_HY(i) (MODE == MODE_COMPAT ? hy_env[i] : s_hy[i])
+#define TAB_HV(l) (s_hv[l])
     // ---- prefetch: every per-env input is requested before the table staging and its barrier, and the PHILOX
     // words that do not depend on state (FCEV arrival level, the three OU normals) are drawn here too, so the
     // memory latencies of this latency-bound kernel overlap instead of queueing behind one another.
@@ -1266,7 +1137,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     double sin_t = tb.sin96[t_next];  // the observation's time feature: requested here, used at the very end
     asm volatile("" : "+v"(sin_t));
     const bool tel_on = hp.telemetry != 0;
-    if (!FUSED) {
+    {
         const int i = threadIdx.x;
         if (i < 100) st_pv = tb.pvT[t_next * 100 + i];
         if (i < 150) st_wd = tb.wdT[t_next * 150 + i];
@@ -1286,8 +1157,8 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         ou_wd = ta.ou[n32 + e32];
         ou_price = ta.ou[2u * n32 + e32];
         in_price_noise = ta.price_noise[e32];
-        if (!WAIT) {
-            const StationRec r0 = rec_load<FUSED>(ta.rec, e32), r1 = rec_load<FUSED>(ta.rec, n32 + e32);
+        {
+            const StationRec r0 = rec_load(ta.rec, e32), r1 = rec_load(ta.rec, n32 + e32);
             mn0 = r0.mn; P0f = r0.chg; mx0 = r0.mx; ln0 = (int) (r0.pkd & 0xFFu); F0i = (int) (int8_t) ((r0.pkd >> 8) & 0xFFu);
             mn1 = r1.mn; P1f = r1.chg; mx1 = r1.mx; ln1 = (int) (r1.pkd & 0xFFu); F1i = (int) (int8_t) ((r1.pkd >> 8) & 0xFFu);
         }
@@ -1304,7 +1175,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             q_len = ta.q_len[e32];
             hv_line = ta.hv_line[e32];
         }
-        if (MODE == MODE_PHILOX && !RESET && !FUSED && hp.lev_in_env) {
+        if (MODE == MODE_PHILOX && !RESET) {
             // this step's state-independent env draws (three OU normals, FCEV arrival count) were made one launch ahead by
             // the level blocks of k_env (draw_env_levels): 350 dependent instructions less on this latency-bound chain
             drw_raw = ((CHUB_G(const u32x4)) ta.drw)[2u * e32];  // unpacked behind the table staging: no wait for it here
@@ -1327,8 +1198,8 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     }
 
 
-    if (!FUSED) {
-        // stand-alone kernel: the table rows requested at the top arrive with the state loads; park them in LDS
+    {
+        // the table rows requested at the top arrive with the state loads; park them in LDS
         static_assert(kEnvBlock >= 150, "one table element per lane");
         const int i = threadIdx.x;
         if (i < 100) ((double *) s_pv)[i] = st_pv;
@@ -1339,26 +1210,11 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         }
         __syncthreads();
     }
-    if (MODE == MODE_PHILOX && !RESET && !FUSED && hp.lev_in_env) {
+    if (MODE == MODE_PHILOX && !RESET) {
         z_pv = (double) __uint_as_float(drw_raw.x);
         z_wd = (double) __uint_as_float(drw_raw.y);
         z_pr = (double) __uint_as_float(drw_raw.z);
         hv_arrive = (int) drw_raw.w;
-    }
-    if (WAIT && live) {
-        // the slot workgroups of this launch write each station record with one 16-byte sc1 store that carries the step's tag
-        const uint32_t want = rec_tag(sa.tick);
-        StationRec r0, r1;
-        int spins = 0;
-        for (;;) {
-            r0 = rec_load<true>(ta.rec, e32);
-            r1 = rec_load<true>(ta.rec, n32 + e32);
-            if (((r0.pkd & 0xFF000000u) == want && (r1.pkd & 0xFF000000u) == want) || ++spins > (1 << 22)) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-        if (spins > (1 << 22)) ev.q_overflow[e32] = 2;  // never seen: gives up loudly (chub_fcev_overflow_count counts it) instead of hanging
-        mn0 = r0.mn; P0f = r0.chg; mx0 = r0.mx; ln0 = (int) (r0.pkd & 0xFFu); F0i = (int) (int8_t) ((r0.pkd >> 8) & 0xFFu);
-        mn1 = r1.mn; P1f = r1.chg; mx1 = r1.mx; ln1 = (int) (r1.pkd & 0xFFu); F1i = (int) (int8_t) ((r1.pkd >> 8) & 0xFFu);
     }
     // stand-alone kernel: output rows go through LDS so that the workgroup writes its kEnvBlock consecutive rows (one
     // contiguous run of memory) with coalesced stores instead of 15 scattered 4-byte stores per lane
@@ -1377,6 +1233,8 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 
     CompatStream rs;
     if (MODE == MODE_COMPAT && !RESET) rs.load(cr, env);
+    const double *hy_env = MODE == MODE_COMPAT ? (const double *) ev.hy_env + (size_t) e32 * 102u : nullptr;
+    (void) hy_env;
 
     const double cap_mass = hp.cap_mass;
     double store_soc, reward = 0.0;
@@ -1417,15 +1275,23 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             // hy_power_speed_list_input[ind - 1]; python index -1 wraps to the last entry (1.0)
             act_el = (ind >= 102 || ind == 0) ? 0.01 * 100 : 0.01 * (ind - 1);
         }
-        // ---- hvs_step (HYD:253-285): FCEV arrivals -> J2601 -> 15-minute FIFO
-        double *qt = (double *) ev.q_time + (size_t) e32 * kQCap, *qm = (double *) ev.q_mass + (size_t) e32 * kQCap;
+        // ---- hvs_step (HYD:253-285): FCEV arrivals -> J2601 -> 15-minute FIFO.  The reference's waiting list is unbounded.
+        // Here: up to hp.qcap explicit entries, which is all a list that still gets served can hold (after a partial serve
+        // it keeps at most arrive - 1 of the step's arrivals, HYD:270-279), plus -- once no prefix fits any more (nobody is
+        // served again until reset) -- a folded tail: entry count and the running sums of time and mass in
+        // the reference's left-to-right order, so that sum(needed_time_list) / sum(needed_hy_list) stay bit-identical.
+        const int qcap = hp.qcap;
+        double *qt = (double *) ev.q_time + (size_t) e32 * (size_t) qcap, *qm = (double *) ev.q_mass + (size_t) e32 * (size_t) qcap;
         if (MODE == MODE_COMPAT) hv_lev = rs.level();
         const int arrive = MODE == MODE_COMPAT ? (int) TAB_HV(hv_lev) : hv_arrive;
         double total_mass = 0.0;
-        const bool fcev_pre = MODE == MODE_PHILOX && !RESET && !FUSED && hp.lev_in_env;
+        const bool fcev_pre = MODE == MODE_PHILOX && !RESET;
         const double pre_tn = __hiloint2double((int) drw_fcev.y, (int) drw_fcev.x);
         const double pre_mn = __hiloint2double((int) drw_fcev.w, (int) drw_fcev.z);
-        if (fcev_pre && q_len == 0 && arrive == 1 && pre_tn <= 15.0) {
+        bool stuck = (hv_line & 128) != 0;
+        hv_line &= 127;
+        uint32_t fold_n = 0;
+        if (fcev_pre && q_len == 0 && !stuck && arrive == 1 && pre_tn <= 15.0) {
             // the common case by far: an empty FIFO, one arrival, served within the slot (hvs_step leaves the FIFO empty and
             // the line at 0, HYD:281-283) -- nothing to read from or write to the queue arrays
             total_mass = pre_mn;
@@ -1433,8 +1299,13 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
                 ev.hv_line[e32] = 0;
                 hv_line = 0;
             }
-        } else if (q_len > 0 || arrive > 0) {
+        } else if (q_len > 0 || stuck || arrive > 0) {
             double total_time = 0.0;
+            if (stuck) {  // q_len == 0: everything is folded
+                total_time = ev.q_fold[2u * e32];
+                total_mass = ev.q_fold[2u * e32 + 1u];
+                fold_n = ev.q_fold_cnt[e32];
+            }
             for (int i = 0; i < q_len; i++) {
                 total_time += qt[i];
                 total_mass += qm[i];
@@ -1452,49 +1323,61 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
                     else socf = soc_from_word(tb.soc_d_icdf, px.block(SITE_HVSOC, (uint32_t) j, 0).v[0]);
                     fcev_time_mass(socf, tn, mn);
                 }
-                if (q_len < kQCap) {
+                if (stuck) {
+                    fold_n++;
+                } else if (q_len < qcap) {  // always (qcap = 2 * max arrivals per step - 1, chub_create)
                     qt[q_len] = tn;
                     qm[q_len] = mn;
                     q_len++;
-                    total_time += tn;
-                    total_mass += mn;
-                } else {
-                    ev.q_overflow[e32] = 1;
                 }
+                total_time += tn;
+                total_mass += mn;
             }
             int hv_num = 0;
             if (total_time > 15.0) {
-                for (int i = 1; i <= arrive - 1; i++) {
-                    int keep = q_len - i;
-                    keep = keep < 0 ? 0 : keep;
-                    double part = 0.0;
-                    for (int j = 0; j < keep; j++) part += qt[j];
-                    if (part <= 15.0) {
-                        hv_line = i;
-                        hv_num = keep;
-                        break;
+                bool found = false;
+                if (!stuck) {
+                    for (int i = 1; i <= arrive - 1; i++) {
+                        int keep = q_len - i;
+                        keep = keep < 0 ? 0 : keep;
+                        double part = 0.0;
+                        for (int j = 0; j < keep; j++) part += qt[j];
+                        if (part <= 15.0) {
+                            hv_line = i;
+                            hv_num = keep;
+                            found = true;
+                            break;
+                        }
                     }
                 }
-                for (int j = hv_num; j < q_len; j++) {
-                    qt[j - hv_num] = qt[j];
-                    qm[j - hv_num] = qm[j];
+                if (found) {
+                    for (int j = hv_num; j < q_len; j++) {
+                        qt[j - hv_num] = qt[j];
+                        qm[j - hv_num] = qm[j];
+                    }
+                    q_len -= hv_num;
+                } else {
+                    // no prefix fits: the list only grows from here on (every later prefix contains this one), so its entries
+                    // are never looked at one by one again -- fold them
+                    fold_n += (uint32_t) q_len;
+                    q_len = 0;
+                    stuck = true;
+                    ev.q_fold[2u * e32] = total_time;
+                    ev.q_fold[2u * e32 + 1u] = total_mass;
+                    ev.q_fold_cnt[e32] = fold_n;
                 }
-                q_len -= hv_num;
             } else {
                 hv_line = 0;
                 q_len = 0;
             }
             ev.q_len[e32] = (uint8_t) q_len;
-            ev.hv_line[e32] = (uint8_t) hv_line;
+            ev.hv_line[e32] = (uint8_t) (hv_line | (stuck ? 128 : 0));
         } else if (hv_line != 0) {
             ev.hv_line[e32] = 0;  // empty FIFO, no arrivals: total time 0 <= 15 -> line = 0 (HYD:281-283)
             hv_line = 0;
         }
         const double total_mass_need = total_mass;
-        if (ABL && (hp.ablate & 4096)) {  // experiment: skip the H2 / money chain
-            store_soc = div_c(cap, cap_mass, hp.rc_cap_mass);
-            reward = total_mass + act_el;
-        } else {
+        {
         // ---- hy_step (HYD:160-195): production clamp, electrolyser + compressor power, tank
         double must_chg = cap_mass * 0.1 - cap;
         must_chg = must_chg > 0 ? must_chg : 0.0;
@@ -1587,7 +1470,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             CHUB_TEL(5, total_mass_need); CHUB_TEL(6, hy_use); CHUB_TEL(7, not_meet); CHUB_TEL(8, fc_power);
             CHUB_TEL(9, hy_to_use); CHUB_TEL(10, used_renew); CHUB_TEL(13, hydrogen_power);
             CHUB_TEL(14, income_hys + income_evs + income_evs_serve + hy_cost); CHUB_TEL(15, reward);
-            CHUB_TEL(19, (double) arrive); CHUB_TEL(20, (double) hv_line); CHUB_TEL(21, (double) q_len);
+            CHUB_TEL(19, (double) arrive); CHUB_TEL(20, (double) hv_line); CHUB_TEL(21, (double) q_len + (double) fold_n);
         }
         }
     }
@@ -1619,7 +1502,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     if (MODE == MODE_COMPAT && !RESET) rs.store(cr, env);
 
     // state_norm (MGR:318-342), written straight to the output row
-    float *obs = FUSED ? sa.obs + (size_t) e32 * (size_t) sa.obs_stride : s_out + (int) threadIdx.x * row_w;
+    float *obs = s_out + (int) threadIdx.x * row_w;
     double *o64 = tel_on ? (double *) ev.obs64 + (size_t) e32 * hp.obs_dim : nullptr;
     int n = 0;
 #define CHUB_OBS(v)                    \
@@ -1651,7 +1534,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 #undef CHUB_OBS
     if (!RESET) {
         const bool dn = (sa.t + 1) >= 96;  // MGR:271-273
-        if (!FUSED && sa.done_f32) {  // packed row: reward and done ride in the same LDS row
+        if (sa.done_f32) {  // packed row: reward and done ride in the same LDS row
             obs[n] = (float) reward;
             obs[n + 1] = dn ? 1.0f : 0.0f;
         } else {
@@ -1666,7 +1549,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         CHUB_TEL(22, (double) pv_day); CHUB_TEL(23, (double) wd_day);
     }
     } while (0);
-    if (!FUSED) flush_rows();
+    flush_rows();
 #undef TAB_PV
 #undef TAB_WD
 #undef TAB_HY
@@ -1705,94 +1588,131 @@ __device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, cons
     }
 }
 
-template <bool RESET, int MODE, bool ABL = false>
+template <bool RESET, int MODE>
 __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, TailArgs ta, int nb_env) {
     __shared__ double s_pv[100], s_wd[150], s_hy[102];
     __shared__ __attribute__((aligned(16))) uint8_t s_hv[kLevels];
     __shared__ float s_out[kEnvBlock * 16];  // output rows: obs_dim + 2 <= 15 floats
     if (MODE == MODE_PHILOX && (int) blockIdx.x >= nb_env) {
-        // the last blocks of the grid (HubParams::lev_in_env): next step's station-level draws, one lane per (station, env).
+        // the last blocks of the grid: next step's station-level draws, one lane per (station, env).
         // They are pure VALU work and fill the issue slots the latency-bound tail waves leave empty.
-        if (ABL && (ctx->hp.ablate & 16)) return;  // experiment: no level draws
         level_block(ctx, sa, (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x, RESET ? 0 : (sa.t + 1) % 96);
         return;
     }
     const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
-    env_tail<RESET, MODE, false, false, ABL>(ctx, sa, env, env < (int) ta.n_envs && !(ABL && (ctx->hp.ablate & 32)), s_pv, s_wd, s_hy,
-                                             s_hv, s_out, (int) blockIdx.x, ta);
+    env_tail<RESET, MODE>(ctx, sa, env, env < (int) ta.n_envs, s_pv, s_wd, s_hy, s_hv, s_out, (int) blockIdx.x, ta);
 }
 
-// One launch per PHILOX step (HubParams::one_launch): [slot workgroups | tail workgroups | level-draw workgroups].  The tail
-// workgroups sit behind all slot workgroups in the grid; each requests its envs' state, stages the tables, and then
-// polls its envs' two station records until they carry this step's tag (the slot workgroups write them as 16-byte sc1
-// granules), so the tail's load burst and the kernel boundary in front of it disappear behind the slot work.  The
-// level-draw workgroups come last and fill the issue slots of the tail phase.  Tail workgroups are a small fraction of
-// the chip's wave slots and every poll loop is bounded, so no dispatch order can stall the grid.
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 8) void k_step(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa, TailArgs ta, uint32_t nb0,
-                                                   uint32_t nb_slot, uint32_t nb_env, uint32_t tail_at) {
-    static_assert(BLOCK == kEnvBlock, "tail rows are flushed per kEnvBlock envs");
-    // the two roles' LDS needs overlap (a workgroup has one role)
-    __shared__ __attribute__((aligned(16))) char lds_raw[(kEnvBlock * 16) * 4 + (100 + 150 + 102) * 8];
+// COMPAT only: HySystem.__init__ (HYD:154-158) builds hy_power_speed_list with 101 REAL hy_step()s from the initial tank:
+// each draws the FCEV arrival level and one mk_soc per arrival from the env's two streams (HYD:250-259), serves the
+// 15-minute FIFO, clamps the production against the tank and moves the tank; entry i is the electrolyser + compressor
+// power at request 0.01 * i.  Then hy_reset().  One lane per env replays exactly that: the streams advance by what the
+// reference's constructor consumes and the table comes out as the reference's (it depends on the draws whenever a tank
+// clamp binds).  Same operations as the step's tail (env_tail), plain f64 divisions.
+__global__ void k_compat_ctor_sweep(const DevCtx *__restrict__ ctx) {
     const HubParams &hp = ctx->hp;
-    // grid order: slot workgroups [0, tail_at) | tail workgroups | the remaining slot workgroups | level-draw workgroups.
-    // The tail workgroups are dispatched a few microseconds of slot work before the end, so their requests are back
-    // and their tables staged when the last station records arrive.
-    uint32_t bid = blockIdx.x;
-    bool tail_role = false;
-    if (bid >= tail_at && bid < tail_at + nb_env) {
-        tail_role = true;
-        bid -= tail_at;
-    } else if (bid >= tail_at + nb_env && bid < nb_slot + nb_env) {
-        bid -= nb_env;
-    }
-    if (!tail_role && bid < nb_slot) {
-        float *lds_f = (float *) lds_raw;                              // [5 * BLOCK]
-        uint32_t *lds_u = (uint32_t *) (lds_raw + 5 * BLOCK * 4);      // [3 * BLOCK + 2]
-        uint64_t *s_ball = (uint64_t *) (lds_raw + 8 * BLOCK * 4 + 16);  // [BLOCK / 64 + 2]
-        int *s_acc = (int *) (lds_raw + 8 * BLOCK * 4 + 16 + (BLOCK / 64 + 2) * 8);  // [BLOCK]
-        const int k = (bid >= nb0) ? 1 : 0;
-        const uint32_t bl = k ? bid - nb0 : bid;
-        if (pa.S[k] == 0) {
-            empty_station_body<BLOCK, true>(sa, pa, k, bl);
-            return;
-        }
-        if (pa.type[k] == 0) slot_body_packed<0, BLOCK, true>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
-        else slot_body_packed<1, BLOCK, true>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
-        return;
-    }
-    if (tail_role) {
-        __builtin_amdgcn_s_setprio(3);  // the launch ends with this chain: ahead of the level-draw waves at the issue ports
-        float *s_out = (float *) lds_raw;                              // [kEnvBlock * 16]
-        double *s_pv = (double *) (lds_raw + kEnvBlock * 16 * 4);      // [100], then wd [150], hy [102]
-        double *s_wd = s_pv + 100, *s_hy = s_wd + 150;
-        const int eb = (int) bid;
-        const int env = eb * kEnvBlock + (int) threadIdx.x;
-        env_tail<false, MODE_PHILOX, false, true>(ctx, sa, env, env < (int) hp.n_envs, s_pv, s_wd, s_hy, nullptr, s_out, eb, ta);
-        return;
-    }
-    if (hp.ablate & 16) return;  // experiment: no level draws
-    level_block(ctx, sa, (int64_t) (bid - nb_slot - nb_env) * kEnvBlock + threadIdx.x, (sa.t + 1) % 96);
-}
-
-// COMPAT only: the reference's constructor consumes draws of the two streams before the first user-visible
-// reset(): HySystem.__init__ runs 101 real hy_step()s (HYD:154), each drawing the FCEV arrival level and one
-// mk_soc per arrival (HYD:250-259).  This kernel advances the streams by exactly those draws.
-__global__ void k_compat_burn_fcev(const DevCtx *__restrict__ ctx, int n_steps) {
+    const EnvArrays &ev = ctx->ev;
+    const Tables &tb = ctx->tb;
     const int64_t env = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= ctx->hp.n_envs) return;
+    if (env >= hp.n_envs) return;
     CompatStream rs;
     rs.load(ctx->cr, env);
-    for (int i = 0; i < n_steps; i++) {
-        const int t = i % 96;
-        const int arrive = (int) ctx->tb.cnt_hv[t * kLevels + rs.level()];
-        for (int j = 0; j < arrive; j++) (void) rs.normal_d(7.0, 3.0);
+    const int qcap = hp.qcap;
+    double *qt = (double *) ev.q_time + (size_t) env * (size_t) qcap, *qm = (double *) ev.q_mass + (size_t) env * (size_t) qcap;
+    double *table = (double *) ev.hy_env + (size_t) env * 102u;
+    const double cap_mass = hp.cap_mass;
+    double cap = hp.init_soc * cap_mass;  // HyStore.__init__ (HYD:99-100)
+    int q_len = 0;
+    bool stuck = false;
+    double fold_t = 0.0, fold_m = 0.0;
+    for (int i = 0; i < 101; i++) {
+        const int t = i % 96;  // sys_time (HYD:192-193)
+        // hvs_step (HYD:253-285)
+        const int arrive = (int) tb.cnt_hv[t * kLevels + rs.level()];
+        double total_time = stuck ? fold_t : 0.0, total_mass = stuck ? fold_m : 0.0;
+        for (int q = 0; q < q_len; q++) {
+            total_time += qt[q];
+            total_mass += qm[q];
+        }
+        for (int j = 0; j < arrive; j++) {
+            double tn, mn;
+            fcev_time_mass(arrive_soc_from(rs.normal_d(7.0, 3.0)), tn, mn);
+            if (!stuck && q_len < qcap) {
+                qt[q_len] = tn;
+                qm[q_len] = mn;
+                q_len++;
+            }
+            total_time += tn;
+            total_mass += mn;
+        }
+        if (total_time > 15.0) {
+            int hv_num = 0;
+            bool found = false;
+            if (!stuck) {
+                for (int a = 1; a <= arrive - 1 && !found; a++) {
+                    int keep = q_len - a;
+                    keep = keep < 0 ? 0 : keep;
+                    double part = 0.0;
+                    for (int j = 0; j < keep; j++) part += qt[j];
+                    if (part <= 15.0) {
+                        hv_num = keep;
+                        found = true;
+                    }
+                }
+            }
+            if (found) {
+                for (int j = hv_num; j < q_len; j++) {
+                    qt[j - hv_num] = qt[j];
+                    qm[j - hv_num] = qm[j];
+                }
+                q_len -= hv_num;
+            } else {
+                stuck = true;
+                q_len = 0;
+                fold_t = total_time;
+                fold_m = total_mass;
+            }
+        } else {
+            q_len = 0;
+        }
+        // hy_step (HYD:160-195) at gen_speed = 0.01 * i
+        const double gen_speed = 0.01 * i;
+        double must_chg = cap_mass * 0.1 - cap;
+        must_chg = must_chg > 0 ? must_chg : 0.0;
+        double upper_charge = cap_mass - cap;
+        upper_charge = upper_charge > 0 ? upper_charge : 0.0;
+        double charge_temp = gen_speed * hp.v_h_max * (15 * 60);
+        charge_temp = charge_temp < upper_charge ? charge_temp : upper_charge;
+        charge_temp = charge_temp > must_chg ? charge_temp : must_chg;
+        double flow = charge_temp / (15 * 60);
+        flow = flow < hp.v_h_max ? flow : hp.v_h_max;
+        double ele_power = 0.0;
+        if (hp.cells != 0.0) {  // Electrolyser.get_power, HYD:38-48
+            const double v_H_mass = flow / hp.cells;
+            const double v_H_mol = v_H_mass / 2.02;
+            const double v_H_L = v_H_mol * hp.v_M;
+            const double v_H = v_H_L * 1000 * 60;
+            const double temp = v_H * 2 * 96487 / (hp.v_M * 1000 * 60);
+            const double power = temp * temp * 0.326 + temp * 1.476;
+            ele_power = hp.cells * power / 1000;
+        }
+        const double cpr_power = ((flow / 2.02) * hp.cpr_w12 / 0.8) / 1000;  // Compressor.generate_W, HYD:74-82
+        // sty_step (HYD:104-126)
+        cap += flow * 15 * 60;
+        double lower_change = cap - 0.1 * cap_mass;
+        lower_change = lower_change > 0 ? lower_change : 0.0;
+        const double hy_use = total_mass < lower_change ? total_mass : lower_change;
+        cap -= hy_use;
+        cap -= cap * hp.hydro_loss;
+        table[i] = ele_power + cpr_power;
     }
+    table[101] = table[100];
     rs.store(ctx->cr, env);
+    // hy_reset (HYD:197-208): the step state is re-initialised by chub_reset; the FIFO arrays were scratch here
 }
 
-void launch_compat_burn_fcev(const HubParams &hp, const DevCtx *ctx, int n_steps, hipStream_t stream) {
-    hipLaunchKernelGGL(k_compat_burn_fcev, dim3((unsigned) ((hp.n_envs + 63) / 64)), dim3(64), 0, stream, ctx, n_steps);
+void launch_compat_ctor_sweep(const HubParams &hp, const DevCtx *ctx, hipStream_t stream) {
+    hipLaunchKernelGGL(k_compat_ctor_sweep, dim3((unsigned) ((hp.n_envs + 63) / 64)), dim3(64), 0, stream, ctx);
 }
 
 // -------------------------------------------------------------------- random policy (bench / tests)
@@ -1862,7 +1782,7 @@ __global__ void k_reset_levels(const DevCtx *__restrict__ ctx, uint32_t tick) {
         const int thr = (int) tb.thr_balk[j < kBalkTab ? j : kBalkTab - 1];
         true_in += ((int) (pick(b, wi & 3) % 1000u) <= thr && j <= S) ? 1 : 0;
     }
-    ctx->st.pk[tick & 1u][u] = (uint64_t) ((uint32_t) (n_in < 0 ? 0 : n_in) | ((uint32_t) true_in << 8));
+    ctx->st.pk[tick & 1u][u] = (uint64_t) (((uint32_t) n_in & 0xFFu) | ((uint32_t) true_in << 8));  // n_in: signed byte
 }
 
 // ------------------------------------------------------------------------------------- launchers
@@ -1873,35 +1793,28 @@ static inline int64_t blocks_for(int64_t n_envs, int H, int block) {
 
 // ev0 / ev1 (may be null): kernel start / stop timestamps of the dispatch itself (hipExtLaunchKernelGGL), what
 // chub_profile_* reports -- plain hipEventRecord pairs around a launch also count the gap in front of it
-template <bool RESET, int MODE, int BLOCK, bool FUSED>
+template <bool RESET, int MODE>
 static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
                           hipEvent_t ev1) {
+    constexpr int BLOCK = 256;
     const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
     if (MODE == MODE_PHILOX) {
         if (RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa.tick);
-        const int64_t nbl = (hp.lev_in_env && !FUSED) ? 0 : (2 * hp.n_envs + BLOCK - 1) / BLOCK;  // + next step's station-level draws
-        hipExtLaunchKernelGGL((k_slot<RESET, MODE, BLOCK, FUSED>), dim3((unsigned) (nb0 + nb1 + nbl)), dim3(BLOCK), 0, stream,
-                              ev0, ev1, 0, ctx, sa, nb0, nbl);
+        hipExtLaunchKernelGGL((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), 0, stream, ev0, ev1, 0, ctx, sa, nb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
             StepArgs s2 = sa;
             s2.station_filter = k;
-            hipExtLaunchKernelGGL((k_slot<RESET, MODE, BLOCK, false>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), 0, stream,
-                                  k == 0 ? ev0 : nullptr, k == 1 ? ev1 : nullptr, 0, ctx, s2, nb0, (int64_t) 0);
+            hipExtLaunchKernelGGL((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), 0, stream,
+                                  k == 0 ? ev0 : nullptr, k == 1 ? ev1 : nullptr, 0, ctx, s2, nb0);
         }
     }
 }
 
-// returns true when the per-env tail ran inside the slot launch (no k_env needed)
-bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
+void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
                  const PackedPtrs &pp, hipEvent_t ev0, hipEvent_t ev1) {
     if (hp.rng_mode == MODE_PHILOX) {
-        if (hp.fused) {
-            if (reset) launch_slot_t<true, MODE_PHILOX, 256, true>(hp, ctx, sa, stream, ev0, ev1);
-            else launch_slot_t<false, MODE_PHILOX, 256, true>(hp, ctx, sa, stream, ev0, ev1);
-            return true;
-        }
-        if (reset) launch_slot_t<true, MODE_PHILOX, 256, false>(hp, ctx, sa, stream, ev0, ev1);
+        if (reset) launch_slot_t<true, MODE_PHILOX>(hp, ctx, sa, stream, ev0, ev1);
         else if (hp.packed && !sa.load_mode) {
             PackedArgs pa;
             for (int k = 0; k < 2; k++) {
@@ -1921,42 +1834,22 @@ bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             pa.init_soc = (CHUB_G(float)) pp.init_soc;
             const uint32_t nb0 = (uint32_t) ((hp.n_envs + hp.upb[0] - 1) / hp.upb[0]);
             const uint32_t nb1 = (uint32_t) ((hp.n_envs + hp.upb[1] - 1) / hp.upb[1]);
-            const uint32_t nbl = hp.lev_in_env ? 0u : (uint32_t) ((2 * hp.n_envs + hp.slot_block - 1) / hp.slot_block);
-            if (hp.one_launch && hp.slot_block == kEnvBlock) {
-                const uint32_t nb_env = (uint32_t) ((hp.n_envs + kEnvBlock - 1) / kEnvBlock);
-                const uint32_t nb_lev3 = (uint32_t) ((3 * hp.n_envs + kEnvBlock - 1) / kEnvBlock);
-                const uint32_t nb_slot = nb0 + nb1;
-                const uint32_t lead = (uint32_t) hp.tail_lead;  // slot workgroups dispatched after the tail workgroups
-                const uint32_t tail_at = nb_slot > lead ? nb_slot - lead : 0u;
-                hipExtLaunchKernelGGL((k_step<kEnvBlock>), dim3(nb_slot + nb_env + nb_lev3), dim3(kEnvBlock), 0, stream, ev0, ev1,
-                                      0, ctx, sa, pa, make_tail_args(*pp.ev, *pp.st, hp, sa), nb0, nb_slot, nb_env, tail_at);
-                return true;  // the tail ran in this launch
-            }
-            const dim3 grid(nb0 + nb1 + nbl);
-            if (hp.slot_block == 192) hipExtLaunchKernelGGL((k_slot_packed<192>), grid, dim3(192), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
-            else if (hp.slot_block == 128) hipExtLaunchKernelGGL((k_slot_packed<128>), grid, dim3(128), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
-            else if (hp.slot_block == 512) hipExtLaunchKernelGGL((k_slot_packed<512>), grid, dim3(512), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
-            else if (hp.ablate) hipExtLaunchKernelGGL((k_slot_packed<256, true>), grid, dim3(256), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
-            else if (nbl == 0) hipExtLaunchKernelGGL((k_slot_packed<256, false, false>), grid, dim3(256), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
-            else hipExtLaunchKernelGGL((k_slot_packed<256>), grid, dim3(256), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0, nbl);
-        } else if (hp.slot_block == 512) launch_slot_t<false, MODE_PHILOX, 512, false>(hp, ctx, sa, stream, ev0, ev1);
-        else if (hp.slot_block == 128) launch_slot_t<false, MODE_PHILOX, 128, false>(hp, ctx, sa, stream, ev0, ev1);
-        else launch_slot_t<false, MODE_PHILOX, 256, false>(hp, ctx, sa, stream, ev0, ev1);
-        return false;
+            hipExtLaunchKernelGGL((k_slot_packed<kSlotBlock>), dim3(nb0 + nb1), dim3(kSlotBlock), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0);
+        } else launch_slot_t<false, MODE_PHILOX>(hp, ctx, sa, stream, ev0, ev1);
+        return;
     }
-    if (reset) launch_slot_t<true, MODE_COMPAT, 256, false>(hp, ctx, sa, stream, ev0, ev1);
-    else launch_slot_t<false, MODE_COMPAT, 256, false>(hp, ctx, sa, stream, ev0, ev1);
-    return false;
+    if (reset) launch_slot_t<true, MODE_COMPAT>(hp, ctx, sa, stream, ev0, ev1);
+    else launch_slot_t<false, MODE_COMPAT>(hp, ctx, sa, stream, ev0, ev1);
 }
 
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
                 hipEvent_t ev1, const PackedPtrs &pp) {
     const TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa);
-    const int nb_env = (int) ((hp.n_envs + 255) / 256);
+    const int nb_env = (int) ((hp.n_envs + kEnvBlock - 1) / kEnvBlock);
     if (hp.rng_mode == MODE_PHILOX) {
-        const unsigned nb = (unsigned) nb_env + ((hp.lev_in_env && !hp.fused) ? (unsigned) ((3 * hp.n_envs + kEnvBlock - 1) / kEnvBlock) : 0u);
+        // + the level-draw workgroups: next step's state-independent variates (3 lanes per env: two stations, one env)
+        const unsigned nb = (unsigned) nb_env + (unsigned) ((3 * hp.n_envs + kEnvBlock - 1) / kEnvBlock);
         if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
-        else if (hp.ablate) hipExtLaunchKernelGGL((k_env<false, MODE_PHILOX, true>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
         else hipExtLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
     } else {
         if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);

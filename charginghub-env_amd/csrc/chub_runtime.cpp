@@ -16,13 +16,13 @@
 #include "chub_device.h"
 
 namespace chub {
-bool launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
+void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
                  const PackedPtrs &pp, hipEvent_t ev0, hipEvent_t ev1);
 void launch_replay_soc(const HubParams &hp, const DevCtx *ctx, float *d_out, hipStream_t stream);
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
                 hipEvent_t ev1, const PackedPtrs &pp);
 void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream);
-void launch_compat_burn_fcev(const HubParams &hp, const DevCtx *ctx, int n_steps, hipStream_t stream);
+void launch_compat_ctor_sweep(const HubParams &hp, const DevCtx *ctx, hipStream_t stream);
 }  // namespace chub
 
 using namespace chub;
@@ -33,6 +33,8 @@ static int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
+// for the other translation units of the library (chub_comm.cpp); not part of the ABI
+extern "C" __attribute__((visibility("hidden"))) int chub_set_last_error_(int code, const char *msg) { return fail(code, msg); }
 
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
@@ -71,7 +73,6 @@ struct chub_env {
     hipStream_t stream;
     // optional per-kernel timing with HIP events on the launch stream (chub_profile_*)
     std::vector<hipEvent_t> prof_events;
-    std::vector<bool> prof_tail;
     size_t prof_used, prof_cap;
     int prof_every, prof_phase;
     bool prof_on;
@@ -269,7 +270,16 @@ int chub_device_count(void) {
 
 int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, int64_t env_id0, int device,
                 uint64_t seed, int rng_mode, chub_env **out) {
+    return chub_create_ex(cfg, data_dir, n_envs, env_id0, device, seed, rng_mode, nullptr, out);
+}
+
+int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs, int64_t env_id0, int device,
+                   uint64_t seed, int rng_mode, const chub_options *opt_in, chub_env **out) {
     if (!cfg || !data_dir || !out) return fail(CHUB_ERR_ARG, "null argument");
+    chub_options opt;
+    memset(&opt, 0, sizeof opt);
+    if (opt_in) opt = *opt_in;
+    if (opt.slot_kernel < 0 || opt.slot_kernel > 2) return fail(CHUB_ERR_ARG, "chub_options.slot_kernel must be 0, 1 or 2");
     *out = nullptr;
     if (n_envs <= 0) return fail(CHUB_ERR_ARG, "n_envs must be positive");
     if (n_envs * (int64_t) (cfg->station_list[0] + cfg->station_list[1] + 2) >= (int64_t) 1 << 31)
@@ -323,12 +333,34 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
         if (he != hipSuccess) return bail(fail(CHUB_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he)));
     }
 
+    // FCEV arrivals per step at most (the count table below is built from the same expression): sizes the explicit part
+    // of the waiting list
+    int hv_max_arrive = 0;
+    {
+        float hv_pin = (float) 0.3, hv_perm = (float) cfg->fcev_permeate;
+        if (hv_perm > 1) hv_perm = (float) 0.01;
+        for (int t = 0; t < 96; t++) {
+            // the largest arrival index of row t: level 999 (u = 1), or 300 when the row's CDF never reaches it (CHS.hpp:731-743)
+            int n = 300;
+            for (int j = 0; j < 301; j++)
+                if ((double) cdf[t * 301 + j] >= (double) level_value(kLevels - 1)) {
+                    n = j;
+                    break;
+                }
+            int c = (int) roundf(hv_pin * hv_perm * (float) n);
+            c = c < 0 ? 0 : (c > 255 ? 255 : c);
+            hv_max_arrive = c > hv_max_arrive ? c : hv_max_arrive;
+        }
+    }
+    if (hv_max_arrive > 127) return bail(fail(CHUB_ERR_UNSUPPORTED, "more than 127 FCEV arrivals per step"));
+    const int qcap = hv_max_arrive > 0 ? 2 * hv_max_arrive - 1 : 1;
+
     {   // arena: generous upper bound of everything allocated below (telemetry buffers come later, separately)
         const size_t S_tot = (size_t) (cfg->station_list[0] + cfg->station_list[1]);
-        const size_t per_env = S_tot * 40 + 2048;
+        const size_t per_env = S_tot * 40 + 1024 + (size_t) qcap * 16 + (rng_mode == CHUB_RNG_COMPAT ? 102 * 8 + 33 * 4 + 256 : 0);
         const size_t want = (size_t) n_envs * per_env + ((size_t) 8 << 20);
         void *q = nullptr;
-        if (!getenv("CHUB_NO_ARENA") && hipMalloc(&q, want) == hipSuccess) {
+        if (!opt.no_arena && hipMalloc(&q, want) == hipSuccess) {
             e->arena = (char *) q;
             e->arena_size = want;
             e->allocs.push_back(q);
@@ -358,13 +390,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     hp.constant_charging = cfg->constant_charging ? 1 : 0;
     hp.rng_mode = rng_mode;
     hp.telemetry = 0;
-    hp.slot_block = getenv("CHUB_SLOT_BLOCK") ? atoi(getenv("CHUB_SLOT_BLOCK")) : 256;
-    if (hp.slot_block != 128 && hp.slot_block != 192 && hp.slot_block != 256 && hp.slot_block != 512) hp.slot_block = 256;
-    // fused tail: measured slower at every size tried (each producer workgroup pays a store drain + a returning
-    // atomic on its critical path) -- kept as an option for experiments, off by default
-    hp.fused = (rng_mode == CHUB_RNG_PHILOX && getenv("CHUB_FUSED") && atoi(getenv("CHUB_FUSED")) == 1) ? 1 : 0;
-    hp.ablate = getenv("CHUB_ABLATE") ? atoi(getenv("CHUB_ABLATE")) : 0;
-    hp.lev_in_env = (rng_mode == CHUB_RNG_PHILOX && !hp.fused && !(getenv("CHUB_LEV_IN_ENV") && atoi(getenv("CHUB_LEV_IN_ENV")) == 0)) ? 1 : 0;
+    hp.qcap = qcap;
     hp.key[0] = (uint32_t) seed;
     hp.key[1] = (uint32_t) (seed >> 32);
     hp.cc = make_curve_consts();
@@ -543,7 +569,7 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
     // packed slot kernel (k_slot_packed): lanes of a workgroup laid over whole units end to end
     std::vector<uint32_t> lane_map[2];
     {
-        const int pb = hp.slot_block;
+        const int pb = 256;  // kSlotBlock of chub_kernels.hip
         bool tighter = false;
         for (int s = 0; s < 2; s++) {
             const int S = hp.S[s];
@@ -572,15 +598,9 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
         for (int s = 0; s < 2 && magic_ok; s++)
             for (int l = 0; l < pb && hp.S[s] > 0; l++)
                 if ((((uint32_t) l * (65536u / (uint32_t) hp.S[s] + 1u)) >> 16) != (uint32_t) (l / hp.S[s])) magic_ok = false;
-        const char *pe = getenv("CHUB_PACKED");
-        hp.packed = (rng_mode == CHUB_RNG_PHILOX && !hp.fused && (hp.S[0] >= 4 || hp.S[0] == 0) && (hp.S[1] >= 4 || hp.S[1] == 0) && magic_ok &&
+        hp.packed = (rng_mode == CHUB_RNG_PHILOX && (hp.S[0] >= 4 || hp.S[0] == 0) && (hp.S[1] >= 4 || hp.S[1] == 0) && magic_ok &&
                      (uint64_t) n_envs * (uint64_t) (hp.S[0] + hp.S[1] + 2) * 16u < ((uint64_t) 1 << 32) &&  // 32-bit byte offsets
-                     
-                     (pe ? atoi(pe) != 0 : true)) ? 1 : 0;
-        hp.tail_lead = getenv("CHUB_TAIL_LEAD") ? atoi(getenv("CHUB_TAIL_LEAD")) : 2048;
-        if (hp.tail_lead < 0) hp.tail_lead = 0;
-        hp.one_launch = (hp.packed && hp.lev_in_env && hp.slot_block == 256 && getenv("CHUB_ONE_LAUNCH") &&
-                         atoi(getenv("CHUB_ONE_LAUNCH")) == 1) ? 1 : 0;
+                     opt.slot_kernel != 1) ? 1 : 0;
         (void) tighter;
     }
     build_hy_table(hp, e->hy_table);
@@ -613,16 +633,20 @@ int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, in
 #define ALLOC(ptr, count)                                        \
     if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
     ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.init_soc, NS);
-    ALLOC(e->st.rec, 8 * N); ALLOC(e->st.pk[0], 2 * N); ALLOC(e->st.pk[1], 2 * N); ALLOC(e->st.grp_cnt, (N + 63) / 64);
+    ALLOC(e->st.rec, 8 * N); ALLOC(e->st.pk[0], 2 * N); ALLOC(e->st.pk[1], 2 * N);
     ALLOC(e->ev.cap, N); ALLOC(e->ev.store_soc, N); ALLOC(e->ev.ou, 3 * N); ALLOC(e->ev.price_noise, N);
     ALLOC(e->ev.re_pv, N); ALLOC(e->ev.re_wd, N); ALLOC(e->ev.price_next, N);
     ALLOC(e->ev.pv_day, N); ALLOC(e->ev.wd_day, N); ALLOC(e->ev.q_len, N); ALLOC(e->ev.hv_line, N);
-    ALLOC(e->ev.q_overflow, N); ALLOC(e->ev.q_time, N * kQCap); ALLOC(e->ev.q_mass, N * kQCap);
+    ALLOC(e->ev.q_fold, 2 * N); ALLOC(e->ev.q_fold_cnt, N); ALLOC(e->ev.q_time, N * (size_t) qcap); ALLOC(e->ev.q_mass, N * (size_t) qcap);
+    e->ev.hy_env = nullptr;
     ALLOC(e->ev.drw[0], 8 * N); ALLOC(e->ev.drw[1], 8 * N);
     e->ev.obs64 = nullptr; e->ev.reward64 = nullptr; e->ev.telem = nullptr;
     e->cr.g = nullptr; e->cr.minstd = nullptr;
     if (rng_mode == CHUB_RNG_COMPAT) {
-        ALLOC(e->cr.g, N * 32); ALLOC(e->cr.minstd, N);
+        ALLOC(e->cr.g, N * 32); ALLOC(e->cr.minstd, N); ALLOC(e->ev.hy_env, N * 102);
+        std::vector<double> rep(N * 102);  // until chub_compat_replay_constructor: every env the zero-demand table
+        for (size_t i = 0; i < N; i++) memcpy(&rep[i * 102], e->hy_table, sizeof e->hy_table);
+        HIP_TRY(hipMemcpy(e->ev.hy_env, rep.data(), rep.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     ALLOC(e->d_ctx, 1);
     e->ctx_dirty = true;
@@ -699,8 +723,8 @@ int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_ex
     sa.obs_stride = e->hp.obs_dim;
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
-    if (!launch_slot(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e), nullptr, nullptr))
-        launch_env(true, e->hp, e->d_ctx, sa, s, nullptr, nullptr, packed_ptrs(e));
+    launch_slot(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e), nullptr, nullptr);
+    launch_env(true, e->hp, e->d_ctx, sa, s, nullptr, nullptr, packed_ptrs(e));
     HIP_TRY(hipGetLastError());
     e->t = 0;
     e->price_count = 0;  // MGR:313 (after make_state)
@@ -721,6 +745,13 @@ int chub_step_device_packed(chub_env *e, const float *d_actions, const double *d
     if (!e || !d_actions || !d_packed) return fail(CHUB_ERR_ARG, "null argument");
     const int D = e->hp.obs_dim;
     return step_common(e, d_actions, d_exo_z, d_packed, D + 2, d_packed + D, D + 2, nullptr, d_packed + D + 1, stream);
+}
+
+int chub_step_gather(chub_env *e, chub_comm *comm, const float *d_actions, float *d_packed, float *d_gathered, void *stream) {
+    if (!e || !comm || !d_actions || !d_packed) return fail(CHUB_ERR_ARG, "null argument");
+    int rc = chub_step_device_packed(e, d_actions, nullptr, d_packed, stream);
+    if (rc) return rc;
+    return chub_comm_gather(comm, d_packed, d_gathered, e->hp.n_envs * (int64_t) (e->hp.obs_dim + 2) * (int64_t) sizeof(float), stream);
 }
 
 int chub_step_load_device(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
@@ -780,12 +811,9 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
     }
     // four events per profiled step: start / stop of the slot kernel, start / stop of the tail kernel
     hipEvent_t *pe = prof ? &e->prof_events[4 * e->prof_used] : nullptr;
-    const bool tail_done = launch_slot(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e), prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
-    if (!tail_done) launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
-    if (prof) {
-        e->prof_tail[e->prof_used] = !tail_done;
-        e->prof_used++;
-    }
+    launch_slot(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e), prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
+    launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
+    if (prof) e->prof_used++;
     HIP_TRY(hipGetLastError());
     e->price_count += 1;
     e->t = (e->t + 1) % 96;
@@ -1038,7 +1066,6 @@ int chub_profile_begin(chub_env *e, int max_steps, int every) {
     e->prof_every = every;
     e->prof_phase = 0;
     HIP_TRY(hipSetDevice(e->device));
-    e->prof_tail.assign((size_t) max_steps, false);
     while (e->prof_events.size() < (size_t) max_steps * 4) {
         hipEvent_t ev;
         HIP_TRY(hipEventCreate(&ev));
@@ -1059,7 +1086,6 @@ int chub_profile_end(chub_env *e, double *slot_ms_sum, double *env_ms_sum, int *
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, e->prof_events[4 * i], e->prof_events[4 * i + 1]));
         a += ms;
-        if (!e->prof_tail[i]) continue;
         HIP_TRY(hipEventElapsedTime(&ms, e->prof_events[4 * i + 2], e->prof_events[4 * i + 3]));
         b += ms;
     }
@@ -1081,8 +1107,9 @@ int chub_compat_replay_constructor(chub_env *e) {
     memset(&sa, 0, sizeof sa);
     sa.station_filter = -1;
     launch_slot(true, e->hp, e->d_ctx, sa, nullptr, packed_ptrs(e), nullptr, nullptr);
-    // (2) HySystem.__init__: 101 hy_step()s with live FCEV arrivals (HYD:154,168,250-259)
-    launch_compat_burn_fcev(e->hp, e->d_ctx, 101, nullptr);
+    // (2) HySystem.__init__: 101 hy_step()s with live FCEV arrivals (HYD:154-157,168,250-259) -> the streams advance and
+    //     every env gets the hy_power_speed_list the reference would have built from its draws
+    launch_compat_ctor_sweep(e->hp, e->d_ctx, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     return CHUB_OK;
@@ -1155,15 +1182,15 @@ int chub_set_state(chub_env *e, const void *buf, int64_t size) {
     return CHUB_OK;
 }
 
-int chub_fcev_overflow_count(chub_env *e, int64_t *out) {
+int chub_fcev_stuck_count(chub_env *e, int64_t *out) {
     if (!e || !out) return fail(CHUB_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
     std::vector<uint8_t> f;
-    int rc = fetch(f, (const uint8_t *) e->ev.q_overflow, (size_t) e->hp.n_envs);
+    int rc = fetch(f, (const uint8_t *) e->ev.hv_line, (size_t) e->hp.n_envs);
     if (rc) return rc;
     int64_t n = 0;
-    for (uint8_t b : f) n += b ? 1 : 0;
+    for (uint8_t b : f) n += (b & 128u) ? 1 : 0;
     *out = n;
     return CHUB_OK;
 }
@@ -1185,11 +1212,28 @@ int chub_get_hy_table(const chub_env *e, double *out102) {
     return CHUB_OK;
 }
 
+int chub_get_hy_table_env(chub_env *e, int64_t env_index, double *out102) {
+    if (!e || !out102) return fail(CHUB_ERR_ARG, "null argument");
+    if (env_index < 0 || env_index >= e->hp.n_envs) return fail(CHUB_ERR_ARG, "env index out of range");
+    if (!e->ev.hy_env) return chub_get_hy_table(e, out102);  // PHILOX: one table for the whole handle
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out102, (const double *) e->ev.hy_env + (size_t) env_index * 102, 102 * sizeof(double), hipMemcpyDeviceToHost));
+    return CHUB_OK;
+}
+
 int chub_set_hy_table(chub_env *e, const double *in102) {
     if (!e || !in102) return fail(CHUB_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
     memcpy(e->hy_table, in102, sizeof e->hy_table);
     HIP_TRY(hipMemcpy((void *) e->tb.hy_table, in102, sizeof e->hy_table, hipMemcpyHostToDevice));
+    if (e->ev.hy_env) {
+        const size_t N = (size_t) e->hp.n_envs;
+        std::vector<double> rep(N * 102);
+        for (size_t i = 0; i < N; i++) memcpy(&rep[i * 102], in102, sizeof e->hy_table);
+        HIP_TRY(hipMemcpy(e->ev.hy_env, rep.data(), rep.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     return CHUB_OK;
 }
 

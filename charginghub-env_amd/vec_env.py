@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import ChubConfig, ChubError, check, load_library
+from ._lib import ChubConfig, ChubError, ChubOptions, check, load_library
 
 
 def make_config(station_list, station_type_list, constant_charging=False, hydro_prod_rate=None, hydro_store_vlt=None,
@@ -46,7 +46,9 @@ def _ptr(a):
 
 class VecChargingHub(object):
     def __init__(self, n_envs, station_list, station_type_list, seed=0, rng="philox", device=0, env_id0=0,
-                 data_dir=None, **kwargs):
+                 data_dir=None, slot_kernel="auto", no_arena=False, **kwargs):
+        """slot_kernel: "auto" (the packed slot kernel wherever the hub shape allows), "wave" (the wave-local one for
+        every step) or "packed"; no_arena: one device allocation per array (no snapshots) -- chub_options."""
         kwargs.pop("seed_rand", None)
         kwargs.pop("use_lagrange", None)  # ignored by the reference too (MGR:126)
         self._lib = load_library()
@@ -56,8 +58,11 @@ class VecChargingHub(object):
         if rng not in ("philox", "compat"):
             raise ValueError("rng must be 'philox' or 'compat'")
         h = C.c_void_p()
-        check(self._lib.chub_create(C.byref(self.cfg), (data_dir or _lib.DATA_DIR).encode(), self.n_envs, int(env_id0),
-                                    int(device), int(seed) & 0xFFFFFFFFFFFFFFFF, self.rng_mode, C.byref(h)))
+        opt = ChubOptions()
+        opt.slot_kernel = _lib.SLOT_KERNELS[slot_kernel]
+        opt.no_arena = int(bool(no_arena))
+        check(self._lib.chub_create_ex(C.byref(self.cfg), (data_dir or _lib.DATA_DIR).encode(), self.n_envs, int(env_id0),
+                                       int(device), int(seed) & 0xFFFFFFFFFFFFFFFF, self.rng_mode, C.byref(opt), C.byref(h)))
         self._h = h
         self.obs_dim = self._lib.chub_obs_dim(h)
         self.act_dim = self._lib.chub_act_dim(h)
@@ -164,10 +169,11 @@ class VecChargingHub(object):
         check(self._lib.chub_get_reward_f64(self._h, _ptr(out)))
         return out
 
-    def fcev_overflow_count(self):
-        """envs whose FCEV waiting list outgrew its 16-car capacity (parity with the reference is lost for them)"""
+    def fcev_stuck_count(self):
+        """envs whose FCEV forecourt is stuck: no prefix of its waiting list fits into 15 minutes any more, so -- as in the
+        reference (HYD:270-276) -- nobody is served again until reset and the list only grows"""
         n = C.c_int64()
-        check(self._lib.chub_fcev_overflow_count(self._h, C.byref(n)))
+        check(self._lib.chub_fcev_stuck_count(self._h, C.byref(n)))
         return n.value
 
     def set_compat_seeds(self, seeds):
@@ -203,9 +209,13 @@ class VecChargingHub(object):
         b = np.ascontiguousarray(blob, dtype=np.uint8)
         check(self._lib.chub_set_state(self._h, _ptr(b), b.size))
 
-    def hy_table(self):
+    def hy_table(self, env=None):
+        """hy_power_speed_list (HYD:154-157): the handle's table, or env i's own (COMPAT after compat_replay_constructor)"""
         out = np.zeros(102, dtype=np.float64)
-        check(self._lib.chub_get_hy_table(self._h, _ptr(out)))
+        if env is None:
+            check(self._lib.chub_get_hy_table(self._h, _ptr(out)))
+        else:
+            check(self._lib.chub_get_hy_table_env(self._h, int(env), _ptr(out)))
         return out
 
     def set_hy_table(self, table):

@@ -33,7 +33,8 @@ enum {
     CHUB_ERR_ARG = -1,      /* bad argument (the reference: AssertionError / ValueError, MGR:37,148; AGG:196) */
     CHUB_ERR_DATA = -2,     /* data files missing or malformed (the reference: silent UB, CHS.hpp:102-105,733) */
     CHUB_ERR_HIP = -3,      /* HIP runtime failure / no GPU */
-    CHUB_ERR_UNSUPPORTED = -4
+    CHUB_ERR_UNSUPPORTED = -4,
+    CHUB_ERR_COMM = -5      /* RCCL failure (multi-GPU gather) */
 };
 
 enum { CHUB_FAST = 0, CHUB_SLOW = 1 };
@@ -64,6 +65,15 @@ typedef struct chub_config {
 
 typedef struct chub_env chub_env;
 
+/* Build options that are not constructor kwargs of the reference (all zero = defaults; the library reads no
+ * environment variables). */
+typedef struct chub_options {
+    int32_t slot_kernel;  /* PHILOX steps: 0 = the packed slot kernel wherever the hub shape allows (default),
+                             1 = the wave-local slot kernel for every step, 2 = same as 0 (kept for tests that name it) */
+    int32_t no_arena;     /* 1: one hipMalloc per array instead of one arena (disables chub_get_state / chub_set_state) */
+    int32_t reserved[6];
+} chub_options;
+
 /* telemetry column indices of chub_get_telemetry (names of the reference attributes, MGR:183-297) */
 enum {
     CHUB_T_HY_ACT = 0, CHUB_T_HY_FLOW_SPEED, CHUB_T_ALL_POWER_SECOND, CHUB_T_STORE_SOC, CHUB_T_CAPACITY,
@@ -81,6 +91,8 @@ enum {
  * handle's first env (shard offset); device = HIP device ordinal.  No reset is performed. */
 int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, int64_t env_id0, int device,
                 uint64_t seed, int rng_mode, chub_env **out);
+int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs, int64_t env_id0, int device,
+                   uint64_t seed, int rng_mode, const chub_options *opt /* NULL = defaults */, chub_env **out);
 int chub_destroy(chub_env *env);
 
 int chub_obs_dim(const chub_env *env);  /* 2 + 4*(#stations with piles>0) + 3 (MGR:74-104) */
@@ -126,6 +138,30 @@ int chub_random_actions_device(chub_env *env, uint64_t key, uint32_t batch, floa
 
 int chub_sync(chub_env *env);
 
+/* ---- multi-GPU: the one collective of the path -----------------------------------------------------------------
+ * No counterpart in the reference (it has nothing distributed): environments are independent, so the
+ * path shards by contiguous ranges of the global env index -- one process per GPU, handle i created with
+ * env_id0 = i * n_local (the Philox streams are keyed by the GLOBAL env id, so results do not depend on the sharding) --
+ * and per step each shard's packed output [n_local, D+2] f32 (chub_step_device_packed) travels to rank 0 in ONE grouped
+ * ncclSend / ncclRecv over the direct xGMI links, enqueued on the same HIP stream as the step kernels: no host wait,
+ * capturable in a hipGraph.  RCCL is loaded on first use (dlopen); a process that never makes a communicator never maps it.
+ *   chub_comm_unique_id: rank 0 makes the 128-byte RCCL id; the host passes it to the other ranks (file, pipe, socket).
+ *   chub_comm_create:    every rank, same id (ncclCommInitRank on `device`).
+ *   chub_comm_gather:    every rank: `bytes` from d_send to rank 0's d_recv + rank * bytes (d_recv ignored elsewhere).
+ *   chub_step_gather:    chub_step_device_packed + chub_comm_gather of the packed block on one stream -- the multi-GPU step.
+ *   chub_comm_max_f64 / chub_comm_barrier: max over ranks of one host double / rendezvous (both synchronise `stream`);
+ *                        what bench.py brackets its timed region with. */
+typedef struct chub_comm chub_comm;
+int chub_comm_unique_id(void *id128);
+int chub_comm_create(const void *id128, int world, int rank, int device, chub_comm **out);
+int chub_comm_destroy(chub_comm *comm);
+int chub_comm_world(const chub_comm *comm);
+int chub_comm_rank(const chub_comm *comm);
+int chub_comm_gather(chub_comm *comm, const void *d_send, void *d_recv, int64_t bytes, void *stream);
+int chub_comm_max_f64(chub_comm *comm, double *value, void *stream);
+int chub_comm_barrier(chub_comm *comm, void *stream);
+int chub_step_gather(chub_env *env, chub_comm *comm, const float *d_actions, float *d_packed, float *d_gathered, void *stream);
+
 /* Per-kernel timing of the step: between chub_profile_begin and chub_profile_end every `every`-th step (up to
  * max_steps samples) records HIP events on the launch stream around the slot kernel and the env kernel; _end
  * synchronises and returns the summed durations in milliseconds and the number of steps sampled. */
@@ -148,9 +184,11 @@ int chub_get_obs_f64(chub_env *env, double *out);
 int chub_get_reward_f64(chub_env *env, double *out);
 int chub_set_telemetry(chub_env *env, int enabled); /* off by default: the hot path then skips those stores */
 
-/* Number of envs whose FCEV waiting list ever exceeded its fixed capacity (16 cars; the reference's list is unbounded,
- * HYD:264-265, and only grows that long once its queue is stuck): for those envs parity with the reference is lost. */
-int chub_fcev_overflow_count(chub_env *env, int64_t *out);
+/* The FCEV waiting list is unbounded as in the reference (HYD:264-265): the entries a list that still gets served can
+ * hold are kept one by one, and once no prefix of it fits into 15 minutes any more (HYD:270-276: nobody is served again
+ * until reset and the list only grows) its entries are folded into their count and running sums, which is all the
+ * reference ever reads of them again.  chub_fcev_stuck_count: number of envs whose forecourt is currently in that state. */
+int chub_fcev_stuck_count(chub_env *env, int64_t *out);
 
 /* COMPAT streams: seeds [N][2] u32 = (srand seed, e.seed()) per env, i.e. what Change_Use_Seed /
  * srand / e.seed would install (CHS.hpp:25-44). */
@@ -159,9 +197,10 @@ int chub_set_rng_compat_seeds(chub_env *env, const uint32_t *seeds);
  * front pointer (rear = front - 3 mod 31), and the minstd_rand0 word -- to continue streams mid-sequence. */
 int chub_set_rng_compat_state(chub_env *env, const uint32_t *state);
 int chub_get_rng_compat_state(chub_env *env, uint32_t *state);
-/* COMPAT: advance the two streams by what the reference's constructor consumes before its first reset() (MGR:25-119):
- * one evs_reset per station constructor (CHS.hpp:1152,1462) and the 101-step electrolyser sweep with live FCEV
- * arrivals (HYD:154).  Call once after chub_create / chub_set_rng_compat_seeds, then chub_reset (= MGR:120). */
+/* COMPAT: what the reference's constructor does with the two streams before its first reset() (MGR:25-119): one
+ * evs_reset per station constructor (CHS.hpp:1152,1462) and the 101-step electrolyser sweep with live FCEV arrivals
+ * (HYD:154-157), which also yields each env's hy_power_speed_list.  Call once after chub_create /
+ * chub_set_rng_compat_seeds, then chub_reset (= MGR:120). */
 int chub_compat_replay_constructor(chub_env *env);
 /* Persistent OU states (never reset by the reference, MGR:304-316): [N][3] f64 pv, wd, price. */
 int chub_set_ou_state(chub_env *env, const double *ou);
@@ -173,14 +212,19 @@ int64_t chub_state_size(const chub_env *env);
 int chub_get_state(chub_env *env, void *buf, int64_t size);
 int chub_set_state(chub_env *env, const void *buf, int64_t size);
 
-/* electrolyser action->power table hy_power_speed_list[102] (HYD:154-157).  Built at create by a
- * zero-demand sweep; the reference's sweep uses live random FCEV demand, which only matters when a
- * tank clamp binds during construction -- chub_set_hy_table lets a caller install that table. */
+/* electrolyser action->power table hy_power_speed_list[102] (HYD:154-157).  The reference builds it at construction
+ * with 101 real hy_step()s, i.e. with live random FCEV demand, which matters whenever a tank clamp binds during that
+ * sweep.  COMPAT: chub_compat_replay_constructor computes exactly that table per env from the env's streams (until
+ * then, and in PHILOX mode, the table is the zero-demand sweep, one per handle: the production mode's definition).
+ * chub_get_hy_table_env returns env i's table (PHILOX: the handle's); chub_set_hy_table installs one for every env. */
 int chub_get_hy_table(const chub_env *env, double *out102);
+int chub_get_hy_table_env(chub_env *env, int64_t env_index, double *out102);
 int chub_set_hy_table(chub_env *env, const double *in102);
 
 const char *chub_last_error(void);
 int chub_device_count(void);
+/* hash of the sources this library was built from (the Python host refuses a library that is older than its sources) */
+const char *chub_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -1414,6 +1414,7 @@ orc_env *orc_env_alloc(void) { return (orc_env *) calloc(1, sizeof(orc_env)); }
 void orc_env_free(orc_env *e) { free(e); }
 orc_station *orc_env_station(orc_env *e, int k) { return &e->st[k]; }
 orc_rng *orc_env_rng(orc_env *e) { return &e->rng; }
+int orc_env_q_overflow(const orc_env *e) { return e->q_overflow; }
 void orc_env_hy_table(const orc_env *e, double *out102) { memcpy(out102, e->hy_table, sizeof e->hy_table); }
 
 /* telemetry named after the reference attributes (MGR:183-297, HYD) */

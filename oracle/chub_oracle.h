@@ -28,7 +28,7 @@ extern "C" {
 #define ORC_MAX_PILES 256
 #define ORC_CDF_ROWS 96
 #define ORC_CDF_COLS 301
-#define ORC_QCAP 16 /* FCEV FIFO capacity (reference list is unbounded, HYD:264-265) */
+#define ORC_QCAP 1024 /* FCEV waiting list: the reference list is unbounded (HYD:264-265); this plain array is long enough for every test (saturating, flagged in q_overflow: tests assert the flag stays 0) */
 
 enum { ORC_FAST = 0, ORC_SLOW = 1 };
 enum { ORC_RNG_COMPAT = 0, ORC_RNG_PHILOX = 1 };
@@ -210,6 +210,7 @@ orc_station *orc_env_station(orc_env *e, int k);
 orc_rng *orc_env_rng(orc_env *e);
 void orc_env_hy_table(const orc_env *e, double *out102);
 int orc_env_telemetry(const orc_env *e, double *out24);
+int orc_env_q_overflow(const orc_env *e); /* 1 once the FCEV waiting list outgrew ORC_QCAP */
 void orc_env_set_hy_table(orc_env *e, const double *in102);
 void orc_env_init_compat_ctor(orc_env *e, const orc_config *cfg, const orc_tables *t, uint32_t glibc_seed,
                               uint32_t minstd_seed);

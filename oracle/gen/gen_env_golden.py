@@ -102,6 +102,13 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
     random.seed(py_seed)
     np.random.seed(py_seed)
     rec = Recorder()
+    ctor_seeds = None
+    if seeds is not None:
+        # the constructor consumes the two C++ streams as well (station constructors' evs_reset, the 101-step electrolyser
+        # sweep with live FCEV demand, HYD:154-157): install known seeds in front of it so that hy_power_speed_list is
+        # reproducible from the fixture alone
+        ctor_seeds = (seeds[0] + 5000, seeds[1] + 5000)
+        orclib.ref().ref_seed(*ctor_seeds)
     with contextlib.redirect_stdout(io.StringIO()):
         env = EvcsspManagerEnv_v6(**kwargs)
     # the constructor runs one reset() (MGR:120): its exogenous draws shape the OU states we start from
@@ -158,6 +165,7 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
     out["slots0"] = np.array(data["slots0"], dtype=np.float32)
     out["slots1"] = np.array(data["slots1"], dtype=np.float32)
     out["hy_table"] = hy_table
+    out["ctor_seeds"] = np.array(ctor_seeds if ctor_seeds is not None else (1, 1))  # c1: the process defaults (CHS:25,35-44)
     out["ctor_days"] = np.array(ctor_days)
     out["ctor_z"] = np.array(ctor_z)
     out["obs_dim"] = np.array(D)
@@ -173,7 +181,8 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
     os.makedirs(GOLD, exist_ok=True)
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     print(name, "obs_dim", D, "steps", len(out["reward"]), "return(ep0)", repr(float(out["ret"])),
-          "final SOC", out["telem"][-1][3], "max queue", out["telem"][:, 21].max())
+          "final SOC", out["telem"][-1][3], "max queue", out["telem"][:, 21].max(), "min reset flow_in",
+          min(out["reset_stations"][:, 5].min(), out["reset_stations"][:, 11].min()))
     return out
 
 
@@ -211,6 +220,15 @@ def main():
         (1515, 1616), py_seed=8)
     # constant-power fleet mode
     run("env_constant", base_kwargs(constant_charging=True), 1, 96, "random", (1313, 1414), py_seed=7)
+    # a 3-pile fast station: init_station_car_number(mu = 1, 3) can come out negative and the fast station records it as
+    # flow_in_number[-1] (CHS:1276, 832-842, 1617); many short episodes so that several resets do
+    out = run("env_small_fast_neg", base_kwargs(station_list=[3, 0], fcev_permeate=0.0), 24, 6, "random", (1717, 1818),
+              py_seed=9, reseed_each_episode=True)
+    assert out["reset_stations"][:, 5].min() < 0, "no negative initial flow_in in this fixture: pick other seeds"
+    # a forecourt whose 15-minute FIFO gets stuck: the waiting list grows to well over a hundred cars
+    out = run("env_fcev_queue_deep", base_kwargs(fcev_permeate=0.08, hydro_store_vlt=400, init_soc=0.6), 1, 70, "random",
+              (1919, 2020), py_seed=10)
+    assert out["telem"][:, 21].max() > 64, out["telem"][:, 21].max()
 
 
 if __name__ == "__main__":

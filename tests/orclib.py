@@ -114,6 +114,7 @@ def _load_oracle():
         "orc_env_hy_table": (None, [P, P]),
         "orc_env_set_hy_table": (None, [P, P]),
         "orc_env_telemetry": (I, [P, P]),
+        "orc_env_q_overflow": (I, [P]),
         "orc_vec_create": (P, [P, P, C.c_long, C.c_long, I, C.c_uint64]),
         "orc_vec_destroy": (None, [P]),
         "orc_vec_env": (P, [P, C.c_long]),
@@ -273,7 +274,7 @@ def golden_config(g):
 
 
 GOLDEN_ENV = ["env_c1_envtest", "env_c3_random", "env_c2_random", "env_c5_random", "env_slow_only_fcev",
-              "env_clamp", "env_full_tank", "env_constant", "env_fcev_queue"]
+              "env_clamp", "env_full_tank", "env_constant", "env_fcev_queue", "env_small_fast_neg", "env_fcev_queue_deep"]
 
 
 class OrcEnv:
@@ -313,6 +314,9 @@ class OrcEnv:
         out = np.zeros(24)
         orc.orc_env_telemetry(self.e, ptr(out))
         return out
+
+    def q_overflow(self):
+        return orc.orc_env_q_overflow(self.e)
 
     def hy_table(self):
         out = np.zeros(102)
