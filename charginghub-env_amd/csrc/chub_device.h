@@ -27,8 +27,17 @@ namespace chub {
 constexpr int kMaxLine = 10;     // Station::max_line, CHS.hpp:197
 constexpr int kLevels = 1000;    // RandomUtil::uniform_rand has 1000 levels k/999, CHS.hpp:35-44
 constexpr int kBalkTab = 512;
-constexpr int kSocLevels = 16384;  // PHILOX: equiprobable levels of the EV arrival SoC (top 14 bits of a Philox word)
+constexpr int kSocLevels = 2048;   // PHILOX: equiprobable classes of the EV arrival SoC (top 11 bits of a Philox word): the class
+                                   // tables of both stations (768 KB) stay resident in every XCD's L2 next to the streamed state
+constexpr int kSocLevelShift = 21;
 constexpr int kPolarMaxTrials = 32;
+#ifndef CHUB_SLOTS_PER_LANE
+#define CHUB_SLOTS_PER_LANE 2
+#endif
+constexpr int kSlotBlock = 256;    // workgroup size of the slot kernels
+constexpr int kSlotsPerLane = CHUB_SLOTS_PER_LANE;  // packed slot kernel: slots per lane (kSlotBlock * kSlotsPerLane virtual lanes per workgroup)
+constexpr int kClsRow = 32;        // PHILOX: entries (power, t_soc) per arrival-SoC class = car_steps a car can take (stay_time <= 27 here)
+constexpr int kTapeClasses = 8192; // PHILOX: room for caller-registered arrival-SoC classes (tape mode)
 constexpr int kTelemCount = 24;
 
 // Philox draw sites (counter word 1 = site << 16 | index)
@@ -52,7 +61,7 @@ struct SlotArrays {          // index = base_k + env*S_k + slot  (station-major)
     //   .z t_soc     soc_to_time(soc)      -- cached, what car_step and calculate_needed both need
     //   .w bits 0-6 stay_time - already_stay_time (0 = empty), bit 7 charging this step, bits 8-14 stay_time,
     //      bits 15-24 target-SoC level l (target = 80 + 20 * l / 999, CHS.hpp:35-44), bits 25-31 car_steps taken since arrival
-    CHUB_G(uint32_t) hot;    // [NS][4]
+    CHUB_G(uint32_t) hot;    // COMPAT [NS][4]; PHILOX [NS][2]: the 8-byte slot state described in chub_kernels.hip
     // cold: written once per arriving car, read only by introspection.  Current SoC = arrival SoC advanced by the
     // recorded number of car_steps (k_replay_soc), target SoC from its level; slots without a car read as zeros.
     CHUB_G(float) init_soc;  // arrival SoC
@@ -112,10 +121,9 @@ struct Tables {
     CHUB_G(const float) normal_tail;  // [4097] its second level for the lowest / highest cell   (PHILOX mode)
     CHUB_G(const double) sin96;       // [96]   sin(2*pi*t/96), the time feature of the observation (MGR:319-320)
     CHUB_G(const float) ttab[2];      // [1000] soc_to_time(target level k) of station k's curve (target = 80 + 20*k/999)
-    CHUB_G(const uint32_t) lane_map[2];  // [slot_block][4] packed slot kernel, per workgroup lane of station k: ballot mask of
-                                      // its unit's lanes in its own wave (2 words) and in the neighbouring wave (2 words)
-    CHUB_G(const float) newcar[2];    // [kSocLevels][4] PHILOX: per arrival-SoC level of station k: soc, soc_to_time(soc),
-                                      //                 time_to_power(soc_to_time(soc)), 0 -- what add_car derives from it
+    CHUB_G(const float) cls[2];       // [kSocLevels + kTapeClasses + 1][kClsRow][2] PHILOX: per arrival-SoC class of station k's curve:
+                                      //   (power, t_soc) after n = 0 .. kClsRow-1 car_steps (entry 0 = what add_car derives, CHS.hpp:864-877)
+    CHUB_G(const float) cls_soc0[2];  // [kSocLevels + kTapeClasses] the class's arrival SoC (introspection)
 };
 
 struct HubParams {
@@ -164,9 +172,8 @@ struct PackedPtrs {
     const EnvArrays *ev;      // host copies of the array tables (launch_env / k_step build TailArgs from them)
     const StationArrays *st;
     uint32_t *hot, *rec;
-    float *init_soc;
     uint64_t *pk[2];
-    const uint32_t *lane_map[2];
+    const float *cls[2], *ttab[2];
 };
 
 struct StepArgs {
@@ -184,6 +191,9 @@ struct StepArgs {
     float *done_f32;         // packed form: element i at done_f32 + i*reward_stride (0.0 / 1.0)
     int32_t obs_stride, reward_stride;
     int32_t load_mode;       // scalar-load control (evs_step(float)): actions[.][0] / [.][S0] carry one kW target per station
+    // tape mode (PHILOX, packed kernel): the step's station-level draws and the per-admission variates come from the caller
+    const uint64_t *pk_tape;   // [2N] packed station draws of this step (layout of StationArrays::pk), or null
+    const uint32_t *car_tape;  // [NS][2] per slot: arrival-SoC class, target level | extra stay << 16, or null
 };
 
 }  // namespace chub

@@ -26,6 +26,7 @@
 namespace chub {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------ Philox
 struct U4 {
@@ -170,7 +171,6 @@ __device__ __forceinline__ int prefix_count(uint64_t m) {
 }
 
 constexpr int MODE_COMPAT = 0, MODE_PHILOX = 1;
-constexpr int kSlotBlock = 256;  // workgroup size of the slot kernels (the host builds lane_map for it)
 // action_to_real (MGR:384-393) switches a pile on iff (a + 1) / 2 >= 0.5 on the f32 array.  In round-to-nearest-even f32
 // that is exactly a >= -2^-25 (a + 1 rounds to 1 from -2^-25 upwards, the tie going to the even 1.0; checked against the
 // two-step form on every f32 around the threshold and a stride over all others), so one compare replaces add, mul, compare.
@@ -281,15 +281,26 @@ __device__ __forceinline__ uint64_t draw_station_levels(const HubParams &hp, con
     return pk;
 }
 
-// ---------------------------------------------------------------------------------------- k_slot
-// What one lane keeps of its slot across the phases of a step.
-struct SlotRegs {
-    float power, t_target, t_soc, soc_new;
-    float step_tt;    // DEFER: curve time at which car_step has to be evaluated
-    int tl, stay;
-    bool car, charge, soc_dirty, leave;
-    bool needs_step;  // DEFER: charging this step and still here afterwards
-};
+// ---------------------------------------------------------------------------------------- slot state
+// COMPAT keeps, per slot, the 16-byte hot record of SlotArrays (power, t_target, t_soc, meta) and evaluates the charge
+// curves in the step (the reference's streams make the arrival SoC a continuous value).
+//
+// PHILOX keeps 8 bytes per slot and no curve is evaluated in the step at all.  The arrival SoC takes one of kSocLevels
+// classes, and a car's whole charging history is the deterministic chain soc -> soc_to_time -> +1 slot -> time_to_soc /
+// time_to_power (car_step, CHS.hpp:900-905 / 1065-1070) from that class: Tables::cls[k] holds, per class, (power, t_soc)
+// after n = 0 .. kClsRow-1 car_steps, built once on the host with the same curve functions (chub_curves.h).  The slot keeps
+//   w0: bits 0-5 stay_time - already_stay_time (0 = empty), bit 6 charging this step, bits 7-12 stay_time,
+//       bits 13-17 n = car_steps taken since arrival, bits 18-27 target-SoC level (target = 80 + 20 * l / 999, CHS.hpp:35-44)
+//   w1: arrival-SoC class
+// and everything the step needs follows from one 16-byte row read (entries n and n + 1: where the car is on its curve and
+// where one more car_step takes it) and one 4-byte read of Tables::ttab (soc_to_time(target)).
+__device__ __forceinline__ int ps_tl(uint32_t w0) { return (int) (w0 & 63u); }
+__device__ __forceinline__ uint32_t ps_n(uint32_t w0) { return (w0 >> 13) & 31u; }
+__device__ __forceinline__ uint32_t ps_tgt(uint32_t w0) { return (w0 >> 18) & 1023u; }
+__device__ __forceinline__ uint32_t ps_make(int stay, uint32_t tgt) {  // a car that has just arrived
+    return (uint32_t) stay | ((uint32_t) stay << 7) | (tgt << 18);
+}
+constexpr int kMaxStay = 63;  // 6-bit fields; chub_create checks that no reachable stay_time comes near it
 
 // car_step (CHS.hpp:900-905 / 1065-1070): soc and power one slot further along the curve, evaluated together.  Same
 // expressions as time_to_soc / time_to_power (chub_curves.h), but the powers of x are shared between the two
@@ -344,55 +355,6 @@ __device__ __forceinline__ void car_step_curves(float tt, bool cp, const CurveCo
     }
 }
 
-// Phase 1: load, urgency, feasibility / on-off, car_step, departure (CHS.hpp:1188-1202 / 1499-1513)
-// DEFER: do not evaluate the curves here, only record that (and where) they are needed -- the caller compacts the
-// charging cars of the whole workgroup and evaluates them densely.  A car that leaves this step is wiped by
-// reset_position right after its car_step (CHS.hpp:1196-1201), so its curve evaluation is skipped altogether.
-template <int TYPE, bool DEFER>
-__device__ __forceinline__ void slot_advance(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, SlotRegs &r,
-                                             uint32_t idx, uint32_t act_idx, bool cp, int on_override) {
-    // the slot's hot record and its action go out together (the action is needed only for occupied slots, but waiting for the occupancy
-    // byte first would put two HBM latencies in series)
-    const u32x4 hot = ((CHUB_G(u32x4)) sl.hot)[idx];
-    r.power = __uint_as_float(hot.x);
-    r.t_target = __uint_as_float(hot.y);
-    r.t_soc = __uint_as_float(hot.z);
-    uint32_t tlb = hot.w;
-    float a = sa.actions[act_idx];
-    asm volatile("" : "+v"(a), "+v"(tlb));
-    r.tl = (int) (tlb & 127u);
-    r.stay = (int) (tlb >> 8);  // all of the meta bits above the flag: stay_time | target level << 7 | car_steps << 17
-    r.car = r.tl > 0;
-    // action_to_real (MGR:384-393): (a+1)/2 >= 0.5 on the f32 array
-    const bool act_on = a >= kActOnThreshold;
-    // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373)
-    const bool on = on_override >= 0 ? (r.car && on_override != 0)
-                                     : (r.car && (act_on || must_charge(r.t_target, r.t_soc, r.tl)));
-    if (on) r.stay += 1 << 17;  // one more car_step on this car's account (its SoC is replayed from it on demand)
-    if (DEFER) {
-        r.step_tt = __fadd_rn(r.t_soc, 1.0f);
-        r.needs_step = on && r.tl > 1;
-    } else if (on) {  // car_step (CHS.hpp:900-905 / 1065-1070)
-        const float tt = __fadd_rn(r.t_soc, 1.0f);
-        car_step_curves<TYPE>(tt, cp, hp.cc, r.soc_new, r.power);
-        r.t_soc = soc_to_time<TYPE>(r.soc_new, cp);
-        r.soc_dirty = true;
-    }
-    if (r.car) {  // remove_car (CHS.hpp:912-923 / 1077-1088)
-        r.tl -= 1;
-        if (r.tl <= 0) {
-            r.car = false;
-            r.leave = true;
-            r.tl = 0;
-            r.power = 0.0f;
-            r.t_target = 0.0f;
-            r.t_soc = 0.0f;
-            r.stay = 0;
-        }
-    }
-    r.charge = on && r.car;
-}
-
 // What add_car (CHS.hpp:864-877 / 1029-1042) produces for one admitted slot.
 struct NewCar {
     float soc, t_target, t_soc, power;
@@ -413,10 +375,73 @@ __device__ __forceinline__ NewCar make_car(float arrive_soc, int lev, float t_ta
     return c;
 }
 
-template <int TYPE, bool RESET, int MODE, int BLOCK>
-__device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
-                          const CompatRng &cr, const Tables &tb, const int k, const int64_t block_local,
-                          float *lds_f, uint32_t *lds_u) {
+// ---- scalar-load control mode, evs_step(float) (CHS.hpp:1169-1186 / 1480-1497): one kW target per station; the piles are
+// switched on in urgency order until the target is met (assign_on_off, CHS.hpp:1318-1362 / 1629-1674).  Wave-local units
+// (H = pow2 >= S lanes).  Returns this lane's on / off decision.
+template <int BLOCK>
+__device__ __forceinline__ bool load_mode_on(const HubParams &hp, const StepArgs &sa, const StationArrays &st, const int k,
+                                             const int env, const bool unit_ok, const bool valid, const int slot, const bool car0,
+                                             const float pw0, const float em0, float *lds_f, uint32_t *lds_u) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = hp.S[k], logH = hp.logH[k];
+    const int uiw = lane >> logH;
+    const uint32_t sidx = (uint32_t) k * (uint32_t) hp.n_envs + (uint32_t) env;
+    const bool cp = hp.constant_charging != 0;
+    // catch_load (CHS.hpp:358-366): clamp to [min_power, max_power] of the previous calculate_output
+    float load = 0.0f;
+    if (unit_ok) {
+        const StationRec pr = rec_load(st.rec, sidx);
+        load = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) (k ? hp.S[0] : 0)];
+        if (load > pr.mx) load = pr.mx;
+        else if (load < pr.mn) load = pr.mn;
+    }
+    // std::multimap keyed by -emergency (CHS.hpp:1324-1336): emergency descending, ties by slot index
+    const int ubase = uiw << logH;
+    int rk = 0;
+    for (int j = 0; j < S; j++) {
+        const float ej = __shfl(em0, ubase + j);
+        rk += (ej > em0 || (ej == em0 && j < slot)) ? 1 : 0;
+    }
+    // rank_power_add (CHS.hpp:1375-1402): cumulative power of the cars in that order, added sequentially in f32
+    float *by_rank = lds_f + wave * 64 + ubase;          // this unit's H floats
+    uint32_t *car_by_rank = lds_u + wave * 64 + ubase;
+    if (valid) {
+        by_rank[rk] = car0 ? pw0 : 0.0f;
+        car_by_rank[rk] = car0 ? 1u : 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float cum = 0.0f, mine = 0.0f;
+    int cars_before = 0, mine_before = 0;
+    for (int q = 0; q < S; q++) {
+        if (q == rk) mine_before = cars_before;
+        cum = __fadd_rn(cum, valid ? by_rank[q] : 0.0f);
+        cars_before += valid ? (int) car_by_rank[q] : 0;
+        if (q == rk) mine = cum;
+    }
+    bool chg;
+    if (cp) {  // constant-power fleet: the first round(load / constant_power) cars in order
+        const float constant_power = hp.type[k] == 0 ? (float) 36.44764034125146 : (float) 5.254973139368931;
+        const int n_on = (int) roundf(__fdiv_rn(load, constant_power));
+        chg = car0 && mine_before < n_on;
+    } else {
+        chg = car0 && ((double) load + 0.0001 >= (double) mine);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();  // the scratch areas are reused below
+    return chg;
+}
+
+// ---------------------------------------------------------------------------------------- k_slot, COMPAT streams
+// lane = charger slot; one (env, station) unit = H = pow2 >= S_k lanes, 64 / H units per wave.  Phases in the reference's order
+// (CHS.hpp:1188-1207 / 1499-1518).  The unit's first lane walks the env's two reference streams in the reference's
+// consumption order; station sums in the reference's sequential f32 order.  Pinned against the recorded reference
+// trajectories (tests/golden).
+template <int TYPE, bool RESET, int BLOCK>
+__device__ void slot_body_compat(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
+                                 const CompatRng &cr, const Tables &tb, const int k, const int64_t block_local,
+                                 float *lds_f, uint32_t *lds_u) {
     constexpr int WAVES = BLOCK / 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -436,300 +461,136 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     const int hub_slot = (k ? hp.S[0] : 0) + slot;
     const bool cp = hp.constant_charging != 0;
 
-    // the unit's queue length and this step's packed station draws: requested now, together with the slot loads
-    // below, so that the wave pays one memory round trip instead of three
+    // the unit's queue length, the slot's hot record and its action go out together (one memory round trip)
     uint32_t line_in = 0;
-    uint64_t pk_in = 0;
-    if (unit_ok) {
-        if (!RESET) line_in = st.rec[4u * sidx + 3u];  // masked after the slot loads have been issued (see slot_advance)
-        if (MODE == MODE_PHILOX) pk_in = st.pk[sa.tick & 1u][sidx];
+    u32x4 hot = {0u, 0u, 0u, 0u};
+    float a = 0.0f;
+    if (!RESET && unit_ok) line_in = st.rec[4u * sidx + 3u];
+    if (!RESET && valid) {
+        hot = ((CHUB_G(u32x4)) sl.hot)[idx];
+        a = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot];
     }
-    SlotRegs r;
-    r.power = r.t_target = r.t_soc = r.soc_new = 0.0f;
-    r.step_tt = 0.0f;
-    r.tl = r.stay = 0;
-    r.car = r.charge = r.soc_dirty = r.leave = r.needs_step = false;
-    // ---- scalar-load control mode, evs_step(float) (CHS.hpp:1169-1186 / 1480-1497): one kW target per station; the
-    // piles are switched on in urgency order until the target is met (assign_on_off, CHS.hpp:1318-1362 / 1629-1674)
+    float power = __uint_as_float(hot.x), t_target = __uint_as_float(hot.y), t_soc = __uint_as_float(hot.z);
+    int tl = (int) (hot.w & 127u);
+    int meta = (int) (hot.w >> 8);  // all of the meta bits above the flag: stay_time | target level << 7 | car_steps << 17
+    bool car = tl > 0, leave = false;
     int on_override = -1;
-    if (!RESET && sa.load_mode) {
-        float pw0 = 0.0f, em0 = 0.0f;
-        bool car0 = false;
-        if (valid) {
-            const u32x4 hot = ((CHUB_G(u32x4)) sl.hot)[idx];
-            pw0 = __uint_as_float(hot.x);
-            const int tl0 = (int) (hot.w & 127u);
-            car0 = tl0 > 0;
-            if (car0) em0 = emergency_of(__uint_as_float(hot.y), __uint_as_float(hot.z), tl0);
-        }
-        // catch_load (CHS.hpp:358-366): clamp to [min_power, max_power] of the previous calculate_output
-        float load = 0.0f;
-        if (unit_ok) {
-            const StationRec pr = rec_load(st.rec, sidx);
-            load = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) (k ? hp.S[0] : 0)];
-            if (load > pr.mx) load = pr.mx;
-            else if (load < pr.mn) load = pr.mn;
-        }
-        // std::multimap keyed by -emergency (CHS.hpp:1324-1336): emergency descending, ties by slot index
-        const int ubase = uiw << logH;
-        int rk = 0;
-        for (int j = 0; j < S; j++) {
-            const float ej = __shfl(em0, ubase + j);
-            rk += (ej > em0 || (ej == em0 && j < slot)) ? 1 : 0;
-        }
-        // rank_power_add (CHS.hpp:1375-1402): cumulative power of the cars in that order, added sequentially in f32
-        float *by_rank = lds_f + wave * 64 + ubase;          // this unit's H floats
-        uint32_t *car_by_rank = lds_u + wave * 64 + ubase;
-        if (valid) {
-            by_rank[rk] = car0 ? pw0 : 0.0f;
-            car_by_rank[rk] = car0 ? 1u : 0u;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float cum = 0.0f, mine = 0.0f;
-        int cars_before = 0, mine_before = 0;
-        for (int q = 0; q < S; q++) {
-            if (q == rk) mine_before = cars_before;
-            cum = __fadd_rn(cum, valid ? by_rank[q] : 0.0f);
-            cars_before += valid ? (int) car_by_rank[q] : 0;
-            if (q == rk) mine = cum;
-        }
-        bool chg;
-        if (cp) {  // constant-power fleet: the first round(load / constant_power) cars in order
-            const float constant_power = TYPE == 0 ? (float) 36.44764034125146 : (float) 5.254973139368931;
-            const int n_on = (int) roundf(__fdiv_rn(load, constant_power));
-            chg = car0 && mine_before < n_on;
-        } else {
-            chg = car0 && ((double) load + 0.0001 >= (double) mine);
-        }
-        on_override = chg ? 1 : 0;
-        __builtin_amdgcn_wave_barrier();
-        __syncthreads();  // the scratch areas are reused by the queues below
+    if (!RESET && sa.load_mode)
+        on_override = load_mode_on<BLOCK>(hp, sa, st, k, env, unit_ok, valid, slot, car, power,
+                                          car ? emergency_of(t_target, t_soc, tl) : 0.0f, lds_f, lds_u) ? 1 : 0;
+    // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373); action_to_real (MGR:384-393)
+    const bool on = on_override >= 0 ? (car && on_override != 0) : (car && (a >= kActOnThreshold || must_charge(t_target, t_soc, tl)));
+    if (on) {  // car_step (CHS.hpp:900-905 / 1065-1070)
+        meta += 1 << 17;  // one more car_step on this car's account (its SoC is replayed from it on demand)
+        float soc_new;
+        car_step_curves<TYPE>(__fadd_rn(t_soc, 1.0f), cp, hp.cc, soc_new, power);
+        t_soc = soc_to_time<TYPE>(soc_new, cp);
     }
-    if (!RESET && valid)
-        slot_advance<TYPE, MODE == MODE_PHILOX>(hp, sa, sl, r, idx, (uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot, cp,
-                                                on_override);
+    if (car) {  // remove_car (CHS.hpp:912-923 / 1077-1088)
+        tl -= 1;
+        if (tl <= 0) {
+            car = false;
+            leave = true;
+            tl = 0;
+            power = t_target = t_soc = 0.0f;
+            meta = 0;
+        }
+    }
+    const bool charge = on && car;
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): arrivals, renege, balk, admission
-    const bool empty = valid && !r.car;
+    const bool empty = valid && !car;
     const uint64_t be = __ballot(empty) & unit_mask;
     const int empties = __popcll(be);
     const int rank = prefix_count(be);
-    asm volatile("" : "+v"(line_in));
     int line = (int) (line_in & 0xFFu);
-    int flow = 0, assign = 0;
     const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
-    NewCar nc;
-    nc.soc = nc.t_target = nc.t_soc = nc.power = 0.0f;
-    nc.stay = nc.lev = 0;
-    bool adm = false;
-
-    if (MODE == MODE_PHILOX) {
-        if (unit_ok) {
-            if (RESET) {
-                // evs_reset: the unit's initial occupancy was drawn by k_reset_levels, one lane per unit, just before
-                // the fast station records the raw draw, which is negative for small stations (mu - 3 < 0, CHS.hpp:1617,
-                // 832-842): assign_car then admits nobody and the queue stays empty
-                flow = (TYPE == 0) ? (int) (int8_t) (pk_in & 0xFFu) : (int) ((pk_in >> 8) & 0xFFu);
-            } else {
-                // this step's station-level draws were packed by the previous launch (draw_station_levels)
-                const uint64_t pk = pk_in;
-                line = __popc((uint32_t) pk & ((1u << line) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
-                const int n_in = (int) (pk >> 10) & 15;
-                // the fast station records the un-thinned count (CHS.hpp:1617), the slow one what survives the balk
-                // pass given the queue length just computed (CHS.hpp:1297-1306)
-                flow = (TYPE == 0) ? n_in : (int) ((pk >> (14 + 4 * line)) & 15);
-            }
-            assign = (line + flow) < empties ? (line + flow) : empties;  // assign_car, CHS.hpp:417-430
-            line = line + flow - assign;
-            line = line < kMaxLine ? line : kMaxLine;
+    // the unit's first lane walks the two reference streams in the reference's order and parks the per-admission
+    // variates in LDS, indexed by admission rank
+    float *lds_soc = lds_f;
+    uint32_t *lds_lev = lds_u, *lds_late = lds_u + BLOCK;
+    const int lbase = wave * 64 + (uiw << logH);
+    int2 fa = make_int2(0, 0);
+    int new_line = line;
+    if (unit_ok && slot == 0) {
+        CompatStream rs;
+        rs.load(cr, env);
+        int n_in;
+        if (RESET) {
+            const float cn = rs.normal_f((float) mu, 1.0f);
+            int temp = (int) roundf(cn);
+            temp = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
+            n_in = temp;
+        } else {
+            n_in = (int) tb.cnt[k][sa.t * kLevels + rs.level()];
         }
-        adm = empty && rank < assign;
-        // ---- the two expensive per-car jobs, compacted over the workgroup through LDS: car_step for the cars that
-        // charge this step, add_car for the newly admitted ones.  Their lanes queue up and the queues are served
-        // densely (one lane per car) instead of every wave running both curve paths for a handful of active lanes.
-        uint32_t *q_cnt = lds_u;                   // [2]  0: new cars, 1: charging cars
-        uint32_t *q_new = lds_u + 2;               // [BLOCK]  tid of the admitted lane
-        uint32_t *q_chg = lds_u + 2 + BLOCK;       // [BLOCK]  tid of the charging lane
-        uint32_t *o_stay = lds_u + 2 + 2 * BLOCK;  // [BLOCK]
-        float *o_soc = lds_f;                      // [BLOCK] each, indexed by the owning lane's tid
-        float *o_tt = lds_f + BLOCK;
-        float *o_ts = lds_f + 2 * BLOCK;
-        float *o_pw = lds_f + 3 * BLOCK;
-        float *in_tt = lds_f + 4 * BLOCK;          // [BLOCK] curve time of a charging car
-        if (tid < 2) q_cnt[tid] = 0;
-        __syncthreads();
-        {
-            const uint64_t ba = __ballot(adm), bc = __ballot(r.needs_step);
-            const int na = __popcll(ba), nc_ = __popcll(bc);
-            uint32_t base_a = 0, base_c = 0;
-            if (lane == 0) {
-                if (na) base_a = atomicAdd(&q_cnt[0], (uint32_t) na);
-                if (nc_) base_c = atomicAdd(&q_cnt[1], (uint32_t) nc_);
-            }
-            base_a = __shfl(base_a, 0);
-            base_c = __shfl(base_c, 0);
-            if (adm) q_new[base_a + prefix_count(ba)] = (uint32_t) tid;
-            if (r.needs_step) {
-                q_chg[base_c + prefix_count(bc)] = (uint32_t) tid;
-                in_tt[tid] = r.step_tt;
-            }
+        int tline = 0;
+        for (int w = 0; w < line; w++) tline += (rs.level() >= (int) tb.thr_renege[w]) ? 1 : 0;
+        new_line = tline;
+        int true_in = 0;
+        for (int j = 0; j < n_in; j++) {
+            const int m = new_line + j;
+            const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
+            true_in += (rs.level() <= thr && j <= S) ? 1 : 0;
         }
-        __syncthreads();
-        const uint32_t n_adm = q_cnt[0], n_chg = q_cnt[1];
-        for (uint32_t i = tid; i < n_chg; i += BLOCK) {  // car_step (CHS.hpp:900-905 / 1065-1070), from the low waves
-            const int src = (int) q_chg[i];
-            float soc_c, pw_c;
-            car_step_curves<TYPE>(in_tt[src], cp, hp.cc, soc_c, pw_c);
-            o_soc[src] = soc_c;
-            o_pw[src] = pw_c;
-            o_ts[src] = soc_to_time<TYPE>(soc_c, cp);
+        const int fl = (TYPE == 0) ? n_in : true_in;
+        int as = (new_line + fl) < empties ? (new_line + fl) : empties;
+        new_line = new_line + fl - as;
+        new_line = new_line < kMaxLine ? new_line : kMaxLine;
+        for (int rr = 0; rr < as; rr++) {  // ascending slot order == ascending rank
+            lds_soc[lbase + rr] = arrive_soc_from(rs.normal_d(7.0, 3.0));
+            lds_lev[lbase + rr] = (uint32_t) rs.level();
+            int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
+            lds_late[lbase + rr] = (uint32_t) (late < 0 ? 0 : late);
         }
-        for (uint32_t i = (uint32_t) (BLOCK - 1 - tid); i < n_adm; i += BLOCK) {  // add_car, from the high waves
-            const int src = (int) q_new[i];
-            const int s_lane = src & 63, s_wave = src >> 6;
-            const int s_env = env_first + s_wave * upw + (s_lane >> logH);
-            const int s_hub_slot = (k ? hp.S[0] : 0) + (s_lane & (H - 1));
-            PhiloxCtx p2{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + s_env)};
-            const U4 o = p2.block(SITE_SOC, (uint32_t) s_hub_slot, 0);  // word 0 SoC, 1 target level, 2 extra stay
-            // everything add_car derives from the arrival SoC is tabulated per SoC level (Tables::newcar)
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const uint32_t lev = o.v[1] % 1000u;
-            f32x4 nw = ((CHUB_G(const f32x4)) tb.newcar[k])[o.v[0] >> 18];
-            float tt_ = tb.ttab[k][lev];
-            asm volatile("" : "+v"(nw), "+v"(tt_));  // both lookups in flight together
-            const int late = late_from_word(tb.late_thr, o.v[2]);
-            int stay = (int) ceilf(__fsub_rn(tt_, nw.y)) + late;  // calculate_min_charging_time + mk_late_time
-            stay = stay > 127 ? 127 : stay;
-            o_soc[src] = nw.x;
-            o_tt[src] = tt_;
-            o_ts[src] = nw.y;
-            o_pw[src] = nw.z;
-            o_stay[src] = (uint32_t) stay | (lev << 7);
-        }
-        __syncthreads();
-        if (adm) {
-            nc.soc = o_soc[tid];
-            nc.t_target = o_tt[tid];
-            nc.t_soc = o_ts[tid];
-            nc.power = o_pw[tid];
-            nc.stay = (int) (o_stay[tid] & 127u);
-            nc.lev = (int) (o_stay[tid] >> 7);
-        }
-        if (r.needs_step) {
-            r.soc_new = o_soc[tid];
-            r.power = o_pw[tid];
-            r.t_soc = o_ts[tid];
-            r.soc_dirty = true;
-        }
-    } else {
-        // COMPAT: the unit's first lane walks the two reference streams in the reference's order and
-        // parks the per-admission variates in LDS, indexed by admission rank.
-        float *lds_soc = lds_f;
-        uint32_t *lds_lev = lds_u, *lds_late = lds_u + BLOCK;
-        const int lbase = wave * 64 + (uiw << logH);
-        int2 fa = make_int2(0, 0);
-        int new_line = line;
-        if (unit_ok && slot == 0) {
-            CompatStream rs;
-            rs.load(cr, env);
-            int n_in;
-            if (RESET) {
-                const float cn = rs.normal_f((float) mu, 1.0f);
-                int temp = (int) roundf(cn);
-                temp = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
-                n_in = temp;
-            } else {
-                n_in = (int) tb.cnt[k][sa.t * kLevels + rs.level()];
-            }
-            int tline = 0;
-            for (int w = 0; w < line; w++) tline += (rs.level() >= (int) tb.thr_renege[w]) ? 1 : 0;
-            new_line = tline;
-            int true_in = 0;
-            for (int j = 0; j < n_in; j++) {
-                const int m = new_line + j;
-                const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
-                true_in += (rs.level() <= thr && j <= S) ? 1 : 0;
-            }
-            const int fl = (TYPE == 0) ? n_in : true_in;
-            int as = (new_line + fl) < empties ? (new_line + fl) : empties;
-            new_line = new_line + fl - as;
-            new_line = new_line < kMaxLine ? new_line : kMaxLine;
-            for (int rr = 0; rr < as; rr++) {  // ascending slot order == ascending rank
-                lds_soc[lbase + rr] = arrive_soc_from(rs.normal_d(7.0, 3.0));
-                lds_lev[lbase + rr] = (uint32_t) rs.level();
-                int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
-                lds_late[lbase + rr] = (uint32_t) (late < 0 ? 0 : late);
-            }
-            rs.store(cr, env);
-            fa = make_int2(fl, as);
-        }
-        const int leader = uiw << logH;
-        flow = __shfl(fa.x, leader);
-        assign = __shfl(fa.y, leader);
-        line = __shfl(new_line, leader);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        adm = empty && rank < assign;
-        if (adm) {
-            const int lev = (int) lds_lev[lbase + rank];
-            const float target = uniform_level(lev, 80.0f, 100.0f);
-            nc = make_car<TYPE>(lds_soc[lbase + rank], lev, soc_to_time<TYPE>(target, cp), (int) lds_late[lbase + rank], cp);
-        }
+        rs.store(cr, env);
+        fa = make_int2(fl, as);
     }
-
+    const int leader = uiw << logH;
+    const int flow = __shfl(fa.x, leader);
+    const int assign = __shfl(fa.y, leader);
+    line = __shfl(new_line, leader);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool adm = empty && rank < assign;
+    float nc_soc = 0.0f;
     if (adm) {
-        r.t_target = nc.t_target;
-        r.t_soc = nc.t_soc;
-        r.tl = nc.stay;
-        r.power = nc.power;
-        r.car = r.tl > 0;
+        const int lev = (int) lds_lev[lbase + rank];
+        const float target = uniform_level(lev, 80.0f, 100.0f);
+        const NewCar nc = make_car<TYPE>(lds_soc[lbase + rank], lev, soc_to_time<TYPE>(target, cp), (int) lds_late[lbase + rank], cp);
+        nc_soc = nc.soc;
+        t_target = nc.t_target;
+        t_soc = nc.t_soc;
+        tl = nc.stay;
+        power = nc.power;
+        car = tl > 0;
+        meta = nc.stay | (nc.lev << 7);
+    } else if (leave || RESET) {
+        meta = 0;
     }
 
-    // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572)
-    const bool urgent = r.car && must_charge(r.t_target, r.t_soc, r.tl);
-    float r_min, r_max, r_chg;
-    if (MODE == MODE_COMPAT) {
-        // the reference adds slot powers sequentially in f32 (CHS.hpp:1244-1255): same order, same roundings
-        const float v_min = urgent ? r.power : 0.0f, v_max = r.car ? r.power : 0.0f;
-        const float v_chg = r.charge ? r.power : 0.0f;
-        const int ubase = uiw << logH;
-        r_min = r_max = r_chg = 0.0f;
-        for (int i = 0; i < S; i++) {
-            r_max = __fadd_rn(r_max, __shfl(v_max, ubase + i));
-            r_min = __fadd_rn(r_min, __shfl(v_min, ubase + i));
-            r_chg = __fadd_rn(r_chg, __shfl(v_chg, ubase + i));
-        }
-    } else {
-        // production: order-independent sums -- every slot power truncated to a multiple of 2^-19 kW, integer butterfly
-        // over the unit's H lanes (DPP lane exchanges inside a 16-lane row, ds_bpermute across rows), one rounding to f32
-        const int q = (int) (r.power * 524288.0f);
-        int i_min = urgent ? q : 0, i_max = r.car ? q : 0, i_chg = r.charge ? q : 0;
-        if (H > 1) { i_min += dppi_xor1(i_min); i_max += dppi_xor1(i_max); i_chg += dppi_xor1(i_chg); }
-        if (H > 2) { i_min += dppi_xor2(i_min); i_max += dppi_xor2(i_max); i_chg += dppi_xor2(i_chg); }
-        if (H > 4) { i_min += dppi_mirror8(i_min); i_max += dppi_mirror8(i_max); i_chg += dppi_mirror8(i_chg); }
-        if (H > 8) { i_min += dppi_mirror16(i_min); i_max += dppi_mirror16(i_max); i_chg += dppi_mirror16(i_chg); }
-        if (H > 16) { i_min += __shfl_xor(i_min, 16); i_max += __shfl_xor(i_max, 16); i_chg += __shfl_xor(i_chg, 16); }
-        if (H > 32) { i_min += __shfl_xor(i_min, 32); i_max += __shfl_xor(i_max, 32); i_chg += __shfl_xor(i_chg, 32); }
-        r_min = fixed_to_kw(i_min);
-        r_max = fixed_to_kw(i_max);
-        r_chg = fixed_to_kw(i_chg);
+    // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572): the reference adds slot powers sequentially in f32
+    // (CHS.hpp:1244-1255): same order, same roundings
+    const bool urgent = car && must_charge(t_target, t_soc, tl);
+    const float v_min = urgent ? power : 0.0f, v_max = car ? power : 0.0f, v_chg = charge ? power : 0.0f;
+    float r_min = 0.0f, r_max = 0.0f, r_chg = 0.0f;
+    for (int i = 0; i < S; i++) {
+        r_max = __fadd_rn(r_max, __shfl(v_max, leader + i));
+        r_min = __fadd_rn(r_min, __shfl(v_min, leader + i));
+        r_chg = __fadd_rn(r_chg, __shfl(v_chg, leader + i));
     }
-    const int cars = __popcll(__ballot(r.car) & unit_mask);
+    const int cars = __popcll(__ballot(car) & unit_mask);
 
     if (valid) {
-        if (adm) r.stay = nc.stay | (nc.lev << 7);
-        else if (r.leave || RESET) r.stay = 0;
-        u32x4 hot;
-        hot.x = __float_as_uint(r.power);
-        hot.y = __float_as_uint(r.t_target);
-        hot.z = __float_as_uint(r.t_soc);
-        hot.w = (uint32_t) r.tl | (r.charge ? 128u : 0u) | ((uint32_t) r.stay << 8);
-        ((CHUB_G(u32x4)) sl.hot)[idx] = hot;
+        u32x4 h2;
+        h2.x = __float_as_uint(power);
+        h2.y = __float_as_uint(t_target);
+        h2.z = __float_as_uint(t_soc);
+        h2.w = (uint32_t) tl | (charge ? 128u : 0u) | ((uint32_t) meta << 8);
+        ((CHUB_G(u32x4)) sl.hot)[idx] = h2;
         // the only cold store: the arrival SoC of a new car (current SoC and target SoC are derived on demand)
-        if (adm) sl.init_soc[idx] = nc.soc;
+        if (adm) sl.init_soc[idx] = nc_soc;
     }
     if (unit_ok && slot == 0) {
         const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) cars << 16);
@@ -737,221 +598,388 @@ __device__ void slot_body(const HubParams &hp, const StepArgs &sa, const SlotArr
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Packed variant of the PHILOX step (no reset, no scalar-load mode): the workgroup's lanes map onto upb = BLOCK / S whole
-// units laid end to end (lane l <-> unit l / S, slot l % S), so a station of 20 piles fills 240 of 256 lanes instead of 160
-// and the workgroup's loads and stores are one contiguous run of memory.  Units may straddle a wave boundary, so what the
-// wave-local variant gets from ballots and butterflies goes through LDS here: every wave publishes its ballot of empty
-// slots (admission rank = empties of the unit in the previous wave + empties below the lane in its own wave, masks from
-// Tables::lane_map), and the station sums are integer LDS atomics (order-independent by definition, see slot_body): lanes
-// whose state is final after phase A add their share at once, the dense loops add the shares of the cars they process,
-// so the unit leaders can emit the station records right after the last barrier.  Same results as slot_body bit for bit.
-//
-// PackedArgs: what the first loads of a wave need, by value in the kernel arguments (one scalar load) instead of
-// behind the context pointer (three dependent ones) -- this kernel's waves spend most of their life waiting, not issuing.
-struct PackedArgs {
-    uint32_t S[2], upb[2], magic[2], base[2], type[2];
-    uint32_t n_envs, act_dim;
-    CHUB_G(uint32_t) hot;
-    CHUB_G(uint32_t) rec;
-    CHUB_G(uint64_t) pk;             // this step's packed station draws
-    CHUB_G(const float) actions;
-    CHUB_G(float) init_soc;
-    CHUB_G(const uint32_t) lane_map[2];
-};
-
-template <int TYPE, int BLOCK>
-__device__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const PackedArgs &pa, const SlotArrays &sl,
-                                 const Tables &tb, const int k, const uint32_t block_local, float *lds_f, uint32_t *lds_u,
-                                 uint64_t *s_ball, int *s_acc) {
+// ---------------------------------------------------------------------------------------- k_slot, PHILOX, wave-local units
+// The same phases on the 8-byte PHILOX slot state for what the packed kernel below does not cover: reset, the scalar-load
+// control mode, stations with 1-3 piles.  One unit = H = pow2 >= S_k lanes of one wave: ballot + prefix rank inside the wave,
+// integer DPP butterfly for the station sums.  Bit for bit the packed kernel's results (test_philox_other_slot_kernel runs
+// every step through this one).
+template <bool RESET, int BLOCK>
+__device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
+                               const Tables &tb, const int k, const int64_t block_local, float *lds_f, uint32_t *lds_u) {
+    constexpr int WAVES = BLOCK / 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int S = (int) pa.S[k], upb = (int) pa.upb[k];
-    const int N = (int) pa.n_envs;
-    const int u = (int) (((uint32_t) tid * pa.magic[k]) >> 16);  // tid / S (magic = 65536 / S + 1, checked on the host)
-    const int slot = tid - u * S;
-    const int env_first = (int) block_local * upb;
-    const int env = env_first + u;
-    const bool valid = u < upb && env < N;
-    const uint32_t idx = pa.base[k] + (uint32_t) env_first * (uint32_t) S + (uint32_t) tid;  // == base + env * S + slot
+    const int H = hp.H[k], S = hp.S[k], logH = hp.logH[k];
+    const int upw = 64 >> logH;
+    const int uiw = lane >> logH;
+    const int slot = lane & (H - 1);
+    const int64_t N = hp.n_envs;
+    const int env_first = (int) block_local * (WAVES * upw);
+    const int env = env_first + wave * upw + uiw;
+    const bool unit_ok = env < (int) N;
+    const bool valid = unit_ok && slot < S;
+    const uint64_t unit_mask = (H == 64) ? ~0ull : (((1ull << H) - 1ull) << (uiw << logH));
+    const uint32_t idx = (uint32_t) hp.base[k] + (uint32_t) env * (uint32_t) S + (uint32_t) slot;
     const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
-    const int S0 = k ? (int) pa.S[0] : 0;
-    const bool cp = hp.constant_charging != 0;
+    const int hub_slot = (k ? hp.S[0] : 0) + slot;
+    const bool fast = hp.type[k] == 0;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    CHUB_G(const float) cls = tb.cls[k];
 
-    // phase A loads: hot record, action, the unit's queue length and packed draws, the lane's ballot masks
-    // no zero fill for the lanes without a slot: what they hold is never used (their occupancy is forced to 0 below,
-    // their ballot masks to empty), and the fill would cost a dozen moves per wave
-    u32x4 hot, lm;
-    float act;
-    uint32_t line_in;
-    uint64_t pk_in;
-    asm volatile("" : "=v"(hot), "=v"(lm), "=v"(act), "=v"(line_in), "=v"(pk_in));
-    // every array reached from here is < 4 GiB (checked at create), so addresses are a uniform base + a 32-bit byte offset
-    // per lane: the loads and stores take the base from SGPRs and need no 64-bit address arithmetic
-#define CHUB_AT(T, base, byte_off) (*(CHUB_G(T)) ((CHUB_G(char)) (base) + (uint32_t) (byte_off)))
-    if (valid) {
-        hot = CHUB_AT(u32x4, pa.hot, idx << 4);
-        act = CHUB_AT(const float, pa.actions, ((uint32_t) env * pa.act_dim + (uint32_t) (S0 + slot)) << 2);
-        line_in = CHUB_AT(uint32_t, pa.rec, (sidx << 4) + 12u);
-        pk_in = CHUB_AT(uint64_t, pa.pk, sidx << 3);
-        lm = CHUB_AT(const u32x4, pa.lane_map[k], (uint32_t) tid << 4);
+    uint32_t line_in = 0;
+    uint64_t pk_in = 0;
+    u32x2 s2 = {0u, 0u};
+    float a = 0.0f;
+    if (unit_ok) {
+        if (!RESET) line_in = st.rec[4u * sidx + 3u];
+        pk_in = st.pk[sa.tick & 1u][sidx];
     }
-    uint32_t *q_cnt = lds_u;                   // [1]  new cars | charging cars << 16
-    uint32_t *q_new = lds_u + 2;               // [BLOCK]  tid of the admitted lane
-    uint32_t *q_chg = lds_u + 2 + BLOCK;       // [BLOCK]  tid of the charging lane
-    uint32_t *o_stay = lds_u + 2 + 2 * BLOCK;  // [BLOCK]  in: stay left of a charging car; out: stay of a new car
-    float *o_soc = lds_f;                      // [BLOCK] each, indexed by the owning lane's tid
-    float *o_tt = lds_f + BLOCK;               // in: t_target of a charging car; out: t_target of a new car
-    float *o_ts = lds_f + 2 * BLOCK;
-    float *o_pw = lds_f + 3 * BLOCK;
-    float *in_tt = lds_f + 4 * BLOCK;          // [BLOCK] curve time of a charging car
-    if (tid == 0) q_cnt[0] = 0;
-    for (int i = tid; i < 4 * upb; i += BLOCK) s_acc[i] = 0;
-    // all five requests are out before the first use of any of them (one memory round trip, not two); the LDS clearing
-    // above sits in front of this point, i.e. inside that round trip
-    asm volatile("" : "+v"(hot), "+v"(act), "+v"(line_in), "+v"(pk_in), "+v"(lm));
-
-    // ---- slot_advance (deferred form): urgency, feasibility / on-off, departure (CHS.hpp:1188-1202 / 1499-1513)
-    float power = __uint_as_float(hot.x), t_target = __uint_as_float(hot.y), t_soc = __uint_as_float(hot.z);
-    const uint32_t tlb = valid ? hot.w : 0u;
-    int tl = (int) (tlb & 127u), stay = (int) (tlb >> 8);  // stay: the meta bits (stay_time | target level << 7 | car_steps << 17)
+    if (!RESET && valid) {
+        s2 = ((CHUB_G(u32x2)) sl.hot)[idx];
+        a = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot];
+    }
+    uint32_t w0 = s2.x, w1 = s2.y;
+    int tl = ps_tl(w0);
     bool car = tl > 0;
-    const bool act_on = act >= kActOnThreshold;  // action_to_real (MGR:384-393)
-    const bool on = car && (act_on || must_charge(t_target, t_soc, tl));
-    const float step_tt = __fadd_rn(t_soc, 1.0f);
-    bool needs_step = on && tl > 1;
-    if (needs_step) stay += 1 << 17;  // one more car_step on this car's account
+    f32x4 row = {0.0f, 0.0f, 0.0f, 0.0f};
+    float t_target = 0.0f;
+    if (car) {
+        row = *(CHUB_G(const f32x4)) ((CHUB_G(const char)) cls + ((size_t) w1 * (kClsRow * 8u) + ps_n(w0) * 8u));
+        t_target = tb.ttab[k][ps_tgt(w0)];
+    }
+    float power = row.x, t_soc = row.y;
+    int on_override = -1;
+    if (!RESET && sa.load_mode)
+        on_override = load_mode_on<BLOCK>(hp, sa, st, k, env, unit_ok, valid, slot, car, power,
+                                          car ? emergency_of(t_target, t_soc, tl) : 0.0f, lds_f, lds_u) ? 1 : 0;
+    const bool on = on_override >= 0 ? (car && on_override != 0) : (car && (a >= kActOnThreshold || must_charge(t_target, t_soc, tl)));
+    const bool step = on && tl > 1;  // a car that leaves this step is wiped right after its car_step (CHS.hpp:1196-1201)
+    if (step) {  // car_step (CHS.hpp:900-905 / 1065-1070) = the next entry of the class row
+        power = row.z;
+        t_soc = row.w;
+        w0 += 1u << 13;
+    }
+    w0 &= ~64u;
     if (car) {  // remove_car (CHS.hpp:912-923 / 1077-1088)
         tl -= 1;
+        w0 -= 1u;
         if (tl <= 0) {
             car = false;
-            tl = 0;
-            stay = 0;
+            w0 = 0u;
             power = t_target = t_soc = 0.0f;
         }
     }
     const bool charge = on && car;
+    if (charge) w0 |= 64u;
+    if (RESET) w0 = 0u;
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): arrivals, renege, balk, admission
     const bool empty = valid && !car;
-    const uint64_t be = __ballot(empty);
-    if (lane == 0) s_ball[wave] = be;
-    __syncthreads();
-    const uint64_t mA = (uint64_t) lm.x | ((uint64_t) lm.y << 32), mB = (uint64_t) lm.z | ((uint64_t) lm.w << 32);
-    const bool b_prev = u * S < wave * 64;                       // the unit began in the previous wave
-    const int cntB = __popcll(s_ball[b_prev ? wave - 1 : wave + 1] & mB);  // its empties there (mB = 0: no lanes there)
-    const int empties = __popcll(be & mA) + cntB;
-    const int rank = prefix_count(be & mA) + (b_prev ? cntB : 0);
+    const uint64_t be = __ballot(empty) & unit_mask;
+    const int empties = __popcll(be);
+    const int rank = prefix_count(be);
     int line = (int) (line_in & 0xFFu);
     int flow = 0, assign = 0;
-    if (valid) {
-        const uint64_t pk = pk_in;
-        line = __popc((uint32_t) pk & ((1u << line) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
-        const int n_in = (int) (pk >> 10) & 15;
-        flow = (TYPE == 0) ? n_in : (int) ((pk >> (14 + 4 * line)) & 15);
+    if (unit_ok) {
+        if (RESET) {
+            // evs_reset: the unit's initial occupancy was drawn by k_reset_levels, one lane per unit, just before.  The fast
+            // station records the raw draw, which is negative for small stations (mu - 3 < 0, CHS.hpp:1617, 832-842):
+            // assign_car then admits nobody and the queue stays empty
+            flow = fast ? (int) (int8_t) (pk_in & 0xFFu) : (int) ((pk_in >> 8) & 0xFFu);
+        } else {
+            // this step's station-level draws were packed one launch ahead (draw_station_levels)
+            line = __popc((uint32_t) pk_in & ((1u << line) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
+            const int n_in = (int) (pk_in >> 10) & 15;
+            // the fast station records the un-thinned count (CHS.hpp:1617), the slow one what survives the balk
+            // pass given the queue length just computed (CHS.hpp:1297-1306)
+            flow = fast ? n_in : (int) ((pk_in >> (14 + 4 * line)) & 15);
+        }
         assign = (line + flow) < empties ? (line + flow) : empties;  // assign_car, CHS.hpp:417-430
         line = line + flow - assign;
         line = line < kMaxLine ? line : kMaxLine;
     }
     const bool adm = empty && rank < assign;
-    int *acc = s_acc + 4 * u;  // the unit's {min, charge, max power in 2^-19 kW, cars}
-    if (car && !needs_step) {  // state final: calculate_output share (CHS.hpp:1233-1261 / 1544-1572) goes in now
-        const int q = (int) (power * 524288.0f);
-        atomicAdd(acc + 2, q);
-        atomicAdd(acc + 3, 1);
-        if (must_charge(t_target, t_soc, tl)) atomicAdd(acc + 0, q);
-        if (charge) atomicAdd(acc + 1, q);
+    if (adm) {  // add_car (CHS.hpp:864-877 / 1029-1042): one Philox block per new car, word 0 SoC class, 1 target level, 2 extra stay
+        PhiloxCtx px{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env)};
+        const U4 o = px.block(SITE_SOC, (uint32_t) hub_slot, 0);
+        const uint32_t c = o.v[0] >> kSocLevelShift, lev = o.v[1] % 1000u;
+        const f32x2 e0 = *(CHUB_G(const f32x2)) ((CHUB_G(const char)) cls + (size_t) c * (kClsRow * 8u));
+        t_target = tb.ttab[k][lev];
+        const int late = late_from_word(tb.late_thr, o.v[2]);
+        int stay = (int) ceilf(__fsub_rn(t_target, e0.y)) + late;  // calculate_min_charging_time + mk_late_time
+        stay = stay > kMaxStay ? kMaxStay : stay;
+        power = e0.x;
+        t_soc = e0.y;
+        tl = stay;
+        car = tl > 0;
+        w0 = car ? ps_make(stay, lev) : 0u;
+        w1 = c;
     }
-    {
-        const uint64_t ba = __ballot(adm), bc = __ballot(needs_step);
-        const uint32_t both = (uint32_t) __popcll(ba) | ((uint32_t) __popcll(bc) << 16);
-        uint32_t base = 0;
-        if (lane == 0 && both) base = atomicAdd(&q_cnt[0], both);
-        base = __shfl(base, 0);
-        if (adm) q_new[(base & 0xFFFFu) + prefix_count(ba)] = (uint32_t) tid;
-        if (needs_step) {
-            q_chg[(base >> 16) + prefix_count(bc)] = (uint32_t) tid;
-            in_tt[tid] = step_tt;
-            o_tt[tid] = t_target;
-            o_stay[tid] = (uint32_t) tl;
+
+    // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572): order-independent sums -- every slot power truncated to a
+    // multiple of 2^-19 kW, integer butterfly over the unit's H lanes, one rounding to f32
+    const bool urgent = car && must_charge(t_target, t_soc, tl);
+    const int q = (int) (power * 524288.0f);
+    int i_min = urgent ? q : 0, i_max = car ? q : 0, i_chg = charge ? q : 0;
+    if (H > 1) { i_min += dppi_xor1(i_min); i_max += dppi_xor1(i_max); i_chg += dppi_xor1(i_chg); }
+    if (H > 2) { i_min += dppi_xor2(i_min); i_max += dppi_xor2(i_max); i_chg += dppi_xor2(i_chg); }
+    if (H > 4) { i_min += dppi_mirror8(i_min); i_max += dppi_mirror8(i_max); i_chg += dppi_mirror8(i_chg); }
+    if (H > 8) { i_min += dppi_mirror16(i_min); i_max += dppi_mirror16(i_max); i_chg += dppi_mirror16(i_chg); }
+    if (H > 16) { i_min += __shfl_xor(i_min, 16); i_max += __shfl_xor(i_max, 16); i_chg += __shfl_xor(i_chg, 16); }
+    if (H > 32) { i_min += __shfl_xor(i_min, 32); i_max += __shfl_xor(i_max, 32); i_chg += __shfl_xor(i_chg, 32); }
+    const int cars = __popcll(__ballot(car) & unit_mask);
+
+    if (valid) {
+        const u32x2 o2 = {w0, w1};
+        ((CHUB_G(u32x2)) sl.hot)[idx] = o2;
+    }
+    if (unit_ok && slot == 0) {
+        const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) cars << 16);
+        rec_store(st.rec, sidx, fixed_to_kw(i_min), fixed_to_kw(i_chg), fixed_to_kw(i_max), pkd);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_slot_packed: the PHILOX step (production).  The workgroup's lanes map onto upb = BLOCK / S whole units laid end to end
+// (lane l <-> unit l / S, slot l % S), so a station of 20 piles fills 240 of 256 lanes and the workgroup's loads and stores
+// are one contiguous run of memory.  Units may straddle a wave boundary, so every wave publishes its ballot of empty slots
+// in LDS (admission rank = empties of the unit in the previous wave + empties below the lane in its own wave, masks from
+// Tables::lane_map), and the station sums are integer LDS atomics (order-independent by definition).  A slot is empty after
+// this step iff its stay is over, which the 8-byte state says by itself: the ballots, the barrier, the renege / balk /
+// admission arithmetic and the queueing of the admitted lanes all run while the class-row reads are still in flight.  The
+// new cars of the workgroup (a handful) are served densely afterwards, one lane per car: one Philox block, two table reads,
+// the state written straight to memory.
+//
+// PackedArgs: what the first loads of a wave need, by value in the kernel arguments (one scalar load) instead of
+// behind the context pointer (three dependent ones).
+struct PackedArgs {
+    uint32_t S[2], upb[2], magic[2], base[2], type[2];
+    uint32_t n_envs, act_dim;
+    CHUB_G(uint32_t) state;          // [NS][2]
+    CHUB_G(uint32_t) rec;
+    CHUB_G(const uint64_t) pk;       // this step's packed station draws (TAPE: supplied by the caller)
+    CHUB_G(const float) actions;
+    CHUB_G(const float) cls[2];
+    CHUB_G(const float) ttab[2];
+    CHUB_G(const uint32_t) car_tape; // TAPE: [NS][2] per slot, used if the slot admits a car this step: class, level | late << 16
+};
+
+template <int BLOCK, int T, bool TAPE>
+__device__ __forceinline__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const PackedArgs &pa, const Tables &tb,
+                                                 const int k, const uint32_t block_local, uint32_t *q_cnt, uint32_t *q_new,
+                                                 uint64_t *s_ball, int *s_acc, uint32_t *s_unit, float *s_tt) {
+    // T slots per lane: the workgroup's BLOCK * T "virtual lanes" v = tid + j * BLOCK (j < T) are what is laid over the
+    // units; virtual wave = wave + j * (BLOCK / 64).  All T slots' loads are in flight together and the barriers are shared.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int WAVES = BLOCK / 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    // every per-station argument is selected from the two copies in SGPRs (indexing the argument block by k would be a
+    // dependent scalar load in front of the first vector load; the caller pinned both copies in SGPRs: otherwise the
+    // compiler turns the select of two loads into a load from a selected address, i.e. exactly that dependent load)
+#define PA(f) (k ? pa.f[1] : pa.f[0])
+    const int S = (int) PA(S), upb = (int) PA(upb);
+    const uint32_t magic = PA(magic);
+    const int N = (int) pa.n_envs;
+    const int env_first = (int) block_local * upb;
+    const uint32_t idx0 = PA(base) + (uint32_t) env_first * (uint32_t) S;
+    const int S0 = k ? (int) pa.S[0] : 0;
+    const bool fast = PA(type) == 0;
+    CHUB_G(const float) cls = PA(cls);
+    CHUB_G(const float) ttab = PA(ttab);
+    // every array reached from here is < 4 GiB (checked at create), so addresses are a uniform base + a 32-bit byte offset
+    // per lane: the loads and stores take the base from SGPRs and need no 64-bit address arithmetic
+#define CHUB_AT(T_, base, byte_off) (*(CHUB_G(T_)) ((CHUB_G(char)) (base) + (uint32_t) (byte_off)))
+
+    // phase A loads: slot state, action, the unit's queue length and packed draws, the lane's ballot masks.  No zero fill for
+    // the lanes without a slot: what they hold is never used (their occupancy is forced to 0 below, their masks to empty).
+    int u[T], slot[T];
+    bool valid[T];
+    uint32_t sidx[T];
+    u32x2 s2[T];
+    float act[T];
+    uint32_t line_in[T];
+    uint64_t pk_in[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        const int v = tid + j * BLOCK;
+        u[j] = (int) (((uint32_t) v * magic) >> 16);  // v / S (magic = 65536 / S + 1, checked on the host)
+        slot[j] = v - u[j] * S;
+        const int env = env_first + u[j];
+        valid[j] = u[j] < upb && env < N;
+        sidx[j] = (uint32_t) k * (uint32_t) N + (uint32_t) env;
+        asm volatile("" : "=v"(s2[j]), "=v"(act[j]), "=v"(line_in[j]), "=v"(pk_in[j]));
+        if (valid[j]) {
+            s2[j] = CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) v) << 3);
+            act[j] = CHUB_AT(const float, pa.actions, ((uint32_t) env * pa.act_dim + (uint32_t) (S0 + slot[j])) << 2);
+            line_in[j] = CHUB_AT(uint32_t, pa.rec, (sidx[j] << 4) + 12u);
+            pk_in[j] = CHUB_AT(const uint64_t, pa.pk, sidx[j] << 3);
         }
     }
-    __syncthreads();
-    const uint32_t qc = q_cnt[0];
-    const uint32_t n_adm = qc & 0xFFFFu, n_chg = qc >> 16;
-    for (uint32_t i = tid; i < n_chg; i += BLOCK) {  // car_step (CHS.hpp:900-905 / 1065-1070), from the low waves
-        const int src = (int) q_chg[i];
-        float soc_c, pw_c;
-        car_step_curves<TYPE>(in_tt[src], cp, hp.cc, soc_c, pw_c);
-        const float ts_c = soc_to_time<TYPE>(soc_c, cp);
-        o_pw[src] = pw_c;
-        o_ts[src] = ts_c;
-        int *ac = s_acc + 4 * (int) (((uint32_t) src * pa.magic[k]) >> 16);
-        const int q = (int) (pw_c * 524288.0f);
-        atomicAdd(ac + 2, q);
-        atomicAdd(ac + 3, 1);
-        atomicAdd(ac + 1, q);  // a car that was stepped is charging
-        if (must_charge(o_tt[src], ts_c, (int) o_stay[src])) atomicAdd(ac + 0, q);
+    // soc_to_time(target) of the 1000 target levels (CHS.hpp:35-44, 867): staged in LDS, where 64 scattered 4-byte reads cost a
+    // few cycles; as a second global gather they cost the vector cache as much as the class-row reads
+    float tt_stage[(kLevels + BLOCK - 1) / BLOCK];
+#pragma unroll
+    for (int i = 0; i < (kLevels + BLOCK - 1) / BLOCK; i++)
+        if (tid + i * BLOCK < kLevels) tt_stage[i] = CHUB_AT(const float, ttab, (uint32_t) (tid + i * BLOCK) << 2);
+    if (tid == 0) q_cnt[0] = 0;
+    for (int i = tid; i < 4 * upb; i += BLOCK) s_acc[i] = 0;
+
+    // ---- second round trip, only for the slots whose car stays: where it is on its curve (entries n, n + 1 of its class
+    // row) and soc_to_time(target).  A car that leaves this step is wiped right after its car_step (CHS.hpp:1196-1201): nothing
+    // of it is needed, and a slot is empty after remove_car (CHS.hpp:912-923 / 1077-1088) iff it had at most one slot of stay left
+    uint32_t w0[T];
+    int tl[T];
+    bool stays[T];
+    f32x4 row[T];
+    float t_target[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        asm volatile("" : "+v"(s2[j]));
+        w0[j] = valid[j] ? s2[j].x : 0u;
+        tl[j] = ps_tl(w0[j]);
+        stays[j] = tl[j] > 1;
+        asm volatile("" : "=v"(row[j]));
+        if (stays[j]) row[j] = CHUB_AT(const f32x4, cls, (s2[j].y << 8) + (ps_n(w0[j]) << 3));
     }
-    for (uint32_t i = (uint32_t) (BLOCK - 1 - tid); i < n_adm; i += BLOCK) {  // add_car, from the high waves
+#pragma unroll
+    for (int i = 0; i < (kLevels + BLOCK - 1) / BLOCK; i++)
+        if (tid + i * BLOCK < kLevels) s_tt[tid + i * BLOCK] = tt_stage[i];
+
+    // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627) while those are in flight
+    bool empty[T];
+    uint64_t be[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        empty[j] = valid[j] && !stays[j];
+        be[j] = __ballot(empty[j]);
+        if (lane == 0) s_ball[wave + j * WAVES] = be[j];
+    }
+    __syncthreads();
+    int line[T], flow[T];
+    bool adm[T];
+    uint64_t ba[T];
+    uint32_t n_push = 0;
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        const int vw = wave + j * WAVES;
+        // ballot masks of the unit's lanes [ub, ue) of the workgroup: in this (virtual) wave, and in the neighbouring wave the unit
+        // began in or runs over into (S <= 64: at most one of the two)
+        const int ub = u[j] * S - vw * 64, ue = ub + S;  // relative to this wave's lane 0
+        const bool b_prev = ub < 0, b_next = ue > 64;
+        const uint64_t mA = (~0ull >> (b_next ? 0 : 64 - ue)) & (~0ull << (b_prev ? 0 : ub));
+        const uint64_t mB = b_prev ? (~0ull << (64 + ub)) : (b_next ? (~0ull >> (128 - ue)) : 0ull);
+        const int cntB = __popcll(s_ball[b_prev ? vw - 1 : vw + 1] & mB);  // its empties there (mB = 0: no lanes there)
+        const int empties = __popcll(be[j] & mA) + cntB;
+        const int rank = prefix_count(be[j] & mA) + (b_prev ? cntB : 0);
+        line[j] = (int) (line_in[j] & 0xFFu);
+        flow[j] = 0;
+        int assign = 0;
+        if (valid[j]) {
+            const uint64_t pk = pk_in[j];
+            line[j] = __popc((uint32_t) pk & ((1u << line[j]) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
+            const int n_in = (int) (pk >> 10) & 15;
+            flow[j] = fast ? n_in : (int) ((pk >> (14 + 4 * line[j])) & 15);
+            assign = (line[j] + flow[j]) < empties ? (line[j] + flow[j]) : empties;  // assign_car, CHS.hpp:417-430
+            line[j] = line[j] + flow[j] - assign;
+            line[j] = line[j] < kMaxLine ? line[j] : kMaxLine;
+        }
+        adm[j] = empty[j] && rank < assign;
+        ba[j] = __ballot(adm[j]);
+        n_push += (uint32_t) __popcll(ba[j]);
+    }
+    if (n_push) {  // wave-uniform
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&q_cnt[0], n_push);
+        base = __shfl(base, 0);
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+            if (adm[j]) q_new[base + prefix_count(ba[j])] = (uint32_t) (tid + j * BLOCK);
+            base += (uint32_t) __popcll(ba[j]);
+        }
+    }
+
+    // ---- the occupied slots' step: urgency, feasibility / on-off, car_step, departure (CHS.hpp:1188-1202 / 1499-1513) and
+    // their share of calculate_output (CHS.hpp:1233-1261 / 1544-1572)
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        asm volatile("" : "+v"(row[j]), "+v"(act[j]));
+        t_target[j] = s_tt[ps_tgt(w0[j])];
+        int *acc = s_acc + 4 * u[j];  // the unit's {min, charge power | max power, cars}: two 64-bit LDS atomics per car
+        uint32_t w0n = 0u;
+        if (stays[j]) {
+            // action_to_real (MGR:384-393), judge_feasibility (CHS.hpp:1404-1413)
+            const bool on = act[j] >= kActOnThreshold || must_charge(t_target[j], row[j].y, tl[j]);
+            const float power = on ? row[j].z : row[j].x, t_soc = on ? row[j].w : row[j].y;  // car_step = the next entry of the class row
+            const int q = (int) (power * 524288.0f);
+            const bool urgent = must_charge(t_target[j], t_soc, tl[j] - 1);
+            w0n = (w0[j] & ~64u) - 1u + (on ? ((1u << 13) | 64u) : 0u);
+            atomicAdd((unsigned long long *) (acc + 2), (unsigned long long) (uint32_t) q | (1ull << 32));
+            if (on || urgent)
+                atomicAdd((unsigned long long *) acc,
+                          (unsigned long long) (urgent ? (uint32_t) q : 0u) | ((unsigned long long) (on ? (uint32_t) q : 0u) << 32));
+        }
+        if (valid[j] && !adm[j]) {
+            const u32x2 o2 = {w0n, s2[j].y};
+            CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) (tid + j * BLOCK)) << 3) = o2;
+        }
+        if (valid[j] && slot[j] == 0) s_unit[u[j]] = (uint32_t) line[j] | (((uint32_t) flow[j] & 0xFFu) << 8);
+    }
+    __syncthreads();
+    // Everything left -- the workgroup's new cars and, after them, the station records -- is the last wave's business: the
+    // other waves are done (their wave slots go to the next workgroup instead of idling at a third barrier through the
+    // Philox block and the two dependent table reads of the new cars)
+    if (wave != WAVES - 1) return;
+    // ---- add_car (CHS.hpp:864-877 / 1029-1042) for the workgroup's new cars, one lane per car, from the high waves
+    const uint32_t n_adm = q_cnt[0];
+    for (uint32_t i = (uint32_t) lane; i < n_adm; i += 64) {
         const int src = (int) q_new[i];
-        const int s_u = (int) (((uint32_t) src * pa.magic[k]) >> 16);
-        const int s_env = env_first + s_u;
-        const int s_hub_slot = S0 + (src - s_u * S);
-        PhiloxCtx p2{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + s_env)};
-        const U4 o = p2.block(SITE_SOC, (uint32_t) s_hub_slot, 0);  // word 0 SoC, 1 target level, 2 extra stay
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const uint32_t lev = o.v[1] % 1000u;
-        f32x4 nw = ((CHUB_G(const f32x4)) tb.newcar[k])[o.v[0] >> 18];
-        float tt_ = tb.ttab[k][lev];
-        asm volatile("" : "+v"(nw), "+v"(tt_));  // both lookups in flight together
-        const int late = late_from_word(tb.late_thr, o.v[2]);
-        int st_ = (int) ceilf(__fsub_rn(tt_, nw.y)) + late;  // calculate_min_charging_time + mk_late_time
-        st_ = st_ > 127 ? 127 : st_;
-        o_soc[src] = nw.x;
-        o_tt[src] = tt_;
-        o_ts[src] = nw.y;
-        o_pw[src] = nw.z;
-        o_stay[src] = (uint32_t) st_ | (lev << 7);
+        const int s_u = (int) (((uint32_t) src * magic) >> 16);
+        uint32_t c, lev;
+        int late;
+        if (TAPE) {
+            const u32x2 tp = CHUB_AT(const u32x2, pa.car_tape, (idx0 + (uint32_t) src) << 3);
+            c = tp.x;
+            lev = tp.y & 0xFFFFu;
+            late = (int) (tp.y >> 16);
+        } else {
+            PhiloxCtx p2{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env_first + s_u)};
+            const U4 o = p2.block(SITE_SOC, (uint32_t) (S0 + (src - s_u * S)), 0);  // word 0 SoC class, 1 target level, 2 extra stay
+            c = o.v[0] >> kSocLevelShift;
+            lev = o.v[1] % 1000u;
+            late = late_from_word(tb.late_thr, o.v[2]);
+        }
+        const f32x2 e0 = CHUB_AT(const f32x2, cls, c << 8);
+        const float tt_ = s_tt[lev];
+        int st_ = (int) ceilf(__fsub_rn(tt_, e0.y)) + late;  // calculate_min_charging_time + mk_late_time
+        st_ = st_ > kMaxStay ? kMaxStay : st_;
+        const u32x2 o2 = {st_ > 0 ? ps_make(st_, lev) : 0u, c};
+        CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) src) << 3) = o2;
         if (st_ > 0) {
             int *ac = s_acc + 4 * s_u;
-            const int q = (int) (nw.z * 524288.0f);
-            atomicAdd(ac + 2, q);
-            atomicAdd(ac + 3, 1);
-            if (must_charge(tt_, nw.y, st_)) atomicAdd(ac + 0, q);
+            const int q = (int) (e0.x * 524288.0f);
+            atomicAdd((unsigned long long *) (ac + 2), (unsigned long long) (uint32_t) q | (1ull << 32));
+            if (must_charge(tt_, e0.y, st_)) atomicAdd(ac, q);
         }
     }
-    __syncthreads();
-    float nc_soc = 0.0f;
-    if (adm) {
-        nc_soc = o_soc[tid];
-        t_target = o_tt[tid];
-        t_soc = o_ts[tid];
-        power = o_pw[tid];
-        stay = (int) o_stay[tid];  // stay_time | target level << 7, no car_steps yet
-        tl = stay & 127;
-    }
-    if (needs_step) {
-        power = o_pw[tid];
-        t_soc = o_ts[tid];
-    }
-    if (valid) {
-        u32x4 h2;
-        h2.x = __float_as_uint(power);
-        h2.y = __float_as_uint(t_target);
-        h2.z = __float_as_uint(t_soc);
-        h2.w = (uint32_t) tl | (charge ? 128u : 0u) | ((uint32_t) stay << 8);
-        CHUB_AT(u32x4, pa.hot, idx << 4) = h2;
-        // the only cold store: the arrival SoC of a new car (current SoC and target SoC are derived on demand)
-        if (adm) CHUB_AT(float, pa.init_soc, idx << 2) = nc_soc;
-        if (slot == 0) {
-            const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) acc[3] << 16);
+    // the wave's own LDS atomics above are in program order with the reads below; nothing else touches s_acc any more
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = lane; i < upb; i += 64) {  // one station record per unit: consecutive envs, one contiguous run of 16-byte stores
+        const int env = env_first + i;
+        if (env < N) {
+            const int *acc = s_acc + 4 * i;
+            const uint32_t pkd = s_unit[i] | ((uint32_t) acc[3] << 16);
             const u32x4 rv = {__float_as_uint(fixed_to_kw(acc[0])), __float_as_uint(fixed_to_kw(acc[1])),
                               __float_as_uint(fixed_to_kw(acc[2])), pkd};
-            CHUB_AT(u32x4, pa.rec, sidx << 4) = rv;
+            CHUB_AT(u32x4, pa.rec, ((uint32_t) k * (uint32_t) N + (uint32_t) env) << 4) = rv;
         }
     }
 #undef CHUB_AT
+#undef PA
 }
 
 // A station without piles still queues, reneges and balks (receive_car runs on it as on any other, CHS.hpp:1272-1316 /
@@ -974,22 +1002,29 @@ __device__ __forceinline__ void empty_station_body(const StepArgs &sa, const Pac
     *((CHUB_G(u32x4)) pa.rec + sidx) = rv;
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa, uint32_t nb0) {
-    __shared__ float lds_f[5 * BLOCK];
-    __shared__ uint32_t lds_u[3 * BLOCK + 2];
-    __shared__ uint64_t s_ball[BLOCK / 64 + 2];  // [1 + wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
-    __shared__ int s_acc[BLOCK];                 // upb <= BLOCK / 4 units x {min, charge, max power, cars}
-    const HubParams &hp = ctx->hp;
+template <int BLOCK, int T, bool TAPE>
+__global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in, uint32_t nb0) {
+    // all kernel arguments this wave needs, requested in ONE batch of scalar loads at its very start (the single asm
+    // statement makes every one of them live here), instead of in a chain of dependent loads in front of the first
+    // vector load
+    PackedArgs pa = pa_in;
+    asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.upb[0]), "+s"(pa.upb[1]), "+s"(pa.magic[0]), "+s"(pa.magic[1]),
+                      "+s"(pa.base[0]), "+s"(pa.base[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.act_dim),
+                      "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls[0]), "+s"(pa.cls[1]), "+s"(pa.ttab[0]), "+s"(pa.ttab[1]), "+s"(nb0));
+    __shared__ uint32_t q_new[BLOCK * T];
+    __shared__ uint32_t q_cnt[2];
+    __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];               // [1 + virtual wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
+    __shared__ __attribute__((aligned(16))) int s_acc[BLOCK * T];  // upb <= BLOCK * T / 4 units x {min, charge, max power, cars}
+    __shared__ uint32_t s_unit[BLOCK * T / 4];                    // per unit: line | flow << 8
+    __shared__ float s_tt[kLevels];                               // soc_to_time(target level) of this station's curve
     const uint32_t bid = blockIdx.x;
     const int k = (bid >= nb0) ? 1 : 0;
     const uint32_t bl = k ? bid - nb0 : bid;
-    if (pa.S[k] == 0) {
+    if ((k ? pa.S[1] : pa.S[0]) == 0) {
         empty_station_body<BLOCK>(sa, pa, k, bl);
         return;
     }
-    if (pa.type[k] == 0) slot_body_packed<0, BLOCK>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
-    else slot_body_packed<1, BLOCK>(hp, sa, pa, ctx->sl, ctx->tb, k, bl, lds_f, lds_u, s_ball + 1, s_acc);
+    slot_body_packed<BLOCK, T, TAPE>(ctx->hp, sa, pa, ctx->tb, k, bl, q_cnt, q_new, s_ball + 1, s_acc, s_unit, s_tt);
 }
 
 // What the tail's first loads need, by value in the kernel arguments: one scalar load at the start of the wave instead
@@ -1035,8 +1070,8 @@ __host__ __device__ inline TailArgs make_tail_args(const EnvArrays &ev, const St
 template <bool RESET, int MODE, int BLOCK>
 __global__ __launch_bounds__(BLOCK, 7) void k_slot(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0) {
     const HubParams &hp = ctx->hp;
-    __shared__ float lds_f[5 * BLOCK];
-    __shared__ uint32_t lds_u[3 * BLOCK + 2];
+    __shared__ float lds_f[BLOCK];
+    __shared__ uint32_t lds_u[2 * BLOCK];
     int k;
     int64_t bl;
     const int64_t bid = blockIdx.x;
@@ -1047,8 +1082,9 @@ __global__ __launch_bounds__(BLOCK, 7) void k_slot(const DevCtx *__restrict__ ct
         k = (bid >= nb0) ? 1 : 0;
         bl = k ? bid - nb0 : bid;
     }
-    if (hp.type[k] == 0) slot_body<0, RESET, MODE, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
-    else slot_body<1, RESET, MODE, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
+    if (MODE == MODE_PHILOX) slot_body_wave<RESET, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->tb, k, bl, lds_f, lds_u);
+    else if (hp.type[k] == 0) slot_body_compat<0, RESET, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
+    else slot_body_compat<1, RESET, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
 }
 
 // ----------------------------------------------------------------------------------------- k_env
@@ -1744,16 +1780,28 @@ __global__ void k_replay_soc(const DevCtx *__restrict__ ctx, float *out) {
     if (idx >= NS) return;
     const int k = idx >= hp.base[1] ? 1 : 0;
     const bool cp = hp.constant_charging != 0;
-    const uint32_t w = ctx->sl.hot[4 * idx + 3];
     float soc = 0.0f;
-    if ((w & 127u) != 0u) {
-        soc = ctx->sl.init_soc[idx];
-        const int n = (int) (w >> 25);
-        for (int i = 0; i < n; i++) {
-            float pw;
-            if (hp.type[k] == 0) car_step_curves<0>(__fadd_rn(soc_to_time<0>(soc, cp), 1.0f), cp, hp.cc, soc, pw);
-            else car_step_curves<1>(__fadd_rn(soc_to_time<1>(soc, cp), 1.0f), cp, hp.cc, soc, pw);
+    int n = 0;
+    bool car;
+    if (hp.rng_mode == MODE_PHILOX) {  // arrival SoC of the slot's class, car_steps from the state word
+        const uint32_t w0 = ctx->sl.hot[2 * idx], w1 = ctx->sl.hot[2 * idx + 1];
+        car = ps_tl(w0) != 0;
+        if (car) {
+            soc = ctx->tb.cls_soc0[k][w1];
+            n = (int) ps_n(w0);
         }
+    } else {
+        const uint32_t w = ctx->sl.hot[4 * idx + 3];
+        car = (w & 127u) != 0u;
+        if (car) {
+            soc = ctx->sl.init_soc[idx];
+            n = (int) (w >> 25);
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        float pw;
+        if (hp.type[k] == 0) car_step_curves<0>(__fadd_rn(soc_to_time<0>(soc, cp), 1.0f), cp, hp.cc, soc, pw);
+        else car_step_curves<1>(__fadd_rn(soc_to_time<1>(soc, cp), 1.0f), cp, hp.cc, soc, pw);
     }
     out[idx] = soc;
 }
@@ -1823,18 +1871,20 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
                 pa.magic[k] = hp.S[k] > 0 ? 65536u / (uint32_t) hp.S[k] + 1u : 0u;
                 pa.base[k] = (uint32_t) hp.base[k];
                 pa.type[k] = (uint32_t) hp.type[k];
-                pa.lane_map[k] = (CHUB_G(const uint32_t)) pp.lane_map[k];
+                pa.cls[k] = (CHUB_G(const float)) pp.cls[k];
+                pa.ttab[k] = (CHUB_G(const float)) pp.ttab[k];
             }
             pa.n_envs = (uint32_t) hp.n_envs;
             pa.act_dim = (uint32_t) hp.act_dim;
-            pa.hot = (CHUB_G(uint32_t)) pp.hot;
+            pa.state = (CHUB_G(uint32_t)) pp.hot;
             pa.rec = (CHUB_G(uint32_t)) pp.rec;
-            pa.pk = (CHUB_G(uint64_t)) pp.pk[sa.tick & 1u];
+            pa.pk = (CHUB_G(const uint64_t)) (sa.pk_tape ? sa.pk_tape : pp.pk[sa.tick & 1u]);
             pa.actions = (CHUB_G(const float)) sa.actions;
-            pa.init_soc = (CHUB_G(float)) pp.init_soc;
+            pa.car_tape = (CHUB_G(const uint32_t)) sa.car_tape;
             const uint32_t nb0 = (uint32_t) ((hp.n_envs + hp.upb[0] - 1) / hp.upb[0]);
             const uint32_t nb1 = (uint32_t) ((hp.n_envs + hp.upb[1] - 1) / hp.upb[1]);
-            hipExtLaunchKernelGGL((k_slot_packed<kSlotBlock>), dim3(nb0 + nb1), dim3(kSlotBlock), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0);
+            if (sa.car_tape) hipExtLaunchKernelGGL((k_slot_packed<kSlotBlock, kSlotsPerLane, true>), dim3(nb0 + nb1), dim3(kSlotBlock), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0);
+            else hipExtLaunchKernelGGL((k_slot_packed<kSlotBlock, kSlotsPerLane, false>), dim3(nb0 + nb1), dim3(kSlotBlock), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0);
         } else launch_slot_t<false, MODE_PHILOX>(hp, ctx, sa, stream, ev0, ev1);
         return;
     }

@@ -71,6 +71,7 @@ struct chub_env {
     double *d_exo_z;
     int32_t *d_exo_days;
     hipStream_t stream;
+    int tape_classes;   // PHILOX tape mode: caller-registered arrival-SoC classes so far
     // optional per-kernel timing with HIP events on the launch stream (chub_profile_*)
     std::vector<hipEvent_t> prof_events;
     size_t prof_used, prof_cap;
@@ -226,6 +227,22 @@ static void build_hy_table(const HubParams &hp, double *table) {
     table[101] = table[100];
 }
 
+// PHILOX: one class row = (power, t_soc) of a car that arrived with `soc` after n = 0 .. kClsRow-1 car_steps
+// (add_car CHS.hpp:864-877 / 1029-1042 for entry 0, car_step CHS.hpp:900-905 / 1065-1070 from entry to entry), evaluated with
+// the curve functions of chub_curves.h on the host
+static void build_class_row(bool fast, bool cp, const CurveConsts &cc, float soc, float *row /* [kClsRow][2] */) {
+    float t_soc = fast ? fast_soc_to_time(soc, cp) : slow_soc_to_time(soc, cp);
+    float power = fast ? fast_time_to_power(t_soc, cp) : slow_time_to_power(t_soc, cp);
+    for (int n = 0; n < kClsRow; n++) {
+        row[2 * n] = power;
+        row[2 * n + 1] = t_soc;
+        const float tt = t_soc + 1.0f;
+        const float soc_n = fast ? fast_time_to_soc(tt, cp, cc) : slow_time_to_soc(tt, cp, cc);
+        power = fast ? fast_time_to_power(tt, cp) : slow_time_to_power(tt, cp);
+        t_soc = fast ? fast_soc_to_time(soc_n, cp) : slow_soc_to_time(soc_n, cp);
+    }
+}
+
 template <typename T>
 static int fetch(std::vector<T> &dst, const T *src, size_t count) {
     dst.resize(count);
@@ -240,11 +257,12 @@ static PackedPtrs packed_ptrs(const chub_env *e) {
     p.st = &e->st;
     p.hot = (uint32_t *) e->sl.hot;
     p.rec = (uint32_t *) e->st.rec;
-    p.init_soc = (float *) e->sl.init_soc;
+    p.cls[0] = e->tb.cls[0];
+    p.cls[1] = e->tb.cls[1];
+    p.ttab[0] = e->tb.ttab[0];
+    p.ttab[1] = e->tb.ttab[1];
     p.pk[0] = (uint64_t *) e->st.pk[0];
     p.pk[1] = (uint64_t *) e->st.pk[1];
-    p.lane_map[0] = e->tb.lane_map[0];
-    p.lane_map[1] = e->tb.lane_map[1];
     return p;
 }
 
@@ -358,7 +376,8 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     {   // arena: generous upper bound of everything allocated below (telemetry buffers come later, separately)
         const size_t S_tot = (size_t) (cfg->station_list[0] + cfg->station_list[1]);
         const size_t per_env = S_tot * 40 + 1024 + (size_t) qcap * 16 + (rng_mode == CHUB_RNG_COMPAT ? 102 * 8 + 33 * 4 + 256 : 0);
-        const size_t want = (size_t) n_envs * per_env + ((size_t) 8 << 20);
+        const size_t want = (size_t) n_envs * per_env + ((size_t) 8 << 20) +
+                            (rng_mode == CHUB_RNG_PHILOX ? 2 * ((size_t) kSocLevels + kTapeClasses + 2) * (kClsRow * 8 + 4) : 0);
         void *q = nullptr;
         if (!opt.no_arena && hipMalloc(&q, want) == hipSuccess) {
             e->arena = (char *) q;
@@ -538,62 +557,45 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     }
     std::vector<double> sin96(96);
     for (int t = 0; t < 96; t++) sin96[t] = sin((2 * M_PI / 96) * (double) t);  // np.sin(k * time), MGR:319-320
-    std::vector<float> ttab[2], newcar[2];
+    std::vector<float> ttab[2], cls[2], cls_soc0[2];
+    const size_t n_classes = (size_t) kSocLevels + kTapeClasses;
     for (int s = 0; s < 2; s++) {
         const bool fast = hp.type[s] == CHUB_FAST, cpw = hp.constant_charging != 0;
         ttab[s].resize(kLevels);
+        float tt_max = 0.0f;
         for (int k = 0; k < kLevels; k++) {
             float tr = (float) k / 999.0f;
             float target = tr * (100.0f - 80.0f) + 80.0f;  // uniform_rand(80, 100), CHS.hpp:35-44
             ttab[s][k] = fast ? fast_soc_to_time(target, cpw) : slow_soc_to_time(target, cpw);
+            tt_max = ttab[s][k] > tt_max ? ttab[s][k] : tt_max;
         }
-        // PHILOX: what add_car (CHS.hpp:864-877 / 1029-1042) derives from the arrival SoC, per SoC level: level l sits at
-        // probability (l + 0.5) / kSocLevels of the tabulated inverse CDF (cell l >> 2, fraction ((l & 3) + 0.5) / 4)
-        newcar[s].assign(4 * (size_t) kSocLevels, 0.0f);
+        if (rng_mode != CHUB_RNG_PHILOX) continue;
+        // PHILOX: the arrival SoC takes one of kSocLevels = 2048 equiprobable classes: class l sits at probability (l + 0.5) /
+        // 2048 of the tabulated inverse CDF of clip(N(7,3),1,10), i.e. exactly at its node 2 l + 1 (mk_soc,
+        // CHS.hpp:804-814); its row holds where the car is on its curve after every number of car_steps it can take
+        cls[s].assign((n_classes + 1) * (size_t) kClsRow * 2, 0.0f);  // + one row of padding: entry n + 1 is read with entry n
+        cls_soc0[s].assign(n_classes, 0.0f);
+        float ts_min = 1e30f;
         for (int l = 0; l < kSocLevels; l++) {
-            const int idx = l >> 2;
-            const float frac = ((float) (l & 3) + 0.5f) * 0.25f;
-            const float a = icdf[idx], b = icdf[idx + 1];
-            const float diff = b - a;
-            const float prod = diff * frac;
-            float d = a + prod;
-            if ((double) d < 1.0) d = 1.0f;  // mk_soc, CHS.hpp:804-814
+            float d = icdf[2 * l + 1];
+            if ((double) d < 1.0) d = 1.0f;
             else if ((double) d > 10.0) d = 10.0f;
             const float soc = (float) (75.0 - 5.0 * (double) d);
-            const float t_soc = fast ? fast_soc_to_time(soc, cpw) : slow_soc_to_time(soc, cpw);
-            newcar[s][4 * l] = soc;
-            newcar[s][4 * l + 1] = t_soc;
-            newcar[s][4 * l + 2] = fast ? fast_time_to_power(t_soc, cpw) : slow_time_to_power(t_soc, cpw);
+            cls_soc0[s][l] = soc;
+            float *row = &cls[s][(size_t) l * kClsRow * 2];
+            build_class_row(fast, cpw, hp.cc, soc, row);
+            ts_min = row[1] < ts_min ? row[1] : ts_min;
         }
+        // stay_time = ceil(soc_to_time(target) - soc_to_time(soc)) + late (late <= 15): the state word has 6 bits for it and a
+        // class row kClsRow entries (a car takes at most stay_time - 1 car_steps)
+        const int max_stay = (int) ceilf(tt_max - ts_min) + 15;
+        if (max_stay > kClsRow) return bail(fail(CHUB_ERR_UNSUPPORTED, "charge curves yield stays longer than a class row"));
     }
-    // packed slot kernel (k_slot_packed): lanes of a workgroup laid over whole units end to end
-    std::vector<uint32_t> lane_map[2];
+    e->tape_classes = 0;
+    // packed slot kernel (k_slot_packed): the workgroup's virtual lanes laid over whole units end to end
     {
-        const int pb = 256;  // kSlotBlock of chub_kernels.hip
-        bool tighter = false;
-        for (int s = 0; s < 2; s++) {
-            const int S = hp.S[s];
-            hp.upb[s] = S > 0 ? pb / S : pb;  // a station without piles: one lane per env (empty_station_body)
-            if (S > 0 && hp.upb[s] > (pb / 64) * (64 / hp.H[s])) tighter = true;
-            lane_map[s].assign((size_t) pb * 4, 0u);
-            for (int l = 0; l < pb && S > 0; l++) {
-                const int u = l / S, slot = l % S, w = l / 64;
-                if (u >= hp.upb[s]) continue;
-                const int ub = u * S, ue = ub + S;  // the unit's lanes [ub, ue) of the workgroup
-                auto mask_in = [&](int wv) -> uint64_t {
-                    const int lo = ub > wv * 64 ? ub : wv * 64, hi = ue < wv * 64 + 64 ? ue : wv * 64 + 64;
-                    if (hi <= lo) return 0;
-                    const int n = hi - lo;
-                    return (n == 64 ? ~0ull : ((1ull << n) - 1ull)) << (lo - wv * 64);
-                };
-                const int w_first = ub / 64, w_last = (ue - 1) / 64;
-                const int wb = (w_first == w_last) ? w : (w == w_first ? w_last : w_first);
-                const uint64_t mA = mask_in(w), mB = (wb == w) ? 0 : mask_in(wb);
-                uint32_t *m = &lane_map[s][(size_t) l * 4];
-                m[0] = (uint32_t) mA; m[1] = (uint32_t) (mA >> 32); m[2] = (uint32_t) mB; m[3] = (uint32_t) (mB >> 32);
-                (void) slot;
-            }
-        }
+        const int pb = kSlotBlock * kSlotsPerLane;
+        for (int s = 0; s < 2; s++) hp.upb[s] = hp.S[s] > 0 ? pb / hp.S[s] : kSlotBlock;  // no piles: one lane per env (empty_station_body)
         bool magic_ok = true;  // the kernel divides lane numbers by S with a 16-bit reciprocal
         for (int s = 0; s < 2 && magic_ok; s++)
             for (int l = 0; l < pb && hp.S[s] > 0; l++)
@@ -601,7 +603,6 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         hp.packed = (rng_mode == CHUB_RNG_PHILOX && (hp.S[0] >= 4 || hp.S[0] == 0) && (hp.S[1] >= 4 || hp.S[1] == 0) && magic_ok &&
                      (uint64_t) n_envs * (uint64_t) (hp.S[0] + hp.S[1] + 2) * 16u < ((uint64_t) 1 << 32) &&  // 32-bit byte offsets
                      opt.slot_kernel != 1) ? 1 : 0;
-        (void) tighter;
     }
     build_hy_table(hp, e->hy_table);
     std::vector<double> hy_v(e->hy_table, e->hy_table + 102);
@@ -623,16 +624,23 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if ((rc = dev_upload(e, &e->tb.sin96, sin96))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.ttab[0], ttab[0]))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.ttab[1], ttab[1]))) return bail(rc);
-    if ((rc = dev_upload(e, &e->tb.lane_map[0], lane_map[0]))) return bail(rc);
-    if ((rc = dev_upload(e, &e->tb.lane_map[1], lane_map[1]))) return bail(rc);
-    if ((rc = dev_upload(e, &e->tb.newcar[0], newcar[0]))) return bail(rc);
-    if ((rc = dev_upload(e, &e->tb.newcar[1], newcar[1]))) return bail(rc);
+    e->tb.cls[0] = e->tb.cls[1] = e->tb.cls_soc0[0] = e->tb.cls_soc0[1] = nullptr;
+    if (rng_mode == CHUB_RNG_PHILOX)
+        for (int s = 0; s < 2; s++) {
+            if ((rc = dev_upload(e, &e->tb.cls[s], cls[s]))) return bail(rc);
+            if ((rc = dev_upload(e, &e->tb.cls_soc0[s], cls_soc0[s]))) return bail(rc);
+        }
 
     // ---- state in HBM
     const size_t N = (size_t) n_envs, NS = N * (size_t) (hp.S[0] + hp.S[1]);
 #define ALLOC(ptr, count)                                        \
     if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
-    ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.init_soc, NS);
+    e->sl.init_soc = nullptr;
+    if (rng_mode == CHUB_RNG_PHILOX) {
+        ALLOC(e->sl.hot, 2 * NS);  // 8-byte slot state
+    } else {
+        ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.init_soc, NS);
+    }
     ALLOC(e->st.rec, 8 * N); ALLOC(e->st.pk[0], 2 * N); ALLOC(e->st.pk[1], 2 * N);
     ALLOC(e->ev.cap, N); ALLOC(e->ev.store_soc, N); ALLOC(e->ev.ou, 3 * N); ALLOC(e->ev.price_noise, N);
     ALLOC(e->ev.re_pv, N); ALLOC(e->ev.re_wd, N); ALLOC(e->ev.price_next, N);
@@ -870,7 +878,8 @@ int chub_get_slots(chub_env *e, float *out) {
     HIP_TRY(hipDeviceSynchronize());
     const HubParams &hp = e->hp;
     const size_t N = (size_t) hp.n_envs, S = (size_t) (hp.S[0] + hp.S[1]), NS = N * S;
-    std::vector<float> soc, init_soc;
+    const bool philox = hp.rng_mode == CHUB_RNG_PHILOX;
+    std::vector<float> soc, init_soc, cls[2], soc0[2], ttab[2];
     std::vector<uint32_t> hot;
     int rc;
     if ((rc = sync_ctx(e, nullptr))) return rc;
@@ -882,20 +891,40 @@ int chub_get_slots(chub_env *e, float *out) {
         (void) hipFree(d_soc);
         if (rc) return rc;
     }
-    if ((rc = fetch(init_soc, (const float *) e->sl.init_soc, NS)) || (rc = fetch(hot, (const uint32_t *) e->sl.hot, 4 * NS)))
+    if ((rc = fetch(hot, (const uint32_t *) e->sl.hot, (philox ? 2 : 4) * NS))) return rc;
+    if (philox) {
+        const size_t n_classes = (size_t) kSocLevels + kTapeClasses;
+        for (int k = 0; k < 2; k++)
+            if ((rc = fetch(cls[k], e->tb.cls[k], (n_classes + 1) * kClsRow * 2)) || (rc = fetch(soc0[k], e->tb.cls_soc0[k], n_classes)) ||
+                (rc = fetch(ttab[k], e->tb.ttab[k], (size_t) kLevels)))
+                return rc;
+    } else if ((rc = fetch(init_soc, (const float *) e->sl.init_soc, NS))) {
         return rc;
+    }
     for (size_t env = 0; env < N; env++) {
         float *o = out + env * 9 * S;
         for (int k = 0; k < 2; k++) {
             const size_t n = (size_t) hp.S[k];
             for (size_t i = 0; i < n; i++) {
                 const size_t idx = (size_t) hp.base[k] + env * n + i;
-                float power, t_target, t_soc;
-                memcpy(&power, &hot[4 * idx + 0], 4);
-                memcpy(&t_target, &hot[4 * idx + 1], 4);
-                memcpy(&t_soc, &hot[4 * idx + 2], 4);
-                const uint32_t w = hot[4 * idx + 3];
-                const int left = (int) (w & 127u), stay = (int) ((w >> 8) & 127u), lev = (int) ((w >> 15) & 1023u);
+                float power = 0, t_target = 0, t_soc = 0, arrive = 0;
+                int left, stay, lev;
+                bool chg;
+                if (philox) {  // 8-byte state: everything else comes from the class row (see chub_kernels.hip)
+                    const uint32_t w0 = hot[2 * idx], w1 = hot[2 * idx + 1];
+                    left = (int) (w0 & 63u); chg = (w0 & 64u) != 0; stay = (int) ((w0 >> 7) & 63u); lev = (int) ((w0 >> 18) & 1023u);
+                    if (left > 0) {
+                        const size_t at = ((size_t) w1 * kClsRow + ((w0 >> 13) & 31u)) * 2;
+                        power = cls[k][at]; t_soc = cls[k][at + 1]; t_target = ttab[k][lev]; arrive = soc0[k][w1];
+                    }
+                } else {
+                    memcpy(&power, &hot[4 * idx + 0], 4);
+                    memcpy(&t_target, &hot[4 * idx + 1], 4);
+                    memcpy(&t_soc, &hot[4 * idx + 2], 4);
+                    const uint32_t w = hot[4 * idx + 3];
+                    left = (int) (w & 127u); chg = (w & 128u) != 0; stay = (int) ((w >> 8) & 127u); lev = (int) ((w >> 15) & 1023u);
+                    arrive = init_soc[idx];
+                }
                 const bool car = left > 0;
                 const float tr = (float) lev / 999.0f;
                 const float target = tr * (100.0f - 80.0f) + 80.0f;  // uniform_rand(80, 100) at level lev, CHS.hpp:35-44
@@ -905,11 +934,11 @@ int chub_get_slots(chub_env *e, float *out) {
                     if (need > 0) em = ((float) left <= ceilf(need)) ? 10.0f : (float) pow((double) (need / (float) left), 2);
                 }
                 o[0 * n + i] = car ? 1.0f : 0.0f;
-                o[1 * n + i] = (w & 128u) ? 1.0f : 0.0f;
+                o[1 * n + i] = chg ? 1.0f : 0.0f;
                 o[2 * n + i] = em;
-                o[3 * n + i] = power;
+                o[3 * n + i] = car ? power : 0.0f;
                 o[4 * n + i] = car ? soc[idx] : 0.0f;
-                o[5 * n + i] = car ? init_soc[idx] : 0.0f;
+                o[5 * n + i] = car ? arrive : 0.0f;
                 o[6 * n + i] = car ? target : 0.0f;
                 o[7 * n + i] = car ? (float) stay : -1.0f;
                 o[8 * n + i] = car ? (float) (stay - left) : -1.0f;

@@ -303,20 +303,12 @@ float orc_soc_from_word(const orc_tables *t, uint32_t w) {
     return soc_from_experience(d);
 }
 
-/* PHILOX mode, EV arrivals: the arrival SoC takes one of 16384 equiprobable levels (the top 14 bits of the word):
- * level l sits at probability (l + 0.5) / 16384 of the same tabulated inverse CDF -- cell l >> 2, fraction
- * ((l & 3) + 0.5) / 4.  A finite level set lets an implementation tabulate everything add_car derives from the
- * arrival SoC (curve time, initial power) once per station. */
-float orc_soc_level_value(const orc_tables *t, uint32_t level) {
-    uint32_t idx = level >> 2;
-    float frac = ((float) (level & 3u) + 0.5f) * 0.25f;
-    float a = t->soc_d_icdf[idx], b = t->soc_d_icdf[idx + 1];
-    float diff = b - a;
-    float prod = diff * frac;
-    float d = a + prod;
-    return soc_from_experience(d);
-}
-float orc_soc_level_from_word(const orc_tables *t, uint32_t w) { return orc_soc_level_value(t, w >> 18); }
+/* PHILOX mode, EV arrivals: the arrival SoC takes one of ORC_SOC_LEVELS = 2048 equiprobable levels (the top 11 bits of
+ * the word): level l sits at probability (l + 0.5) / 2048 of the same tabulated inverse CDF, i.e. exactly at its node
+ * 2 l + 1.  A finite level set lets an implementation tabulate a car's whole charging history (curve time and power after
+ * every number of car_steps) once per level and station. */
+float orc_soc_level_value(const orc_tables *t, uint32_t level) { return soc_from_experience(t->soc_d_icdf[2u * level + 1u]); }
+float orc_soc_level_from_word(const orc_tables *t, uint32_t w) { return orc_soc_level_value(t, w >> 21); }
 
 /* CHS:816-830 mk_late_time -- both pile classes pass "slow" (CHS:869, CHS:1034): max(0, round(N(2,2))) */
 int orc_mk_late_time(orc_rng *r) {

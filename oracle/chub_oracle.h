@@ -28,6 +28,7 @@ extern "C" {
 #define ORC_MAX_PILES 256
 #define ORC_CDF_ROWS 96
 #define ORC_CDF_COLS 301
+#define ORC_SOC_LEVELS 2048 /* PHILOX mode: equiprobable levels of the EV arrival SoC */
 #define ORC_QCAP 1024 /* FCEV waiting list: the reference list is unbounded (HYD:264-265); this plain array is long enough for every test (saturating, flagged in q_overflow: tests assert the flag stays 0) */
 
 enum { ORC_FAST = 0, ORC_SLOW = 1 };
@@ -147,7 +148,7 @@ int orc_draw_k(orc_rng *r, int tag, int index, int j);
 float orc_mk_soc(orc_rng *r);                                          /* CHS:804-814, reference streams */
 int orc_mk_late_time(orc_rng *r);                                      /* CHS:816-830 ("slow" law), reference streams */
 float orc_soc_from_word(const orc_tables *t, uint32_t w);              /* PHILOX mode: mk_soc from one 32-bit uniform (FCEV) */
-float orc_soc_level_value(const orc_tables *t, uint32_t level);       /* PHILOX mode: EV arrival SoC of level 0..16383 */
+float orc_soc_level_value(const orc_tables *t, uint32_t level);       /* PHILOX mode: EV arrival SoC of level 0..ORC_SOC_LEVELS-1 */
 float orc_soc_level_from_word(const orc_tables *t, uint32_t w);       /* PHILOX mode: EV arrival SoC from one uniform */
 int orc_late_from_word(const orc_tables *t, uint32_t w);               /* PHILOX mode: mk_late_time from one uniform */
 int orc_init_station_car_number(orc_rng *r, const orc_tables *t, int station, int mu); /* CHS:832-842 */

@@ -96,16 +96,16 @@ def test_philox_sampling_tables_match_reference_distributions():
     rsoc = np.array([orc.orc_mk_soc(g) for _ in range(100000)])
     rlate = np.array([orc.orc_mk_late_time(g) for _ in range(100000)])
     orc.orc_rng_free(g)
-    lsoc = np.array([orc.orc_soc_level_from_word(t, int(x)) for x in w[:100000]])   # EV arrivals: 16384 levels
+    lsoc = np.array([orc.orc_soc_level_from_word(t, int(x)) for x in w[:100000]])   # EV arrivals: 2048 levels
     qs = [0.05, 0.25, 0.5, 0.75, 0.9]
     for got in (soc, lsoc):
         assert got.min() >= 25.0 and got.max() <= 70.0
         assert np.allclose(np.quantile(got, qs), np.quantile(rsoc, qs), atol=0.35)
         assert abs((got == 25.0).mean() - (rsoc == 25.0).mean()) < 0.005   # clip mass at driver_experience = 10
         assert abs((got == 70.0).mean() - (rsoc == 70.0).mean()) < 0.005   # ... and = 1
-    lv = np.array([orc.orc_soc_level_value(t, l) for l in range(16384)])
+    lv = np.array([orc.orc_soc_level_value(t, l) for l in range(2048)])
     assert np.all(np.diff(lv) <= 0) and lv[0] == 70.0 and lv[-1] == 25.0   # monotone in the level, clipped ends
-    assert np.abs(lsoc - soc).max() < 0.05                                 # level = the continuous variate, quantised
+    assert np.abs(lsoc - soc).max() < 0.1                                  # level = the continuous variate, quantised
     for j in range(8):
         assert abs((late == j).mean() - (rlate == j).mean()) < 0.006, j
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
