@@ -72,6 +72,9 @@ struct chub_env {
     int32_t *d_exo_days;
     hipStream_t stream;
     int tape_classes;   // PHILOX tape mode: caller-registered arrival-SoC classes so far
+    std::vector<float> h_cls[2], h_soc0[2], h_ttab[2];  // host copies of the class tables (introspection)
+    const uint64_t *tape_pk;   // set for the duration of chub_step_tape
+    const uint32_t *tape_car;
     // optional per-kernel timing with HIP events on the launch stream (chub_profile_*)
     std::vector<hipEvent_t> prof_events;
     size_t prof_used, prof_cap;
@@ -592,6 +595,8 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         if (max_stay > kClsRow) return bail(fail(CHUB_ERR_UNSUPPORTED, "charge curves yield stays longer than a class row"));
     }
     e->tape_classes = 0;
+    e->tape_pk = nullptr;
+    e->tape_car = nullptr;
     // packed slot kernel (k_slot_packed): the workgroup's virtual lanes laid over whole units end to end
     {
         const int pb = kSlotBlock * kSlotsPerLane;
@@ -629,6 +634,9 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         for (int s = 0; s < 2; s++) {
             if ((rc = dev_upload(e, &e->tb.cls[s], cls[s]))) return bail(rc);
             if ((rc = dev_upload(e, &e->tb.cls_soc0[s], cls_soc0[s]))) return bail(rc);
+            e->h_cls[s] = cls[s];
+            e->h_soc0[s] = cls_soc0[s];
+            e->h_ttab[s] = ttab[s];
         }
 
     // ---- state in HBM
@@ -810,6 +818,8 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
     sa.done = d_done;
     sa.done_f32 = d_done_f32;
     sa.load_mode = load_mode;
+    sa.pk_tape = e->tape_pk;
+    sa.car_tape = e->tape_car;
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
     bool prof = e->prof_on && e->prof_used < e->prof_cap;
@@ -863,6 +873,123 @@ int chub_step(chub_env *e, const float *actions, const double *exo_z, float *obs
     return CHUB_OK;
 }
 
+// ---- tape mode (parity instrument, PHILOX handles): recorded decisions replayed through the production kernels -------
+int chub_tape_register_soc(chub_env *e, const float *soc, int32_t count, uint32_t *class_ids) {
+    if (!e || !soc || !class_ids || count < 0) return fail(CHUB_ERR_ARG, "bad argument");
+    if (e->hp.rng_mode != CHUB_RNG_PHILOX) return fail(CHUB_ERR_ARG, "tape mode needs a PHILOX handle");
+    if (e->tape_classes + count > kTapeClasses) return fail(CHUB_ERR_UNSUPPORTED, "too many tape classes");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const bool cp = e->hp.constant_charging != 0;
+    std::vector<float> rows((size_t) count * kClsRow * 2);
+    const size_t first = (size_t) kSocLevels + (size_t) e->tape_classes;
+    for (int k = 0; k < 2; k++) {
+        const bool fast = e->hp.type[k] == CHUB_FAST;
+        for (int i = 0; i < count; i++) build_class_row(fast, cp, e->hp.cc, soc[i], &rows[(size_t) i * kClsRow * 2]);
+        if (count) {
+            HIP_TRY(hipMemcpy((void *) (e->tb.cls[k] + first * kClsRow * 2), rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy((void *) (e->tb.cls_soc0[k] + first), soc, (size_t) count * sizeof(float), hipMemcpyHostToDevice));
+            memcpy(&e->h_cls[k][first * kClsRow * 2], rows.data(), rows.size() * sizeof(float));
+            memcpy(&e->h_soc0[k][first], soc, (size_t) count * sizeof(float));
+        }
+    }
+    for (int i = 0; i < count; i++) class_ids[i] = (uint32_t) (first + (size_t) i);
+    e->tape_classes += count;
+    return CHUB_OK;
+}
+
+int chub_set_slots(chub_env *e, const int32_t *rows) {
+    if (!e || !rows) return fail(CHUB_ERR_ARG, "null argument");
+    if (e->hp.rng_mode != CHUB_RNG_PHILOX) return fail(CHUB_ERR_ARG, "chub_set_slots needs a PHILOX handle");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const HubParams &hp = e->hp;
+    const size_t N = (size_t) hp.n_envs, S = (size_t) (hp.S[0] + hp.S[1]);
+    const uint32_t n_classes = (uint32_t) kSocLevels + (uint32_t) e->tape_classes;
+    std::vector<uint32_t> st(2 * N * S, 0u);
+    for (size_t env = 0; env < N; env++)
+        for (int k = 0; k < 2; k++)
+            for (size_t i = 0; i < (size_t) hp.S[k]; i++) {
+                const int32_t *r = rows + (env * S + (k ? (size_t) hp.S[0] : 0) + i) * 6;
+                if (r[0] < 0) continue;  // empty slot
+                const int left = r[2] - r[3];
+                if ((uint32_t) r[0] >= n_classes || r[1] < 0 || r[1] >= kLevels || r[2] < 1 || r[2] > 63 || left < 1 || r[4] < 0 ||
+                    r[4] >= kClsRow)
+                    return fail(CHUB_ERR_ARG, "chub_set_slots: field out of range");
+                const size_t idx = (size_t) hp.base[k] + env * (size_t) hp.S[k] + i;
+                st[2 * idx] = (uint32_t) left | (r[5] ? 64u : 0u) | ((uint32_t) r[2] << 7) | ((uint32_t) r[4] << 13) | ((uint32_t) r[1] << 18);
+                st[2 * idx + 1] = (uint32_t) r[0];
+            }
+    HIP_TRY(hipMemcpy(e->sl.hot, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return CHUB_OK;
+}
+
+int chub_set_station_queue(chub_env *e, const int32_t *line) {
+    if (!e || !line) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t) e->hp.n_envs;
+    std::vector<uint32_t> rec;
+    int rc = fetch(rec, (const uint32_t *) e->st.rec, 8 * N);
+    if (rc) return rc;
+    for (size_t env = 0; env < N; env++)
+        for (int k = 0; k < 2; k++) {
+            if (line[env * 2 + k] < 0 || line[env * 2 + k] > kMaxLine) return fail(CHUB_ERR_ARG, "queue length out of range");
+            uint32_t &w = rec[4 * ((size_t) k * N + env) + 3];
+            w = (w & ~0xFFu) | (uint32_t) line[env * 2 + k];
+        }
+    HIP_TRY(hipMemcpy(e->st.rec, rec.data(), rec.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return CHUB_OK;
+}
+
+int chub_step_tape(chub_env *e, const float *actions, const uint64_t *pk_tape, const uint32_t *car_tape, float *obs, float *reward,
+                   uint8_t *done) {
+    if (!e || !actions || !pk_tape || !car_tape || !obs || !reward || !done) return fail(CHUB_ERR_ARG, "null argument");
+    if (e->hp.rng_mode != CHUB_RNG_PHILOX || !e->hp.packed)
+        return fail(CHUB_ERR_ARG, "tape mode drives the packed PHILOX slot kernel: the hub shape must be one it covers");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t N = (size_t) e->hp.n_envs, S = (size_t) (e->hp.S[0] + e->hp.S[1]);
+    // the car tape comes in hub order [N][S][2] (station 0's slots first): to the kernel's station-major slot index
+    std::vector<uint32_t> ct(2 * N * S);
+    for (size_t env = 0; env < N; env++)
+        for (int k = 0; k < 2; k++)
+            for (size_t i = 0; i < (size_t) e->hp.S[k]; i++) {
+                const size_t src = env * S + (k ? (size_t) e->hp.S[0] : 0) + i, dst = (size_t) e->hp.base[k] + env * (size_t) e->hp.S[k] + i;
+                ct[2 * dst] = car_tape[2 * src];
+                ct[2 * dst + 1] = car_tape[2 * src + 1];
+            }
+    uint64_t *d_pk = nullptr;
+    uint32_t *d_ct = nullptr;
+    HIP_TRY(hipMalloc((void **) &d_pk, 2 * N * sizeof(uint64_t)));
+    hipError_t he = hipMalloc((void **) &d_ct, ct.size() * sizeof(uint32_t));
+    if (he != hipSuccess) {
+        (void) hipFree(d_pk);
+        return fail(CHUB_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(he));
+    }
+    int rc = CHUB_OK;
+    auto done_ = [&](int code) {
+        (void) hipDeviceSynchronize();
+        (void) hipFree(d_pk);
+        (void) hipFree(d_ct);
+        return code;
+    };
+    if (hipMemcpy(d_pk, pk_tape, 2 * N * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ct, ct.data(), ct.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->d_actions, actions, N * (size_t) e->hp.act_dim * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return done_(fail(CHUB_ERR_HIP, "hipMemcpy failed"));
+    e->tape_pk = d_pk;
+    e->tape_car = d_ct;
+    rc = chub_step_device(e, e->d_actions, nullptr, e->d_obs, e->d_reward, e->d_done, nullptr);
+    e->tape_pk = nullptr;
+    e->tape_car = nullptr;
+    if (rc) return done_(rc);
+    if (hipMemcpy(obs, e->d_obs, N * (size_t) e->hp.obs_dim * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(done, e->d_done, N, hipMemcpyDeviceToHost) != hipSuccess)
+        return done_(fail(CHUB_ERR_HIP, "hipMemcpy failed"));
+    return done_(CHUB_OK);
+}
+
 int chub_random_actions_device(chub_env *e, uint64_t key, uint32_t batch, float *d_actions, void *stream) {
     if (!e || !d_actions) return fail(CHUB_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
@@ -879,7 +1006,8 @@ int chub_get_slots(chub_env *e, float *out) {
     const HubParams &hp = e->hp;
     const size_t N = (size_t) hp.n_envs, S = (size_t) (hp.S[0] + hp.S[1]), NS = N * S;
     const bool philox = hp.rng_mode == CHUB_RNG_PHILOX;
-    std::vector<float> soc, init_soc, cls[2], soc0[2], ttab[2];
+    std::vector<float> soc, init_soc;
+    const std::vector<float> *cls = e->h_cls, *soc0 = e->h_soc0, *ttab = e->h_ttab;
     std::vector<uint32_t> hot;
     int rc;
     if ((rc = sync_ctx(e, nullptr))) return rc;
@@ -892,15 +1020,7 @@ int chub_get_slots(chub_env *e, float *out) {
         if (rc) return rc;
     }
     if ((rc = fetch(hot, (const uint32_t *) e->sl.hot, (philox ? 2 : 4) * NS))) return rc;
-    if (philox) {
-        const size_t n_classes = (size_t) kSocLevels + kTapeClasses;
-        for (int k = 0; k < 2; k++)
-            if ((rc = fetch(cls[k], e->tb.cls[k], (n_classes + 1) * kClsRow * 2)) || (rc = fetch(soc0[k], e->tb.cls_soc0[k], n_classes)) ||
-                (rc = fetch(ttab[k], e->tb.ttab[k], (size_t) kLevels)))
-                return rc;
-    } else if ((rc = fetch(init_soc, (const float *) e->sl.init_soc, NS))) {
-        return rc;
-    }
+    if (!philox && (rc = fetch(init_soc, (const float *) e->sl.init_soc, NS))) return rc;
     for (size_t env = 0; env < N; env++) {
         float *o = out + env * 9 * S;
         for (int k = 0; k < 2; k++) {

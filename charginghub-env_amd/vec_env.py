@@ -105,6 +105,28 @@ class VecChargingHub(object):
         check(self._lib.chub_step_load(self._h, _ptr(a), _ptr(z), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
         return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
 
+    # ---- tape mode (parity instrument, see include/chub.h): recorded decisions through the production kernels
+    def tape_register_soc(self, soc):
+        s = np.ascontiguousarray(soc, dtype=np.float32).ravel()
+        ids = np.zeros(s.size, dtype=np.uint32)
+        check(self._lib.chub_tape_register_soc(self._h, _ptr(s), int(s.size), _ptr(ids)))
+        return ids
+
+    def set_slots(self, rows):
+        r = np.ascontiguousarray(rows, dtype=np.int32).reshape(self.n_envs, self.n_slots, 6)
+        check(self._lib.chub_set_slots(self._h, _ptr(r)))
+
+    def set_station_queue(self, line):
+        q = np.ascontiguousarray(line, dtype=np.int32).reshape(self.n_envs, 2)
+        check(self._lib.chub_set_station_queue(self._h, _ptr(q)))
+
+    def step_tape(self, actions, pk_tape, car_tape):
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n_envs, self.act_dim)
+        pk = np.ascontiguousarray(pk_tape, dtype=np.uint64).reshape(2, self.n_envs)
+        ct = np.ascontiguousarray(car_tape, dtype=np.uint32).reshape(self.n_envs, self.n_slots, 2)
+        check(self._lib.chub_step_tape(self._h, _ptr(a), _ptr(pk), _ptr(ct), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
+        return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
+
     # ---- device-pointer path (ints are raw device addresses, e.g. torch.Tensor.data_ptr())
     def reset_device(self, d_obs, d_exo_days=0, d_exo_z=0, stream=0):
         check(self._lib.chub_reset_device(self._h, d_exo_days or None, d_exo_z or None, d_obs, stream or None))

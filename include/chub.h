@@ -205,6 +205,25 @@ int chub_compat_replay_constructor(chub_env *env);
 /* Persistent OU states (never reset by the reference, MGR:304-316): [N][3] f64 pv, wd, price. */
 int chub_set_ou_state(chub_env *env, const double *ou);
 
+/* ---- tape mode: a parity instrument for the production (PHILOX) kernels ------------------------------------------------
+ * The production streams are this build's own definition, so the kernels that run them cannot be compared with the
+ * reference's recorded trajectories seed for seed.  Tape mode closes that gap: the caller supplies what the streams
+ * would have drawn -- per (station, env) unit the step's packed station-level decisions (queue renege bits, arrivals,
+ * balk survivors: the layout draw_station_levels packs, chub_kernels.hip) and per admitted car its arrival SoC, target
+ * level and extra stay -- and the SAME packed slot kernel replays them.  Arbitrary arrival SoCs are registered as extra
+ * classes of the class table first.  tests/test_gpu_tape.py replays the reference fixtures this way.
+ *   chub_tape_register_soc: soc[count] -> class_ids[count] (at most 8192 per handle).
+ *   chub_set_slots:        rows [N][S][6] i32 in hub order (station 0's slots first): class (-1 = empty), target level,
+ *                          stay_time, already_stay_time, car_steps taken, charging flag.
+ *   chub_set_station_queue: line [N][2] i32 (Station::line).
+ *   chub_step_tape:        one step; pk_tape [2][N] u64, car_tape [N][S][2] u32 in hub order = class, level | late << 16
+ *                          (read only for slots that admit a car this step).  Host pointers. */
+int chub_tape_register_soc(chub_env *env, const float *soc, int32_t count, uint32_t *class_ids);
+int chub_set_slots(chub_env *env, const int32_t *rows);
+int chub_set_station_queue(chub_env *env, const int32_t *line);
+int chub_step_tape(chub_env *env, const float *actions, const uint64_t *pk_tape, const uint32_t *car_tape, float *obs,
+                   float *reward, uint8_t *done);
+
 /* Snapshot / restore of the whole simulation state (clock, streams, every slot and env variable): checkpoint /
  * resume, planners that branch from a state.  The reference cannot do this (pickling disabled, main.cpp:234; raw
  * back-pointers, CHS.hpp:238).  A snapshot restores only into a handle created with the same arguments. */

@@ -125,7 +125,7 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
     D = int(env.observation_space.shape[0])
     hy_table = np.array(env.hy_sys.hy_power_speed_list, dtype=np.float64)
     data = dict(obs=[], reward=[], done=[], action=[], exo_z=[], telem=[], stations=[], reset_obs=[], reset_days=[],
-                reset_z=[], reset_stations=[], slots0=[], slots1=[], seeds=[])
+                reset_z=[], reset_stations=[], slots0=[], slots1=[], seeds=[], reset_slots0=[], reset_slots1=[])
     for ep in range(episodes):
         if seeds is not None and (ep == 0 or reseed_each_episode):
             g, m = seeds[0] + ep, seeds[1] + ep
@@ -137,6 +137,8 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
         data["reset_days"].append([env.renew.pv_day, env.renew.wd_day])
         data["reset_z"].append(rec.take())
         data["reset_stations"].append(station_block(env))
+        data["reset_slots0"].append(env.env_aggregator.evcssp_evs_objects[0].slots())
+        data["reset_slots1"].append(env.env_aggregator.evcssp_evs_objects[1].slots())
         for t in range(steps_per_episode):
             if action_kind == "none":
                 act_in = None
@@ -161,9 +163,9 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
             data["slots0"].append(sts[0].slots())
             data["slots1"].append(sts[1].slots())
     rec.close()
-    out = {k: np.array(v) for k, v in data.items() if k not in ("slots0", "slots1")}
-    out["slots0"] = np.array(data["slots0"], dtype=np.float32)
-    out["slots1"] = np.array(data["slots1"], dtype=np.float32)
+    out = {k: np.array(v) for k, v in data.items() if k not in ("slots0", "slots1", "reset_slots0", "reset_slots1")}
+    for key in ("slots0", "slots1", "reset_slots0", "reset_slots1"):
+        out[key] = np.array(data[key], dtype=np.float32)
     out["hy_table"] = hy_table
     out["ctor_seeds"] = np.array(ctor_seeds if ctor_seeds is not None else (1, 1))  # c1: the process defaults (CHS:25,35-44)
     out["ctor_days"] = np.array(ctor_days)
