@@ -4,16 +4,24 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path (chub_step: slot kernel + env kernel) over all 65 536 envs of the
-reference test hub [20 fast, 25 slow] (BASELINE.json configs[3]; it fits one GPU, so N=1 runs the same
-workload).  The envs are sharded over the N ranks (strong scaling: 65 536 / N envs per GPU, global env ids keep
-the Philox streams identical for every N); every step each rank's packed (obs, reward, done) block is gathered
-to rank 0 with one RCCL gather, as the north star specifies.  Actions are a random policy drawn on the device
-before the timed region (8 resident batches, cycled); episodes are reset every 96 steps inside the timed region.
+No PyTorch in here: the host is ctypes + numpy over libchub (the launcher only provides RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_PORT); device buffers, streams, the hipGraph capture and the RCCL gather are libchub's own (include/chub.h).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the slot kernel) with ALGORITHMIC bytes
- over its average duration measured with HIP events on the launch stream; `cpu_baseline` is
-the CPU oracle (oracle/chub_oracle.c, kind "port") timed on this box's host cores on a bounded sample.
+One "step" = one pass of the hot path (slot kernel + env kernel) over all envs of the workload: 65 536 envs of the
+reference test hub [20 fast, 25 slow] (BASELINE.json configs[3]; it fits one GPU, so N=1 runs the same workload).
+--scaling strong (default): the 65 536 envs are sharded over the N ranks (global env ids keep the Philox streams identical
+for every N); --scaling weak: BASELINE.json configs[4] (hub [32 fast, 32 slow], real price / PV / wind series), 262 144 / 8 =
+32 768 envs PER GPU, so the 8-GPU run is the configs[4] job.  Every step each rank's packed (obs, reward, done) block goes
+to rank 0 in one RCCL gather (chub_step_gather), stream-ordered behind the step kernels.  Actions are a random policy drawn
+on the device before the timed region (8 resident batches, cycled); episodes are reset every 96 steps inside the timed region.
+
+With N > 1 (or --graph) whole episodes are captured into a hipGraph (2 episodes = 2 resets + 192 steps per replay): at
+8192 envs per GPU the kernels of a step take less time than the host needs to issue them.  At N = 1 the default is eager
+launches, with HIP events on every 4th step for the per-kernel times behind `roofline`.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the slot kernel) with ALGORITHMIC bytes (DESIGN.md
+section 5) over its average duration; `roofline_step` prices the whole step the same way (B * env-steps/s /
+8e12).  `cpu_baseline` is the CPU oracle (oracle/chub_oracle.c, kind "port") timed on this box's host cores on a bounded sample.
 """
 import argparse
 import ctypes as C
@@ -27,11 +35,10 @@ sys.path.insert(0, ROOT)
 # kernel arguments in device memory instead of host memory: every wave's first scalar loads then stay on the GPU
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
-TOTAL_ENVS = 65536
 HUB = dict(station_list=[20, 25], station_type_list=["fast", "slow"], constant_charging=False, hydro_prod_rate=100.0,
            hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01, renew_fluctuate=0.0,
            price_fluctuate=0.0, hydro_loss=0.0)
-# the other BASELINE.json configs (parity-test sizes; selectable with --config for the results table, not the headline)
+# BASELINE.json configs (c4 = the headline; the others are selectable for the results table)
 CONFIGS = {
     "c2": (4096, dict(HUB, station_list=[16, 0], fcev_permeate=0.0)),
     "c3": (32768, dict(HUB)),
@@ -43,6 +50,7 @@ ACTION_KEY = 0xC0FFEE
 N_ACTION_BATCHES = 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 PROFILE_EVERY = 4      # HIP events around the two kernels on every 4th step of the timed region
+GRAPH_EPISODES = 2     # episodes per captured graph: 2 resets + 192 steps = an even number of launches (double-buffered draws)
 
 
 def algorithmic_bytes(S, D):
@@ -54,29 +62,24 @@ def algorithmic_bytes(S, D):
     return slot_kernel, env_kernel
 
 
-def measured_traffic(envs_per_gpu):
-    """HBM bytes per k_slot launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
-    corrected with the calibration kernel of tools/microbench/copy4.hip) -- collected offline with this same command
-    and committed under profiles/; scaled to this run's shard size."""
+def measured_traffic(build_id, envs_per_gpu, total_envs):
+    """HBM bytes per slot-kernel launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+    gfx950 correction of MI355X_MICROARCH.md), collected offline by tools/refresh_profiles.sh with this same command and
+    committed under profiles/ TOGETHER WITH the build id of the library they were measured on: a profile of another build
+    is not this build's traffic -> None."""
     import glob
 
-    import re
-
-    def version(path):
-        m = re.search(r"round(\d+)_v(\d+)_pmc_traffic", path)
-        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")), key=version)
-    if not files:
-        return None
-    try:
-        rec = json.load(open(files[-1]))
-        return rec["k_slot"]["traffic_bytes_per_launch"] * envs_per_gpu / float(TOTAL_ENVS)  # measured on the c4 hub
-    except Exception:
-        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(f))
+        except Exception:
+            continue
+        if rec.get("build_id") == build_id and rec.get("envs") == total_envs:
+            return rec["k_slot"]["traffic_bytes_per_launch"] * envs_per_gpu / float(total_envs), os.path.basename(f)
+    return None, None
 
 
-def cpu_baseline(target_seconds=12.0):
+def cpu_baseline(hub_kw, total_envs, target_seconds=12.0):
     """The oracle's scalar restatement (kind "port"), PHILOX streams, all host cores of this box, on a bounded
     sample of the same workload: n_envs chosen so the run takes ~target_seconds; reports env-steps/s."""
     import numpy as np
@@ -86,12 +89,13 @@ def cpu_baseline(target_seconds=12.0):
     from orclib import orc, ptr
 
     cores = min(len(os.sched_getaffinity(0)), 16)  # a one-GPU box's CPU share
-    cfg = orclib.make_config(piles=HUB["station_list"], types=HUB["station_type_list"], hydro_prod_rate=100.0,
-                             hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
+    cfg = orclib.make_config(piles=hub_kw["station_list"], types=hub_kw["station_type_list"], hydro_prod_rate=100.0,
+                             hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=hub_kw["fcev_permeate"])
+    D = orc.orc_env_obs_dim(C.byref(cfg))
+    A = sum(hub_kw["station_list"]) + 2
 
     def run(n, steps):
         h = orc.orc_vec_create(C.byref(cfg), orclib.tables(), n, 0, orclib.PHILOX, SEED)
-        D, A = 13, 47
         obs = np.zeros((n, D))
         rew = np.zeros(n)
         done = np.zeros(n, dtype=np.uint8)
@@ -110,9 +114,9 @@ def cpu_baseline(target_seconds=12.0):
     n = 64 * cores
     rate = run(n, 24)  # calibration burst
     steps = 96
-    n = int(max(64 * cores, min(TOTAL_ENVS, rate * target_seconds / steps)))
+    n = int(max(64 * cores, min(total_envs, rate * target_seconds / steps)))
     n -= n % cores
-    if n == TOTAL_ENVS:  # whole workload fits: add whole episodes until the sample is ~target_seconds long
+    if n == total_envs:  # whole workload fits: add whole episodes until the sample is ~target_seconds long
         steps = 96 * max(1, min(4, int(round(rate * target_seconds / (n * 96.0)))))
     rate = run(n, steps)
     return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
@@ -125,8 +129,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4800)
     ap.add_argument("--warmup", type=int, default=960)
-    ap.add_argument("--envs", type=int, default=None)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c4")
+    ap.add_argument("--envs", type=int, default=None, help="total envs (strong) / envs per GPU (weak); default: the config's")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="capture whole episodes into a hipGraph (auto: on for N > 1, off for N = 1)")
+    ap.add_argument("--force-comm", action="store_true", help="N = 1: still make the communicator and gather (to rank 0 itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events in the timed region")
     args = ap.parse_args()
@@ -136,131 +144,150 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
+            raise SystemExit("bench.py --gpus %d must be launched with one process per GPU, e.g. python -m torch.distributed.run "
+                             "--nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
 
-    import torch  # first: libchub must share torch's HIP runtime (same soname)
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # Rehearsal switch (never used by the driver): CHUB_BENCH_REHEARSE=1 runs all ranks on GPU 0 with the gloo
-    # backend (host-staged gather), to exercise the multi-rank orchestration on a one-GPU box.
-    rehearse = os.environ.get("CHUB_BENCH_REHEARSE") == "1"
-    if rehearse:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL
+    import numpy as np
 
     import charginghub_env_amd as chub
+    from charginghub_env_amd import multi_gpu
 
-    cfg_envs, hub_kw = CONFIGS[args.config]
-    total = args.envs if args.envs is not None else cfg_envs
-    assert total % world == 0
-    per = total // world
+    lib = chub.load_library()
+    if lib.chub_device_count() <= 0:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+
+    config = args.config or ("c5" if args.scaling == "weak" else "c4")
+    cfg_envs, hub_kw = CONFIGS[config]
+    if args.scaling == "weak":
+        per = args.envs if args.envs is not None else cfg_envs // 8  # configs[4]: 262 144 envs over the 8 GPUs of a node
+        total = per * world
+    else:
+        total = args.envs if args.envs is not None else cfg_envs
+        assert total % world == 0
+        per = total // world
+    use_comm = world > 1 or args.force_comm
+    use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
+    steps, warmup = args.steps, args.warmup
+    per_graph = 96 * GRAPH_EPISODES
+    if use_graph:  # whole graphs only: round the two counts up
+        steps = -(-steps // per_graph) * per_graph
+        warmup = -(-warmup // per_graph) * per_graph
+
+    comm = multi_gpu.Comm(rank, world, local_rank) if use_comm else None
     v = chub.VecChargingHub(per, seed=SEED, rng="philox", device=local_rank, env_id0=rank * per, **hub_kw)
     D, A, S = v.obs_dim, v.act_dim, v.n_slots
-    stream = torch.cuda.current_stream().cuda_stream
-
-    actions = [torch.empty((per, A), dtype=torch.float32, device=dev) for _ in range(N_ACTION_BATCHES)]
+    stream = multi_gpu.Stream(local_rank)
+    row = (D + 2) * 4
+    actions = [multi_gpu.DeviceBuffer(per * A * 4, local_rank) for _ in range(N_ACTION_BATCHES)]
     for b, a in enumerate(actions):
-        v.random_actions_device(a.data_ptr(), ACTION_KEY, b, stream)
-    # packed step output (obs, reward, done); two buffers so that the gather of step i (RCCL's own stream) can
-    # overlap with the kernels of step i+1, which write the other buffer
-    packed = [torch.empty((per, D + 2), dtype=torch.float32, device=dev) for _ in range(2)]
-    reset_obs = torch.empty((per, D), dtype=torch.float32, device=dev)
-    gathered = [None, None]
-    gdev = "cpu" if rehearse else dev
-    if world > 1 and rank == 0:
-        gathered = [[torch.empty((per, D + 2), dtype=torch.float32, device=gdev) for _ in range(world)] for _ in range(2)]
-    pending = [None, None]
+        v.random_actions_device(a.ptr, ACTION_KEY, b, stream.ptr)
+    # packed step output (obs, reward, done), double-buffered so that a consumer of step i's block is not overwritten by step i+1
+    packed = [multi_gpu.DeviceBuffer(per * row, local_rank) for _ in range(2)]
+    gathered = [multi_gpu.DeviceBuffer(total * row, local_rank) if (use_comm and rank == 0) else None for _ in range(2)]
+    reset_obs = multi_gpu.DeviceBuffer(per * D * 4, local_rank)
 
     def one_step(i):
         b = i & 1
-        if pending[b] is not None:
-            pending[b].wait()  # stream-level: the step that reuses this buffer waits for its previous gather
-            pending[b] = None
         if i % 96 == 0:
-            v.reset_device(reset_obs.data_ptr(), stream=stream)
-        v.step_device_packed(actions[i % N_ACTION_BATCHES].data_ptr(), packed[b].data_ptr(), stream=stream)
-        if world > 1:
-            src = packed[b].cpu() if rehearse else packed[b]
-            pending[b] = dist.gather(src, gather_list=gathered[b], dst=0, async_op=True)
+            v.reset_device(reset_obs.ptr, stream=stream.ptr)
+        if use_comm:  # step kernels + ONE grouped ncclSend / ncclRecv on the same stream (chub_step_gather)
+            chub._lib.check(lib.chub_step_gather(v._h, comm._h, actions[i % N_ACTION_BATCHES].ptr, packed[b].ptr,
+                                                 gathered[b].ptr if rank == 0 else None, stream.ptr))
+        else:
+            v.step_device_packed(actions[i % N_ACTION_BATCHES].ptr, packed[b].ptr, stream=stream.ptr)
 
     def fence():
-        for b in (0, 1):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        stream.sync()
+        if comm is not None:
+            comm.barrier(stream.ptr)
+        stream.sync()
 
-    for i in range(args.warmup):
-        one_step(i)
+    graph = None
+    if use_graph:
+        stream.sync()
+        v.graph_begin(stream.ptr)
+        for i in range(per_graph):
+            one_step(i)
+        graph = v.graph_end(stream.ptr)
+
+    def run(n_steps, first):
+        if graph is not None:
+            for _ in range(n_steps // per_graph):
+                v.graph_launch(graph, stream.ptr)
+        else:
+            for i in range(n_steps):
+                one_step(first + i)
+
+    run(warmup, 0)
     fence()
-    use_events = not args.no_events
+    use_events = not args.no_events and graph is None
     if use_events:
-        v.profile_begin(args.steps, every=PROFILE_EVERY)
+        v.profile_begin(steps, every=PROFILE_EVERY)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + i)
+    run(steps, warmup)
+    t_issue = time.perf_counter() - t0  # host time to issue the whole timed region (eager: launches; graph: replays)
     fence()
     dt = time.perf_counter() - t0
     slot_ms = env_ms = 0.0
     n_prof = 0
     if use_events:
         slot_ms, env_ms, n_prof = v.profile_end()
-
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    if comm is not None:
+        dt = comm.max(dt, stream.ptr)
     # sanity on the last outputs (rank-local): finite, done flag consistent with the clock
-    last = packed[(args.warmup + args.steps - 1) & 1].cpu()
-    assert bool(torch.isfinite(last).all()), "non-finite step output"
+    last = packed[(steps - 1) & 1].to_host(np.float32, (per, D + 2), stream.ptr)
+    assert np.isfinite(last).all(), "non-finite step output"
+    assert (last[:, D + 1] > 0.5).all() == ((steps % 96) == 0), "done flag out of step with the clock"
+    if use_comm and rank == 0:  # the gathered block's own shard is the local block
+        g = gathered[(steps - 1) & 1].to_host(np.float32, (total, D + 2), stream.ptr)
+        assert np.array_equal(g[:per], last), "gathered block differs from the local one"
+        assert np.isfinite(g).all()
 
     if rank == 0:
-        value = total * args.steps / dt
+        value = total * steps / dt
         slot_b, env_b = algorithmic_bytes(S, D)
+        build_id = lib.chub_build_id().decode()
         roofline = None
         if n_prof:
             slot_s = slot_ms / 1e3 / n_prof
             achieved = slot_b * per / slot_s / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_slot_packed (k_slot for hub shapes it does not cover)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(per) if args.config in ("c3", "c4") else None,
+            traffic, traffic_src = measured_traffic(build_id, per, total)
+            roofline = {"bound": "hbm", "kernel": "k_slot_packed", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": slot_b * per, "avg_launch_us": slot_s * 1e6,
                         "env_kernel_avg_launch_us": env_ms / n_prof * 1e3,
                         "env_kernel_algorithmic_bytes_per_launch": env_b * per}
+        step_achieved = (slot_b + env_b) * total / (dt / steps) / 1e9 / world  # per GPU
         out = {
             "metric": "env-steps/sec at 65 536 parallel envs", "value": value, "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "%d envs x hub [%d fast, %d slow] (BASELINE.json %s), fcev_permeate %g, "
                                    "random policy resident in HBM, reset every 96 steps, Philox streams"
                                    % (total, hub_kw["station_list"][0], hub_kw["station_list"][1],
-                                      "configs[3]" if args.config == "c4" else args.config, hub_kw["fcev_permeate"]),
-                       "envs_per_gpu": per, "obs_dim": D, "act_dim": A,
-                       "collective": "none" if world == 1 else "one RCCL gather of [envs_per_gpu, %d] f32 per step" % (D + 2)},
+                                      {"c4": "configs[3]", "c5": "configs[4]"}.get(config, config), hub_kw["fcev_permeate"]),
+                       "envs_per_gpu": per, "obs_dim": D, "act_dim": A, "launch": "hipGraph of %d episodes" % GRAPH_EPISODES if graph else "eager",
+                       "host_issue_ms_per_step": t_issue / steps * 1e3,
+                       "collective": "none" if not use_comm else
+                       "one grouped ncclSend/ncclRecv (RCCL) of [envs_per_gpu, %d] f32 per step to rank 0, on the step's stream" % (D + 2)},
             "roofline": roofline,
+            "roofline_step": {"bound": "hbm", "what": "whole step (slot kernel + env kernel + launch gaps), SURVEY.md 8(d): B * env-steps/s per GPU",
+                              "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_achieved / HBM_PEAK_GBS,
+                              "algorithmic_bytes_per_env_step": slot_b + env_b},
+            "build_id": build_id,
         }
-        if not args.no_cpu_baseline and world == 1 and args.config == "c4":
-            out["cpu_baseline"] = cpu_baseline()
+        if not args.no_cpu_baseline and world == 1 and config == "c4":
+            out["cpu_baseline"] = cpu_baseline(hub_kw, total)
         print(json.dumps(out))
+    if graph is not None:
+        v.graph_destroy(graph)
+    stream.sync()
     v.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

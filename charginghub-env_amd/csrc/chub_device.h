@@ -139,6 +139,7 @@ struct HubParams {
     int32_t rng_mode;
     int32_t telemetry;
     uint32_t key[2];
+    CHUB_G(const uint32_t) tick_base;  // PHILOX: added to every launch's host tick (moves only when a captured graph of steps replays)
     CurveConsts cc;
     float transformer_limit[2];
     // hydrogen system constants (HYD)

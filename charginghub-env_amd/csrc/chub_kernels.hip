@@ -57,6 +57,9 @@ __device__ __forceinline__ uint32_t pick(const U4 &b, int i) {
     return r;
 }
 
+// Philox tick of a launch = the host's tick (a kernel argument) + a base kept in device memory: a captured graph of steps bakes
+// the host ticks in, and every replay moves the base on (k_tick_advance, the graph's last node), so no counter ever repeats
+#define CHUB_TICK(hp, host_tick) ((host_tick) + *(hp).tick_base)
 struct PhiloxCtx {
     uint32_t k0, k1, tick, gid;
     __device__ __forceinline__ U4 block(uint32_t site, uint32_t index, uint32_t blk) const {
@@ -701,7 +704,7 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     }
     const bool adm = empty && rank < assign;
     if (adm) {  // add_car (CHS.hpp:864-877 / 1029-1042): one Philox block per new car, word 0 SoC class, 1 target level, 2 extra stay
-        PhiloxCtx px{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env)};
+        PhiloxCtx px{hp.key[0], hp.key[1], CHUB_TICK(hp, sa.tick), (uint32_t) (hp.env_id0 + env)};
         const U4 o = px.block(SITE_SOC, (uint32_t) hub_slot, 0);
         const uint32_t c = o.v[0] >> kSocLevelShift, lev = o.v[1] % 1000u;
         const f32x2 e0 = *(CHUB_G(const f32x2)) ((CHUB_G(const char)) cls + (size_t) c * (kClsRow * 8u));
@@ -945,7 +948,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
             lev = tp.y & 0xFFFFu;
             late = (int) (tp.y >> 16);
         } else {
-            PhiloxCtx p2{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env_first + s_u)};
+            PhiloxCtx p2{hp.key[0], hp.key[1], CHUB_TICK(hp, sa.tick), (uint32_t) (hp.env_id0 + env_first + s_u)};
             const U4 o = p2.block(SITE_SOC, (uint32_t) (S0 + (src - s_u * S)), 0);  // word 0 SoC class, 1 target level, 2 extra stay
             c = o.v[0] >> kSocLevelShift;
             lev = o.v[1] % 1000u;
@@ -1182,7 +1185,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             if (MODE == MODE_COMPAT && i < kLevels / 4) st_hv = ((CHUB_G(const uint32_t)) tb.cnt_hv)[sa.t * (kLevels / 4) + i];
         }
     }
-    PhiloxCtx px{hp.key[0], hp.key[1], sa.tick, (uint32_t) (hp.env_id0 + env)};
+    PhiloxCtx px{hp.key[0], hp.key[1], MODE == MODE_PHILOX ? CHUB_TICK(hp, sa.tick) : sa.tick, (uint32_t) (hp.env_id0 + env)};
     double cap = 0.0, in_re_wd = 0.0, in_re_pv = 0.0, in_price_next = 0.0, in_price_noise = 0.0;
     double ou_pv = 0.0, ou_wd = 0.0, ou_price = 0.0, z_pv = 0.0, z_wd = 0.0, z_pr = 0.0;
     float a_el_f = 0.0f, a_fc_f = 0.0f, P0f = 0.0f, P1f = 0.0f, mn0 = 0.0f, mx0 = 0.0f, mn1 = 0.0f, mx1 = 0.0f;
@@ -1598,12 +1601,12 @@ __device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, cons
     const int64_t N = hp.n_envs;
     if (u < 2 * N) {
         const int kk = u >= N ? 1 : 0;
-        ctx->st.pk[(sa.tick + 1u) & 1u][u] = draw_station_levels(hp, ctx->tb, sa.tick + 1u, t_next, kk, u - (int64_t) kk * N);
+        ctx->st.pk[(sa.tick + 1u) & 1u][u] = draw_station_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick + 1u), t_next, kk, u - (int64_t) kk * N);
     } else if (u < 3 * N) {
         // the per-env draws (same Philox sites and counters the tail would use itself)
         const uint32_t e = (uint32_t) (u - 2 * N);
         const Tables &tb = ctx->tb;
-        PhiloxCtx px{hp.key[0], hp.key[1], sa.tick + 1u, (uint32_t) (hp.env_id0 + e)};
+        PhiloxCtx px{hp.key[0], hp.key[1], CHUB_TICK(hp, sa.tick + 1u), (uint32_t) (hp.env_id0 + e)};
         const U4 ow = px.block(SITE_OU, 0, 0);  // word 0 pv, 1 wind, 2 price
         const uint32_t hv_lev = px.block(SITE_HV, 0, 0).v[0] % 1000u;
         u32x4 d;
@@ -1818,7 +1821,7 @@ __global__ void k_reset_levels(const DevCtx *__restrict__ ctx, uint32_t tick) {
     const int k = u >= N ? 1 : 0;
     const int64_t env = u - (int64_t) k * N;
     const int S = hp.S[k], mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
-    PhiloxCtx px{hp.key[0], hp.key[1], tick, (uint32_t) (hp.env_id0 + env)};
+    PhiloxCtx px{hp.key[0], hp.key[1], CHUB_TICK(hp, tick), (uint32_t) (hp.env_id0 + env)};
     U4 b = px.block(SITE_ARRIVE, (uint32_t) k, 0);
     const float cn = __fadd_rn(normal_from_word(tb.normal_icdf, tb.normal_tail, px.block(SITE_INIT, (uint32_t) k, 0).v[0]), (float) mu);
     int n_in = (int) roundf(cn);
@@ -1834,6 +1837,12 @@ __global__ void k_reset_levels(const DevCtx *__restrict__ ctx, uint32_t tick) {
 }
 
 // ------------------------------------------------------------------------------------- launchers
+// kernel launch with the dispatch's own start / stop timestamps when asked for (chub_profile_*), a plain launch otherwise
+#define CHUB_LAUNCH(kernel, grid, block, stream, ev0, ev1, ...)                                         \
+    do {                                                                                                \
+        if ((ev0) || (ev1)) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev0, ev1, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                           \
+    } while (0)
 static inline int64_t blocks_for(int64_t n_envs, int H, int block) {
     const int64_t upb = (int64_t) (block / 64) * (64 / H);
     return (n_envs + upb - 1) / upb;
@@ -1848,13 +1857,12 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
     const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
     if (MODE == MODE_PHILOX) {
         if (RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa.tick);
-        hipExtLaunchKernelGGL((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), 0, stream, ev0, ev1, 0, ctx, sa, nb0);
+        CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, ev1, ctx, sa, nb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
             StepArgs s2 = sa;
             s2.station_filter = k;
-            hipExtLaunchKernelGGL((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), 0, stream,
-                                  k == 0 ? ev0 : nullptr, k == 1 ? ev1 : nullptr, 0, ctx, s2, nb0);
+            CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), stream, k == 0 ? ev0 : nullptr, k == 1 ? ev1 : nullptr, ctx, s2, nb0);
         }
     }
 }
@@ -1883,8 +1891,8 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             pa.car_tape = (CHUB_G(const uint32_t)) sa.car_tape;
             const uint32_t nb0 = (uint32_t) ((hp.n_envs + hp.upb[0] - 1) / hp.upb[0]);
             const uint32_t nb1 = (uint32_t) ((hp.n_envs + hp.upb[1] - 1) / hp.upb[1]);
-            if (sa.car_tape) hipExtLaunchKernelGGL((k_slot_packed<kSlotBlock, kSlotsPerLane, true>), dim3(nb0 + nb1), dim3(kSlotBlock), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0);
-            else hipExtLaunchKernelGGL((k_slot_packed<kSlotBlock, kSlotsPerLane, false>), dim3(nb0 + nb1), dim3(kSlotBlock), 0, stream, ev0, ev1, 0, ctx, sa, pa, nb0);
+            if (sa.car_tape) CHUB_LAUNCH((k_slot_packed<kSlotBlock, kSlotsPerLane, true>), dim3(nb0 + nb1), dim3(kSlotBlock), stream, ev0, ev1, ctx, sa, pa, nb0);
+            else CHUB_LAUNCH((k_slot_packed<kSlotBlock, kSlotsPerLane, false>), dim3(nb0 + nb1), dim3(kSlotBlock), stream, ev0, ev1, ctx, sa, pa, nb0);
         } else launch_slot_t<false, MODE_PHILOX>(hp, ctx, sa, stream, ev0, ev1);
         return;
     }
@@ -1899,12 +1907,17 @@ void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepAr
     if (hp.rng_mode == MODE_PHILOX) {
         // + the level-draw workgroups: next step's state-independent variates (3 lanes per env: two stations, one env)
         const unsigned nb = (unsigned) nb_env + (unsigned) ((3 * hp.n_envs + kEnvBlock - 1) / kEnvBlock);
-        if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
-        else hipExtLaunchKernelGGL((k_env<false, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
+        if (reset) CHUB_LAUNCH((k_env<true, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
+        else CHUB_LAUNCH((k_env<false, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
     } else {
-        if (reset) hipExtLaunchKernelGGL((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
-        else hipExtLaunchKernelGGL((k_env<false, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), 0, stream, ev0, ev1, 0, ctx, sa, ta, nb_env);
+        if (reset) CHUB_LAUNCH((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
+        else CHUB_LAUNCH((k_env<false, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
     }
+}
+
+__global__ void k_tick_advance(uint32_t *tick_base, uint32_t by) { *tick_base += by; }
+void launch_tick_advance(uint32_t *tick_base, uint32_t by, hipStream_t stream) {
+    hipLaunchKernelGGL(k_tick_advance, dim3(1), dim3(1), 0, stream, tick_base, by);
 }
 
 void launch_replay_soc(const HubParams &hp, const DevCtx *ctx, float *d_out, hipStream_t stream) {

@@ -23,6 +23,7 @@ void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepAr
                 hipEvent_t ev1, const PackedPtrs &pp);
 void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream);
 void launch_compat_ctor_sweep(const HubParams &hp, const DevCtx *ctx, hipStream_t stream);
+void launch_tick_advance(uint32_t *tick_base, uint32_t by, hipStream_t stream);
 }  // namespace chub
 
 using namespace chub;
@@ -73,6 +74,11 @@ struct chub_env {
     hipStream_t stream;
     int tape_classes;   // PHILOX tape mode: caller-registered arrival-SoC classes so far
     std::vector<float> h_cls[2], h_soc0[2], h_ttab[2];  // host copies of the class tables (introspection)
+    uint32_t *d_tick_base;     // see HubParams::tick_base
+    uint32_t graph_base;       // host mirror of *d_tick_base: ticks covered by the graph replays so far
+    uint32_t graph_tick0;      // host state at chub_graph_begin (restored at chub_graph_end: a capture runs nothing)
+    int graph_t0, graph_pc0;
+    bool capturing;
     const uint64_t *tape_pk;   // set for the duration of chub_step_tape
     const uint32_t *tape_car;
     // optional per-kernel timing with HIP events on the launch stream (chub_profile_*)
@@ -597,6 +603,8 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->tape_classes = 0;
     e->tape_pk = nullptr;
     e->tape_car = nullptr;
+    e->capturing = false;
+    e->graph_base = 0;
     // packed slot kernel (k_slot_packed): the workgroup's virtual lanes laid over whole units end to end
     {
         const int pb = kSlotBlock * kSlotsPerLane;
@@ -664,6 +672,8 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         for (size_t i = 0; i < N; i++) memcpy(&rep[i * 102], e->hy_table, sizeof e->hy_table);
         HIP_TRY(hipMemcpy(e->ev.hy_env, rep.data(), rep.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    ALLOC(e->d_tick_base, 64);
+    e->hp.tick_base = e->d_tick_base;
     ALLOC(e->d_ctx, 1);
     e->ctx_dirty = true;
     ALLOC(e->d_actions, N * (size_t) hp.act_dim); ALLOC(e->d_obs, N * (size_t) hp.obs_dim); ALLOC(e->d_reward, N);
@@ -729,7 +739,7 @@ int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_ex
     StepArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.t = 0;
-    sa.tick = e->tick;
+    sa.tick = e->tick - e->graph_base;
     sa.draw_price = (e->price_count % 4 == 0) ? 1 : 0;
     sa.station_filter = -1;
     sa.price_last = e->price[95];  // AGG:171: price = [] + mean_for_MAD; price[-1]
@@ -805,7 +815,7 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
     StepArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.t = e->t;
-    sa.tick = e->tick;
+    sa.tick = e->tick - e->graph_base;
     sa.draw_price = (e->price_count % 4 == 0) ? 1 : 0;
     sa.station_filter = -1;
     sa.price_last = e->price[e->t];  // AGG:147
@@ -870,6 +880,140 @@ int chub_step(chub_env *e, const float *actions, const double *exo_z, float *obs
     HIP_TRY(hipMemcpy(obs, e->d_obs, N * (size_t) e->hp.obs_dim * sizeof(float), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(done, e->d_done, N, hipMemcpyDeviceToHost));
+    return CHUB_OK;
+}
+
+// ---- hipGraph capture of whole episodes (launch-bound loops: small shards, multi-GPU strong scaling) -----------------------
+struct chub_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    int device;
+    chub_env *env;
+    uint32_t ticks;       // resets + steps one replay covers
+    int t_end, pc_end;    // the handle's clocks after a replay
+};
+
+int chub_graph_begin(chub_env *e, void *stream) {
+    if (!e || !stream) return fail(CHUB_ERR_ARG, "chub_graph_begin needs a handle and a created (non-default) stream");
+    if (e->capturing) return fail(CHUB_ERR_ARG, "a capture is already in progress on this handle");
+    if (e->hp.rng_mode != CHUB_RNG_PHILOX) return fail(CHUB_ERR_ARG, "graphs replay PHILOX steps (COMPAT takes host draws every step)");
+    if (e->prof_on) return fail(CHUB_ERR_ARG, "per-kernel profiling is on");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = sync_ctx(e, (hipStream_t) stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamBeginCapture((hipStream_t) stream, hipStreamCaptureModeRelaxed));
+    e->capturing = true;
+    e->graph_tick0 = e->tick;
+    e->graph_t0 = e->t;
+    e->graph_pc0 = e->price_count;
+    return CHUB_OK;
+}
+
+int chub_graph_end(chub_env *e, void *stream, chub_graph **out) {
+    if (!e || !stream || !out) return fail(CHUB_ERR_ARG, "null argument");
+    if (!e->capturing) return fail(CHUB_ERR_ARG, "no capture in progress");
+    *out = nullptr;
+    e->capturing = false;
+    const uint32_t ticks = e->tick - e->graph_tick0;
+    const int t_end = e->t, pc_end = e->price_count;
+    // nothing ran: the handle is where it was at chub_graph_begin; every chub_graph_launch moves it on by one replay
+    e->tick = e->graph_tick0;
+    e->t = e->graph_t0;
+    e->price_count = e->graph_pc0;
+    // every replay moves the Philox tick base on by the ticks the graph covers (its last node)
+    launch_tick_advance(e->d_tick_base, ticks, (hipStream_t) stream);
+    hipGraph_t g = nullptr;
+    hipError_t he = hipStreamEndCapture((hipStream_t) stream, &g);
+    if (he != hipSuccess || !g) return fail(CHUB_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(he));
+    if (ticks == 0 || (ticks & 1u)) {
+        (void) hipGraphDestroy(g);
+        return fail(CHUB_ERR_ARG, "a graph must cover an even, non-zero number of resets + steps (double-buffered draws)");
+    }
+    hipGraphExec_t x = nullptr;
+    he = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (he != hipSuccess) {
+        (void) hipGraphDestroy(g);
+        return fail(CHUB_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(he));
+    }
+    chub_graph *cg = new chub_graph();
+    cg->graph = g;
+    cg->exec = x;
+    cg->device = e->device;
+    cg->env = e;
+    cg->ticks = ticks;
+    cg->t_end = t_end;
+    cg->pc_end = pc_end;
+    *out = cg;
+    return CHUB_OK;
+}
+
+int chub_graph_launch(chub_graph *g, void *stream) {
+    if (!g) return fail(CHUB_ERR_ARG, "null graph");
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipGraphLaunch(g->exec, (hipStream_t) stream));
+    // the replay covers g->ticks resets + steps: its last node moves the device-side tick base on, the host mirrors it, so that
+    // calls issued one by one afterwards continue the same tick sequence (their argument is the tick minus the base)
+    chub_env *e = g->env;
+    e->tick += g->ticks;
+    e->graph_base += g->ticks;
+    e->t = g->t_end;
+    e->price_count = g->pc_end;
+    return CHUB_OK;
+}
+
+int chub_graph_destroy(chub_graph *g) {
+    if (!g) return CHUB_OK;
+    (void) hipSetDevice(g->device);
+    (void) hipGraphExecDestroy(g->exec);
+    (void) hipGraphDestroy(g->graph);
+    delete g;
+    return CHUB_OK;
+}
+
+// ---- device memory and streams for hosts without a GPU array library (the Python host is ctypes + numpy) ----------------
+int chub_malloc_device(int device, int64_t bytes, void **out) {
+    if (!out || bytes <= 0) return fail(CHUB_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(out, (size_t) bytes));
+    return CHUB_OK;
+}
+int chub_free_device(int device, void *p) {
+    if (!p) return CHUB_OK;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(p));
+    return CHUB_OK;
+}
+int chub_copy_to_host(int device, void *dst, const void *d_src, int64_t bytes, void *stream) {
+    if (!dst || !d_src || bytes < 0) return fail(CHUB_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpyAsync(dst, d_src, (size_t) bytes, hipMemcpyDeviceToHost, (hipStream_t) stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
+    return CHUB_OK;
+}
+int chub_copy_to_device(int device, void *d_dst, const void *src, int64_t bytes, void *stream) {
+    if (!d_dst || !src || bytes < 0) return fail(CHUB_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpyAsync(d_dst, src, (size_t) bytes, hipMemcpyHostToDevice, (hipStream_t) stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
+    return CHUB_OK;
+}
+int chub_stream_create(int device, void **out) {
+    if (!out) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (void *) s;
+    return CHUB_OK;
+}
+int chub_stream_destroy(int device, void *stream) {
+    if (!stream) return CHUB_OK;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamDestroy((hipStream_t) stream));
+    return CHUB_OK;
+}
+int chub_stream_sync(int device, void *stream) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
     return CHUB_OK;
 }
 
@@ -1271,7 +1415,7 @@ struct SnapshotHeader {
     int64_t n_envs, env_id0;
     chub_config cfg;
     int32_t rng_mode, t, price_count;
-    uint32_t tick;
+    uint32_t tick, graph_base;
     uint64_t arena_used;
     double hy_table[102];
 };
@@ -1300,6 +1444,7 @@ int chub_get_state(chub_env *e, void *buf, int64_t size) {
     h.t = e->t;
     h.price_count = e->price_count;
     h.tick = e->tick;
+    h.graph_base = e->graph_base;
     h.arena_used = e->arena_used;
     memcpy(h.hy_table, e->hy_table, sizeof h.hy_table);
     memcpy(buf, &h, sizeof h);
@@ -1326,6 +1471,7 @@ int chub_set_state(chub_env *e, const void *buf, int64_t size) {
     e->t = h.t;
     e->price_count = h.price_count;
     e->tick = h.tick;
+    e->graph_base = h.graph_base;
     memcpy(e->hy_table, h.hy_table, sizeof h.hy_table);
     e->ctx_dirty = true;
     return CHUB_OK;

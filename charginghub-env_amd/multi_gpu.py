@@ -1,0 +1,223 @@
+"""The multi-GPU form of the path without PyTorch: ctypes + numpy over libchub's own RCCL leg (include/chub.h, chub_comm_*).
+
+One process per GPU (launched by any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK, e.g. ``python -m
+torch.distributed.run`` -- only its environment variables are used).  Env shards are contiguous ranges of the global env
+index; per step each shard's packed output [n_local, D+2] f32 (obs, reward, done) goes to rank 0 in ONE grouped
+ncclSend / ncclRecv enqueued on the same HIP stream as the step kernels (``chub_step_gather``): no host wait per step.
+
+The 128-byte RCCL id travels from rank 0 to the other ranks of the node through a file in /tmp (single node: the north star's
+8 GPUs of one node); nothing else is exchanged on the host side.
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, load_library
+
+
+class DeviceBuffer(object):
+    """a plain device allocation (chub_malloc_device) with numpy round trips"""
+
+    def __init__(self, nbytes, device=0):
+        self._lib = load_library()
+        self.device = int(device)
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(self._lib.chub_malloc_device(self.device, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def to_host(self, dtype, shape, stream=0):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(self._lib.chub_copy_to_host(self.device, out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes, stream or None))
+        return out
+
+    def from_host(self, a, stream=0):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        check(self._lib.chub_copy_to_device(self.device, self.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes, stream or None))
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self._lib.chub_free_device(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Stream(object):
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self.device = int(device)
+        p = C.c_void_p()
+        check(self._lib.chub_stream_create(self.device, C.byref(p)))
+        self.ptr = p.value
+
+    def sync(self):
+        check(self._lib.chub_stream_sync(self.device, self.ptr))
+
+    def destroy(self):
+        if getattr(self, "ptr", None):
+            self._lib.chub_stream_destroy(self.device, self.ptr)
+            self.ptr = None
+
+
+def _rendezvous_path():
+    # all ranks of one launch share the launcher as parent process; the port tells concurrent launches apart
+    return "/tmp/chub_rccl_id_%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                                           os.getppid())
+
+
+def exchange_unique_id(rank, world, timeout=300.0):
+    """rank 0 makes the RCCL id (chub_comm_unique_id) and publishes it atomically; the others wait for the file"""
+    lib = load_library()
+    path = _rendezvous_path()
+    if rank == 0:
+        buf = (C.c_char * 128)()
+        check(lib.chub_comm_unique_id(buf))
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(bytes(buf))
+        os.replace(tmp, path)
+        return bytes(buf)
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                b = f.read()
+            if len(b) == 128:
+                return b
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout:
+            raise _lib.ChubError("no RCCL id from rank 0 within %.0f s (%s)" % (timeout, path))
+        time.sleep(0.01)
+
+
+class Comm(object):
+    """libchub's communicator: ncclCommInitRank behind the C ABI"""
+
+    def __init__(self, rank=None, world=None, device=None):
+        self._lib = load_library()
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        self.device = int(os.environ.get("LOCAL_RANK", "0")) if device is None else int(device)
+        uid = exchange_unique_id(self.rank, self.world)
+        h = C.c_void_p()
+        check(self._lib.chub_comm_create(uid, self.world, self.rank, self.device, C.byref(h)))
+        self._h = h
+        self.barrier()
+        if self.rank == 0:  # every rank holds the id by now
+            try:
+                os.remove(_rendezvous_path())
+            except OSError:
+                pass
+
+    def gather(self, d_send, d_recv, nbytes, stream=0):
+        check(self._lib.chub_comm_gather(self._h, d_send, d_recv or None, int(nbytes), stream or None))
+
+    def max(self, value, stream=0):
+        v = C.c_double(float(value))
+        check(self._lib.chub_comm_max_f64(self._h, C.byref(v), stream or None))
+        return v.value
+
+    def barrier(self, stream=0):
+        check(self._lib.chub_comm_barrier(self._h, stream or None))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.chub_comm_destroy(self._h)
+            self._h = None
+
+
+class HipShard(object):
+    """this rank's env shard on its GPU: libchub handle + the device buffers of the packed step output"""
+
+    def __init__(self, n_local, env_id0, device, seed, hub_kwargs, total_envs, is_root):
+        from .vec_env import VecChargingHub
+
+        self.vec = VecChargingHub(n_local, seed=seed, rng="philox", device=device, env_id0=env_id0, **hub_kwargs)
+        self.obs_dim, self.act_dim = self.vec.obs_dim, self.vec.act_dim
+        self.device = device
+        self.stream = Stream(device)
+        row = (self.obs_dim + 2) * 4
+        self.packed = [DeviceBuffer(n_local * row, device) for _ in range(2)]
+        self.gathered = [DeviceBuffer(total_envs * row, device) if is_root else None for _ in range(2)]
+        self.reset_obs = DeviceBuffer(n_local * self.obs_dim * 4, device)
+        self.total_envs = total_envs
+
+    def reset(self):
+        self.vec.reset_device(self.reset_obs.ptr, stream=self.stream.ptr)
+
+    def step_gather(self, d_actions, b, comm):
+        """the multi-GPU step in ONE ABI call: step kernels + the grouped ncclSend / ncclRecv on the same stream"""
+        check(self.vec._lib.chub_step_gather(self.vec._h, comm._h, d_actions, self.packed[b].ptr,
+                                             self.gathered[b].ptr if self.gathered[b] is not None else None, self.stream.ptr))
+
+    def fetch(self, b):
+        return self.gathered[b].to_host(np.float32, (self.total_envs, self.obs_dim + 2), self.stream.ptr)
+
+    def close(self):
+        self.stream.sync()
+        self.vec.close()
+        for buf in self.packed + [g for g in self.gathered if g is not None] + [self.reset_obs]:
+            buf.free()
+        self.stream.destroy()
+
+
+class NativeShardedHub(object):
+    """Env shard of this rank + the per-step gather, no PyTorch: contiguous shards of the global env index, ONE gather of
+    the packed (obs, reward, done) rows to rank 0 per step, double-buffered.  step() returns at once (stream order is the
+    only synchronisation); rank 0 reads a gathered block with fetch() when it wants it on the host.
+
+    `comm` / `shard` can be injected (tests drive this same class on CPU, two processes, with a host-side gather and the
+    CPU oracle as the shard): comm has .rank, .world and .gather(send, recv, nbytes, stream); a shard without
+    step_gather() has .step(actions, b), .packed[b], .gathered[b] and .fetch(b)."""
+
+    def __init__(self, total_envs, hub_kwargs, seed=0, comm=None, shard=None):
+        from .sharded import shard_range
+
+        self.comm = comm if comm is not None else Comm()
+        self.rank, self.world = self.comm.rank, self.comm.world
+        self.total_envs = int(total_envs)
+        self.env_id0, self.n_local = shard_range(self.total_envs, self.world, self.rank)
+        if shard is None:
+            shard = HipShard(self.n_local, self.env_id0, self.comm.device, seed, hub_kwargs, self.total_envs, self.rank == 0)
+        elif callable(shard):
+            shard = shard(self.n_local, self.env_id0, self.total_envs, self.rank == 0)
+        self.shard = shard
+        self.obs_dim, self.act_dim = shard.obs_dim, shard.act_dim
+        self._i = 0
+
+    def reset(self):
+        self.shard.reset()
+
+    def step(self, actions):
+        """actions: this rank's [n_local, A] f32 actions (a device address for the HIP shard).  Returns the buffer index."""
+        b = self._i & 1
+        self._i += 1
+        if hasattr(self.shard, "step_gather"):
+            self.shard.step_gather(actions, b, self.comm)
+        else:
+            self.shard.step(actions, b)
+            row = (self.obs_dim + 2) * 4
+            self.comm.gather(self.shard.packed[b], self.shard.gathered[b], self.n_local * row, getattr(self.shard, "stream", None))
+        return b
+
+    def fetch(self, b):
+        """rank 0: (obs [total, D], reward [total], done [total]) of buffer b on the host"""
+        if self.rank != 0:
+            return None
+        D = self.obs_dim
+        full = self.shard.fetch(b)
+        return full[:, :D], full[:, D], full[:, D + 1] > 0.5
+
+    def close(self):
+        self.shard.close()

@@ -141,6 +141,21 @@ class VecChargingHub(object):
     def random_actions_device(self, d_actions, key, batch, stream=0):
         check(self._lib.chub_random_actions_device(self._h, int(key), int(batch), d_actions, stream or None))
 
+    def graph_begin(self, stream):
+        """record the device-pointer calls issued on `stream` from here on instead of running them (chub_graph_begin)"""
+        check(self._lib.chub_graph_begin(self._h, stream))
+
+    def graph_end(self, stream):
+        g = C.c_void_p()
+        check(self._lib.chub_graph_end(self._h, stream, C.byref(g)))
+        return g
+
+    def graph_launch(self, graph, stream):
+        check(self._lib.chub_graph_launch(graph, stream))
+
+    def graph_destroy(self, graph):
+        self._lib.chub_graph_destroy(graph)
+
     def profile_begin(self, max_steps, every=1):
         check(self._lib.chub_profile_begin(self._h, int(max_steps), int(every)))
 

@@ -205,6 +205,29 @@ int chub_compat_replay_constructor(chub_env *env);
 /* Persistent OU states (never reset by the reference, MGR:304-316): [N][3] f64 pv, wd, price. */
 int chub_set_ou_state(chub_env *env, const double *ou);
 
+/* ---- hipGraph capture: a launch-bound loop as one submission ---------------------------------------------------------------
+ * Between chub_graph_begin and chub_graph_end the device-pointer entry points (chub_reset_device, chub_step_device*,
+ * chub_step_gather, chub_random_actions_device) called with `stream` are recorded, not run; chub_graph_launch replays the
+ * recording.  What a replay repeats verbatim: clocks, buffers and the order of calls -- so record whole episodes (reset + 96
+ * steps), an even number of calls (the state-independent draws are double-buffered).  What it does not repeat: the random
+ * streams -- every replay moves the Philox tick base on, so a replayed episode is a new episode.  PHILOX handles only.
+ * `stream` is a created stream (chub_stream_create or the caller's own), not the default stream. */
+typedef struct chub_graph chub_graph;
+int chub_graph_begin(chub_env *env, void *stream);
+int chub_graph_end(chub_env *env, void *stream, chub_graph **out);
+int chub_graph_launch(chub_graph *graph, void *stream);
+int chub_graph_destroy(chub_graph *graph);
+
+/* ---- device buffers and streams for hosts without a GPU array library (the reference-shaped Python host is ctypes + numpy):
+ * plain hipMalloc / hipFree / hipMemcpy (synchronising) / hipStream* on `device`. */
+int chub_malloc_device(int device, int64_t bytes, void **out);
+int chub_free_device(int device, void *d_ptr);
+int chub_copy_to_host(int device, void *dst, const void *d_src, int64_t bytes, void *stream);
+int chub_copy_to_device(int device, void *d_dst, const void *src, int64_t bytes, void *stream);
+int chub_stream_create(int device, void **out);
+int chub_stream_destroy(int device, void *stream);
+int chub_stream_sync(int device, void *stream);
+
 /* ---- tape mode: a parity instrument for the production (PHILOX) kernels ------------------------------------------------
  * The production streams are this build's own definition, so the kernels that run them cannot be compared with the
  * reference's recorded trajectories seed for seed.  Tape mode closes that gap: the caller supplies what the streams

@@ -645,3 +645,62 @@ def test_philox_is_statistically_the_reference_process_on_gpu():
     assert abs(a["ret"].std() - b["ret"].std()) < 0.1 * a["ret"].std()
     for key, tol in (("cars", 0.1), ("line", 0.05), ("flow", 0.05), ("soc", 0.01)):
         assert abs(a[key] - b[key]) < tol, (key, a[key], b[key])
+
+
+def test_graph_replay_equals_eager():
+    """a hipGraph of two whole episodes (chub_graph_*), replayed twice, against the same four episodes issued call by call:
+    the replays bake clocks and buffers in but not the random streams (the Philox tick base moves on with every replay), so
+    the two runs are the same simulation bit for bit"""
+    chub = hub()
+    from charginghub_env_amd import multi_gpu
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.02, renew_fluctuate=0.2, price_fluctuate=0.1)
+    n = 3000
+    out = []
+    for mode in ("eager", "graph"):
+        v = chub.VecChargingHub(n, seed=2024, **kw)
+        st = multi_gpu.Stream(0)
+        acts = [multi_gpu.DeviceBuffer(n * v.act_dim * 4) for _ in range(4)]
+        for b, a in enumerate(acts):
+            v.random_actions_device(a.ptr, 5, b, st.ptr)
+        packed = [multi_gpu.DeviceBuffer(n * (v.obs_dim + 2) * 4) for _ in range(2)]
+        obs0 = multi_gpu.DeviceBuffer(n * v.obs_dim * 4)
+
+        def episode_pair():
+            for i in range(192):
+                if i % 96 == 0:
+                    v.reset_device(obs0.ptr, stream=st.ptr)
+                v.step_device_packed(acts[i % 4].ptr, packed[i & 1].ptr, stream=st.ptr)
+
+        if mode == "eager":
+            episode_pair()
+            episode_pair()
+        else:
+            st.sync()
+            v.graph_begin(st.ptr)
+            episode_pair()
+            g = v.graph_end(st.ptr)
+            v.graph_launch(g, st.ptr)
+            v.graph_launch(g, st.ptr)
+            st.sync()
+            v.graph_destroy(g)
+        last = packed[1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr)
+        out.append((last, v.slots(), v.station_scalars()))
+        # and the handle goes on eagerly from there, the same in both runs
+        o = v.reset()
+        out[-1] += (o, v.step(np.zeros((n, v.act_dim), dtype=np.float32))[0])
+        v.close()
+        st.destroy()
+    (la, sa_, ca, oa, na), (lb, sb, cb, ob, nb) = out
+    assert np.array_equal(la, lb) and np.array_equal(ca, cb) and all(np.array_equal(x, y) for x, y in zip(sa_, sb))
+    assert np.array_equal(oa, ob) and np.array_equal(na, nb)
+    assert (la[:, -1] == 1.0).all()                                    # the 96th step of an episode: done
+    with pytest.raises(chub.ChubError):                                # an odd number of calls cannot be replayed
+        v = chub.VecChargingHub(64, seed=1, **kw)
+        st = multi_gpu.Stream(0)
+        try:
+            v.graph_begin(st.ptr)
+            v.reset_device(obs0.ptr, stream=st.ptr) if False else v.reset_device(multi_gpu.DeviceBuffer(64 * v.obs_dim * 4).ptr, stream=st.ptr)
+            v.graph_end(st.ptr)
+        finally:
+            v.close()

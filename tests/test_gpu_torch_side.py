@@ -53,6 +53,49 @@ def test_rccl_world_of_one():
     assert r.returncode == 0 and "RCCL_SINGLE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+NATIVE_CHILD = r'''
+import os, sys
+sys.path.insert(0, os.environ["CHUB_ROOT"])
+import numpy as np
+import charginghub_env_amd as chub
+from charginghub_env_amd import multi_gpu
+assert "torch" not in sys.modules
+kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+          init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
+n = 512
+hub = multi_gpu.NativeShardedHub(n, kw, seed=9)          # RANK / WORLD_SIZE / LOCAL_RANK from the environment: a world of one
+ref = chub.VecChargingHub(n, seed=9, **kw)
+acts = [multi_gpu.DeviceBuffer(n * hub.act_dim * 4) for _ in range(2)]
+host_acts = []
+for b, a in enumerate(acts):
+    hub.shard.vec.random_actions_device(a.ptr, 77, b, hub.shard.stream.ptr)
+    host_acts.append(a.to_host(np.float32, (n, hub.act_dim), hub.shard.stream.ptr))
+hub.reset(); ref.reset()
+for t in range(100):
+    if t == 96:
+        hub.reset(); ref.reset()
+    b = hub.step(acts[t & 1].ptr)                         # chub_step_gather: step kernels + grouped ncclSend/ncclRecv, one stream
+    obs, rew, done = hub.fetch(b)
+    ro, rr, rd, _ = ref.step(host_acts[t & 1])
+    assert np.array_equal(obs, ro) and np.array_equal(rew, rr) and np.array_equal(done, rd), t
+assert abs(hub.comm.max(2.5, hub.shard.stream.ptr) - 2.5) < 1e-12
+hub.comm.barrier(hub.shard.stream.ptr)
+hub.close(); hub.comm.close(); ref.close()
+assert "torch" not in sys.modules
+print("NATIVE_RCCL_OK")
+'''
+
+
+def test_native_rccl_gather_world_of_one():
+    """libchub's own RCCL leg (chub_comm_*, chub_step_gather) from a host without PyTorch: the gathered block equals the
+    single-handle run step for step; max / barrier run through RCCL"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CHUB_ROOT=root, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT="29731",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", NATIVE_CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "NATIVE_RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 TORCH_CHILD = r'''
 import os, sys
 sys.path.insert(0, os.environ["CHUB_ROOT"])

@@ -89,6 +89,108 @@ def _worker(rank, world, port, total, piles, seed, steps, q):
         dist.destroy_process_group()
 
 
+class _GlooComm(object):
+    """host-side gather (gloo) behind the interface of multi_gpu.Comm -- what the no-PyTorch multi-GPU host is given in
+    place of libchub's RCCL leg when there is no GPU"""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.device = rank, world, 0
+
+    def gather(self, send, recv, nbytes, stream=None):
+        import torch
+        import torch.distributed as dist
+        assert send.nbytes == nbytes
+        t = torch.from_numpy(send)
+        if self.rank == 0:
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            dist.gather(t, gather_list=parts, dst=0)
+            recv[...] = torch.cat(parts, dim=0).numpy()
+        else:
+            dist.gather(t, dst=0)
+
+
+class _OracleShard(object):
+    """the CPU oracle as this rank's shard (tests only): numpy buffers instead of device buffers"""
+
+    def __init__(self, n_local, env_id0, total, is_root, seed, piles):
+        self.eng = OracleEngine(n_local, env_id0, seed, piles)
+        self.obs_dim, self.act_dim = self.eng.obs_dim, self.eng.act_dim
+        self.packed = [np.zeros((n_local, self.obs_dim + 2), dtype=np.float32) for _ in range(2)]
+        self.gathered = [np.zeros((total, self.obs_dim + 2), dtype=np.float32) if is_root else None for _ in range(2)]
+
+    def reset(self):
+        self.eng.reset()
+
+    def step(self, actions, b):
+        import torch
+        self.eng.step(torch.from_numpy(actions))
+        self.packed[b][...] = self.eng.packed.numpy()
+
+    def fetch(self, b):
+        return self.gathered[b].copy()
+
+    def close(self):
+        pass
+
+
+def _native_worker(rank, world, port, total, piles, seed, steps, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from charginghub_env_amd.multi_gpu import NativeShardedHub
+
+        hub = NativeShardedHub(total, {}, seed=seed, comm=_GlooComm(rank, world),
+                               shard=lambda n, id0, tot, root: _OracleShard(n, id0, tot, root, seed, piles))
+        rs = np.random.RandomState(11)
+        out = []
+        hub.reset()
+        for t in range(steps):
+            act = rs.uniform(-1, 1, size=(total, hub.act_dim)).astype(np.float32)
+            b = hub.step(np.ascontiguousarray(act[hub.env_id0:hub.env_id0 + hub.n_local]))
+            res = hub.fetch(b)
+            if rank == 0:
+                obs, rew, done = res
+                out.append(np.concatenate([obs, rew[:, None], done[:, None].astype(np.float32)], axis=1))
+            else:
+                assert res is None
+        if rank == 0:
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_native_sharded_hub_two_ranks_host_gather():
+    """multi_gpu.NativeShardedHub (the no-PyTorch multi-GPU host: shards, double-buffered packed rows, one gather per step)
+    with a host-side gloo gather injected in place of libchub's RCCL leg and the CPU oracle as the shard"""
+    import torch.multiprocessing as mp
+
+    total, piles, seed, steps, world = 12, (20, 25), 77, 12, 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, total, piles, seed, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import torch
+    eng = OracleEngine(total, 0, seed, piles)
+    rs = np.random.RandomState(11)
+    eng.reset()
+    for t in range(steps):
+        act = rs.uniform(-1, 1, size=(total, eng.act_dim)).astype(np.float32)
+        eng.step(torch.from_numpy(act))
+        assert np.array_equal(got[t], eng.packed.numpy()), t
+
+
 @pytest.mark.timeout(300)
 def test_two_rank_gather_matches_single_process():
     import torch.multiprocessing as mp
