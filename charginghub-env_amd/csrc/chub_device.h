@@ -61,7 +61,8 @@ struct SlotArrays {          // index = base_k + env*S_k + slot  (station-major)
     //   .z t_soc     soc_to_time(soc)      -- cached, what car_step and calculate_needed both need
     //   .w bits 0-6 stay_time - already_stay_time (0 = empty), bit 7 charging this step, bits 8-14 stay_time,
     //      bits 15-24 target-SoC level l (target = 80 + 20 * l / 999, CHS.hpp:35-44), bits 25-31 car_steps taken since arrival
-    CHUB_G(uint32_t) hot;    // COMPAT [NS][4]; PHILOX [NS][2]: the 8-byte slot state described in chub_kernels.hip
+    CHUB_G(uint32_t) hot;    // COMPAT [NS][4], station-major; PHILOX [N][S0 + S1][2]: the 8-byte slot state described in
+                             // chub_kernels.hip, hub-major (station 0's piles, then station 1's, like an action row)
     // cold: written once per arriving car, read only by introspection.  Current SoC = arrival SoC advanced by the
     // recorded number of car_steps (k_replay_soc), target SoC from its level; slots without a car read as zeros.
     CHUB_G(float) init_soc;  // arrival SoC
@@ -153,8 +154,8 @@ struct HubParams {
     double rc_cells, rc_cap_mass, rc_vm60k, rc_price_std, rc_half_range[2];
     float hv_rate;           // f32(f32(0.3) * f32(permeate))
     int32_t qcap;            // explicit FCEV waiting-list entries per env = max(1, 2 * (max arrivals per step) - 1)
-    int32_t upb[2];          // packed slot kernel: whole units per workgroup = slot_block / S_k
-    int32_t packed;          // PHILOX steps run k_slot_packed (every station has 0 or >= 4 piles)
+    int32_t epb;             // packed slot kernel: whole envs per workgroup = kSlotBlock * kSlotsPerLane / (S0 + S1)
+    int32_t packed;          // PHILOX steps run k_slot_packed (the hub has >= 4 piles in all)
 };
 
 // Everything a kernel needs that does not change from step to step, kept in device memory and passed by pointer

@@ -622,9 +622,9 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     const bool unit_ok = env < (int) N;
     const bool valid = unit_ok && slot < S;
     const uint64_t unit_mask = (H == 64) ? ~0ull : (((1ull << H) - 1ull) << (uiw << logH));
-    const uint32_t idx = (uint32_t) hp.base[k] + (uint32_t) env * (uint32_t) S + (uint32_t) slot;
-    const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
     const int hub_slot = (k ? hp.S[0] : 0) + slot;
+    const uint32_t idx = (uint32_t) env * (uint32_t) (hp.S[0] + hp.S[1]) + (uint32_t) hub_slot;  // PHILOX state is hub-major
+    const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
     const bool fast = hp.type[k] == 0;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -744,61 +744,52 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_slot_packed: the PHILOX step (production).  The workgroup's lanes map onto upb = BLOCK / S whole units laid end to end
-// (lane l <-> unit l / S, slot l % S), so a station of 20 piles fills 240 of 256 lanes and the workgroup's loads and stores
-// are one contiguous run of memory.  Units may straddle a wave boundary, so every wave publishes its ballot of empty slots
-// in LDS (admission rank = empties of the unit in the previous wave + empties below the lane in its own wave, masks from
-// Tables::lane_map), and the station sums are integer LDS atomics (order-independent by definition).  A slot is empty after
-// this step iff its stay is over, which the 8-byte state says by itself: the ballots, the barrier, the renege / balk /
-// admission arithmetic and the queueing of the admitted lanes all run while the class-row reads are still in flight.  The
-// new cars of the workgroup (a handful) are served densely afterwards, one lane per car: one Philox block, two table reads,
-// the state written straight to memory.
+// k_slot_packed: the PHILOX step (production).  PHILOX slot state is laid out hub-major, [env][hub slot] (station 0's piles,
+// then station 1's), like the action rows: the workgroup's BLOCK * T virtual lanes map onto epb = BLOCK * T / (S0 + S1) whole
+// envs laid end to end, so its state loads, action loads and state stores are each ONE contiguous run of memory, read or
+// written once.  A unit = one (env, station) = S_k consecutive virtual lanes; units may straddle a wave boundary, so every
+// (virtual) wave publishes its ballot of empty slots in LDS (admission rank = empties of the unit in the previous wave +
+// empties below the lane in its own wave), and the station sums are integer LDS atomics (order-independent by definition).
+// A slot is empty after this step iff its stay is over, which the 8-byte state says by itself: the ballots, the barrier,
+// the renege / balk / admission arithmetic and the queueing of the admitted lanes all run while the class-row reads are
+// still in flight.  The new cars of the workgroup (a handful) and the station records are the last wave's business, one
+// lane per car / per unit; the other waves are done after the second barrier.
 //
-// PackedArgs: what the first loads of a wave need, by value in the kernel arguments (one scalar load) instead of
-// behind the context pointer (three dependent ones).
+// PackedArgs: everything a wave needs up front, by value in the kernel arguments and requested in one scalar batch.
 struct PackedArgs {
-    uint32_t S[2], upb[2], magic[2], base[2], type[2];
-    uint32_t n_envs, act_dim;
-    CHUB_G(uint32_t) state;          // [NS][2]
+    uint32_t S[2], type[2];
+    uint32_t n_envs, epb, magic, cls_delta;  // envs per workgroup; 65536 / (S0 + S1) + 1; byte distance cls[1] - cls[0]
+    CHUB_G(uint32_t) state;          // [N][S0 + S1][2]
     CHUB_G(uint32_t) rec;
     CHUB_G(const uint64_t) pk;       // this step's packed station draws (TAPE: supplied by the caller)
     CHUB_G(const float) actions;
-    CHUB_G(const float) cls[2];
+    CHUB_G(const float) cls0;        // station 0's class table; station 1's is cls_delta bytes further
     CHUB_G(const float) ttab[2];
-    CHUB_G(const uint32_t) car_tape; // TAPE: [NS][2] per slot, used if the slot admits a car this step: class, level | late << 16
+    CHUB_G(const uint32_t) car_tape; // TAPE: [N][S0 + S1][2] per slot, used if the slot admits a car this step: class, level | late << 16
 };
 
 template <int BLOCK, int T, bool TAPE>
 __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const PackedArgs &pa, const Tables &tb,
-                                                 const int k, const uint32_t block_local, uint32_t *q_cnt, uint32_t *q_new,
+                                                 const uint32_t block_local, uint32_t *q_cnt, uint32_t *q_new,
                                                  uint64_t *s_ball, int *s_acc, uint32_t *s_unit, float *s_tt) {
-    // T slots per lane: the workgroup's BLOCK * T "virtual lanes" v = tid + j * BLOCK (j < T) are what is laid over the
-    // units; virtual wave = wave + j * (BLOCK / 64).  All T slots' loads are in flight together and the barriers are shared.
+    // T slots per lane: virtual lane v = tid + j * BLOCK (j < T), virtual wave = wave + j * (BLOCK / 64).  All T slots' loads
+    // are in flight together and the barriers are shared.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     constexpr int WAVES = BLOCK / 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    // every per-station argument is selected from the two copies in SGPRs (indexing the argument block by k would be a
-    // dependent scalar load in front of the first vector load; the caller pinned both copies in SGPRs: otherwise the
-    // compiler turns the select of two loads into a load from a selected address, i.e. exactly that dependent load)
-#define PA(f) (k ? pa.f[1] : pa.f[0])
-    const int S = (int) PA(S), upb = (int) PA(upb);
-    const uint32_t magic = PA(magic);
-    const int N = (int) pa.n_envs;
-    const int env_first = (int) block_local * upb;
-    const uint32_t idx0 = PA(base) + (uint32_t) env_first * (uint32_t) S;
-    const int S0 = k ? (int) pa.S[0] : 0;
-    const bool fast = PA(type) == 0;
-    CHUB_G(const float) cls = PA(cls);
-    CHUB_G(const float) ttab = PA(ttab);
+    const int S0 = (int) pa.S[0], S1 = (int) pa.S[1], St = S0 + S1;
+    const int epb = (int) pa.epb, N = (int) pa.n_envs;
+    const int env_first = (int) block_local * epb;
+    const uint32_t idx0 = (uint32_t) env_first * (uint32_t) St;
     // every array reached from here is < 4 GiB (checked at create), so addresses are a uniform base + a 32-bit byte offset
     // per lane: the loads and stores take the base from SGPRs and need no 64-bit address arithmetic
 #define CHUB_AT(T_, base, byte_off) (*(CHUB_G(T_)) ((CHUB_G(char)) (base) + (uint32_t) (byte_off)))
 
-    // phase A loads: slot state, action, the unit's queue length and packed draws, the lane's ballot masks.  No zero fill for
-    // the lanes without a slot: what they hold is never used (their occupancy is forced to 0 below, their masks to empty).
-    int u[T], slot[T];
+    // phase A loads: slot state, action, the unit's queue length and packed draws.  No zero fill for the lanes without a slot:
+    // what they hold is never used (their occupancy is forced to 0 below).
+    int e_[T], k_[T], slot[T];
     bool valid[T];
     uint32_t sidx[T];
     u32x2 s2[T];
@@ -808,36 +799,41 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
 #pragma unroll
     for (int j = 0; j < T; j++) {
         const int v = tid + j * BLOCK;
-        u[j] = (int) (((uint32_t) v * magic) >> 16);  // v / S (magic = 65536 / S + 1, checked on the host)
-        slot[j] = v - u[j] * S;
-        const int env = env_first + u[j];
-        valid[j] = u[j] < upb && env < N;
-        sidx[j] = (uint32_t) k * (uint32_t) N + (uint32_t) env;
+        e_[j] = (int) (((uint32_t) v * pa.magic) >> 16);  // v / (S0 + S1) (magic = 65536 / St + 1, checked on the host)
+        const int hs = v - e_[j] * St;                    // hub slot
+        k_[j] = hs >= S0 ? 1 : 0;
+        slot[j] = hs - (k_[j] ? S0 : 0);
+        const int env = env_first + e_[j];
+        valid[j] = e_[j] < epb && env < N;
+        sidx[j] = (uint32_t) (k_[j] ? N : 0) + (uint32_t) env;
         asm volatile("" : "=v"(s2[j]), "=v"(act[j]), "=v"(line_in[j]), "=v"(pk_in[j]));
         if (valid[j]) {
             s2[j] = CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) v) << 3);
-            act[j] = CHUB_AT(const float, pa.actions, ((uint32_t) env * pa.act_dim + (uint32_t) (S0 + slot[j])) << 2);
+            act[j] = CHUB_AT(const float, pa.actions, (idx0 + (uint32_t) v + 2u * (uint32_t) env) << 2);  // row stride S0 + S1 + 2
             line_in[j] = CHUB_AT(uint32_t, pa.rec, (sidx[j] << 4) + 12u);
             pk_in[j] = CHUB_AT(const uint64_t, pa.pk, sidx[j] << 3);
         }
     }
-    // soc_to_time(target) of the 1000 target levels (CHS.hpp:35-44, 867): staged in LDS, where 64 scattered 4-byte reads cost a
-    // few cycles; as a second global gather they cost the vector cache as much as the class-row reads
-    float tt_stage[(kLevels + BLOCK - 1) / BLOCK];
+    // soc_to_time(target) of the 1000 target levels of both stations' curves (CHS.hpp:35-44, 867): staged in LDS, where 64
+    // scattered 4-byte reads cost a few cycles; as a second global gather they cost the vector cache as much as the class rows
+    constexpr int TT_PER = (2 * kLevels + BLOCK - 1) / BLOCK;
+    float tt_stage[TT_PER];
 #pragma unroll
-    for (int i = 0; i < (kLevels + BLOCK - 1) / BLOCK; i++)
-        if (tid + i * BLOCK < kLevels) tt_stage[i] = CHUB_AT(const float, ttab, (uint32_t) (tid + i * BLOCK) << 2);
+    for (int i = 0; i < TT_PER; i++) {
+        const int at = tid + i * BLOCK;
+        if (at < 2 * kLevels) tt_stage[i] = at < kLevels ? CHUB_AT(const float, pa.ttab[0], (uint32_t) at << 2)
+                                                         : CHUB_AT(const float, pa.ttab[1], (uint32_t) (at - kLevels) << 2);
+    }
     if (tid == 0) q_cnt[0] = 0;
-    for (int i = tid; i < 4 * upb; i += BLOCK) s_acc[i] = 0;
+    for (int i = tid; i < 8 * epb; i += BLOCK) s_acc[i] = 0;
 
     // ---- second round trip, only for the slots whose car stays: where it is on its curve (entries n, n + 1 of its class
-    // row) and soc_to_time(target).  A car that leaves this step is wiped right after its car_step (CHS.hpp:1196-1201): nothing
-    // of it is needed, and a slot is empty after remove_car (CHS.hpp:912-923 / 1077-1088) iff it had at most one slot of stay left
+    // row).  A car that leaves this step is wiped right after its car_step (CHS.hpp:1196-1201): nothing of it is needed, and
+    // a slot is empty after remove_car (CHS.hpp:912-923 / 1077-1088) iff it had at most one slot of stay left
     uint32_t w0[T];
     int tl[T];
     bool stays[T];
     f32x4 row[T];
-    float t_target[T];
 #pragma unroll
     for (int j = 0; j < T; j++) {
         asm volatile("" : "+v"(s2[j]));
@@ -845,11 +841,11 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         tl[j] = ps_tl(w0[j]);
         stays[j] = tl[j] > 1;
         asm volatile("" : "=v"(row[j]));
-        if (stays[j]) row[j] = CHUB_AT(const f32x4, cls, (s2[j].y << 8) + (ps_n(w0[j]) << 3));
+        if (stays[j]) row[j] = CHUB_AT(const f32x4, pa.cls0, (k_[j] ? pa.cls_delta : 0u) + (s2[j].y << 8) + (ps_n(w0[j]) << 3));
     }
 #pragma unroll
-    for (int i = 0; i < (kLevels + BLOCK - 1) / BLOCK; i++)
-        if (tid + i * BLOCK < kLevels) s_tt[tid + i * BLOCK] = tt_stage[i];
+    for (int i = 0; i < TT_PER; i++)
+        if (tid + i * BLOCK < 2 * kLevels) s_tt[tid + i * BLOCK] = tt_stage[i];
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627) while those are in flight
     bool empty[T];
@@ -868,9 +864,10 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
 #pragma unroll
     for (int j = 0; j < T; j++) {
         const int vw = wave + j * WAVES;
+        const int Sk = k_[j] ? S1 : S0;
         // ballot masks of the unit's lanes [ub, ue) of the workgroup: in this (virtual) wave, and in the neighbouring wave the unit
-        // began in or runs over into (S <= 64: at most one of the two)
-        const int ub = u[j] * S - vw * 64, ue = ub + S;  // relative to this wave's lane 0
+        // began in or runs over into (S_k <= 64: at most one of the two)
+        const int ub = e_[j] * St + (k_[j] ? S0 : 0) - vw * 64, ue = ub + Sk;  // relative to this wave's lane 0
         const bool b_prev = ub < 0, b_next = ue > 64;
         const uint64_t mA = (~0ull >> (b_next ? 0 : 64 - ue)) & (~0ull << (b_prev ? 0 : ub));
         const uint64_t mB = b_prev ? (~0ull << (64 + ub)) : (b_next ? (~0ull >> (128 - ue)) : 0ull);
@@ -882,8 +879,11 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         int assign = 0;
         if (valid[j]) {
             const uint64_t pk = pk_in[j];
+            const bool fast = (k_[j] ? pa.type[1] : pa.type[0]) == 0;
             line[j] = __popc((uint32_t) pk & ((1u << line[j]) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
             const int n_in = (int) (pk >> 10) & 15;
+            // the fast station records the un-thinned count (CHS.hpp:1617), the slow one what survives the balk pass given the
+            // queue length just computed (CHS.hpp:1297-1306)
             flow[j] = fast ? n_in : (int) ((pk >> (14 + 4 * line[j])) & 15);
             assign = (line[j] + flow[j]) < empties ? (line[j] + flow[j]) : empties;  // assign_car, CHS.hpp:417-430
             line[j] = line[j] + flow[j] - assign;
@@ -909,15 +909,16 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
 #pragma unroll
     for (int j = 0; j < T; j++) {
         asm volatile("" : "+v"(row[j]), "+v"(act[j]));
-        t_target[j] = s_tt[ps_tgt(w0[j])];
-        int *acc = s_acc + 4 * u[j];  // the unit's {min, charge power | max power, cars}: two 64-bit LDS atomics per car
+        const int u = 2 * e_[j] + k_[j];
+        int *acc = s_acc + 4 * u;  // the unit's {min, charge power | max power, cars}: two 64-bit LDS atomics per car
         uint32_t w0n = 0u;
         if (stays[j]) {
+            const float t_target = s_tt[(k_[j] ? kLevels : 0) + (int) ps_tgt(w0[j])];
             // action_to_real (MGR:384-393), judge_feasibility (CHS.hpp:1404-1413)
-            const bool on = act[j] >= kActOnThreshold || must_charge(t_target[j], row[j].y, tl[j]);
+            const bool on = act[j] >= kActOnThreshold || must_charge(t_target, row[j].y, tl[j]);
             const float power = on ? row[j].z : row[j].x, t_soc = on ? row[j].w : row[j].y;  // car_step = the next entry of the class row
             const int q = (int) (power * 524288.0f);
-            const bool urgent = must_charge(t_target[j], t_soc, tl[j] - 1);
+            const bool urgent = must_charge(t_target, t_soc, tl[j] - 1);
             w0n = (w0[j] & ~64u) - 1u + (on ? ((1u << 13) | 64u) : 0u);
             atomicAdd((unsigned long long *) (acc + 2), (unsigned long long) (uint32_t) q | (1ull << 32));
             if (on || urgent)
@@ -928,18 +929,20 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
             const u32x2 o2 = {w0n, s2[j].y};
             CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) (tid + j * BLOCK)) << 3) = o2;
         }
-        if (valid[j] && slot[j] == 0) s_unit[u[j]] = (uint32_t) line[j] | (((uint32_t) flow[j] & 0xFFu) << 8);
+        if (valid[j] && slot[j] == 0) s_unit[u] = (uint32_t) line[j] | (((uint32_t) flow[j] & 0xFFu) << 8);
     }
     __syncthreads();
     // Everything left -- the workgroup's new cars and, after them, the station records -- is the last wave's business: the
     // other waves are done (their wave slots go to the next workgroup instead of idling at a third barrier through the
-    // Philox block and the two dependent table reads of the new cars)
+    // Philox block and the dependent table read of the new cars)
     if (wave != WAVES - 1) return;
-    // ---- add_car (CHS.hpp:864-877 / 1029-1042) for the workgroup's new cars, one lane per car, from the high waves
+    // ---- add_car (CHS.hpp:864-877 / 1029-1042) for the workgroup's new cars, one lane per car
     const uint32_t n_adm = q_cnt[0];
     for (uint32_t i = (uint32_t) lane; i < n_adm; i += 64) {
         const int src = (int) q_new[i];
-        const int s_u = (int) (((uint32_t) src * magic) >> 16);
+        const int s_e = (int) (((uint32_t) src * pa.magic) >> 16);
+        const int s_hs = src - s_e * St;
+        const int s_k = s_hs >= S0 ? 1 : 0;
         uint32_t c, lev;
         int late;
         if (TAPE) {
@@ -948,20 +951,20 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
             lev = tp.y & 0xFFFFu;
             late = (int) (tp.y >> 16);
         } else {
-            PhiloxCtx p2{hp.key[0], hp.key[1], CHUB_TICK(hp, sa.tick), (uint32_t) (hp.env_id0 + env_first + s_u)};
-            const U4 o = p2.block(SITE_SOC, (uint32_t) (S0 + (src - s_u * S)), 0);  // word 0 SoC class, 1 target level, 2 extra stay
+            PhiloxCtx p2{hp.key[0], hp.key[1], CHUB_TICK(hp, sa.tick), (uint32_t) (hp.env_id0 + env_first + s_e)};
+            const U4 o = p2.block(SITE_SOC, (uint32_t) s_hs, 0);  // word 0 SoC class, 1 target level, 2 extra stay
             c = o.v[0] >> kSocLevelShift;
             lev = o.v[1] % 1000u;
             late = late_from_word(tb.late_thr, o.v[2]);
         }
-        const f32x2 e0 = CHUB_AT(const f32x2, cls, c << 8);
-        const float tt_ = s_tt[lev];
+        const f32x2 e0 = CHUB_AT(const f32x2, pa.cls0, (s_k ? pa.cls_delta : 0u) + (c << 8));
+        const float tt_ = s_tt[(s_k ? kLevels : 0) + (int) lev];
         int st_ = (int) ceilf(__fsub_rn(tt_, e0.y)) + late;  // calculate_min_charging_time + mk_late_time
         st_ = st_ > kMaxStay ? kMaxStay : st_;
         const u32x2 o2 = {st_ > 0 ? ps_make(st_, lev) : 0u, c};
         CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) src) << 3) = o2;
         if (st_ > 0) {
-            int *ac = s_acc + 4 * s_u;
+            int *ac = s_acc + 4 * (2 * s_e + s_k);
             const int q = (int) (e0.x * 524288.0f);
             atomicAdd((unsigned long long *) (ac + 2), (unsigned long long) (uint32_t) q | (1ull << 32));
             if (must_charge(tt_, e0.y, st_)) atomicAdd(ac, q);
@@ -971,63 +974,50 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int i = lane; i < upb; i += 64) {  // one station record per unit: consecutive envs, one contiguous run of 16-byte stores
-        const int env = env_first + i;
-        if (env < N) {
-            const int *acc = s_acc + 4 * i;
-            const uint32_t pkd = s_unit[i] | ((uint32_t) acc[3] << 16);
-            const u32x4 rv = {__float_as_uint(fixed_to_kw(acc[0])), __float_as_uint(fixed_to_kw(acc[1])),
-                              __float_as_uint(fixed_to_kw(acc[2])), pkd};
-            CHUB_AT(u32x4, pa.rec, ((uint32_t) k * (uint32_t) N + (uint32_t) env) << 4) = rv;
+    for (int i = lane; i < 2 * epb; i += 64) {  // one station record per unit
+        const int e = i >> 1, k = i & 1;
+        const int env = env_first + e;
+        if (env >= N) continue;
+        const uint32_t su = (uint32_t) (k ? N : 0) + (uint32_t) env;
+        uint32_t lf = s_unit[i];
+        if ((k ? S1 : S0) == 0) {
+            // a station without piles still queues, reneges and balks (receive_car runs on it as on any other, CHS.hpp:1272-1316 /
+            // 1583-1627; nobody is ever admitted): its queue length and arrival count move on here, power sums and cars stay 0
+            const uint32_t l_in = CHUB_AT(uint32_t, pa.rec, (su << 4) + 12u);
+            const uint64_t pk = CHUB_AT(const uint64_t, pa.pk, su << 3);
+            int ln = (int) (l_in & 0xFFu);
+            ln = __popc((uint32_t) pk & ((1u << ln) - 1u));
+            const int n_in = (int) (pk >> 10) & 15;
+            const int fl = ((k ? pa.type[1] : pa.type[0]) == 0) ? n_in : (int) ((pk >> (14 + 4 * ln)) & 15);
+            ln = ln + fl;
+            ln = ln < kMaxLine ? ln : kMaxLine;
+            lf = (uint32_t) ln | (((uint32_t) fl & 0xFFu) << 8);
         }
+        const int *acc = s_acc + 4 * i;
+        const uint32_t pkd = lf | ((uint32_t) acc[3] << 16);
+        const u32x4 rv = {__float_as_uint(fixed_to_kw(acc[0])), __float_as_uint(fixed_to_kw(acc[1])),
+                          __float_as_uint(fixed_to_kw(acc[2])), pkd};
+        CHUB_AT(u32x4, pa.rec, su << 4) = rv;
     }
 #undef CHUB_AT
-#undef PA
-}
-
-// A station without piles still queues, reneges and balks (receive_car runs on it as on any other, CHS.hpp:1272-1316 /
-// 1583-1627; nobody is ever admitted): one lane per env advances its queue length and arrival count and writes the station
-// record (power sums and car count 0).
-template <int BLOCK>
-__device__ __forceinline__ void empty_station_body(const StepArgs &sa, const PackedArgs &pa, const int k, const uint32_t block_local) {
-    const uint32_t env = block_local * BLOCK + threadIdx.x;
-    if (env >= pa.n_envs) return;
-    const uint32_t sidx = (uint32_t) k * pa.n_envs + env;
-    const uint32_t line_in = pa.rec[4u * sidx + 3u];
-    const uint64_t pk = pa.pk[sidx];
-    int line = (int) (line_in & 0xFFu);
-    line = __popc((uint32_t) pk & ((1u << line) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
-    const int n_in = (int) (pk >> 10) & 15;
-    const int flow = (pa.type[k] == 0) ? n_in : (int) ((pk >> (14 + 4 * line)) & 15);
-    line = line + flow;
-    line = line < kMaxLine ? line : kMaxLine;
-    const u32x4 rv = {0u, 0u, 0u, (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8)};
-    *((CHUB_G(u32x4)) pa.rec + sidx) = rv;
 }
 
 template <int BLOCK, int T, bool TAPE>
-__global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in, uint32_t nb0) {
+__global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in) {
+    __shared__ uint32_t q_new[BLOCK * T];
+    __shared__ uint32_t q_cnt[2];
+    __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];                   // [1 + virtual wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
+    __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T];  // 2 epb <= BLOCK * T / 2 units x {min, charge, max power, cars}
+    __shared__ uint32_t s_unit[BLOCK * T / 2];                        // per unit: line | flow << 8
+    __shared__ float s_tt[2 * kLevels];                               // soc_to_time(target level) of both stations' curves
     // all kernel arguments this wave needs, requested in ONE batch of scalar loads at its very start (the single asm
     // statement makes every one of them live here), instead of in a chain of dependent loads in front of the first
     // vector load
     PackedArgs pa = pa_in;
-    asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.upb[0]), "+s"(pa.upb[1]), "+s"(pa.magic[0]), "+s"(pa.magic[1]),
-                      "+s"(pa.base[0]), "+s"(pa.base[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.act_dim),
-                      "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls[0]), "+s"(pa.cls[1]), "+s"(pa.ttab[0]), "+s"(pa.ttab[1]), "+s"(nb0));
-    __shared__ uint32_t q_new[BLOCK * T];
-    __shared__ uint32_t q_cnt[2];
-    __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];               // [1 + virtual wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
-    __shared__ __attribute__((aligned(16))) int s_acc[BLOCK * T];  // upb <= BLOCK * T / 4 units x {min, charge, max power, cars}
-    __shared__ uint32_t s_unit[BLOCK * T / 4];                    // per unit: line | flow << 8
-    __shared__ float s_tt[kLevels];                               // soc_to_time(target level) of this station's curve
-    const uint32_t bid = blockIdx.x;
-    const int k = (bid >= nb0) ? 1 : 0;
-    const uint32_t bl = k ? bid - nb0 : bid;
-    if ((k ? pa.S[1] : pa.S[0]) == 0) {
-        empty_station_body<BLOCK>(sa, pa, k, bl);
-        return;
-    }
-    slot_body_packed<BLOCK, T, TAPE>(ctx->hp, sa, pa, ctx->tb, k, bl, q_cnt, q_new, s_ball + 1, s_acc, s_unit, s_tt);
+    asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
+                      "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab[0]),
+                      "+s"(pa.ttab[1]));
+    slot_body_packed<BLOCK, T, TAPE>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new, s_ball + 1, s_acc, s_unit, s_tt);
 }
 
 // What the tail's first loads need, by value in the kernel arguments: one scalar load at the start of the wave instead
@@ -1781,7 +1771,8 @@ __global__ void k_replay_soc(const DevCtx *__restrict__ ctx, float *out) {
     const int64_t NS = hp.n_envs * (int64_t) (hp.S[0] + hp.S[1]);
     const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= NS) return;
-    const int k = idx >= hp.base[1] ? 1 : 0;
+    const int St = hp.S[0] + hp.S[1];
+    const int k = hp.rng_mode == MODE_PHILOX ? ((int) (idx % St) >= hp.S[0] ? 1 : 0) : (idx >= hp.base[1] ? 1 : 0);
     const bool cp = hp.constant_charging != 0;
     float soc = 0.0f;
     int n = 0;
@@ -1875,24 +1866,22 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             PackedArgs pa;
             for (int k = 0; k < 2; k++) {
                 pa.S[k] = (uint32_t) hp.S[k];
-                pa.upb[k] = (uint32_t) hp.upb[k];
-                pa.magic[k] = hp.S[k] > 0 ? 65536u / (uint32_t) hp.S[k] + 1u : 0u;
-                pa.base[k] = (uint32_t) hp.base[k];
                 pa.type[k] = (uint32_t) hp.type[k];
-                pa.cls[k] = (CHUB_G(const float)) pp.cls[k];
                 pa.ttab[k] = (CHUB_G(const float)) pp.ttab[k];
             }
             pa.n_envs = (uint32_t) hp.n_envs;
-            pa.act_dim = (uint32_t) hp.act_dim;
+            pa.epb = (uint32_t) hp.epb;
+            pa.magic = 65536u / (uint32_t) (hp.S[0] + hp.S[1]) + 1u;
+            pa.cls_delta = (uint32_t) ((const char *) pp.cls[1] - (const char *) pp.cls[0]);
             pa.state = (CHUB_G(uint32_t)) pp.hot;
             pa.rec = (CHUB_G(uint32_t)) pp.rec;
             pa.pk = (CHUB_G(const uint64_t)) (sa.pk_tape ? sa.pk_tape : pp.pk[sa.tick & 1u]);
             pa.actions = (CHUB_G(const float)) sa.actions;
+            pa.cls0 = (CHUB_G(const float)) pp.cls[0];
             pa.car_tape = (CHUB_G(const uint32_t)) sa.car_tape;
-            const uint32_t nb0 = (uint32_t) ((hp.n_envs + hp.upb[0] - 1) / hp.upb[0]);
-            const uint32_t nb1 = (uint32_t) ((hp.n_envs + hp.upb[1] - 1) / hp.upb[1]);
-            if (sa.car_tape) CHUB_LAUNCH((k_slot_packed<kSlotBlock, kSlotsPerLane, true>), dim3(nb0 + nb1), dim3(kSlotBlock), stream, ev0, ev1, ctx, sa, pa, nb0);
-            else CHUB_LAUNCH((k_slot_packed<kSlotBlock, kSlotsPerLane, false>), dim3(nb0 + nb1), dim3(kSlotBlock), stream, ev0, ev1, ctx, sa, pa, nb0);
+            const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
+            if (sa.car_tape) CHUB_LAUNCH((k_slot_packed<kSlotBlock, kSlotsPerLane, true>), dim3(nb), dim3(kSlotBlock), stream, ev0, ev1, ctx, sa, pa);
+            else CHUB_LAUNCH((k_slot_packed<kSlotBlock, kSlotsPerLane, false>), dim3(nb), dim3(kSlotBlock), stream, ev0, ev1, ctx, sa, pa);
         } else launch_slot_t<false, MODE_PHILOX>(hp, ctx, sa, stream, ev0, ev1);
         return;
     }

@@ -605,16 +605,15 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->tape_car = nullptr;
     e->capturing = false;
     e->graph_base = 0;
-    // packed slot kernel (k_slot_packed): the workgroup's virtual lanes laid over whole units end to end
+    // packed slot kernel (k_slot_packed): the workgroup's virtual lanes laid over whole envs end to end
     {
-        const int pb = kSlotBlock * kSlotsPerLane;
-        for (int s = 0; s < 2; s++) hp.upb[s] = hp.S[s] > 0 ? pb / hp.S[s] : kSlotBlock;  // no piles: one lane per env (empty_station_body)
-        bool magic_ok = true;  // the kernel divides lane numbers by S with a 16-bit reciprocal
-        for (int s = 0; s < 2 && magic_ok; s++)
-            for (int l = 0; l < pb && hp.S[s] > 0; l++)
-                if ((((uint32_t) l * (65536u / (uint32_t) hp.S[s] + 1u)) >> 16) != (uint32_t) (l / hp.S[s])) magic_ok = false;
-        hp.packed = (rng_mode == CHUB_RNG_PHILOX && (hp.S[0] >= 4 || hp.S[0] == 0) && (hp.S[1] >= 4 || hp.S[1] == 0) && magic_ok &&
-                     (uint64_t) n_envs * (uint64_t) (hp.S[0] + hp.S[1] + 2) * 16u < ((uint64_t) 1 << 32) &&  // 32-bit byte offsets
+        const int pb = kSlotBlock * kSlotsPerLane, St = hp.S[0] + hp.S[1];
+        hp.epb = pb / St > 0 ? pb / St : 1;
+        bool magic_ok = true;  // the kernel divides lane numbers by S0 + S1 with a 16-bit reciprocal
+        for (int l = 0; l < pb && magic_ok; l++)
+            if ((((uint32_t) l * (65536u / (uint32_t) St + 1u)) >> 16) != (uint32_t) (l / St)) magic_ok = false;
+        hp.packed = (rng_mode == CHUB_RNG_PHILOX && St >= 4 && St <= pb && magic_ok &&
+                     (uint64_t) n_envs * (uint64_t) (St + 2) * 16u < ((uint64_t) 1 << 32) &&  // 32-bit byte offsets
                      opt.slot_kernel != 1) ? 1 : 0;
     }
     build_hy_table(hp, e->hy_table);
@@ -638,14 +637,19 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if ((rc = dev_upload(e, &e->tb.ttab[0], ttab[0]))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.ttab[1], ttab[1]))) return bail(rc);
     e->tb.cls[0] = e->tb.cls[1] = e->tb.cls_soc0[0] = e->tb.cls_soc0[1] = nullptr;
-    if (rng_mode == CHUB_RNG_PHILOX)
+    if (rng_mode == CHUB_RNG_PHILOX) {
+        // both stations' class tables in one buffer (the packed kernel addresses station 1's as station 0's + a byte distance)
+        std::vector<float> both(cls[0]);
+        both.insert(both.end(), cls[1].begin(), cls[1].end());
+        if ((rc = dev_upload(e, &e->tb.cls[0], both))) return bail(rc);
+        e->tb.cls[1] = e->tb.cls[0] + cls[0].size();
         for (int s = 0; s < 2; s++) {
-            if ((rc = dev_upload(e, &e->tb.cls[s], cls[s]))) return bail(rc);
             if ((rc = dev_upload(e, &e->tb.cls_soc0[s], cls_soc0[s]))) return bail(rc);
             e->h_cls[s] = cls[s];
             e->h_soc0[s] = cls_soc0[s];
             e->h_ttab[s] = ttab[s];
         }
+    }
 
     // ---- state in HBM
     const size_t N = (size_t) n_envs, NS = N * (size_t) (hp.S[0] + hp.S[1]);
@@ -1060,7 +1064,7 @@ int chub_set_slots(chub_env *e, const int32_t *rows) {
                 if ((uint32_t) r[0] >= n_classes || r[1] < 0 || r[1] >= kLevels || r[2] < 1 || r[2] > 63 || left < 1 || r[4] < 0 ||
                     r[4] >= kClsRow)
                     return fail(CHUB_ERR_ARG, "chub_set_slots: field out of range");
-                const size_t idx = (size_t) hp.base[k] + env * (size_t) hp.S[k] + i;
+                const size_t idx = env * S + (k ? (size_t) hp.S[0] : 0) + i;  // PHILOX state is hub-major
                 st[2 * idx] = (uint32_t) left | (r[5] ? 64u : 0u) | ((uint32_t) r[2] << 7) | ((uint32_t) r[4] << 13) | ((uint32_t) r[1] << 18);
                 st[2 * idx + 1] = (uint32_t) r[0];
             }
@@ -1093,15 +1097,8 @@ int chub_step_tape(chub_env *e, const float *actions, const uint64_t *pk_tape, c
         return fail(CHUB_ERR_ARG, "tape mode drives the packed PHILOX slot kernel: the hub shape must be one it covers");
     HIP_TRY(hipSetDevice(e->device));
     const size_t N = (size_t) e->hp.n_envs, S = (size_t) (e->hp.S[0] + e->hp.S[1]);
-    // the car tape comes in hub order [N][S][2] (station 0's slots first): to the kernel's station-major slot index
-    std::vector<uint32_t> ct(2 * N * S);
-    for (size_t env = 0; env < N; env++)
-        for (int k = 0; k < 2; k++)
-            for (size_t i = 0; i < (size_t) e->hp.S[k]; i++) {
-                const size_t src = env * S + (k ? (size_t) e->hp.S[0] : 0) + i, dst = (size_t) e->hp.base[k] + env * (size_t) e->hp.S[k] + i;
-                ct[2 * dst] = car_tape[2 * src];
-                ct[2 * dst + 1] = car_tape[2 * src + 1];
-            }
+    // the car tape is in hub order [N][S][2] (station 0's slots first), which is the kernel's own slot order
+    const std::vector<uint32_t> ct(car_tape, car_tape + 2 * N * S);
     uint64_t *d_pk = nullptr;
     uint32_t *d_ct = nullptr;
     HIP_TRY(hipMalloc((void **) &d_pk, 2 * N * sizeof(uint64_t)));
@@ -1170,7 +1167,7 @@ int chub_get_slots(chub_env *e, float *out) {
         for (int k = 0; k < 2; k++) {
             const size_t n = (size_t) hp.S[k];
             for (size_t i = 0; i < n; i++) {
-                const size_t idx = (size_t) hp.base[k] + env * n + i;
+                const size_t idx = philox ? env * S + (k ? (size_t) hp.S[0] : 0) + i : (size_t) hp.base[k] + env * n + i;
                 float power = 0, t_target = 0, t_soc = 0, arrive = 0;
                 int left, stay, lev;
                 bool chg;

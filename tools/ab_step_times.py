@@ -4,24 +4,25 @@
 tools/ab_step_times.py; done"""
 import os, sys
 sys.path.insert(0, ".")
-import torch
 import charginghub_env_amd as chub
-n=65536
-for perm in (0.01,):
-    kw = dict(station_list=[20,25], station_type_list=["fast","slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=perm)
-    v = chub.VecChargingHub(n, seed=1, **kw)
-    dev = torch.device("cuda", 0)
-    acts = [torch.empty((n, 47), device=dev) for _ in range(4)]
-    for b,a in enumerate(acts): v.random_actions_device(a.data_ptr(), 123, b, 0)
-    packed = torch.empty((n, 15), device=dev); obs0 = torch.empty((n, 13), device=dev)
-    for i in range(960):
-        if i % 96 == 0: v.reset_device(obs0.data_ptr())
-        v.step_device_packed(acts[i%4].data_ptr(), packed.data_ptr())
-    torch.cuda.synchronize()
-    v.profile_begin(1920, every=2)
-    for i in range(1920):
-        if i % 96 == 0: v.reset_device(obs0.data_ptr())
-        v.step_device_packed(acts[i%4].data_ptr(), packed.data_ptr())
-    a,b,k = v.profile_end()
-    print(os.environ.get("CHUB_LIB","")[-12:], "permeate", perm, "slot_us %.2f env_us %.2f" % (a/k*1e3, b/k*1e3))
-    v.close()
+from charginghub_env_amd import multi_gpu
+n = int(os.environ.get("AB_ENVS", "65536"))
+kw = dict(station_list=[20,25], station_type_list=["fast","slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
+v = chub.VecChargingHub(n, seed=1, **kw)
+acts = [multi_gpu.DeviceBuffer(n * 47 * 4) for _ in range(4)]
+for b, a in enumerate(acts): v.random_actions_device(a.ptr, 123, b, 0)
+packed = multi_gpu.DeviceBuffer(n * 15 * 4); obs0 = multi_gpu.DeviceBuffer(n * 13 * 4)
+for i in range(960):
+    if i % 96 == 0: v.reset_device(obs0.ptr)
+    v.step_device_packed(acts[i%4].ptr, packed.ptr)
+v.sync()
+v.profile_begin(1920, every=2)
+import time
+t0 = time.perf_counter()
+for i in range(1920):
+    if i % 96 == 0: v.reset_device(obs0.ptr)
+    v.step_device_packed(acts[i%4].ptr, packed.ptr)
+a, b, k = v.profile_end()
+dt = time.perf_counter() - t0
+print(os.environ.get("CHUB_LIB","")[-12:], "slot_us %.2f env_us %.2f step_us %.2f" % (a/k*1e3, b/k*1e3, dt/1920*1e6))
+v.close()
