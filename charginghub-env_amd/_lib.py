@@ -79,7 +79,7 @@ def load_library():
         "chub_create": (I, [C.POINTER(ChubConfig), C.c_char_p, L, L, I, C.c_uint64, I, C.POINTER(P)]),
         "chub_create_ex": (I, [C.POINTER(ChubConfig), C.c_char_p, L, L, I, C.c_uint64, I, C.POINTER(ChubOptions), C.POINTER(P)]),
         "chub_destroy": (I, [P]),
-        "chub_obs_dim": (I, [P]), "chub_act_dim": (I, [P]), "chub_num_envs": (L, [P]), "chub_clock": (I, [P]),
+        "chub_obs_dim": (I, [P]), "chub_act_dim": (I, [P]), "chub_num_envs": (L, [P]), "chub_clock": (I, [P]), "chub_uses_packed_kernel": (I, [P]),
         "chub_reset": (I, [P, P, P, P]),
         "chub_step": (I, [P, P, P, P, P, P]),
         "chub_reset_device": (I, [P, P, P, P, P]),
@@ -116,7 +116,7 @@ def load_library():
     return lib
 
 
-EXPORTED = ["chub_create", "chub_create_ex", "chub_destroy", "chub_obs_dim", "chub_act_dim", "chub_num_envs", "chub_clock", "chub_reset",
+EXPORTED = ["chub_create", "chub_create_ex", "chub_destroy", "chub_obs_dim", "chub_act_dim", "chub_num_envs", "chub_clock", "chub_uses_packed_kernel", "chub_reset",
             "chub_step", "chub_reset_device", "chub_step_device", "chub_step_device_packed", "chub_step_load", "chub_step_load_device", "chub_random_actions_device", "chub_sync", "chub_profile_begin", "chub_profile_end",
             "chub_get_slots", "chub_get_station_scalars", "chub_get_telemetry", "chub_get_obs_f64",
             "chub_get_reward_f64", "chub_set_telemetry", "chub_fcev_stuck_count", "chub_set_rng_compat_seeds", "chub_set_rng_compat_state", "chub_get_rng_compat_state", "chub_compat_replay_constructor", "chub_set_ou_state",

@@ -724,6 +724,7 @@ int chub_obs_dim(const chub_env *e) { return e ? e->hp.obs_dim : CHUB_ERR_ARG; }
 int chub_act_dim(const chub_env *e) { return e ? e->hp.act_dim : CHUB_ERR_ARG; }
 int64_t chub_num_envs(const chub_env *e) { return e ? e->hp.n_envs : CHUB_ERR_ARG; }
 int chub_clock(const chub_env *e) { return e ? e->t : CHUB_ERR_ARG; }
+int chub_uses_packed_kernel(const chub_env *e) { return e ? e->hp.packed : CHUB_ERR_ARG; }
 
 int chub_sync(chub_env *e) {
     if (!e) return fail(CHUB_ERR_ARG, "null handle");

@@ -169,6 +169,10 @@ class VecChargingHub(object):
         check(self._lib.chub_sync(self._h))
 
     @property
+    def uses_packed_kernel(self):
+        return bool(self._lib.chub_uses_packed_kernel(self._h))
+
+    @property
     def clock(self):
         return self._lib.chub_clock(self._h)
 

@@ -99,6 +99,7 @@ int chub_obs_dim(const chub_env *env);  /* 2 + 4*(#stations with piles>0) + 3 (M
 int chub_act_dim(const chub_env *env);  /* S + 2 (MGR:108-113) */
 int64_t chub_num_envs(const chub_env *env);
 int chub_clock(const chub_env *env);    /* 0..95, shared by all envs (lock-step) */
+int chub_uses_packed_kernel(const chub_env *env); /* 1: PHILOX steps of this handle run k_slot_packed (the production kernel) */
 
 /* ---- hot path ------------------------------------------------------------------------------
  * chub_reset replaces EvcsspManagerEnv_v6.reset (MGR:304-316 -> AGG:157-175 evs_reset main.cpp:199,251,

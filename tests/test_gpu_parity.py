@@ -704,3 +704,46 @@ def test_graph_replay_equals_eager():
             v.graph_end(st.ptr)
         finally:
             v.close()
+
+
+def test_full_size_c5_properties():
+    """BASELINE.json configs[4] at its own size: 262 144 envs x hub [32 fast, 32 slow] with fluctuating price / PV / wind, one
+    episode on the production (packed) kernel: 4-way shard independence (what the 8-GPU job relies on), the invariants the
+    reference asserts (MGR:191,205; HYD:111-112), occupancy bookkeeping.  This is the size where 32-bit slot offsets and the
+    arena are largest."""
+    chub = hub()
+    kw = dict(station_list=[32, 32], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01, renew_fluctuate=0.3, price_fluctuate=0.3)
+    N, Q = 262144, 4
+    whole = chub.VecChargingHub(N, seed=12345, rng="philox", **kw)
+    assert whole.uses_packed_kernel
+    parts = [chub.VecChargingHub(N // Q, seed=12345, rng="philox", env_id0=q * (N // Q), **kw) for q in range(Q)]
+    rs = np.random.RandomState(3)
+    acts = [rs.uniform(-1, 1, size=(N, whole.act_dim)).astype(np.float32) for _ in range(3)]
+    o = whole.reset()
+    assert np.array_equal(o, np.concatenate([p.reset() for p in parts]))
+    ret = np.zeros(N)
+    for t in range(96):
+        act = acts[t % 3]
+        o, r, d, _ = whole.step(act)
+        po, pr = zip(*[p.step(act[q * (N // Q):(q + 1) * (N // Q)])[:2] for q, p in enumerate(parts)])
+        assert np.array_equal(o, np.concatenate(po)) and np.array_equal(r, np.concatenate(pr)), t
+        assert np.all(np.isfinite(o)) and np.all(np.isfinite(r))
+        assert d.all() == (t == 95) and d.any() == (t == 95)
+        ret += r
+        if t in (0, 50, 95):
+            sc = whole.station_scalars()
+            sl = whole.slots()
+            for k in (0, 1):
+                assert np.array_equal(sl[k][:, 0, :].sum(axis=1), sc[:, k, 3])   # car_number == occupied slots
+                assert np.all(sc[:, k, 4] >= 0) and np.all(sc[:, k, 4] <= 10)    # line <= max_line (CHS.hpp:197)
+                assert np.all(sc[:, k, 0] <= sc[:, k, 2] + 1e-3) and np.all(sc[:, k, 1] <= sc[:, k, 2] + 1e-3)
+                occ = sl[k][:, 0, :] > 0
+                assert np.all(sl[k][:, 4, :][occ] >= 25.0 - 1e-3) and np.all(sl[k][:, 4, :][occ] <= 100.0)
+            assert np.all(o[:, -3] >= 0.1 - 1e-6) and np.all(o[:, -3] <= 1.0 + 1e-6)   # tank SOC bounds (HYD:111-112)
+            del sl
+    assert whole.fcev_stuck_count() == 0
+    assert 0 < ret.mean() < 200 and ret.std() > 0.1
+    whole.close()
+    for p in parts:
+        p.close()
