@@ -81,7 +81,7 @@ def load_library():
         "chub_destroy": (I, [P]),
         "chub_obs_dim": (I, [P]), "chub_act_dim": (I, [P]), "chub_num_envs": (L, [P]), "chub_clock": (I, [P]), "chub_uses_packed_kernel": (I, [P]),
         "chub_reset": (I, [P, P, P, P]),
-        "chub_step": (I, [P, P, P, P, P, P]),
+        "chub_step": (I, [P, P, P, P, P, P]), "chub_host_actions": (I, [P, C.POINTER(P)]),
         "chub_reset_device": (I, [P, P, P, P, P]),
         "chub_step_device": (I, [P, P, P, P, P, P, P]),
         "chub_step_device_packed": (I, [P, P, P, P, P]),
@@ -105,7 +105,7 @@ def load_library():
         "chub_graph_begin": (I, [P, P]), "chub_graph_end": (I, [P, P, C.POINTER(P)]), "chub_graph_launch": (I, [P, P]),
         "chub_graph_destroy": (I, [P]),
         "chub_malloc_device": (I, [I, L, C.POINTER(P)]), "chub_free_device": (I, [I, P]), "chub_copy_to_host": (I, [I, P, P, L, P]),
-        "chub_copy_to_device": (I, [I, P, P, L, P]), "chub_stream_create": (I, [I, C.POINTER(P)]), "chub_stream_destroy": (I, [I, P]),
+        "chub_copy_to_device": (I, [I, P, P, L, P]), "chub_alloc_host": (I, [I, L, C.POINTER(P)]), "chub_free_host": (I, [I, P]), "chub_stream_create": (I, [I, C.POINTER(P)]), "chub_stream_destroy": (I, [I, P]),
         "chub_stream_sync": (I, [I, P]),
     }
     for name, (res, args) in sig.items():
@@ -117,14 +117,14 @@ def load_library():
 
 
 EXPORTED = ["chub_create", "chub_create_ex", "chub_destroy", "chub_obs_dim", "chub_act_dim", "chub_num_envs", "chub_clock", "chub_uses_packed_kernel", "chub_reset",
-            "chub_step", "chub_reset_device", "chub_step_device", "chub_step_device_packed", "chub_step_load", "chub_step_load_device", "chub_random_actions_device", "chub_sync", "chub_profile_begin", "chub_profile_end",
+            "chub_step", "chub_host_actions", "chub_reset_device", "chub_step_device", "chub_step_device_packed", "chub_step_load", "chub_step_load_device", "chub_random_actions_device", "chub_sync", "chub_profile_begin", "chub_profile_end",
             "chub_get_slots", "chub_get_station_scalars", "chub_get_telemetry", "chub_get_obs_f64",
             "chub_get_reward_f64", "chub_set_telemetry", "chub_fcev_stuck_count", "chub_set_rng_compat_seeds", "chub_set_rng_compat_state", "chub_get_rng_compat_state", "chub_compat_replay_constructor", "chub_set_ou_state",
             "chub_state_size", "chub_get_state", "chub_set_state", "chub_get_hy_table", "chub_get_hy_table_env", "chub_set_hy_table", "chub_last_error", "chub_device_count", "chub_build_id",
             "chub_comm_unique_id", "chub_comm_create", "chub_comm_destroy", "chub_comm_world", "chub_comm_rank", "chub_comm_gather",
             "chub_comm_max_f64", "chub_comm_barrier", "chub_step_gather", "chub_tape_register_soc", "chub_set_slots",
             "chub_set_station_queue", "chub_step_tape", "chub_graph_begin", "chub_graph_end", "chub_graph_launch", "chub_graph_destroy",
-            "chub_malloc_device", "chub_free_device", "chub_copy_to_host", "chub_copy_to_device", "chub_stream_create",
+            "chub_malloc_device", "chub_free_device", "chub_copy_to_host", "chub_copy_to_device", "chub_alloc_host", "chub_free_host", "chub_stream_create",
             "chub_stream_destroy", "chub_stream_sync"]
 
 

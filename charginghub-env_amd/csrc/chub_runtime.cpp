@@ -72,6 +72,10 @@ struct chub_env {
     double *d_exo_z;
     int32_t *d_exo_days;
     hipStream_t stream;
+    // host-pointer entry points: pinned staging + a private stream (lazily made by host_path_init)
+    hipStream_t host_stream;
+    float *h_actions, *h_packed;  // pinned: [N][A], [N][D+2]
+    float *d_packed;              // [N][D+2]
     int tape_classes;   // PHILOX tape mode: caller-registered arrival-SoC classes so far
     std::vector<float> h_cls[2], h_soc0[2], h_ttab[2];  // host copies of the class tables (introspection)
     uint32_t *d_tick_base;     // see HubParams::tick_base
@@ -332,6 +336,8 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->price_count = 0;
     e->tick = 0;
     e->stream = nullptr;
+    e->host_stream = nullptr;
+    e->h_actions = e->h_packed = e->d_packed = nullptr;
     e->prof_used = e->prof_cap = 0;
     e->prof_on = false;
     e->arena = nullptr;
@@ -714,6 +720,10 @@ int chub_destroy(chub_env *e) {
         (void) hipDeviceSynchronize();
         for (void *p : e->allocs) (void) hipFree(p);
         for (hipEvent_t ev : e->prof_events) (void) hipEventDestroy(ev);
+        if (e->h_actions) (void) hipHostFree(e->h_actions);
+        if (e->h_packed) (void) hipHostFree(e->h_packed);
+        if (e->d_packed) (void) hipFree(e->d_packed);
+        if (e->host_stream) (void) hipStreamDestroy(e->host_stream);
     }
     (void) hipGetLastError();  // HIP's last-error slot is per thread and sticky: do not leave ours for the next handle's checks
     delete e;
@@ -871,20 +881,46 @@ int chub_reset(chub_env *e, const int32_t *exo_days, const double *exo_z, float 
     return CHUB_OK;
 }
 
+// Host-pointer step: the reference-shaped API (numpy in / numpy out), bounded by PCIe: (A + D + 2) * 4 bytes per env and
+// step.  A private stream; the actions go up from the handle's pinned buffer when the caller filled that one
+// (chub_host_actions: one DMA, no staging copy), otherwise through the runtime's pageable-copy path; outputs come back
+// into the caller's arrays.
+static int host_path_init(chub_env *e) {
+    if (e->host_stream) return CHUB_OK;
+    const size_t N = (size_t) e->hp.n_envs, A = (size_t) e->hp.act_dim;
+    HIP_TRY(hipStreamCreateWithFlags(&e->host_stream, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc((void **) &e->h_actions, N * A * sizeof(float), hipHostMallocDefault));
+    return CHUB_OK;
+}
+
+int chub_host_actions(chub_env *e, float **out) {
+    if (!e || !out) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = host_path_init(e);
+    if (rc) return rc;
+    *out = e->h_actions;
+    return CHUB_OK;
+}
+
 int chub_step(chub_env *e, const float *actions, const double *exo_z, float *obs, float *reward, uint8_t *done) {
     if (!e || !actions || !obs || !reward || !done) return fail(CHUB_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
-    const size_t N = (size_t) e->hp.n_envs;
-    HIP_TRY(hipMemcpy(e->d_actions, actions, N * (size_t) e->hp.act_dim * sizeof(float), hipMemcpyHostToDevice));
+    int rc = host_path_init(e);
+    if (rc) return rc;
+    const size_t N = (size_t) e->hp.n_envs, A = (size_t) e->hp.act_dim, D = (size_t) e->hp.obs_dim;
+    hipStream_t s = e->host_stream;
     if (e->hp.rng_mode == CHUB_RNG_COMPAT) {
         if (!exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
-        HIP_TRY(hipMemcpy(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     }
-    int rc = chub_step_device(e, e->d_actions, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, nullptr);
+    if (actions == e->h_actions) HIP_TRY(hipMemcpyAsync(e->d_actions, actions, N * A * sizeof(float), hipMemcpyHostToDevice, s));
+    else HIP_TRY(hipMemcpyAsync(e->d_actions, actions, N * A * sizeof(float), hipMemcpyHostToDevice, s));  // pageable: staged by HIP
+    rc = chub_step_device(e, e->d_actions, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, s);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(obs, e->d_obs, N * (size_t) e->hp.obs_dim * sizeof(float), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(done, e->d_done, N, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(obs, e->d_obs, N * D * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(done, e->d_done, N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return CHUB_OK;
 }
 
@@ -1000,6 +1036,18 @@ int chub_copy_to_device(int device, void *d_dst, const void *src, int64_t bytes,
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipMemcpyAsync(d_dst, src, (size_t) bytes, hipMemcpyHostToDevice, (hipStream_t) stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
+    return CHUB_OK;
+}
+int chub_alloc_host(int device, int64_t bytes, void **out) {
+    if (!out || bytes <= 0) return fail(CHUB_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipHostMalloc(out, (size_t) bytes, hipHostMallocDefault));
+    return CHUB_OK;
+}
+int chub_free_host(int device, void *p) {
+    if (!p) return CHUB_OK;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipHostFree(p));
     return CHUB_OK;
 }
 int chub_stream_create(int device, void **out) {

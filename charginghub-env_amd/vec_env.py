@@ -68,9 +68,22 @@ class VecChargingHub(object):
         self.act_dim = self._lib.chub_act_dim(h)
         self.n_slots = self.act_dim - 2
         self.piles = (int(station_list[0]), int(station_list[1]))
-        self._obs = np.zeros((self.n_envs, self.obs_dim), dtype=np.float32)
-        self._reward = np.zeros(self.n_envs, dtype=np.float32)
-        self._done = np.zeros(self.n_envs, dtype=np.uint8)
+        self._device = int(device)
+        self._host_allocs = []
+        # the arrays the host-pointer entry points write into: pinned, so that the copies back are plain DMA
+        self._obs = self._pinned_array((self.n_envs, self.obs_dim), np.float32)
+        self._reward = self._pinned_array((self.n_envs,), np.float32)
+        self._done = self._pinned_array((self.n_envs,), np.uint8)
+
+    def _pinned_array(self, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        check(self._lib.chub_alloc_host(self._device, max(n, 1), C.byref(p)))
+        self._host_allocs.append(p.value)
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        a[...] = 0
+        return a
 
     # ---- hot path
     def reset(self, exo_days=None, exo_z=None):
@@ -86,6 +99,16 @@ class VecChargingHub(object):
         z = None if exo_z is None else np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)).reshape(self.n_envs, 3)
         check(self._lib.chub_step(self._h, _ptr(a), _ptr(z), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
         return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
+
+    def pinned_actions(self):
+        """the handle's pinned [N, A] f32 action buffer as a numpy array: fill it in place and pass it to step() to save the
+        CPU copy into pinned memory (chub_host_actions)"""
+        if getattr(self, "_pinned", None) is None:
+            p = C.c_void_p()
+            check(self._lib.chub_host_actions(self._h, C.byref(p)))
+            buf = (C.c_float * (self.n_envs * self.act_dim)).from_address(p.value)
+            self._pinned = np.frombuffer(buf, dtype=np.float32).reshape(self.n_envs, self.act_dim)
+        return self._pinned
 
     def load_actions(self, loads, tail):
         """[N, A] action array of the scalar-load mode: loads [N, 2] in kW (one per station), tail [N, 2] as in step()."""
@@ -269,6 +292,10 @@ class VecChargingHub(object):
         if getattr(self, "_h", None):
             self._lib.chub_destroy(self._h)
             self._h = None
+            self._obs = self._reward = self._done = self._pinned = None
+            for p in self._host_allocs:
+                self._lib.chub_free_host(self._device, p)
+            self._host_allocs = []
 
     def __del__(self):
         try:

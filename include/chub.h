@@ -112,6 +112,9 @@ int chub_uses_packed_kernel(const chub_env *env); /* 1: PHILOX steps of this han
  * Host-pointer forms copy in/out around the device-pointer forms. */
 int chub_reset(chub_env *env, const int32_t *exo_days, const double *exo_z, float *obs);
 int chub_step(chub_env *env, const float *actions, const double *exo_z, float *obs, float *reward, uint8_t *done);
+/* The handle's pinned action buffer [N,A] f32: a host that writes its actions there and passes this pointer to chub_step
+ * saves the CPU copy into pinned memory (any other host pointer works too). */
+int chub_host_actions(chub_env *env, float **out);
 
 /* Same, all pointers device memory, enqueued on `stream` (a hipStream_t, NULL = default stream);
  * returns after enqueueing.  This is the form the multi-GPU host and bench.py use. */
@@ -225,6 +228,8 @@ int chub_malloc_device(int device, int64_t bytes, void **out);
 int chub_free_device(int device, void *d_ptr);
 int chub_copy_to_host(int device, void *dst, const void *d_src, int64_t bytes, void *stream);
 int chub_copy_to_device(int device, void *d_dst, const void *src, int64_t bytes, void *stream);
+int chub_alloc_host(int device, int64_t bytes, void **out);  /* pinned host memory: the DMA engines reach it directly */
+int chub_free_host(int device, void *ptr);
 int chub_stream_create(int device, void **out);
 int chub_stream_destroy(int device, void *stream);
 int chub_stream_sync(int device, void *stream);

@@ -26,3 +26,13 @@ for i in range(steps):
     v.step(a)
 dt = time.perf_counter() - t0
 print("host-pointer path: %d envs, %.3f ms/step, %.1f M env-steps/s" % (n, dt / steps * 1e3, n * steps / dt / 1e6))
+p = v.pinned_actions()
+p[...] = a
+t0 = time.perf_counter()
+for i in range(steps):
+    if i % 96 == 0:
+        v.reset()
+    v.step(p)
+dt = time.perf_counter() - t0
+print("  ... actions written into the pinned buffer: %.3f ms/step, %.1f M env-steps/s; PCIe bound %d B per env-step"
+      % (dt / steps * 1e3, n * steps / dt / 1e6, (v.act_dim + v.obs_dim + 2) * 4))
