@@ -54,6 +54,13 @@ enum Site : uint32_t {
     SITE_DAY = 11     // word 0 -> pv day, word 1 -> wd day (reset)
 };
 
+// StationRec::pkd, the integer part of a station record: bits 0-3 Station::line (<= max_line = 10), bits 4-15
+// flow_in_number.back() (signed: negative right after the reset of a small fast station, CHS.hpp:1617), bits 16-31 car_number
+CHUB_HD uint32_t pkd_make(int line, int flow, int cars) { return (uint32_t) line | (((uint32_t) flow & 0xFFFu) << 4) | ((uint32_t) cars << 16); }
+CHUB_HD int pkd_line(uint32_t w) { return (int) (w & 15u); }
+CHUB_HD int pkd_flow(uint32_t w) { return ((int) (w << 16)) >> 20; }
+CHUB_HD int pkd_cars(uint32_t w) { return (int) (w >> 16); }
+
 struct SlotArrays {          // index = base_k + env*S_k + slot  (station-major)
     // the hot record, one 16-byte load and one 16-byte store per slot and step:
     //   .x power     kW at the car's current point of the curve (Station::situation["power"])

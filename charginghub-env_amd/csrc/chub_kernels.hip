@@ -182,7 +182,7 @@ constexpr float kActOnThreshold = -2.98023223876953125e-8f;
 // What k_slot hands to the per-env tail for one (station, env) unit: one 16-byte record.
 struct StationRec {
     float mn, chg, mx;  // min_power, charge_power, max_power (CHS.hpp:1257-1259)
-    uint32_t pkd;       // line | (flow_in & 255) << 8 | car_number << 16
+    uint32_t pkd;       // pkd_make(line, flow_in, car_number), chub_device.h
 };
 __device__ __forceinline__ void rec_store(CHUB_G(uint32_t) rec, uint32_t u, float mn, float chg, float mx, uint32_t pkd) {
     u32x4 v = {__float_as_uint(mn), __float_as_uint(chg), __float_as_uint(mx), pkd};
@@ -506,7 +506,7 @@ __device__ void slot_body_compat(const HubParams &hp, const StepArgs &sa, const 
     const uint64_t be = __ballot(empty) & unit_mask;
     const int empties = __popcll(be);
     const int rank = prefix_count(be);
-    int line = (int) (line_in & 0xFFu);
+    int line = pkd_line(line_in);
     const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
     // the unit's first lane walks the two reference streams in the reference's order and parks the per-admission
     // variates in LDS, indexed by admission rank
@@ -596,8 +596,7 @@ __device__ void slot_body_compat(const HubParams &hp, const StepArgs &sa, const 
         if (adm) sl.init_soc[idx] = nc_soc;
     }
     if (unit_ok && slot == 0) {
-        const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) cars << 16);
-        rec_store(st.rec, sidx, r_min, r_chg, r_max, pkd);
+        rec_store(st.rec, sidx, r_min, r_chg, r_max, pkd_make(line, flow, cars));
     }
 }
 
@@ -682,14 +681,14 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     const uint64_t be = __ballot(empty) & unit_mask;
     const int empties = __popcll(be);
     const int rank = prefix_count(be);
-    int line = (int) (line_in & 0xFFu);
+    int line = pkd_line(line_in);
     int flow = 0, assign = 0;
     if (unit_ok) {
         if (RESET) {
             // evs_reset: the unit's initial occupancy was drawn by k_reset_levels, one lane per unit, just before.  The fast
             // station records the raw draw, which is negative for small stations (mu - 3 < 0, CHS.hpp:1617, 832-842):
             // assign_car then admits nobody and the queue stays empty
-            flow = fast ? (int) (int8_t) (pk_in & 0xFFu) : (int) ((pk_in >> 8) & 0xFFu);
+            flow = fast ? (int) (int16_t) (pk_in & 0xFFFFu) : (int) ((pk_in >> 16) & 0xFFFFu);
         } else {
             // this step's station-level draws were packed one launch ahead (draw_station_levels)
             line = __popc((uint32_t) pk_in & ((1u << line) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
@@ -738,8 +737,7 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
         ((CHUB_G(u32x2)) sl.hot)[idx] = o2;
     }
     if (unit_ok && slot == 0) {
-        const uint32_t pkd = (uint32_t) line | (((uint32_t) flow & 0xFFu) << 8) | ((uint32_t) cars << 16);
-        rec_store(st.rec, sidx, fixed_to_kw(i_min), fixed_to_kw(i_chg), fixed_to_kw(i_max), pkd);
+        rec_store(st.rec, sidx, fixed_to_kw(i_min), fixed_to_kw(i_chg), fixed_to_kw(i_max), pkd_make(line, flow, cars));
     }
 }
 
@@ -758,7 +756,7 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
 // PackedArgs: everything a wave needs up front, by value in the kernel arguments and requested in one scalar batch.
 struct PackedArgs {
     uint32_t S[2], type[2];
-    uint32_t n_envs, epb, magic, cls_delta;  // envs per workgroup; 65536 / (S0 + S1) + 1; byte distance cls[1] - cls[0]
+    uint32_t n_envs, epb, magic, cls_delta;  // envs per workgroup; 2^20 / (S0 + S1) + 1; byte distance cls[1] - cls[0]
     CHUB_G(uint32_t) state;          // [N][S0 + S1][2]
     CHUB_G(uint32_t) rec;
     CHUB_G(const uint64_t) pk;       // this step's packed station draws (TAPE: supplied by the caller)
@@ -768,7 +766,10 @@ struct PackedArgs {
     CHUB_G(const uint32_t) car_tape; // TAPE: [N][S0 + S1][2] per slot, used if the slot admits a car this step: class, level | late << 16
 };
 
-template <int BLOCK, int T, bool TAPE>
+// RESET: evs_reset (CHS.hpp:1209-1231 / 1520-1542) on the same layout: no state comes in, the unit's initial occupancy was drawn
+// by k_reset_levels, every wave helps with the (many) new cars.  BIG: a station with more than 64 piles -- a unit then spans
+// several waves (its empties are counted over all of them) and its power sums need 64 bits.
+template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG>
 __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const PackedArgs &pa, const Tables &tb,
                                                  const uint32_t block_local, uint32_t *q_cnt, uint32_t *q_new,
                                                  uint64_t *s_ball, int *s_acc, uint32_t *s_unit, float *s_tt) {
@@ -799,7 +800,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
 #pragma unroll
     for (int j = 0; j < T; j++) {
         const int v = tid + j * BLOCK;
-        e_[j] = (int) (((uint32_t) v * pa.magic) >> 16);  // v / (S0 + S1) (magic = 65536 / St + 1, checked on the host)
+        e_[j] = (int) (((uint32_t) v * pa.magic) >> 20);  // v / (S0 + S1) (magic = 2^20 / St + 1, checked on the host)
         const int hs = v - e_[j] * St;                    // hub slot
         k_[j] = hs >= S0 ? 1 : 0;
         slot[j] = hs - (k_[j] ? S0 : 0);
@@ -807,10 +808,17 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         valid[j] = e_[j] < epb && env < N;
         sidx[j] = (uint32_t) (k_[j] ? N : 0) + (uint32_t) env;
         asm volatile("" : "=v"(s2[j]), "=v"(act[j]), "=v"(line_in[j]), "=v"(pk_in[j]));
+        if (RESET) {
+            s2[j] = u32x2{0u, 0u};
+            act[j] = 0.0f;
+            line_in[j] = 0u;
+        }
         if (valid[j]) {
-            s2[j] = CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) v) << 3);
-            act[j] = CHUB_AT(const float, pa.actions, (idx0 + (uint32_t) v + 2u * (uint32_t) env) << 2);  // row stride S0 + S1 + 2
-            line_in[j] = CHUB_AT(uint32_t, pa.rec, (sidx[j] << 4) + 12u);
+            if (!RESET) {
+                s2[j] = CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) v) << 3);
+                act[j] = CHUB_AT(const float, pa.actions, (idx0 + (uint32_t) v + 2u * (uint32_t) env) << 2);  // row stride S0 + S1 + 2
+                line_in[j] = CHUB_AT(uint32_t, pa.rec, (sidx[j] << 4) + 12u);
+            }
             pk_in[j] = CHUB_AT(const uint64_t, pa.pk, sidx[j] << 3);
         }
     }
@@ -825,7 +833,8 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
                                                          : CHUB_AT(const float, pa.ttab[1], (uint32_t) (at - kLevels) << 2);
     }
     if (tid == 0) q_cnt[0] = 0;
-    for (int i = tid; i < 8 * epb; i += BLOCK) s_acc[i] = 0;
+    for (int i = tid; i < (BIG ? 16 : 8) * epb; i += BLOCK) s_acc[i] = 0;
+    long long *s_acc64 = (long long *) s_acc;  // BIG: {min, charge, max power, cars} as four 64-bit sums per unit
 
     // ---- second round trip, only for the slots whose car stays: where it is on its curve (entries n, n + 1 of its class
     // row).  A car that leaves this step is wiped right after its car_step (CHS.hpp:1196-1201): nothing of it is needed, and
@@ -865,26 +874,52 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
     for (int j = 0; j < T; j++) {
         const int vw = wave + j * WAVES;
         const int Sk = k_[j] ? S1 : S0;
-        // ballot masks of the unit's lanes [ub, ue) of the workgroup: in this (virtual) wave, and in the neighbouring wave the unit
-        // began in or runs over into (S_k <= 64: at most one of the two)
+        // ballot masks of the unit's lanes [ub, ue) of the workgroup
         const int ub = e_[j] * St + (k_[j] ? S0 : 0) - vw * 64, ue = ub + Sk;  // relative to this wave's lane 0
-        const bool b_prev = ub < 0, b_next = ue > 64;
-        const uint64_t mA = (~0ull >> (b_next ? 0 : 64 - ue)) & (~0ull << (b_prev ? 0 : ub));
-        const uint64_t mB = b_prev ? (~0ull << (64 + ub)) : (b_next ? (~0ull >> (128 - ue)) : 0ull);
-        const int cntB = __popcll(s_ball[b_prev ? vw - 1 : vw + 1] & mB);  // its empties there (mB = 0: no lanes there)
-        const int empties = __popcll(be[j] & mA) + cntB;
-        const int rank = prefix_count(be[j] & mA) + (b_prev ? cntB : 0);
-        line[j] = (int) (line_in[j] & 0xFFu);
+        int empties, rank;
+        if (!BIG) {
+            // in this (virtual) wave, and in the neighbouring wave the unit began in or runs over into (S_k <= 64: at most one)
+            const bool b_prev = ub < 0, b_next = ue > 64;
+            const uint64_t mA = (~0ull >> (b_next ? 0 : 64 - ue)) & (~0ull << (b_prev ? 0 : ub));
+            const uint64_t mB = b_prev ? (~0ull << (64 + ub)) : (b_next ? (~0ull >> (128 - ue)) : 0ull);
+            const int cntB = __popcll(s_ball[b_prev ? vw - 1 : vw + 1] & mB);  // its empties there (mB = 0: no lanes there)
+            empties = __popcll(be[j] & mA) + cntB;
+            rank = prefix_count(be[j] & mA) + (b_prev ? cntB : 0);
+        } else {
+            // a unit of up to 256 lanes: its empties in every virtual wave it touches; those in earlier waves come before this lane
+            empties = 0;
+            rank = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES * T; w++) {
+                int lo = ub + (vw - w) * 64, hi = ue + (vw - w) * 64;  // the unit's lanes relative to wave w's lane 0
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > 64 ? 64 : hi;
+                if (hi > lo) {
+                    const uint64_t m = (~0ull >> (64 - hi)) & (~0ull << lo);
+                    const uint64_t b = (w == vw ? be[j] : s_ball[w]) & m;
+                    empties += __popcll(b);
+                    if (w < vw) rank += __popcll(b);
+                    else if (w == vw) rank += prefix_count(b);
+                }
+            }
+        }
+        line[j] = pkd_line(line_in[j]);
         flow[j] = 0;
         int assign = 0;
         if (valid[j]) {
             const uint64_t pk = pk_in[j];
             const bool fast = (k_[j] ? pa.type[1] : pa.type[0]) == 0;
-            line[j] = __popc((uint32_t) pk & ((1u << line[j]) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
-            const int n_in = (int) (pk >> 10) & 15;
-            // the fast station records the un-thinned count (CHS.hpp:1617), the slow one what survives the balk pass given the
-            // queue length just computed (CHS.hpp:1297-1306)
-            flow[j] = fast ? n_in : (int) ((pk >> (14 + 4 * line[j])) & 15);
+            if (RESET) {
+                // the unit's initial occupancy, drawn by k_reset_levels just before.  The fast station records the raw draw, which is
+                // negative for small stations (mu - 3 < 0, CHS.hpp:1617, 832-842): assign_car then admits nobody, the queue stays empty
+                flow[j] = fast ? (int) (int16_t) (pk & 0xFFFFu) : (int) ((pk >> 16) & 0xFFFFu);
+            } else {
+                line[j] = __popc((uint32_t) pk & ((1u << line[j]) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
+                const int n_in = (int) (pk >> 10) & 15;
+                // the fast station records the un-thinned count (CHS.hpp:1617), the slow one what survives the balk pass given
+                // the queue length just computed (CHS.hpp:1297-1306)
+                flow[j] = fast ? n_in : (int) ((pk >> (14 + 4 * line[j])) & 15);
+            }
             assign = (line[j] + flow[j]) < empties ? (line[j] + flow[j]) : empties;  // assign_car, CHS.hpp:417-430
             line[j] = line[j] + flow[j] - assign;
             line[j] = line[j] < kMaxLine ? line[j] : kMaxLine;
@@ -920,27 +955,36 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
             const int q = (int) (power * 524288.0f);
             const bool urgent = must_charge(t_target, t_soc, tl[j] - 1);
             w0n = (w0[j] & ~64u) - 1u + (on ? ((1u << 13) | 64u) : 0u);
-            atomicAdd((unsigned long long *) (acc + 2), (unsigned long long) (uint32_t) q | (1ull << 32));
-            if (on || urgent)
-                atomicAdd((unsigned long long *) acc,
-                          (unsigned long long) (urgent ? (uint32_t) q : 0u) | ((unsigned long long) (on ? (uint32_t) q : 0u) << 32));
+            if (!BIG) {
+                atomicAdd((unsigned long long *) (acc + 2), (unsigned long long) (uint32_t) q | (1ull << 32));
+                if (on || urgent)
+                    atomicAdd((unsigned long long *) acc,
+                              (unsigned long long) (urgent ? (uint32_t) q : 0u) | ((unsigned long long) (on ? (uint32_t) q : 0u) << 32));
+            } else {
+                unsigned long long *a64 = (unsigned long long *) (s_acc64 + 4 * u);
+                atomicAdd(a64 + 2, (unsigned long long) q);
+                atomicAdd(a64 + 3, 1ull);
+                if (urgent) atomicAdd(a64 + 0, (unsigned long long) q);
+                if (on) atomicAdd(a64 + 1, (unsigned long long) q);
+            }
         }
         if (valid[j] && !adm[j]) {
             const u32x2 o2 = {w0n, s2[j].y};
             CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) (tid + j * BLOCK)) << 3) = o2;
         }
-        if (valid[j] && slot[j] == 0) s_unit[u] = (uint32_t) line[j] | (((uint32_t) flow[j] & 0xFFu) << 8);
+        if (valid[j] && slot[j] == 0) s_unit[u] = pkd_make(line[j], flow[j], 0);
     }
     __syncthreads();
     // Everything left -- the workgroup's new cars and, after them, the station records -- is the last wave's business: the
     // other waves are done (their wave slots go to the next workgroup instead of idling at a third barrier through the
-    // Philox block and the dependent table read of the new cars)
-    if (wave != WAVES - 1) return;
+    // Philox block and the dependent table read of the new cars).  RESET: about half of all slots get a car, so every wave
+    // serves its share and the workgroup meets again in front of the records.
+    if (!RESET && wave != WAVES - 1) return;
     // ---- add_car (CHS.hpp:864-877 / 1029-1042) for the workgroup's new cars, one lane per car
     const uint32_t n_adm = q_cnt[0];
-    for (uint32_t i = (uint32_t) lane; i < n_adm; i += 64) {
+    for (uint32_t i = (uint32_t) (RESET ? tid : lane); i < n_adm; i += (RESET ? BLOCK : 64)) {
         const int src = (int) q_new[i];
-        const int s_e = (int) (((uint32_t) src * pa.magic) >> 16);
+        const int s_e = (int) (((uint32_t) src * pa.magic) >> 20);
         const int s_hs = src - s_e * St;
         const int s_k = s_hs >= S0 ? 1 : 0;
         uint32_t c, lev;
@@ -964,11 +1008,22 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         const u32x2 o2 = {st_ > 0 ? ps_make(st_, lev) : 0u, c};
         CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) src) << 3) = o2;
         if (st_ > 0) {
-            int *ac = s_acc + 4 * (2 * s_e + s_k);
             const int q = (int) (e0.x * 524288.0f);
-            atomicAdd((unsigned long long *) (ac + 2), (unsigned long long) (uint32_t) q | (1ull << 32));
-            if (must_charge(tt_, e0.y, st_)) atomicAdd(ac, q);
+            if (!BIG) {
+                int *ac = s_acc + 4 * (2 * s_e + s_k);
+                atomicAdd((unsigned long long *) (ac + 2), (unsigned long long) (uint32_t) q | (1ull << 32));
+                if (must_charge(tt_, e0.y, st_)) atomicAdd(ac, q);
+            } else {
+                unsigned long long *a64 = (unsigned long long *) (s_acc64 + 4 * (2 * s_e + s_k));
+                atomicAdd(a64 + 2, (unsigned long long) q);
+                atomicAdd(a64 + 3, 1ull);
+                if (must_charge(tt_, e0.y, st_)) atomicAdd(a64 + 0, (unsigned long long) q);
+            }
         }
+    }
+    if (RESET) {
+        __syncthreads();
+        if (wave != WAVES - 1) return;
     }
     // the wave's own LDS atomics above are in program order with the reads below; nothing else touches s_acc any more
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -985,29 +1040,43 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
             // 1583-1627; nobody is ever admitted): its queue length and arrival count move on here, power sums and cars stay 0
             const uint32_t l_in = CHUB_AT(uint32_t, pa.rec, (su << 4) + 12u);
             const uint64_t pk = CHUB_AT(const uint64_t, pa.pk, su << 3);
-            int ln = (int) (l_in & 0xFFu);
-            ln = __popc((uint32_t) pk & ((1u << ln) - 1u));
-            const int n_in = (int) (pk >> 10) & 15;
-            const int fl = ((k ? pa.type[1] : pa.type[0]) == 0) ? n_in : (int) ((pk >> (14 + 4 * ln)) & 15);
-            ln = ln + fl;
+            const bool fast = (k ? pa.type[1] : pa.type[0]) == 0;
+            int ln = 0, fl;
+            if (RESET) {  // evs_reset of a station without piles: init_station_car_number(0, 3) arrivals, nobody queues
+                fl = fast ? (int) (int16_t) (pk & 0xFFFFu) : (int) ((pk >> 16) & 0xFFFFu);
+            } else {
+                ln = pkd_line(l_in);
+                ln = __popc((uint32_t) pk & ((1u << ln) - 1u));
+                const int n_in = (int) (pk >> 10) & 15;
+                fl = fast ? n_in : (int) ((pk >> (14 + 4 * ln)) & 15);
+            }
+            // assign_car (CHS.hpp:417-430) with no empty slot: min(line + flow, 0) cars are assigned, the rest queue
+            const int as = (ln + fl) < 0 ? (ln + fl) : 0;
+            ln = ln + fl - as;
             ln = ln < kMaxLine ? ln : kMaxLine;
-            lf = (uint32_t) ln | (((uint32_t) fl & 0xFFu) << 8);
+            lf = pkd_make(ln, fl, 0);
         }
-        const int *acc = s_acc + 4 * i;
-        const uint32_t pkd = lf | ((uint32_t) acc[3] << 16);
-        const u32x4 rv = {__float_as_uint(fixed_to_kw(acc[0])), __float_as_uint(fixed_to_kw(acc[1])),
-                          __float_as_uint(fixed_to_kw(acc[2])), pkd};
+        u32x4 rv;
+        if (!BIG) {
+            const int *acc = s_acc + 4 * i;
+            rv = u32x4{__float_as_uint(fixed_to_kw(acc[0])), __float_as_uint(fixed_to_kw(acc[1])), __float_as_uint(fixed_to_kw(acc[2])),
+                       lf | ((uint32_t) acc[3] << 16)};
+        } else {
+            const long long *a64 = s_acc64 + 4 * i;
+            rv = u32x4{__float_as_uint((float) a64[0] * (1.0f / 524288.0f)), __float_as_uint((float) a64[1] * (1.0f / 524288.0f)),
+                       __float_as_uint((float) a64[2] * (1.0f / 524288.0f)), lf | ((uint32_t) a64[3] << 16)};
+        }
         CHUB_AT(u32x4, pa.rec, su << 4) = rv;
     }
 #undef CHUB_AT
 }
 
-template <int BLOCK, int T, bool TAPE>
+template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG>
 __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in) {
     __shared__ uint32_t q_new[BLOCK * T];
     __shared__ uint32_t q_cnt[2];
     __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];                   // [1 + virtual wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
-    __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T];  // 2 epb <= BLOCK * T / 2 units x {min, charge, max power, cars}
+    __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T];  // 2 epb <= BLOCK * T / 2 units x {min, charge, max power, cars} (BIG: as 64-bit sums, few units)
     __shared__ uint32_t s_unit[BLOCK * T / 2];                        // per unit: line | flow << 8
     __shared__ float s_tt[2 * kLevels];                               // soc_to_time(target level) of both stations' curves
     // all kernel arguments this wave needs, requested in ONE batch of scalar loads at its very start (the single asm
@@ -1017,7 +1086,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restri
     asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
                       "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab[0]),
                       "+s"(pa.ttab[1]));
-    slot_body_packed<BLOCK, T, TAPE>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new, s_ball + 1, s_acc, s_unit, s_tt);
+    slot_body_packed<BLOCK, T, TAPE, RESET, BIG>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new, s_ball + 1, s_acc, s_unit, s_tt);
 }
 
 // What the tail's first loads need, by value in the kernel arguments: one scalar load at the start of the wave instead
@@ -1188,8 +1257,8 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         in_price_noise = ta.price_noise[e32];
         {
             const StationRec r0 = rec_load(ta.rec, e32), r1 = rec_load(ta.rec, n32 + e32);
-            mn0 = r0.mn; P0f = r0.chg; mx0 = r0.mx; ln0 = (int) (r0.pkd & 0xFFu); F0i = (int) (int8_t) ((r0.pkd >> 8) & 0xFFu);
-            mn1 = r1.mn; P1f = r1.chg; mx1 = r1.mx; ln1 = (int) (r1.pkd & 0xFFu); F1i = (int) (int8_t) ((r1.pkd >> 8) & 0xFFu);
+            mn0 = r0.mn; P0f = r0.chg; mx0 = r0.mx; ln0 = pkd_line(r0.pkd); F0i = pkd_flow(r0.pkd);
+            mn1 = r1.mn; P1f = r1.chg; mx1 = r1.mx; ln1 = pkd_line(r1.pkd); F1i = pkd_flow(r1.pkd);
         }
         if (!RESET) {
             const uint32_t ai = e32 * ta.act_dim + ta.s_tot;
@@ -1824,7 +1893,7 @@ __global__ void k_reset_levels(const DevCtx *__restrict__ ctx, uint32_t tick) {
         const int thr = (int) tb.thr_balk[j < kBalkTab ? j : kBalkTab - 1];
         true_in += ((int) (pick(b, wi & 3) % 1000u) <= thr && j <= S) ? 1 : 0;
     }
-    ctx->st.pk[tick & 1u][u] = (uint64_t) (((uint32_t) n_in & 0xFFu) | ((uint32_t) true_in << 8));  // n_in: signed byte
+    ctx->st.pk[tick & 1u][u] = (uint64_t) (((uint32_t) n_in & 0xFFFFu) | ((uint32_t) true_in << 16));  // n_in: signed 16 bits
 }
 
 // ------------------------------------------------------------------------------------- launchers
@@ -1861,8 +1930,8 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
 void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
                  const PackedPtrs &pp, hipEvent_t ev0, hipEvent_t ev1) {
     if (hp.rng_mode == MODE_PHILOX) {
-        if (reset) launch_slot_t<true, MODE_PHILOX>(hp, ctx, sa, stream, ev0, ev1);
-        else if (hp.packed && !sa.load_mode) {
+        if (hp.packed && !sa.load_mode) {
+            if (reset) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa.tick);
             PackedArgs pa;
             for (int k = 0; k < 2; k++) {
                 pa.S[k] = (uint32_t) hp.S[k];
@@ -1871,7 +1940,7 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             }
             pa.n_envs = (uint32_t) hp.n_envs;
             pa.epb = (uint32_t) hp.epb;
-            pa.magic = 65536u / (uint32_t) (hp.S[0] + hp.S[1]) + 1u;
+            pa.magic = (1u << 20) / (uint32_t) (hp.S[0] + hp.S[1]) + 1u;
             pa.cls_delta = (uint32_t) ((const char *) pp.cls[1] - (const char *) pp.cls[0]);
             pa.state = (CHUB_G(uint32_t)) pp.hot;
             pa.rec = (CHUB_G(uint32_t)) pp.rec;
@@ -1880,9 +1949,22 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             pa.cls0 = (CHUB_G(const float)) pp.cls[0];
             pa.car_tape = (CHUB_G(const uint32_t)) sa.car_tape;
             const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
-            if (sa.car_tape) CHUB_LAUNCH((k_slot_packed<kSlotBlock, kSlotsPerLane, true>), dim3(nb), dim3(kSlotBlock), stream, ev0, ev1, ctx, sa, pa);
-            else CHUB_LAUNCH((k_slot_packed<kSlotBlock, kSlotsPerLane, false>), dim3(nb), dim3(kSlotBlock), stream, ev0, ev1, ctx, sa, pa);
-        } else launch_slot_t<false, MODE_PHILOX>(hp, ctx, sa, stream, ev0, ev1);
+#define CHUB_PACKED(TAPE_, RESET_, BIG_) \
+    CHUB_LAUNCH((k_slot_packed<kSlotBlock, kSlotsPerLane, TAPE_, RESET_, BIG_>), dim3(nb), dim3(kSlotBlock), stream, ev0, ev1, ctx, sa, pa)
+            const bool big = hp.S[0] > 64 || hp.S[1] > 64;
+            if (reset) {
+                if (big) CHUB_PACKED(false, true, true);
+                else CHUB_PACKED(false, true, false);
+            } else if (sa.car_tape) {
+                CHUB_PACKED(true, false, false);
+            } else if (big) {
+                CHUB_PACKED(false, false, true);
+            } else {
+                CHUB_PACKED(false, false, false);
+            }
+#undef CHUB_PACKED
+        } else if (reset) launch_slot_t<true, MODE_PHILOX>(hp, ctx, sa, stream, ev0, ev1);
+        else launch_slot_t<false, MODE_PHILOX>(hp, ctx, sa, stream, ev0, ev1);
         return;
     }
     if (reset) launch_slot_t<true, MODE_COMPAT>(hp, ctx, sa, stream, ev0, ev1);

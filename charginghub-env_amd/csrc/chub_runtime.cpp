@@ -318,8 +318,11 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if (rng_mode != CHUB_RNG_COMPAT && rng_mode != CHUB_RNG_PHILOX) return fail(CHUB_ERR_ARG, "unknown rng_mode");
     for (int k = 0; k < 2; k++) {
         if (cfg->station_list[k] < 0) return fail(CHUB_ERR_ARG, "station_list entries must be >= 0");
-        if (cfg->station_list[k] > 64)
-            return fail(CHUB_ERR_UNSUPPORTED, "more than 64 piles per station is not supported yet");
+        // the production (PHILOX) kernel lays whole envs over a workgroup's 512 virtual lanes and counts car_number in 16 bits;
+        // the COMPAT kernel (parity instrument) keeps one unit inside a wave
+        if (cfg->station_list[k] > (rng_mode == CHUB_RNG_PHILOX ? 256 : 64))
+            return fail(CHUB_ERR_UNSUPPORTED, rng_mode == CHUB_RNG_PHILOX ? "more than 256 piles per station is not supported"
+                                                                           : "COMPAT streams: more than 64 piles per station is not supported");
         if (cfg->station_type_list[k] != CHUB_FAST && cfg->station_type_list[k] != CHUB_SLOW)
             return fail(CHUB_ERR_ARG, "EVS type must be fast or slow");  // AGG:196
     }
@@ -409,7 +412,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     for (int k = 0; k < 2; k++) {
         hp.S[k] = cfg->station_list[k];
         hp.type[k] = cfg->station_type_list[k];
-        hp.H[k] = pow2_ge(hp.S[k] > 0 ? hp.S[k] : 1);
+        hp.H[k] = pow2_ge(hp.S[k] > 0 ? (hp.S[k] < 64 ? hp.S[k] : 64) : 1);  // wave-local kernels: units of at most one wave
         hp.logH[k] = 0;
         while ((1 << hp.logH[k]) < hp.H[k]) hp.logH[k]++;
         active += hp.S[k] > 0;
@@ -615,12 +618,15 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     {
         const int pb = kSlotBlock * kSlotsPerLane, St = hp.S[0] + hp.S[1];
         hp.epb = pb / St > 0 ? pb / St : 1;
-        bool magic_ok = true;  // the kernel divides lane numbers by S0 + S1 with a 16-bit reciprocal
+        bool magic_ok = true;  // the kernel divides lane numbers by S0 + S1 with a 20-bit reciprocal
         for (int l = 0; l < pb && magic_ok; l++)
-            if ((((uint32_t) l * (65536u / (uint32_t) St + 1u)) >> 16) != (uint32_t) (l / St)) magic_ok = false;
+            if ((((uint32_t) l * ((1u << 20) / (uint32_t) St + 1u)) >> 20) != (uint32_t) (l / St)) magic_ok = false;
         hp.packed = (rng_mode == CHUB_RNG_PHILOX && St >= 4 && St <= pb && magic_ok &&
                      (uint64_t) n_envs * (uint64_t) (St + 2) * 16u < ((uint64_t) 1 << 32) &&  // 32-bit byte offsets
                      opt.slot_kernel != 1) ? 1 : 0;
+        if ((hp.S[0] > 64 || hp.S[1] > 64) && !hp.packed)
+            return bail(fail(CHUB_ERR_UNSUPPORTED, "stations with more than 64 piles run on the packed slot kernel only: at most 512 "
+                                                   "piles per hub, n_envs * (piles + 2) * 16 < 2^32, slot_kernel not forced to 1"));
     }
     build_hy_table(hp, e->hy_table);
     std::vector<double> hy_v(e->hy_table, e->hy_table + 102);
@@ -798,6 +804,8 @@ int chub_step_gather(chub_env *e, chub_comm *comm, const float *d_actions, float
 int chub_step_load_device(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
                           uint8_t *d_done, void *stream) {
     if (!e || !d_actions || !d_obs || !d_reward || !d_done) return fail(CHUB_ERR_ARG, "null argument");
+    if (e->hp.S[0] > 64 || e->hp.S[1] > 64)
+        return fail(CHUB_ERR_UNSUPPORTED, "scalar-load control: stations with more than 64 piles are not supported");
     return step_common(e, d_actions, d_exo_z, d_obs, e->hp.obs_dim, d_reward, 1, d_done, nullptr, stream, 1);
 }
 
@@ -1133,7 +1141,7 @@ int chub_set_station_queue(chub_env *e, const int32_t *line) {
         for (int k = 0; k < 2; k++) {
             if (line[env * 2 + k] < 0 || line[env * 2 + k] > kMaxLine) return fail(CHUB_ERR_ARG, "queue length out of range");
             uint32_t &w = rec[4 * ((size_t) k * N + env) + 3];
-            w = (w & ~0xFFu) | (uint32_t) line[env * 2 + k];
+            w = (w & ~15u) | (uint32_t) line[env * 2 + k];
         }
     HIP_TRY(hipMemcpy(e->st.rec, rec.data(), rec.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return CHUB_OK;
@@ -1274,9 +1282,9 @@ int chub_get_station_scalars(chub_env *e, double *out) {
             float mn, ch, mx;
             memcpy(&mn, &r[0], 4); memcpy(&ch, &r[1], 4); memcpy(&mx, &r[2], 4);
             o[0] = mn; o[1] = ch; o[2] = mx;
-            o[3] = (double) ((r[3] >> 16) & 0xFFu);          // car_number
-            o[4] = (double) (r[3] & 0xFFu);                  // line
-            o[5] = (double) (int8_t) ((r[3] >> 8) & 0xFFu);  // flow_in_number[-1] (can be negative right after reset)
+            o[3] = (double) pkd_cars(r[3]);  // car_number
+            o[4] = (double) pkd_line(r[3]);  // line
+            o[5] = (double) pkd_flow(r[3]);  // flow_in_number[-1] (can be negative right after reset)
             o[6] = e->t; o[7] = e->hp.transformer_limit[k];
         }
     return CHUB_OK;

@@ -558,11 +558,11 @@ static void calculate_output(orc_station *s) {
     int number = 0;
     if (s->exact_sums) {
         /* production semantics (PHILOX mode): the three sums are order-independent -- every slot power is truncated to
-         * a multiple of 2^-19 kW (C cast of power * 2^19 to int32: |power| < 64 kW, at most 64 slots, so the int32 sum
-         * cannot overflow), the integers are added, and the total is rounded once to f32.  Within n * 2^-19 kW of the
+         * a multiple of 2^-19 kW (C cast of power * 2^19 to an integer: |power| < 64 kW), the integers are added exactly (64
+         * bits: up to 256 slots), and the total is rounded once to f32.  Within n * 2^-19 kW of the
          * exact sum; the reference's sequential f32 sum (CHS:1244-1255) is within n * 2^-24 relative of it.  An
          * implementation may add the terms in any order and with any grouping (wave butterflies, LDS atomics). */
-        int32_t amin = 0, amax = 0, anow = 0;
+        int64_t amin = 0, amax = 0, anow = 0;
         for (int i = 0; i < s->n; i++) {
             if (!(s->car[i] > 0.5)) continue;
             number += 1;

@@ -136,6 +136,11 @@ PHILOX_CASES = [
     # reference's list is unbounded, HYD:264-279)
     ("fcev_stuck", dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0,
                         hydro_store_vlt=400.0, init_soc=0.6, fc_max_power=100.0, fcev_permeate=0.1), 48),
+    # more than 64 piles per station (the reference takes any size, CHS.hpp:1148,1458): units span several waves, 64-bit sums
+    ("big_100_70", dict(station_list=[100, 70], station_type_list=["fast", "slow"], hydro_prod_rate=2000.0,
+                        hydro_store_vlt=5000.0, init_soc=0.5, fc_max_power=100.0, fcev_permeate=0.02), 19),
+    ("big_256", dict(station_list=[256, 0], station_type_list=["slow", "fast"], hydro_prod_rate=2000.0,
+                     hydro_store_vlt=5000.0, init_soc=0.5, fc_max_power=100.0, fcev_permeate=0.01), 7),
     # a 3-pile fast station: evs_reset can record a negative flow_in (CHS.hpp:1276, 832-842, 1617)
     ("small_fast", dict(station_list=[3, 2], station_type_list=["fast", "fast"], hydro_prod_rate=100.0,
                         hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01), 200),
