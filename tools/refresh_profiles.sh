@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root):  tools/refresh_profiles.sh v11
+# usage (on the GPU box, from the repo root):  tools/refresh_profiles.sh v3
 # Writes gpurun_out/profiles_<tag>/: the default bench line, the rocprofv3 kernel-trace stats of the same command, and the
 # FETCH_SIZE / WRITE_SIZE / SQ counter passes (each --pmc set in its own run) summarised into one JSON.
 # Copy the files into profiles/ (tracked) afterwards.
@@ -8,10 +8,10 @@ TAG=${1:-vX}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python3 bench.py > $OUT/round1_${TAG}_bench.json 2> $OUT/bench.err
-echo "bench done"; tail -c 400 $OUT/round1_${TAG}_bench.json; echo
-rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/round1_${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
-cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/round1_${TAG}_kernel_stats.csv
+python3 bench.py > $OUT/round2_${TAG}_bench.json 2> $OUT/bench.err
+echo "bench done"; tail -c 400 $OUT/round2_${TAG}_bench.json; echo
+rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/round2_${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
+cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/round2_${TAG}_kernel_stats.csv
 echo "kernel trace done"
 ARGS="--steps 96 --warmup 96 --no-cpu-baseline --no-events"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch --output-format csv -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err
@@ -20,6 +20,9 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write --output-format csv -- python3 benc
 echo "write pass done"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmc_sq --output-format csv -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_sq.err
 echo "sq pass done"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_tcc --output-format csv -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_tcc.err
+rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum -d $OUT/pmc_tcp --output-format csv -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_tcp.err
+echo "cache passes done"
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, sys
 from collections import defaultdict
@@ -36,19 +39,28 @@ def pick(acc, key):
             return {c: sum(v) / len(v) for c, v in acc[name].items()}
     return {}
 fe, wr, sq = collect(out + "/pmc_fetch"), collect(out + "/pmc_write"), collect(out + "/pmc_sq")
-# gfx950 corrections measured with tools/microbench/copy4.hip (profiles/round1_v10_pmc_traffic.json): FETCH_SIZE reports
-# half of the bytes fetched for this access shape, WRITE_SIZE is exact; both in KiB
-FETCH_FACTOR, WRITE_FACTOR = 1.9998847180168786, 1.0
-res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes), mean per dispatch over the step kernels of "
-               "bench.py --steps 96 at 65536 envs x [20,25]; KiB; corrections from tools/microbench/copy4.hip",
+for extra in ("/pmc_tcc", "/pmc_tcp"):
+    for name, d in collect(out + extra).items():
+        for c, v in d.items():
+            sq[name][c] = v
+import ctypes, os
+sys.path.insert(0, os.getcwd())
+import charginghub_env_amd as chub
+build_id = chub.load_library().chub_build_id().decode()
+# gfx950 corrections (MI355X_MICROARCH.md, HBM section; confirmed in round 1 with tools/microbench/copy4.hip): FETCH_SIZE
+# reports half of the bytes fetched (128-byte requests tallied at 64 bytes), WRITE_SIZE is exact; both in KiB
+FETCH_FACTOR, WRITE_FACTOR = 2.0, 1.0
+res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* / TCC_* / TCP_* (separate passes), mean per dispatch over the step kernels "
+               "of bench.py --steps 96 at 65536 envs x [20,25]; KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950",
+       "build_id": build_id, "envs": 65536,
        "calibration": {"fetch_factor": FETCH_FACTOR, "write_factor": WRITE_FACTOR}}
-for label, key in (("k_slot", ("k_slot_packed", "k_slot<false")), ("k_env", ("k_env<false",))):
+for label, key in (("k_slot", ("k_slot_packed<256, 2, false, false",)), ("k_env", ("k_env<false",))):
     f, w = pick(fe, key).get("FETCH_SIZE", 0.0), pick(wr, key).get("WRITE_SIZE", 0.0)
     res[label] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                   "traffic_bytes_per_launch": (f * FETCH_FACTOR + w * WRITE_FACTOR) * 1024.0}
     res[label + "_sq_counters_per_dispatch"] = pick(sq, key)
-json.dump(res, open("%s/round1_%s_pmc_traffic.json" % (out, tag), "w"), indent=1)
+json.dump(res, open("%s/round2_%s_pmc_traffic.json" % (out, tag), "w"), indent=1)
 print(json.dumps(res["k_slot"]))
 PY
-rm -rf $OUT/kt $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+rm -rf $OUT/kt $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_tcc $OUT/pmc_tcp
 ls $OUT
