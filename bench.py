@@ -15,9 +15,11 @@ for every N); --scaling weak: BASELINE.json configs[4] (hub [32 fast, 32 slow], 
 to rank 0 in one RCCL gather (chub_step_gather), stream-ordered behind the step kernels.  Actions are a random policy drawn
 on the device before the timed region (8 resident batches, cycled); episodes are reset every 96 steps inside the timed region.
 
-With N > 1 (or --graph) whole episodes are captured into a hipGraph (2 episodes = 2 resets + 192 steps per replay): at
-8192 envs per GPU the kernels of a step take less time than the host needs to issue them.  At N = 1 the default is eager
-launches, with HIP events on every 4th step for the per-kernel times behind `roofline`.
+By default whole episodes are captured into a hipGraph (2 episodes = 2 resets + 192 steps per replay) and the timed region
+is graph replays plus, at its end, one segment of 192 steps issued call by call with HIP events around the two kernels
+of every 4th step: the per-kernel times behind `roofline` are measured inside the timed region, and the launch-bound case
+(8192 envs per GPU at N = 8: the kernels of a step take less time than the host needs to issue them) is covered.
+--graph off issues every step call by call.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the slot kernel) with ALGORITHMIC bytes (DESIGN.md
 section 5) over its average duration; `roofline_step` prices the whole step the same way (B * env-steps/s /
@@ -132,8 +134,8 @@ def main():
     ap.add_argument("--envs", type=int, default=None, help="total envs (strong) / envs per GPU (weak); default: the config's")
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
-    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="capture whole episodes into a hipGraph (auto: on for N > 1, off for N = 1)")
+    ap.add_argument("--graph", choices=["on", "off"], default="on",
+                    help="capture whole episodes into a hipGraph; the last 192 steps of the timed region stay eager for the HIP events")
     ap.add_argument("--force-comm", action="store_true", help="N = 1: still make the communicator and gather (to rank 0 itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events in the timed region")
@@ -167,12 +169,12 @@ def main():
         assert total % world == 0
         per = total // world
     use_comm = world > 1 or args.force_comm
-    use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
-    steps, warmup = args.steps, args.warmup
+    use_graph = args.graph == "on"
+    steps, warmup = args.steps, args.warmup  # exactly W untimed and K timed steps, whatever the launch form
     per_graph = 96 * GRAPH_EPISODES
-    if use_graph:  # whole graphs only: round the two counts up
-        steps = -(-steps // per_graph) * per_graph
-        warmup = -(-warmup // per_graph) * per_graph
+    # the end of the timed region is issued call by call, with HIP events on every PROFILE_EVERY-th step (all of it when no
+    # graph fits in front: a replay starts at an episode boundary and covers per_graph steps)
+    eager_tail = 0 if args.no_events else min(steps, per_graph)
 
     comm = multi_gpu.Comm(rank, world, local_rank) if use_comm else None
     v = chub.VecChargingHub(per, seed=SEED, rng="philox", device=local_rank, env_id0=rank * per, **hub_kw)
@@ -211,22 +213,33 @@ def main():
             one_step(i)
         graph = v.graph_end(stream.ptr)
 
-    def run(n_steps, first):
-        if graph is not None:
-            for _ in range(n_steps // per_graph):
-                v.graph_launch(graph, stream.ptr)
-        else:
-            for i in range(n_steps):
-                one_step(first + i)
+    replayed = [0]
 
-    run(warmup, 0)
+    def run(first, n_steps, reserve):
+        """steps first .. first + n_steps - 1: graph replays wherever one fits (it starts at an episode boundary and must end
+        `reserve` steps before the end of the span), single calls otherwise"""
+        i, end = first, first + n_steps
+        while i < end:
+            if graph is not None and i % 96 == 0 and end - reserve - i >= per_graph:
+                v.graph_launch(graph, stream.ptr)
+                i += per_graph
+                replayed[0] += per_graph
+            else:
+                one_step(i)
+                i += 1
+        return i
+
+    run(0, warmup, 0)
     fence()
-    use_events = not args.no_events and graph is None
-    if use_events:
-        v.profile_begin(steps, every=PROFILE_EVERY)
+    replayed[0] = 0
+    use_events = not args.no_events
     t0 = time.perf_counter()
-    run(steps, warmup)
-    t_issue = time.perf_counter() - t0  # host time to issue the whole timed region (eager: launches; graph: replays)
+    head = steps - eager_tail
+    run(warmup, head, 0)
+    if use_events:
+        v.profile_begin(eager_tail, every=PROFILE_EVERY)
+    run(warmup + head, eager_tail, eager_tail)
+    t_issue = time.perf_counter() - t0  # host time to issue the whole timed region
     fence()
     dt = time.perf_counter() - t0
     slot_ms = env_ms = 0.0
@@ -268,7 +281,9 @@ def main():
                                    "random policy resident in HBM, reset every 96 steps, Philox streams"
                                    % (total, hub_kw["station_list"][0], hub_kw["station_list"][1],
                                       {"c4": "configs[3]", "c5": "configs[4]"}.get(config, config), hub_kw["fcev_permeate"]),
-                       "envs_per_gpu": per, "obs_dim": D, "act_dim": A, "launch": "hipGraph of %d episodes" % GRAPH_EPISODES if graph else "eager",
+                       "envs_per_gpu": per, "obs_dim": D, "act_dim": A, "launch": ("hipGraph of %d episodes: %d of the %d timed steps are replays, the others (incl. the last %d, with "
+                                  "HIP events) are single calls" % (GRAPH_EPISODES, replayed[0], steps, eager_tail))
+                       if graph else "every step a call",
                        "host_issue_ms_per_step": t_issue / steps * 1e3,
                        "collective": "none" if not use_comm else
                        "one grouped ncclSend/ncclRecv (RCCL) of [envs_per_gpu, %d] f32 per step to rank 0, on the step's stream" % (D + 2)},
