@@ -129,6 +129,7 @@ struct Tables {
     CHUB_G(const float) normal_tail;  // [4097] its second level for the lowest / highest cell   (PHILOX mode)
     CHUB_G(const double) sin96;       // [96]   sin(2*pi*t/96), the time feature of the observation (MGR:319-320)
     CHUB_G(const float) ttab[2];      // [1000] soc_to_time(target level k) of station k's curve (target = 80 + 20*k/999)
+    CHUB_G(const float) ttab2;        // [2][1024] the same two tables in one padded buffer (packed slot kernel: LDS staging)
     CHUB_G(const float) cls[2];       // [kSocLevels + kTapeClasses + 1][kClsRow][2] PHILOX: per arrival-SoC class of station k's curve:
                                       //   (power, t_soc) after n = 0 .. kClsRow-1 car_steps (entry 0 = what add_car derives, CHS.hpp:864-877)
     CHUB_G(const float) cls_soc0[2];  // [kSocLevels + kTapeClasses] the class's arrival SoC (introspection)
@@ -182,7 +183,7 @@ struct PackedPtrs {
     const StationArrays *st;
     uint32_t *hot, *rec;
     uint64_t *pk[2];
-    const float *cls[2], *ttab[2];
+    const float *cls[2], *ttab[2], *ttab2;
 };
 
 struct StepArgs {

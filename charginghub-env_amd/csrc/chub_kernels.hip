@@ -762,7 +762,7 @@ struct PackedArgs {
     CHUB_G(const uint64_t) pk;       // this step's packed station draws (TAPE: supplied by the caller)
     CHUB_G(const float) actions;
     CHUB_G(const float) cls0;        // station 0's class table; station 1's is cls_delta bytes further
-    CHUB_G(const float) ttab[2];
+    CHUB_G(const float) ttab2;       // [2][1024] soc_to_time(target level) of both stations' curves (1000 used)
     CHUB_G(const uint32_t) car_tape; // TAPE: [N][S0 + S1][2] per slot, used if the slot admits a car this step: class, level | late << 16
 };
 
@@ -823,15 +823,11 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         }
     }
     // soc_to_time(target) of the 1000 target levels of both stations' curves (CHS.hpp:35-44, 867): staged in LDS, where 64
-    // scattered 4-byte reads cost a few cycles; as a second global gather they cost the vector cache as much as the class rows
-    constexpr int TT_PER = (2 * kLevels + BLOCK - 1) / BLOCK;
-    float tt_stage[TT_PER];
-#pragma unroll
-    for (int i = 0; i < TT_PER; i++) {
-        const int at = tid + i * BLOCK;
-        if (at < 2 * kLevels) tt_stage[i] = at < kLevels ? CHUB_AT(const float, pa.ttab[0], (uint32_t) at << 2)
-                                                         : CHUB_AT(const float, pa.ttab[1], (uint32_t) (at - kLevels) << 2);
-    }
+    // scattered 4-byte reads cost a few cycles; as a second global gather they cost the vector cache as much as the class rows.
+    // One padded table [2][1024] (Tables::ttab2): two 16-byte loads and two 16-byte LDS stores per lane, no address arithmetic.
+    static_assert(BLOCK == 256, "ttab2 staging: 2048 floats = 256 lanes x 2 x 4");
+    const f32x4 tt_a = CHUB_AT(const f32x4, pa.ttab2, (uint32_t) tid << 4);
+    const f32x4 tt_b = CHUB_AT(const f32x4, pa.ttab2, ((uint32_t) tid << 4) + 4096u);
     if (tid == 0) q_cnt[0] = 0;
     for (int i = tid; i < (BIG ? 16 : 8) * epb; i += BLOCK) s_acc[i] = 0;
     long long *s_acc64 = (long long *) s_acc;  // BIG: {min, charge, max power, cars} as four 64-bit sums per unit
@@ -852,9 +848,8 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         asm volatile("" : "=v"(row[j]));
         if (stays[j]) row[j] = CHUB_AT(const f32x4, pa.cls0, (k_[j] ? pa.cls_delta : 0u) + (s2[j].y << 8) + (ps_n(w0[j]) << 3));
     }
-#pragma unroll
-    for (int i = 0; i < TT_PER; i++)
-        if (tid + i * BLOCK < 2 * kLevels) s_tt[tid + i * BLOCK] = tt_stage[i];
+    ((f32x4 *) s_tt)[tid] = tt_a;
+    ((f32x4 *) s_tt)[tid + 256] = tt_b;
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627) while those are in flight
     bool empty[T];
@@ -948,7 +943,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         int *acc = s_acc + 4 * u;  // the unit's {min, charge power | max power, cars}: two 64-bit LDS atomics per car
         uint32_t w0n = 0u;
         if (stays[j]) {
-            const float t_target = s_tt[(k_[j] ? kLevels : 0) + (int) ps_tgt(w0[j])];
+            const float t_target = s_tt[(k_[j] ? 1024 : 0) + (int) ps_tgt(w0[j])];
             // action_to_real (MGR:384-393), judge_feasibility (CHS.hpp:1404-1413)
             const bool on = act[j] >= kActOnThreshold || must_charge(t_target, row[j].y, tl[j]);
             const float power = on ? row[j].z : row[j].x, t_soc = on ? row[j].w : row[j].y;  // car_step = the next entry of the class row
@@ -1002,7 +997,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
             late = late_from_word(tb.late_thr, o.v[2]);
         }
         const f32x2 e0 = CHUB_AT(const f32x2, pa.cls0, (s_k ? pa.cls_delta : 0u) + (c << 8));
-        const float tt_ = s_tt[(s_k ? kLevels : 0) + (int) lev];
+        const float tt_ = s_tt[(s_k ? 1024 : 0) + (int) lev];
         int st_ = (int) ceilf(__fsub_rn(tt_, e0.y)) + late;  // calculate_min_charging_time + mk_late_time
         st_ = st_ > kMaxStay ? kMaxStay : st_;
         const u32x2 o2 = {st_ > 0 ? ps_make(st_, lev) : 0u, c};
@@ -1078,14 +1073,13 @@ __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restri
     __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];                   // [1 + virtual wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
     __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T];  // 2 epb <= BLOCK * T / 2 units x {min, charge, max power, cars} (BIG: as 64-bit sums, few units)
     __shared__ uint32_t s_unit[BLOCK * T / 2];                        // per unit: line | flow << 8
-    __shared__ float s_tt[2 * kLevels];                               // soc_to_time(target level) of both stations' curves
+    __shared__ __attribute__((aligned(16))) float s_tt[2048];         // soc_to_time(target level) of both stations' curves, [2][1024]
     // all kernel arguments this wave needs, requested in ONE batch of scalar loads at its very start (the single asm
     // statement makes every one of them live here), instead of in a chain of dependent loads in front of the first
     // vector load
     PackedArgs pa = pa_in;
     asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
-                      "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab[0]),
-                      "+s"(pa.ttab[1]));
+                      "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
     slot_body_packed<BLOCK, T, TAPE, RESET, BIG>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new, s_ball + 1, s_acc, s_unit, s_tt);
 }
 
@@ -1322,7 +1316,15 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         const int env0 = env_block * kEnvBlock;
         const int rows = (int) N - env0 < kEnvBlock ? (int) N - env0 : kEnvBlock;
         float *dst = sa.obs + (size_t) env0 * (size_t) row_w;
-        for (int i = threadIdx.x; i < rows * row_w; i += kEnvBlock) dst[i] = s_out[i];
+        const int total = rows * row_w;
+        if ((((uintptr_t) dst) & 15u) == 0) {  // 16 bytes per lane and store: a quarter of the store instructions
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const int quads = total >> 2;
+            for (int i = threadIdx.x; i < quads; i += kEnvBlock) ((f32x4 *) dst)[i] = ((const f32x4 *) s_out)[i];
+            for (int i = (quads << 2) + threadIdx.x; i < total; i += kEnvBlock) dst[i] = s_out[i];
+        } else {
+            for (int i = threadIdx.x; i < total; i += kEnvBlock) dst[i] = s_out[i];
+        }
     };
     // one pass of a do/while so that lanes without an env skip the work but still reach the workgroup barrier of
     // flush_rows() at the same program point as everybody else
@@ -1690,7 +1692,7 @@ template <bool RESET, int MODE>
 __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, TailArgs ta, int nb_env) {
     __shared__ double s_pv[100], s_wd[150], s_hy[102];
     __shared__ __attribute__((aligned(16))) uint8_t s_hv[kLevels];
-    __shared__ float s_out[kEnvBlock * 16];  // output rows: obs_dim + 2 <= 15 floats
+    __shared__ __attribute__((aligned(16))) float s_out[kEnvBlock * 16];  // output rows: obs_dim + 2 <= 15 floats
     if (MODE == MODE_PHILOX && (int) blockIdx.x >= nb_env) {
         // the last blocks of the grid: next step's station-level draws, one lane per (station, env).
         // They are pure VALU work and fill the issue slots the latency-bound tail waves leave empty.
@@ -1936,7 +1938,6 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             for (int k = 0; k < 2; k++) {
                 pa.S[k] = (uint32_t) hp.S[k];
                 pa.type[k] = (uint32_t) hp.type[k];
-                pa.ttab[k] = (CHUB_G(const float)) pp.ttab[k];
             }
             pa.n_envs = (uint32_t) hp.n_envs;
             pa.epb = (uint32_t) hp.epb;
@@ -1947,6 +1948,7 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             pa.pk = (CHUB_G(const uint64_t)) (sa.pk_tape ? sa.pk_tape : pp.pk[sa.tick & 1u]);
             pa.actions = (CHUB_G(const float)) sa.actions;
             pa.cls0 = (CHUB_G(const float)) pp.cls[0];
+            pa.ttab2 = (CHUB_G(const float)) pp.ttab2;
             pa.car_tape = (CHUB_G(const uint32_t)) sa.car_tape;
             const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
 #define CHUB_PACKED(TAPE_, RESET_, BIG_) \

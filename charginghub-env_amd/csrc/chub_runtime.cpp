@@ -274,6 +274,7 @@ static PackedPtrs packed_ptrs(const chub_env *e) {
     p.cls[1] = e->tb.cls[1];
     p.ttab[0] = e->tb.ttab[0];
     p.ttab[1] = e->tb.ttab[1];
+    p.ttab2 = e->tb.ttab2;
     p.pk[0] = (uint64_t *) e->st.pk[0];
     p.pk[1] = (uint64_t *) e->st.pk[1];
     return p;
@@ -648,6 +649,11 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if ((rc = dev_upload(e, &e->tb.sin96, sin96))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.ttab[0], ttab[0]))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.ttab[1], ttab[1]))) return bail(rc);
+    {
+        std::vector<float> t2(2048, 0.0f);
+        for (int s = 0; s < 2; s++) memcpy(&t2[(size_t) s * 1024], ttab[s].data(), kLevels * sizeof(float));
+        if ((rc = dev_upload(e, &e->tb.ttab2, t2))) return bail(rc);
+    }
     e->tb.cls[0] = e->tb.cls[1] = e->tb.cls_soc0[0] = e->tb.cls_soc0[1] = nullptr;
     if (rng_mode == CHUB_RNG_PHILOX) {
         // both stations' class tables in one buffer (the packed kernel addresses station 1's as station 0's + a byte distance)
