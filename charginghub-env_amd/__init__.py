@@ -2,8 +2,8 @@
 
 Host side of the drop-in for the reference's ``reset()/step()`` path
 (``evcssp_env_cpp.envs.EvcsspManagerEnv_v6``, evcssp_manager.py:19): a thin ctypes + numpy layer over
-``libchub.so`` (HIP kernels for gfx950 behind the C ABI of ``include/chub.h``).  No PyTorch here; the
-multi-GPU launcher (``sharded.py``) borrows torch only for device buffers and the RCCL gather.
+``libchub.so`` (HIP kernels for gfx950 behind the C ABI of ``include/chub.h``).  No PyTorch here: the multi-GPU host
+(``multi_gpu.py``) drives libchub's own RCCL leg; ``sharded.py`` / ``TorchHubVecEnv`` are adapters for trainers that live in torch.
 """
 from ._lib import ChubError, lib_path, load_library  # noqa: F401
 from .vec_env import VecChargingHub, make_config  # noqa: F401
