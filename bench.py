@@ -15,11 +15,11 @@ for every N); --scaling weak: BASELINE.json configs[4] (hub [32 fast, 32 slow], 
 to rank 0 in one RCCL gather (chub_step_gather), stream-ordered behind the step kernels.  Actions are a random policy drawn
 on the device before the timed region (8 resident batches, cycled); episodes are reset every 96 steps inside the timed region.
 
-By default whole episodes are captured into a hipGraph (2 episodes = 2 resets + 192 steps per replay) and the timed region
+At N = 1 whole episodes are captured into a hipGraph (2 episodes = 2 resets + 192 steps per replay) and the timed region
 is graph replays plus, at its end, one segment of 192 steps issued call by call with HIP events around the two kernels
-of every 4th step: the per-kernel times behind `roofline` are measured inside the timed region, and the launch-bound case
-(8192 envs per GPU at N = 8: the kernels of a step take less time than the host needs to issue them) is covered.
---graph off issues every step call by call.
+of every 4th step: the per-kernel times behind `roofline` are measured inside the timed region.  At N > 1 every step is a
+call by default (16 us of host time per step, below the GPU time of a shard's step + gather); --graph on captures there
+too (RCCL inside the capture: verified on a world of one).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the slot kernel) with ALGORITHMIC bytes (DESIGN.md
 section 5) over its average duration; `roofline_step` prices the whole step the same way (B * env-steps/s /
@@ -134,8 +134,10 @@ def main():
     ap.add_argument("--envs", type=int, default=None, help="total envs (strong) / envs per GPU (weak); default: the config's")
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
-    ap.add_argument("--graph", choices=["on", "off"], default="on",
-                    help="capture whole episodes into a hipGraph; the last 192 steps of the timed region stay eager for the HIP events")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="capture whole episodes into a hipGraph (the last 192 steps of the timed region stay single calls for the HIP "
+                         "events); auto: on at N = 1, off at N > 1, where the capture holds RCCL operations of several processes, "
+                         "which this repository could only exercise on a world of one")
     ap.add_argument("--force-comm", action="store_true", help="N = 1: still make the communicator and gather (to rank 0 itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events in the timed region")
@@ -169,7 +171,7 @@ def main():
         assert total % world == 0
         per = total // world
     use_comm = world > 1 or args.force_comm
-    use_graph = args.graph == "on"
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
     steps, warmup = args.steps, args.warmup  # exactly W untimed and K timed steps, whatever the launch form
     per_graph = 96 * GRAPH_EPISODES
     # the end of the timed region is issued call by call, with HIP events on every PROFILE_EVERY-th step (all of it when no

@@ -8,8 +8,10 @@ ncclSend / ncclRecv enqueued on the same HIP stream as the step kernels (``chub_
 The 128-byte RCCL id travels from rank 0 to the other ranks of the node through a file in /tmp (single node: the north star's
 8 GPUs of one node); nothing else is exchanged on the host side.
 """
+import contextlib
 import ctypes as C
 import os
+import sys
 import time
 
 import numpy as np
@@ -101,6 +103,23 @@ def exchange_unique_id(rank, world, timeout=300.0):
         time.sleep(0.01)
 
 
+@contextlib.contextmanager
+def _c_stdout_to_stderr():
+    """RCCL prints a banner ("Hostname", "Librccl path") to the C stdout when it initialises; programs that print results on
+    stdout (bench.py: one JSON line) want it on stderr"""
+    libc = C.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class Comm(object):
     """libchub's communicator: ncclCommInitRank behind the C ABI"""
 
@@ -109,11 +128,12 @@ class Comm(object):
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         self.device = int(os.environ.get("LOCAL_RANK", "0")) if device is None else int(device)
-        uid = exchange_unique_id(self.rank, self.world)
-        h = C.c_void_p()
-        check(self._lib.chub_comm_create(uid, self.world, self.rank, self.device, C.byref(h)))
-        self._h = h
-        self.barrier()
+        with _c_stdout_to_stderr():
+            uid = exchange_unique_id(self.rank, self.world)
+            h = C.c_void_p()
+            check(self._lib.chub_comm_create(uid, self.world, self.rank, self.device, C.byref(h)))
+            self._h = h
+            self.barrier()
         if self.rank == 0:  # every rank holds the id by now
             try:
                 os.remove(_rendezvous_path())
