@@ -128,6 +128,7 @@ class Comm(object):
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         self.device = int(os.environ.get("LOCAL_RANK", "0")) if device is None else int(device)
+        self.device %= max(1, self._lib.chub_device_count())  # a rank that is shown only its own GPU sees it as ordinal 0
         with _c_stdout_to_stderr():
             uid = exchange_unique_id(self.rank, self.world)
             h = C.c_void_p()
