@@ -293,16 +293,18 @@ __device__ __forceinline__ uint64_t draw_station_levels(const HubParams &hp, con
 // time_to_power (car_step, CHS.hpp:900-905 / 1065-1070) from that class: Tables::cls[k] holds, per class, (power, t_soc)
 // after n = 0 .. kClsRow-1 car_steps, built once on the host with the same curve functions (chub_curves.h).  The slot keeps
 //   w0: bits 0-5 stay_time - already_stay_time (0 = empty), bit 6 charging this step, bits 7-12 stay_time,
-//       bits 13-17 n = car_steps taken since arrival, bits 18-27 target-SoC level (target = 80 + 20 * l / 999, CHS.hpp:35-44)
-//   w1: arrival-SoC class
+//       bits 13-17 n = car_steps taken since arrival, bits 18-31 arrival-SoC class
+//   w1: soc_to_time(target SoC), f32 -- one of the 1000 values of Tables::ttab (target = 80 + 20 * l / 999, CHS.hpp:35-44),
+//       looked up once, when the car is admitted
 // and everything the step needs follows from one 16-byte row read (entries n and n + 1: where the car is on its curve and
-// where one more car_step takes it) and one 4-byte read of Tables::ttab (soc_to_time(target)).
+// where one more car_step takes it).
 __device__ __forceinline__ int ps_tl(uint32_t w0) { return (int) (w0 & 63u); }
 __device__ __forceinline__ uint32_t ps_n(uint32_t w0) { return (w0 >> 13) & 31u; }
-__device__ __forceinline__ uint32_t ps_tgt(uint32_t w0) { return (w0 >> 18) & 1023u; }
-__device__ __forceinline__ uint32_t ps_make(int stay, uint32_t tgt) {  // a car that has just arrived
-    return (uint32_t) stay | ((uint32_t) stay << 7) | (tgt << 18);
+__device__ __forceinline__ uint32_t ps_cls(uint32_t w0) { return w0 >> 18; }
+__device__ __forceinline__ uint32_t ps_make(int stay, uint32_t cls) {  // a car that has just arrived
+    return (uint32_t) stay | ((uint32_t) stay << 7) | (cls << 18);
 }
+static_assert(kSocLevels + kTapeClasses <= (1 << 14), "the class id has 14 bits of the state word");
 constexpr int kMaxStay = 63;  // 6-bit fields; chub_create checks that no reachable stay_time comes near it
 
 // car_step (CHS.hpp:900-905 / 1065-1070): soc and power one slot further along the curve, evaluated together.  Same
@@ -647,8 +649,8 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     f32x4 row = {0.0f, 0.0f, 0.0f, 0.0f};
     float t_target = 0.0f;
     if (car) {
-        row = *(CHUB_G(const f32x4)) ((CHUB_G(const char)) cls + ((size_t) w1 * (kClsRow * 8u) + ps_n(w0) * 8u));
-        t_target = tb.ttab[k][ps_tgt(w0)];
+        row = *(CHUB_G(const f32x4)) ((CHUB_G(const char)) cls + ((size_t) ps_cls(w0) * (kClsRow * 8u) + ps_n(w0) * 8u));
+        t_target = __uint_as_float(w1);
     }
     float power = row.x, t_soc = row.y;
     int on_override = -1;
@@ -715,8 +717,8 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
         t_soc = e0.y;
         tl = stay;
         car = tl > 0;
-        w0 = car ? ps_make(stay, lev) : 0u;
-        w1 = c;
+        w0 = car ? ps_make(stay, c) : 0u;
+        w1 = __float_as_uint(t_target);
     }
 
     // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572): order-independent sums -- every slot power truncated to a
@@ -772,7 +774,7 @@ struct PackedArgs {
 template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG>
 __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const PackedArgs &pa, const Tables &tb,
                                                  const uint32_t block_local, uint32_t *q_cnt, uint32_t *q_new,
-                                                 uint64_t *s_ball, int *s_acc, uint32_t *s_unit, float *s_tt) {
+                                                 uint64_t *s_ball, int *s_acc, uint32_t *s_unit) {
     // T slots per lane: virtual lane v = tid + j * BLOCK (j < T), virtual wave = wave + j * (BLOCK / 64).  All T slots' loads
     // are in flight together and the barriers are shared.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -822,12 +824,6 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
             pk_in[j] = CHUB_AT(const uint64_t, pa.pk, sidx[j] << 3);
         }
     }
-    // soc_to_time(target) of the 1000 target levels of both stations' curves (CHS.hpp:35-44, 867): staged in LDS, where 64
-    // scattered 4-byte reads cost a few cycles; as a second global gather they cost the vector cache as much as the class rows.
-    // One padded table [2][1024] (Tables::ttab2): two 16-byte loads and two 16-byte LDS stores per lane, no address arithmetic.
-    static_assert(BLOCK == 256, "ttab2 staging: 2048 floats = 256 lanes x 2 x 4");
-    const f32x4 tt_a = CHUB_AT(const f32x4, pa.ttab2, (uint32_t) tid << 4);
-    const f32x4 tt_b = CHUB_AT(const f32x4, pa.ttab2, ((uint32_t) tid << 4) + 4096u);
     if (tid == 0) q_cnt[0] = 0;
     for (int i = tid; i < (BIG ? 16 : 8) * epb; i += BLOCK) s_acc[i] = 0;
     long long *s_acc64 = (long long *) s_acc;  // BIG: {min, charge, max power, cars} as four 64-bit sums per unit
@@ -846,10 +842,8 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         tl[j] = ps_tl(w0[j]);
         stays[j] = tl[j] > 1;
         asm volatile("" : "=v"(row[j]));
-        if (stays[j]) row[j] = CHUB_AT(const f32x4, pa.cls0, (k_[j] ? pa.cls_delta : 0u) + (s2[j].y << 8) + (ps_n(w0[j]) << 3));
+        if (stays[j]) row[j] = CHUB_AT(const f32x4, pa.cls0, (k_[j] ? pa.cls_delta : 0u) + (ps_cls(w0[j]) << 8) + (ps_n(w0[j]) << 3));
     }
-    ((f32x4 *) s_tt)[tid] = tt_a;
-    ((f32x4 *) s_tt)[tid + 256] = tt_b;
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627) while those are in flight
     bool empty[T];
@@ -943,7 +937,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         int *acc = s_acc + 4 * u;  // the unit's {min, charge power | max power, cars}: two 64-bit LDS atomics per car
         uint32_t w0n = 0u;
         if (stays[j]) {
-            const float t_target = s_tt[(k_[j] ? 1024 : 0) + (int) ps_tgt(w0[j])];
+            const float t_target = __uint_as_float(s2[j].y);
             // action_to_real (MGR:384-393), judge_feasibility (CHS.hpp:1404-1413)
             const bool on = act[j] >= kActOnThreshold || must_charge(t_target, row[j].y, tl[j]);
             const float power = on ? row[j].z : row[j].x, t_soc = on ? row[j].w : row[j].y;  // car_step = the next entry of the class row
@@ -996,11 +990,12 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
             lev = o.v[1] % 1000u;
             late = late_from_word(tb.late_thr, o.v[2]);
         }
-        const f32x2 e0 = CHUB_AT(const f32x2, pa.cls0, (s_k ? pa.cls_delta : 0u) + (c << 8));
-        const float tt_ = s_tt[(s_k ? 1024 : 0) + (int) lev];
+        f32x2 e0 = CHUB_AT(const f32x2, pa.cls0, (s_k ? pa.cls_delta : 0u) + (c << 8));
+        float tt_ = CHUB_AT(const float, pa.ttab2, (s_k ? 4096u : 0u) + (lev << 2));  // soc_to_time(target), CHS.hpp:867 / 1032
+        asm volatile("" : "+v"(e0), "+v"(tt_));  // both lookups in flight together
         int st_ = (int) ceilf(__fsub_rn(tt_, e0.y)) + late;  // calculate_min_charging_time + mk_late_time
         st_ = st_ > kMaxStay ? kMaxStay : st_;
-        const u32x2 o2 = {st_ > 0 ? ps_make(st_, lev) : 0u, c};
+        const u32x2 o2 = {st_ > 0 ? ps_make(st_, c) : 0u, __float_as_uint(tt_)};
         CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) src) << 3) = o2;
         if (st_ > 0) {
             const int q = (int) (e0.x * 524288.0f);
@@ -1073,14 +1068,13 @@ __global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restri
     __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];                   // [1 + virtual wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
     __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T];  // 2 epb <= BLOCK * T / 2 units x {min, charge, max power, cars} (BIG: as 64-bit sums, few units)
     __shared__ uint32_t s_unit[BLOCK * T / 2];                        // per unit: line | flow << 8
-    __shared__ __attribute__((aligned(16))) float s_tt[2048];         // soc_to_time(target level) of both stations' curves, [2][1024]
     // all kernel arguments this wave needs, requested in ONE batch of scalar loads at its very start (the single asm
     // statement makes every one of them live here), instead of in a chain of dependent loads in front of the first
     // vector load
     PackedArgs pa = pa_in;
     asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
                       "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
-    slot_body_packed<BLOCK, T, TAPE, RESET, BIG>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new, s_ball + 1, s_acc, s_unit, s_tt);
+    slot_body_packed<BLOCK, T, TAPE, RESET, BIG>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new, s_ball + 1, s_acc, s_unit);
 }
 
 // What the tail's first loads need, by value in the kernel arguments: one scalar load at the start of the wave instead
@@ -1849,10 +1843,10 @@ __global__ void k_replay_soc(const DevCtx *__restrict__ ctx, float *out) {
     int n = 0;
     bool car;
     if (hp.rng_mode == MODE_PHILOX) {  // arrival SoC of the slot's class, car_steps from the state word
-        const uint32_t w0 = ctx->sl.hot[2 * idx], w1 = ctx->sl.hot[2 * idx + 1];
+        const uint32_t w0 = ctx->sl.hot[2 * idx];
         car = ps_tl(w0) != 0;
         if (car) {
-            soc = ctx->tb.cls_soc0[k][w1];
+            soc = ctx->tb.cls_soc0[k][ps_cls(w0)];
             n = (int) ps_n(w0);
         }
     } else {

@@ -9,6 +9,7 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -666,6 +667,10 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
             e->h_cls[s] = cls[s];
             e->h_soc0[s] = cls_soc0[s];
             e->h_ttab[s] = ttab[s];
+            // the slot state keeps soc_to_time(target) itself and chub_get_slots finds the level back by its value
+            for (int l = 1; l < kLevels; l++)
+                if (!(ttab[s][(size_t) l] > ttab[s][(size_t) l - 1]))
+                    return bail(fail(CHUB_ERR_UNSUPPORTED, "soc_to_time is not strictly increasing over the target-SoC levels"));
         }
     }
 
@@ -1128,8 +1133,8 @@ int chub_set_slots(chub_env *e, const int32_t *rows) {
                     r[4] >= kClsRow)
                     return fail(CHUB_ERR_ARG, "chub_set_slots: field out of range");
                 const size_t idx = env * S + (k ? (size_t) hp.S[0] : 0) + i;  // PHILOX state is hub-major
-                st[2 * idx] = (uint32_t) left | (r[5] ? 64u : 0u) | ((uint32_t) r[2] << 7) | ((uint32_t) r[4] << 13) | ((uint32_t) r[1] << 18);
-                st[2 * idx + 1] = (uint32_t) r[0];
+                st[2 * idx] = (uint32_t) left | (r[5] ? 64u : 0u) | ((uint32_t) r[2] << 7) | ((uint32_t) r[4] << 13) | ((uint32_t) r[0] << 18);
+                memcpy(&st[2 * idx + 1], &e->h_ttab[k][(size_t) r[1]], 4);
             }
     HIP_TRY(hipMemcpy(e->sl.hot, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return CHUB_OK;
@@ -1236,10 +1241,12 @@ int chub_get_slots(chub_env *e, float *out) {
                 bool chg;
                 if (philox) {  // 8-byte state: everything else comes from the class row (see chub_kernels.hip)
                     const uint32_t w0 = hot[2 * idx], w1 = hot[2 * idx + 1];
-                    left = (int) (w0 & 63u); chg = (w0 & 64u) != 0; stay = (int) ((w0 >> 7) & 63u); lev = (int) ((w0 >> 18) & 1023u);
+                    left = (int) (w0 & 63u); chg = (w0 & 64u) != 0; stay = (int) ((w0 >> 7) & 63u); lev = 0;
                     if (left > 0) {
-                        const size_t at = ((size_t) w1 * kClsRow + ((w0 >> 13) & 31u)) * 2;
-                        power = cls[k][at]; t_soc = cls[k][at + 1]; t_target = ttab[k][lev]; arrive = soc0[k][w1];
+                        const size_t c = (size_t) (w0 >> 18), at = (c * kClsRow + ((w0 >> 13) & 31u)) * 2;
+                        power = cls[k][at]; t_soc = cls[k][at + 1]; arrive = soc0[k][c];
+                        memcpy(&t_target, &w1, 4);  // the state keeps soc_to_time(target) itself: its level is its place in the table
+                        lev = (int) (std::lower_bound(ttab[k].begin(), ttab[k].end(), t_target) - ttab[k].begin());
                     }
                 } else {
                     memcpy(&power, &hot[4 * idx + 0], 4);
