@@ -35,7 +35,11 @@ constexpr int kPolarMaxTrials = 32;
 #define CHUB_SLOTS_PER_LANE 2
 #endif
 constexpr int kSlotBlock = 256;    // workgroup size of the slot kernels
-constexpr int kSlotsPerLane = CHUB_SLOTS_PER_LANE;  // packed slot kernel: slots per lane (kSlotBlock * kSlotsPerLane virtual lanes per workgroup)
+#ifndef CHUB_PACKED_BLOCK
+#define CHUB_PACKED_BLOCK 256
+#endif
+constexpr int kPackedBlock = CHUB_PACKED_BLOCK;  // workgroup size of the packed slot kernel
+constexpr int kSlotsPerLane = CHUB_SLOTS_PER_LANE;  // packed slot kernel: slots per lane (kPackedBlock * kSlotsPerLane virtual lanes per workgroup)
 constexpr int kClsRow = 32;        // PHILOX: entries (power, t_soc) per arrival-SoC class = car_steps a car can take (stay_time <= 27 here)
 constexpr int kTapeClasses = 8192; // PHILOX: room for caller-registered arrival-SoC classes (tape mode)
 constexpr int kTelemCount = 24;
@@ -162,7 +166,7 @@ struct HubParams {
     double rc_cells, rc_cap_mass, rc_vm60k, rc_price_std, rc_half_range[2];
     float hv_rate;           // f32(f32(0.3) * f32(permeate))
     int32_t qcap;            // explicit FCEV waiting-list entries per env = max(1, 2 * (max arrivals per step) - 1)
-    int32_t epb;             // packed slot kernel: whole envs per workgroup = kSlotBlock * kSlotsPerLane / (S0 + S1)
+    int32_t epb;             // packed slot kernel: whole envs per workgroup = kPackedBlock * kSlotsPerLane / (S0 + S1)
     int32_t packed;          // PHILOX steps run k_slot_packed (the hub has >= 4 piles in all)
 };
 
@@ -184,6 +188,7 @@ struct PackedPtrs {
     uint32_t *hot, *rec;
     uint64_t *pk[2];
     const float *cls[2], *ttab[2], *ttab2;
+    uint32_t late8[8];        // the first 8 thresholds of Tables::late_thr, passed to the packed kernel by value
 };
 
 struct StepArgs {

@@ -766,13 +766,21 @@ struct PackedArgs {
     CHUB_G(const float) cls0;        // station 0's class table; station 1's is cls_delta bytes further
     CHUB_G(const float) ttab2;       // [2][1024] soc_to_time(target level) of both stations' curves (1000 used)
     CHUB_G(const uint32_t) car_tape; // TAPE: [N][S0 + S1][2] per slot, used if the slot admits a car this step: class, level | late << 16
+    // add_car's Philox block (the new cars come last in the workgroup, behind two barriers: nothing of theirs should wait
+    // for a load that could have been issued at the start of the wave)
+    uint32_t key[2], gid0, tick;     // Philox key, global id of env 0, host tick
+    const uint32_t *tick_base;       // device-side tick offset (graph replays), added to tick
+    uint32_t late[8];                // the first 8 thresholds of mk_late_time's table (late_from_word); beyond them with probability 0.3 %
 };
+
+typedef const uint32_t __attribute__((address_space(4))) *chub_sptr;  // constant address space: scalar loads
+__device__ __forceinline__ uint32_t sload_u32(const void *p, int i) { return ((chub_sptr) (uintptr_t) p)[i]; }
 
 // RESET: evs_reset (CHS.hpp:1209-1231 / 1520-1542) on the same layout: no state comes in, the unit's initial occupancy was drawn
 // by k_reset_levels, every wave helps with the (many) new cars.  BIG: a station with more than 64 piles -- a unit then spans
 // several waves (its empties are counted over all of them) and its power sums need 64 bits.
 template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG>
-__device__ __forceinline__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, const PackedArgs &pa, const Tables &tb,
+__device__ __forceinline__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, PackedArgs &pa, const Tables &tb,
                                                  const uint32_t block_local, uint32_t *q_cnt, uint32_t *q_new,
                                                  uint64_t *s_ball, int *s_acc, uint32_t *s_unit) {
     // T slots per lane: virtual lane v = tid + j * BLOCK (j < T), virtual wave = wave + j * (BLOCK / 64).  All T slots' loads
@@ -823,6 +831,11 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
             }
             pk_in[j] = CHUB_AT(const uint64_t, pa.pk, sidx[j] << 3);
         }
+    }
+    if (!TAPE) {  // the new cars' Philox inputs: scalar registers from here on, requested behind the first loads
+        pa.tick += sload_u32(pa.tick_base, 0);  // CHUB_TICK
+        asm volatile("" : "+s"(pa.key[0]), "+s"(pa.key[1]), "+s"(pa.gid0), "+s"(pa.tick), "+s"(pa.late[0]), "+s"(pa.late[1]), "+s"(pa.late[2]),
+                          "+s"(pa.late[3]), "+s"(pa.late[4]), "+s"(pa.late[5]), "+s"(pa.late[6]), "+s"(pa.late[7]));
     }
     if (tid == 0) q_cnt[0] = 0;
     for (int i = tid; i < (BIG ? 16 : 8) * epb; i += BLOCK) s_acc[i] = 0;
@@ -984,11 +997,17 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
             lev = tp.y & 0xFFFFu;
             late = (int) (tp.y >> 16);
         } else {
-            PhiloxCtx p2{hp.key[0], hp.key[1], CHUB_TICK(hp, sa.tick), (uint32_t) (hp.env_id0 + env_first + s_e)};
+            PhiloxCtx p2{pa.key[0], pa.key[1], pa.tick, pa.gid0 + (uint32_t) (env_first + s_e)};
             const U4 o = p2.block(SITE_SOC, (uint32_t) s_hs, 0);  // word 0 SoC class, 1 target level, 2 extra stay
             c = o.v[0] >> kSocLevelShift;
             lev = o.v[1] % 1000u;
-            late = late_from_word(tb.late_thr, o.v[2]);
+            late = 0;  // late_from_word, the first 8 thresholds from registers
+#pragma unroll
+            for (int j = 0; j < 8; j++) late += (o.v[2] >= pa.late[j]) ? 1 : 0;
+            if (__any(o.v[2] >= pa.late[7])) {
+#pragma unroll
+                for (int j = 8; j < 16; j++) late += (o.v[2] >= tb.late_thr[j]) ? 1 : 0;
+            }
         }
         f32x2 e0 = CHUB_AT(const f32x2, pa.cls0, (s_k ? pa.cls_delta : 0u) + (c << 8));
         float tt_ = CHUB_AT(const float, pa.ttab2, (s_k ? 4096u : 0u) + (lev << 2));  // soc_to_time(target), CHS.hpp:867 / 1032
@@ -1062,7 +1081,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
 }
 
 template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG>
-__global__ __launch_bounds__(BLOCK, 8) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in) {
+__global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in) {
     __shared__ uint32_t q_new[BLOCK * T];
     __shared__ uint32_t q_cnt[2];
     __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];                   // [1 + virtual wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
@@ -1944,9 +1963,15 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             pa.cls0 = (CHUB_G(const float)) pp.cls[0];
             pa.ttab2 = (CHUB_G(const float)) pp.ttab2;
             pa.car_tape = (CHUB_G(const uint32_t)) sa.car_tape;
+            pa.key[0] = hp.key[0];
+            pa.key[1] = hp.key[1];
+            pa.gid0 = (uint32_t) hp.env_id0;
+            pa.tick = sa.tick;
+            pa.tick_base = hp.tick_base;
+            for (int j = 0; j < 8; j++) pa.late[j] = pp.late8[j];
             const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
 #define CHUB_PACKED(TAPE_, RESET_, BIG_) \
-    CHUB_LAUNCH((k_slot_packed<kSlotBlock, kSlotsPerLane, TAPE_, RESET_, BIG_>), dim3(nb), dim3(kSlotBlock), stream, ev0, ev1, ctx, sa, pa)
+    CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, TAPE_, RESET_, BIG_>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa)
             const bool big = hp.S[0] > 64 || hp.S[1] > 64;
             if (reset) {
                 if (big) CHUB_PACKED(false, true, true);

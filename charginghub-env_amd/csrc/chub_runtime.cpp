@@ -78,6 +78,7 @@ struct chub_env {
     float *h_actions, *h_packed;  // pinned: [N][A], [N][D+2]
     float *d_packed;              // [N][D+2]
     int tape_classes;   // PHILOX tape mode: caller-registered arrival-SoC classes so far
+    uint32_t h_late8[8];
     std::vector<float> h_cls[2], h_soc0[2], h_ttab[2];  // host copies of the class tables (introspection)
     uint32_t *d_tick_base;     // see HubParams::tick_base
     uint32_t graph_base;       // host mirror of *d_tick_base: ticks covered by the graph replays so far
@@ -276,6 +277,7 @@ static PackedPtrs packed_ptrs(const chub_env *e) {
     p.ttab[0] = e->tb.ttab[0];
     p.ttab[1] = e->tb.ttab[1];
     p.ttab2 = e->tb.ttab2;
+    memcpy(p.late8, e->h_late8, sizeof p.late8);
     p.pk[0] = (uint64_t *) e->st.pk[0];
     p.pk[1] = (uint64_t *) e->st.pk[1];
     return p;
@@ -618,7 +620,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->graph_base = 0;
     // packed slot kernel (k_slot_packed): the workgroup's virtual lanes laid over whole envs end to end
     {
-        const int pb = kSlotBlock * kSlotsPerLane, St = hp.S[0] + hp.S[1];
+        const int pb = kPackedBlock * kSlotsPerLane, St = hp.S[0] + hp.S[1];
         hp.epb = pb / St > 0 ? pb / St : 1;
         bool magic_ok = true;  // the kernel divides lane numbers by S0 + S1 with a 20-bit reciprocal
         for (int l = 0; l < pb && magic_ok; l++)
@@ -645,6 +647,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if ((rc = dev_upload(e, &e->tb.hy_table, hy_v))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.soc_d_icdf, icdf))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.late_thr, late_thr))) return bail(rc);
+    memcpy(e->h_late8, late_thr.data(), sizeof e->h_late8);
     if ((rc = dev_upload(e, &e->tb.normal_icdf, nicdf))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.normal_tail, ntail))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.sin96, sin96))) return bail(rc);

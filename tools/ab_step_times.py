@@ -24,5 +24,7 @@ for i in range(1920):
     v.step_device_packed(acts[i%4].ptr, packed.ptr)
 a, b, k = v.profile_end()
 dt = time.perf_counter() - t0
-print(os.environ.get("CHUB_LIB","")[-12:], "slot_us %.2f env_us %.2f step_us %.2f" % (a/k*1e3, b/k*1e3, dt/1920*1e6))
+import numpy as np
+chk = float(packed.to_host(np.float32, (n, 15)).astype(np.float64).sum())  # same seeds, same result whatever the build
+print(os.environ.get("CHUB_LIB","")[-12:], "slot_us %.2f env_us %.2f step_us %.2f  checksum %.6f" % (a/k*1e3, b/k*1e3, dt/1920*1e6, chk))
 v.close()
