@@ -209,6 +209,14 @@ struct StepArgs {
     // tape mode (PHILOX, packed kernel): the step's station-level draws and the per-admission variates come from the caller
     const uint64_t *pk_tape;   // [2N] packed station draws of this step (layout of StationArrays::pk), or null
     const uint32_t *car_tape;  // [NS][2] per slot: arrival-SoC class, target level | extra stay << 16, or null
+    // per-env clocks (chub_reset_envs / chub_step_envs): the launch touches only the envs of one clock group
+    const uint16_t *env_group; // [N] clock group of every env, or null: every env (one clock for all)
+    uint32_t group;
+    // The state-independent draws of a PHILOX step (station levels, OU normals, FCEV arrival) are normally made one launch
+    // ahead by the previous launch's level blocks.  fresh: this launch makes its own (k_draw_levels in front of the slot
+    // kernel, the tail draws inline) and leaves none for the next -- same Philox counters, same values; used whenever the
+    // previous launch was not this clock's previous step (per-env clocks, the first lock-step launch after them).
+    int32_t fresh;
 };
 
 }  // namespace chub

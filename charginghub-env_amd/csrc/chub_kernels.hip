@@ -28,6 +28,11 @@ namespace chub {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// Per-env clocks: a launch carries ONE clock (StepArgs::t / tick) and touches the envs of that clock's group only.
+__device__ __forceinline__ bool in_group(const StepArgs &sa, int64_t env) {
+    return !sa.env_group || (uint32_t) sa.env_group[env] == sa.group;
+}
+
 // ------------------------------------------------------------------------------------------ Philox
 struct U4 {
     uint32_t v[4];
@@ -620,7 +625,7 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     const int64_t N = hp.n_envs;
     const int env_first = (int) block_local * (WAVES * upw);
     const int env = env_first + wave * upw + uiw;
-    const bool unit_ok = env < (int) N;
+    const bool unit_ok = env < (int) N && in_group(sa, env);
     const bool valid = unit_ok && slot < S;
     const uint64_t unit_mask = (H == 64) ? ~0ull : (((1ull << H) - 1ull) << (uiw << logH));
     const int hub_slot = (k ? hp.S[0] : 0) + slot;
@@ -771,6 +776,8 @@ struct PackedArgs {
     uint32_t key[2], gid0, tick;     // Philox key, global id of env 0, host tick
     const uint32_t *tick_base;       // device-side tick offset (graph replays), added to tick
     uint32_t late[8];                // the first 8 thresholds of mk_late_time's table (late_from_word); beyond them with probability 0.3 %
+    CHUB_G(const uint16_t) env_group; // per-env clocks: this launch touches the envs of `group` only (null: every env)
+    uint32_t group;
 };
 
 typedef const uint32_t __attribute__((address_space(4))) *chub_sptr;  // constant address space: scalar loads
@@ -816,6 +823,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         slot[j] = hs - (k_[j] ? S0 : 0);
         const int env = env_first + e_[j];
         valid[j] = e_[j] < epb && env < N;
+        if (pa.env_group && valid[j]) valid[j] = (uint32_t) pa.env_group[env] == pa.group;
         sidx[j] = (uint32_t) (k_[j] ? N : 0) + (uint32_t) env;
         asm volatile("" : "=v"(s2[j]), "=v"(act[j]), "=v"(line_in[j]), "=v"(pk_in[j]));
         if (RESET) {
@@ -1042,6 +1050,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         const int e = i >> 1, k = i & 1;
         const int env = env_first + e;
         if (env >= N) continue;
+        if (pa.env_group && (uint32_t) pa.env_group[env] != pa.group) continue;
         const uint32_t su = (uint32_t) (k ? N : 0) + (uint32_t) env;
         uint32_t lf = s_unit[i];
         if ((k ? S1 : S0) == 0) {
@@ -1280,7 +1289,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             q_len = ta.q_len[e32];
             hv_line = ta.hv_line[e32];
         }
-        if (MODE == MODE_PHILOX && !RESET) {
+        if (MODE == MODE_PHILOX && !RESET && !sa.fresh) {
             // this step's state-independent env draws (three OU normals, FCEV arrival count) were made one launch ahead by
             // the level blocks of k_env (draw_env_levels): 350 dependent instructions less on this latency-bound chain
             drw_raw = ((CHUB_G(const u32x4)) ta.drw)[2u * e32];  // unpacked behind the table staging: no wait for it here
@@ -1315,7 +1324,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         }
         __syncthreads();
     }
-    if (MODE == MODE_PHILOX && !RESET) {
+    if (MODE == MODE_PHILOX && !RESET && !sa.fresh) {
         z_pv = (double) __uint_as_float(drw_raw.x);
         z_wd = (double) __uint_as_float(drw_raw.y);
         z_pr = (double) __uint_as_float(drw_raw.z);
@@ -1330,7 +1339,10 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         const int rows = (int) N - env0 < kEnvBlock ? (int) N - env0 : kEnvBlock;
         float *dst = sa.obs + (size_t) env0 * (size_t) row_w;
         const int total = rows * row_w;
-        if ((((uintptr_t) dst) & 15u) == 0) {  // 16 bytes per lane and store: a quarter of the store instructions
+        if (sa.env_group) {  // per-env clocks: only the rows of this launch's clock group
+            for (int i = threadIdx.x; i < total; i += kEnvBlock)
+                if ((uint32_t) sa.env_group[env0 + i / row_w] == sa.group) dst[i] = s_out[i];
+        } else if ((((uintptr_t) dst) & 15u) == 0) {  // 16 bytes per lane and store: a quarter of the store instructions
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const int quads = total >> 2;
             for (int i = threadIdx.x; i < quads; i += kEnvBlock) ((f32x4 *) dst)[i] = ((const f32x4 *) s_out)[i];
@@ -1398,7 +1410,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         if (MODE == MODE_COMPAT) hv_lev = rs.level();
         const int arrive = MODE == MODE_COMPAT ? (int) TAB_HV(hv_lev) : hv_arrive;
         double total_mass = 0.0;
-        const bool fcev_pre = MODE == MODE_PHILOX && !RESET;
+        const bool fcev_pre = MODE == MODE_PHILOX && !RESET && !sa.fresh;
         const double pre_tn = __hiloint2double((int) drw_fcev.y, (int) drw_fcev.x);
         const double pre_mn = __hiloint2double((int) drw_fcev.w, (int) drw_fcev.z);
         bool stuck = (hv_line & 128) != 0;
@@ -1675,8 +1687,10 @@ __device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, cons
     const int64_t N = hp.n_envs;
     if (u < 2 * N) {
         const int kk = u >= N ? 1 : 0;
+        if (!in_group(sa, u - (int64_t) kk * N)) return;
         ctx->st.pk[(sa.tick + 1u) & 1u][u] = draw_station_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick + 1u), t_next, kk, u - (int64_t) kk * N);
     } else if (u < 3 * N) {
+        if (!in_group(sa, u - 2 * N)) return;
         // the per-env draws (same Philox sites and counters the tail would use itself)
         const uint32_t e = (uint32_t) (u - 2 * N);
         const Tables &tb = ctx->tb;
@@ -1713,7 +1727,7 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
         return;
     }
     const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
-    env_tail<RESET, MODE>(ctx, sa, env, env < (int) ta.n_envs, s_pv, s_wd, s_hy, s_hv, s_out, (int) blockIdx.x, ta);
+    env_tail<RESET, MODE>(ctx, sa, env, env < (int) ta.n_envs && in_group(sa, env), s_pv, s_wd, s_hy, s_hv, s_out, (int) blockIdx.x, ta);
 }
 
 // COMPAT only: HySystem.__init__ (HYD:154-158) builds hy_power_speed_list with 101 REAL hy_step()s from the initial tank:
@@ -1887,7 +1901,7 @@ __global__ void k_replay_soc(const DevCtx *__restrict__ ctx, float *out) {
 // PHILOX reset: evs_reset's initial occupancy per (station, env) unit -- init_station_car_number(mu, 3) (CHS.hpp:832-842)
 // thinned by the balk test of an empty queue -- drawn once per unit here (every lane of the unit used to redo it),
 // handed to k_slot<RESET> through this tick's pk word: arrivals | arrivals that stay << 8.
-__global__ void k_reset_levels(const DevCtx *__restrict__ ctx, uint32_t tick) {
+__global__ void k_reset_levels(const DevCtx *__restrict__ ctx, uint32_t tick, const uint16_t *env_group, uint32_t group) {
     const HubParams &hp = ctx->hp;
     const Tables &tb = ctx->tb;
     const int64_t N = hp.n_envs;
@@ -1895,6 +1909,7 @@ __global__ void k_reset_levels(const DevCtx *__restrict__ ctx, uint32_t tick) {
     if (u >= 2 * N) return;
     const int k = u >= N ? 1 : 0;
     const int64_t env = u - (int64_t) k * N;
+    if (env_group && (uint32_t) env_group[env] != group) return;
     const int S = hp.S[k], mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
     PhiloxCtx px{hp.key[0], hp.key[1], CHUB_TICK(hp, tick), (uint32_t) (hp.env_id0 + env)};
     U4 b = px.block(SITE_ARRIVE, (uint32_t) k, 0);
@@ -1909,6 +1924,18 @@ __global__ void k_reset_levels(const DevCtx *__restrict__ ctx, uint32_t tick) {
         true_in += ((int) (pick(b, wi & 3) % 1000u) <= thr && j <= S) ? 1 : 0;
     }
     ctx->st.pk[tick & 1u][u] = (uint64_t) (((uint32_t) n_in & 0xFFFFu) | ((uint32_t) true_in << 16));  // n_in: signed 16 bits
+}
+
+// fresh launches (StepArgs::fresh): this step's station-level draws, made right in front of the slot kernel -- what the
+// previous launch's level blocks would have left in pk[tick & 1]
+__global__ void k_draw_levels(const DevCtx *__restrict__ ctx, StepArgs sa) {
+    const HubParams &hp = ctx->hp;
+    const int64_t N = hp.n_envs;
+    const int64_t u = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= 2 * N) return;
+    const int kk = u >= N ? 1 : 0;
+    if (!in_group(sa, u - (int64_t) kk * N)) return;
+    ctx->st.pk[sa.tick & 1u][u] = draw_station_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick), sa.t, kk, u - (int64_t) kk * N);
 }
 
 // ------------------------------------------------------------------------------------- launchers
@@ -1931,7 +1958,7 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
     constexpr int BLOCK = 256;
     const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
     if (MODE == MODE_PHILOX) {
-        if (RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa.tick);
+        if (RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa.tick, sa.env_group, sa.group);
         CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, ev1, ctx, sa, nb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
@@ -1944,9 +1971,13 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
 
 void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
                  const PackedPtrs &pp, hipEvent_t ev0, hipEvent_t ev1) {
+    if (hp.rng_mode == MODE_PHILOX && !reset && sa.fresh && !sa.pk_tape)
+        hipLaunchKernelGGL(k_draw_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
     if (hp.rng_mode == MODE_PHILOX) {
         if (hp.packed && !sa.load_mode) {
-            if (reset) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa.tick);
+            if (reset)
+                hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa.tick,
+                                   sa.env_group, sa.group);
             PackedArgs pa;
             for (int k = 0; k < 2; k++) {
                 pa.S[k] = (uint32_t) hp.S[k];
@@ -1969,6 +2000,8 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             pa.tick = sa.tick;
             pa.tick_base = hp.tick_base;
             for (int j = 0; j < 8; j++) pa.late[j] = pp.late8[j];
+            pa.env_group = (CHUB_G(const uint16_t)) sa.env_group;
+            pa.group = sa.group;
             const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
 #define CHUB_PACKED(TAPE_, RESET_, BIG_) \
     CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, TAPE_, RESET_, BIG_>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa)
@@ -1997,8 +2030,9 @@ void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepAr
     const TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa);
     const int nb_env = (int) ((hp.n_envs + kEnvBlock - 1) / kEnvBlock);
     if (hp.rng_mode == MODE_PHILOX) {
-        // + the level-draw workgroups: next step's state-independent variates (3 lanes per env: two stations, one env)
-        const unsigned nb = (unsigned) nb_env + (unsigned) ((3 * hp.n_envs + kEnvBlock - 1) / kEnvBlock);
+        // + the level-draw workgroups: next step's state-independent variates (3 lanes per env: two stations, one env);
+        // none behind a launch of one clock group (per-env clocks): its next launch makes its own (StepArgs::fresh)
+        const unsigned nb = (unsigned) nb_env + (sa.env_group ? 0u : (unsigned) ((3 * hp.n_envs + kEnvBlock - 1) / kEnvBlock));
         if (reset) CHUB_LAUNCH((k_env<true, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
         else CHUB_LAUNCH((k_env<false, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
     } else {

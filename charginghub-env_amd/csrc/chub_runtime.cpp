@@ -45,6 +45,13 @@ extern "C" __attribute__((visibility("hidden"))) int chub_set_last_error_(int co
             return fail(CHUB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
     } while (0)
 
+struct ClockGroup {
+    int32_t t, price_count;
+    int64_t members;
+    uint32_t last_tick;  // Philox tick of the group's last launch; 0: differs between its envs (chub_env::h_tick)
+};
+constexpr int kMaxGroups = 128;  // distinct clocks at one time (a day has 96 slots)
+
 struct chub_env {
     chub_config cfg;
     HubParams hp;
@@ -59,7 +66,15 @@ struct chub_env {
     // lock-step clock (MGR:137-140,299; CHS.hpp:1204; AGG:150-151; HYD:192-193 are three copies of it)
     int t;
     int price_count;
-    uint32_t tick;
+    uint32_t tick;             // Philox tick: +1 per launched reset / step (one per clock group and call)
+    // per-env clocks (chub_reset_envs / chub_step_envs): envs with the same (t, price_count) form a clock group; one launch
+    // per group and call.  groups empty = lock-step (the clock above holds for every env).
+    std::vector<ClockGroup> groups;
+    std::vector<uint16_t> h_group;  // [N] group of every env (host mirror of d_group; valid while groups is not empty)
+    uint16_t *d_group;              // [N], in the arena
+    std::vector<uint32_t> h_tick;   // [N] tick of every env's last launch (chub_env_clocks)
+    bool predrawn;                  // the last launch left the next step's state-independent draws (lock-step chain intact)
+    bool tick_uniform;              // lock-step: every env's last launch was the handle's last launch (else h_tick)
     double price[96];
     double hy_table[102];
     std::vector<void *> allocs;
@@ -84,6 +99,7 @@ struct chub_env {
     uint32_t graph_base;       // host mirror of *d_tick_base: ticks covered by the graph replays so far
     uint32_t graph_tick0;      // host state at chub_graph_begin (restored at chub_graph_end: a capture runs nothing)
     int graph_t0, graph_pc0;
+    bool graph_predrawn0;
     bool capturing;
     const uint64_t *tape_pk;   // set for the duration of chub_step_tape
     const uint32_t *tape_car;
@@ -342,6 +358,9 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->t = 0;
     e->price_count = 0;
     e->tick = 0;
+    e->d_group = nullptr;
+    e->predrawn = false;
+    e->tick_uniform = true;
     e->stream = nullptr;
     e->host_stream = nullptr;
     e->h_actions = e->h_packed = e->d_packed = nullptr;
@@ -702,6 +721,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         for (size_t i = 0; i < N; i++) memcpy(&rep[i * 102], e->hy_table, sizeof e->hy_table);
         HIP_TRY(hipMemcpy(e->ev.hy_env, rep.data(), rep.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    ALLOC(e->d_group, N);
     ALLOC(e->d_tick_base, 64);
     e->hp.tick_base = e->d_tick_base;
     ALLOC(e->d_ctx, 1);
@@ -753,7 +773,10 @@ int chub_destroy(chub_env *e) {
 int chub_obs_dim(const chub_env *e) { return e ? e->hp.obs_dim : CHUB_ERR_ARG; }
 int chub_act_dim(const chub_env *e) { return e ? e->hp.act_dim : CHUB_ERR_ARG; }
 int64_t chub_num_envs(const chub_env *e) { return e ? e->hp.n_envs : CHUB_ERR_ARG; }
-int chub_clock(const chub_env *e) { return e ? e->t : CHUB_ERR_ARG; }
+int chub_clock(const chub_env *e) {  // lock-step: the clock; per-env clocks: env 0's (chub_env_clocks has them all)
+    if (!e) return CHUB_ERR_ARG;
+    return e->groups.empty() ? e->t : e->groups[e->h_group[0]].t;
+}
 int chub_uses_packed_kernel(const chub_env *e) { return e ? e->hp.packed : CHUB_ERR_ARG; }
 
 int chub_sync(chub_env *e) {
@@ -763,33 +786,177 @@ int chub_sync(chub_env *e) {
     return CHUB_OK;
 }
 
-int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs, void *stream) {
-    if (!e || !d_obs) return fail(CHUB_ERR_ARG, "null argument");
-    if (e->hp.rng_mode == CHUB_RNG_COMPAT && (!d_exo_days || !d_exo_z))
-        return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_days and exo_z");
-    HIP_TRY(hipSetDevice(e->device));
-    (void) hipGetLastError();  // a stale error of an earlier, unrelated call must not be reported as this step's
-    hipStream_t s = (hipStream_t) stream;
+// ---- clocks -----------------------------------------------------------------------------------------------------------------
+// Every reference env owns its clock (MGR:137-140, 271-273, 299).  Here envs with the same clock form a group; lock-step
+// (the usual case: everybody reset and stepped together) is the handle's own clock and no group at all.  A call that names
+// a subset of the envs (chub_reset_envs / chub_step_envs) splits the groups along its mask; every call launches once per
+// clock it touches, each launch with its own Philox tick, and groups whose clocks coincide again are merged.
+static void flush_ticks(chub_env *e) {  // the groups' last ticks -> the per-env record (before labels change)
+    const size_t N = (size_t) e->hp.n_envs;
+    if (e->h_tick.size() != N) e->h_tick.assign(N, e->tick);
+    for (size_t i = 0; i < N && !e->groups.empty(); i++) {
+        const uint32_t lt = e->groups[e->h_group[i]].last_tick;
+        if (lt) e->h_tick[i] = lt;
+    }
+}
+
+// The clock groups one call has to launch, in ascending order (-1: every env, lock-step).  mask null = every env.  Splits
+// and merges groups as the mask requires and uploads the labels when they changed.
+static int groups_for_call(chub_env *e, const uint8_t *mask, hipStream_t s, std::vector<int> &launch) {
+    const size_t N = (size_t) e->hp.n_envs;
+    launch.clear();
+    size_t n_masked = N;
+    if (mask) {
+        n_masked = 0;
+        for (size_t i = 0; i < N; i++) n_masked += mask[i] ? 1 : 0;
+        if (n_masked == 0) return CHUB_OK;
+    }
+    if (e->groups.empty() && n_masked == N) {
+        launch.push_back(-1);
+        return CHUB_OK;
+    }
+    if (e->hp.rng_mode != CHUB_RNG_PHILOX)
+        return fail(CHUB_ERR_UNSUPPORTED, "per-env clocks need a PHILOX handle (the COMPAT streams are replayed in lock-step)");
+    if (e->capturing) return fail(CHUB_ERR_ARG, "a graph capture covers lock-step calls only");
+    if (e->tape_pk) return fail(CHUB_ERR_ARG, "tape mode runs in lock-step");
+    HIP_TRY(hipStreamSynchronize(s));  // the labels may change: no launch that reads them may still be in flight
+    bool relabel = false;
+    if (e->groups.empty()) {
+        flush_ticks(e);
+        e->groups.push_back(ClockGroup{e->t, e->price_count, (int64_t) N, e->tick_uniform ? e->tick : 0u});
+        e->h_group.assign(N, 0);
+        relabel = true;
+    }
+    // clocks that coincide again: one group
+    for (size_t a = 0; a < e->groups.size(); a++)
+        for (size_t b = a + 1; b < e->groups.size(); b++) {
+            ClockGroup &ga = e->groups[a], &gb = e->groups[b];
+            if (ga.members == 0 || gb.members == 0 || ga.t != gb.t || ga.price_count != gb.price_count) continue;
+            flush_ticks(e);
+            for (size_t i = 0; i < N; i++)
+                if (e->h_group[i] == (uint16_t) b) e->h_group[i] = (uint16_t) a;
+            ga.members += gb.members;
+            gb.members = 0;
+            if (ga.last_tick != gb.last_tick) ga.last_tick = 0;  // per env from here on (h_tick)
+            relabel = true;
+        }
+    if (mask && n_masked < N) {
+        const size_t G = e->groups.size();
+        std::vector<int64_t> in(G, 0);
+        for (size_t i = 0; i < N; i++)
+            if (mask[i]) in[e->h_group[i]]++;
+        std::vector<int> target(G, -1);
+        bool split = false;
+        for (size_t g = 0; g < G; g++) {
+            if (in[g] == 0) continue;
+            if (in[g] == e->groups[g].members) {
+                target[g] = (int) g;
+                continue;
+            }
+            size_t slot = 0;  // a free entry, or a new one
+            while (slot < e->groups.size() && e->groups[slot].members != 0) slot++;
+            if (slot == e->groups.size()) {
+                if ((int) slot >= kMaxGroups) return fail(CHUB_ERR_UNSUPPORTED, "more than 128 distinct env clocks at one time");
+                e->groups.push_back(ClockGroup{0, 0, 0, 0u});
+            }
+            ClockGroup ng = e->groups[g];
+            ng.members = in[g];
+            e->groups[g].members -= in[g];
+            e->groups[slot] = ng;
+            target[g] = (int) slot;
+            split = true;
+        }
+        if (split) {
+            for (size_t i = 0; i < N; i++)
+                if (mask[i]) e->h_group[i] = (uint16_t) target[e->h_group[i]];
+            relabel = true;
+        }
+        for (size_t g = 0; g < G; g++)
+            if (target[g] >= 0) launch.push_back(target[g]);
+        std::sort(launch.begin(), launch.end());
+    } else {
+        for (size_t g = 0; g < e->groups.size(); g++)
+            if (e->groups[g].members > 0) launch.push_back((int) g);
+    }
+    if (relabel) HIP_TRY(hipMemcpy(e->d_group, e->h_group.data(), N * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return CHUB_OK;
+}
+
+// after a call: back to lock-step when every env shows the same clock again (a reset of everybody, for one)
+static void collapse_groups(chub_env *e) {
+    if (e->groups.empty()) return;
+    const ClockGroup *first = nullptr;
+    for (const ClockGroup &g : e->groups) {
+        if (g.members == 0) continue;
+        if (!first) first = &g;
+        else if (g.t != first->t || g.price_count != first->price_count) return;
+    }
+    if (!first) return;
+    flush_ticks(e);
+    e->t = first->t;
+    e->price_count = first->price_count;
+    e->tick_uniform = false;  // the envs' last launches carried different ticks: chub_env_clocks reads the per-env record
+    e->groups.clear();
+}
+
+// one launched reset of ONE clock (group < 0: every env)
+static int run_reset(chub_env *e, int32_t &t, int32_t &pc, int group, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs,
+                     hipStream_t s) {
     e->tick += 1;
     StepArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.t = 0;
     sa.tick = e->tick - e->graph_base;
-    sa.draw_price = (e->price_count % 4 == 0) ? 1 : 0;
+    sa.draw_price = (pc % 4 == 0) ? 1 : 0;
     sa.station_filter = -1;
     sa.price_last = e->price[95];  // AGG:171: price = [] + mean_for_MAD; price[-1]
     sa.exo_days = d_exo_days;
     sa.exo_z = d_exo_z;
     sa.obs = d_obs;
     sa.obs_stride = e->hp.obs_dim;
+    if (group >= 0) {
+        sa.env_group = e->d_group;
+        sa.group = (uint32_t) group;
+    }
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
     launch_slot(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e), nullptr, nullptr);
     launch_env(true, e->hp, e->d_ctx, sa, s, nullptr, nullptr, packed_ptrs(e));
     HIP_TRY(hipGetLastError());
-    e->t = 0;
-    e->price_count = 0;  // MGR:313 (after make_state)
+    t = 0;
+    pc = 0;  // MGR:313 (after make_state)
+    e->predrawn = group < 0;
+    if (group < 0) e->tick_uniform = true;
+    else e->groups[(size_t) group].last_tick = e->tick;
     return CHUB_OK;
+}
+
+static int reset_masked(chub_env *e, const uint8_t *mask, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs, void *stream) {
+    if (!e || !d_obs) return fail(CHUB_ERR_ARG, "null argument");
+    if (e->hp.rng_mode == CHUB_RNG_COMPAT && (!d_exo_days || !d_exo_z))
+        return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_days and exo_z");
+    HIP_TRY(hipSetDevice(e->device));
+    (void) hipGetLastError();  // a stale error of an earlier, unrelated call must not be reported as this step's
+    hipStream_t s = (hipStream_t) stream;
+    std::vector<int> launch;
+    int rc = groups_for_call(e, mask, s, launch);
+    if (rc) return rc;
+    for (int g : launch) {
+        if (g < 0) rc = run_reset(e, e->t, e->price_count, -1, d_exo_days, d_exo_z, d_obs, s);
+        else rc = run_reset(e, e->groups[(size_t) g].t, e->groups[(size_t) g].price_count, g, d_exo_days, d_exo_z, d_obs, s);
+        if (rc) return rc;
+    }
+    collapse_groups(e);
+    return CHUB_OK;
+}
+
+int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs, void *stream) {
+    return reset_masked(e, nullptr, d_exo_days, d_exo_z, d_obs, stream);
+}
+
+int chub_reset_envs_device(chub_env *e, const uint8_t *mask, float *d_obs, void *stream) {
+    if (!mask) return fail(CHUB_ERR_ARG, "null argument");
+    return reset_masked(e, mask, nullptr, nullptr, d_obs, stream);
 }
 
 static int step_common(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, int obs_stride,
@@ -840,22 +1007,18 @@ int chub_step_load(chub_env *e, const float *actions, const double *exo_z, float
     return CHUB_OK;
 }
 
-static int step_common(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, int obs_stride,
-                       float *d_reward, int reward_stride, uint8_t *d_done, float *d_done_f32, void *stream,
-                       int load_mode) {
-    if (e->tick == 0) return fail(CHUB_ERR_ARG, "step() before reset()");
-    if (e->hp.rng_mode == CHUB_RNG_COMPAT && !d_exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
-    HIP_TRY(hipSetDevice(e->device));
-    (void) hipGetLastError();  // a stale error of an earlier, unrelated call must not be reported as this step's
-    hipStream_t s = (hipStream_t) stream;
+// one launched step of ONE clock (group < 0: every env)
+static int run_step(chub_env *e, int32_t &t, int32_t &pc, int group, const float *d_actions, const double *d_exo_z, float *d_obs,
+                    int obs_stride, float *d_reward, int reward_stride, uint8_t *d_done, float *d_done_f32, hipStream_t s,
+                    int load_mode) {
     e->tick += 1;
     StepArgs sa;
     memset(&sa, 0, sizeof sa);
-    sa.t = e->t;
+    sa.t = t;
     sa.tick = e->tick - e->graph_base;
-    sa.draw_price = (e->price_count % 4 == 0) ? 1 : 0;
+    sa.draw_price = (pc % 4 == 0) ? 1 : 0;
     sa.station_filter = -1;
-    sa.price_last = e->price[e->t];  // AGG:147
+    sa.price_last = e->price[t];  // AGG:147
     sa.actions = d_actions;
     sa.exo_z = d_exo_z;
     sa.obs = d_obs;
@@ -867,9 +1030,17 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
     sa.load_mode = load_mode;
     sa.pk_tape = e->tape_pk;
     sa.car_tape = e->tape_car;
+    if (group >= 0) {
+        sa.env_group = e->d_group;
+        sa.group = (uint32_t) group;
+    }
+    // the state-independent draws of this step: left by the previous launch if that was this clock's previous step (the
+    // lock-step chain), otherwise made by this launch itself
+    // (a graph's first step always makes its own: a replay must not depend on what ran before it)
+    sa.fresh = (group >= 0 || !e->predrawn || (e->capturing && e->tick == e->graph_tick0 + 1u)) ? 1 : 0;
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
-    bool prof = e->prof_on && e->prof_used < e->prof_cap;
+    bool prof = group < 0 && e->prof_on && e->prof_used < e->prof_cap;
     if (prof) {
         prof = (e->prof_phase % e->prof_every) == 0;  // sample: the event records are not free
         e->prof_phase++;
@@ -880,9 +1051,102 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
     launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
     if (prof) e->prof_used++;
     HIP_TRY(hipGetLastError());
-    e->price_count += 1;
-    e->t = (e->t + 1) % 96;
+    pc += 1;
+    t = (t + 1) % 96;
+    e->predrawn = group < 0;
+    if (group < 0) e->tick_uniform = true;
+    else e->groups[(size_t) group].last_tick = e->tick;
     return CHUB_OK;
+}
+
+static int step_masked(chub_env *e, const uint8_t *mask, const float *d_actions, const double *d_exo_z, float *d_obs, int obs_stride,
+                       float *d_reward, int reward_stride, uint8_t *d_done, float *d_done_f32, void *stream, int load_mode) {
+    if (e->tick == 0) return fail(CHUB_ERR_ARG, "step() before reset()");
+    if (e->hp.rng_mode == CHUB_RNG_COMPAT && !d_exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
+    HIP_TRY(hipSetDevice(e->device));
+    (void) hipGetLastError();  // a stale error of an earlier, unrelated call must not be reported as this step's
+    hipStream_t s = (hipStream_t) stream;
+    std::vector<int> launch;
+    int rc = groups_for_call(e, mask, s, launch);
+    if (rc) return rc;
+    for (int g : launch) {
+        int32_t &t = g < 0 ? e->t : e->groups[(size_t) g].t, &pc = g < 0 ? e->price_count : e->groups[(size_t) g].price_count;
+        rc = run_step(e, t, pc, g, d_actions, d_exo_z, d_obs, obs_stride, d_reward, reward_stride, d_done, d_done_f32, s, load_mode);
+        if (rc) return rc;
+    }
+    collapse_groups(e);
+    return CHUB_OK;
+}
+
+static int step_common(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, int obs_stride,
+                       float *d_reward, int reward_stride, uint8_t *d_done, float *d_done_f32, void *stream,
+                       int load_mode) {
+    return step_masked(e, nullptr, d_actions, d_exo_z, d_obs, obs_stride, d_reward, reward_stride, d_done, d_done_f32, stream, load_mode);
+}
+
+int chub_step_envs_device(chub_env *e, const uint8_t *mask, const float *d_actions, float *d_obs, float *d_reward, uint8_t *d_done,
+                          void *stream) {
+    if (!e || !mask || !d_actions || !d_obs || !d_reward || !d_done) return fail(CHUB_ERR_ARG, "null argument");
+    return step_masked(e, mask, d_actions, nullptr, d_obs, e->hp.obs_dim, d_reward, 1, d_done, nullptr, stream, 0);
+}
+
+// host-pointer forms: full-size arrays, only the rows of the named envs are read and written
+int chub_reset_envs(chub_env *e, const uint8_t *mask, float *obs) {
+    if (!e || !mask || !obs) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t N = (size_t) e->hp.n_envs, D = (size_t) e->hp.obs_dim;
+    int rc = chub_reset_envs_device(e, mask, e->d_obs, nullptr);
+    if (rc) return rc;
+    std::vector<float> o(N * D);
+    HIP_TRY(hipMemcpy(o.data(), e->d_obs, o.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++)
+        if (mask[i]) memcpy(obs + i * D, &o[i * D], D * sizeof(float));
+    return CHUB_OK;
+}
+
+int chub_step_envs(chub_env *e, const uint8_t *mask, const float *actions, float *obs, float *reward, uint8_t *done) {
+    if (!e || !mask || !actions || !obs || !reward || !done) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t N = (size_t) e->hp.n_envs, A = (size_t) e->hp.act_dim, D = (size_t) e->hp.obs_dim;
+    HIP_TRY(hipMemcpy(e->d_actions, actions, N * A * sizeof(float), hipMemcpyHostToDevice));
+    int rc = chub_step_envs_device(e, mask, e->d_actions, e->d_obs, e->d_reward, e->d_done, nullptr);
+    if (rc) return rc;
+    std::vector<float> o(N * D), r(N);
+    std::vector<uint8_t> d(N);
+    HIP_TRY(hipMemcpy(o.data(), e->d_obs, o.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(r.data(), e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(d.data(), e->d_done, N, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++)
+        if (mask[i]) {
+            memcpy(obs + i * D, &o[i * D], D * sizeof(float));
+            reward[i] = r[i];
+            done[i] = d[i];
+        }
+    return CHUB_OK;
+}
+
+// slot of day (and, if asked, the Philox tick of the last launch) of every env
+int chub_env_clocks(chub_env *e, int32_t *t_out, uint32_t *tick_out) {
+    if (!e || !t_out) return fail(CHUB_ERR_ARG, "null argument");
+    const size_t N = (size_t) e->hp.n_envs;
+    for (size_t i = 0; i < N; i++) {
+        if (e->groups.empty()) {
+            t_out[i] = e->t;
+            if (tick_out) tick_out[i] = e->tick_uniform ? e->tick : e->h_tick[i];
+        } else {
+            const ClockGroup &g = e->groups[e->h_group[i]];
+            t_out[i] = g.t;
+            if (tick_out) tick_out[i] = g.last_tick ? g.last_tick : e->h_tick[i];
+        }
+    }
+    return CHUB_OK;
+}
+
+int chub_clock_groups(const chub_env *e) {
+    if (!e) return CHUB_ERR_ARG;
+    int n = 0;
+    for (const ClockGroup &g : e->groups) n += g.members > 0 ? 1 : 0;
+    return e->groups.empty() ? 1 : n;
 }
 
 int chub_reset(chub_env *e, const int32_t *exo_days, const double *exo_z, float *obs) {
@@ -961,6 +1225,7 @@ int chub_graph_begin(chub_env *e, void *stream) {
     if (e->capturing) return fail(CHUB_ERR_ARG, "a capture is already in progress on this handle");
     if (e->hp.rng_mode != CHUB_RNG_PHILOX) return fail(CHUB_ERR_ARG, "graphs replay PHILOX steps (COMPAT takes host draws every step)");
     if (e->prof_on) return fail(CHUB_ERR_ARG, "per-kernel profiling is on");
+    if (!e->groups.empty()) return fail(CHUB_ERR_ARG, "graphs cover lock-step calls: the envs of this handle run on different clocks");
     HIP_TRY(hipSetDevice(e->device));
     int rc = sync_ctx(e, (hipStream_t) stream);
     if (rc) return rc;
@@ -969,6 +1234,7 @@ int chub_graph_begin(chub_env *e, void *stream) {
     e->graph_tick0 = e->tick;
     e->graph_t0 = e->t;
     e->graph_pc0 = e->price_count;
+    e->graph_predrawn0 = e->predrawn;
     return CHUB_OK;
 }
 
@@ -983,6 +1249,7 @@ int chub_graph_end(chub_env *e, void *stream, chub_graph **out) {
     e->tick = e->graph_tick0;
     e->t = e->graph_t0;
     e->price_count = e->graph_pc0;
+    e->predrawn = e->graph_predrawn0;
     // every replay moves the Philox tick base on by the ticks the graph covers (its last node)
     launch_tick_advance(e->d_tick_base, ticks, (hipStream_t) stream);
     hipGraph_t g = nullptr;
@@ -1012,6 +1279,7 @@ int chub_graph_end(chub_env *e, void *stream, chub_graph **out) {
 
 int chub_graph_launch(chub_graph *g, void *stream) {
     if (!g) return fail(CHUB_ERR_ARG, "null graph");
+    if (!g->env->groups.empty()) return fail(CHUB_ERR_ARG, "graphs replay lock-step calls: the envs of this handle run on different clocks");
     HIP_TRY(hipSetDevice(g->device));
     HIP_TRY(hipGraphLaunch(g->exec, (hipStream_t) stream));
     // the replay covers g->ticks resets + steps: its last node moves the device-side tick base on, the host mirrors it, so that
@@ -1021,6 +1289,8 @@ int chub_graph_launch(chub_graph *g, void *stream) {
     e->graph_base += g->ticks;
     e->t = g->t_end;
     e->price_count = g->pc_end;
+    e->predrawn = true;
+    e->tick_uniform = true;
     return CHUB_OK;
 }
 
@@ -1488,13 +1758,19 @@ struct SnapshotHeader {
     uint32_t tick, graph_base;
     uint64_t arena_used;
     double hy_table[102];
+    // per-env clocks: the group table (the labels are in the arena); the blob ends with every env's last tick
+    int32_t predrawn, n_groups;
+    struct {
+        int32_t t, price_count;
+        int64_t members;
+    } groups[kMaxGroups];
 };
 static const uint64_t kSnapMagic = 0x43485542534e4150ull;  // "CHUBSNAP"
 
 int64_t chub_state_size(const chub_env *e) {
     if (!e) return fail(CHUB_ERR_ARG, "null handle");
     if (!e->arena) return fail(CHUB_ERR_UNSUPPORTED, "snapshot needs the single-arena allocation (CHUB_NO_ARENA is set)");
-    return (int64_t) (sizeof(SnapshotHeader) + e->arena_used);
+    return (int64_t) (sizeof(SnapshotHeader) + e->arena_used + (size_t) e->hp.n_envs * sizeof(uint32_t));
 }
 
 int chub_get_state(chub_env *e, void *buf, int64_t size) {
@@ -1517,8 +1793,23 @@ int chub_get_state(chub_env *e, void *buf, int64_t size) {
     h.graph_base = e->graph_base;
     h.arena_used = e->arena_used;
     memcpy(h.hy_table, e->hy_table, sizeof h.hy_table);
+    h.predrawn = e->predrawn ? 1 : 0;
+    h.n_groups = (int32_t) e->groups.size();
+    for (size_t g = 0; g < e->groups.size(); g++) {
+        h.groups[g].t = e->groups[g].t;
+        h.groups[g].price_count = e->groups[g].price_count;
+        h.groups[g].members = e->groups[g].members;
+    }
     memcpy(buf, &h, sizeof h);
     HIP_TRY(hipMemcpy((char *) buf + sizeof h, e->arena, e->arena_used, hipMemcpyDeviceToHost));
+    {
+        const size_t N = (size_t) e->hp.n_envs;
+        std::vector<int32_t> t(N);
+        std::vector<uint32_t> tk(N);
+        int rc = chub_env_clocks(e, t.data(), tk.data());
+        if (rc) return rc;
+        memcpy((char *) buf + sizeof h + e->arena_used, tk.data(), N * sizeof(uint32_t));
+    }
     return CHUB_OK;
 }
 
@@ -1544,6 +1835,23 @@ int chub_set_state(chub_env *e, const void *buf, int64_t size) {
     e->graph_base = h.graph_base;
     memcpy(e->hy_table, h.hy_table, sizeof h.hy_table);
     e->ctx_dirty = true;
+    {
+        const size_t N = (size_t) e->hp.n_envs;
+        if (h.n_groups < 0 || h.n_groups > kMaxGroups) return fail(CHUB_ERR_ARG, "snapshot: bad clock-group table");
+        e->predrawn = h.predrawn != 0;
+        e->groups.clear();
+        for (int g = 0; g < h.n_groups; g++)
+            e->groups.push_back(ClockGroup{h.groups[g].t, h.groups[g].price_count, h.groups[g].members, 0u});
+        e->h_tick.resize(N);
+        memcpy(e->h_tick.data(), (const char *) buf + sizeof h + e->arena_used, N * sizeof(uint32_t));
+        e->tick_uniform = false;  // per env, from the blob
+        if (!e->groups.empty()) {
+            e->h_group.resize(N);
+            HIP_TRY(hipMemcpy(e->h_group.data(), e->d_group, N * sizeof(uint16_t), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < N; i++)
+                if (e->h_group[i] >= e->groups.size()) return fail(CHUB_ERR_ARG, "snapshot: clock-group label out of range");
+        }
+    }
     return CHUB_OK;
 }
 

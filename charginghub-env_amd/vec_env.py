@@ -150,6 +150,42 @@ class VecChargingHub(object):
         check(self._lib.chub_step_tape(self._h, _ptr(a), _ptr(pk), _ptr(ct), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
         return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
 
+    # ---- per-env clocks (every reference env owns its clock, MGR:137-140, 304-316): reset / step a subset of the envs
+    def _mask(self, mask):
+        m = np.ascontiguousarray(np.asarray(mask).astype(bool), dtype=np.uint8)
+        if m.shape != (self.n_envs,):
+            raise AssertionError("mask must have shape (%d,)" % self.n_envs)
+        return m
+
+    def reset_envs(self, mask):
+        """reset the envs of `mask`; returns the current observation of every env ([N, D]: fresh rows for the envs of the
+        mask, the others as their last call left them)"""
+        m = self._mask(mask)
+        check(self._lib.chub_reset_envs(self._h, _ptr(m), _ptr(self._obs)))
+        return self._obs.copy()
+
+    def step_envs(self, mask, actions):
+        """step the envs of `mask` only ([N, A] actions, the other rows are ignored); returns full-size obs, reward, done with
+        the rows of the other envs as their last call left them"""
+        m = self._mask(mask)
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        if a.shape != (self.n_envs, self.act_dim):  # MGR:148
+            raise AssertionError("actions must have shape (%d, %d)" % (self.n_envs, self.act_dim))
+        check(self._lib.chub_step_envs(self._h, _ptr(m), _ptr(a), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
+        return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
+
+    def env_clocks(self, ticks=False):
+        """slot of day of every env (and, with ticks=True, the Philox tick of every env's last launch)"""
+        t = np.zeros(self.n_envs, dtype=np.int32)
+        tk = np.zeros(self.n_envs, dtype=np.uint32)
+        check(self._lib.chub_env_clocks(self._h, _ptr(t), _ptr(tk)))
+        return (t, tk) if ticks else t
+
+    @property
+    def clock_groups(self):
+        """number of distinct env clocks right now (1 = lock-step)"""
+        return self._lib.chub_clock_groups(self._h)
+
     # ---- device-pointer path (ints are raw device addresses, e.g. torch.Tensor.data_ptr())
     def reset_device(self, d_obs, d_exo_days=0, d_exo_z=0, stream=0):
         check(self._lib.chub_reset_device(self._h, d_exo_days or None, d_exo_z or None, d_obs, stream or None))

@@ -291,18 +291,23 @@ class TorchHubVecEnv(object):
 class StaggeredHub(object):
     """Non-lock-step episodes: G groups of envs whose days are offset against each other by 96/G slots.
 
-    The N envs of one VecChargingHub share one clock, so all N episodes end in the same step -- convenient for the
-    kernels, but a learner then sees every env at the same time of day.  This front splits the env range into G
-    contiguous groups (one hub each, global env ids and therefore Philox streams unchanged: group g covers
-    ``[g*N/G, (g+1)*N/G)``), and keeps group g ``g * 96 // G`` slots ahead: ``reset()`` resets all groups and then walks
-    group g through its head start with the all-on action (the reference's ``step(None)``, MGR:146-147).  ``step()`` steps
-    every group, and a group whose day has ended (its own ``done``) is reset on the spot (``autoreset=True``): the
-    returned observation rows of that group are the first of its next episode, ``info['terminal_observation']`` keeps
-    the last ones and ``info['reset_groups']`` lists the groups reset in this step.
+    The N envs of a VecChargingHub that is only ever reset and stepped as a whole share one clock, so all N episodes end
+    in the same step -- convenient for the kernels, but a learner then sees every env at the same time of day.  This front
+    splits the env range into G contiguous groups (global env ids unchanged: group g covers ``[g*N/G, (g+1)*N/G)``) and keeps
+    group g ``g * 96 // G`` slots ahead: ``reset()`` resets all groups and then walks group g through its head start with
+    the all-on action (the reference's ``step(None)``, MGR:146-147).  ``step()`` steps every group, and a group whose day
+    has ended (its own ``done``) is reset on the spot (``autoreset=True``): the returned observation rows of that group are
+    the first of its next episode, ``info['terminal_observation']`` keeps the last ones and ``info['reset_groups']`` lists
+    the groups reset in this step.
+
+    Two forms.  The default keeps one hub per group: every group is bit-identical to a plain hub over the same global env
+    range given the same head start.  ``one_handle=True`` runs all N envs in ONE hub with per-env clocks
+    (``reset_envs`` / ``step_envs``, include/chub.h): one allocation, one launch per clock and call; its Philox ticks count
+    the handle's launches, so its random streams differ from the per-group form's (same distribution).
     """
 
     def __init__(self, n_envs, groups, station_list, station_type_list, seed=0, env_id0=0, autoreset=True,
-                 hub_factory=None, **hub_kwargs):
+                 hub_factory=None, one_handle=False, **hub_kwargs):
         groups = int(groups)
         if groups < 1 or n_envs % groups:
             raise ValueError("n_envs must split evenly over the groups")
@@ -311,8 +316,13 @@ class StaggeredHub(object):
         make = hub_factory or VecChargingHub
         self.n_envs, self.groups, self.per = int(n_envs), groups, int(n_envs) // groups
         self.offsets = [g * 96 // groups for g in range(groups)]
-        self.hubs = [make(self.per, station_list, station_type_list, seed=seed, env_id0=env_id0 + g * self.per,
-                          **hub_kwargs) for g in range(groups)]
+        self.hub = None
+        if one_handle:
+            self.hub = make(self.n_envs, station_list, station_type_list, seed=seed, env_id0=env_id0, **hub_kwargs)
+            self.hubs = [self.hub]
+        else:
+            self.hubs = [make(self.per, station_list, station_type_list, seed=seed, env_id0=env_id0 + g * self.per,
+                              **hub_kwargs) for g in range(groups)]
         self.obs_dim, self.act_dim = self.hubs[0].obs_dim, self.hubs[0].act_dim
         self.piles, self.n_slots = self.hubs[0].piles, self.act_dim - 2
         self.autoreset = bool(autoreset)
@@ -320,12 +330,27 @@ class StaggeredHub(object):
     def _rows(self, g):
         return slice(g * self.per, (g + 1) * self.per)
 
+    def _mask(self, gs):
+        m = np.zeros(self.n_envs, dtype=bool)
+        for g in gs:
+            m[self._rows(g)] = True
+        return m
+
     @property
     def clocks(self):
         """slot of day of every group"""
+        if self.hub is not None:
+            return [int(t) for t in self.hub.env_clocks()[::self.per]]
         return [h.clock for h in self.hubs]
 
     def reset(self):
+        if self.hub is not None:
+            head = np.zeros((self.n_envs, self.act_dim), dtype=np.float32)
+            head[:, :self.n_slots] = 1.0  # step(None): every pile on, fuel cell and electrolyser at 0 (MGR:146-147, 384-404)
+            obs = self.hub.reset()
+            for k in range(1, max(self.offsets) + 1):  # the k-th head-start step: every group that is at least k slots ahead
+                obs = self.hub.step_envs(self._mask([g for g in range(self.groups) if self.offsets[g] >= k]), head)[0]
+            return obs
         obs = np.zeros((self.n_envs, self.obs_dim), dtype=np.float32)
         head = np.zeros((self.per, self.act_dim), dtype=np.float32)
         head[:, :self.n_slots] = 1.0  # step(None): every pile on, fuel cell and electrolyser at 0 (MGR:146-147, 384-404)
@@ -340,10 +365,20 @@ class StaggeredHub(object):
         a = np.ascontiguousarray(actions, dtype=np.float32)
         if a.shape != (self.n_envs, self.act_dim):  # MGR:148
             raise AssertionError("actions must have shape (%d, %d)" % (self.n_envs, self.act_dim))
+        info = {}
+        if self.hub is not None:
+            obs, reward, done, _ = self.hub.step(a)
+            ended = [g for g in range(self.groups) if done[self._rows(g)].all()]
+            if ended and self.autoreset:
+                info["terminal_observation"] = np.zeros_like(obs)
+                m = self._mask(ended)
+                info["terminal_observation"][m] = obs[m]
+                info["reset_groups"] = ended
+                obs = self.hub.reset_envs(m)
+            return obs, reward, done, info
         obs = np.zeros((self.n_envs, self.obs_dim), dtype=np.float32)
         reward = np.zeros(self.n_envs, dtype=np.float32)
         done = np.zeros(self.n_envs, dtype=bool)
-        info = {}
         for g, h in enumerate(self.hubs):
             rows = self._rows(g)
             o, r, d, _ = h.step(a[rows])

@@ -98,7 +98,7 @@ int chub_destroy(chub_env *env);
 int chub_obs_dim(const chub_env *env);  /* 2 + 4*(#stations with piles>0) + 3 (MGR:74-104) */
 int chub_act_dim(const chub_env *env);  /* S + 2 (MGR:108-113) */
 int64_t chub_num_envs(const chub_env *env);
-int chub_clock(const chub_env *env);    /* 0..95, shared by all envs (lock-step) */
+int chub_clock(const chub_env *env);    /* 0..95: the slot of day, shared by all envs while they run in lock-step (env 0's otherwise) */
 int chub_uses_packed_kernel(const chub_env *env); /* 1: PHILOX steps of this handle run k_slot_packed (the production kernel) */
 
 /* ---- hot path ------------------------------------------------------------------------------
@@ -121,6 +121,23 @@ int chub_host_actions(chub_env *env, float **out);
 int chub_reset_device(chub_env *env, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs, void *stream);
 int chub_step_device(chub_env *env, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
                      uint8_t *d_done, void *stream);
+
+/* Per-env clocks.  Every reference env is its own object with its own clock: any one of them can be reset, or stepped,
+ * while the others are not (MGR:137-140, 271-273, 299, 304-316).  These entry points take a host array mask[n_envs]
+ * (non-zero = the env takes part) next to full-size [n_envs, ...] arrays of which only the rows of the named envs are
+ * read and written.  PHILOX handles.  Envs that show the same slot of day and the same number of steps since their
+ * reset share a clock group; a call launches once per group it touches (each launch with its own Philox tick, in
+ * ascending group order), so lock-step use -- chub_reset / chub_step on everybody -- is the one-group special case and
+ * costs what it did.  chub_reset of everybody brings all envs back onto one clock.  At most 128 distinct clocks at one
+ * time.  chub_env_clocks: slot of day of every env and (tick_out may be NULL) the Philox tick of its last launch;
+ * chub_clock_groups: number of distinct clocks right now. */
+int chub_reset_envs(chub_env *env, const uint8_t *mask, float *obs);
+int chub_step_envs(chub_env *env, const uint8_t *mask, const float *actions, float *obs, float *reward, uint8_t *done);
+int chub_reset_envs_device(chub_env *env, const uint8_t *mask /* host */, float *d_obs, void *stream);
+int chub_step_envs_device(chub_env *env, const uint8_t *mask /* host */, const float *d_actions, float *d_obs, float *d_reward,
+                          uint8_t *d_done, void *stream);
+int chub_env_clocks(chub_env *env, int32_t *t_out, uint32_t *tick_out);
+int chub_clock_groups(const chub_env *env);
 
 /* Scalar-load control mode: replaces EvcsspManagerEnv-level use of Fast/SlowChargeStation.evs_step(float)
  * (CHS.hpp:1169-1186 / 1480-1497, bound at main.cpp:196-197,248-249): one kW target per station instead of one bit per
