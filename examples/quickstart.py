@@ -49,6 +49,13 @@ def batched_host(n=4096):
     dt = time.perf_counter() - t0
     print("2. %d envs through numpy: %.1f M env-steps/s, mean reward %.4f, all done: %s"
           % (n, n * 96 / dt / 1e6, reward.mean(), bool(done.all())))
+    # every reference env owns its clock: any subset can start a new day (or move) on its own
+    obs = hub.reset()
+    for t in range(30):
+        obs, reward, done, _ = hub.step(rs.uniform(-1, 1, (n, hub.act_dim)).astype(np.float32))
+    obs = hub.reset_envs(np.arange(n) % 2 == 0)              # half of the envs abandon their day
+    obs, reward, done, _ = hub.step(rs.uniform(-1, 1, (n, hub.act_dim)).astype(np.float32))
+    print("   per-env clocks: slots of day now %s (%d clocks)" % (sorted(set(hub.env_clocks().tolist())), hub.clock_groups))
     hub.close()
 
 
