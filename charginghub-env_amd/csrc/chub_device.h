@@ -209,13 +209,15 @@ struct StepArgs {
     // tape mode (PHILOX, packed kernel): the step's station-level draws and the per-admission variates come from the caller
     const uint64_t *pk_tape;   // [2N] packed station draws of this step (layout of StationArrays::pk), or null
     const uint32_t *car_tape;  // [NS][2] per slot: arrival-SoC class, target level | extra stay << 16, or null
-    // per-env clocks (chub_reset_envs / chub_step_envs): the launch touches only the envs of one clock group
-    const uint16_t *env_group; // [N] clock group of every env, or null: every env (one clock for all)
-    uint32_t group;
+    // per-env clocks (chub_reset_envs / chub_step_envs): the clock is per-env state, [2][N] u16 (bits 0-6 slot of day, bits 8-9
+    // price_count & 3): a launch reads [tick & 1] and writes [(tick + 1) & 1] for EVERY env (the envs it does not serve keep
+    // theirs).  null: lock-step, the one clock above holds for every env.
+    uint16_t *env_clk;
+    const uint8_t *env_mask;   // [N] non-zero = the launch serves this env; null: every env
     // The state-independent draws of a PHILOX step (station levels, OU normals, FCEV arrival) are normally made one launch
     // ahead by the previous launch's level blocks.  fresh: this launch makes its own (k_draw_levels in front of the slot
     // kernel, the tail draws inline) and leaves none for the next -- same Philox counters, same values; used whenever the
-    // previous launch was not this clock's previous step (per-env clocks, the first lock-step launch after them).
+    // previous launch was not the previous step of every env it serves (per-env clocks, the first lock-step launch after them).
     int32_t fresh;
 };
 

@@ -28,9 +28,15 @@ namespace chub {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-// Per-env clocks: a launch carries ONE clock (StepArgs::t / tick) and touches the envs of that clock's group only.
-__device__ __forceinline__ bool in_group(const StepArgs &sa, int64_t env) {
-    return !sa.env_group || (uint32_t) sa.env_group[env] == sa.group;
+// Per-env clocks: the envs a launch serves (StepArgs::env_mask) and the clock each env is on (StepArgs::env_clk, double-
+// buffered by tick parity; lock-step: every env, the clock in StepArgs itself)
+__device__ __forceinline__ bool in_group(const StepArgs &sa, int64_t env) { return !sa.env_mask || sa.env_mask[env] != 0; }
+__device__ __forceinline__ uint32_t env_clk(const StepArgs &sa, int64_t n_envs, int64_t env) {
+    return sa.env_clk[(int64_t) (sa.tick & 1u) * n_envs + env];
+}
+__device__ __forceinline__ int clk_t(uint32_t c) { return (int) (c & 127u); }
+__device__ __forceinline__ uint32_t clk_next(uint32_t c) {  // one step later: slot of day + 1 (mod 96), price_count + 1 (mod 4)
+    return (uint32_t) ((clk_t(c) + 1) % 96) | ((((c >> 8) + 1u) & 3u) << 8);
 }
 
 // ------------------------------------------------------------------------------------------ Philox
@@ -776,8 +782,7 @@ struct PackedArgs {
     uint32_t key[2], gid0, tick;     // Philox key, global id of env 0, host tick
     const uint32_t *tick_base;       // device-side tick offset (graph replays), added to tick
     uint32_t late[8];                // the first 8 thresholds of mk_late_time's table (late_from_word); beyond them with probability 0.3 %
-    CHUB_G(const uint16_t) env_group; // per-env clocks: this launch touches the envs of `group` only (null: every env)
-    uint32_t group;
+    CHUB_G(const uint8_t) env_mask;  // per-env clocks: non-zero = the launch serves this env (null: every env)
 };
 
 typedef const uint32_t __attribute__((address_space(4))) *chub_sptr;  // constant address space: scalar loads
@@ -823,7 +828,8 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         slot[j] = hs - (k_[j] ? S0 : 0);
         const int env = env_first + e_[j];
         valid[j] = e_[j] < epb && env < N;
-        if (pa.env_group && valid[j]) valid[j] = (uint32_t) pa.env_group[env] == pa.group;
+        uint32_t served = 1u;  // per-env clocks: is the env served by this launch?  Requested with the state, looked at after it
+        if (pa.env_mask && valid[j]) served = pa.env_mask[env];
         sidx[j] = (uint32_t) (k_[j] ? N : 0) + (uint32_t) env;
         asm volatile("" : "=v"(s2[j]), "=v"(act[j]), "=v"(line_in[j]), "=v"(pk_in[j]));
         if (RESET) {
@@ -839,6 +845,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
             }
             pk_in[j] = CHUB_AT(const uint64_t, pa.pk, sidx[j] << 3);
         }
+        if (pa.env_mask && valid[j]) valid[j] = served != 0u;
     }
     if (!TAPE) {  // the new cars' Philox inputs: scalar registers from here on, requested behind the first loads
         pa.tick += sload_u32(pa.tick_base, 0);  // CHUB_TICK
@@ -1050,7 +1057,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         const int e = i >> 1, k = i & 1;
         const int env = env_first + e;
         if (env >= N) continue;
-        if (pa.env_group && (uint32_t) pa.env_group[env] != pa.group) continue;
+        if (pa.env_mask && pa.env_mask[env] == 0) continue;
         const uint32_t su = (uint32_t) (k ? N : 0) + (uint32_t) env;
         uint32_t lf = s_unit[i];
         if ((k ? S1 : S0) == 0) {
@@ -1226,7 +1233,7 @@ constexpr int kEnvBlock = 256;  // compile-time (reading blockDim.x fetches the 
 
 // ---- the per-env tail of step() / reset() for one env per lane: the body of k_env (tables staged in LDS between the
 // load burst and the arithmetic).
-template <bool RESET, int MODE>
+template <bool RESET, int MODE, bool MULTI>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
                                          float *s_out, const int env_block, const TailArgs &ta) {
@@ -1235,9 +1242,18 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     const CompatRng &cr = ctx->cr;
     const Tables &tb = ctx->tb;
     const int64_t N = hp.n_envs;
-    const int t_next = RESET ? 0 : (sa.t + 1) % 96;
-#define TAB_PV(d) (s_pv[d])
-#define TAB_WD(d) (s_wd[d])
+    // the clock of this lane's env: the launch's (lock-step), or its group's (per-env clocks: table rows then come straight
+    // from global memory instead of the LDS copy of "the" slot of the day)
+    constexpr bool multi = MULTI;  // its own instantiation: the lock-step kernel carries none of this
+    const uint32_t my_clk = (multi && env < (int) N) ? env_clk(sa, N, env) : 0u;
+    if (multi && env < (int) N)  // every env's clock moves to the other buffer: one step on, back to 0, or as it is
+        sa.env_clk[(int64_t) ((sa.tick + 1u) & 1u) * N + env] = (uint16_t) (!live ? my_clk : (RESET ? 0u : clk_next(my_clk)));
+    const int t_now = multi ? clk_t(my_clk) : sa.t;
+    const int t_next = RESET ? 0 : (t_now + 1) % 96;
+    const bool draw_price = multi ? ((my_clk >> 8) & 3u) == 0u : sa.draw_price != 0;
+    const double price_last = multi ? tb.price[RESET ? 95 : t_now] : sa.price_last;
+#define TAB_PV(d) (multi ? tb.pvT[t_next * 100 + (d)] : s_pv[d])
+#define TAB_WD(d) (multi ? tb.wdT[t_next * 150 + (d)] : s_wd[d])
 #define TAB_HY(i) (MODE == MODE_COMPAT ? hy_env[i] : s_hy[i])
 #define TAB_HV(l) (s_hv[l])
     // ---- prefetch: every per-env input is requested before the table staging and its barrier, and the PHILOX
@@ -1253,8 +1269,9 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     const bool tel_on = hp.telemetry != 0;
     {
         const int i = threadIdx.x;
-        if (i < 100) st_pv = tb.pvT[t_next * 100 + i];
-        if (i < 150) st_wd = tb.wdT[t_next * 150 + i];
+        const int tn = RESET ? 0 : (sa.t + 1) % 96;  // lock-step: the launch's clock
+        if (i < 100) st_pv = tb.pvT[tn * 100 + i];
+        if (i < 150) st_wd = tb.wdT[tn * 150 + i];
         if (!RESET) {
             if (i < 102) st_hy = tb.hy_table[i];
             if (MODE == MODE_COMPAT && i < kLevels / 4) st_hv = ((CHUB_G(const uint32_t)) tb.cnt_hv)[sa.t * (kLevels / 4) + i];
@@ -1302,7 +1319,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             if (!RESET) {
                 // the FCEV arrival level is state-independent: look its count up now, one byte straight from the table
                 hv_lev = (int) (px.block(SITE_HV, 0, 0).v[0] % 1000u);
-                hv_arrive = (int) tb.cnt_hv[(uint32_t) sa.t * (uint32_t) kLevels + (uint32_t) hv_lev];
+                hv_arrive = (int) tb.cnt_hv[(uint32_t) t_now * (uint32_t) kLevels + (uint32_t) hv_lev];
             }
         } else {
             z_pv = sa.exo_z[e32 * 3u + 0u];
@@ -1339,9 +1356,10 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         const int rows = (int) N - env0 < kEnvBlock ? (int) N - env0 : kEnvBlock;
         float *dst = sa.obs + (size_t) env0 * (size_t) row_w;
         const int total = rows * row_w;
-        if (sa.env_group) {  // per-env clocks: only the rows of this launch's clock group
+        // per-env clocks: only the rows of the envs this launch serves (whole block served: the plain path)
+        if (MULTI && sa.env_mask && !__syncthreads_and((live || env >= (int) N) ? 1 : 0)) {
             for (int i = threadIdx.x; i < total; i += kEnvBlock)
-                if ((uint32_t) sa.env_group[env0 + i / row_w] == sa.group) dst[i] = s_out[i];
+                if (in_group(sa, env0 + i / row_w)) dst[i] = s_out[i];
         } else if ((((uintptr_t) dst) & 15u) == 0) {  // 16 bytes per lane and store: a quarter of the store instructions
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const int quads = total >> 2;
@@ -1612,13 +1630,13 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     ev.ou[n32 + e32] = ou_wd;
     const double re_wd = (temp > 0 ? temp : 0.0) * 1;
     double price_next;
-    if (sa.draw_price) {  // MGR:354-357
+    if (draw_price) {  // MGR:354-357
         price_next = ou_sample(ou_price, .1, 0.005, z_pr) * hp.price_fluct1;
         ev.ou[2u * n32 + e32] = ou_price;
         ev.price_noise[e32] = price_next;
-        price_next += sa.price_last;
+        price_next += price_last;
     } else {
-        price_next = sa.price_last + in_price_noise;
+        price_next = price_last + in_price_noise;
     }
     ev.re_pv[e32] = re_pv;
     ev.re_wd[e32] = re_wd;
@@ -1658,7 +1676,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     CHUB_OBS(DIV_K(re_wd, 92 * 1));
 #undef CHUB_OBS
     if (!RESET) {
-        const bool dn = (sa.t + 1) >= 96;  // MGR:271-273
+        const bool dn = (t_now + 1) >= 96;  // MGR:271-273
         if (sa.done_f32) {  // packed row: reward and done ride in the same LDS row
             obs[n] = (float) reward;
             obs[n + 1] = dn ? 1.0f : 0.0f;
@@ -1682,15 +1700,19 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 }
 
 // Next step's state-independent draws, lane u: [0, 2N) the station-level variates of unit u, [2N, 3N) the per-env draws
-__device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int64_t u, const int t_next) {
+template <bool RESET, bool MULTI>
+__device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int64_t u) {
     const HubParams &hp = ctx->hp;
     const int64_t N = hp.n_envs;
+    if (u >= 3 * N) return;
+    const int64_t env_ = u < N ? u : (u < 2 * N ? u - N : u - 2 * N);
+    if (MULTI && !in_group(sa, env_)) return;
+    // the slot of day the draws are for: the one after this launch's, on the env's own clock
+    const int t_next = RESET ? 0 : ((MULTI ? clk_t(env_clk(sa, N, env_)) : sa.t) + 1) % 96;
     if (u < 2 * N) {
         const int kk = u >= N ? 1 : 0;
-        if (!in_group(sa, u - (int64_t) kk * N)) return;
         ctx->st.pk[(sa.tick + 1u) & 1u][u] = draw_station_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick + 1u), t_next, kk, u - (int64_t) kk * N);
-    } else if (u < 3 * N) {
-        if (!in_group(sa, u - 2 * N)) return;
+    } else {
         // the per-env draws (same Philox sites and counters the tail would use itself)
         const uint32_t e = (uint32_t) (u - 2 * N);
         const Tables &tb = ctx->tb;
@@ -1715,7 +1737,7 @@ __device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, cons
     }
 }
 
-template <bool RESET, int MODE>
+template <bool RESET, int MODE, bool MULTI>
 __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, TailArgs ta, int nb_env) {
     __shared__ double s_pv[100], s_wd[150], s_hy[102];
     __shared__ __attribute__((aligned(16))) uint8_t s_hv[kLevels];
@@ -1723,11 +1745,12 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     if (MODE == MODE_PHILOX && (int) blockIdx.x >= nb_env) {
         // the last blocks of the grid: next step's station-level draws, one lane per (station, env).
         // They are pure VALU work and fill the issue slots the latency-bound tail waves leave empty.
-        level_block(ctx, sa, (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x, RESET ? 0 : (sa.t + 1) % 96);
+        level_block<RESET, MULTI>(ctx, sa, (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x);
         return;
     }
     const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
-    env_tail<RESET, MODE>(ctx, sa, env, env < (int) ta.n_envs && in_group(sa, env), s_pv, s_wd, s_hy, s_hv, s_out, (int) blockIdx.x, ta);
+    env_tail<RESET, MODE, MULTI>(ctx, sa, env, env < (int) ta.n_envs && (!MULTI || in_group(sa, env)), s_pv, s_wd, s_hy, s_hv, s_out,
+                                 (int) blockIdx.x, ta);
 }
 
 // COMPAT only: HySystem.__init__ (HYD:154-158) builds hy_power_speed_list with 101 REAL hy_step()s from the initial tank:
@@ -1901,7 +1924,8 @@ __global__ void k_replay_soc(const DevCtx *__restrict__ ctx, float *out) {
 // PHILOX reset: evs_reset's initial occupancy per (station, env) unit -- init_station_car_number(mu, 3) (CHS.hpp:832-842)
 // thinned by the balk test of an empty queue -- drawn once per unit here (every lane of the unit used to redo it),
 // handed to k_slot<RESET> through this tick's pk word: arrivals | arrivals that stay << 8.
-__global__ void k_reset_levels(const DevCtx *__restrict__ ctx, uint32_t tick, const uint16_t *env_group, uint32_t group) {
+__global__ void k_reset_levels(const DevCtx *__restrict__ ctx, StepArgs sa) {
+    const uint32_t tick = sa.tick;
     const HubParams &hp = ctx->hp;
     const Tables &tb = ctx->tb;
     const int64_t N = hp.n_envs;
@@ -1909,7 +1933,7 @@ __global__ void k_reset_levels(const DevCtx *__restrict__ ctx, uint32_t tick, co
     if (u >= 2 * N) return;
     const int k = u >= N ? 1 : 0;
     const int64_t env = u - (int64_t) k * N;
-    if (env_group && (uint32_t) env_group[env] != group) return;
+    if (!in_group(sa, env)) return;
     const int S = hp.S[k], mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
     PhiloxCtx px{hp.key[0], hp.key[1], CHUB_TICK(hp, tick), (uint32_t) (hp.env_id0 + env)};
     U4 b = px.block(SITE_ARRIVE, (uint32_t) k, 0);
@@ -1934,8 +1958,10 @@ __global__ void k_draw_levels(const DevCtx *__restrict__ ctx, StepArgs sa) {
     const int64_t u = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= 2 * N) return;
     const int kk = u >= N ? 1 : 0;
-    if (!in_group(sa, u - (int64_t) kk * N)) return;
-    ctx->st.pk[sa.tick & 1u][u] = draw_station_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick), sa.t, kk, u - (int64_t) kk * N);
+    const int64_t env = u - (int64_t) kk * N;
+    if (!in_group(sa, env)) return;
+    const int t = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;
+    ctx->st.pk[sa.tick & 1u][u] = draw_station_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick), t, kk, env);
 }
 
 // ------------------------------------------------------------------------------------- launchers
@@ -1958,7 +1984,7 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
     constexpr int BLOCK = 256;
     const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
     if (MODE == MODE_PHILOX) {
-        if (RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa.tick, sa.env_group, sa.group);
+        if (RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
         CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, ev1, ctx, sa, nb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
@@ -1976,8 +2002,7 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
     if (hp.rng_mode == MODE_PHILOX) {
         if (hp.packed && !sa.load_mode) {
             if (reset)
-                hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa.tick,
-                                   sa.env_group, sa.group);
+                hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
             PackedArgs pa;
             for (int k = 0; k < 2; k++) {
                 pa.S[k] = (uint32_t) hp.S[k];
@@ -2000,8 +2025,7 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             pa.tick = sa.tick;
             pa.tick_base = hp.tick_base;
             for (int j = 0; j < 8; j++) pa.late[j] = pp.late8[j];
-            pa.env_group = (CHUB_G(const uint16_t)) sa.env_group;
-            pa.group = sa.group;
+            pa.env_mask = (CHUB_G(const uint8_t)) sa.env_mask;
             const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
 #define CHUB_PACKED(TAPE_, RESET_, BIG_) \
     CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, TAPE_, RESET_, BIG_>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa)
@@ -2030,18 +2054,29 @@ void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepAr
     const TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa);
     const int nb_env = (int) ((hp.n_envs + kEnvBlock - 1) / kEnvBlock);
     if (hp.rng_mode == MODE_PHILOX) {
-        // + the level-draw workgroups: next step's state-independent variates (3 lanes per env: two stations, one env);
-        // none behind a launch of one clock group (per-env clocks): its next launch makes its own (StepArgs::fresh)
-        const unsigned nb = (unsigned) nb_env + (sa.env_group ? 0u : (unsigned) ((3 * hp.n_envs + kEnvBlock - 1) / kEnvBlock));
-        if (reset) CHUB_LAUNCH((k_env<true, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
-        else CHUB_LAUNCH((k_env<false, MODE_PHILOX>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
+        // + the level-draw workgroups: next step's state-independent variates (3 lanes per env: two stations, one env)
+        const unsigned nb = (unsigned) nb_env + (unsigned) ((3 * hp.n_envs + kEnvBlock - 1) / kEnvBlock);
+        if (sa.env_clk) {  // per-env clocks: its own instantiation
+            if (reset) CHUB_LAUNCH((k_env<true, MODE_PHILOX, true>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
+            else CHUB_LAUNCH((k_env<false, MODE_PHILOX, true>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
+        } else if (reset) CHUB_LAUNCH((k_env<true, MODE_PHILOX, false>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
+        else CHUB_LAUNCH((k_env<false, MODE_PHILOX, false>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
     } else {
-        if (reset) CHUB_LAUNCH((k_env<true, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
-        else CHUB_LAUNCH((k_env<false, MODE_COMPAT>), dim3((unsigned) nb_env), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
+        if (reset) CHUB_LAUNCH((k_env<true, MODE_COMPAT, false>), dim3((unsigned) nb_env), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
+        else CHUB_LAUNCH((k_env<false, MODE_COMPAT, false>), dim3((unsigned) nb_env), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
     }
 }
 
 __global__ void k_tick_advance(uint32_t *tick_base, uint32_t by) { *tick_base += by; }
+
+// entering per-env clocks: every env starts from the handle's lock-step clock
+__global__ void k_fill_clocks(uint16_t *dst, int64_t n, uint16_t value) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+void launch_fill_clocks(uint16_t *dst, int64_t n, uint16_t value, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fill_clocks, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, dst, n, value);
+}
 void launch_tick_advance(uint32_t *tick_base, uint32_t by, hipStream_t stream) {
     hipLaunchKernelGGL(k_tick_advance, dim3(1), dim3(1), 0, stream, tick_base, by);
 }

@@ -25,6 +25,7 @@ void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepAr
 void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream);
 void launch_compat_ctor_sweep(const HubParams &hp, const DevCtx *ctx, hipStream_t stream);
 void launch_tick_advance(uint32_t *tick_base, uint32_t by, hipStream_t stream);
+void launch_fill_clocks(uint16_t *dst, int64_t n, uint16_t value, hipStream_t stream);
 }  // namespace chub
 
 using namespace chub;
@@ -45,13 +46,6 @@ extern "C" __attribute__((visibility("hidden"))) int chub_set_last_error_(int co
             return fail(CHUB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
     } while (0)
 
-struct ClockGroup {
-    int32_t t, price_count;
-    int64_t members;
-    uint32_t last_tick;  // Philox tick of the group's last launch; 0: differs between its envs (chub_env::h_tick)
-};
-constexpr int kMaxGroups = 128;  // distinct clocks at one time (a day has 96 slots)
-
 struct chub_env {
     chub_config cfg;
     HubParams hp;
@@ -67,14 +61,14 @@ struct chub_env {
     int t;
     int price_count;
     uint32_t tick;             // Philox tick: +1 per launched reset / step (one per clock group and call)
-    // per-env clocks (chub_reset_envs / chub_step_envs): envs with the same (t, price_count) form a clock group; one launch
-    // per group and call.  groups empty = lock-step (the clock above holds for every env).
-    std::vector<ClockGroup> groups;
-    std::vector<uint16_t> h_group;  // [N] group of every env (host mirror of d_group; valid while groups is not empty)
-    uint16_t *d_group;              // [N], in the arena
-    std::vector<uint32_t> h_tick;   // [N] tick of every env's last launch (chub_env_clocks)
-    bool predrawn;                  // the last launch left the next step's state-independent draws (lock-step chain intact)
-    bool tick_uniform;              // lock-step: every env's last launch was the handle's last launch (else h_tick)
+    // per-env clocks (chub_reset_envs / chub_step_envs): once a call names a subset of the envs, the clock is per-env device
+    // state (StepArgs::env_clk) and the lock-step clock above is unused -- until everybody is reset again
+    bool per_env;
+    uint16_t *d_env_clk;            // [2][N], in the arena
+    uint8_t *d_mask;                // [N], in the arena: the mask of the call in flight
+    std::vector<uint32_t> h_tick;   // [N] tick of the last launch that served the env through a mask (chub_env_clocks)
+    uint32_t full_tick;             // tick of the last launch that served every env
+    bool predrawn;                  // the last launch served every env: its level blocks left the next step's state-independent draws
     double price[96];
     double hy_table[102];
     std::vector<void *> allocs;
@@ -358,9 +352,11 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->t = 0;
     e->price_count = 0;
     e->tick = 0;
-    e->d_group = nullptr;
+    e->per_env = false;
+    e->d_env_clk = nullptr;
+    e->d_mask = nullptr;
+    e->full_tick = 0;
     e->predrawn = false;
-    e->tick_uniform = true;
     e->stream = nullptr;
     e->host_stream = nullptr;
     e->h_actions = e->h_packed = e->d_packed = nullptr;
@@ -721,7 +717,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         for (size_t i = 0; i < N; i++) memcpy(&rep[i * 102], e->hy_table, sizeof e->hy_table);
         HIP_TRY(hipMemcpy(e->ev.hy_env, rep.data(), rep.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    ALLOC(e->d_group, N);
+    ALLOC(e->d_env_clk, 2 * N); ALLOC(e->d_mask, N);
     ALLOC(e->d_tick_base, 64);
     e->hp.tick_base = e->d_tick_base;
     ALLOC(e->d_ctx, 1);
@@ -775,7 +771,12 @@ int chub_act_dim(const chub_env *e) { return e ? e->hp.act_dim : CHUB_ERR_ARG; }
 int64_t chub_num_envs(const chub_env *e) { return e ? e->hp.n_envs : CHUB_ERR_ARG; }
 int chub_clock(const chub_env *e) {  // lock-step: the clock; per-env clocks: env 0's (chub_env_clocks has them all)
     if (!e) return CHUB_ERR_ARG;
-    return e->groups.empty() ? e->t : e->groups[e->h_group[0]].t;
+    if (!e->per_env) return e->t;
+    uint16_t c = 0;
+    if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(&c, e->d_env_clk + (size_t) ((e->tick + 1u - e->graph_base) & 1u) * (size_t) e->hp.n_envs, sizeof c, hipMemcpyDeviceToHost) != hipSuccess)
+        return CHUB_ERR_HIP;
+    return (int) (c & 127u);
 }
 int chub_uses_packed_kernel(const chub_env *e) { return e ? e->hp.packed : CHUB_ERR_ARG; }
 
@@ -787,147 +788,79 @@ int chub_sync(chub_env *e) {
 }
 
 // ---- clocks -----------------------------------------------------------------------------------------------------------------
-// Every reference env owns its clock (MGR:137-140, 271-273, 299).  Here envs with the same clock form a group; lock-step
-// (the usual case: everybody reset and stepped together) is the handle's own clock and no group at all.  A call that names
-// a subset of the envs (chub_reset_envs / chub_step_envs) splits the groups along its mask; every call launches once per
-// clock it touches, each launch with its own Philox tick, and groups whose clocks coincide again are merged.
-static void flush_ticks(chub_env *e) {  // the groups' last ticks -> the per-env record (before labels change)
-    const size_t N = (size_t) e->hp.n_envs;
-    if (e->h_tick.size() != N) e->h_tick.assign(N, e->tick);
-    for (size_t i = 0; i < N && !e->groups.empty(); i++) {
-        const uint32_t lt = e->groups[e->h_group[i]].last_tick;
-        if (lt) e->h_tick[i] = lt;
-    }
-}
+// Every reference env owns its clock (MGR:137-140, 271-273, 299).  Lock-step (the usual case: everybody reset and stepped
+// together) is ONE clock on the host, passed to the kernels as an argument.  The first call that names a subset of the envs
+// (chub_reset_envs / chub_step_envs) makes the clock per-env device state: [2][N] u16, read at [tick & 1] and written at
+// [(tick + 1) & 1] by the tail kernel for every env (served envs: one step on, or back to 0; the others: unchanged), so
+// any call is still ONE launch with one Philox tick, however many different clocks the envs show.  A reset of everybody
+// returns to the host clock.
 
-// The clock groups one call has to launch, in ascending order (-1: every env, lock-step).  mask null = every env.  Splits
-// and merges groups as the mask requires and uploads the labels when they changed.
-static int groups_for_call(chub_env *e, const uint8_t *mask, hipStream_t s, std::vector<int> &launch) {
+// What one call serves: 0 nobody, 1 a subset (mask uploaded, per-env clocks on), 2 every env.
+static int serve_mask(chub_env *e, const uint8_t *mask, hipStream_t s, int &served) {
     const size_t N = (size_t) e->hp.n_envs;
-    launch.clear();
     size_t n_masked = N;
     if (mask) {
         n_masked = 0;
         for (size_t i = 0; i < N; i++) n_masked += mask[i] ? 1 : 0;
-        if (n_masked == 0) return CHUB_OK;
     }
-    if (e->groups.empty() && n_masked == N) {
-        launch.push_back(-1);
-        return CHUB_OK;
-    }
+    served = n_masked == 0 ? 0 : (n_masked == N ? 2 : 1);
+    if (served != 1) return CHUB_OK;
     if (e->hp.rng_mode != CHUB_RNG_PHILOX)
         return fail(CHUB_ERR_UNSUPPORTED, "per-env clocks need a PHILOX handle (the COMPAT streams are replayed in lock-step)");
-    if (e->capturing) return fail(CHUB_ERR_ARG, "a graph capture covers lock-step calls only");
+    if (e->capturing) return fail(CHUB_ERR_ARG, "a graph capture covers calls on every env only");
     if (e->tape_pk) return fail(CHUB_ERR_ARG, "tape mode runs in lock-step");
-    HIP_TRY(hipStreamSynchronize(s));  // the labels may change: no launch that reads them may still be in flight
-    bool relabel = false;
-    if (e->groups.empty()) {
-        flush_ticks(e);
-        e->groups.push_back(ClockGroup{e->t, e->price_count, (int64_t) N, e->tick_uniform ? e->tick : 0u});
-        e->h_group.assign(N, 0);
-        relabel = true;
+    if (!e->per_env) {  // every env starts from the lock-step clock, in the buffer the next launch reads
+        const uint16_t c = (uint16_t) ((uint32_t) e->t | (((uint32_t) e->price_count & 3u) << 8));
+        launch_fill_clocks(e->d_env_clk + (size_t) ((e->tick + 1u - e->graph_base) & 1u) * N, (int64_t) N, c, s);
+        e->per_env = true;
+        if (e->h_tick.size() != N) e->h_tick.assign(N, 0u);
     }
-    // clocks that coincide again: one group
-    for (size_t a = 0; a < e->groups.size(); a++)
-        for (size_t b = a + 1; b < e->groups.size(); b++) {
-            ClockGroup &ga = e->groups[a], &gb = e->groups[b];
-            if (ga.members == 0 || gb.members == 0 || ga.t != gb.t || ga.price_count != gb.price_count) continue;
-            flush_ticks(e);
-            for (size_t i = 0; i < N; i++)
-                if (e->h_group[i] == (uint16_t) b) e->h_group[i] = (uint16_t) a;
-            ga.members += gb.members;
-            gb.members = 0;
-            if (ga.last_tick != gb.last_tick) ga.last_tick = 0;  // per env from here on (h_tick)
-            relabel = true;
-        }
-    if (mask && n_masked < N) {
-        const size_t G = e->groups.size();
-        std::vector<int64_t> in(G, 0);
-        for (size_t i = 0; i < N; i++)
-            if (mask[i]) in[e->h_group[i]]++;
-        std::vector<int> target(G, -1);
-        bool split = false;
-        for (size_t g = 0; g < G; g++) {
-            if (in[g] == 0) continue;
-            if (in[g] == e->groups[g].members) {
-                target[g] = (int) g;
-                continue;
-            }
-            size_t slot = 0;  // a free entry, or a new one
-            while (slot < e->groups.size() && e->groups[slot].members != 0) slot++;
-            if (slot == e->groups.size()) {
-                if ((int) slot >= kMaxGroups) return fail(CHUB_ERR_UNSUPPORTED, "more than 128 distinct env clocks at one time");
-                e->groups.push_back(ClockGroup{0, 0, 0, 0u});
-            }
-            ClockGroup ng = e->groups[g];
-            ng.members = in[g];
-            e->groups[g].members -= in[g];
-            e->groups[slot] = ng;
-            target[g] = (int) slot;
-            split = true;
-        }
-        if (split) {
-            for (size_t i = 0; i < N; i++)
-                if (mask[i]) e->h_group[i] = (uint16_t) target[e->h_group[i]];
-            relabel = true;
-        }
-        for (size_t g = 0; g < G; g++)
-            if (target[g] >= 0) launch.push_back(target[g]);
-        std::sort(launch.begin(), launch.end());
-    } else {
-        for (size_t g = 0; g < e->groups.size(); g++)
-            if (e->groups[g].members > 0) launch.push_back((int) g);
-    }
-    if (relabel) HIP_TRY(hipMemcpy(e->d_group, e->h_group.data(), N * sizeof(uint16_t), hipMemcpyHostToDevice));
+    // the mask of this call: the launches of the previous masked call must have read theirs, and the caller's array is only
+    // borrowed for the duration of the call
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(e->d_mask, mask, N, hipMemcpyHostToDevice));
     return CHUB_OK;
 }
 
-// after a call: back to lock-step when every env shows the same clock again (a reset of everybody, for one)
-static void collapse_groups(chub_env *e) {
-    if (e->groups.empty()) return;
-    const ClockGroup *first = nullptr;
-    for (const ClockGroup &g : e->groups) {
-        if (g.members == 0) continue;
-        if (!first) first = &g;
-        else if (g.t != first->t || g.price_count != first->price_count) return;
+static void note_served(chub_env *e, const uint8_t *mask, int served) {
+    if (served == 2) {
+        e->full_tick = e->tick;
+        return;
     }
-    if (!first) return;
-    flush_ticks(e);
-    e->t = first->t;
-    e->price_count = first->price_count;
-    e->tick_uniform = false;  // the envs' last launches carried different ticks: chub_env_clocks reads the per-env record
-    e->groups.clear();
+    const size_t N = (size_t) e->hp.n_envs;
+    for (size_t i = 0; i < N; i++)
+        if (mask[i]) e->h_tick[i] = e->tick;
 }
 
-// one launched reset of ONE clock (group < 0: every env)
-static int run_reset(chub_env *e, int32_t &t, int32_t &pc, int group, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs,
-                     hipStream_t s) {
+// ONE launched reset: of every env (served = 2) or of the envs of the uploaded mask (served = 1)
+static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs, hipStream_t s) {
     e->tick += 1;
     StepArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.t = 0;
     sa.tick = e->tick - e->graph_base;
-    sa.draw_price = (pc % 4 == 0) ? 1 : 0;
+    sa.draw_price = (e->price_count % 4 == 0) ? 1 : 0;
     sa.station_filter = -1;
     sa.price_last = e->price[95];  // AGG:171: price = [] + mean_for_MAD; price[-1]
     sa.exo_days = d_exo_days;
     sa.exo_z = d_exo_z;
     sa.obs = d_obs;
     sa.obs_stride = e->hp.obs_dim;
-    if (group >= 0) {
-        sa.env_group = e->d_group;
-        sa.group = (uint32_t) group;
+    if (e->per_env) {
+        sa.env_clk = e->d_env_clk;
+        sa.env_mask = served == 1 ? e->d_mask : nullptr;
     }
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
     launch_slot(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e), nullptr, nullptr);
     launch_env(true, e->hp, e->d_ctx, sa, s, nullptr, nullptr, packed_ptrs(e));
     HIP_TRY(hipGetLastError());
-    t = 0;
-    pc = 0;  // MGR:313 (after make_state)
-    e->predrawn = group < 0;
-    if (group < 0) e->tick_uniform = true;
-    else e->groups[(size_t) group].last_tick = e->tick;
+    e->predrawn = served == 2;  // the launch's level blocks left the next step's draws of every env it served
+    if (served == 2) {  // everybody starts a new day: one clock again (the launch itself still ran on the envs' own clocks)
+        e->per_env = false;
+        e->t = 0;
+        e->price_count = 0;  // MGR:313 (after make_state)
+    }
     return CHUB_OK;
 }
 
@@ -938,15 +871,12 @@ static int reset_masked(chub_env *e, const uint8_t *mask, const int32_t *d_exo_d
     HIP_TRY(hipSetDevice(e->device));
     (void) hipGetLastError();  // a stale error of an earlier, unrelated call must not be reported as this step's
     hipStream_t s = (hipStream_t) stream;
-    std::vector<int> launch;
-    int rc = groups_for_call(e, mask, s, launch);
+    int served = 0;
+    int rc = serve_mask(e, mask, s, served);
+    if (rc || served == 0) return rc;
+    rc = run_reset(e, served, d_exo_days, d_exo_z, d_obs, s);
     if (rc) return rc;
-    for (int g : launch) {
-        if (g < 0) rc = run_reset(e, e->t, e->price_count, -1, d_exo_days, d_exo_z, d_obs, s);
-        else rc = run_reset(e, e->groups[(size_t) g].t, e->groups[(size_t) g].price_count, g, d_exo_days, d_exo_z, d_obs, s);
-        if (rc) return rc;
-    }
-    collapse_groups(e);
+    note_served(e, mask, served);
     return CHUB_OK;
 }
 
@@ -1007,18 +937,17 @@ int chub_step_load(chub_env *e, const float *actions, const double *exo_z, float
     return CHUB_OK;
 }
 
-// one launched step of ONE clock (group < 0: every env)
-static int run_step(chub_env *e, int32_t &t, int32_t &pc, int group, const float *d_actions, const double *d_exo_z, float *d_obs,
-                    int obs_stride, float *d_reward, int reward_stride, uint8_t *d_done, float *d_done_f32, hipStream_t s,
-                    int load_mode) {
+// ONE launched step: of every env (served = 2) or of the envs of the uploaded mask (served = 1)
+static int run_step(chub_env *e, int served, const float *d_actions, const double *d_exo_z, float *d_obs, int obs_stride,
+                    float *d_reward, int reward_stride, uint8_t *d_done, float *d_done_f32, hipStream_t s, int load_mode) {
     e->tick += 1;
     StepArgs sa;
     memset(&sa, 0, sizeof sa);
-    sa.t = t;
+    sa.t = e->t;
     sa.tick = e->tick - e->graph_base;
-    sa.draw_price = (pc % 4 == 0) ? 1 : 0;
+    sa.draw_price = (e->price_count % 4 == 0) ? 1 : 0;
     sa.station_filter = -1;
-    sa.price_last = e->price[t];  // AGG:147
+    sa.price_last = e->price[e->t];  // AGG:147
     sa.actions = d_actions;
     sa.exo_z = d_exo_z;
     sa.obs = d_obs;
@@ -1030,17 +959,17 @@ static int run_step(chub_env *e, int32_t &t, int32_t &pc, int group, const float
     sa.load_mode = load_mode;
     sa.pk_tape = e->tape_pk;
     sa.car_tape = e->tape_car;
-    if (group >= 0) {
-        sa.env_group = e->d_group;
-        sa.group = (uint32_t) group;
+    if (e->per_env) {
+        sa.env_clk = e->d_env_clk;
+        sa.env_mask = served == 1 ? e->d_mask : nullptr;
     }
-    // the state-independent draws of this step: left by the previous launch if that was this clock's previous step (the
-    // lock-step chain), otherwise made by this launch itself
-    // (a graph's first step always makes its own: a replay must not depend on what ran before it)
-    sa.fresh = (group >= 0 || !e->predrawn || (e->capturing && e->tick == e->graph_tick0 + 1u)) ? 1 : 0;
+    // the state-independent draws of this step: left by the previous launch's level blocks if that launch served every env
+    // (for the tick that is now this launch's), otherwise made by this launch itself (a graph's first step always makes its
+    // own: a replay must not depend on what ran before it)
+    sa.fresh = (!e->predrawn || (e->capturing && e->tick == e->graph_tick0 + 1u)) ? 1 : 0;
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
-    bool prof = group < 0 && e->prof_on && e->prof_used < e->prof_cap;
+    bool prof = e->prof_on && e->prof_used < e->prof_cap;
     if (prof) {
         prof = (e->prof_phase % e->prof_every) == 0;  // sample: the event records are not free
         e->prof_phase++;
@@ -1051,11 +980,11 @@ static int run_step(chub_env *e, int32_t &t, int32_t &pc, int group, const float
     launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
     if (prof) e->prof_used++;
     HIP_TRY(hipGetLastError());
-    pc += 1;
-    t = (t + 1) % 96;
-    e->predrawn = group < 0;
-    if (group < 0) e->tick_uniform = true;
-    else e->groups[(size_t) group].last_tick = e->tick;
+    e->predrawn = served == 2;
+    if (!e->per_env) {
+        e->price_count += 1;
+        e->t = (e->t + 1) % 96;
+    }
     return CHUB_OK;
 }
 
@@ -1066,15 +995,12 @@ static int step_masked(chub_env *e, const uint8_t *mask, const float *d_actions,
     HIP_TRY(hipSetDevice(e->device));
     (void) hipGetLastError();  // a stale error of an earlier, unrelated call must not be reported as this step's
     hipStream_t s = (hipStream_t) stream;
-    std::vector<int> launch;
-    int rc = groups_for_call(e, mask, s, launch);
+    int served = 0;
+    int rc = serve_mask(e, mask, s, served);
+    if (rc || served == 0) return rc;
+    rc = run_step(e, served, d_actions, d_exo_z, d_obs, obs_stride, d_reward, reward_stride, d_done, d_done_f32, s, load_mode);
     if (rc) return rc;
-    for (int g : launch) {
-        int32_t &t = g < 0 ? e->t : e->groups[(size_t) g].t, &pc = g < 0 ? e->price_count : e->groups[(size_t) g].price_count;
-        rc = run_step(e, t, pc, g, d_actions, d_exo_z, d_obs, obs_stride, d_reward, reward_stride, d_done, d_done_f32, s, load_mode);
-        if (rc) return rc;
-    }
-    collapse_groups(e);
+    note_served(e, mask, served);
     return CHUB_OK;
 }
 
@@ -1126,27 +1052,37 @@ int chub_step_envs(chub_env *e, const uint8_t *mask, const float *actions, float
 }
 
 // slot of day (and, if asked, the Philox tick of the last launch) of every env
+static int fetch_clocks(chub_env *e, std::vector<uint16_t> &c) {
+    const size_t N = (size_t) e->hp.n_envs;
+    c.assign(N, (uint16_t) ((uint32_t) e->t | (((uint32_t) e->price_count & 3u) << 8)));
+    if (!e->per_env) return CHUB_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    // the buffer the next launch reads
+    HIP_TRY(hipMemcpy(c.data(), e->d_env_clk + (size_t) ((e->tick + 1u - e->graph_base) & 1u) * N, N * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    return CHUB_OK;
+}
+
 int chub_env_clocks(chub_env *e, int32_t *t_out, uint32_t *tick_out) {
     if (!e || !t_out) return fail(CHUB_ERR_ARG, "null argument");
     const size_t N = (size_t) e->hp.n_envs;
+    std::vector<uint16_t> c;
+    int rc = fetch_clocks(e, c);
+    if (rc) return rc;
     for (size_t i = 0; i < N; i++) {
-        if (e->groups.empty()) {
-            t_out[i] = e->t;
-            if (tick_out) tick_out[i] = e->tick_uniform ? e->tick : e->h_tick[i];
-        } else {
-            const ClockGroup &g = e->groups[e->h_group[i]];
-            t_out[i] = g.t;
-            if (tick_out) tick_out[i] = g.last_tick ? g.last_tick : e->h_tick[i];
-        }
+        t_out[i] = (int32_t) (c[i] & 127u);
+        if (tick_out) tick_out[i] = (e->h_tick.size() == N && e->h_tick[i] > e->full_tick) ? e->h_tick[i] : e->full_tick;
     }
     return CHUB_OK;
 }
 
-int chub_clock_groups(const chub_env *e) {
+int chub_clock_groups(chub_env *e) {  // number of distinct clocks among the envs
     if (!e) return CHUB_ERR_ARG;
-    int n = 0;
-    for (const ClockGroup &g : e->groups) n += g.members > 0 ? 1 : 0;
-    return e->groups.empty() ? 1 : n;
+    std::vector<uint16_t> c;
+    int rc = fetch_clocks(e, c);
+    if (rc) return rc;
+    std::sort(c.begin(), c.end());
+    return (int) (std::unique(c.begin(), c.end()) - c.begin());
 }
 
 int chub_reset(chub_env *e, const int32_t *exo_days, const double *exo_z, float *obs) {
@@ -1225,7 +1161,7 @@ int chub_graph_begin(chub_env *e, void *stream) {
     if (e->capturing) return fail(CHUB_ERR_ARG, "a capture is already in progress on this handle");
     if (e->hp.rng_mode != CHUB_RNG_PHILOX) return fail(CHUB_ERR_ARG, "graphs replay PHILOX steps (COMPAT takes host draws every step)");
     if (e->prof_on) return fail(CHUB_ERR_ARG, "per-kernel profiling is on");
-    if (!e->groups.empty()) return fail(CHUB_ERR_ARG, "graphs cover lock-step calls: the envs of this handle run on different clocks");
+    if (e->per_env) return fail(CHUB_ERR_ARG, "graphs cover lock-step calls: the envs of this handle run on their own clocks (reset all of them first)");
     HIP_TRY(hipSetDevice(e->device));
     int rc = sync_ctx(e, (hipStream_t) stream);
     if (rc) return rc;
@@ -1279,7 +1215,7 @@ int chub_graph_end(chub_env *e, void *stream, chub_graph **out) {
 
 int chub_graph_launch(chub_graph *g, void *stream) {
     if (!g) return fail(CHUB_ERR_ARG, "null graph");
-    if (!g->env->groups.empty()) return fail(CHUB_ERR_ARG, "graphs replay lock-step calls: the envs of this handle run on different clocks");
+    if (g->env->per_env) return fail(CHUB_ERR_ARG, "graphs replay lock-step calls: the envs of this handle run on their own clocks (reset all of them first)");
     HIP_TRY(hipSetDevice(g->device));
     HIP_TRY(hipGraphLaunch(g->exec, (hipStream_t) stream));
     // the replay covers g->ticks resets + steps: its last node moves the device-side tick base on, the host mirrors it, so that
@@ -1290,7 +1226,7 @@ int chub_graph_launch(chub_graph *g, void *stream) {
     e->t = g->t_end;
     e->price_count = g->pc_end;
     e->predrawn = true;
-    e->tick_uniform = true;
+    e->full_tick = e->tick;
     return CHUB_OK;
 }
 
@@ -1758,12 +1694,8 @@ struct SnapshotHeader {
     uint32_t tick, graph_base;
     uint64_t arena_used;
     double hy_table[102];
-    // per-env clocks: the group table (the labels are in the arena); the blob ends with every env's last tick
-    int32_t predrawn, n_groups;
-    struct {
-        int32_t t, price_count;
-        int64_t members;
-    } groups[kMaxGroups];
+    // per-env clocks (the clocks themselves are in the arena); the blob ends with every env's last tick
+    int32_t predrawn, per_env;
 };
 static const uint64_t kSnapMagic = 0x43485542534e4150ull;  // "CHUBSNAP"
 
@@ -1794,12 +1726,7 @@ int chub_get_state(chub_env *e, void *buf, int64_t size) {
     h.arena_used = e->arena_used;
     memcpy(h.hy_table, e->hy_table, sizeof h.hy_table);
     h.predrawn = e->predrawn ? 1 : 0;
-    h.n_groups = (int32_t) e->groups.size();
-    for (size_t g = 0; g < e->groups.size(); g++) {
-        h.groups[g].t = e->groups[g].t;
-        h.groups[g].price_count = e->groups[g].price_count;
-        h.groups[g].members = e->groups[g].members;
-    }
+    h.per_env = e->per_env ? 1 : 0;
     memcpy(buf, &h, sizeof h);
     HIP_TRY(hipMemcpy((char *) buf + sizeof h, e->arena, e->arena_used, hipMemcpyDeviceToHost));
     {
@@ -1837,20 +1764,11 @@ int chub_set_state(chub_env *e, const void *buf, int64_t size) {
     e->ctx_dirty = true;
     {
         const size_t N = (size_t) e->hp.n_envs;
-        if (h.n_groups < 0 || h.n_groups > kMaxGroups) return fail(CHUB_ERR_ARG, "snapshot: bad clock-group table");
         e->predrawn = h.predrawn != 0;
-        e->groups.clear();
-        for (int g = 0; g < h.n_groups; g++)
-            e->groups.push_back(ClockGroup{h.groups[g].t, h.groups[g].price_count, h.groups[g].members, 0u});
+        e->per_env = h.per_env != 0;
         e->h_tick.resize(N);
         memcpy(e->h_tick.data(), (const char *) buf + sizeof h + e->arena_used, N * sizeof(uint32_t));
-        e->tick_uniform = false;  // per env, from the blob
-        if (!e->groups.empty()) {
-            e->h_group.resize(N);
-            HIP_TRY(hipMemcpy(e->h_group.data(), e->d_group, N * sizeof(uint16_t), hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < N; i++)
-                if (e->h_group[i] >= e->groups.size()) return fail(CHUB_ERR_ARG, "snapshot: clock-group label out of range");
-        }
+        e->full_tick = 0;  // per env, from the blob
     }
     return CHUB_OK;
 }

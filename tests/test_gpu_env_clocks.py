@@ -1,6 +1,6 @@
 """Per-env clocks: every reference env owns its clock (evcssp_manager.py:137-140, 271-273, 299, 304-316), so any subset of the
 envs can be reset, or stepped, while the others are not.  One handle does that through chub_reset_envs / chub_step_envs
-(clock groups, one launch per clock a call touches).  Checked here against the oracle, whose envs ARE separate objects
+(the clock becomes per-env device state; every call stays one launch).  Checked here against the oracle, whose envs ARE separate objects
 with their own clocks: each oracle env is given the Philox tick the library reports for that env's launch, and must then
 agree bit for bit (slot state, station records) / to 1e-12 (f64 observation, reward)."""
 import ctypes as C
@@ -129,6 +129,23 @@ def test_subset_resets_and_steps_match_the_oracle(slot_kernel):
     assert p.v.clock_groups == 1
     for i in range(4):
         p.step(label=("lock-step again", i))  # the first of these makes its own draws, the others find them left by the launch before
+    p.close()
+
+
+def test_every_env_on_its_own_clock():
+    """one env after the other is reset alone: 100 envs, (nearly) 100 different clocks in one launch per call"""
+    n = 100
+    p = Pair(KW, n)
+    p.reset(label="all")
+    for i in range(n):
+        p.step(label=("all", i))
+        one = np.zeros(n, dtype=bool)
+        one[i] = True
+        p.reset(one, ("env alone", i))
+    assert p.v.clock_groups >= 95
+    for i in range(8):
+        done = p.step(label=("everybody on its own clock", i))
+    assert np.array_equal(np.sort(p.v.env_clocks()), np.sort(p.t))
     p.close()
 
 
