@@ -1,21 +1,24 @@
 // chub_kernels.hip -- the per-step hot path of the charging-hub environment as CDNA4 (gfx950) kernels.
 //
-//   k_slot_packed   lane = charger slot, PHILOX steps (production).  The workgroup's 256 lanes are laid over whole
-//           (env, station) units end to end; phases in the reference's order (CHS.hpp:1188-1207 / 1499-1518):
-//           urgency -> feasibility / on-off -> departures -> arrivals (pre-drawn levels, renege, balk) -> admission by
-//           ballot + prefix rank (across waves through LDS) -> dense car_step / add_car over LDS queues -> station sums
-//           (integer LDS atomics) -> one 16-byte station record per unit.
-//   k_slot  the same phases with wave-local units (H = pow2 >= S_k lanes each): reset, COMPAT streams, scalar-load
-//           control, stations with 1-3 piles.
+//   k_slot_packed   2 charger slots per lane, every PHILOX step and reset (production).  The workgroup's 512 virtual lanes are
+//           laid over whole envs end to end (hub-major 8-byte slot state, like the action rows); phases in the reference's
+//           order (CHS.hpp:1188-1207 / 1499-1518): departures -> arrivals (pre-drawn levels, renege, balk) -> admission by
+//           ballot + prefix rank (across waves through LDS) in the shadow of the class-row reads -> on/off, car_step = the
+//           next row entry -> station sums (integer LDS atomics) -> last wave: add_car for the new cars, one 16-byte
+//           station record per unit.
+//   k_slot  the same phases with wave-local units (H = pow2 >= S_k lanes each): COMPAT streams (16-byte hot record, curves
+//           evaluated), PHILOX scalar-load control and hubs of 1-3 piles.
 //   k_env   lane = environment.  The scalar tail of step(): electrolyser clamp against the grid limit, FCEV arrivals +
-//           SAE-J2601 fueling + 15-min FIFO, electrolyser / compressor / tank, renewable netting, fuel cell, incomes and
+//           SAE-J2601 fueling + the waiting list, electrolyser / compressor / tank, renewable netting, fuel cell, incomes and
 //           reward, done, exogenous update (PV / wind / price OU) and the normalised observation.  The J2601 breakpoints
 //           are immediates; the PV and wind rows of the current slot and the electrolyser action->power table are staged
-//           in LDS; its last workgroups draw the next step's state-independent variates.
-//   k_reset_levels, k_replay_soc, k_random_actions, k_compat_burn_fcev: small helpers (reset draws, SoC introspection,
-//           bench policy, COMPAT constructor replay).
+//           in LDS; its last workgroups draw the next step's state-independent variates.  MULTI: per-env clocks.
+//   k_reset_levels, k_draw_levels, k_compat_ctor_sweep, k_replay_soc, k_random_actions, k_tick_advance, k_fill_clocks: small
+//           helpers (reset draws, a step's own station draws, COMPAT constructor replay, SoC introspection, bench policy,
+//           graph replays, per-env clocks).
 //
-// No MFMA: there is no dense contraction anywhere in this path; by bytes it is HBM-bound, measured it is VALU-issue bound.
+// No MFMA: there is no dense contraction anywhere in this path.  By bytes it is HBM-bound; measured VALU
+// issue, the vector L1's access rate and HBM streaming are each more than half used.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>

@@ -65,7 +65,10 @@ struct chub_env {
     // state (StepArgs::env_clk) and the lock-step clock above is unused -- until everybody is reset again
     bool per_env;
     uint16_t *d_env_clk;            // [2][N], in the arena
-    uint8_t *d_mask;                // [N], in the arena: the mask of the call in flight
+    uint8_t *d_mask;                // [2][N], in the arena: the masks of the last two masked calls (the launches in flight read them)
+    uint8_t *h_mask;                // [2][N] pinned staging for them
+    hipEvent_t mask_done[2];        // recorded behind the launches that read d_mask[i]
+    uint32_t mask_seq;
     std::vector<uint32_t> h_tick;   // [N] tick of the last launch that served the env through a mask (chub_env_clocks)
     uint32_t full_tick;             // tick of the last launch that served every env
     bool predrawn;                  // the last launch served every env: its level blocks left the next step's state-independent draws
@@ -355,6 +358,9 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->per_env = false;
     e->d_env_clk = nullptr;
     e->d_mask = nullptr;
+    e->h_mask = nullptr;
+    e->mask_done[0] = e->mask_done[1] = nullptr;
+    e->mask_seq = 0;
     e->full_tick = 0;
     e->predrawn = false;
     e->stream = nullptr;
@@ -717,7 +723,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         for (size_t i = 0; i < N; i++) memcpy(&rep[i * 102], e->hy_table, sizeof e->hy_table);
         HIP_TRY(hipMemcpy(e->ev.hy_env, rep.data(), rep.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    ALLOC(e->d_env_clk, 2 * N); ALLOC(e->d_mask, N);
+    ALLOC(e->d_env_clk, 2 * N); ALLOC(e->d_mask, 2 * N);
     ALLOC(e->d_tick_base, 64);
     e->hp.tick_base = e->d_tick_base;
     ALLOC(e->d_ctx, 1);
@@ -757,6 +763,9 @@ int chub_destroy(chub_env *e) {
         for (void *p : e->allocs) (void) hipFree(p);
         for (hipEvent_t ev : e->prof_events) (void) hipEventDestroy(ev);
         if (e->h_actions) (void) hipHostFree(e->h_actions);
+        if (e->h_mask) (void) hipHostFree(e->h_mask);
+        for (hipEvent_t ev : e->mask_done)
+            if (ev) (void) hipEventDestroy(ev);
         if (e->h_packed) (void) hipHostFree(e->h_packed);
         if (e->d_packed) (void) hipFree(e->d_packed);
         if (e->host_stream) (void) hipStreamDestroy(e->host_stream);
@@ -815,21 +824,30 @@ static int serve_mask(chub_env *e, const uint8_t *mask, hipStream_t s, int &serv
         e->per_env = true;
         if (e->h_tick.size() != N) e->h_tick.assign(N, 0u);
     }
-    // the mask of this call: the launches of the previous masked call must have read theirs, and the caller's array is only
-    // borrowed for the duration of the call
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipMemcpy(e->d_mask, mask, N, hipMemcpyHostToDevice));
+    // the mask of this call: the caller's array is only borrowed for the duration of the call, so it goes through one of two
+    // pinned staging buffers; a buffer is reused once the launches that read its device copy are done (two masked calls ago)
+    if (!e->h_mask) {
+        HIP_TRY(hipHostMalloc((void **) &e->h_mask, 2 * N, hipHostMallocDefault));
+        for (hipEvent_t &ev : e->mask_done) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const uint32_t b = e->mask_seq & 1u;
+    if (e->mask_seq >= 2) HIP_TRY(hipEventSynchronize(e->mask_done[b]));
+    memcpy(e->h_mask + (size_t) b * N, mask, N);
+    HIP_TRY(hipMemcpyAsync(e->d_mask + (size_t) b * N, e->h_mask + (size_t) b * N, N, hipMemcpyHostToDevice, s));
     return CHUB_OK;
 }
 
-static void note_served(chub_env *e, const uint8_t *mask, int served) {
+static int note_served(chub_env *e, const uint8_t *mask, int served, hipStream_t s) {
     if (served == 2) {
         e->full_tick = e->tick;
-        return;
+        return CHUB_OK;
     }
+    HIP_TRY(hipEventRecord(e->mask_done[e->mask_seq & 1u], s));
+    e->mask_seq += 1;
     const size_t N = (size_t) e->hp.n_envs;
     for (size_t i = 0; i < N; i++)
         if (mask[i]) e->h_tick[i] = e->tick;
+    return CHUB_OK;
 }
 
 // ONE launched reset: of every env (served = 2) or of the envs of the uploaded mask (served = 1)
@@ -848,7 +866,7 @@ static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const d
     sa.obs_stride = e->hp.obs_dim;
     if (e->per_env) {
         sa.env_clk = e->d_env_clk;
-        sa.env_mask = served == 1 ? e->d_mask : nullptr;
+        sa.env_mask = served == 1 ? e->d_mask + (size_t) (e->mask_seq & 1u) * (size_t) e->hp.n_envs : nullptr;
     }
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
@@ -876,8 +894,7 @@ static int reset_masked(chub_env *e, const uint8_t *mask, const int32_t *d_exo_d
     if (rc || served == 0) return rc;
     rc = run_reset(e, served, d_exo_days, d_exo_z, d_obs, s);
     if (rc) return rc;
-    note_served(e, mask, served);
-    return CHUB_OK;
+    return note_served(e, mask, served, s);
 }
 
 int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs, void *stream) {
@@ -961,7 +978,7 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     sa.car_tape = e->tape_car;
     if (e->per_env) {
         sa.env_clk = e->d_env_clk;
-        sa.env_mask = served == 1 ? e->d_mask : nullptr;
+        sa.env_mask = served == 1 ? e->d_mask + (size_t) (e->mask_seq & 1u) * (size_t) e->hp.n_envs : nullptr;
     }
     // the state-independent draws of this step: left by the previous launch's level blocks if that launch served every env
     // (for the tick that is now this launch's), otherwise made by this launch itself (a graph's first step always makes its
@@ -1000,8 +1017,7 @@ static int step_masked(chub_env *e, const uint8_t *mask, const float *d_actions,
     if (rc || served == 0) return rc;
     rc = run_step(e, served, d_actions, d_exo_z, d_obs, obs_stride, d_reward, reward_stride, d_done, d_done_f32, s, load_mode);
     if (rc) return rc;
-    note_served(e, mask, served);
-    return CHUB_OK;
+    return note_served(e, mask, served, s);
 }
 
 static int step_common(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, int obs_stride,
