@@ -189,6 +189,8 @@ struct PackedPtrs {
     uint64_t *pk[2];
     const float *cls[2], *ttab[2], *ttab2;
     uint32_t late8[8];        // the first 8 thresholds of Tables::late_thr, passed to the packed kernel by value
+    const Tables *tb;         // host copy of the table pointers
+    const double *sin96;      // host copy of Tables::sin96 (the tail gets its slot's value by value)
 };
 
 struct StepArgs {

@@ -1132,9 +1132,28 @@ struct TailArgs {
     CHUB_G(uint32_t) rec;
     CHUB_G(const float) actions;
     uint32_t n_envs, act_dim, s_tot, pad;
+    // the rows of this slot of the day and what the tail's Philox context needs: nothing in front of the load burst goes
+    // through the context pointer (each hop there is a dependent scalar round trip of this latency-bound kernel)
+    CHUB_G(const double) pv_row;   // pvT + t_next * 100
+    CHUB_G(const double) wd_row;   // wdT + t_next * 150
+    CHUB_G(const double) hy_table;
+    const uint32_t *tick_base;
+    double sin_t;                  // sin96[t_next] (lock-step; per-env clocks read the table)
+    uint32_t key[2], gid0, pad2;
 };
-__host__ __device__ inline TailArgs make_tail_args(const EnvArrays &ev, const StationArrays &st, const HubParams &hp, const StepArgs &sa) {
+inline TailArgs make_tail_args(const EnvArrays &ev, const StationArrays &st, const HubParams &hp, const StepArgs &sa, const PackedPtrs &pp,
+                               bool reset) {
     TailArgs ta;
+    const int t_next = reset ? 0 : (sa.t + 1) % 96;
+    ta.pv_row = (CHUB_G(const double)) (pp.tb->pvT + t_next * 100);
+    ta.wd_row = (CHUB_G(const double)) (pp.tb->wdT + t_next * 150);
+    ta.hy_table = (CHUB_G(const double)) pp.tb->hy_table;
+    ta.tick_base = hp.tick_base;
+    ta.sin_t = pp.sin96[t_next];
+    ta.key[0] = hp.key[0];
+    ta.key[1] = hp.key[1];
+    ta.gid0 = (uint32_t) hp.env_id0;
+    ta.pad2 = 0;
     ta.ou = (CHUB_G(const double)) ev.ou;
     ta.price_noise = (CHUB_G(const double)) ev.price_noise;
     ta.cap = (CHUB_G(const double)) ev.cap;
@@ -1267,20 +1286,21 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     // the same burst as the state loads: one memory round trip for everything (they are parked in LDS further down)
     double st_pv = 0.0, st_wd = 0.0, st_hy = 0.0;
     uint32_t st_hv = 0;
-    double sin_t = tb.sin96[t_next];  // the observation's time feature: requested here, used at the very end
-    asm volatile("" : "+v"(sin_t));
+    const double sin_t = multi ? tb.sin96[t_next] : ta.sin_t;  // the observation's time feature
     const bool tel_on = hp.telemetry != 0;
     {
         const int i = threadIdx.x;
-        const int tn = RESET ? 0 : (sa.t + 1) % 96;  // lock-step: the launch's clock
-        if (i < 100) st_pv = tb.pvT[tn * 100 + i];
-        if (i < 150) st_wd = tb.wdT[tn * 150 + i];
+        if (!multi) {  // lock-step: the rows of the launch's slot of the day
+            if (i < 100) st_pv = ta.pv_row[i];
+            if (i < 150) st_wd = ta.wd_row[i];
+        }
         if (!RESET) {
-            if (i < 102) st_hy = tb.hy_table[i];
+            if (i < 102) st_hy = ta.hy_table[i];
             if (MODE == MODE_COMPAT && i < kLevels / 4) st_hv = ((CHUB_G(const uint32_t)) tb.cnt_hv)[sa.t * (kLevels / 4) + i];
         }
     }
-    PhiloxCtx px{hp.key[0], hp.key[1], MODE == MODE_PHILOX ? CHUB_TICK(hp, sa.tick) : sa.tick, (uint32_t) (hp.env_id0 + env)};
+    // (the device-side tick offset of graph replays comes by scalar load: it does not hold up the vector loads behind it)
+    PhiloxCtx px{ta.key[0], ta.key[1], MODE == MODE_PHILOX ? sa.tick + sload_u32(ta.tick_base, 0) : sa.tick, ta.gid0 + (uint32_t) env};
     double cap = 0.0, in_re_wd = 0.0, in_re_pv = 0.0, in_price_next = 0.0, in_price_noise = 0.0;
     double ou_pv = 0.0, ou_wd = 0.0, ou_price = 0.0, z_pv = 0.0, z_wd = 0.0, z_pr = 0.0;
     float a_el_f = 0.0f, a_fc_f = 0.0f, P0f = 0.0f, P1f = 0.0f, mn0 = 0.0f, mx0 = 0.0f, mn1 = 0.0f, mx1 = 0.0f;
@@ -2054,7 +2074,7 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
 
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
                 hipEvent_t ev1, const PackedPtrs &pp) {
-    const TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa);
+    const TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa, pp, reset);
     const int nb_env = (int) ((hp.n_envs + kEnvBlock - 1) / kEnvBlock);
     if (hp.rng_mode == MODE_PHILOX) {
         // + the level-draw workgroups: next step's state-independent variates (3 lanes per env: two stations, one env)

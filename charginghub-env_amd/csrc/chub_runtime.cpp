@@ -91,6 +91,7 @@ struct chub_env {
     float *d_packed;              // [N][D+2]
     int tape_classes;   // PHILOX tape mode: caller-registered arrival-SoC classes so far
     uint32_t h_late8[8];
+    double h_sin96[96];
     std::vector<float> h_cls[2], h_soc0[2], h_ttab[2];  // host copies of the class tables (introspection)
     uint32_t *d_tick_base;     // see HubParams::tick_base
     uint32_t graph_base;       // host mirror of *d_tick_base: ticks covered by the graph replays so far
@@ -291,6 +292,8 @@ static PackedPtrs packed_ptrs(const chub_env *e) {
     p.ttab[1] = e->tb.ttab[1];
     p.ttab2 = e->tb.ttab2;
     memcpy(p.late8, e->h_late8, sizeof p.late8);
+    p.tb = &e->tb;
+    p.sin96 = e->h_sin96;
     p.pk[0] = (uint64_t *) e->st.pk[0];
     p.pk[1] = (uint64_t *) e->st.pk[1];
     return p;
@@ -672,6 +675,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if ((rc = dev_upload(e, &e->tb.normal_icdf, nicdf))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.normal_tail, ntail))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.sin96, sin96))) return bail(rc);
+    memcpy(e->h_sin96, sin96.data(), sizeof e->h_sin96);
     if ((rc = dev_upload(e, &e->tb.ttab[0], ttab[0]))) return bail(rc);
     if ((rc = dev_upload(e, &e->tb.ttab[1], ttab[1]))) return bail(rc);
     {
