@@ -82,6 +82,9 @@ struct SlotArrays {          // index = base_k + env*S_k + slot  (station-major)
 struct StationArrays {       // unit index u = k*N + env
     CHUB_G(uint32_t) rec;        // [2N][4] per-unit record written by k_slot: min_power, charge_power, max_power (f32 bits),
                                  // line | flow_in << 8 | car_number << 16  (Station::line, flow_in_number.back(), car_number)
+    CHUB_G(float) tail_act;      // [N][2] PHILOX: the env's two tail actions (electrolyser, fuel cell), copied by the packed slot kernel
+                                 // out of the action row it has just read: the tail kernel reads 8 contiguous bytes per env
+                                 // instead of one 128-byte line per env of the [N, S+2] action matrix
     CHUB_G(uint64_t) pk[2];      // PHILOX: packed state-independent station draws of a step (double-buffered by tick
                                  // parity): bits 0-9 renege pass per queue position, 10-13 arrivals, 14+4j balk limit of arrival j
 };

@@ -786,6 +786,7 @@ struct PackedArgs {
     const uint32_t *tick_base;       // device-side tick offset (graph replays), added to tick
     uint32_t late[8];                // the first 8 thresholds of mk_late_time's table (late_from_word); beyond them with probability 0.3 %
     CHUB_G(const uint8_t) env_mask;  // per-env clocks: non-zero = the launch serves this env (null: every env)
+    CHUB_G(float) tail_act;          // [N][2] out: the env's two tail actions, for the tail kernel (StationArrays::tail_act)
 };
 
 typedef const uint32_t __attribute__((address_space(4))) *chub_sptr;  // constant address space: scalar loads
@@ -1062,6 +1063,12 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         if (env >= N) continue;
         if (pa.env_mask && pa.env_mask[env] == 0) continue;
         const uint32_t su = (uint32_t) (k ? N : 0) + (uint32_t) env;
+        if (!RESET && k == 0) {  // the env's tail actions sit in the lines this workgroup has just read: hand them to the tail kernel packed
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+            const uint32_t ai = ((uint32_t) env * (uint32_t) (St + 2) + (uint32_t) St) << 2;
+            const f32x2_ tv = {CHUB_AT(const float, pa.actions, ai), CHUB_AT(const float, pa.actions, ai + 4u)};
+            CHUB_AT(f32x2_, pa.tail_act, (uint32_t) env << 3) = tv;
+        }
         uint32_t lf = s_unit[i];
         if ((k ? S1 : S0) == 0) {
             // a station without piles still queues, reneges and balks (receive_car runs on it as on any other, CHS.hpp:1272-1316 /
@@ -1134,6 +1141,7 @@ struct TailArgs {
     uint32_t n_envs, act_dim, s_tot, pad;
     // the rows of this slot of the day and what the tail's Philox context needs: nothing in front of the load burst goes
     // through the context pointer (each hop there is a dependent scalar round trip of this latency-bound kernel)
+    CHUB_G(const float) tail_act;  // [N][2] the tail actions as the packed slot kernel left them, or null: read the action rows
     CHUB_G(const double) pv_row;   // pvT + t_next * 100
     CHUB_G(const double) wd_row;   // wdT + t_next * 150
     CHUB_G(const double) hy_table;
@@ -1145,6 +1153,7 @@ inline TailArgs make_tail_args(const EnvArrays &ev, const StationArrays &st, con
                                bool reset) {
     TailArgs ta;
     const int t_next = reset ? 0 : (sa.t + 1) % 96;
+    ta.tail_act = (hp.rng_mode == MODE_PHILOX && hp.packed && !sa.load_mode && !reset) ? (CHUB_G(const float)) st.tail_act : nullptr;
     ta.pv_row = (CHUB_G(const double)) (pp.tb->pvT + t_next * 100);
     ta.wd_row = (CHUB_G(const double)) (pp.tb->wdT + t_next * 150);
     ta.hy_table = (CHUB_G(const double)) pp.tb->hy_table;
@@ -1317,9 +1326,16 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             mn1 = r1.mn; P1f = r1.chg; mx1 = r1.mx; ln1 = pkd_line(r1.pkd); F1i = pkd_flow(r1.pkd);
         }
         if (!RESET) {
-            const uint32_t ai = e32 * ta.act_dim + ta.s_tot;
-            a_el_f = ta.actions[ai];
-            a_fc_f = ta.actions[ai + 1u];
+            if (ta.tail_act) {
+                typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                const f32x2_ tv = ((CHUB_G(const f32x2_)) ta.tail_act)[e32];
+                a_el_f = tv.x;
+                a_fc_f = tv.y;
+            } else {
+                const uint32_t ai = e32 * ta.act_dim + ta.s_tot;
+                a_el_f = ta.actions[ai];
+                a_fc_f = ta.actions[ai + 1u];
+            }
             cap = ta.cap[e32];
             in_re_wd = ta.re_wd[e32];
             in_re_pv = ta.re_pv[e32];
@@ -2049,6 +2065,7 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             pa.tick_base = hp.tick_base;
             for (int j = 0; j < 8; j++) pa.late[j] = pp.late8[j];
             pa.env_mask = (CHUB_G(const uint8_t)) sa.env_mask;
+            pa.tail_act = (CHUB_G(float)) pp.st->tail_act;
             const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
 #define CHUB_PACKED(TAPE_, RESET_, BIG_) \
     CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, TAPE_, RESET_, BIG_>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa)

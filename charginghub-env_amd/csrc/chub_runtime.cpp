@@ -712,7 +712,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     } else {
         ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.init_soc, NS);
     }
-    ALLOC(e->st.rec, 8 * N); ALLOC(e->st.pk[0], 2 * N); ALLOC(e->st.pk[1], 2 * N);
+    ALLOC(e->st.rec, 8 * N); ALLOC(e->st.pk[0], 2 * N); ALLOC(e->st.pk[1], 2 * N); ALLOC(e->st.tail_act, 2 * N);
     ALLOC(e->ev.cap, N); ALLOC(e->ev.store_soc, N); ALLOC(e->ev.ou, 3 * N); ALLOC(e->ev.price_noise, N);
     ALLOC(e->ev.re_pv, N); ALLOC(e->ev.re_wd, N); ALLOC(e->ev.price_next, N);
     ALLOC(e->ev.pv_day, N); ALLOC(e->ev.wd_day, N); ALLOC(e->ev.q_len, N); ALLOC(e->ev.hv_line, N);
