@@ -303,7 +303,7 @@ class StaggeredHub(object):
     Two forms.  The default keeps one hub per group: every group is bit-identical to a plain hub over the same global env
     range given the same head start.  ``one_handle=True`` runs all N envs in ONE hub with per-env clocks
     (``reset_envs`` / ``step_envs``, include/chub.h): one allocation, one launch per call whatever the number of groups
-    (65 536 envs in 8 groups: 1.8 G env-steps/s on the device-pointer path); its Philox ticks count the handle's calls, so
+    (65 536 envs in 8 groups: 1.9 G env-steps/s on the device-pointer path); its Philox ticks count the handle's calls, so
     its random streams differ from the per-group form's (same distribution).
     """
 
