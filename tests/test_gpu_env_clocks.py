@@ -96,10 +96,20 @@ class Pair(object):
         self.v.close()
 
 
-@pytest.mark.parametrize("slot_kernel", ["auto", "wave"])
-def test_subset_resets_and_steps_match_the_oracle(slot_kernel):
+SHAPES = {
+    "auto": (KW, "auto"),
+    "wave": (KW, "wave"),                                                   # the wave-local slot kernel
+    "big": (dict(KW, station_list=[100, 70]), "auto"),                      # units spanning several waves (BIG instantiation)
+    "tiny": (dict(KW, station_list=[1, 2]), "auto"),                        # fewer than 4 piles: always the wave-local kernel
+    "one_station": (dict(KW, station_list=[0, 9], fcev_permeate=0.05), "auto"),
+}
+
+
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+def test_subset_resets_and_steps_match_the_oracle(shape):
+    kw, slot_kernel = SHAPES[shape]
     n = 44
-    p = Pair(KW, n, slot_kernel)
+    p = Pair(kw, n, slot_kernel)
     idx = np.arange(n)
     p.reset(label="all")
     for i in range(6):
