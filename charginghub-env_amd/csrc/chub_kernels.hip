@@ -1964,29 +1964,41 @@ __global__ void k_replay_soc(const DevCtx *__restrict__ ctx, float *out) {
 // thinned by the balk test of an empty queue -- drawn once per unit here (every lane of the unit used to redo it),
 // handed to k_slot<RESET> through this tick's pk word: arrivals | arrivals that stay << 8.
 __global__ void k_reset_levels(const DevCtx *__restrict__ ctx, StepArgs sa) {
+    // four lanes per unit: lane q takes the Philox blocks q, q + 4, ... of the unit's arrival words (four arrivals each), the
+    // quad adds up.  (One lane per unit walking all its arrivals was a 15-iteration dependent chain at two waves per SIMD:
+    // 20 us per reset.)
     const uint32_t tick = sa.tick;
     const HubParams &hp = ctx->hp;
     const Tables &tb = ctx->tb;
     const int64_t N = hp.n_envs;
-    const int64_t u = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= 2 * N) return;
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t u = t >> 2;
+    const int q = (int) (t & 3);
+    const bool live = u < 2 * N;
     const int k = u >= N ? 1 : 0;
-    const int64_t env = u - (int64_t) k * N;
-    if (!in_group(sa, env)) return;
+    const int64_t env = live ? u - (int64_t) k * N : 0;
+    const bool served = live && in_group(sa, env);
     const int S = hp.S[k], mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
     PhiloxCtx px{hp.key[0], hp.key[1], CHUB_TICK(hp, tick), (uint32_t) (hp.env_id0 + env)};
-    U4 b = px.block(SITE_ARRIVE, (uint32_t) k, 0);
     const float cn = __fadd_rn(normal_from_word(tb.normal_icdf, tb.normal_tail, px.block(SITE_INIT, (uint32_t) k, 0).v[0]), (float) mu);
     int n_in = (int) roundf(cn);
     n_in = n_in > mu + 3 ? mu + 3 : (n_in < mu - 3 ? mu - 3 : n_in);
     int true_in = 0;
-    for (int j = 0; j < n_in; j++) {  // arrival j stays iff u <= expf(-0.01*(line+j)) and j <= S
-        const int wi = 1 + j;
-        if ((wi & 3) == 0) b = px.block(SITE_ARRIVE, (uint32_t) k, (uint32_t) (wi >> 2));
-        const int thr = (int) tb.thr_balk[j < kBalkTab ? j : kBalkTab - 1];
-        true_in += ((int) (pick(b, wi & 3) % 1000u) <= thr && j <= S) ? 1 : 0;
+    // arrival j (word 1 + j of the unit's SITE_ARRIVE stream) stays iff u <= expf(-0.01*(line+j)) and j <= S
+    for (int blk = q; served && 4 * blk <= n_in; blk += 4) {
+        const U4 b = px.block(SITE_ARRIVE, (uint32_t) k, (uint32_t) blk);
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int j = 4 * blk + w - 1;
+            if (j < 0 || j >= n_in) continue;
+            const int thr = (int) tb.thr_balk[j < kBalkTab ? j : kBalkTab - 1];
+            true_in += ((int) (b.v[w] % 1000u) <= thr && j <= S) ? 1 : 0;
+        }
     }
-    ctx->st.pk[tick & 1u][u] = (uint64_t) (((uint32_t) n_in & 0xFFFFu) | ((uint32_t) true_in << 16));  // n_in: signed 16 bits
+    true_in += __shfl_xor(true_in, 1);
+    true_in += __shfl_xor(true_in, 2);
+    if (served && q == 0)
+        ctx->st.pk[tick & 1u][u] = (uint64_t) (((uint32_t) n_in & 0xFFFFu) | ((uint32_t) true_in << 16));  // n_in: signed 16 bits
 }
 
 // fresh launches (StepArgs::fresh): this step's station-level draws, made right in front of the slot kernel -- what the
@@ -2023,7 +2035,7 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
     constexpr int BLOCK = 256;
     const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
     if (MODE == MODE_PHILOX) {
-        if (RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
+        if (RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((8 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
         CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, ev1, ctx, sa, nb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
@@ -2041,7 +2053,7 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
     if (hp.rng_mode == MODE_PHILOX) {
         if (hp.packed && !sa.load_mode) {
             if (reset)
-                hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
+                hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((8 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
             PackedArgs pa;
             for (int k = 0; k < 2; k++) {
                 pa.S[k] = (uint32_t) hp.S[k];
