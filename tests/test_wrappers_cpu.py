@@ -151,6 +151,78 @@ class ClockHub(FakeHub):
         return self.t
 
 
+class PerEnvClockHub(object):
+    """a hub with per-env clocks (the part of VecChargingHub the one-handle StaggeredHub uses): obs[:, 0] = clock, obs[:, 1] = episode"""
+
+    def __init__(self, n, station_list, station_type_list, seed=0, env_id0=0, **kw):
+        self.n_envs, self.piles = n, tuple(station_list)
+        self.act_dim, self.obs_dim = sum(self.piles) + 2, 13
+        self.t = np.zeros(n, dtype=np.int64)
+        self.ep = np.zeros(n, dtype=np.int64)
+        self.calls, self.closed = [], False
+
+    def _obs(self):
+        o = np.zeros((self.n_envs, self.obs_dim), dtype=np.float32)
+        o[:, 0], o[:, 1] = self.t, self.ep
+        return o
+
+    def reset(self):
+        return self.reset_envs(np.ones(self.n_envs, dtype=bool))
+
+    def reset_envs(self, mask):
+        m = np.asarray(mask, dtype=bool)
+        self.calls.append(("reset", int(m.sum())))
+        self.t[m] = 0
+        self.ep[m] += 1
+        return self._obs()
+
+    def step(self, actions):
+        return self.step_envs(np.ones(self.n_envs, dtype=bool), actions)
+
+    def step_envs(self, mask, actions):
+        assert np.asarray(actions).shape == (self.n_envs, self.act_dim)
+        m = np.asarray(mask, dtype=bool)
+        self.calls.append(("step", int(m.sum())))
+        self.t[m] = (self.t[m] + 1) % 96
+        return self._obs(), np.ones(self.n_envs, dtype=np.float32), m & (self.t == 0), {}
+
+    def env_clocks(self):
+        return self.t.copy()
+
+    def close(self):
+        self.closed = True
+
+
+def test_staggered_groups_on_one_handle():
+    """one_handle=True: the same schedule as one hub per group, driven through reset_envs / step_envs of a single hub"""
+    st = wrappers.StaggeredHub(8, 4, [2, 3], ["fast", "slow"], seed=1, env_id0=100, hub_factory=PerEnvClockHub, one_handle=True)
+    assert st.hub is not None and st.hub.n_envs == 8
+    obs = st.reset()
+    assert list(obs[::2, 0]) == [0, 24, 48, 72] and st.clocks == [0, 24, 48, 72]
+    # the head start: the k-th extra step moves every group that is at least k slots ahead
+    assert st.hub.calls[0] == ("reset", 8) and st.hub.calls[1:25] == [("step", 6)] * 24 and st.hub.calls[25:49] == [("step", 4)] * 24
+    assert st.hub.calls[49:73] == [("step", 2)] * 24 and len(st.hub.calls) == 73
+    a = np.zeros((8, 7), dtype=np.float32)
+    seen = []
+    for t in range(1, 100):
+        obs, rew, done, info = st.step(a)
+        for g in range(4):
+            ended = (t + st.offsets[g]) % 96 == 0
+            assert done[2 * g] == ended and done[2 * g + 1] == ended
+            if ended:
+                seen.append((t, g))
+                assert info["reset_groups"] == [g] and obs[2 * g, 0] == 0 and obs[2 * g, 1] == 2
+                assert info["terminal_observation"][2 * g, 0] == 0 and info["terminal_observation"][2 * g, 1] == 1
+                assert not info["terminal_observation"][[i for i in range(8) if i // 2 != g]].any()
+            else:
+                assert obs[2 * g, 0] == (t + st.offsets[g]) % 96
+        if not any((t + o) % 96 == 0 for o in st.offsets):
+            assert info == {}
+    assert seen == [(24, 3), (48, 2), (72, 1), (96, 0)]
+    st.close()
+    assert st.hub.closed
+
+
 def test_staggered_groups():
     st = wrappers.StaggeredHub(8, 4, [2, 3], ["fast", "slow"], seed=1, env_id0=100, hub_factory=ClockHub)
     assert [h.env_id0 for h in st.hubs] == [100, 102, 104, 106] and st.offsets == [0, 24, 48, 72]
