@@ -85,8 +85,8 @@ def load_library():
         "chub_reset_device": (I, [P, P, P, P, P]),
         "chub_step_device": (I, [P, P, P, P, P, P, P]),
         "chub_step_device_packed": (I, [P, P, P, P, P]),
-        "chub_reset_envs": (I, [P, P, P]), "chub_step_envs": (I, [P, P, P, P, P, P]), "chub_reset_envs_device": (I, [P, P, P, P]),
-        "chub_step_envs_device": (I, [P, P, P, P, P, P, P]), "chub_env_clocks": (I, [P, P, P]), "chub_clock_groups": (I, [P]),
+        "chub_reset_envs": (I, [P, P, P, P, P]), "chub_step_envs": (I, [P, P, P, P, P, P, P]), "chub_reset_envs_device": (I, [P, P, P, P, P, P]),
+        "chub_step_envs_device": (I, [P, P, P, P, P, P, P, P]), "chub_env_clocks": (I, [P, P, P]), "chub_clock_groups": (I, [P]),
         "chub_step_load": (I, [P, P, P, P, P, P]), "chub_step_load_device": (I, [P, P, P, P, P, P, P]),
         "chub_random_actions_device": (I, [P, C.c_uint64, C.c_uint32, P, P]),
         "chub_sync": (I, [P]),

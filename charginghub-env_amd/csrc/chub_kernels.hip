@@ -472,7 +472,7 @@ __device__ void slot_body_compat(const HubParams &hp, const StepArgs &sa, const 
     // 32-bit indices: n_envs * (piles + 2) < 2^31 is checked at create
     const int env_first = (int) block_local * (WAVES * upw);
     const int env = env_first + wave * upw + uiw;
-    const bool unit_ok = env < (int) N;
+    const bool unit_ok = env < (int) N && in_group(sa, env);
     const bool valid = unit_ok && slot < S;
     const uint64_t unit_mask = (H == 64) ? ~0ull : (((1ull << H) - 1ull) << (uiw << logH));
     const uint32_t idx = (uint32_t) hp.base[k] + (uint32_t) env * (uint32_t) S + (uint32_t) slot;
@@ -541,7 +541,8 @@ __device__ void slot_body_compat(const HubParams &hp, const StepArgs &sa, const 
             temp = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
             n_in = temp;
         } else {
-            n_in = (int) tb.cnt[k][sa.t * kLevels + rs.level()];
+            const int t_env = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;  // per-env clocks: the env's own slot of day
+            n_in = (int) tb.cnt[k][t_env * kLevels + rs.level()];
         }
         int tline = 0;
         for (int w = 0; w < line; w++) tline += (rs.level() >= (int) tb.thr_renege[w]) ? 1 : 0;
@@ -1286,7 +1287,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 #define TAB_PV(d) (multi ? tb.pvT[t_next * 100 + (d)] : s_pv[d])
 #define TAB_WD(d) (multi ? tb.wdT[t_next * 150 + (d)] : s_wd[d])
 #define TAB_HY(i) (MODE == MODE_COMPAT ? hy_env[i] : s_hy[i])
-#define TAB_HV(l) (s_hv[l])
+#define TAB_HV(l) (multi ? tb.cnt_hv[(uint32_t) t_now * (uint32_t) kLevels + (uint32_t) (l)] : s_hv[l])
     // ---- prefetch: every per-env input is requested before the table staging and its barrier, and the PHILOX
     // words that do not depend on state (FCEV arrival level, the three OU normals) are drawn here too, so the
     // memory latencies of this latency-bound kernel overlap instead of queueing behind one another.
@@ -1305,7 +1306,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         }
         if (!RESET) {
             if (i < 102) st_hy = ta.hy_table[i];
-            if (MODE == MODE_COMPAT && i < kLevels / 4) st_hv = ((CHUB_G(const uint32_t)) tb.cnt_hv)[sa.t * (kLevels / 4) + i];
+            if (MODE == MODE_COMPAT && !multi && i < kLevels / 4) st_hv = ((CHUB_G(const uint32_t)) tb.cnt_hv)[sa.t * (kLevels / 4) + i];
         }
     }
     // (the device-side tick offset of graph replays comes by scalar load: it does not hold up the vector loads behind it)
@@ -2114,7 +2115,10 @@ void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepAr
         } else if (reset) CHUB_LAUNCH((k_env<true, MODE_PHILOX, false>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
         else CHUB_LAUNCH((k_env<false, MODE_PHILOX, false>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
     } else {
-        if (reset) CHUB_LAUNCH((k_env<true, MODE_COMPAT, false>), dim3((unsigned) nb_env), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
+        if (sa.env_clk) {  // per-env clocks
+            if (reset) CHUB_LAUNCH((k_env<true, MODE_COMPAT, true>), dim3((unsigned) nb_env), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
+            else CHUB_LAUNCH((k_env<false, MODE_COMPAT, true>), dim3((unsigned) nb_env), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
+        } else if (reset) CHUB_LAUNCH((k_env<true, MODE_COMPAT, false>), dim3((unsigned) nb_env), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
         else CHUB_LAUNCH((k_env<false, MODE_COMPAT, false>), dim3((unsigned) nb_env), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
     }
 }

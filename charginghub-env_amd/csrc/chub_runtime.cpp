@@ -818,8 +818,6 @@ static int serve_mask(chub_env *e, const uint8_t *mask, hipStream_t s, int &serv
     }
     served = n_masked == 0 ? 0 : (n_masked == N ? 2 : 1);
     if (served != 1) return CHUB_OK;
-    if (e->hp.rng_mode != CHUB_RNG_PHILOX)
-        return fail(CHUB_ERR_UNSUPPORTED, "per-env clocks need a PHILOX handle (the COMPAT streams are replayed in lock-step)");
     if (e->capturing) return fail(CHUB_ERR_ARG, "a graph capture covers calls on every env only");
     if (e->tape_pk) return fail(CHUB_ERR_ARG, "tape mode runs in lock-step");
     if (!e->per_env) {  // every env starts from the lock-step clock, in the buffer the next launch reads
@@ -905,9 +903,9 @@ int chub_reset_device(chub_env *e, const int32_t *d_exo_days, const double *d_ex
     return reset_masked(e, nullptr, d_exo_days, d_exo_z, d_obs, stream);
 }
 
-int chub_reset_envs_device(chub_env *e, const uint8_t *mask, float *d_obs, void *stream) {
+int chub_reset_envs_device(chub_env *e, const uint8_t *mask, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs, void *stream) {
     if (!mask) return fail(CHUB_ERR_ARG, "null argument");
-    return reset_masked(e, mask, nullptr, nullptr, d_obs, stream);
+    return reset_masked(e, mask, d_exo_days, d_exo_z, d_obs, stream);
 }
 
 static int step_common(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, int obs_stride,
@@ -1030,18 +1028,26 @@ static int step_common(chub_env *e, const float *d_actions, const double *d_exo_
     return step_masked(e, nullptr, d_actions, d_exo_z, d_obs, obs_stride, d_reward, reward_stride, d_done, d_done_f32, stream, load_mode);
 }
 
-int chub_step_envs_device(chub_env *e, const uint8_t *mask, const float *d_actions, float *d_obs, float *d_reward, uint8_t *d_done,
-                          void *stream) {
+int chub_step_envs_device(chub_env *e, const uint8_t *mask, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
+                          uint8_t *d_done, void *stream) {
     if (!e || !mask || !d_actions || !d_obs || !d_reward || !d_done) return fail(CHUB_ERR_ARG, "null argument");
-    return step_masked(e, mask, d_actions, nullptr, d_obs, e->hp.obs_dim, d_reward, 1, d_done, nullptr, stream, 0);
+    return step_masked(e, mask, d_actions, d_exo_z, d_obs, e->hp.obs_dim, d_reward, 1, d_done, nullptr, stream, 0);
 }
 
 // host-pointer forms: full-size arrays, only the rows of the named envs are read and written
-int chub_reset_envs(chub_env *e, const uint8_t *mask, float *obs) {
+int chub_reset_envs(chub_env *e, const uint8_t *mask, const int32_t *exo_days, const double *exo_z, float *obs) {
     if (!e || !mask || !obs) return fail(CHUB_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     const size_t N = (size_t) e->hp.n_envs, D = (size_t) e->hp.obs_dim;
-    int rc = chub_reset_envs_device(e, mask, e->d_obs, nullptr);
+    if (e->hp.rng_mode == CHUB_RNG_COMPAT) {  // as chub_reset: the values of the envs outside the mask are not looked at
+        if (!exo_days || !exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_days and exo_z");
+        for (size_t i = 0; i < N; i++)
+            if (mask[i] && (exo_days[2 * i] < 0 || exo_days[2 * i] >= 100 || exo_days[2 * i + 1] < 0 || exo_days[2 * i + 1] >= 150))
+                return fail(CHUB_ERR_ARG, "exo_days out of range");
+        HIP_TRY(hipMemcpy(e->d_exo_days, exo_days, N * 2 * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    int rc = chub_reset_envs_device(e, mask, e->d_exo_days, e->d_exo_z, e->d_obs, nullptr);
     if (rc) return rc;
     std::vector<float> o(N * D);
     HIP_TRY(hipMemcpy(o.data(), e->d_obs, o.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -1050,12 +1056,16 @@ int chub_reset_envs(chub_env *e, const uint8_t *mask, float *obs) {
     return CHUB_OK;
 }
 
-int chub_step_envs(chub_env *e, const uint8_t *mask, const float *actions, float *obs, float *reward, uint8_t *done) {
+int chub_step_envs(chub_env *e, const uint8_t *mask, const float *actions, const double *exo_z, float *obs, float *reward, uint8_t *done) {
     if (!e || !mask || !actions || !obs || !reward || !done) return fail(CHUB_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     const size_t N = (size_t) e->hp.n_envs, A = (size_t) e->hp.act_dim, D = (size_t) e->hp.obs_dim;
     HIP_TRY(hipMemcpy(e->d_actions, actions, N * A * sizeof(float), hipMemcpyHostToDevice));
-    int rc = chub_step_envs_device(e, mask, e->d_actions, e->d_obs, e->d_reward, e->d_done, nullptr);
+    if (e->hp.rng_mode == CHUB_RNG_COMPAT) {
+        if (!exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
+        HIP_TRY(hipMemcpy(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    int rc = chub_step_envs_device(e, mask, e->d_actions, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, nullptr);
     if (rc) return rc;
     std::vector<float> o(N * D), r(N);
     std::vector<uint8_t> d(N);

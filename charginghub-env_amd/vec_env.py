@@ -157,21 +157,24 @@ class VecChargingHub(object):
             raise AssertionError("mask must have shape (%d,)" % self.n_envs)
         return m
 
-    def reset_envs(self, mask):
+    def reset_envs(self, mask, exo_days=None, exo_z=None):
         """reset the envs of `mask`; returns the current observation of every env ([N, D]: fresh rows for the envs of the
-        mask, the others as their last call left them)"""
+        mask, the others as their last call left them).  exo_days / exo_z: as for reset() (COMPAT handles)"""
         m = self._mask(mask)
-        check(self._lib.chub_reset_envs(self._h, _ptr(m), _ptr(self._obs)))
+        d = np.ascontiguousarray(exo_days, dtype=np.int32) if exo_days is not None else None
+        z = np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)) if exo_z is not None else None
+        check(self._lib.chub_reset_envs(self._h, _ptr(m), _ptr(d), _ptr(z), _ptr(self._obs)))
         return self._obs.copy()
 
-    def step_envs(self, mask, actions):
+    def step_envs(self, mask, actions, exo_z=None):
         """step the envs of `mask` only ([N, A] actions, the other rows are ignored); returns full-size obs, reward, done with
         the rows of the other envs as their last call left them"""
         m = self._mask(mask)
         a = np.ascontiguousarray(actions, dtype=np.float32)
         if a.shape != (self.n_envs, self.act_dim):  # MGR:148
             raise AssertionError("actions must have shape (%d, %d)" % (self.n_envs, self.act_dim))
-        check(self._lib.chub_step_envs(self._h, _ptr(m), _ptr(a), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
+        z = np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)) if exo_z is not None else None
+        check(self._lib.chub_step_envs(self._h, _ptr(m), _ptr(a), _ptr(z), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
         return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
 
     def env_clocks(self, ticks=False):

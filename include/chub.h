@@ -125,16 +125,18 @@ int chub_step_device(chub_env *env, const float *d_actions, const double *d_exo_
 /* Per-env clocks.  Every reference env is its own object with its own clock: any one of them can be reset, or stepped,
  * while the others are not (MGR:137-140, 271-273, 299, 304-316).  These entry points take a host array mask[n_envs]
  * (non-zero = the env takes part) next to full-size [n_envs, ...] arrays of which only the rows of the named envs are
- * read and written.  PHILOX handles.  The first such call makes the clock two bytes of per-env device state; a call is
+ * read and written (exo_days / exo_z as for chub_reset / chub_step: COMPAT handles only).  The first such call makes the clock two bytes of per-env device state; a call is
  * still ONE launch (one Philox tick) in which every env it names runs on its own clock, and lock-step use -- chub_reset /
  * chub_step on everybody -- costs what it did.  chub_reset of everybody brings all envs back onto one clock.
  * chub_env_clocks: slot of day of every env and (tick_out may be NULL) the Philox tick of its last launch;
  * chub_clock_groups: number of distinct clocks right now.  (Both read the device: they synchronise.) */
-int chub_reset_envs(chub_env *env, const uint8_t *mask, float *obs);
-int chub_step_envs(chub_env *env, const uint8_t *mask, const float *actions, float *obs, float *reward, uint8_t *done);
-int chub_reset_envs_device(chub_env *env, const uint8_t *mask /* host */, float *d_obs, void *stream);
-int chub_step_envs_device(chub_env *env, const uint8_t *mask /* host */, const float *d_actions, float *d_obs, float *d_reward,
-                          uint8_t *d_done, void *stream);
+int chub_reset_envs(chub_env *env, const uint8_t *mask, const int32_t *exo_days, const double *exo_z, float *obs);
+int chub_step_envs(chub_env *env, const uint8_t *mask, const float *actions, const double *exo_z, float *obs, float *reward,
+                   uint8_t *done);
+int chub_reset_envs_device(chub_env *env, const uint8_t *mask /* host */, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs,
+                           void *stream);
+int chub_step_envs_device(chub_env *env, const uint8_t *mask /* host */, const float *d_actions, const double *d_exo_z, float *d_obs,
+                          float *d_reward, uint8_t *d_done, void *stream);
 int chub_env_clocks(chub_env *env, int32_t *t_out, uint32_t *tick_out);
 int chub_clock_groups(chub_env *env);
 

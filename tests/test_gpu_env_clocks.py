@@ -241,3 +241,81 @@ def test_staggered_hub_on_one_handle():
     assert st.hub.fcev_stuck_count() == 0
     st.close()
     ref.close()
+
+
+@pytest.mark.parametrize("name", ["env_c3_random", "env_slow_only_fcev", "env_small_fast_neg", "env_fcev_queue"])
+def test_compat_envs_replay_the_reference_fixture_on_their_own_clocks(name):
+    """The reference's own recorded trajectories, with every env of ONE handle on its own clock: env e runs the fixture's
+    sequence of calls (the constructor's reset, then per episode reseed / reset / steps) `lag[e]` calls behind env 0, so at
+    most library calls some envs are reset while others step, each at its own slot of day -- and every env must still equal
+    the recorded single-env run bit for bit (COMPAT streams; tests/golden, recorded from the unmodified reference)."""
+    from test_gpu_parity import kwargs_of
+    chub = hub()
+    g = orclib.load_golden(name)
+    kw = kwargs_of(g)
+    lags = [0, 3, 7, 20]
+    n = len(lags)
+    v = chub.VecChargingHub(n, rng="compat", **kw)
+    scratch = chub.VecChargingHub(1, rng="compat", **kw)  # turns a seed pair into stream states
+    v.set_telemetry(True)
+    A, D = v.act_dim, v.obs_dim
+    rep = lambda a: np.repeat(np.asarray(a)[None, :], n, axis=0)
+    v.set_compat_seeds(rep(g["ctor_seeds"]))
+    v.compat_replay_constructor()                          # before any clock matters: the same for every env
+    seeds = {int(ep): (int(a), int(b)) for ep, a, b in g["seeds"]}
+    steps = int(g["steps_per_episode"])
+    prog = [("reset", g["ctor_days"], g["ctor_z"], None)]  # the constructor's reset (MGR:120)
+    i = 0
+    for ep in range(int(g["episodes"])):
+        prog.append(("reset", g["reset_days"][ep], g["reset_z"][ep], ep))
+        for t in range(steps):
+            prog.append(("step", i))
+            i += 1
+    checked = 0
+    for tau in range(len(prog) + max(lags)):
+        ops = {e: prog[tau - lag] for e, lag in enumerate(lags) if 0 <= tau - lag < len(prog)}
+        resets = [e for e, op in ops.items() if op[0] == "reset"]
+        movers = [e for e, op in ops.items() if op[0] == "step"]
+        if resets:
+            mask = np.zeros(n, dtype=bool)
+            days, z = np.zeros((n, 2), dtype=np.int32), np.zeros((n, 3))
+            for e in resets:
+                _, d_, z_, ep = ops[e]
+                if ep is not None and ep in seeds:       # e.seed() / srand() of this env only
+                    scratch.set_compat_seeds([seeds[ep]])
+                    st = v.compat_state()
+                    st[e] = scratch.compat_state()[0]
+                    v.set_compat_state(st)
+                mask[e], days[e], z[e] = True, d_, z_
+            v.reset_envs(mask, days, z)
+            o64, sc = v.obs_f64(), v.station_scalars()
+            for e in resets:
+                ep = ops[e][3]
+                if ep is None:
+                    continue
+                close(o64[e], g["reset_obs"][ep], (name, "reset obs", e, ep), rtol=TIGHT, atol=TIGHT)
+                got = np.concatenate([sc[e, 0, :6], sc[e, 1, :6]])
+                assert np.array_equal(got, g["reset_stations"][ep]), (name, "reset stations", e, ep, got)
+        if movers:
+            mask = np.zeros(n, dtype=bool)
+            act, z = np.zeros((n, A), dtype=np.float32), np.zeros((n, 3))
+            for e in movers:
+                k = ops[e][1]
+                mask[e], act[e], z[e] = True, g["action"][k], g["exo_z"][k]
+            obs, rew, done, _ = v.step_envs(mask, act, z)
+            sl, sc, tel, o64, r64 = v.slots(), v.station_scalars(), v.telemetry(), v.obs_f64(), v.reward_f64()
+            for e in movers:
+                k = ops[e][1]
+                check_slots(sl[0][e], g["slots0"][k], (name, e, k, "station0"))
+                check_slots(sl[1][e], g["slots1"][k], (name, e, k, "station1"))
+                got = np.concatenate([sc[e, 0, :6], sc[e, 1, :6]])
+                assert np.array_equal(got, g["stations"][k]), (name, e, k, got, g["stations"][k])
+                assert bool(done[e]) == bool(g["done"][k])
+                assert np.array_equal(tel[e, 19:22], g["telem"][k][19:22]), (name, e, k, "fcev ints")
+                close(o64[e], g["obs"][k], (name, "obs", e, k), rtol=TIGHT, atol=TIGHT)
+                close(r64[e], g["reward"][k], (name, "reward", e, k), rtol=TIGHT, atol=TIGHT)
+                close(tel[e, :19], g["telem"][k][:19], (name, "telemetry", e, k), rtol=TIGHT, atol=1e-7)
+                checked += 1
+    assert checked == n * i and v.clock_groups >= 1
+    v.close()
+    scratch.close()

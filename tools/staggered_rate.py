@@ -33,7 +33,7 @@ def run(steps, staggered):
         t_grp = (t_grp + 1) % 96
         for g in np.nonzero(t_grp == 0)[0]:
             if staggered:
-                check(lib.chub_reset_envs_device(h, masks[g].ctypes.data, obs.ptr, None))
+                check(lib.chub_reset_envs_device(h, masks[g].ctypes.data, None, None, obs.ptr, None))
             else:
                 v.reset_device(obs.ptr)
                 break
@@ -46,7 +46,7 @@ print("lock-step: %.1f us per step (%d clocks)" % (run(960, False), v.clock_grou
 v.reset_device(obs.ptr)
 for k in range(1, 96 * (G - 1) // G + 1):  # head starts: group g ends up g * 96 / G slots ahead
     m = np.ascontiguousarray(grp * 96 // G >= k, dtype=np.uint8)
-    check(lib.chub_step_envs_device(h, m.ctypes.data, acts[k % 4].ptr, obs.ptr, rew.ptr, done.ptr, None))
+    check(lib.chub_step_envs_device(h, m.ctypes.data, acts[k % 4].ptr, None, obs.ptr, rew.ptr, done.ptr, None))
 v.sync()
 print("clocks:", sorted(set(v.env_clocks().tolist())), v.clock_groups)
 us = run(960, True)
