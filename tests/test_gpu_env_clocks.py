@@ -319,3 +319,32 @@ def test_compat_envs_replay_the_reference_fixture_on_their_own_clocks(name):
     assert checked == n * i and v.clock_groups >= 1
     v.close()
     scratch.close()
+
+
+def test_scalar_load_steps_while_envs_are_on_their_own_clocks():
+    """evs_step(float) (one kW target per station) steps every env of a handle whose envs show different slots of day"""
+    n = 40
+    p = Pair(dict(KW, renew_fluctuate=0.0, price_fluctuate=0.0, hydro_loss=0.0), n)
+    p.reset(label="all")
+    for i in range(5):
+        p.step(label=("lock-step", i))
+    p.reset(np.arange(n) % 3 == 1, "a third of the envs")
+    p.step(np.arange(n) < n // 2, "half of the envs")
+    assert p.v.clock_groups == 4
+    rs = np.random.RandomState(6)
+    for t in range(12):
+        sc = p.v.station_scalars()
+        loads = np.stack([rs.uniform(0, 1.2, n) * (sc[:, 0, 2] + 1.0), rs.uniform(0, 1.2, n) * (sc[:, 1, 2] + 1.0)], axis=1).astype(np.float32)
+        tail = rs.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+        act = p.v.load_actions(loads, tail)
+        obs, rew, done, _ = p.v.step_load(loads, tail)
+        _, ticks = p.v.env_clocks(ticks=True)
+        for e in range(n):
+            p._oracle_tick(e, ticks[e])
+            d, r = C.c_int(0), C.c_double(0.0)
+            orc.orc_env_step_load(orc.orc_vec_env(p.h, e), ptr(act[e]), None, ptr(p.o_obs[e]), C.byref(r), C.byref(d))
+            p.o_rew[e], p.o_done[e] = r.value, d.value
+        p.t = (p.t + 1) % 96
+        assert np.array_equal(p.v.env_clocks(), p.t)
+        p._compare(np.arange(n), ("load step", t), True)
+    p.close()
