@@ -46,9 +46,11 @@ def _ptr(a):
 
 class VecChargingHub(object):
     def __init__(self, n_envs, station_list, station_type_list, seed=0, rng="philox", device=0, env_id0=0,
-                 data_dir=None, slot_kernel="auto", no_arena=False, **kwargs):
+                 data_dir=None, slot_kernel="auto", no_arena=False, copy_outputs=True, **kwargs):
         """slot_kernel: "auto" (the packed slot kernel wherever the hub shape allows), "wave" (the wave-local one for
-        every step) or "packed"; no_arena: one device allocation per array (no snapshots) -- chub_options."""
+        every step) or "packed"; no_arena: one device allocation per array (no snapshots) -- chub_options.
+        copy_outputs=False: reset() / step() return the handle's own pinned arrays (valid until the next call) instead of
+        fresh copies -- at 65 536 envs the copies are a third of a host-pointer step."""
         kwargs.pop("seed_rand", None)
         kwargs.pop("use_lagrange", None)  # ignored by the reference too (MGR:126)
         self._lib = load_library()
@@ -61,6 +63,7 @@ class VecChargingHub(object):
         opt = ChubOptions()
         opt.slot_kernel = _lib.SLOT_KERNELS[slot_kernel]
         opt.no_arena = int(bool(no_arena))
+        self._copy_outputs = bool(copy_outputs)
         check(self._lib.chub_create_ex(C.byref(self.cfg), (data_dir or _lib.DATA_DIR).encode(), self.n_envs, int(env_id0),
                                        int(device), int(seed) & 0xFFFFFFFFFFFFFFFF, self.rng_mode, C.byref(opt), C.byref(h)))
         self._h = h
@@ -85,12 +88,17 @@ class VecChargingHub(object):
         a[...] = 0
         return a
 
+    def _out(self):
+        if self._copy_outputs:
+            return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
+        return self._obs, self._reward, self._done.view(np.bool_), {}
+
     # ---- hot path
     def reset(self, exo_days=None, exo_z=None):
         d = None if exo_days is None else np.ascontiguousarray(exo_days, dtype=np.int32).reshape(self.n_envs, 2)
         z = None if exo_z is None else np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)).reshape(self.n_envs, 3)
         check(self._lib.chub_reset(self._h, _ptr(d), _ptr(z), _ptr(self._obs)))
-        return self._obs.copy()
+        return self._obs.copy() if self._copy_outputs else self._obs
 
     def step(self, actions, exo_z=None):
         a = np.ascontiguousarray(actions, dtype=np.float32)
@@ -98,7 +106,7 @@ class VecChargingHub(object):
             raise AssertionError("actions must have shape (%d, %d)" % (self.n_envs, self.act_dim))
         z = None if exo_z is None else np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)).reshape(self.n_envs, 3)
         check(self._lib.chub_step(self._h, _ptr(a), _ptr(z), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
-        return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
+        return self._out()
 
     def pinned_actions(self):
         """the handle's pinned [N, A] f32 action buffer as a numpy array: fill it in place and pass it to step() to save the
@@ -126,7 +134,7 @@ class VecChargingHub(object):
         a = self.load_actions(loads, tail)
         z = None if exo_z is None else np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)).reshape(self.n_envs, 3)
         check(self._lib.chub_step_load(self._h, _ptr(a), _ptr(z), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
-        return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
+        return self._out()
 
     # ---- tape mode (parity instrument, see include/chub.h): recorded decisions through the production kernels
     def tape_register_soc(self, soc):
@@ -148,7 +156,7 @@ class VecChargingHub(object):
         pk = np.ascontiguousarray(pk_tape, dtype=np.uint64).reshape(2, self.n_envs)
         ct = np.ascontiguousarray(car_tape, dtype=np.uint32).reshape(self.n_envs, self.n_slots, 2)
         check(self._lib.chub_step_tape(self._h, _ptr(a), _ptr(pk), _ptr(ct), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
-        return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
+        return self._out()
 
     # ---- per-env clocks (every reference env owns its clock, MGR:137-140, 304-316): reset / step a subset of the envs
     def _mask(self, mask):
@@ -175,7 +183,7 @@ class VecChargingHub(object):
             raise AssertionError("actions must have shape (%d, %d)" % (self.n_envs, self.act_dim))
         z = np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)) if exo_z is not None else None
         check(self._lib.chub_step_envs(self._h, _ptr(m), _ptr(a), _ptr(z), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
-        return self._obs.copy(), self._reward.copy(), self._done.astype(bool), {}
+        return self._out()
 
     def env_clocks(self, ticks=False):
         """slot of day of every env (and, with ticks=True, the Philox tick of every env's last launch)"""

@@ -752,3 +752,24 @@ def test_full_size_c5_properties():
     whole.close()
     for p in parts:
         p.close()
+
+
+def test_copy_outputs_false_returns_the_pinned_arrays():
+    """copy_outputs=False: step() hands out the handle's own pinned arrays (no copies on the Python side) with the same values"""
+    chub = hub()
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
+    n = 300
+    a_, b_ = chub.VecChargingHub(n, seed=4, **kw), chub.VecChargingHub(n, seed=4, copy_outputs=False, **kw)
+    rs = np.random.RandomState(1)
+    assert np.array_equal(a_.reset(), b_.reset())
+    first = None
+    for t in range(100):
+        act = rs.uniform(-1, 1, size=(n, 47)).astype(np.float32)
+        oa, ra, da, _ = a_.step(act)
+        ob, rb, db, _ = b_.step(act)
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db) and db.dtype == np.bool_
+        first = ob if first is None else first
+        assert ob is first                                 # the same array object every step
+    a_.close()
+    b_.close()
