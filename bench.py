@@ -36,6 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # kernel arguments in device memory instead of host memory: every wave's first scalar loads then stay on the GPU
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# RCCL between the ranks of a node: this pool's host driver only supports dmabuf IPC (exported in the images; kept for bare environments)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HUB = dict(station_list=[20, 25], station_type_list=["fast", "slow"], constant_charging=False, hydro_prod_rate=100.0,
            hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01, renew_fluctuate=0.0,

@@ -16,8 +16,12 @@ import time
 
 import numpy as np
 
-from . import _lib
-from ._lib import check, load_library
+# the pool's host driver only supports dmabuf IPC: RCCL's peer-to-peer setup between the ranks of a node needs this before the
+# HIP runtime initialises (it is exported in the images this runs in; a bare environment gets it here)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from . import _lib  # noqa: E402
+from ._lib import check, load_library  # noqa: E402
 
 
 class DeviceBuffer(object):
