@@ -43,9 +43,10 @@ def batched_host(n=4096):
     hub = chub.VecChargingHub(n, seed=0, **HUB)
     obs = hub.reset()
     rs = np.random.RandomState(0)
+    batches = [rs.uniform(-1, 1, (n, hub.act_dim)).astype(np.float32) for _ in range(8)]   # a policy would produce these
     t0 = time.perf_counter()
     for t in range(96):
-        obs, reward, done, _ = hub.step(rs.uniform(-1, 1, (n, hub.act_dim)).astype(np.float32))
+        obs, reward, done, _ = hub.step(batches[t % 8])
     dt = time.perf_counter() - t0
     print("2. %d envs through numpy: %.1f M env-steps/s, mean reward %.4f, all done: %s"
           % (n, n * 96 / dt / 1e6, reward.mean(), bool(done.all())))
