@@ -348,3 +348,30 @@ def test_scalar_load_steps_while_envs_are_on_their_own_clocks():
         assert np.array_equal(p.v.env_clocks(), p.t)
         p._compare(np.arange(n), ("load step", t), True)
     p.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_sequences_of_masked_calls_match_the_oracle(seed):
+    """300 calls drawn at random -- resets and steps of random subsets (sparse, dense, single envs, everybody, nobody) --
+    against the oracle's separate env objects"""
+    n = 48
+    p = Pair(KW, n)
+    rs = np.random.RandomState(seed)
+    p.reset(label="all")
+    for i in range(300):
+        kind = rs.randint(10)
+        density = rs.choice([0.03, 0.3, 0.7, 0.97])
+        mask = rs.uniform(size=n) < density
+        if kind == 0:
+            mask[:] = True
+        elif kind == 1:
+            mask[:] = False
+            mask[rs.randint(n)] = True
+        elif kind == 2:
+            mask[:] = False
+        if rs.randint(4) == 0:
+            p.reset(mask if kind != 0 else None, ("fuzz reset", i))
+        else:
+            p.step(mask if kind != 0 else None, ("fuzz step", i))
+    assert np.array_equal(p.v.env_clocks(), p.t)
+    p.close()
