@@ -4,8 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-No PyTorch in here: the host is ctypes + numpy over libchub (the launcher only provides RANK / LOCAL_RANK / WORLD_SIZE /
-MASTER_PORT); device buffers, streams, the hipGraph capture and the RCCL gather are libchub's own (include/chub.h).
+Both forms work for N > 1.  Started WITHOUT a launcher (no WORLD_SIZE in the environment) `--gpus N` makes this process the
+launcher: it spawns N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT and a private rendezvous directory in
+their environment), relays rank 0's JSON line and exits non-zero if any rank does.  The launcher itself never loads libchub
+or touches the GPU (no re-exec of a process that has initialised HIP, ever).
+
+No PyTorch in here: the host is ctypes + numpy over libchub; device buffers, streams, the hipGraph capture and the RCCL gather
+are libchub's own (include/chub.h).
 
 One "step" = one pass of the hot path (slot kernel + env kernel) over all envs of the workload: 65 536 envs of the
 reference test hub [20 fast, 25 slow] (BASELINE.json configs[3]; it fits one GPU, so N=1 runs the same workload).
@@ -15,18 +20,22 @@ for every N); --scaling weak: BASELINE.json configs[4] (hub [32 fast, 32 slow], 
 to rank 0 in one RCCL gather (chub_step_gather), stream-ordered behind the step kernels.  Actions are a random policy drawn
 on the device before the timed region (8 resident batches, cycled); episodes are reset every 96 steps inside the timed region.
 
-At N = 1 whole episodes are captured into a hipGraph (2 episodes = 2 resets + 192 steps per replay) and the timed region
-is graph replays plus, at its end, one segment of 192 steps issued call by call with HIP events around the two kernels
-of every 4th step: the per-kernel times behind `roofline` are measured inside the timed region.  At N > 1 every step is a
-call by default (16 us of host time per step, below the GPU time of a shard's step + gather); --graph on captures there
-too (RCCL inside the capture: verified on a world of one).
+Timed region = EXACTLY the K steps W .. W+K-1, nothing else.  At N = 1 they are hipGraph replays: whole episodes (2 episodes =
+2 resets + 192 steps per replay) when K is long, one graph of the K steps themselves when K is short; at N > 1 every step is a
+call by default (--graph on captures there too: RCCL inside the capture, verified on a world of one).
+
+The per-kernel times behind `roofline` are NOT taken from the timed window (a short window is a time-of-day sample: the slot
+kernel's duration follows the arrival rate of the slot of day): after the timed region the run continues to the next episode
+boundary and then steps ONE WHOLE UNTIMED DAY (reset + 96 steps) call by call with the dispatch's own start / stop timestamps
+around both kernels of every step.  `roofline.avg_launch_us` is that day's average -- what `rocprofv3 --kernel-trace --stats`
+of whole days reports as AverageNs -- at any --steps.  `roofline_c5` does the same for 262 144 envs x hub [32, 32] (configs[4]'s
+whole job on one GPU): a working set beyond the 256 MB Infinity Cache, i.e. genuinely HBM-resident.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the slot kernel) with ALGORITHMIC bytes (DESIGN.md
 section 5) over its average duration; `roofline_step` prices the whole step the same way (B * env-steps/s /
 8e12).  `cpu_baseline` is the CPU oracle (oracle/chub_oracle.c, kind "port") timed on this box's host cores on a bounded sample.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -53,8 +62,8 @@ SEED = 12345
 ACTION_KEY = 0xC0FFEE
 N_ACTION_BATCHES = 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_EVERY = 4      # HIP events around the two kernels on every 4th step of the timed region
 GRAPH_EPISODES = 2     # episodes per captured graph: 2 resets + 192 steps = an even number of launches (double-buffered draws)
+SPAN_GRAPH_MAX = 1920  # a timed region of up to this many steps is captured as ONE graph of exactly those steps
 
 
 def algorithmic_bytes(S, D):
@@ -66,19 +75,19 @@ def algorithmic_bytes(S, D):
     return slot_kernel, env_kernel
 
 
-def measured_traffic(build_id, envs_per_gpu, total_envs):
+def measured_traffic(build_id, envs_per_gpu, total_envs, hub):
     """HBM bytes per slot-kernel launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
     gfx950 correction of MI355X_MICROARCH.md), collected offline by tools/refresh_profiles.sh with this same command and
     committed under profiles/ TOGETHER WITH the build id of the library they were measured on: a profile of another build
-    is not this build's traffic -> None."""
+    (or another workload) is not this build's traffic -> None."""
     import glob
 
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic*.json")), reverse=True):
         try:
             rec = json.load(open(f))
         except Exception:
             continue
-        if rec.get("build_id") == build_id and rec.get("envs") == total_envs:
+        if rec.get("build_id") == build_id and rec.get("envs") == total_envs and rec.get("hub", [20, 25]) == list(hub):
             return rec["k_slot"]["traffic_bytes_per_launch"] * envs_per_gpu / float(total_envs), os.path.basename(f)
     return None, None
 
@@ -86,6 +95,8 @@ def measured_traffic(build_id, envs_per_gpu, total_envs):
 def cpu_baseline(hub_kw, total_envs, target_seconds=12.0):
     """The oracle's scalar restatement (kind "port"), PHILOX streams, all host cores of this box, on a bounded
     sample of the same workload: n_envs chosen so the run takes ~target_seconds; reports env-steps/s."""
+    import ctypes as C
+
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -128,6 +139,152 @@ def cpu_baseline(hub_kw, total_envs, target_seconds=12.0):
                       % (n, steps, cores)}
 
 
+# ------------------------------------------------------------------------------------------------ the launcher (N > 1, no WORLD_SIZE)
+def launch_ranks(args):
+    """`python bench.py --gpus N` by itself: this process becomes the launcher of N fresh rank processes.  It imports
+    neither numpy nor the package, never maps libchub / the HIP runtime, and only relays: rank 0's stdout (the JSON line) to
+    its own stdout, everything else to stderr.  Exit status: 0 iff every rank exited 0."""
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+
+    n = args.gpus
+    with socket.socket() as s:  # a free port: tells concurrent launches apart for anything that keys on MASTER_PORT
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    rdv = tempfile.mkdtemp(prefix="chub_launch_")  # mode 0700, fresh per launch: the RCCL id travels through it
+    procs, outs = [], []
+    rc = 0
+    try:
+        for r in range(n):
+            env = dict(os.environ)
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), CHUB_RENDEZVOUS_DIR=rdv, CHUB_LAUNCHER_PID=str(os.getpid()))
+            out = open(os.path.join(rdv, "rank%d.out" % r), "w+")
+            outs.append(out)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out,
+                                          stderr=None, stdin=subprocess.DEVNULL))
+        deadline = time.time() + args.launch_timeout
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py launcher: rank %d exited with status %d; stopping the other ranks\n" % (r, code))
+                    for q in alive:
+                        procs[q].terminate()  # exactly the PIDs this launcher started
+            if alive and time.time() > deadline:
+                rc = rc or 124
+                sys.stderr.write("bench.py launcher: ranks %s still running after %.0f s; stopping them\n" % (sorted(alive), args.launch_timeout))
+                for q in alive:
+                    procs[q].kill()
+                for q in alive:
+                    procs[q].wait()
+                alive = set()
+            if alive:
+                time.sleep(0.05)
+        lines = []
+        for r, out in enumerate(outs):
+            out.seek(0)
+            text = out.read()
+            if r == 0:
+                lines = [ln for ln in text.splitlines() if ln.strip()]
+            elif text.strip() and not args.dry_run:
+                sys.stderr.write(text)
+        if args.dry_run:
+            children = []
+            for r, out in enumerate(outs):
+                out.seek(0)
+                for ln in out.read().splitlines():
+                    if ln.startswith("{"):
+                        children.append(json.loads(ln))
+            maps = open("/proc/self/maps").read()
+            print(json.dumps({"dry_run": True, "launcher_pid": os.getpid(), "children": children, "rendezvous_dir": rdv,
+                              "launcher_maps_libchub": "libchub" in maps, "launcher_maps_hip": "libamdhip64" in maps,
+                              "exit": rc}))
+        else:
+            for ln in lines:
+                print(ln)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for out in outs:
+            out.close()
+        shutil.rmtree(rdv, ignore_errors=True)
+    sys.stdout.flush()
+    raise SystemExit(rc)
+
+
+def profiled_day(v, one_step, first_step):
+    """reset + 96 steps issued call by call from `first_step` (an episode boundary), the dispatch's own start / stop timestamps
+    around both kernels of every step -> (slot kernel us, env kernel us) averaged over the day, steps sampled, host wall seconds"""
+    assert first_step % 96 == 0
+    v.profile_begin(96, every=1)
+    t0 = time.perf_counter()
+    for j in range(96):
+        one_step(first_step + j)
+    slot_ms, env_ms, n_prof = v.profile_end()  # synchronises
+    wall = time.perf_counter() - t0
+    return slot_ms / n_prof * 1e3, env_ms / n_prof * 1e3, n_prof, wall
+
+
+def roofline_block(slot_us, env_us, slot_b, env_b, per, traffic, traffic_src, n_prof, window):
+    achieved = slot_b * per / (slot_us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": "k_slot_packed", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": slot_b * per, "avg_launch_us": slot_us, "launches_sampled": n_prof,
+            "window": window, "env_kernel_avg_launch_us": env_us, "env_kernel_algorithmic_bytes_per_launch": env_b * per,
+            "env_kernel_frac": env_b * per / (env_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+
+
+def c5_roofline(chub, multi_gpu, lib, device, build_id):
+    """The working set that does not fit the Infinity Cache: 262 144 envs x hub [32 fast, 32 slow] (BASELINE.json configs[4],
+    the whole job on one GPU).  One warm-up day, then one profiled day as for the headline."""
+    import numpy as np
+
+    n, kw = CONFIGS["c5"]
+    v = chub.VecChargingHub(n, seed=SEED, rng="philox", device=device, **kw)
+    D, A, S = v.obs_dim, v.act_dim, v.n_slots
+    stream = multi_gpu.Stream(device)
+    acts = [multi_gpu.DeviceBuffer(n * A * 4, device) for _ in range(2)]
+    for b, a in enumerate(acts):
+        v.random_actions_device(a.ptr, ACTION_KEY, b, stream.ptr)
+    packed = [multi_gpu.DeviceBuffer(n * (D + 2) * 4, device) for _ in range(2)]
+    reset_obs = multi_gpu.DeviceBuffer(n * D * 4, device)
+
+    def one_step(i):
+        if i % 96 == 0:
+            v.reset_device(reset_obs.ptr, stream=stream.ptr)
+        v.step_device_packed(acts[i & 1].ptr, packed[i & 1].ptr, stream=stream.ptr)
+
+    for i in range(96):
+        one_step(i)
+    stream.sync()
+    slot_us, env_us, n_prof, wall = profiled_day(v, one_step, 96)
+    last = packed[(96 + 95) & 1].to_host(np.float32, (n, D + 2), stream.ptr)
+    assert np.isfinite(last).all() and (last[:, D + 1] > 0.5).all()
+    slot_b, env_b = algorithmic_bytes(S, D)
+    traffic, src = measured_traffic(build_id, n, n, kw["station_list"])
+    out = roofline_block(slot_us, env_us, slot_b, env_b, n, traffic, src, n_prof,
+                         "one whole day (reset + slots 0..95) issued call by call after one warm-up day")
+    out["workload"] = "%d envs x hub [%d fast, %d slow] (BASELINE.json configs[4] on one GPU), renew / price fluctuate 0.3" % (
+        n, kw["station_list"][0], kw["station_list"][1])
+    out["state_bytes"] = n * S * 8
+    out["step_frac_call_by_call"] = (slot_b + env_b) * n * 96 / wall / 1e9 / HBM_PEAK_GBS
+    out["ms_per_step_call_by_call"] = wall / 96 * 1e3
+    v.close()
+    for b in acts + packed + [reset_obs]:
+        b.free()
+    stream.destroy()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,22 +294,35 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="capture whole episodes into a hipGraph (the last 192 steps of the timed region stay single calls for the HIP "
-                         "events); auto: on at N = 1, off at N > 1, where the capture holds RCCL operations of several processes, "
-                         "which this repository could only exercise on a world of one")
+                    help="the timed steps as hipGraph replays; auto: on at N = 1, off at N > 1, where the capture holds RCCL "
+                         "operations of several processes, which this repository could only exercise on a world of one")
     ap.add_argument("--force-comm", action="store_true", help="N = 1: still make the communicator and gather (to rank 0 itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events in the timed region")
+    ap.add_argument("--no-events", action="store_true", help="skip the untimed profiled day (no `roofline` block)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the secondary roofline_c5 block")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="stop every rank before libchub is loaded and print who it is (launch plumbing check, runs without a GPU)")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="(tests) with --dry-run: this rank exits with status 3")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="launcher: seconds before ranks still running are stopped")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with one process per GPU, e.g. python -m torch.distributed.run "
-                             "--nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+    if args.dry_run:
+        maps = open("/proc/self/maps").read()
+        print(json.dumps({"rank": rank, "world": world, "local_rank": local_rank, "pid": os.getpid(), "ppid": os.getppid(),
+                          "rendezvous_dir": os.environ.get("CHUB_RENDEZVOUS_DIR"), "maps_libchub": "libchub" in maps,
+                          "maps_hip": "libamdhip64" in maps}))
+        if rank == args.dry_run_fail_rank:
+            raise SystemExit(3)
+        if args.dry_run_fail_rank >= 0:
+            time.sleep(30)  # the launcher stops the surviving ranks long before this
+        return
 
     import numpy as np
 
@@ -178,9 +348,6 @@ def main():
     use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
     steps, warmup = args.steps, args.warmup  # exactly W untimed and K timed steps, whatever the launch form
     per_graph = 96 * GRAPH_EPISODES
-    # the end of the timed region is issued call by call, with HIP events on every PROFILE_EVERY-th step (all of it when no
-    # graph fits in front: a replay starts at an episode boundary and covers per_graph steps)
-    eager_tail = 0 if args.no_events else min(steps, per_graph)
 
     comm = multi_gpu.Comm(rank, world, local_rank) if use_comm else None
     v = chub.VecChargingHub(per, seed=SEED, rng="philox", device=local_rank, env_id0=rank * per, **hub_kw)
@@ -194,6 +361,30 @@ def main():
     packed = [multi_gpu.DeviceBuffer(per * row, local_rank) for _ in range(2)]
     gathered = [multi_gpu.DeviceBuffer(total * row, local_rank) if (use_comm and rank == 0) else None for _ in range(2)]
     reset_obs = multi_gpu.DeviceBuffer(per * D * 4, local_rank)
+
+    # who is there: RCCL's own count of the communicator, an all-reduce over it, and the GPU every rank sits on
+    n_ranks_seen, comm_count, rank_devices = 1, 1, None
+    info = np.zeros(4, dtype=np.int32)
+    chub._lib.check(lib.chub_device_info(local_rank, info.ctypes.data))
+    me = np.array([rank, local_rank, info[0], info[1], info[2], info[3], os.getpid(), 0], dtype=np.int32)
+    if comm is not None:
+        comm_count = comm.world_seen()
+        n_ranks_seen = comm.ranks_seen(stream.ptr)
+        d_me = multi_gpu.DeviceBuffer(me.nbytes, local_rank)
+        d_all = multi_gpu.DeviceBuffer(me.nbytes * world, local_rank) if rank == 0 else None
+        d_me.from_host(me, stream.ptr)
+        comm.gather(d_me.ptr, d_all.ptr if d_all else 0, me.nbytes, stream.ptr)
+        if rank == 0:
+            everyone = d_all.to_host(np.int32, (world, 8), stream.ptr)
+        else:
+            stream.sync()
+    else:
+        everyone = me.reshape(1, 8)
+    if rank == 0:
+        rank_devices = [{"rank": int(r[0]), "device": int(r[1]), "pci": "%04x:%02x:%02x" % (r[2], r[3], r[4]), "cus": int(r[5]),
+                         "pid": int(r[6])} for r in everyone]
+        if len({d["pci"] for d in rank_devices}) != world and not args.force_comm:
+            raise SystemExit("ranks share a GPU: %s" % rank_devices)
 
     def one_step(i):
         b = i & 1
@@ -211,57 +402,87 @@ def main():
             comm.barrier(stream.ptr)
         stream.sync()
 
-    graph = None
-    if use_graph:
+    def ticks_of(first, n):  # launches (resets + steps) of steps first .. first + n - 1
+        return n + sum(1 for i in range(first, first + n) if i % 96 == 0)
+
+    # long timed regions: a graph of whole episodes, captured before anything has run (the handle is at the start of a day)
+    span_graph_steps = 0
+    episode_graph = None
+    if use_graph and steps > SPAN_GRAPH_MAX:
         stream.sync()
         v.graph_begin(stream.ptr)
         for i in range(per_graph):
             one_step(i)
-        graph = v.graph_end(stream.ptr)
+        episode_graph = v.graph_end(stream.ptr)
 
     replayed = [0]
 
-    def run(first, n_steps, reserve):
-        """steps first .. first + n_steps - 1: graph replays wherever one fits (it starts at an episode boundary and must end
-        `reserve` steps before the end of the span), single calls otherwise"""
+    def run(first, n_steps):
+        """steps first .. first + n_steps - 1: episode-graph replays wherever one fits (it starts at an episode boundary), single
+        calls otherwise"""
         i, end = first, first + n_steps
         while i < end:
-            if graph is not None and i % 96 == 0 and end - reserve - i >= per_graph:
-                v.graph_launch(graph, stream.ptr)
+            if episode_graph is not None and i % 96 == 0 and end - i >= per_graph:
+                v.graph_launch(episode_graph, stream.ptr)
                 i += per_graph
                 replayed[0] += per_graph
             else:
                 one_step(i)
                 i += 1
-        return i
 
-    run(0, warmup, 0)
+    run(0, warmup)
     fence()
     replayed[0] = 0
-    use_events = not args.no_events
+    # short timed regions: ONE graph of exactly the timed steps, captured here (a capture runs nothing: the handle stays where
+    # the warm-up left it) -- minus at most a few last steps, issued as calls, when the launch count would be odd (the
+    # state-independent draws are double-buffered by launch parity)
+    span_graph = None
+    if use_graph and episode_graph is None and steps >= 2:
+        n = steps
+        while n > 0 and ticks_of(warmup, n) % 2:
+            n -= 1
+        if n > 0:
+            v.graph_begin(stream.ptr)
+            for i in range(warmup, warmup + n):
+                one_step(i)
+            span_graph = v.graph_end(stream.ptr)
+            span_graph_steps = n
+            fence()
     t0 = time.perf_counter()
-    head = steps - eager_tail
-    run(warmup, head, 0)
-    if use_events:
-        v.profile_begin(eager_tail, every=PROFILE_EVERY)
-    run(warmup + head, eager_tail, eager_tail)
+    if span_graph is not None:
+        v.graph_launch(span_graph, stream.ptr)
+        replayed[0] += span_graph_steps
+        run(warmup + span_graph_steps, steps - span_graph_steps)
+    else:
+        run(warmup, steps)
     t_issue = time.perf_counter() - t0  # host time to issue the whole timed region
     fence()
     dt = time.perf_counter() - t0
-    slot_ms = env_ms = 0.0
-    n_prof = 0
-    if use_events:
-        slot_ms, env_ms, n_prof = v.profile_end()
     if comm is not None:
         dt = comm.max(dt, stream.ptr)
     # sanity on the last outputs (rank-local): finite, done flag consistent with the clock
-    last = packed[(steps - 1) & 1].to_host(np.float32, (per, D + 2), stream.ptr)
+    last_i = warmup + steps - 1
+    last = packed[last_i & 1].to_host(np.float32, (per, D + 2), stream.ptr)
     assert np.isfinite(last).all(), "non-finite step output"
-    assert (last[:, D + 1] > 0.5).all() == ((steps % 96) == 0), "done flag out of step with the clock"
-    if use_comm and rank == 0:  # the gathered block's own shard is the local block
-        g = gathered[(steps - 1) & 1].to_host(np.float32, (total, D + 2), stream.ptr)
+    assert (last[:, D + 1] > 0.5).all() == (((warmup + steps) % 96) == 0), "done flag out of step with the clock"
+    if use_comm and rank == 0:  # the gathered block's own shard is the local block; every other shard has arrived too
+        g = gathered[last_i & 1].to_host(np.float32, (total, D + 2), stream.ptr)
         assert np.array_equal(g[:per], last), "gathered block differs from the local one"
         assert np.isfinite(g).all()
+        assert ((g[:, D + 1] > 0.5) == (((warmup + steps) % 96) == 0)).all(), "a shard's done flags are out of step"
+        assert (np.abs(g[:, :D]).sum(axis=1) > 0).all(), "a shard's rows never arrived"
+
+    # ---- untimed: on to the next episode boundary, then one whole day with per-kernel timestamps
+    slot_us = env_us = 0.0
+    n_prof = 0
+    i = warmup + steps
+    if not args.no_events:
+        while i % 96:
+            one_step(i)
+            i += 1
+        slot_us, env_us, n_prof, _ = profiled_day(v, one_step, i)
+        i += 96
+    fence()
 
     if rank == 0:
         value = total * steps / dt
@@ -269,15 +490,18 @@ def main():
         build_id = lib.chub_build_id().decode()
         roofline = None
         if n_prof:
-            slot_s = slot_ms / 1e3 / n_prof
-            achieved = slot_b * per / slot_s / 1e9
-            traffic, traffic_src = measured_traffic(build_id, per, total)
-            roofline = {"bound": "hbm", "kernel": "k_slot_packed", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_launch": slot_b * per, "avg_launch_us": slot_s * 1e6,
-                        "env_kernel_avg_launch_us": env_ms / n_prof * 1e3,
-                        "env_kernel_algorithmic_bytes_per_launch": env_b * per}
+            traffic, traffic_src = measured_traffic(build_id, per, total, hub_kw["station_list"])
+            roofline = roofline_block(slot_us, env_us, slot_b, env_b, per, traffic, traffic_src, n_prof,
+                                      "one whole untimed day (reset + slots 0..95) issued call by call after the timed region")
         step_achieved = (slot_b + env_b) * total / (dt / steps) / 1e9 / world  # per GPU
+        d0, s0 = divmod(warmup, 96)
+        d1, s1 = divmod(warmup + steps - 1, 96)
+        if span_graph is not None:
+            launch = "one hipGraph of the timed steps: %d of %d are its replay, the others single calls" % (replayed[0], steps)
+        elif episode_graph is not None:
+            launch = "hipGraph of %d episodes: %d of the %d timed steps are replays, the others single calls" % (GRAPH_EPISODES, replayed[0], steps)
+        else:
+            launch = "every step a call"
         out = {
             "metric": "env-steps/sec at 65 536 parallel envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
@@ -287,28 +511,34 @@ def main():
                                    "random policy resident in HBM, reset every 96 steps, Philox streams"
                                    % (total, hub_kw["station_list"][0], hub_kw["station_list"][1],
                                       {"c4": "configs[3]", "c5": "configs[4]"}.get(config, config), hub_kw["fcev_permeate"]),
-                       "envs_per_gpu": per, "obs_dim": D, "act_dim": A, "launch": ("hipGraph of %d episodes: %d of the %d timed steps are replays, the others (incl. the last %d, with "
-                                  "HIP events) are single calls" % (GRAPH_EPISODES, replayed[0], steps, eager_tail))
-                       if graph else "every step a call",
+                       "envs_per_gpu": per, "obs_dim": D, "act_dim": A, "launch": launch,
+                       "window": "timed: slot %d of day %d .. slot %d of day %d; roofline: a whole untimed day afterwards" % (s0, d0, s1, d1),
                        "host_issue_ms_per_step": t_issue / steps * 1e3,
                        "collective": "none" if not use_comm else
                        "one grouped ncclSend/ncclRecv (RCCL) of [envs_per_gpu, %d] f32 per step to rank 0, on the step's stream" % (D + 2)},
+            "n_ranks_seen": n_ranks_seen, "rccl_comm_count": comm_count, "ranks": rank_devices,
             "roofline": roofline,
             "roofline_step": {"bound": "hbm", "what": "whole step (slot kernel + env kernel + launch gaps), SURVEY.md 8(d): B * env-steps/s per GPU",
                               "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_achieved / HBM_PEAK_GBS,
                               "algorithmic_bytes_per_env_step": slot_b + env_b},
             "build_id": build_id,
         }
-        if not args.no_cpu_baseline and world == 1 and config == "c4":
-            out["cpu_baseline"] = cpu_baseline(hub_kw, total)
-        print(json.dumps(out))
-    if graph is not None:
-        v.graph_destroy(graph)
+    for g in (episode_graph, span_graph):
+        if g is not None:
+            v.graph_destroy(g)
     stream.sync()
     v.close()
+    for b in actions + packed + [g for g in gathered if g is not None] + [reset_obs]:
+        b.free()
     if comm is not None:
         comm.barrier()
         comm.close()
+    if rank == 0:
+        if world == 1 and config == "c4" and not args.no_c5 and not args.no_events:
+            out["roofline_c5"] = c5_roofline(chub, multi_gpu, lib, local_rank, out["build_id"])
+        if not args.no_cpu_baseline and world == 1 and config == "c4":
+            out["cpu_baseline"] = cpu_baseline(hub_kw, total)
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

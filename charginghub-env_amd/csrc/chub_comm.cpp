@@ -28,7 +28,7 @@ typedef struct {
 } ncclUniqueId;
 typedef int ncclResult_t;
 }
-enum { kNcclSuccess = 0, kNcclUint8 = 1, kNcclFloat64 = 8, kNcclMax = 2 };
+enum { kNcclSuccess = 0, kNcclUint8 = 1, kNcclFloat64 = 8, kNcclSum = 0, kNcclMax = 2 };
 
 namespace {
 struct Rccl {
@@ -42,6 +42,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     std::string why;
 };
 Rccl g_rccl;
@@ -75,6 +76,7 @@ bool load_rccl() {
     BIND(GroupEnd, "ncclGroupEnd");
     BIND(AllReduce, "ncclAllReduce");
     BIND(GetErrorString, "ncclGetErrorString");
+    BIND(CommCount, "ncclCommCount");
 #undef BIND
     g_rccl.handle = h;
     return true;
@@ -154,7 +156,13 @@ int chub_comm_destroy(chub_comm *c) {
     return CHUB_OK;
 }
 
-int chub_comm_world(const chub_comm *c) { return c ? c->world : CHUB_ERR_ARG; }
+// the communicator's size as RCCL itself reports it (ncclCommCount), not the number the host passed in
+int chub_comm_world(const chub_comm *c) {
+    if (!c) return CHUB_ERR_ARG;
+    int n = 0;
+    if (!c->comm || g_rccl.CommCount(c->comm, &n) != kNcclSuccess) return comm_fail(CHUB_ERR_COMM, "ncclCommCount failed");
+    return n;
+}
 int chub_comm_rank(const chub_comm *c) { return c ? c->rank : CHUB_ERR_ARG; }
 
 // every rank's `bytes` at d_send -> rank 0's d_recv[rank * bytes ...]; enqueued on `stream`, returns at once
@@ -182,6 +190,21 @@ int chub_comm_max_f64(chub_comm *c, double *value, void *stream) {
     NCCL_TRY(g_rccl.AllReduce(c->d_scratch, c->d_scratch + 1, 1, kNcclFloat64, kNcclMax, c->comm, s));
     HIPC_TRY(hipMemcpyAsync(value, c->d_scratch + 1, sizeof(double), hipMemcpyDeviceToHost, s));
     HIPC_TRY(hipStreamSynchronize(s));
+    return CHUB_OK;
+}
+
+// how many ranks take part in a collective right now: every rank contributes 1 to an all-reduce sum over the communicator
+// (what bench.py reports as n_ranks_seen: RCCL moved data between that many processes); synchronises the stream
+int chub_comm_ranks_seen(chub_comm *c, int *out, void *stream) {
+    if (!c || !out) return comm_fail(CHUB_ERR_ARG, "null argument");
+    hipStream_t s = (hipStream_t) stream;
+    double one = 1.0, sum = 0.0;
+    HIPC_TRY(hipSetDevice(c->device));
+    HIPC_TRY(hipMemcpyAsync(c->d_scratch, &one, sizeof(double), hipMemcpyHostToDevice, s));
+    NCCL_TRY(g_rccl.AllReduce(c->d_scratch, c->d_scratch + 1, 1, kNcclFloat64, kNcclSum, c->comm, s));
+    HIPC_TRY(hipMemcpyAsync(&sum, c->d_scratch + 1, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPC_TRY(hipStreamSynchronize(s));
+    *out = (int) (sum + 0.5);
     return CHUB_OK;
 }
 

@@ -319,6 +319,17 @@ int chub_device_count(void) {
     return n;
 }
 
+int chub_device_info(int device, int32_t *out4) {
+    if (!out4) return fail(CHUB_ERR_ARG, "null argument");
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    out4[0] = p.pciDomainID;
+    out4[1] = p.pciBusID;
+    out4[2] = p.pciDeviceID;
+    out4[3] = p.multiProcessorCount;
+    return CHUB_OK;
+}
+
 int chub_create(const chub_config *cfg, const char *data_dir, int64_t n_envs, int64_t env_id0, int device,
                 uint64_t seed, int rng_mode, chub_env **out) {
     return chub_create_ex(cfg, data_dir, n_envs, env_id0, device, seed, rng_mode, nullptr, out);
@@ -892,10 +903,14 @@ static int reset_masked(chub_env *e, const uint8_t *mask, const int32_t *d_exo_d
     (void) hipGetLastError();  // a stale error of an earlier, unrelated call must not be reported as this step's
     hipStream_t s = (hipStream_t) stream;
     int served = 0;
+    const bool was_per_env = e->per_env;
     int rc = serve_mask(e, mask, s, served);
     if (rc || served == 0) return rc;
     rc = run_reset(e, served, d_exo_days, d_exo_z, d_obs, s);
-    if (rc) return rc;
+    if (rc) {
+        e->per_env = was_per_env;  // nothing was launched: the handle stays on the clock(s) it was on
+        return rc;
+    }
     return note_served(e, mask, served, s);
 }
 
@@ -1015,10 +1030,14 @@ static int step_masked(chub_env *e, const uint8_t *mask, const float *d_actions,
     (void) hipGetLastError();  // a stale error of an earlier, unrelated call must not be reported as this step's
     hipStream_t s = (hipStream_t) stream;
     int served = 0;
+    const bool was_per_env = e->per_env;
     int rc = serve_mask(e, mask, s, served);
     if (rc || served == 0) return rc;
     rc = run_step(e, served, d_actions, d_exo_z, d_obs, obs_stride, d_reward, reward_stride, d_done, d_done_f32, s, load_mode);
-    if (rc) return rc;
+    if (rc) {
+        e->per_env = was_per_env;  // nothing was launched: the handle stays on the clock(s) it was on
+        return rc;
+    }
     return note_served(e, mask, served, s);
 }
 
@@ -1165,8 +1184,8 @@ int chub_step(chub_env *e, const float *actions, const double *exo_z, float *obs
         if (!exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
         HIP_TRY(hipMemcpyAsync(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     }
-    if (actions == e->h_actions) HIP_TRY(hipMemcpyAsync(e->d_actions, actions, N * A * sizeof(float), hipMemcpyHostToDevice, s));
-    else HIP_TRY(hipMemcpyAsync(e->d_actions, actions, N * A * sizeof(float), hipMemcpyHostToDevice, s));  // pageable: staged by HIP
+    // from the handle's pinned buffer (chub_host_actions) this is one DMA; any other host pointer is staged by the HIP runtime
+    HIP_TRY(hipMemcpyAsync(e->d_actions, actions, N * A * sizeof(float), hipMemcpyHostToDevice, s));
     rc = chub_step_device(e, e->d_actions, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, s);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(obs, e->d_obs, N * D * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1183,6 +1202,7 @@ struct chub_graph {
     int device;
     chub_env *env;
     uint32_t ticks;       // resets + steps one replay covers
+    uint32_t arg0;        // host tick - tick base at chub_graph_begin: the captured launches carry arg0 + 1 .. arg0 + ticks
     int t_end, pc_end;    // the handle's clocks after a replay
 };
 
@@ -1237,6 +1257,7 @@ int chub_graph_end(chub_env *e, void *stream, chub_graph **out) {
     cg->device = e->device;
     cg->env = e;
     cg->ticks = ticks;
+    cg->arg0 = e->graph_tick0 - e->graph_base;
     cg->t_end = t_end;
     cg->pc_end = pc_end;
     *out = cg;
@@ -1247,10 +1268,20 @@ int chub_graph_launch(chub_graph *g, void *stream) {
     if (!g) return fail(CHUB_ERR_ARG, "null graph");
     if (g->env->per_env) return fail(CHUB_ERR_ARG, "graphs replay lock-step calls: the envs of this handle run on their own clocks (reset all of them first)");
     HIP_TRY(hipSetDevice(g->device));
+    chub_env *e = g->env;
+    // The captured launches carry the arguments arg0 + 1 .. arg0 + ticks, and a launch's effective Philox tick is its argument
+    // + the device-side tick base.  Calls issued one by one since the capture (or since the last replay) have moved the host
+    // tick on without moving the base: bring the base to where argument arg0 + k means tick + k again, so that a replay never
+    // runs on a tick an eager call has already used (nor the other way round).
+    const uint32_t delta = (e->tick - e->graph_base) - g->arg0;
+    if (delta != 0u) {
+        launch_tick_advance(e->d_tick_base, delta, (hipStream_t) stream);
+        HIP_TRY(hipGetLastError());
+        e->graph_base += delta;
+    }
     HIP_TRY(hipGraphLaunch(g->exec, (hipStream_t) stream));
     // the replay covers g->ticks resets + steps: its last node moves the device-side tick base on, the host mirrors it, so that
     // calls issued one by one afterwards continue the same tick sequence (their argument is the tick minus the base)
-    chub_env *e = g->env;
     e->tick += g->ticks;
     e->graph_base += g->ticks;
     e->t = g->t_end;
@@ -1525,8 +1556,9 @@ int chub_get_station_scalars(chub_env *e, double *out) {
     HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t) e->hp.n_envs;
     std::vector<uint32_t> rec;
+    std::vector<uint16_t> clk;  // station_time_hole (CHS.hpp:1204) is the env's own slot of day
     int rc;
-    if ((rc = fetch(rec, (const uint32_t *) e->st.rec, 8 * N))) return rc;
+    if ((rc = fetch(rec, (const uint32_t *) e->st.rec, 8 * N)) || (rc = fetch_clocks(e, clk))) return rc;
     for (size_t env = 0; env < N; env++)
         for (int k = 0; k < 2; k++) {
             double *o = out + (env * 2 + k) * 8;
@@ -1537,7 +1569,7 @@ int chub_get_station_scalars(chub_env *e, double *out) {
             o[3] = (double) pkd_cars(r[3]);  // car_number
             o[4] = (double) pkd_line(r[3]);  // line
             o[5] = (double) pkd_flow(r[3]);  // flow_in_number[-1] (can be negative right after reset)
-            o[6] = e->t; o[7] = e->hp.transformer_limit[k];
+            o[6] = (double) (clk[env] & 127u); o[7] = e->hp.transformer_limit[k];
         }
     return CHUB_OK;
 }

@@ -5,8 +5,9 @@ torch.distributed.run`` -- only its environment variables are used).  Env shards
 index; per step each shard's packed output [n_local, D+2] f32 (obs, reward, done) goes to rank 0 in ONE grouped
 ncclSend / ncclRecv enqueued on the same HIP stream as the step kernels (``chub_step_gather``): no host wait per step.
 
-The 128-byte RCCL id travels from rank 0 to the other ranks of the node through a file in /tmp (single node: the north star's
-8 GPUs of one node); nothing else is exchanged on the host side.
+The 128-byte RCCL id travels from rank 0 to the other ranks of the node through a file in a private directory (single node: the
+north star's 8 GPUs of one node) -- the launcher's (CHUB_RENDEZVOUS_DIR: `bench.py --gpus N` makes one per launch) or one under
+/tmp keyed on user, port and launcher; nothing else is exchanged on the host side.
 """
 import contextlib
 import ctypes as C
@@ -75,36 +76,110 @@ class Stream(object):
             self.ptr = None
 
 
-def _rendezvous_path():
-    # all ranks of one launch share the launcher as parent process; the port tells concurrent launches apart
-    return "/tmp/chub_rccl_id_%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
-                                           os.getppid())
+RENDEZVOUS_ENV = "CHUB_RENDEZVOUS_DIR"  # a private directory made by the launcher (bench.py --gpus N makes one per launch)
+_ID_MAGIC = b"CHUBID01"
 
 
-def exchange_unique_id(rank, world, timeout=300.0):
-    """rank 0 makes the RCCL id (chub_comm_unique_id) and publishes it atomically; the others wait for the file"""
-    lib = load_library()
-    path = _rendezvous_path()
+def _launcher_start_time():
+    """wall-clock time at which the parent process (the launcher all ranks share) started, or 0.0 if /proc does not say"""
+    try:
+        with open("/proc/%d/stat" % os.getppid(), "rb") as f:
+            fields = f.read().rsplit(b")", 1)[1].split()
+        ticks = int(fields[19])  # starttime: field 22 of proc(5), in clock ticks since boot
+        with open("/proc/uptime") as f:
+            uptime = float(f.read().split()[0])
+        return time.time() - uptime + ticks / float(os.sysconf("SC_CLK_TCK"))
+    except Exception:
+        return 0.0
+
+
+def _rendezvous_dir():
+    """Where rank 0 leaves the RCCL id.  A launcher that passes CHUB_RENDEZVOUS_DIR (a fresh private directory per launch) is
+    taken at its word.  Otherwise (torch.distributed.run and the like: only RANK / WORLD_SIZE / MASTER_PORT) a directory
+    /tmp/chub_rdv_<uid>_<port>_<run id>_<launcher pid>, mode 0700, which must be a real directory owned by this user."""
+    d = os.environ.get(RENDEZVOUS_ENV)
+    if d:
+        return d, False
+    d = "/tmp/chub_rdv_%d_%s_%s_%d" % (os.getuid(), os.environ.get("MASTER_PORT", "0"),
+                                       os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat as _stat
+
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise _lib.ChubError("rendezvous directory %s is not a private directory of this user" % d)
+    return d, True
+
+
+def exchange_unique_id(rank, world, timeout=None, make_id=None):
+    """rank 0 makes the RCCL id (chub_comm_unique_id) and publishes it; the others wait for it.
+
+    The file is created with O_EXCL | O_NOFOLLOW, mode 0600, under a temporary name and renamed into place, and carries a
+    header (magic, time written).  A reader only accepts an id written after the launcher of THIS launch started, so the
+    leftover of a crashed earlier launch (same port, same recycled launcher pid) is never picked up; rank 0 removes such a
+    leftover before it writes.  `timeout` seconds (default 120, CHUB_RENDEZVOUS_TIMEOUT) without an id is an error naming
+    the path.  make_id: tests inject the id source (the real one needs RCCL)."""
+    import struct
+
+    if timeout is None:
+        timeout = float(os.environ.get("CHUB_RENDEZVOUS_TIMEOUT", "120"))
+    d, shared_tmp = _rendezvous_dir()
+    path = os.path.join(d, "rccl_id")
+    not_before = _launcher_start_time() - 1.0 if shared_tmp else 0.0
     if rank == 0:
-        buf = (C.c_char * 128)()
-        check(lib.chub_comm_unique_id(buf))
-        tmp = path + ".tmp"
-        with open(tmp, "wb") as f:
-            f.write(bytes(buf))
-        os.replace(tmp, path)
-        return bytes(buf)
+        if make_id is None:
+            lib = load_library()
+            buf = (C.c_char * 128)()
+            check(lib.chub_comm_unique_id(buf))
+            uid = bytes(buf)
+        else:
+            uid = make_id()
+        assert len(uid) == 128
+        for leftover in (path, path + ".tmp"):
+            try:
+                os.unlink(leftover)
+            except FileNotFoundError:
+                pass
+        fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(_ID_MAGIC + struct.pack("<d", time.time()) + uid)
+        os.rename(path + ".tmp", path)
+        return uid
     t0 = time.time()
+    why = "no file"
     while True:
         try:
-            with open(path, "rb") as f:
+            fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+            with os.fdopen(fd, "rb") as f:
                 b = f.read()
-            if len(b) == 128:
-                return b
+            if len(b) == 144 and b[:8] == _ID_MAGIC:
+                if struct.unpack("<d", b[8:16])[0] >= not_before:
+                    return b[16:]
+                why = "only a stale id of an earlier launch"
+            else:
+                why = "a malformed id file"
         except FileNotFoundError:
-            pass
+            why = "no file"
         if time.time() - t0 > timeout:
-            raise _lib.ChubError("no RCCL id from rank 0 within %.0f s (%s)" % (timeout, path))
+            raise _lib.ChubError("rank %d of %d: no RCCL id from rank 0 within %.0f s at %s (%s): is rank 0 running, and do all "
+                                 "ranks share %s / MASTER_PORT and the launcher?" % (rank, world, timeout, path, why, RENDEZVOUS_ENV))
         time.sleep(0.01)
+
+
+def _rendezvous_cleanup():
+    d = os.environ.get(RENDEZVOUS_ENV)
+    try:
+        if d:
+            os.unlink(os.path.join(d, "rccl_id"))  # the directory is the launcher's
+        else:
+            d, _ = _rendezvous_dir()
+            os.unlink(os.path.join(d, "rccl_id"))
+            os.rmdir(d)
+    except OSError:
+        pass
 
 
 @contextlib.contextmanager
@@ -140,10 +215,20 @@ class Comm(object):
             self._h = h
             self.barrier()
         if self.rank == 0:  # every rank holds the id by now
-            try:
-                os.remove(_rendezvous_path())
-            except OSError:
-                pass
+            _rendezvous_cleanup()
+
+    def world_seen(self):
+        """ncclCommCount: the communicator's size as RCCL reports it"""
+        n = self._lib.chub_comm_world(self._h)
+        if n < 0:
+            check(n)
+        return n
+
+    def ranks_seen(self, stream=0):
+        """all-reduce sum of one 1 per rank: how many processes RCCL actually moved data between"""
+        n = C.c_int(0)
+        check(self._lib.chub_comm_ranks_seen(self._h, C.byref(n), stream or None))
+        return n.value
 
     def gather(self, d_send, d_recv, nbytes, stream=0):
         check(self._lib.chub_comm_gather(self._h, d_send, d_recv or None, int(nbytes), stream or None))

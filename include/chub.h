@@ -172,7 +172,11 @@ int chub_sync(chub_env *env);
  *   chub_comm_gather:    every rank: `bytes` from d_send to rank 0's d_recv + rank * bytes (d_recv ignored elsewhere).
  *   chub_step_gather:    chub_step_device_packed + chub_comm_gather of the packed block on one stream -- the multi-GPU step.
  *   chub_comm_max_f64 / chub_comm_barrier: max over ranks of one host double / rendezvous (both synchronise `stream`);
- *                        what bench.py brackets its timed region with. */
+ *                        what bench.py brackets its timed region with.
+ *   chub_comm_world:     the communicator's size as RCCL reports it (ncclCommCount).
+ *   chub_comm_ranks_seen: all-reduce sum of one 1 per rank: the number of processes RCCL actually moved data between.
+ *   chub_device_info:    out[4] = PCI domain, bus, device of HIP device `device` and its compute-unit count (which physical GPU a
+ *                        rank sits on; bench.py lists it per rank). */
 typedef struct chub_comm chub_comm;
 int chub_comm_unique_id(void *id128);
 int chub_comm_create(const void *id128, int world, int rank, int device, chub_comm **out);
@@ -182,6 +186,8 @@ int chub_comm_rank(const chub_comm *comm);
 int chub_comm_gather(chub_comm *comm, const void *d_send, void *d_recv, int64_t bytes, void *stream);
 int chub_comm_max_f64(chub_comm *comm, double *value, void *stream);
 int chub_comm_barrier(chub_comm *comm, void *stream);
+int chub_comm_ranks_seen(chub_comm *comm, int *out, void *stream);
+int chub_device_info(int device, int32_t *out4);
 int chub_step_gather(chub_env *env, chub_comm *comm, const float *d_actions, float *d_packed, float *d_gathered, void *stream);
 
 /* Per-kernel timing of the step: between chub_profile_begin and chub_profile_end every `every`-th step (up to

@@ -711,6 +711,72 @@ def test_graph_replay_equals_eager():
             v.close()
 
 
+def test_graph_replays_mixed_with_eager_calls():
+    """replay -> eager calls -> replay (the second replay used to run on ticks the eager calls had consumed), a
+    graph captured in the middle of an episode (bench.py's form for short timed regions: W warm-up steps, then ONE graph of the
+    K timed steps), and two graphs of one handle replayed alternately: every sequence equals the same calls issued one by one"""
+    chub = hub()
+    from charginghub_env_amd import multi_gpu
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.02, renew_fluctuate=0.2, price_fluctuate=0.1)
+    n = 1500
+    # a program is a list of segments ("g", name, first, count) = graph `name` covering steps first .. first+count-1 (captured at
+    # its first use, replayed at every use), or ("e", first, count) = those steps as calls; step i resets first when i % 96 == 0
+    programs = {
+        "replay_eager_replay": [("g", "a", 0, 192), ("e", 0, 97), ("g", "a", 0, 192), ("e", 0, 5), ("g", "a", 0, 192), ("e", 0, 3)],
+        "span_mid_episode": [("e", 0, 5), ("g", "s", 5, 20), ("e", 25, 71), ("e", 0, 1)],
+        "span_with_reset_inside": [("e", 0, 90), ("g", "s", 90, 13), ("e", 103, 4)],
+        "two_graphs": [("g", "a", 0, 190), ("e", 94, 2), ("g", "b", 0, 190), ("e", 94, 3), ("g", "a", 0, 190), ("e", 94, 2), ("g", "b", 0, 190)],
+    }
+    for name, prog in programs.items():
+        res = []
+        for mode in ("eager", "graph"):
+            v = chub.VecChargingHub(n, seed=77, **kw)
+            st = multi_gpu.Stream(0)
+            acts = [multi_gpu.DeviceBuffer(n * v.act_dim * 4) for _ in range(4)]
+            for b, a in enumerate(acts):
+                v.random_actions_device(a.ptr, 9, b, st.ptr)
+            packed = [multi_gpu.DeviceBuffer(n * (v.obs_dim + 2) * 4) for _ in range(2)]
+            obs0 = multi_gpu.DeviceBuffer(n * v.obs_dim * 4)
+
+            def steps(first, count):
+                for i in range(first, first + count):
+                    if i % 96 == 0:
+                        v.reset_device(obs0.ptr, stream=st.ptr)
+                    v.step_device_packed(acts[i % 4].ptr, packed[i & 1].ptr, stream=st.ptr)
+
+            graphs = {}
+            trace = []
+            for seg in prog:
+                if seg[0] == "e" or mode == "eager":
+                    first, count = seg[-2], seg[-1]
+                    steps(first, count)
+                else:
+                    _, gname, first, count = seg
+                    if gname not in graphs:
+                        st.sync()
+                        v.graph_begin(st.ptr)
+                        steps(first, count)
+                        graphs[gname] = v.graph_end(st.ptr)
+                    v.graph_launch(graphs[gname], st.ptr)
+                last_i = seg[-2] + seg[-1] - 1
+                trace.append(packed[last_i & 1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr))
+            trace.append(np.concatenate([x.reshape(n, -1) for x in v.slots()], axis=1))
+            trace.append(v.station_scalars().reshape(n, -1))
+            res.append(trace)
+            for g in graphs.values():
+                v.graph_destroy(g)
+            v.close()
+            st.destroy()
+        for k, (a, b) in enumerate(zip(*res)):
+            assert np.array_equal(a, b), (name, "segment", k)
+        # no two episodes of a run are the same episode (a replay that reused ticks would repeat one)
+        ends = [t for t in res[1][:-2]]
+        for x in range(len(ends)):
+            for y in range(x + 1, len(ends)):
+                assert not np.array_equal(ends[x][:, :-2], ends[y][:, :-2]), (name, "segments", x, y, "ended in the same state")
+
+
 def test_full_size_c5_properties():
     """BASELINE.json configs[4] at its own size: 262 144 envs x hub [32 fast, 32 slow] with fluctuating price / PV / wind, one
     episode on the production (packed) kernel: 4-way shard independence (what the 8-GPU job relies on), the invariants the

@@ -1,0 +1,153 @@
+"""CPU-side tests of the multi-GPU launch plumbing (no GPU, no RCCL): `python bench.py --gpus N` as its own launcher, and
+the RCCL-id rendezvous of charginghub-env_amd/multi_gpu.py.  BASELINE.json north_star: "1/2/4/8-GPU scaling curve reported"
+-- the command that reports it must not be able to fail for launch reasons."""
+import json
+import multiprocessing as mp
+import os
+import struct
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "CHUB_RENDEZVOUS_DIR"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_launches_its_own_ranks(n):
+    """no launcher in the environment: the process becomes one, spawns n fresh ranks BEFORE anything touches the GPU stack,
+    and relays; --dry-run stops every rank in front of load_library()"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--steps", "20", "--warmup", "5", "--dry-run"], env=_clean_env(),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "the launcher prints ONE line"
+    rec = json.loads(lines[0])
+    kids = rec["children"]
+    assert len(kids) == n
+    assert sorted(k["rank"] for k in kids) == list(range(n))
+    assert sorted(k["local_rank"] for k in kids) == list(range(n))
+    assert all(k["world"] == n for k in kids)
+    assert len({k["pid"] for k in kids}) == n and all(k["ppid"] == rec["launcher_pid"] for k in kids)
+    assert len({k["rendezvous_dir"] for k in kids}) == 1 and kids[0]["rendezvous_dir"] == rec["rendezvous_dir"]
+    # the launcher never maps libchub or the HIP runtime (it must never have to re-exec a process that initialised the GPU)
+    assert rec["launcher_maps_libchub"] is False and rec["launcher_maps_hip"] is False
+    assert not any(k["maps_libchub"] or k["maps_hip"] for k in kids), "a dry-run rank stops in front of load_library()"
+    assert not os.path.exists(rec["rendezvous_dir"]), "the launcher removes its rendezvous directory"
+
+
+def test_launcher_fails_when_a_rank_fails():
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--dry-run", "--dry-run-fail-rank", "1"], env=_clean_env(),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3
+    assert "rank 1 exited with status 3" in r.stderr
+    assert time.time() - t0 < 25, "the surviving ranks are stopped, not waited for"
+
+
+def test_rank_under_an_external_launcher_does_not_spawn():
+    env = _clean_env()
+    env.update(RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_PORT="29511")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    rec = json.loads(r.stdout.strip())
+    assert rec["rank"] == 1 and rec["world"] == 2 and "children" not in rec
+    env["WORLD_SIZE"] = "4"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+# ---- the RCCL id rendezvous (multi_gpu.exchange_unique_id) with an injected id source
+def _rank_proc(rank, world, env, q, delay):
+    os.environ.update(env)
+    sys.path.insert(0, ROOT)
+    from charginghub_env_amd import multi_gpu
+
+    time.sleep(delay)
+    try:
+        uid = multi_gpu.exchange_unique_id(rank, world, timeout=20.0, make_id=lambda: bytes([7 + rank]) * 128)
+        q.put((rank, uid))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+@pytest.mark.parametrize("private_dir", [True, False])
+def test_id_rendezvous_two_ranks(tmp_path, private_dir):
+    """rank 0 starts late: the others wait; the id arrives whole; with a launcher's private directory and with the /tmp fallback"""
+    env = {"MASTER_PORT": str(20000 + os.getpid() % 20000), "TORCHELASTIC_RUN_ID": "t%d" % time.time_ns()}
+    if private_dir:
+        env["CHUB_RENDEZVOUS_DIR"] = str(tmp_path)
+    else:
+        os.environ.pop("CHUB_RENDEZVOUS_DIR", None)
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rank_proc, args=(r, 3, env, q, 0.5 if r == 0 else 0.0)) for r in range(3)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in ps)
+    for p in ps:
+        p.join(30)
+    assert got[0] == bytes([7]) * 128 and got[1] == got[0] and got[2] == got[0], got
+    if not private_dir:  # rank 0 cleans up after a Comm; here by hand
+        sys.path.insert(0, ROOT)
+        from charginghub_env_amd import multi_gpu
+
+        os.environ.update(env)
+        try:
+            multi_gpu._rendezvous_cleanup()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+
+
+def test_stale_id_of_an_earlier_launch_is_not_accepted(monkeypatch):
+    """/tmp fallback: a leftover id file (same port, same launcher pid) written before this launch's launcher started is
+    rejected by the readers, and the error says what was found"""
+    sys.path.insert(0, ROOT)
+    from charginghub_env_amd import multi_gpu
+    from charginghub_env_amd._lib import ChubError
+
+    monkeypatch.delenv("CHUB_RENDEZVOUS_DIR", raising=False)
+    monkeypatch.setenv("MASTER_PORT", str(20000 + os.getpid() % 20000))
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "stale%d" % time.time_ns())
+    d, shared = multi_gpu._rendezvous_dir()
+    assert shared and (os.lstat(d).st_mode & 0o777) == 0o700
+    path = os.path.join(d, "rccl_id")
+    try:
+        with open(path, "wb") as f:  # "written" long before the parent of this process (pytest's launcher) started
+            f.write(multi_gpu._ID_MAGIC + struct.pack("<d", multi_gpu._launcher_start_time() - 3600.0) + b"\x01" * 128)
+        with pytest.raises(ChubError) as ei:
+            multi_gpu.exchange_unique_id(1, 2, timeout=0.3)
+        assert "stale" in str(ei.value) and path in str(ei.value)
+        # rank 0 of the new launch replaces the leftover; then the readers accept
+        uid = multi_gpu.exchange_unique_id(0, 2, make_id=lambda: b"\x02" * 128)
+        assert multi_gpu.exchange_unique_id(1, 2, timeout=5.0) == uid == b"\x02" * 128
+    finally:
+        multi_gpu._rendezvous_cleanup()
+    assert not os.path.exists(d)
+
+
+def test_rendezvous_refuses_a_symlinked_directory(monkeypatch, tmp_path):
+    sys.path.insert(0, ROOT)
+    from charginghub_env_amd import multi_gpu
+    from charginghub_env_amd._lib import ChubError
+
+    monkeypatch.delenv("CHUB_RENDEZVOUS_DIR", raising=False)
+    monkeypatch.setenv("MASTER_PORT", str(20000 + os.getpid() % 20000))
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "link%d" % time.time_ns())
+    d = "/tmp/chub_rdv_%d_%s_%s_%d" % (os.getuid(), os.environ["MASTER_PORT"], os.environ["TORCHELASTIC_RUN_ID"], os.getppid())
+    os.symlink(str(tmp_path), d)
+    try:
+        with pytest.raises(ChubError):
+            multi_gpu._rendezvous_dir()
+    finally:
+        os.unlink(d)
