@@ -240,15 +240,16 @@ __device__ __forceinline__ int late_from_word(const uint32_t *thr, uint32_t w) {
 }
 
 // PHILOX mode: N(0,1) from one 32-bit uniform by two-level tabulated inverse CDF (tools/gen_tables.py): 4096 cells,
-// linear interpolation inside a cell; the lowest cell is refined by a second table, the highest is its mirror.
+// linear interpolation inside a cell; the lowest 16 cells (p < 2^-8: where the quantile function bends most) are refined by a
+// second table with cells of 2^-20, the highest 16 are their mirror.
 __device__ __forceinline__ float normal_from_word(const float *tz, const float *tl, uint32_t w) {
     const uint32_t cell = w >> 20;
-    const bool hi = cell == 4095u, lo = cell == 0u;
-    const uint32_t m = hi ? ~w : w;
+    const bool hi = cell >= 4096u - 16u, lo = cell < 16u;
+    const uint32_t m = hi ? ~w : w;  // tail: < 2^24
     const bool tail = hi || lo;
     const float *tab = tail ? tl : tz;
-    const uint32_t idx = tail ? (m >> 8) : cell;
-    const float frac = tail ? (float) (m & 0xFFu) * (1.0f / 256.0f) : (float) (w & 0xFFFFFu) * (1.0f / 1048576.0f);
+    const uint32_t idx = tail ? (m >> 12) : cell;
+    const float frac = tail ? (float) (m & 0xFFFu) * (1.0f / 4096.0f) : (float) (w & 0xFFFFFu) * (1.0f / 1048576.0f);
     const float a = tab[idx], b = tab[idx + 1];
     const float z = __fadd_rn(a, __fmul_rn(__fsub_rn(b, a), frac));
     return hi ? -z : z;

@@ -1203,6 +1203,7 @@ struct chub_graph {
     chub_env *env;
     uint32_t ticks;       // resets + steps one replay covers
     uint32_t arg0;        // host tick - tick base at chub_graph_begin: the captured launches carry arg0 + 1 .. arg0 + ticks
+    int t_begin, pc_begin;  // the handle's clocks at chub_graph_begin: what a replay starts from (baked into the launches)
     int t_end, pc_end;    // the handle's clocks after a replay
 };
 
@@ -1258,6 +1259,8 @@ int chub_graph_end(chub_env *e, void *stream, chub_graph **out) {
     cg->env = e;
     cg->ticks = ticks;
     cg->arg0 = e->graph_tick0 - e->graph_base;
+    cg->t_begin = e->graph_t0;
+    cg->pc_begin = e->graph_pc0;
     cg->t_end = t_end;
     cg->pc_end = pc_end;
     *out = cg;
@@ -1269,6 +1272,11 @@ int chub_graph_launch(chub_graph *g, void *stream) {
     if (g->env->per_env) return fail(CHUB_ERR_ARG, "graphs replay lock-step calls: the envs of this handle run on their own clocks (reset all of them first)");
     HIP_TRY(hipSetDevice(g->device));
     chub_env *e = g->env;
+    // a replay repeats the clocks of its launches verbatim (slot of day, price-noise phase: kernel arguments): it continues the
+    // handle's run only from where the capture started
+    if (e->t != g->t_begin || ((e->price_count ^ g->pc_begin) & 3) != 0)
+        return fail(CHUB_ERR_ARG, "the handle is not at the clock this graph was captured at (slot of day " + std::to_string(g->t_begin) +
+                                      ", steps since reset mod 4 = " + std::to_string(g->pc_begin & 3) + "): a replay bakes the clocks in");
     // The captured launches carry the arguments arg0 + 1 .. arg0 + ticks, and a launch's effective Philox tick is its argument
     // + the device-side tick base.  Calls issued one by one since the capture (or since the last replay) have moved the host
     // tick on without moving the base: bring the base to where argument arg0 + k means tick + k again, so that a replay never

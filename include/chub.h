@@ -237,8 +237,10 @@ int chub_set_ou_state(chub_env *env, const double *ou);
  * Between chub_graph_begin and chub_graph_end the device-pointer entry points (chub_reset_device, chub_step_device*,
  * chub_step_gather, chub_random_actions_device) called with `stream` are recorded, not run; chub_graph_launch replays the
  * recording.  What a replay repeats verbatim: clocks, buffers and the order of calls -- so record whole episodes (reset + 96
- * steps), an even number of calls (the state-independent draws are double-buffered).  What it does not repeat: the random
- * streams -- every replay moves the Philox tick base on, so a replayed episode is a new episode.  PHILOX handles only.
+ * steps), an even number of calls (the state-independent draws are double-buffered), and replay only when the handle is back at
+ * the clock the capture started from (slot of day, steps since the last reset mod 4: chub_graph_launch refuses otherwise).
+ * What it does not repeat: the random streams -- every replay (and every call issued one by one between replays) moves the
+ * Philox tick on, so a replayed episode is a new episode.  PHILOX handles only.
  * `stream` is a created stream (chub_stream_create or the caller's own), not the default stream. */
 typedef struct chub_graph chub_graph;
 int chub_graph_begin(chub_env *env, void *stream);

@@ -264,8 +264,10 @@ static float normal_float_compat(orc_rng *r, float mean, float sd) {
 }
 
 /* PHILOX mode: standard normal from one 32-bit uniform by two-level tabulated inverse CDF (tools/gen_tables.py):
- * 4096 cells, linear interpolation inside a cell; the lowest cell is refined by a second 4096-entry table, the
- * highest cell is its mirror image. */
+ * 4096 cells, linear interpolation inside a cell; the lowest 16 cells (p < 2^-8, where the quantile function bends most) are
+ * refined by a second 4096-entry table with cells of 2^-20, the highest 16 are their mirror image.  Kolmogorov distance to the
+ * normal law <= 2e-6 (tests/test_law_fidelity_cpu.py). */
+#define ORC_NORMAL_TAIL_CELLS 16u
 static float icdf_interp(const float *tab, uint32_t idx, float frac) {
     float a = tab[idx], b = tab[idx + 1];
     float diff = b - a;
@@ -274,11 +276,11 @@ static float icdf_interp(const float *tab, uint32_t idx, float frac) {
 }
 float orc_normal_from_word(const orc_tables *t, uint32_t w) {
     uint32_t cell = w >> 20;
-    if (cell == 4095u) {
-        uint32_t m = ~w; /* < 2^20 */
-        return -icdf_interp(t->normal_tail, m >> 8, (float) (m & 0xFFu) * (1.0f / 256.0f));
+    if (cell >= 4096u - ORC_NORMAL_TAIL_CELLS) {
+        uint32_t m = ~w; /* < 2^24 */
+        return -icdf_interp(t->normal_tail, m >> 12, (float) (m & 0xFFFu) * (1.0f / 4096.0f));
     }
-    if (cell == 0u) return icdf_interp(t->normal_tail, w >> 8, (float) (w & 0xFFu) * (1.0f / 256.0f));
+    if (cell < ORC_NORMAL_TAIL_CELLS) return icdf_interp(t->normal_tail, w >> 12, (float) (w & 0xFFFu) * (1.0f / 4096.0f));
     return icdf_interp(t->normal_icdf, cell, (float) (w & 0xFFFFFu) * (1.0f / 1048576.0f));
 }
 

@@ -24,7 +24,7 @@ class Pair(object):
 
     def __init__(self, kw, n, slot_kernel="auto"):
         chub = hub()
-        self.n, self.kw = n, kw
+        self.n, self.kw, self.slot_kernel = n, kw, slot_kernel
         seed, env_id0 = 0xFEED5EED, 4000
         self.v = chub.VecChargingHub(n, seed=seed, rng="philox", env_id0=env_id0, slot_kernel=slot_kernel, **kw)
         self.v.set_telemetry(True)
@@ -90,6 +90,17 @@ class Pair(object):
         self._compare(rows, ("step", label), True)
         close(obs[rows], self.o_obs[rows], (label, "obs f32"), atol=1e-6)
         return done
+
+    def migrate(self):
+        """checkpoint / resume across handles: snapshot, DESTROY the handle, create a fresh one with the
+        same arguments, restore -- the oracle's envs run on uninterrupted"""
+        chub = hub()
+        snap = self.v.get_state()
+        args = dict(seed=0xFEED5EED, rng="philox", env_id0=4000, slot_kernel=self.slot_kernel)
+        self.v.close()
+        self.v = chub.VecChargingHub(self.n, **args, **self.kw)
+        self.v.set_telemetry(True)  # same arena layout as the handle the snapshot came from
+        self.v.set_state(snap)
 
     def close(self):
         orc.orc_vec_destroy(self.h)
@@ -202,6 +213,48 @@ def test_snapshot_restore_with_clock_groups():
         for p, q in zip(x, y):
             assert np.array_equal(p, q)
     v.close()
+
+
+@pytest.mark.parametrize("shape", ["auto", "wave", "big", "one_station"])
+def test_restore_into_a_fresh_handle_continues_the_oracle_run(shape):
+    """row (f)2: chub_set_state against the ORACLE, not against the library itself.  At several points of a run -- in lock-step
+    in the middle of a day, with the envs on diverged clocks, right after a reset of everybody, with a stuck FCEV list -- the
+    state is taken out of the handle, the handle is destroyed, a fresh handle is created and restored, and the run goes on
+    against the oracle's uninterrupted envs: slot state and station records bit for bit, f64 observation / reward to 1e-9."""
+    kw, slot_kernel = SHAPES[shape]
+    n = 36
+    p = Pair(kw, n, slot_kernel)
+    idx = np.arange(n)
+    p.reset(label="all")
+    for i in range(10):
+        p.step(label=("lock-step", i))
+    p.migrate()                                   # lock-step, slot 10 of the day, draws of the next step pending
+    assert p.v.clock == 10 and p.v.clock_groups == 1
+    for i in range(5):
+        p.step(label=("after the first restore", i))
+    p.reset(idx % 3 == 0, "every third env")
+    p.step(idx < n // 2, "first half only")
+    p.step(idx < n // 2, "first half only")
+    assert p.v.clock_groups == 4
+    p.migrate()                                   # four different clocks; the last launch did not serve everybody
+    assert p.v.clock_groups == 4 and np.array_equal(p.v.env_clocks(), p.t)
+    for i in range(3):
+        p.step(label=("diverged clocks, restored", i))
+    p.step(idx % 2 == 1, "odd envs")
+    p.reset(idx % 5 == 2, "a scattered subset")
+    p.migrate()                                   # right after a masked reset
+    for i in range(82):                           # every group passes the end of its own day
+        d = p.step(label=("towards the end of the day", i))
+        if d.any():
+            p.reset(d, ("reset at done", i))
+            if i % 2:
+                p.migrate()                       # right after a reset at the end of a group's day
+    p.reset(label="everybody")
+    p.migrate()                                   # right after a reset of everybody: one clock again
+    assert p.v.clock_groups == 1
+    for i in range(4):
+        p.step(label=("lock-step again", i))
+    p.close()
 
 
 def test_staggered_hub_on_one_handle():
