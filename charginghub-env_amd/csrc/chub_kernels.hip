@@ -759,6 +759,294 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     }
 }
 
+// ---------------------------------------------------------------------------------------- k_slot_unit: one workgroup per unit
+// Stations of more than 64 piles (the reference takes any size, CHS.hpp:1148, 1458) outside the packed production kernel: COMPAT
+// streams, the scalar-load control mode, PHILOX handles forced onto the wave-local kernels.  One (env, station) unit = ONE
+// workgroup of 256 lanes (S_k <= 256), lane = charger slot; the same phases as slot_body_compat / slot_body_wave with the
+// wave-local steps made workgroup-wide through LDS: ballots of empty slots per wave, the stream walk / the decode of the
+// pre-drawn levels on lane 0, the reference's sequential f32 sums (COMPAT) or 64-bit integer sums (PHILOX: what the packed
+// kernel's BIG path adds up) by lane 0 over the slots in order.  A parity instrument, not a fast path.
+template <bool RESET, int MODE>
+__global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ctx, StepArgs sa, int k) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const HubParams &hp = ctx->hp;
+    const SlotArrays &sl = ctx->sl;
+    const StationArrays &st = ctx->st;
+    const Tables &tb = ctx->tb;
+    __shared__ float s_a[256], s_b[256], s_c[256];  // load mode: emergency, power, power by rank; sums: min, charge, max power per slot
+    __shared__ uint32_t s_u[256], s_v[256], s_w[256];
+    __shared__ float s_soc[256];                    // COMPAT: per-admission variates, by admission rank
+    __shared__ uint64_t s_ball[8];
+    __shared__ int s_hdr[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int env = (int) blockIdx.x;
+    const int64_t N = hp.n_envs;
+    if (!in_group(sa, env)) return;  // the whole workgroup: nothing of an env that is not served is touched
+    const int S = hp.S[k], slot = tid;
+    const bool valid = slot < S;
+    const bool fast = hp.type[k] == 0, cp = hp.constant_charging != 0;
+    const int hub_slot = (k ? hp.S[0] : 0) + slot;
+    const uint32_t idx = MODE == MODE_PHILOX ? (uint32_t) env * (uint32_t) (hp.S[0] + hp.S[1]) + (uint32_t) hub_slot
+                                             : (uint32_t) hp.base[k] + (uint32_t) env * (uint32_t) S + (uint32_t) slot;
+    const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
+    CHUB_G(const float) cls = tb.cls[k];
+
+    // ---- the slot as the previous step left it
+    float power = 0.0f, t_target = 0.0f, t_soc = 0.0f, a = 0.0f, next_power = 0.0f, next_t_soc = 0.0f;
+    int tl = 0, meta = 0;
+    uint32_t w0 = 0u, w1 = 0u;
+    if (!RESET && valid) {
+        a = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot];
+        if (MODE == MODE_COMPAT) {
+            const u32x4 hot = ((CHUB_G(u32x4)) sl.hot)[idx];
+            power = __uint_as_float(hot.x); t_target = __uint_as_float(hot.y); t_soc = __uint_as_float(hot.z);
+            tl = (int) (hot.w & 127u);
+            meta = (int) (hot.w >> 8);
+        } else {
+            const u32x2 s2 = ((CHUB_G(u32x2)) sl.hot)[idx];
+            w0 = s2.x; w1 = s2.y;
+            tl = ps_tl(w0);
+            if (tl > 0) {
+                const f32x4 row = *(CHUB_G(const f32x4)) ((CHUB_G(const char)) cls + ((size_t) ps_cls(w0) * (kClsRow * 8u) + ps_n(w0) * 8u));
+                power = row.x; t_soc = row.y; next_power = row.z; next_t_soc = row.w;
+                t_target = __uint_as_float(w1);
+            }
+        }
+    }
+    bool car = tl > 0, leave = false;
+
+    // ---- on / off: judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373), or the scalar-load control
+    // (assign_on_off, CHS.hpp:1318-1362 / 1629-1674: the piles in urgency order, std::multimap keyed by -emergency)
+    bool on;
+    if (!RESET && sa.load_mode) {
+        const float em0 = car ? emergency_of(t_target, t_soc, tl) : 0.0f;
+        s_a[tid] = em0;
+        __syncthreads();
+        int rk = 0;
+        for (int j = 0; j < S; j++) {
+            const float ej = s_a[j];
+            rk += (ej > em0 || (ej == em0 && j < slot)) ? 1 : 0;
+        }
+        if (valid) {
+            s_c[rk] = car ? power : 0.0f;
+            s_u[rk] = car ? 1u : 0u;
+        }
+        __syncthreads();
+        // catch_load (CHS.hpp:358-366) against the previous calculate_output; rank_power_add (CHS.hpp:1375-1402): sequential f32
+        const StationRec pr = rec_load(st.rec, sidx);
+        float load = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) (k ? hp.S[0] : 0)];
+        if (load > pr.mx) load = pr.mx;
+        else if (load < pr.mn) load = pr.mn;
+        float cum = 0.0f, mine = 0.0f;
+        int cars_before = 0, mine_before = 0;
+        for (int q = 0; q < S; q++) {
+            if (q == rk) mine_before = cars_before;
+            cum = __fadd_rn(cum, s_c[q]);
+            cars_before += (int) s_u[q];
+            if (q == rk) mine = cum;
+        }
+        if (cp) {
+            const float constant_power = fast ? (float) 36.44764034125146 : (float) 5.254973139368931;
+            const int n_on = (int) roundf(__fdiv_rn(load, constant_power));
+            on = car && mine_before < n_on;
+        } else {
+            on = car && ((double) load + 0.0001 >= (double) mine);
+        }
+        __syncthreads();
+    } else {
+        on = car && (a >= kActOnThreshold || must_charge(t_target, t_soc, tl));
+    }
+
+    // ---- car_step (CHS.hpp:900-905 / 1065-1070), remove_car (CHS.hpp:912-923 / 1077-1088)
+    if (MODE == MODE_COMPAT) {
+        if (on) {
+            meta += 1 << 17;
+            float soc_new;
+            const float tt = __fadd_rn(t_soc, 1.0f);
+            if (fast) {
+                car_step_curves<0>(tt, cp, hp.cc, soc_new, power);
+                t_soc = soc_to_time<0>(soc_new, cp);
+            } else {
+                car_step_curves<1>(tt, cp, hp.cc, soc_new, power);
+                t_soc = soc_to_time<1>(soc_new, cp);
+            }
+        }
+        if (car) {
+            tl -= 1;
+            if (tl <= 0) {
+                car = false; leave = true; tl = 0;
+                power = t_target = t_soc = 0.0f;
+                meta = 0;
+            }
+        }
+    } else {
+        if (on && tl > 1) {  // a car that leaves this step is wiped right after its car_step (CHS.hpp:1196-1201)
+            power = next_power;
+            t_soc = next_t_soc;
+            w0 += 1u << 13;
+        }
+        w0 &= ~64u;
+        if (car) {
+            tl -= 1;
+            w0 -= 1u;
+            if (tl <= 0) {
+                car = false;
+                w0 = 0u;
+                power = t_target = t_soc = 0.0f;
+            }
+        }
+        if (RESET) w0 = 0u;
+    }
+    const bool charge = on && car;
+    if (MODE == MODE_PHILOX && charge) w0 |= 64u;
+
+    // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): empties over the whole unit, admission rank = empties below the slot
+    const bool empty = valid && !car;
+    const uint64_t be = __ballot(empty);
+    if (lane == 0) s_ball[wave] = be;
+    __syncthreads();
+    int empties = 0, rank = prefix_count(be);
+    for (int w = 0; w < 4; w++) {
+        const int c = __popcll(s_ball[w]);
+        empties += c;
+        rank += w < wave ? c : 0;
+    }
+    if (tid == 0) {
+        int line = RESET ? 0 : pkd_line(st.rec[4u * sidx + 3u]);
+        int flow, assign;
+        if (MODE == MODE_COMPAT) {
+            const CompatRng &cr = ctx->cr;
+            CompatStream rs;
+            rs.load(cr, env);
+            const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
+            int n_in;
+            if (RESET) {
+                int temp = (int) roundf(rs.normal_f((float) mu, 1.0f));
+                n_in = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
+            } else {
+                const int t_env = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;
+                n_in = (int) tb.cnt[k][t_env * kLevels + rs.level()];
+            }
+            int tline = 0;
+            for (int w = 0; w < line; w++) tline += (rs.level() >= (int) tb.thr_renege[w]) ? 1 : 0;
+            line = tline;
+            int true_in = 0;
+            for (int j = 0; j < n_in; j++) {
+                const int m = line + j;
+                const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
+                true_in += (rs.level() <= thr && j <= S) ? 1 : 0;
+            }
+            flow = fast ? n_in : true_in;  // CHS.hpp:1617 / 1306
+            assign = (line + flow) < empties ? (line + flow) : empties;
+            line = line + flow - assign;
+            line = line < kMaxLine ? line : kMaxLine;
+            for (int rr = 0; rr < assign; rr++) {  // ascending slot order == ascending rank
+                s_soc[rr] = arrive_soc_from(rs.normal_d(7.0, 3.0));
+                s_v[rr] = (uint32_t) rs.level();
+                const int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
+                s_w[rr] = (uint32_t) (late < 0 ? 0 : late);
+            }
+            rs.store(cr, env);
+        } else {
+            const uint64_t pk = st.pk[sa.tick & 1u][sidx];
+            if (RESET) {
+                flow = fast ? (int) (int16_t) (pk & 0xFFFFu) : (int) ((pk >> 16) & 0xFFFFu);
+            } else {
+                line = __popc((uint32_t) pk & ((1u << line) - 1u));
+                const int n_in = (int) (pk >> 10) & 15;
+                flow = fast ? n_in : (int) ((pk >> (14 + 4 * line)) & 15);
+            }
+            assign = (line + flow) < empties ? (line + flow) : empties;
+            line = line + flow - assign;
+            line = line < kMaxLine ? line : kMaxLine;
+        }
+        s_hdr[0] = assign; s_hdr[1] = flow; s_hdr[2] = line;
+    }
+    __syncthreads();
+    const int assign = s_hdr[0];
+    const bool adm = empty && rank < assign;
+    float nc_soc = 0.0f;
+    if (adm) {  // add_car (CHS.hpp:864-877 / 1029-1042)
+        if (MODE == MODE_COMPAT) {
+            const int lev = (int) s_v[rank];
+            const float target = uniform_level(lev, 80.0f, 100.0f);
+            const NewCar nc = fast ? make_car<0>(s_soc[rank], lev, soc_to_time<0>(target, cp), (int) s_w[rank], cp)
+                                   : make_car<1>(s_soc[rank], lev, soc_to_time<1>(target, cp), (int) s_w[rank], cp);
+            nc_soc = nc.soc;
+            t_target = nc.t_target; t_soc = nc.t_soc; tl = nc.stay; power = nc.power;
+            car = tl > 0;
+            meta = nc.stay | (nc.lev << 7);
+        } else {
+            PhiloxCtx px{hp.key[0], hp.key[1], CHUB_TICK(hp, sa.tick), (uint32_t) (hp.env_id0 + env)};
+            const U4 o = px.block(SITE_SOC, (uint32_t) hub_slot, 0);
+            const uint32_t c = o.v[0] >> kSocLevelShift, lev = o.v[1] % 1000u;
+            const f32x2 e0 = *(CHUB_G(const f32x2)) ((CHUB_G(const char)) cls + (size_t) c * (kClsRow * 8u));
+            t_target = tb.ttab[k][lev];
+            const int late = late_from_word(tb.late_thr, o.v[2]);
+            int stay = (int) ceilf(__fsub_rn(t_target, e0.y)) + late;
+            stay = stay > kMaxStay ? kMaxStay : stay;
+            power = e0.x; t_soc = e0.y; tl = stay;
+            car = tl > 0;
+            w0 = car ? ps_make(stay, c) : 0u;
+            w1 = __float_as_uint(t_target);
+        }
+    } else if (MODE == MODE_COMPAT && (leave || RESET)) {
+        meta = 0;
+    }
+
+    // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572)
+    const bool urgent = car && must_charge(t_target, t_soc, tl);
+    const uint64_t bc = __ballot(car);
+    if (lane == 0) s_ball[4 + wave] = bc;
+    if (MODE == MODE_COMPAT) {
+        s_a[tid] = urgent ? power : 0.0f;
+        s_b[tid] = charge ? power : 0.0f;
+        s_c[tid] = car ? power : 0.0f;
+    } else {
+        const int q = (int) (power * 524288.0f);
+        s_u[tid] = (uint32_t) (urgent ? q : 0);
+        s_v[tid] = (uint32_t) (charge ? q : 0);
+        s_w[tid] = (uint32_t) (car ? q : 0);
+    }
+    if (valid) {
+        if (MODE == MODE_COMPAT) {
+            u32x4 h2;
+            h2.x = __float_as_uint(power); h2.y = __float_as_uint(t_target); h2.z = __float_as_uint(t_soc);
+            h2.w = (uint32_t) tl | (charge ? 128u : 0u) | ((uint32_t) meta << 8);
+            ((CHUB_G(u32x4)) sl.hot)[idx] = h2;
+            if (adm) sl.init_soc[idx] = nc_soc;
+        } else {
+            const u32x2 o2 = {w0, w1};
+            ((CHUB_G(u32x2)) sl.hot)[idx] = o2;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int cars = __popcll(s_ball[4]) + __popcll(s_ball[5]) + __popcll(s_ball[6]) + __popcll(s_ball[7]);
+        float r_min, r_chg, r_max;
+        if (MODE == MODE_COMPAT) {  // the reference adds the slot powers sequentially in f32 (CHS.hpp:1244-1255)
+            r_min = r_chg = r_max = 0.0f;
+            for (int i = 0; i < S; i++) {
+                r_max = __fadd_rn(r_max, s_c[i]);
+                r_min = __fadd_rn(r_min, s_a[i]);
+                r_chg = __fadd_rn(r_chg, s_b[i]);
+            }
+        } else {  // order-independent: 64-bit sums of the slot powers in units of 2^-19 kW, one rounding to f32
+            long long i_min = 0, i_chg = 0, i_max = 0;
+            for (int i = 0; i < S; i++) {
+                i_min += (long long) (int) s_u[i];
+                i_chg += (long long) (int) s_v[i];
+                i_max += (long long) (int) s_w[i];
+            }
+            r_min = (float) i_min * (1.0f / 524288.0f);
+            r_chg = (float) i_chg * (1.0f / 524288.0f);
+            r_max = (float) i_max * (1.0f / 524288.0f);
+        }
+        rec_store(st.rec, sidx, r_min, r_chg, r_max, pkd_make(s_hdr[2], s_hdr[1], cars));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // k_slot_packed: the PHILOX step (production).  PHILOX slot state is laid out hub-major, [env][hub slot] (station 0's piles,
 // then station 1's), like the action rows: the workgroup's BLOCK * T virtual lanes map onto epb = BLOCK * T / (S0 + S1) whole
@@ -2036,14 +2324,17 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
                           hipEvent_t ev1) {
     constexpr int BLOCK = 256;
     const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
-    if (MODE == MODE_PHILOX) {
-        if (RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((8 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
+    const bool big = hp.S[0] > 64 || hp.S[1] > 64;  // a unit of more than 64 piles is a workgroup of its own (k_slot_unit)
+    if (MODE == MODE_PHILOX && RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((8 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
+    if (MODE == MODE_PHILOX && !big) {
         CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, ev1, ctx, sa, nb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
             StepArgs s2 = sa;
             s2.station_filter = k;
-            CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), stream, k == 0 ? ev0 : nullptr, k == 1 ? ev1 : nullptr, ctx, s2, nb0);
+            hipEvent_t e0 = k == 0 ? ev0 : nullptr, e1 = k == 1 ? ev1 : nullptr;
+            if (hp.S[k] > 64) CHUB_LAUNCH((k_slot_unit<RESET, MODE>), dim3((unsigned) hp.n_envs), dim3(256), stream, e0, e1, ctx, s2, k);
+            else CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), stream, e0, e1, ctx, s2, nb0);
         }
     }
 }
@@ -2125,6 +2416,30 @@ void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepAr
 }
 
 __global__ void k_tick_advance(uint32_t *tick_base, uint32_t by) { *tick_base += by; }
+
+// chub_step_bits: the pile decisions arrive as one bit per pile (what action_to_real makes of the action row, MGR:384-393) and
+// the two tail actions as floats; this writes the [N, S + 2] f32 action rows the step kernels read: +1 / -1 for the piles (any
+// value on the same side of the threshold gives the same step), the tail as it is
+__global__ void k_expand_bits(int64_t n_envs, int S, int W, const uint64_t *__restrict__ bits, const float *__restrict__ tail,
+                              float *__restrict__ actions) {
+    const int A = S + 2;
+    const int64_t total = n_envs * (int64_t) A;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t env = i / A;
+        const int j = (int) (i - env * A);
+        float v;
+        if (j < S) v = ((bits[env * W + (j >> 6)] >> (j & 63)) & 1ull) ? 1.0f : -1.0f;
+        else v = tail[env * 2 + (j - S)];
+        actions[i] = v;
+    }
+}
+void launch_expand_bits(const HubParams &hp, const uint64_t *d_bits, const float *d_tail, float *d_actions, hipStream_t stream) {
+    const int S = hp.S[0] + hp.S[1];
+    const int64_t total = hp.n_envs * (int64_t) (S + 2);
+    int64_t nb = (total + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(k_expand_bits, dim3((unsigned) nb), dim3(256), 0, stream, hp.n_envs, S, (S + 63) / 64, d_bits, d_tail, d_actions);
+}
 
 // entering per-env clocks: every env starts from the handle's lock-step clock
 __global__ void k_fill_clocks(uint16_t *dst, int64_t n, uint16_t value) {

@@ -26,6 +26,7 @@ void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, fl
 void launch_compat_ctor_sweep(const HubParams &hp, const DevCtx *ctx, hipStream_t stream);
 void launch_tick_advance(uint32_t *tick_base, uint32_t by, hipStream_t stream);
 void launch_fill_clocks(uint16_t *dst, int64_t n, uint16_t value, hipStream_t stream);
+void launch_expand_bits(const HubParams &hp, const uint64_t *d_bits, const float *d_tail, float *d_actions, hipStream_t stream);
 }  // namespace chub
 
 using namespace chub;
@@ -88,6 +89,8 @@ struct chub_env {
     // host-pointer entry points: pinned staging + a private stream (lazily made by host_path_init)
     hipStream_t host_stream;
     float *h_actions, *h_packed;  // pinned: [N][A], [N][D+2]
+    uint64_t *h_bits, *d_bits;    // chub_step_bits: [N][ceil(S / 64)] pinned staging and its device copy
+    float *h_tail, *d_tail;       //                 [N][2]
     float *d_packed;              // [N][D+2]
     int tape_classes;   // PHILOX tape mode: caller-registered arrival-SoC classes so far
     uint32_t h_late8[8];
@@ -350,10 +353,8 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     for (int k = 0; k < 2; k++) {
         if (cfg->station_list[k] < 0) return fail(CHUB_ERR_ARG, "station_list entries must be >= 0");
         // the production (PHILOX) kernel lays whole envs over a workgroup's 512 virtual lanes and counts car_number in 16 bits;
-        // the COMPAT kernel (parity instrument) keeps one unit inside a wave
-        if (cfg->station_list[k] > (rng_mode == CHUB_RNG_PHILOX ? 256 : 64))
-            return fail(CHUB_ERR_UNSUPPORTED, rng_mode == CHUB_RNG_PHILOX ? "more than 256 piles per station is not supported"
-                                                                           : "COMPAT streams: more than 64 piles per station is not supported");
+        // the wave-local kernels keep a unit of up to 64 piles inside a wave and give a larger one a workgroup of 256 lanes
+        if (cfg->station_list[k] > 256) return fail(CHUB_ERR_UNSUPPORTED, "more than 256 piles per station is not supported");
         if (cfg->station_type_list[k] != CHUB_FAST && cfg->station_type_list[k] != CHUB_SLOW)
             return fail(CHUB_ERR_ARG, "EVS type must be fast or slow");  // AGG:196
     }
@@ -380,6 +381,8 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->stream = nullptr;
     e->host_stream = nullptr;
     e->h_actions = e->h_packed = e->d_packed = nullptr;
+    e->h_bits = e->d_bits = nullptr;
+    e->h_tail = e->d_tail = nullptr;
     e->prof_used = e->prof_cap = 0;
     e->prof_on = false;
     e->arena = nullptr;
@@ -663,9 +666,6 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         hp.packed = (rng_mode == CHUB_RNG_PHILOX && St >= 4 && St <= pb && magic_ok &&
                      (uint64_t) n_envs * (uint64_t) (St + 2) * 16u < ((uint64_t) 1 << 32) &&  // 32-bit byte offsets
                      opt.slot_kernel != 1) ? 1 : 0;
-        if ((hp.S[0] > 64 || hp.S[1] > 64) && !hp.packed)
-            return bail(fail(CHUB_ERR_UNSUPPORTED, "stations with more than 64 piles run on the packed slot kernel only: at most 512 "
-                                                   "piles per hub, n_envs * (piles + 2) * 16 < 2^32, slot_kernel not forced to 1"));
     }
     build_hy_table(hp, e->hy_table);
     std::vector<double> hy_v(e->hy_table, e->hy_table + 102);
@@ -782,6 +782,10 @@ int chub_destroy(chub_env *e) {
         for (hipEvent_t ev : e->mask_done)
             if (ev) (void) hipEventDestroy(ev);
         if (e->h_packed) (void) hipHostFree(e->h_packed);
+        if (e->h_bits) (void) hipHostFree(e->h_bits);
+        if (e->h_tail) (void) hipHostFree(e->h_tail);
+        if (e->d_bits) (void) hipFree(e->d_bits);
+        if (e->d_tail) (void) hipFree(e->d_tail);
         if (e->d_packed) (void) hipFree(e->d_packed);
         if (e->host_stream) (void) hipStreamDestroy(e->host_stream);
     }
@@ -949,8 +953,6 @@ int chub_step_gather(chub_env *e, chub_comm *comm, const float *d_actions, float
 int chub_step_load_device(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
                           uint8_t *d_done, void *stream) {
     if (!e || !d_actions || !d_obs || !d_reward || !d_done) return fail(CHUB_ERR_ARG, "null argument");
-    if (e->hp.S[0] > 64 || e->hp.S[1] > 64)
-        return fail(CHUB_ERR_UNSUPPORTED, "scalar-load control: stations with more than 64 piles are not supported");
     return step_common(e, d_actions, d_exo_z, d_obs, e->hp.obs_dim, d_reward, 1, d_done, nullptr, stream, 1);
 }
 
@@ -1053,6 +1055,13 @@ int chub_step_envs_device(chub_env *e, const uint8_t *mask, const float *d_actio
     return step_masked(e, mask, d_actions, d_exo_z, d_obs, e->hp.obs_dim, d_reward, 1, d_done, nullptr, stream, 0);
 }
 
+// the scalar-load step on a subset of the envs (every reference env can take evs_step(float) on its own, CHS.hpp:1169-1186 / 1480-1497)
+int chub_step_load_envs_device(chub_env *e, const uint8_t *mask, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
+                               uint8_t *d_done, void *stream) {
+    if (!e || !mask || !d_actions || !d_obs || !d_reward || !d_done) return fail(CHUB_ERR_ARG, "null argument");
+    return step_masked(e, mask, d_actions, d_exo_z, d_obs, e->hp.obs_dim, d_reward, 1, d_done, nullptr, stream, 1);
+}
+
 // host-pointer forms: full-size arrays, only the rows of the named envs are read and written
 int chub_reset_envs(chub_env *e, const uint8_t *mask, const int32_t *exo_days, const double *exo_z, float *obs) {
     if (!e || !mask || !obs) return fail(CHUB_ERR_ARG, "null argument");
@@ -1075,7 +1084,8 @@ int chub_reset_envs(chub_env *e, const uint8_t *mask, const int32_t *exo_days, c
     return CHUB_OK;
 }
 
-int chub_step_envs(chub_env *e, const uint8_t *mask, const float *actions, const double *exo_z, float *obs, float *reward, uint8_t *done) {
+static int step_envs_host(chub_env *e, const uint8_t *mask, const float *actions, const double *exo_z, float *obs, float *reward, uint8_t *done,
+                          int load_mode) {
     if (!e || !mask || !actions || !obs || !reward || !done) return fail(CHUB_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     const size_t N = (size_t) e->hp.n_envs, A = (size_t) e->hp.act_dim, D = (size_t) e->hp.obs_dim;
@@ -1084,7 +1094,8 @@ int chub_step_envs(chub_env *e, const uint8_t *mask, const float *actions, const
         if (!exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
         HIP_TRY(hipMemcpy(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice));
     }
-    int rc = chub_step_envs_device(e, mask, e->d_actions, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, nullptr);
+    int rc = load_mode ? chub_step_load_envs_device(e, mask, e->d_actions, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, nullptr)
+                       : chub_step_envs_device(e, mask, e->d_actions, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, nullptr);
     if (rc) return rc;
     std::vector<float> o(N * D), r(N);
     std::vector<uint8_t> d(N);
@@ -1098,6 +1109,14 @@ int chub_step_envs(chub_env *e, const uint8_t *mask, const float *actions, const
             done[i] = d[i];
         }
     return CHUB_OK;
+}
+
+int chub_step_envs(chub_env *e, const uint8_t *mask, const float *actions, const double *exo_z, float *obs, float *reward, uint8_t *done) {
+    return step_envs_host(e, mask, actions, exo_z, obs, reward, done, 0);
+}
+
+int chub_step_load_envs(chub_env *e, const uint8_t *mask, const float *actions, const double *exo_z, float *obs, float *reward, uint8_t *done) {
+    return step_envs_host(e, mask, actions, exo_z, obs, reward, done, 1);
 }
 
 // slot of day (and, if asked, the Philox tick of the last launch) of every env
@@ -1187,6 +1206,64 @@ int chub_step(chub_env *e, const float *actions, const double *exo_z, float *obs
     // from the handle's pinned buffer (chub_host_actions) this is one DMA; any other host pointer is staged by the HIP runtime
     HIP_TRY(hipMemcpyAsync(e->d_actions, actions, N * A * sizeof(float), hipMemcpyHostToDevice, s));
     rc = chub_step_device(e, e->d_actions, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(obs, e->d_obs, N * D * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(done, e->d_done, N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return CHUB_OK;
+}
+
+// ---- packed-action form of the host-pointer step: one bit per pile + the two tail floats (16 bytes per env for hubs of up to
+// 64 piles instead of 4 * (S + 2)): what action_to_real (MGR:384-393) keeps of an action row.  The bits are expanded on the
+// device into the action rows the step kernels read, so the step itself is the one chub_step runs, bit for bit.
+static int bits_path_init(chub_env *e) {
+    int rc = host_path_init(e);
+    if (rc || e->h_bits) return rc;
+    const size_t N = (size_t) e->hp.n_envs, W = (size_t) ((e->hp.S[0] + e->hp.S[1] + 63) / 64);
+    HIP_TRY(hipHostMalloc((void **) &e->h_bits, N * W * sizeof(uint64_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **) &e->h_tail, N * 2 * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **) &e->d_bits, N * W * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **) &e->d_tail, N * 2 * sizeof(float)));
+    return CHUB_OK;
+}
+
+int chub_host_bits(chub_env *e, uint64_t **bits_out, float **tail_out) {
+    if (!e || !bits_out || !tail_out) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = bits_path_init(e);
+    if (rc) return rc;
+    *bits_out = e->h_bits;
+    *tail_out = e->h_tail;
+    return CHUB_OK;
+}
+
+int chub_step_bits_device(chub_env *e, const uint64_t *d_pile_bits, const float *d_tail, const double *d_exo_z, float *d_obs,
+                          float *d_reward, uint8_t *d_done, void *stream) {
+    if (!e || !d_pile_bits || !d_tail || !d_obs || !d_reward || !d_done) return fail(CHUB_ERR_ARG, "null argument");
+    if (e->tick == 0) return fail(CHUB_ERR_ARG, "step() before reset()");
+    HIP_TRY(hipSetDevice(e->device));
+    launch_expand_bits(e->hp, d_pile_bits, d_tail, e->d_actions, (hipStream_t) stream);
+    HIP_TRY(hipGetLastError());
+    return chub_step_device(e, e->d_actions, d_exo_z, d_obs, d_reward, d_done, stream);
+}
+
+int chub_step_bits(chub_env *e, const uint64_t *pile_bits, const float *tail, const double *exo_z, float *obs, float *reward,
+                   uint8_t *done) {
+    if (!e || !pile_bits || !tail || !obs || !reward || !done) return fail(CHUB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = bits_path_init(e);
+    if (rc) return rc;
+    const size_t N = (size_t) e->hp.n_envs, D = (size_t) e->hp.obs_dim, W = (size_t) ((e->hp.S[0] + e->hp.S[1] + 63) / 64);
+    hipStream_t s = e->host_stream;
+    if (e->hp.rng_mode == CHUB_RNG_COMPAT) {
+        if (!exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
+        HIP_TRY(hipMemcpyAsync(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    // from the handle's pinned buffers (chub_host_bits) each of these is one DMA; any other host pointer is staged by the HIP runtime
+    HIP_TRY(hipMemcpyAsync(e->d_bits, pile_bits, N * W * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->d_tail, tail, N * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+    rc = chub_step_bits_device(e, e->d_bits, e->d_tail, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, s);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(obs, e->d_obs, N * D * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost, s));

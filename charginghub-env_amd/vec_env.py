@@ -118,6 +118,49 @@ class VecChargingHub(object):
             self._pinned = np.frombuffer(buf, dtype=np.float32).reshape(self.n_envs, self.act_dim)
         return self._pinned
 
+    # ---- packed actions (chub_step_bits): one bit per pile + the two tail floats, 16 bytes per env up to 64 piles
+    @property
+    def bit_words(self):
+        return (self.n_slots + 63) // 64
+
+    def pack_actions(self, actions, out=None):
+        """[N, A] f32 action rows -> (pile_bits [N, ceil(S / 64)] u64, tail [N, 2] f32): exactly what action_to_real
+        (evcssp_manager.py:384-393) keeps of them -- pile on iff f32((a + 1) / 2) >= 0.5, i.e. a >= -2^-25.  out: the arrays to
+        fill (e.g. pinned_bits())"""
+        a = np.asarray(actions, dtype=np.float32)
+        if a.shape != (self.n_envs, self.act_dim):
+            raise AssertionError("actions must have shape (%d, %d)" % (self.n_envs, self.act_dim))
+        bits, tail = out if out is not None else (np.zeros((self.n_envs, self.bit_words), dtype=np.uint64),
+                                                  np.zeros((self.n_envs, 2), dtype=np.float32))
+        on = a[:, :self.n_slots] >= np.float32(-2.0 ** -25)
+        packed = np.packbits(on, axis=1, bitorder="little")
+        pad = self.bit_words * 8 - packed.shape[1]
+        if pad:
+            packed = np.concatenate([packed, np.zeros((self.n_envs, pad), dtype=np.uint8)], axis=1)
+        bits[...] = np.ascontiguousarray(packed).view("<u8")
+        tail[...] = a[:, self.n_slots:]
+        return bits, tail
+
+    def pinned_bits(self):
+        """the handle's pinned (pile_bits, tail) staging arrays (chub_host_bits): fill them in place and pass them to step_bits()"""
+        if getattr(self, "_pinned_bits", None) is None:
+            pb, pt = C.c_void_p(), C.c_void_p()
+            check(self._lib.chub_host_bits(self._h, C.byref(pb), C.byref(pt)))
+            b = np.frombuffer((C.c_uint64 * (self.n_envs * self.bit_words)).from_address(pb.value), dtype=np.uint64)
+            t = np.frombuffer((C.c_float * (self.n_envs * 2)).from_address(pt.value), dtype=np.float32)
+            self._pinned_bits = (b.reshape(self.n_envs, self.bit_words), t.reshape(self.n_envs, 2))
+        return self._pinned_bits
+
+    def step_bits(self, pile_bits, tail, exo_z=None):
+        """step() with the actions already reduced to what the env uses of them: 16 bytes per env over PCIe instead of 4 (S + 2)"""
+        b = np.ascontiguousarray(pile_bits, dtype=np.uint64)
+        t = np.ascontiguousarray(tail, dtype=np.float32)
+        if b.shape != (self.n_envs, self.bit_words) or t.shape != (self.n_envs, 2):
+            raise AssertionError("pile_bits must have shape (%d, %d) and tail (%d, 2)" % (self.n_envs, self.bit_words, self.n_envs))
+        z = None if exo_z is None else np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)).reshape(self.n_envs, 3)
+        check(self._lib.chub_step_bits(self._h, _ptr(b), _ptr(t), _ptr(z), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
+        return self._out()
+
     def load_actions(self, loads, tail):
         """[N, A] action array of the scalar-load mode: loads [N, 2] in kW (one per station), tail [N, 2] as in step()."""
         a = np.zeros((self.n_envs, self.act_dim), dtype=np.float32)
@@ -183,6 +226,14 @@ class VecChargingHub(object):
             raise AssertionError("actions must have shape (%d, %d)" % (self.n_envs, self.act_dim))
         z = np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)) if exo_z is not None else None
         check(self._lib.chub_step_envs(self._h, _ptr(m), _ptr(a), _ptr(z), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
+        return self._out()
+
+    def step_load_envs(self, mask, loads, tail, exo_z=None):
+        """step_load() for the envs of `mask` only"""
+        m = self._mask(mask)
+        a = self.load_actions(loads, tail)
+        z = np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)) if exo_z is not None else None
+        check(self._lib.chub_step_load_envs(self._h, _ptr(m), _ptr(a), _ptr(z), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
         return self._out()
 
     def env_clocks(self, ticks=False):
@@ -339,7 +390,7 @@ class VecChargingHub(object):
         if getattr(self, "_h", None):
             self._lib.chub_destroy(self._h)
             self._h = None
-            self._obs = self._reward = self._done = self._pinned = None
+            self._obs = self._reward = self._done = self._pinned = self._pinned_bits = None
             for p in self._host_allocs:
                 self._lib.chub_free_host(self._device, p)
             self._host_allocs = []

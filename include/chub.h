@@ -116,6 +116,18 @@ int chub_step(chub_env *env, const float *actions, const double *exo_z, float *o
  * saves the CPU copy into pinned memory (any other host pointer works too). */
 int chub_host_actions(chub_env *env, float **out);
 
+/* Packed-action form of chub_step for hosts that sit behind PCIe: all that action_to_real (MGR:384-393) keeps of an action row is
+ * one bit per pile ((a + 1) / 2 >= 0.5) and the two tail floats, so that is what travels: pile_bits [N, ceil(S / 64)] u64 (bit b of
+ * word w = hub slot 64 w + b: station 0's piles first, as in an action row; 1 = on) and tail [N, 2] f32 = the last two entries
+ * of the action row, unchanged.  16 bytes per env for hubs of up to 64 piles instead of 4 (S + 2).  Results are bit for bit those of
+ * chub_step on any action rows with the same bits and tail.  chub_host_bits: the handle's pinned staging for both arrays (fill in
+ * place and pass these pointers to save a staging copy).  The _device form takes device pointers on `stream`. */
+int chub_step_bits(chub_env *env, const uint64_t *pile_bits, const float *tail, const double *exo_z, float *obs, float *reward,
+                   uint8_t *done);
+int chub_host_bits(chub_env *env, uint64_t **pile_bits_out, float **tail_out);
+int chub_step_bits_device(chub_env *env, const uint64_t *d_pile_bits, const float *d_tail, const double *d_exo_z, float *d_obs,
+                          float *d_reward, uint8_t *d_done, void *stream);
+
 /* Same, all pointers device memory, enqueued on `stream` (a hipStream_t, NULL = default stream);
  * returns after enqueueing.  This is the form the multi-GPU host and bench.py use. */
 int chub_reset_device(chub_env *env, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs, void *stream);
@@ -148,6 +160,11 @@ int chub_clock_groups(chub_env *env);
 int chub_step_load(chub_env *env, const float *actions, const double *exo_z, float *obs, float *reward, uint8_t *done);
 int chub_step_load_device(chub_env *env, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
                           uint8_t *d_done, void *stream);
+/* ... and on a subset of the envs (mask as for chub_step_envs: every reference station takes evs_step(float) on its own) */
+int chub_step_load_envs(chub_env *env, const uint8_t *mask, const float *actions, const double *exo_z, float *obs, float *reward,
+                        uint8_t *done);
+int chub_step_load_envs_device(chub_env *env, const uint8_t *mask /* host */, const float *d_actions, const double *d_exo_z, float *d_obs,
+                               float *d_reward, uint8_t *d_done, void *stream);
 
 /* Packed form for the multi-GPU gather: one [N, D+2] f32 buffer, row = obs[D], reward, done (0.0 / 1.0), so that
  * a shard's whole step output travels in a single RCCL gather. */

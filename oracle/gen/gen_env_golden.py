@@ -231,6 +231,9 @@ def main():
     out = run("env_fcev_queue_deep", base_kwargs(fcev_permeate=0.08, hydro_store_vlt=400, init_soc=0.6), 1, 70, "random",
               (1919, 2020), py_seed=10)
     assert out["telem"][:, 21].max() > 64, out["telem"][:, 21].max()
+    # stations of more than 64 piles (the reference takes any size, CHS:1148, 1458): 100 fast + 70 slow, a big electrolyser
+    run("env_big_100_70", base_kwargs(station_list=[100, 70], hydro_prod_rate=2000, hydro_store_vlt=5000, init_soc=0.5,
+                                      fcev_permeate=0.02), 2, 60, "random", (2121, 2222), py_seed=11)
 
 
 if __name__ == "__main__":

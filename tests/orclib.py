@@ -274,7 +274,8 @@ def golden_config(g):
 
 
 GOLDEN_ENV = ["env_c1_envtest", "env_c3_random", "env_c2_random", "env_c5_random", "env_slow_only_fcev",
-              "env_clamp", "env_full_tank", "env_constant", "env_fcev_queue", "env_small_fast_neg", "env_fcev_queue_deep"]
+              "env_clamp", "env_full_tank", "env_constant", "env_fcev_queue", "env_small_fast_neg", "env_fcev_queue_deep",
+              "env_big_100_70"]
 
 
 class OrcEnv:

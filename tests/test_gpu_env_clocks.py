@@ -403,6 +403,49 @@ def test_scalar_load_steps_while_envs_are_on_their_own_clocks():
     p.close()
 
 
+@pytest.mark.parametrize("shape", ["auto", "big"])
+def test_masked_scalar_load_steps_match_the_oracle(shape):
+    """chub_step_load_envs: evs_step(float) for a SUBSET of the envs (every reference station takes it on its own,
+    CHS.hpp:1169-1186 / 1480-1497), mixed with masked vector-action steps and resets, the envs on diverged clocks"""
+    kw, slot_kernel = SHAPES[shape]
+    kw = dict(kw, renew_fluctuate=0.0, price_fluctuate=0.0, hydro_loss=0.0)
+    n = 30
+    p = Pair(kw, n, slot_kernel)
+    p.reset(label="all")
+    for i in range(3):
+        p.step(label=("lock-step", i))
+    rs = np.random.RandomState(16)
+    for t in range(40):
+        kind = rs.randint(4)
+        mask = rs.uniform(size=n) < rs.choice([0.1, 0.5, 0.9])
+        if kind == 0:
+            p.reset(mask, ("reset", t))
+            continue
+        if kind == 1:
+            p.step(mask, ("vector step", t))
+            continue
+        rows = np.nonzero(mask)[0]
+        sc = p.v.station_scalars()
+        loads = np.stack([rs.uniform(0, 1.2, n) * (sc[:, 0, 2] + 1.0), rs.uniform(0, 1.2, n) * (sc[:, 1, 2] + 1.0)], axis=1).astype(np.float32)
+        tail = rs.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+        act = p.v.load_actions(loads, tail)
+        obs, rew, done, _ = p.v.step_load_envs(mask, loads, tail)
+        if len(rows) == 0:
+            continue
+        _, ticks = p.v.env_clocks(ticks=True)
+        for e in rows:
+            p._oracle_tick(e, ticks[e])
+            d, r = C.c_int(0), C.c_double(0.0)
+            orc.orc_env_step_load(orc.orc_vec_env(p.h, e), ptr(act[e]), None, ptr(p.o_obs[e]), C.byref(r), C.byref(d))
+            p.o_rew[e], p.o_done[e] = r.value, d.value
+        p.t[rows] = (p.t[rows] + 1) % 96
+        assert np.array_equal(p.v.env_clocks(), p.t)
+        assert np.array_equal(done[rows], p.o_done[rows].astype(bool))
+        p._compare(rows, ("masked load step", t), True)
+    assert p.v.clock_groups > 2
+    p.close()
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_random_sequences_of_masked_calls_match_the_oracle(seed):
     """300 calls drawn at random -- resets and steps of random subsets (sparse, dense, single envs, everybody, nobody) --

@@ -161,7 +161,8 @@ def test_philox_matches_oracle(label, kw, n):
     _philox_parity(label, kw, n)
 
 
-@pytest.mark.parametrize("label,kernel", [("c3", "wave"), ("constant", "wave"), ("c5", "wave"), ("max64", "wave"), ("c2", "wave")])
+@pytest.mark.parametrize("label,kernel", [("c3", "wave"), ("constant", "wave"), ("c5", "wave"), ("max64", "wave"), ("c2", "wave"),
+                                          ("big_100_70", "wave"), ("big_256", "wave")])
 def test_philox_other_slot_kernel(label, kernel):
     """PHILOX steps have two slot kernels (wave-local units / units packed end to end over the workgroup) and the
     library picks the packed one wherever the hub shape allows: force the other one (chub_options.slot_kernel) through
@@ -399,14 +400,17 @@ def test_snapshot_restore_roundtrip(rng):
 
 @pytest.mark.parametrize("cc", [False, True])
 @pytest.mark.parametrize("rng", ["philox", "compat"])
-def test_scalar_load_mode_matches_oracle(rng, cc):
+@pytest.mark.parametrize("piles", [(20, 25), (100, 70), (3, 170)], ids=["20_25", "100_70", "3_170"])
+def test_scalar_load_mode_matches_oracle(piles, rng, cc):
     """evs_step(float) on the GPU against the oracle, whose station code for this mode is pinned
-    bit for bit against the reference (tests/test_oracle_vs_ref.py::test_station_scalar_load_mode)."""
+    bit for bit against the reference (tests/test_oracle_vs_ref.py::test_station_scalar_load_mode, up to 170 piles).  Stations of
+    more than 64 piles: a unit is a workgroup of its own (k_slot_unit) and the multimap order of assign_on_off
+    (CHS.hpp:1318-1362 / 1629-1674) is a rank over the whole workgroup."""
     chub = hub()
-    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+    kw = dict(station_list=list(piles), station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
               init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01, constant_charging=cc, renew_fluctuate=0.0,
               price_fluctuate=0.0, hydro_loss=0.0)
-    n, seed = 70, 99
+    n, seed = (70, 99) if piles == (20, 25) else (9, 99)
     v = chub.VecChargingHub(n, seed=seed, rng=rng, **kw)
     v.set_telemetry(True)
     cfg = orclib.make_config(piles=kw["station_list"], types=kw["station_type_list"], constant_charging=cc,
@@ -436,7 +440,7 @@ def test_scalar_load_mode_matches_oracle(rng, cc):
         sc = v.station_scalars()
         for e in range(n):
             env = orc.orc_vec_env(h, e)
-            for k, nk in ((0, 20), (1, 25)):
+            for k, nk in ((0, piles[0]), (1, piles[1])):
                 want = np.zeros((9, nk), dtype=np.float32)
                 orc.orc_station_slots(orc.orc_env_station(env, k), ptr(want))
                 check_slots(sl[k][e], want, ("load mode", rng, cc, t, e, k))
@@ -863,6 +867,42 @@ def test_full_size_c5_properties():
     whole.close()
     for p in parts:
         p.close()
+
+
+@pytest.mark.parametrize("label", ["c3", "big_100_70", "one_pile", "max64"])
+def test_step_bits_equals_step_on_the_thresholded_actions(label):
+    """chub_step_bits (one bit per pile + the two tail floats over PCIe) against chub_step on the full f32 action rows: the same
+    handle arguments, the same actions -- observation, reward, done, slot state and station records bit for bit
+    (action_to_real, evcssp_manager.py:384-393: a pile is on iff f32((a + 1) / 2) >= 0.5, i.e. a >= -2^-25)"""
+    chub = hub()
+    kw, n = next((c[1], c[2]) for c in PHILOX_CASES if c[0] == label)
+    a = chub.VecChargingHub(n, seed=99, **kw)
+    b = chub.VecChargingHub(n, seed=99, **kw)
+    S = a.n_slots
+    assert b.bit_words == (S + 63) // 64
+    rs = np.random.RandomState(4)
+    assert np.array_equal(a.reset(), b.reset())
+    pinned = b.pinned_bits()
+    for t in range(40):
+        act = rs.uniform(-1, 1, size=(n, a.act_dim)).astype(np.float32)
+        edge = rs.randint(0, 6, size=(n, S))  # values at and around the threshold
+        act[:, :S] = np.where(edge == 0, np.float32(-2.0 ** -25), np.where(edge == 1, np.nextafter(np.float32(-2.0 ** -25), np.float32(-1)), act[:, :S]))
+        if t % 9 == 0:
+            act[:, :S] = 1.0 if t % 2 else -1.0
+        o1, r1, d1, _ = a.step(act)
+        bits, tail = b.pack_actions(act, out=pinned if t % 2 else None)
+        # the packing itself, against the definition: bit j of env e
+        for e in (0, n - 1):
+            for j in (0, S - 1, S // 2):
+                assert bool((int(bits[e, j >> 6]) >> (j & 63)) & 1) == bool(np.float32((act[e, j] + np.float32(1)) / np.float32(2)) >= np.float32(0.5))
+        o2, r2, d2, _ = b.step_bits(bits, tail)
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2), (label, t)
+    assert all(np.array_equal(x, y) for x, y in zip(a.slots(), b.slots()))
+    assert np.array_equal(a.station_scalars(), b.station_scalars())
+    with pytest.raises(AssertionError):
+        b.step_bits(np.zeros((n, b.bit_words + 1), dtype=np.uint64), np.zeros((n, 2), dtype=np.float32))
+    a.close()
+    b.close()
 
 
 def test_copy_outputs_false_returns_the_pinned_arrays():

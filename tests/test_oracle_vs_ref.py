@@ -136,7 +136,8 @@ def _action_program(kind, step, n, rs):
 
 
 @pytest.mark.parametrize("typ,piles", [(FAST, 16), (SLOW, 16), (FAST, 20), (SLOW, 25), (FAST, 32), (SLOW, 32),
-                                       (FAST, 1), (SLOW, 3), (FAST, 0), (SLOW, 64)])
+                                       (FAST, 1), (SLOW, 3), (FAST, 0), (SLOW, 64),
+                                       (FAST, 100), (SLOW, 170), (FAST, 256)])  # the reference takes any size (CHS.hpp:1148, 1458)
 @pytest.mark.parametrize("kind", ["ones", "zeros", "random"])
 def test_station_trajectories(typ, piles, kind):
     r = orclib.ref()
@@ -161,7 +162,7 @@ def test_station_trajectories(typ, piles, kind):
             assert np.array_equal(a.scalars(), b.scalars()), (ep, step, a.scalars(), b.scalars())
 
 
-@pytest.mark.parametrize("typ,piles", [(FAST, 20), (SLOW, 25)])
+@pytest.mark.parametrize("typ,piles", [(FAST, 20), (SLOW, 25), (FAST, 100), (SLOW, 170)])
 @pytest.mark.parametrize("cc", [False, True])
 def test_station_scalar_load_mode(typ, piles, cc):
     """evs_step(float): the other operator of the boundary."""

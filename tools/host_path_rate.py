@@ -50,3 +50,29 @@ for i in range(steps):
 dt = time.perf_counter() - t0
 print("  ... copy_outputs=False (the handle's pinned arrays are returned, no copies on the Python side): %.3f ms/step, %.1f M env-steps/s"
       % (dt / steps * 1e3, n * steps / dt / 1e6))
+
+# ---- packed actions (chub_step_bits): one bit per pile + the two tail floats, 16 bytes per env instead of 4 * (S + 2)
+bits, tail = v.pinned_bits()
+v.pack_actions(a, out=(bits, tail))
+v.reset()
+for _ in range(20):
+    v.step_bits(bits, tail)
+t0 = time.perf_counter()
+for i in range(steps):
+    if i % 96 == 0:
+        v.reset()
+    v.step_bits(bits, tail)
+dt = time.perf_counter() - t0
+print("packed-action path (chub_step_bits, bits resident in the handle's pinned staging, copy_outputs=False): %.3f ms/step, "
+      "%.1f M env-steps/s; PCIe %d B up + %d B down per env-step"
+      % (dt / steps * 1e3, n * steps / dt / 1e6, v.bit_words * 8 + 8, (v.obs_dim + 1) * 4 + 1))
+t0 = time.perf_counter()
+for i in range(steps):
+    if i % 96 == 0:
+        v.reset()
+    v.pack_actions(a, out=(bits, tail))
+    v.step_bits(bits, tail)
+dt = time.perf_counter() - t0
+print("  ... packing the f32 action rows on the host (numpy) inside the loop: %.3f ms/step, %.1f M env-steps/s"
+      % (dt / steps * 1e3, n * steps / dt / 1e6))
+v.close()
