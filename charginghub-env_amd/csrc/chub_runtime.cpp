@@ -70,6 +70,15 @@ struct chub_env {
     uint8_t *h_mask;                // [2][N] pinned staging for them
     hipEvent_t mask_done[2];        // recorded behind the launches that read d_mask[i]
     uint32_t mask_seq;
+    const uint8_t *cur_mask;        // device copy of the mask of the call in progress
+    // a capture on per-env clocks: every masked call gets a device mask of its own (owned by the graph: a replay reads no host
+    // memory), and the capture notes which launch of it served each env last (chub_env_clocks after a replay)
+    std::vector<void *> cap_masks;
+    std::vector<uint32_t> cap_rel;  // [N] launch number (1-based) within the capture of the env's last masked launch, 0 = none
+    uint32_t cap_full_rel;          // launch number of the capture's last launch that served every env, 0 = none
+    bool graph_per_env0;
+    uint32_t graph_full_tick0;
+    std::vector<uint32_t> graph_h_tick0;
     std::vector<uint32_t> h_tick;   // [N] tick of the last launch that served the env through a mask (chub_env_clocks)
     uint32_t full_tick;             // tick of the last launch that served every env
     bool predrawn;                  // the last launch served every env: its level blocks left the next step's state-independent draws
@@ -376,6 +385,10 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->h_mask = nullptr;
     e->mask_done[0] = e->mask_done[1] = nullptr;
     e->mask_seq = 0;
+    e->cur_mask = nullptr;
+    e->cap_full_rel = 0;
+    e->graph_per_env0 = false;
+    e->graph_full_tick0 = 0;
     e->full_tick = 0;
     e->predrawn = false;
     e->stream = nullptr;
@@ -833,8 +846,20 @@ static int serve_mask(chub_env *e, const uint8_t *mask, hipStream_t s, int &serv
     }
     served = n_masked == 0 ? 0 : (n_masked == N ? 2 : 1);
     if (served != 1) return CHUB_OK;
-    if (e->capturing) return fail(CHUB_ERR_ARG, "a graph capture covers calls on every env only");
     if (e->tape_pk) return fail(CHUB_ERR_ARG, "tape mode runs in lock-step");
+    if (e->capturing) {
+        // a replay must not read the caller's (or the handle's staging) memory: the mask of a captured call lives in a device
+        // buffer of its own, filled now and freed with the graph.  The clocks are device state, so nothing of them is baked in.
+        if (!e->per_env)
+            return fail(CHUB_ERR_ARG, "a capture that names subsets of the envs must start on per-env clocks: make the first call "
+                                      "on a subset before chub_graph_begin (it fills the per-env clocks from the handle's clock)");
+        uint8_t *d = nullptr;
+        HIP_TRY(hipMalloc((void **) &d, N));
+        e->cap_masks.push_back(d);
+        HIP_TRY(hipMemcpy(d, mask, N, hipMemcpyHostToDevice));  // synchronous, on the null stream: not part of the capture
+        e->cur_mask = d;
+        return CHUB_OK;
+    }
     if (!e->per_env) {  // every env starts from the lock-step clock, in the buffer the next launch reads
         const uint16_t c = (uint16_t) ((uint32_t) e->t | (((uint32_t) e->price_count & 3u) << 8));
         launch_fill_clocks(e->d_env_clk + (size_t) ((e->tick + 1u - e->graph_base) & 1u) * N, (int64_t) N, c, s);
@@ -851,17 +876,28 @@ static int serve_mask(chub_env *e, const uint8_t *mask, hipStream_t s, int &serv
     if (e->mask_seq >= 2) HIP_TRY(hipEventSynchronize(e->mask_done[b]));
     memcpy(e->h_mask + (size_t) b * N, mask, N);
     HIP_TRY(hipMemcpyAsync(e->d_mask + (size_t) b * N, e->h_mask + (size_t) b * N, N, hipMemcpyHostToDevice, s));
+    e->cur_mask = e->d_mask + (size_t) b * N;
     return CHUB_OK;
 }
 
 static int note_served(chub_env *e, const uint8_t *mask, int served, hipStream_t s) {
+    const size_t N = (size_t) e->hp.n_envs;
+    if (e->capturing) {  // nothing ran: only note which launch of the capture this was (applied by every replay)
+        const uint32_t rel = e->tick - e->graph_tick0;
+        if (served == 2) e->cap_full_rel = rel;
+        else {
+            if (e->cap_rel.size() != N) e->cap_rel.assign(N, 0u);
+            for (size_t i = 0; i < N; i++)
+                if (mask[i]) e->cap_rel[i] = rel;
+        }
+        return CHUB_OK;
+    }
     if (served == 2) {
         e->full_tick = e->tick;
         return CHUB_OK;
     }
     HIP_TRY(hipEventRecord(e->mask_done[e->mask_seq & 1u], s));
     e->mask_seq += 1;
-    const size_t N = (size_t) e->hp.n_envs;
     for (size_t i = 0; i < N; i++)
         if (mask[i]) e->h_tick[i] = e->tick;
     return CHUB_OK;
@@ -883,7 +919,7 @@ static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const d
     sa.obs_stride = e->hp.obs_dim;
     if (e->per_env) {
         sa.env_clk = e->d_env_clk;
-        sa.env_mask = served == 1 ? e->d_mask + (size_t) (e->mask_seq & 1u) * (size_t) e->hp.n_envs : nullptr;
+        sa.env_mask = served == 1 ? e->cur_mask : nullptr;
     }
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
@@ -997,7 +1033,7 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     sa.car_tape = e->tape_car;
     if (e->per_env) {
         sa.env_clk = e->d_env_clk;
-        sa.env_mask = served == 1 ? e->d_mask + (size_t) (e->mask_seq & 1u) * (size_t) e->hp.n_envs : nullptr;
+        sa.env_mask = served == 1 ? e->cur_mask : nullptr;
     }
     // the state-independent draws of this step: left by the previous launch's level blocks if that launch served every env
     // (for the tick that is now this launch's), otherwise made by this launch itself (a graph's first step always makes its
@@ -1281,6 +1317,10 @@ struct chub_graph {
     uint32_t ticks;       // resets + steps one replay covers
     uint32_t arg0;        // host tick - tick base at chub_graph_begin: the captured launches carry arg0 + 1 .. arg0 + ticks
     int t_begin, pc_begin;  // the handle's clocks at chub_graph_begin: what a replay starts from (baked into the launches)
+    bool per_env_begin, per_env_end, predrawn_end;  // captured on per-env clocks (device state: nothing of them is baked in)
+    std::vector<void *> masks;        // device masks of the captured calls on subsets of the envs
+    std::vector<uint32_t> rel;        // [N] or empty: launch number within the graph of every env's last masked launch
+    uint32_t full_rel;                // launch number of the graph's last launch on every env
     int t_end, pc_end;    // the handle's clocks after a replay
 };
 
@@ -1289,7 +1329,6 @@ int chub_graph_begin(chub_env *e, void *stream) {
     if (e->capturing) return fail(CHUB_ERR_ARG, "a capture is already in progress on this handle");
     if (e->hp.rng_mode != CHUB_RNG_PHILOX) return fail(CHUB_ERR_ARG, "graphs replay PHILOX steps (COMPAT takes host draws every step)");
     if (e->prof_on) return fail(CHUB_ERR_ARG, "per-kernel profiling is on");
-    if (e->per_env) return fail(CHUB_ERR_ARG, "graphs cover lock-step calls: the envs of this handle run on their own clocks (reset all of them first)");
     HIP_TRY(hipSetDevice(e->device));
     int rc = sync_ctx(e, (hipStream_t) stream);
     if (rc) return rc;
@@ -1299,6 +1338,12 @@ int chub_graph_begin(chub_env *e, void *stream) {
     e->graph_t0 = e->t;
     e->graph_pc0 = e->price_count;
     e->graph_predrawn0 = e->predrawn;
+    e->graph_per_env0 = e->per_env;
+    e->graph_full_tick0 = e->full_tick;
+    e->graph_h_tick0 = e->h_tick;
+    e->cap_masks.clear();
+    e->cap_rel.clear();
+    e->cap_full_rel = 0;
     return CHUB_OK;
 }
 
@@ -1309,24 +1354,38 @@ int chub_graph_end(chub_env *e, void *stream, chub_graph **out) {
     e->capturing = false;
     const uint32_t ticks = e->tick - e->graph_tick0;
     const int t_end = e->t, pc_end = e->price_count;
+    const bool per_env_end = e->per_env, predrawn_end = e->predrawn;
+    std::vector<void *> masks;
+    masks.swap(e->cap_masks);
+    auto drop_masks = [&]() {
+        for (void *m : masks) (void) hipFree(m);
+    };
     // nothing ran: the handle is where it was at chub_graph_begin; every chub_graph_launch moves it on by one replay
     e->tick = e->graph_tick0;
     e->t = e->graph_t0;
     e->price_count = e->graph_pc0;
     e->predrawn = e->graph_predrawn0;
+    e->per_env = e->graph_per_env0;
+    e->full_tick = e->graph_full_tick0;
+    e->h_tick = e->graph_h_tick0;
     // every replay moves the Philox tick base on by the ticks the graph covers (its last node)
     launch_tick_advance(e->d_tick_base, ticks, (hipStream_t) stream);
     hipGraph_t g = nullptr;
     hipError_t he = hipStreamEndCapture((hipStream_t) stream, &g);
-    if (he != hipSuccess || !g) return fail(CHUB_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(he));
+    if (he != hipSuccess || !g) {
+        drop_masks();
+        return fail(CHUB_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(he));
+    }
     if (ticks == 0 || (ticks & 1u)) {
         (void) hipGraphDestroy(g);
+        drop_masks();
         return fail(CHUB_ERR_ARG, "a graph must cover an even, non-zero number of resets + steps (double-buffered draws)");
     }
     hipGraphExec_t x = nullptr;
     he = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
     if (he != hipSuccess) {
         (void) hipGraphDestroy(g);
+        drop_masks();
         return fail(CHUB_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(he));
     }
     chub_graph *cg = new chub_graph();
@@ -1338,6 +1397,12 @@ int chub_graph_end(chub_env *e, void *stream, chub_graph **out) {
     cg->arg0 = e->graph_tick0 - e->graph_base;
     cg->t_begin = e->graph_t0;
     cg->pc_begin = e->graph_pc0;
+    cg->per_env_begin = e->graph_per_env0;
+    cg->per_env_end = per_env_end;
+    cg->predrawn_end = predrawn_end;
+    cg->masks.swap(masks);
+    cg->rel.swap(e->cap_rel);
+    cg->full_rel = e->cap_full_rel;
     cg->t_end = t_end;
     cg->pc_end = pc_end;
     *out = cg;
@@ -1346,12 +1411,16 @@ int chub_graph_end(chub_env *e, void *stream, chub_graph **out) {
 
 int chub_graph_launch(chub_graph *g, void *stream) {
     if (!g) return fail(CHUB_ERR_ARG, "null graph");
-    if (g->env->per_env) return fail(CHUB_ERR_ARG, "graphs replay lock-step calls: the envs of this handle run on their own clocks (reset all of them first)");
     HIP_TRY(hipSetDevice(g->device));
     chub_env *e = g->env;
-    // a replay repeats the clocks of its launches verbatim (slot of day, price-noise phase: kernel arguments): it continues the
-    // handle's run only from where the capture started
-    if (e->t != g->t_begin || ((e->price_count ^ g->pc_begin) & 3) != 0)
+    if (e->capturing) return fail(CHUB_ERR_ARG, "a capture is in progress on this handle");
+    if (g->per_env_begin != e->per_env)
+        return fail(CHUB_ERR_ARG, g->per_env_begin ? "this graph was captured on per-env clocks: the handle is in lock-step (make a call on a subset of the envs first)"
+                                                   : "this graph replays lock-step calls: the envs of this handle run on their own clocks (reset all of them first)");
+    // a lock-step replay repeats the clocks of its launches verbatim (slot of day, price-noise phase: kernel arguments): it
+    // continues the handle's run only from where the capture started.  On per-env clocks the clocks are device state and a replay
+    // continues from wherever every env is.
+    if (!g->per_env_begin && (e->t != g->t_begin || ((e->price_count ^ g->pc_begin) & 3) != 0))
         return fail(CHUB_ERR_ARG, "the handle is not at the clock this graph was captured at (slot of day " + std::to_string(g->t_begin) +
                                       ", steps since reset mod 4 = " + std::to_string(g->pc_begin & 3) + "): a replay bakes the clocks in");
     // The captured launches carry the arguments arg0 + 1 .. arg0 + ticks, and a launch's effective Philox tick is its argument
@@ -1367,12 +1436,22 @@ int chub_graph_launch(chub_graph *g, void *stream) {
     HIP_TRY(hipGraphLaunch(g->exec, (hipStream_t) stream));
     // the replay covers g->ticks resets + steps: its last node moves the device-side tick base on, the host mirrors it, so that
     // calls issued one by one afterwards continue the same tick sequence (their argument is the tick minus the base)
+    const uint32_t tick0 = e->tick;
     e->tick += g->ticks;
     e->graph_base += g->ticks;
-    e->t = g->t_end;
-    e->price_count = g->pc_end;
-    e->predrawn = true;
-    e->full_tick = e->tick;
+    e->per_env = g->per_env_end;
+    if (!g->per_env_begin || !g->per_env_end) {  // the replay ran on, or ended on, the one clock of the handle
+        e->t = g->t_end;
+        e->price_count = g->pc_end;
+    }
+    e->predrawn = g->predrawn_end;
+    if (g->full_rel) e->full_tick = tick0 + g->full_rel;
+    if (!g->rel.empty()) {
+        const size_t N = (size_t) e->hp.n_envs;
+        if (e->h_tick.size() != N) e->h_tick.assign(N, 0u);
+        for (size_t i = 0; i < N; i++)
+            if (g->rel[i]) e->h_tick[i] = tick0 + g->rel[i];
+    }
     return CHUB_OK;
 }
 
@@ -1381,6 +1460,8 @@ int chub_graph_destroy(chub_graph *g) {
     (void) hipSetDevice(g->device);
     (void) hipGraphExecDestroy(g->exec);
     (void) hipGraphDestroy(g->graph);
+    (void) hipDeviceSynchronize();  // a replay still in flight reads the masks
+    for (void *m : g->masks) (void) hipFree(m);
     delete g;
     return CHUB_OK;
 }

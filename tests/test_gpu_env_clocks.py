@@ -403,6 +403,87 @@ def test_scalar_load_steps_while_envs_are_on_their_own_clocks():
     p.close()
 
 
+@pytest.mark.parametrize("G", [4, 3])
+def test_graph_replay_on_per_env_clocks(G):
+    """hipGraph capture while the envs are on their own clocks: one period of a staggered schedule (96 steps of everybody + one
+    masked reset per group, each at its own end of day) captured once and replayed, against the same calls issued one by one.
+    The clocks are device state and the masks of the captured calls live in device buffers owned by the graph, so a replay reads
+    nothing from the host; ticks (and with them every random stream) move on from replay to replay."""
+    chub = hub()
+    from charginghub_env_amd import multi_gpu
+    from charginghub_env_amd._lib import check
+    n = 96 * 5
+    kw = dict(KW)
+    grp = np.arange(n) * G // n
+    offs = [g * 96 // G for g in range(G)]
+    masks = [np.ascontiguousarray(grp == g, dtype=np.uint8) for g in range(G)]
+    periods = 1 if (96 + G) % 2 == 0 else 2  # launches per graph must be even
+    out = []
+    for mode in ("eager", "graph"):
+        v = chub.VecChargingHub(n, seed=808, env_id0=77, **kw)
+        lib, h = v._lib, v._h
+        st = multi_gpu.Stream(0)
+        acts = [multi_gpu.DeviceBuffer(n * v.act_dim * 4) for _ in range(4)]
+        for b, a in enumerate(acts):
+            v.random_actions_device(a.ptr, 31, b, st.ptr)
+        packed = [multi_gpu.DeviceBuffer(n * (v.obs_dim + 2) * 4) for _ in range(2)]
+        obs = multi_gpu.DeviceBuffer(n * v.obs_dim * 4)
+        rew, done = multi_gpu.DeviceBuffer(n * 4), multi_gpu.DeviceBuffer(n)
+        v.reset_device(obs.ptr, stream=st.ptr)
+        for k in range(1, max(offs) + 1):  # head starts, call by call: group g ends up offs[g] slots ahead
+            m = np.ascontiguousarray(np.array(offs)[grp] >= k, dtype=np.uint8)
+            check(lib.chub_step_envs_device(h, m.ctypes.data, acts[k % 4].ptr, None, obs.ptr, rew.ptr, done.ptr, st.ptr))
+        st.sync()
+        assert v.clock_groups == G
+        t_grp = np.array(offs)
+
+        def period(i0):
+            tg = t_grp.copy()
+            for i in range(i0, i0 + 96):
+                v.step_device_packed(acts[i % 4].ptr, packed[i & 1].ptr, stream=st.ptr)
+                tg = (tg + 1) % 96
+                for g in np.nonzero(tg == 0)[0]:
+                    check(lib.chub_reset_envs_device(h, masks[g].ctypes.data, None, None, obs.ptr, st.ptr))
+            assert np.array_equal(tg, t_grp)
+
+        trace = []
+        if mode == "eager":
+            for rep in range(3 * periods):
+                period(96 * rep)
+                if (rep + 1) % periods == 0:
+                    trace.append(packed[1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr))
+        else:
+            st.sync()
+            v.graph_begin(st.ptr)
+            for rep in range(periods):
+                period(96 * rep)
+            g = v.graph_end(st.ptr)
+            assert np.array_equal(v.env_clocks(), np.array(offs)[grp]), "a capture runs nothing"
+            for rep in range(3):
+                v.graph_launch(g, st.ptr)
+                trace.append(packed[1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr))
+        t, ticks = v.env_clocks(ticks=True)
+        assert np.array_equal(t, np.array(offs)[grp]) and v.clock_groups == G
+        trace += [np.concatenate([x.reshape(n, -1) for x in v.slots()], axis=1), v.station_scalars().reshape(n, -1), ticks]
+        # and on from there call by call, the same in both runs
+        m = np.ascontiguousarray(grp == 0, dtype=np.uint8)
+        check(lib.chub_step_envs_device(h, m.ctypes.data, acts[1].ptr, None, obs.ptr, rew.ptr, done.ptr, st.ptr))
+        v.step_device_packed(acts[2].ptr, packed[0].ptr, stream=st.ptr)
+        trace.append(packed[0].to_host(np.float32, (n, v.obs_dim + 2), st.ptr))
+        trace.append(obs.to_host(np.float32, (n, v.obs_dim), st.ptr))
+        out.append(trace)
+        if mode == "graph":
+            with pytest.raises(chub.ChubError, match="lock-step"):  # a lock-step handle cannot replay a per-env graph
+                v.reset_device(obs.ptr, stream=st.ptr)
+                v.graph_launch(g, st.ptr)
+            v.graph_destroy(g)
+        v.close()
+        st.destroy()
+    for k, (a, b) in enumerate(zip(*out)):
+        assert np.array_equal(a, b), ("segment", k)
+    assert not np.array_equal(out[1][0][:, :-2], out[1][1][:, :-2]), "a replay is a new period, not the same one again"
+
+
 @pytest.mark.parametrize("shape", ["auto", "big"])
 def test_masked_scalar_load_steps_match_the_oracle(shape):
     """chub_step_load_envs: evs_step(float) for a SUBSET of the envs (every reference station takes it on its own,

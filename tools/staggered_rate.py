@@ -51,4 +51,30 @@ v.sync()
 print("clocks:", sorted(set(v.env_clocks().tolist())), v.clock_groups)
 us = run(960, True)
 print("%d clocks in one handle: %.1f us per step = %.0f M env-steps/s (%d clocks at the end)" % (G, us, n / us, v.clock_groups))
+
+# the same schedule as hipGraph replays: one period (96 steps + G masked resets) captured on per-env clocks, replayed 10 times
+st = multi_gpu.Stream(0)
+periods = 1 if (96 + G) % 2 == 0 else 2
+masks = [np.ascontiguousarray(grp == g, dtype=np.uint8) for g in range(G)]
+t_grp0 = v.env_clocks()[::n // G].copy()
+v.sync()
+v.graph_begin(st.ptr)
+t_grp = t_grp0.copy()
+for i in range(96 * periods):
+    v.step_device_packed(acts[i % 4].ptr, packed.ptr, stream=st.ptr)
+    t_grp = (t_grp + 1) % 96
+    for g in np.nonzero(t_grp == 0)[0]:
+        check(lib.chub_reset_envs_device(h, masks[g].ctypes.data, None, None, obs.ptr, st.ptr))
+graph = v.graph_end(st.ptr)
+v.graph_launch(graph, st.ptr)
+st.sync()
+reps = 10
+t0 = time.perf_counter()
+for _ in range(reps):
+    v.graph_launch(graph, st.ptr)
+st.sync()
+us = (time.perf_counter() - t0) / (reps * 96 * periods) * 1e6
+print("%d clocks in one handle, hipGraph replays of one period: %.1f us per step = %.0f M env-steps/s (%d clocks at the end)"
+      % (G, us, n / us, v.clock_groups))
+v.graph_destroy(graph)
 v.close()
