@@ -85,8 +85,10 @@ struct StationArrays {       // unit index u = k*N + env
     CHUB_G(float) tail_act;      // [N][2] PHILOX: the env's two tail actions (electrolyser, fuel cell), copied by the packed slot kernel
                                  // out of the action row it has just read: the tail kernel reads 8 contiguous bytes per env
                                  // instead of one 128-byte line per env of the [N, S+2] action matrix
-    CHUB_G(uint64_t) pk[2];      // PHILOX: packed state-independent station draws of a step (double-buffered by tick
-                                 // parity): bits 0-9 renege pass per queue position, 10-13 arrivals, 14+4j balk limit of arrival j
+    CHUB_G(uint32_t) pk[2];      // PHILOX, double-buffered by tick parity: what a unit's station-level draws of a step come to,
+                                 // decoded one launch ahead against the queue the previous step left (dk_make): bits 0-7 queue after
+                                 // the renege pass + arrivals that stay = the cars that want a slot, bits 8-15 flow_in.  For a reset:
+                                 // the raw initial-occupancy draws of k_reset_levels (arrivals, signed 16 bits | arrivals that stay << 16)
 };
 
 struct EnvArrays {           // index = env (or field*N + env)
@@ -94,9 +96,8 @@ struct EnvArrays {           // index = env (or field*N + env)
     CHUB_G(double) store_soc;    // HyStore.Store_SOC as last computed by sty_step (stale after the fuel cell, HYD:428)
     CHUB_G(double) ou;           // [3][N] OU states pv, wd, price (REN:56-76), never reset
     CHUB_G(double) price_noise;  // self.price_next noise part (MGR:356)
-    CHUB_G(double) re_pv;        // exogenous powers produced by the previous make_state (MGR:349-350)
-    CHUB_G(double) re_wd;
-    CHUB_G(double) price_next;   // real_state[1]
+    // (the exogenous powers and the price produced by the previous make_state, MGR:349-359, are not state: they are functions of
+    //  the table rows of the env's slot of day and of the OU states / price noise above, and the tail re-derives them, bit for bit)
     CHUB_G(int16_t) pv_day;
     CHUB_G(int16_t) wd_day;
     CHUB_G(uint8_t) q_len;       // FCEV waiting list: explicit entries (<= HubParams::qcap)
@@ -107,7 +108,8 @@ struct EnvArrays {           // index = env (or field*N + env)
     CHUB_G(double) hy_env;       // [N][102] COMPAT only: per-env hy_power_speed_list (the reference builds it with live random
                                  // FCEV demand at construction, HYD:154-157, so it depends on the env's streams)
     CHUB_G(uint32_t) drw[2];     // [N][4] PHILOX: a step's state-independent env draws, made one launch ahead (double-buffered by
-                                 // tick parity): three OU normals (f32 bits: pv, wind, price) and the FCEV arrival count
+                                 // tick parity): three OU normals (f32 bits: pv, wind, price) and the first FCEV arrival's SoC (f32 bits)
+    CHUB_G(uint8_t) drw_cnt[2];  // [N]    ... and the FCEV arrival count
     CHUB_G(double) q_time;       // [N][qcap]
     CHUB_G(double) q_mass;
     CHUB_G(double) obs64;        // [N][D]  (telemetry only)
@@ -189,7 +191,7 @@ struct PackedPtrs {
     const EnvArrays *ev;      // host copies of the array tables (launch_env / k_step build TailArgs from them)
     const StationArrays *st;
     uint32_t *hot, *rec;
-    uint64_t *pk[2];
+    uint32_t *pk[2];
     const float *cls[2], *ttab[2], *ttab2;
     uint32_t late8[8];        // the first 8 thresholds of Tables::late_thr, passed to the packed kernel by value
     const Tables *tb;         // host copy of the table pointers
@@ -202,6 +204,7 @@ struct StepArgs {
     int32_t draw_price;      // price_count % 4 == 0 (MGR:354)
     int32_t station_filter;  // -1 both stations in one launch, else only station k (COMPAT: serial streams)
     double price_last;       // env_aggregator.price[-1] seen by this step's make_state
+    double price_prev;       // ... and by the previous make_state of a lock-step run: the tariff of the slot before this one
     const float *actions;    // [N][A]
     const double *exo_z;     // [N][3] or null
     const int32_t *exo_days; // [N][2] or null (reset)

@@ -299,6 +299,20 @@ __device__ __forceinline__ uint64_t draw_station_levels(const HubParams &hp, con
     return pk;
 }
 
+// What those draws come to for a unit whose queue holds `line` cars (Station::line as the previous step left it): the renege
+// pass over the queue (CHS.hpp:1286-1293), the arrivals, and -- slow station -- those of them that stay given the queue just
+// thinned (CHS.hpp:1297-1306; the fast station records the un-thinned count, CHS.hpp:1617).  Decoded ONCE per unit, where the draws
+// are made (one launch ahead), instead of by every lane of the unit in the slot kernel, which then only needs
+//   assign = min(want, empties), line = min(want - assign, max_line)     (assign_car, CHS.hpp:417-430)
+__device__ __forceinline__ uint32_t dk_make(uint64_t pk, int line, bool fast) {
+    line = __popc((uint32_t) pk & ((1u << line) - 1u));
+    const int n_in = (int) (pk >> 10) & 15;
+    const int flow = fast ? n_in : (int) ((pk >> (14 + 4 * line)) & 15);
+    return (uint32_t) (line + flow) | ((uint32_t) flow << 8);
+}
+__device__ __forceinline__ int dk_want(uint32_t dk) { return (int) (dk & 255u); }
+__device__ __forceinline__ int dk_flow(uint32_t dk) { return (int) ((dk >> 8) & 255u); }
+
 // ---------------------------------------------------------------------------------------- slot state
 // COMPAT keeps, per slot, the 16-byte hot record of SlotArrays (power, t_target, t_soc, meta) and evaluates the charge
 // curves in the step (the reference's streams make the arrival SoC a continuous value).
@@ -647,14 +661,10 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     CHUB_G(const float) cls = tb.cls[k];
 
-    uint32_t line_in = 0;
-    uint64_t pk_in = 0;
+    uint32_t pk_in = 0;
     u32x2 s2 = {0u, 0u};
     float a = 0.0f;
-    if (unit_ok) {
-        if (!RESET) line_in = st.rec[4u * sidx + 3u];
-        pk_in = st.pk[sa.tick & 1u][sidx];
-    }
+    if (unit_ok) pk_in = st.pk[sa.tick & 1u][sidx];
     if (!RESET && valid) {
         s2 = ((CHUB_G(u32x2)) sl.hot)[idx];
         a = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot];
@@ -699,24 +709,22 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     const uint64_t be = __ballot(empty) & unit_mask;
     const int empties = __popcll(be);
     const int rank = prefix_count(be);
-    int line = pkd_line(line_in);
-    int flow = 0, assign = 0;
+    int line = 0, flow = 0, assign = 0;
     if (unit_ok) {
+        int want;
         if (RESET) {
             // evs_reset: the unit's initial occupancy was drawn by k_reset_levels, one lane per unit, just before.  The fast
             // station records the raw draw, which is negative for small stations (mu - 3 < 0, CHS.hpp:1617, 832-842):
             // assign_car then admits nobody and the queue stays empty
             flow = fast ? (int) (int16_t) (pk_in & 0xFFFFu) : (int) ((pk_in >> 16) & 0xFFFFu);
+            want = flow;
         } else {
-            // this step's station-level draws were packed one launch ahead (draw_station_levels)
-            line = __popc((uint32_t) pk_in & ((1u << line) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
-            const int n_in = (int) (pk_in >> 10) & 15;
-            // the fast station records the un-thinned count (CHS.hpp:1617), the slow one what survives the balk
-            // pass given the queue length just computed (CHS.hpp:1297-1306)
-            flow = fast ? n_in : (int) ((pk_in >> (14 + 4 * line)) & 15);
+            // this step's station-level draws were made and decoded one launch ahead (draw_station_levels, dk_make)
+            want = dk_want(pk_in);
+            flow = dk_flow(pk_in);
         }
-        assign = (line + flow) < empties ? (line + flow) : empties;  // assign_car, CHS.hpp:417-430
-        line = line + flow - assign;
+        assign = want < empties ? want : empties;  // assign_car, CHS.hpp:417-430
+        line = want - assign;
         line = line < kMaxLine ? line : kMaxLine;
     }
     const bool adm = empty && rank < assign;
@@ -913,7 +921,7 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
         rank += w < wave ? c : 0;
     }
     if (tid == 0) {
-        int line = RESET ? 0 : pkd_line(st.rec[4u * sidx + 3u]);
+        int line = (RESET || MODE == MODE_PHILOX) ? 0 : pkd_line(st.rec[4u * sidx + 3u]);
         int flow, assign;
         if (MODE == MODE_COMPAT) {
             const CompatRng &cr = ctx->cr;
@@ -949,16 +957,17 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
             }
             rs.store(cr, env);
         } else {
-            const uint64_t pk = st.pk[sa.tick & 1u][sidx];
+            const uint32_t pk = st.pk[sa.tick & 1u][sidx];
+            int want;
             if (RESET) {
                 flow = fast ? (int) (int16_t) (pk & 0xFFFFu) : (int) ((pk >> 16) & 0xFFFFu);
+                want = flow;
             } else {
-                line = __popc((uint32_t) pk & ((1u << line) - 1u));
-                const int n_in = (int) (pk >> 10) & 15;
-                flow = fast ? n_in : (int) ((pk >> (14 + 4 * line)) & 15);
+                want = dk_want(pk);
+                flow = dk_flow(pk);
             }
-            assign = (line + flow) < empties ? (line + flow) : empties;
-            line = line + flow - assign;
+            assign = want < empties ? want : empties;
+            line = want - assign;
             line = line < kMaxLine ? line : kMaxLine;
         }
         s_hdr[0] = assign; s_hdr[1] = flow; s_hdr[2] = line;
@@ -1065,7 +1074,7 @@ struct PackedArgs {
     uint32_t n_envs, epb, magic, cls_delta;  // envs per workgroup; 2^20 / (S0 + S1) + 1; byte distance cls[1] - cls[0]
     CHUB_G(uint32_t) state;          // [N][S0 + S1][2]
     CHUB_G(uint32_t) rec;
-    CHUB_G(const uint64_t) pk;       // this step's packed station draws (TAPE: supplied by the caller)
+    CHUB_G(const uint32_t) pk;       // this step's station draws per unit, decoded (dk_make); RESET: the raw initial-occupancy draws
     CHUB_G(const float) actions;
     CHUB_G(const float) cls0;        // station 0's class table; station 1's is cls_delta bytes further
     CHUB_G(const float) ttab2;       // [2][1024] soc_to_time(target level) of both stations' curves (1000 used)
@@ -1111,8 +1120,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
     uint32_t sidx[T];
     u32x2 s2[T];
     float act[T];
-    uint32_t line_in[T];
-    uint64_t pk_in[T];
+    uint32_t pk_in[T];
 #pragma unroll
     for (int j = 0; j < T; j++) {
         const int v = tid + j * BLOCK;
@@ -1125,19 +1133,17 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         uint32_t served = 1u;  // per-env clocks: is the env served by this launch?  Requested with the state, looked at after it
         if (pa.env_mask && valid[j]) served = pa.env_mask[env];
         sidx[j] = (uint32_t) (k_[j] ? N : 0) + (uint32_t) env;
-        asm volatile("" : "=v"(s2[j]), "=v"(act[j]), "=v"(line_in[j]), "=v"(pk_in[j]));
+        asm volatile("" : "=v"(s2[j]), "=v"(act[j]), "=v"(pk_in[j]));
         if (RESET) {
             s2[j] = u32x2{0u, 0u};
             act[j] = 0.0f;
-            line_in[j] = 0u;
         }
         if (valid[j]) {
             if (!RESET) {
                 s2[j] = CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) v) << 3);
                 act[j] = CHUB_AT(const float, pa.actions, (idx0 + (uint32_t) v + 2u * (uint32_t) env) << 2);  // row stride S0 + S1 + 2
-                line_in[j] = CHUB_AT(uint32_t, pa.rec, (sidx[j] << 4) + 12u);
             }
-            pk_in[j] = CHUB_AT(const uint64_t, pa.pk, sidx[j] << 3);
+            pk_in[j] = CHUB_AT(const uint32_t, pa.pk, sidx[j] << 2);
         }
         if (pa.env_mask && valid[j]) valid[j] = served != 0u;
     }
@@ -1214,25 +1220,25 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
                 }
             }
         }
-        line[j] = pkd_line(line_in[j]);
+        line[j] = 0;
         flow[j] = 0;
         int assign = 0;
         if (valid[j]) {
-            const uint64_t pk = pk_in[j];
-            const bool fast = (k_[j] ? pa.type[1] : pa.type[0]) == 0;
+            const uint32_t pk = pk_in[j];
+            int want;
             if (RESET) {
                 // the unit's initial occupancy, drawn by k_reset_levels just before.  The fast station records the raw draw, which is
                 // negative for small stations (mu - 3 < 0, CHS.hpp:1617, 832-842): assign_car then admits nobody, the queue stays empty
+                const bool fast = (k_[j] ? pa.type[1] : pa.type[0]) == 0;
                 flow[j] = fast ? (int) (int16_t) (pk & 0xFFFFu) : (int) ((pk >> 16) & 0xFFFFu);
+                want = flow[j];
             } else {
-                line[j] = __popc((uint32_t) pk & ((1u << line[j]) - 1u));  // renege pass over the queue (CHS.hpp:1286-1293)
-                const int n_in = (int) (pk >> 10) & 15;
-                // the fast station records the un-thinned count (CHS.hpp:1617), the slow one what survives the balk pass given
-                // the queue length just computed (CHS.hpp:1297-1306)
-                flow[j] = fast ? n_in : (int) ((pk >> (14 + 4 * line[j])) & 15);
+                // queue after the renege pass + the arrivals that stay, and flow_in: decoded one launch ahead, once per unit (dk_make)
+                want = dk_want(pk);
+                flow[j] = dk_flow(pk);
             }
-            assign = (line[j] + flow[j]) < empties ? (line[j] + flow[j]) : empties;  // assign_car, CHS.hpp:417-430
-            line[j] = line[j] + flow[j] - assign;
+            assign = want < empties ? want : empties;  // assign_car, CHS.hpp:417-430
+            line[j] = want - assign;
             line[j] = line[j] < kMaxLine ? line[j] : kMaxLine;
         }
         adm[j] = empty[j] && rank < assign;
@@ -1363,21 +1369,19 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         if ((k ? S1 : S0) == 0) {
             // a station without piles still queues, reneges and balks (receive_car runs on it as on any other, CHS.hpp:1272-1316 /
             // 1583-1627; nobody is ever admitted): its queue length and arrival count move on here, power sums and cars stay 0
-            const uint32_t l_in = CHUB_AT(uint32_t, pa.rec, (su << 4) + 12u);
-            const uint64_t pk = CHUB_AT(const uint64_t, pa.pk, su << 3);
+            const uint32_t pk = CHUB_AT(const uint32_t, pa.pk, su << 2);
             const bool fast = (k ? pa.type[1] : pa.type[0]) == 0;
-            int ln = 0, fl;
+            int want, fl;
             if (RESET) {  // evs_reset of a station without piles: init_station_car_number(0, 3) arrivals, nobody queues
                 fl = fast ? (int) (int16_t) (pk & 0xFFFFu) : (int) ((pk >> 16) & 0xFFFFu);
+                want = fl;
             } else {
-                ln = pkd_line(l_in);
-                ln = __popc((uint32_t) pk & ((1u << ln) - 1u));
-                const int n_in = (int) (pk >> 10) & 15;
-                fl = fast ? n_in : (int) ((pk >> (14 + 4 * ln)) & 15);
+                want = dk_want(pk);
+                fl = dk_flow(pk);
             }
             // assign_car (CHS.hpp:417-430) with no empty slot: min(line + flow, 0) cars are assigned, the rest queue
-            const int as = (ln + fl) < 0 ? (ln + fl) : 0;
-            ln = ln + fl - as;
+            const int as = want < 0 ? want : 0;
+            int ln = want - as;
             ln = ln < kMaxLine ? ln : kMaxLine;
             lf = pkd_make(ln, fl, 0);
         }
@@ -1418,14 +1422,12 @@ struct TailArgs {
     CHUB_G(const double) ou;
     CHUB_G(const double) price_noise;
     CHUB_G(const double) cap;
-    CHUB_G(const double) re_wd;
-    CHUB_G(const double) re_pv;
-    CHUB_G(const double) price_next;
     CHUB_G(const int16_t) pv_day;
     CHUB_G(const int16_t) wd_day;
     CHUB_G(const uint8_t) q_len;
     CHUB_G(const uint8_t) hv_line;
     CHUB_G(const uint32_t) drw;   // this step's pre-drawn env variates
+    CHUB_G(const uint8_t) drw_cnt;
     CHUB_G(uint32_t) rec;
     CHUB_G(const float) actions;
     uint32_t n_envs, act_dim, s_tot, pad;
@@ -1434,6 +1436,8 @@ struct TailArgs {
     CHUB_G(const float) tail_act;  // [N][2] the tail actions as the packed slot kernel left them, or null: read the action rows
     CHUB_G(const double) pv_row;   // pvT + t_next * 100
     CHUB_G(const double) wd_row;   // wdT + t_next * 150
+    CHUB_G(const double) pv_row_now;  // ... and the rows of the slot being simulated: what the previous make_state looked up
+    CHUB_G(const double) wd_row_now;
     CHUB_G(const double) hy_table;
     const uint32_t *tick_base;
     double sin_t;                  // sin96[t_next] (lock-step; per-env clocks read the table)
@@ -1446,6 +1450,8 @@ inline TailArgs make_tail_args(const EnvArrays &ev, const StationArrays &st, con
     ta.tail_act = (hp.rng_mode == MODE_PHILOX && hp.packed && !sa.load_mode && !reset) ? (CHUB_G(const float)) st.tail_act : nullptr;
     ta.pv_row = (CHUB_G(const double)) (pp.tb->pvT + t_next * 100);
     ta.wd_row = (CHUB_G(const double)) (pp.tb->wdT + t_next * 150);
+    ta.pv_row_now = (CHUB_G(const double)) (pp.tb->pvT + (reset ? 0 : sa.t) * 100);
+    ta.wd_row_now = (CHUB_G(const double)) (pp.tb->wdT + (reset ? 0 : sa.t) * 150);
     ta.hy_table = (CHUB_G(const double)) pp.tb->hy_table;
     ta.tick_base = hp.tick_base;
     ta.sin_t = pp.sin96[t_next];
@@ -1456,14 +1462,12 @@ inline TailArgs make_tail_args(const EnvArrays &ev, const StationArrays &st, con
     ta.ou = (CHUB_G(const double)) ev.ou;
     ta.price_noise = (CHUB_G(const double)) ev.price_noise;
     ta.cap = (CHUB_G(const double)) ev.cap;
-    ta.re_wd = (CHUB_G(const double)) ev.re_wd;
-    ta.re_pv = (CHUB_G(const double)) ev.re_pv;
-    ta.price_next = (CHUB_G(const double)) ev.price_next;
     ta.pv_day = (CHUB_G(const int16_t)) ev.pv_day;
     ta.wd_day = (CHUB_G(const int16_t)) ev.wd_day;
     ta.q_len = (CHUB_G(const uint8_t)) ev.q_len;
     ta.hv_line = (CHUB_G(const uint8_t)) ev.hv_line;
     ta.drw = (CHUB_G(const uint32_t)) ev.drw[sa.tick & 1u];
+    ta.drw_cnt = (CHUB_G(const uint8_t)) ev.drw_cnt[sa.tick & 1u];
     ta.rec = (CHUB_G(uint32_t)) st.rec;
     ta.actions = (CHUB_G(const float)) sa.actions;
     ta.n_envs = (uint32_t) hp.n_envs;
@@ -1556,8 +1560,8 @@ constexpr int kEnvBlock = 256;  // compile-time (reading blockDim.x fetches the 
 // load burst and the arithmetic).
 template <bool RESET, int MODE, bool MULTI>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
-                                         const double *s_pv, const double *s_wd, const double *s_hy, const uint8_t *s_hv,
-                                         float *s_out, const int env_block, const TailArgs &ta) {
+                                         const double *s_pv, const double *s_wd, const double *s_pv_now, const double *s_wd_now,
+                                         const double *s_hy, const uint8_t *s_hv, float *s_out, const int env_block, const TailArgs &ta) {
     const HubParams &hp = ctx->hp;
     const EnvArrays &ev = ctx->ev;
     const CompatRng &cr = ctx->cr;
@@ -1573,8 +1577,11 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     const int t_next = RESET ? 0 : (t_now + 1) % 96;
     const bool draw_price = multi ? ((my_clk >> 8) & 3u) == 0u : sa.draw_price != 0;
     const double price_last = multi ? tb.price[RESET ? 95 : t_now] : sa.price_last;
+    const double price_prev = multi ? tb.price[(t_now + 95) % 96] : sa.price_prev;  // what the previous make_state saw as price[-1]
 #define TAB_PV(d) (multi ? tb.pvT[t_next * 100 + (d)] : s_pv[d])
 #define TAB_WD(d) (multi ? tb.wdT[t_next * 150 + (d)] : s_wd[d])
+#define TAB_PV_NOW(d) (multi ? tb.pvT[t_now * 100 + (d)] : s_pv_now[d])
+#define TAB_WD_NOW(d) (multi ? tb.wdT[t_now * 150 + (d)] : s_wd_now[d])
 #define TAB_HY(i) (MODE == MODE_COMPAT ? hy_env[i] : s_hy[i])
 #define TAB_HV(l) (multi ? tb.cnt_hv[(uint32_t) t_now * (uint32_t) kLevels + (uint32_t) (l)] : s_hv[l])
     // ---- prefetch: every per-env input is requested before the table staging and its barrier, and the PHILOX
@@ -1583,7 +1590,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     const uint32_t e32 = (uint32_t) env, n32 = ta.n_envs;
     // the table rows of this slot of the day (PV, wind, hy_table; COMPAT: FCEV counts) go out first, one element per lane, in
     // the same burst as the state loads: one memory round trip for everything (they are parked in LDS further down)
-    double st_pv = 0.0, st_wd = 0.0, st_hy = 0.0;
+    double st_pv = 0.0, st_wd = 0.0, st_hy = 0.0, st_pv_now = 0.0, st_wd_now = 0.0;
     uint32_t st_hv = 0;
     const double sin_t = multi ? tb.sin96[t_next] : ta.sin_t;  // the observation's time feature
     const bool tel_on = hp.telemetry != 0;
@@ -1592,6 +1599,10 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         if (!multi) {  // lock-step: the rows of the launch's slot of the day
             if (i < 100) st_pv = ta.pv_row[i];
             if (i < 150) st_wd = ta.wd_row[i];
+            if (!RESET) {
+                if (i < 100) st_pv_now = ta.pv_row_now[i];
+                if (i < 150) st_wd_now = ta.wd_row_now[i];
+            }
         }
         if (!RESET) {
             if (i < 102) st_hy = ta.hy_table[i];
@@ -1600,11 +1611,12 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     }
     // (the device-side tick offset of graph replays comes by scalar load: it does not hold up the vector loads behind it)
     PhiloxCtx px{ta.key[0], ta.key[1], MODE == MODE_PHILOX ? sa.tick + sload_u32(ta.tick_base, 0) : sa.tick, ta.gid0 + (uint32_t) env};
-    double cap = 0.0, in_re_wd = 0.0, in_re_pv = 0.0, in_price_next = 0.0, in_price_noise = 0.0;
+    double cap = 0.0, in_price_noise = 0.0;
     double ou_pv = 0.0, ou_wd = 0.0, ou_price = 0.0, z_pv = 0.0, z_wd = 0.0, z_pr = 0.0;
     float a_el_f = 0.0f, a_fc_f = 0.0f, P0f = 0.0f, P1f = 0.0f, mn0 = 0.0f, mx0 = 0.0f, mn1 = 0.0f, mx1 = 0.0f;
     int pv_day = 0, wd_day = 0, q_len = 0, hv_line = 0, F0i = 0, F1i = 0, ln0 = 0, ln1 = 0, hv_lev = 0, hv_arrive = 0;
-    u32x4 drw_raw = {0u, 0u, 0u, 0u}, drw_fcev = {0u, 0u, 0u, 0u};
+    u32x4 drw_raw = {0u, 0u, 0u, 0u};
+    uint32_t drw_n = 0u;
     if (live) {
         ou_pv = ta.ou[e32];
         ou_wd = ta.ou[n32 + e32];
@@ -1627,9 +1639,6 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
                 a_fc_f = ta.actions[ai + 1u];
             }
             cap = ta.cap[e32];
-            in_re_wd = ta.re_wd[e32];
-            in_re_pv = ta.re_pv[e32];
-            in_price_next = ta.price_next[e32];
             pv_day = ta.pv_day[e32];
             wd_day = ta.wd_day[e32];
             q_len = ta.q_len[e32];
@@ -1638,8 +1647,8 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         if (MODE == MODE_PHILOX && !RESET && !sa.fresh) {
             // this step's state-independent env draws (three OU normals, FCEV arrival count) were made one launch ahead by
             // the level blocks of k_env (draw_env_levels): 350 dependent instructions less on this latency-bound chain
-            drw_raw = ((CHUB_G(const u32x4)) ta.drw)[2u * e32];  // unpacked behind the table staging: no wait for it here
-            drw_fcev = ((CHUB_G(const u32x4)) ta.drw)[2u * e32 + 1u];
+            drw_raw = ((CHUB_G(const u32x4)) ta.drw)[e32];  // unpacked behind the table staging: no wait for it here
+            drw_n = ta.drw_cnt[e32];
         } else if (MODE == MODE_PHILOX) {
             const U4 ow = px.block(SITE_OU, 0, 0);  // word 0 pv, 1 wind, 2 price
             z_pv = (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[0]);
@@ -1665,6 +1674,8 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         if (i < 100) ((double *) s_pv)[i] = st_pv;
         if (i < 150) ((double *) s_wd)[i] = st_wd;
         if (!RESET) {
+            if (i < 100) ((double *) s_pv_now)[i] = st_pv_now;
+            if (i < 150) ((double *) s_wd_now)[i] = st_wd_now;
             if (i < 102) ((double *) s_hy)[i] = st_hy;
             if (MODE == MODE_COMPAT && i < kLevels / 4) ((uint32_t *) s_hv)[i] = st_hv;
         }
@@ -1674,7 +1685,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         z_pv = (double) __uint_as_float(drw_raw.x);
         z_wd = (double) __uint_as_float(drw_raw.y);
         z_pr = (double) __uint_as_float(drw_raw.z);
-        hv_arrive = (int) drw_raw.w;
+        hv_arrive = (int) drw_n;
     }
     // stand-alone kernel: output rows go through LDS so that the workgroup writes its kEnvBlock consecutive rows (one
     // contiguous run of memory) with coalesced stores instead of 15 scattered 4-byte stores per lane
@@ -1733,6 +1744,19 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         const double a_fc = ((double) a_fc_f + 1) / 2;  // action_real[-2] <- action[-1]  (MGR:395-398)
         const double P0 = (double) P0f, P1 = (double) P1f;
         const double F0 = (double) F0i, F1 = (double) F1i;
+        // What the previous make_state (MGR:344-361: the end of the previous step, or reset) produced for THIS slot is not kept as
+        // state but re-derived, operation for operation, from what it was computed from: the table rows of this slot of the day,
+        // the OU states as that make_state left them (the values loaded above), the price noise and the tariff it saw last.
+        double in_re_pv, in_re_wd;
+        {
+            double tp = TAB_PV_NOW(pv_day);
+            if (tp > 0 && (pv_day % 2) == 0) tp += ou_pv * hp.renew_fluct1;  // REN:38-43
+            in_re_pv = (tp > 0 ? tp : 0.0) * 5;
+            double tw = TAB_WD_NOW(wd_day);
+            tw += ou_wd * hp.renew_fluct1;                                    // REN:45-49
+            in_re_wd = (tw > 0 ? tw : 0.0) * 1;
+        }
+        const double in_price_next = price_prev + in_price_noise;            // MGR:354-359
         double re_new_power = in_re_wd + in_re_pv;    // MGR:143
         const double charging_power = 0.0 + P0 + P1;  // MGR:157
         // ---- electrolyser request clamp against the grid limit (MGR:160-180)
@@ -1758,8 +1782,10 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         const int arrive = MODE == MODE_COMPAT ? (int) TAB_HV(hv_lev) : hv_arrive;
         double total_mass = 0.0;
         const bool fcev_pre = MODE == MODE_PHILOX && !RESET && !sa.fresh;
-        const double pre_tn = __hiloint2double((int) drw_fcev.y, (int) drw_fcev.x);
-        const double pre_mn = __hiloint2double((int) drw_fcev.w, (int) drw_fcev.z);
+        // the first arrival's SoC was drawn one launch ahead with the other env draws (level_block: same Philox counter); its
+        // fueling time and mass follow from it alone
+        double pre_tn = 0.0, pre_mn = 0.0;
+        if (fcev_pre && arrive > 0) fcev_time_mass(__uint_as_float(drw_raw.w), pre_tn, pre_mn);
         bool stuck = (hv_line & 128) != 0;
         hv_line &= 127;
         uint32_t fold_n = 0;
@@ -1785,8 +1811,6 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             for (int j = 0; j < arrive; j++) {
                 double tn, mn;
                 if (fcev_pre && j == 0) {
-                    // the first arrival's fueling time and mass depend on its drawn SoC only: made one launch ahead with the
-                    // other env draws (level_block), same functions, same Philox counter
                     tn = pre_tn;
                     mn = pre_mn;
                 } else {
@@ -1967,9 +1991,6 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     } else {
         price_next = price_last + in_price_noise;
     }
-    ev.re_pv[e32] = re_pv;
-    ev.re_wd[e32] = re_wd;
-    ev.price_next[e32] = price_next;
     ev.cap[e32] = cap;
     if (MODE == MODE_COMPAT && !RESET) rs.store(cr, env);
 
@@ -2024,6 +2045,8 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     flush_rows();
 #undef TAB_PV
 #undef TAB_WD
+#undef TAB_PV_NOW
+#undef TAB_WD_NOW
 #undef TAB_HY
 #undef TAB_HV
 }
@@ -2040,7 +2063,10 @@ __device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, cons
     const int t_next = RESET ? 0 : ((MULTI ? clk_t(env_clk(sa, N, env_)) : sa.t) + 1) % 96;
     if (u < 2 * N) {
         const int kk = u >= N ? 1 : 0;
-        ctx->st.pk[(sa.tick + 1u) & 1u][u] = draw_station_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick + 1u), t_next, kk, u - (int64_t) kk * N);
+        // drawn AND decoded here, against the queue the slot kernel of this launch has just left in the unit's record
+        const int line_now = pkd_line(ctx->st.rec[4u * (uint32_t) u + 3u]);
+        ctx->st.pk[(sa.tick + 1u) & 1u][u] = dk_make(draw_station_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick + 1u), t_next, kk, u - (int64_t) kk * N),
+                                                     line_now, hp.type[kk] == 0);
     } else {
         // the per-env draws (same Philox sites and counters the tail would use itself)
         const uint32_t e = (uint32_t) (u - 2 * N);
@@ -2052,23 +2078,16 @@ __device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, cons
         d.x = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[0]));
         d.y = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[1]));
         d.z = __float_as_uint(normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[2]));
-        d.w = (uint32_t) tb.cnt_hv[(uint32_t) t_next * (uint32_t) kLevels + hv_lev];
-        u32x4 f = {0u, 0u, 0u, 0u};
-        if (d.w != 0u) {
-            double tn, mn;
-            fcev_time_mass(soc_from_word(tb.soc_d_icdf, px.block(SITE_HVSOC, 0, 0).v[0]), tn, mn);
-            f.x = (uint32_t) __double2loint(tn); f.y = (uint32_t) __double2hiint(tn);
-            f.z = (uint32_t) __double2loint(mn); f.w = (uint32_t) __double2hiint(mn);
-        }
-        CHUB_G(u32x4) dst = (CHUB_G(u32x4)) ctx->ev.drw[(sa.tick + 1u) & 1u] + 2u * e;
-        dst[0] = d;
-        dst[1] = f;
+        const uint32_t cnt = (uint32_t) tb.cnt_hv[(uint32_t) t_next * (uint32_t) kLevels + hv_lev];
+        d.w = cnt != 0u ? __float_as_uint(soc_from_word(tb.soc_d_icdf, px.block(SITE_HVSOC, 0, 0).v[0])) : 0u;  // the first arrival's SoC
+        ((CHUB_G(u32x4)) ctx->ev.drw[(sa.tick + 1u) & 1u])[e] = d;
+        ctx->ev.drw_cnt[(sa.tick + 1u) & 1u][e] = (uint8_t) cnt;
     }
 }
 
 template <bool RESET, int MODE, bool MULTI>
 __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, TailArgs ta, int nb_env) {
-    __shared__ double s_pv[100], s_wd[150], s_hy[102];
+    __shared__ double s_pv[100], s_wd[150], s_pv_now[100], s_wd_now[150], s_hy[102];
     __shared__ __attribute__((aligned(16))) uint8_t s_hv[kLevels];
     __shared__ __attribute__((aligned(16))) float s_out[kEnvBlock * 16];  // output rows: obs_dim + 2 <= 15 floats
     if (MODE == MODE_PHILOX && (int) blockIdx.x >= nb_env) {
@@ -2078,8 +2097,8 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
         return;
     }
     const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
-    env_tail<RESET, MODE, MULTI>(ctx, sa, env, env < (int) ta.n_envs && (!MULTI || in_group(sa, env)), s_pv, s_wd, s_hy, s_hv, s_out,
-                                 (int) blockIdx.x, ta);
+    env_tail<RESET, MODE, MULTI>(ctx, sa, env, env < (int) ta.n_envs && (!MULTI || in_group(sa, env)), s_pv, s_wd, s_pv_now, s_wd_now, s_hy,
+                                 s_hv, s_out, (int) blockIdx.x, ta);
 }
 
 // COMPAT only: HySystem.__init__ (HYD:154-158) builds hy_power_speed_list with 101 REAL hy_step()s from the initial tank:
@@ -2288,7 +2307,7 @@ __global__ void k_reset_levels(const DevCtx *__restrict__ ctx, StepArgs sa) {
     true_in += __shfl_xor(true_in, 1);
     true_in += __shfl_xor(true_in, 2);
     if (served && q == 0)
-        ctx->st.pk[tick & 1u][u] = (uint64_t) (((uint32_t) n_in & 0xFFFFu) | ((uint32_t) true_in << 16));  // n_in: signed 16 bits
+        ctx->st.pk[tick & 1u][u] = ((uint32_t) n_in & 0xFFFFu) | ((uint32_t) true_in << 16);  // n_in: signed 16 bits
 }
 
 // fresh launches (StepArgs::fresh): this step's station-level draws, made right in front of the slot kernel -- what the
@@ -2302,7 +2321,9 @@ __global__ void k_draw_levels(const DevCtx *__restrict__ ctx, StepArgs sa) {
     const int64_t env = u - (int64_t) kk * N;
     if (!in_group(sa, env)) return;
     const int t = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;
-    ctx->st.pk[sa.tick & 1u][u] = draw_station_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick), t, kk, env);
+    // tape mode: the caller's recorded draws instead of this build's (same layout: draw_station_levels), decoded the same way
+    const uint64_t raw = sa.pk_tape ? sa.pk_tape[u] : draw_station_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick), t, kk, env);
+    ctx->st.pk[sa.tick & 1u][u] = dk_make(raw, pkd_line(ctx->st.rec[4u * (uint32_t) u + 3u]), hp.type[kk] == 0);
 }
 
 // ------------------------------------------------------------------------------------- launchers
@@ -2341,7 +2362,7 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
 
 void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
                  const PackedPtrs &pp, hipEvent_t ev0, hipEvent_t ev1) {
-    if (hp.rng_mode == MODE_PHILOX && !reset && sa.fresh && !sa.pk_tape)
+    if (hp.rng_mode == MODE_PHILOX && !reset && (sa.fresh || sa.pk_tape))
         hipLaunchKernelGGL(k_draw_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
     if (hp.rng_mode == MODE_PHILOX) {
         if (hp.packed && !sa.load_mode) {
@@ -2358,7 +2379,7 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             pa.cls_delta = (uint32_t) ((const char *) pp.cls[1] - (const char *) pp.cls[0]);
             pa.state = (CHUB_G(uint32_t)) pp.hot;
             pa.rec = (CHUB_G(uint32_t)) pp.rec;
-            pa.pk = (CHUB_G(const uint64_t)) (sa.pk_tape ? sa.pk_tape : pp.pk[sa.tick & 1u]);
+            pa.pk = (CHUB_G(const uint32_t)) pp.pk[sa.tick & 1u];
             pa.actions = (CHUB_G(const float)) sa.actions;
             pa.cls0 = (CHUB_G(const float)) pp.cls[0];
             pa.ttab2 = (CHUB_G(const float)) pp.ttab2;
@@ -2422,14 +2443,14 @@ __global__ void k_tick_advance(uint32_t *tick_base, uint32_t by) { *tick_base +=
 // value on the same side of the threshold gives the same step), the tail as it is
 __global__ void k_expand_bits(int64_t n_envs, int S, int W, const uint64_t *__restrict__ bits, const float *__restrict__ tail,
                               float *__restrict__ actions) {
-    const int A = S + 2;
-    const int64_t total = n_envs * (int64_t) A;
-    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
-        const int64_t env = i / A;
-        const int j = (int) (i - env * A);
+    const uint32_t A = (uint32_t) S + 2u;
+    const uint32_t total = (uint32_t) n_envs * A;  // n_envs * (piles + 2) < 2^31 (checked at create)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t env = i / A;
+        const uint32_t j = i - env * A;
         float v;
-        if (j < S) v = ((bits[env * W + (j >> 6)] >> (j & 63)) & 1ull) ? 1.0f : -1.0f;
-        else v = tail[env * 2 + (j - S)];
+        if (j < (uint32_t) S) v = ((bits[(size_t) env * (size_t) W + (j >> 6)] >> (j & 63u)) & 1ull) ? 1.0f : -1.0f;
+        else v = tail[env * 2u + (j - (uint32_t) S)];
         actions[i] = v;
     }
 }

@@ -97,6 +97,7 @@ struct chub_env {
     hipStream_t stream;
     // host-pointer entry points: pinned staging + a private stream (lazily made by host_path_init)
     hipStream_t host_stream;
+    hipStream_t upload_stream;    // uploads that must stay outside a capture in progress (masks of captured calls)
     float *h_actions, *h_packed;  // pinned: [N][A], [N][D+2]
     uint64_t *h_bits, *d_bits;    // chub_step_bits: [N][ceil(S / 64)] pinned staging and its device copy
     float *h_tail, *d_tail;       //                 [N][2]
@@ -306,8 +307,8 @@ static PackedPtrs packed_ptrs(const chub_env *e) {
     memcpy(p.late8, e->h_late8, sizeof p.late8);
     p.tb = &e->tb;
     p.sin96 = e->h_sin96;
-    p.pk[0] = (uint64_t *) e->st.pk[0];
-    p.pk[1] = (uint64_t *) e->st.pk[1];
+    p.pk[0] = (uint32_t *) e->st.pk[0];
+    p.pk[1] = (uint32_t *) e->st.pk[1];
     return p;
 }
 
@@ -393,6 +394,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->predrawn = false;
     e->stream = nullptr;
     e->host_stream = nullptr;
+    e->upload_stream = nullptr;
     e->h_actions = e->h_packed = e->d_packed = nullptr;
     e->h_bits = e->d_bits = nullptr;
     e->h_tail = e->d_tail = nullptr;
@@ -738,11 +740,10 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     }
     ALLOC(e->st.rec, 8 * N); ALLOC(e->st.pk[0], 2 * N); ALLOC(e->st.pk[1], 2 * N); ALLOC(e->st.tail_act, 2 * N);
     ALLOC(e->ev.cap, N); ALLOC(e->ev.store_soc, N); ALLOC(e->ev.ou, 3 * N); ALLOC(e->ev.price_noise, N);
-    ALLOC(e->ev.re_pv, N); ALLOC(e->ev.re_wd, N); ALLOC(e->ev.price_next, N);
     ALLOC(e->ev.pv_day, N); ALLOC(e->ev.wd_day, N); ALLOC(e->ev.q_len, N); ALLOC(e->ev.hv_line, N);
     ALLOC(e->ev.q_fold, 2 * N); ALLOC(e->ev.q_fold_cnt, N); ALLOC(e->ev.q_time, N * (size_t) qcap); ALLOC(e->ev.q_mass, N * (size_t) qcap);
     e->ev.hy_env = nullptr;
-    ALLOC(e->ev.drw[0], 8 * N); ALLOC(e->ev.drw[1], 8 * N);
+    ALLOC(e->ev.drw[0], 4 * N); ALLOC(e->ev.drw[1], 4 * N); ALLOC(e->ev.drw_cnt[0], N); ALLOC(e->ev.drw_cnt[1], N);
     e->ev.obs64 = nullptr; e->ev.reward64 = nullptr; e->ev.telem = nullptr;
     e->cr.g = nullptr; e->cr.minstd = nullptr;
     if (rng_mode == CHUB_RNG_COMPAT) {
@@ -795,12 +796,11 @@ int chub_destroy(chub_env *e) {
         for (hipEvent_t ev : e->mask_done)
             if (ev) (void) hipEventDestroy(ev);
         if (e->h_packed) (void) hipHostFree(e->h_packed);
-        if (e->h_bits) (void) hipHostFree(e->h_bits);
-        if (e->h_tail) (void) hipHostFree(e->h_tail);
+        if (e->h_bits) (void) hipHostFree(e->h_bits);  // h_tail / d_tail are the ends of the same blocks
         if (e->d_bits) (void) hipFree(e->d_bits);
-        if (e->d_tail) (void) hipFree(e->d_tail);
         if (e->d_packed) (void) hipFree(e->d_packed);
         if (e->host_stream) (void) hipStreamDestroy(e->host_stream);
+        if (e->upload_stream) (void) hipStreamDestroy(e->upload_stream);
     }
     (void) hipGetLastError();  // HIP's last-error slot is per thread and sticky: do not leave ours for the next handle's checks
     delete e;
@@ -856,7 +856,10 @@ static int serve_mask(chub_env *e, const uint8_t *mask, hipStream_t s, int &serv
         uint8_t *d = nullptr;
         HIP_TRY(hipMalloc((void **) &d, N));
         e->cap_masks.push_back(d);
-        HIP_TRY(hipMemcpy(d, mask, N, hipMemcpyHostToDevice));  // synchronous, on the null stream: not part of the capture
+        // filled now, outside the capture: on a stream of its own (the null stream may not be touched while another stream captures)
+        if (!e->upload_stream) HIP_TRY(hipStreamCreateWithFlags(&e->upload_stream, hipStreamNonBlocking));
+        HIP_TRY(hipMemcpyAsync(d, mask, N, hipMemcpyHostToDevice, e->upload_stream));
+        HIP_TRY(hipStreamSynchronize(e->upload_stream));
         e->cur_mask = d;
         return CHUB_OK;
     }
@@ -1020,6 +1023,7 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     sa.draw_price = (e->price_count % 4 == 0) ? 1 : 0;
     sa.station_filter = -1;
     sa.price_last = e->price[e->t];  // AGG:147
+    sa.price_prev = e->price[(e->t + 95) % 96];  // what the make_state before this step saw there (the reset: price[95], AGG:171)
     sa.actions = d_actions;
     sa.exo_z = d_exo_z;
     sa.obs = d_obs;
@@ -1207,6 +1211,20 @@ int chub_reset(chub_env *e, const int32_t *exo_days, const double *exo_z, float 
     return CHUB_OK;
 }
 
+// The output arrays of a host-pointer step, as the device sees them: pinned host memory (hipHostMalloc: chub_alloc_host, what
+// VecChargingHub hands in) is mapped into the device's address space, so the tail kernel can store its rows straight into the
+// caller's arrays -- they cross PCIe as posted writes while the kernel runs instead of in a copy phase of their own behind it.
+// Any other host memory gets the handle's device staging and a copy back.
+static bool device_view(void *host, void **dev) {
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess || !d) {
+        (void) hipGetLastError();
+        return false;
+    }
+    *dev = d;
+    return true;
+}
+
 // Host-pointer step: the reference-shaped API (numpy in / numpy out), bounded by PCIe: (A + D + 2) * 4 bytes per env and
 // step.  A private stream; the actions go up from the handle's pinned buffer when the caller filled that one
 // (chub_host_actions: one DMA, no staging copy), otherwise through the runtime's pageable-copy path; outputs come back
@@ -1241,11 +1259,18 @@ int chub_step(chub_env *e, const float *actions, const double *exo_z, float *obs
     }
     // from the handle's pinned buffer (chub_host_actions) this is one DMA; any other host pointer is staged by the HIP runtime
     HIP_TRY(hipMemcpyAsync(e->d_actions, actions, N * A * sizeof(float), hipMemcpyHostToDevice, s));
-    rc = chub_step_device(e, e->d_actions, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, s);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(obs, e->d_obs, N * D * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(done, e->d_done, N, hipMemcpyDeviceToHost, s));
+    void *v_obs = nullptr, *v_rew = nullptr, *v_done = nullptr;
+    if (device_view(obs, &v_obs) && device_view(reward, &v_rew) && device_view(done, &v_done)) {
+        // pinned output arrays: the tail kernel stores into them directly (see device_view)
+        rc = chub_step_device(e, e->d_actions, e->d_exo_z, (float *) v_obs, (float *) v_rew, (uint8_t *) v_done, s);
+        if (rc) return rc;
+    } else {
+        rc = chub_step_device(e, e->d_actions, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, s);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(obs, e->d_obs, N * D * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(done, e->d_done, N, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     return CHUB_OK;
 }
@@ -1257,10 +1282,11 @@ static int bits_path_init(chub_env *e) {
     int rc = host_path_init(e);
     if (rc || e->h_bits) return rc;
     const size_t N = (size_t) e->hp.n_envs, W = (size_t) ((e->hp.S[0] + e->hp.S[1] + 63) / 64);
-    HIP_TRY(hipHostMalloc((void **) &e->h_bits, N * W * sizeof(uint64_t), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **) &e->h_tail, N * 2 * sizeof(float), hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **) &e->d_bits, N * W * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **) &e->d_tail, N * 2 * sizeof(float)));
+    // bits and tail in ONE pinned block and one device block: a caller that fills the handle's staging goes up in a single DMA
+    HIP_TRY(hipHostMalloc((void **) &e->h_bits, N * W * sizeof(uint64_t) + N * 2 * sizeof(float), hipHostMallocDefault));
+    e->h_tail = (float *) (e->h_bits + N * W);
+    HIP_TRY(hipMalloc((void **) &e->d_bits, N * W * sizeof(uint64_t) + N * 2 * sizeof(float)));
+    e->d_tail = (float *) (e->d_bits + N * W);
     return CHUB_OK;
 }
 
@@ -1296,14 +1322,25 @@ int chub_step_bits(chub_env *e, const uint64_t *pile_bits, const float *tail, co
         if (!exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
         HIP_TRY(hipMemcpyAsync(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     }
-    // from the handle's pinned buffers (chub_host_bits) each of these is one DMA; any other host pointer is staged by the HIP runtime
-    HIP_TRY(hipMemcpyAsync(e->d_bits, pile_bits, N * W * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(e->d_tail, tail, N * 2 * sizeof(float), hipMemcpyHostToDevice, s));
-    rc = chub_step_bits_device(e, e->d_bits, e->d_tail, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, s);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(obs, e->d_obs, N * D * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(done, e->d_done, N, hipMemcpyDeviceToHost, s));
+    // from the handle's pinned block (chub_host_bits) this is ONE DMA; any other host pointers are staged by the HIP runtime
+    if (pile_bits == e->h_bits && tail == e->h_tail) {
+        HIP_TRY(hipMemcpyAsync(e->d_bits, pile_bits, N * W * sizeof(uint64_t) + N * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(e->d_bits, pile_bits, N * W * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(e->d_tail, tail, N * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+    void *v_obs = nullptr, *v_rew = nullptr, *v_done = nullptr;
+    const bool direct = device_view(obs, &v_obs) && device_view(reward, &v_rew) && device_view(done, &v_done);
+    if (direct) {
+        rc = chub_step_bits_device(e, e->d_bits, e->d_tail, e->d_exo_z, (float *) v_obs, (float *) v_rew, (uint8_t *) v_done, s);
+        if (rc) return rc;
+    } else {
+        rc = chub_step_bits_device(e, e->d_bits, e->d_tail, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, s);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(obs, e->d_obs, N * D * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(done, e->d_done, N, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     return CHUB_OK;
 }

@@ -56,7 +56,7 @@ def test_create_fails_loudly_without_gpu_and_validates_arguments():
     assert b"must have fast pile or slow pile" in lib.chub_last_error()  # MGR:336
     big = m.make_config([257, 1], ["fast", "slow"])
     assert lib.chub_create(C.byref(big), data, 4, 0, 0, 1, _lib.RNG_PHILOX, C.byref(h)) == -4
-    big = m.make_config([65, 1], ["fast", "slow"])
+    big = m.make_config([65, 257], ["fast", "slow"])  # COMPAT streams take stations of up to 256 piles too (the reference: any size)
     assert lib.chub_create(C.byref(big), data, 4, 0, 0, 1, _lib.RNG_COMPAT, C.byref(h)) == -4
     lowsoc = m.make_config([4, 4], ["fast", "slow"], init_soc=0.05)
     assert lib.chub_create(C.byref(lowsoc), data, 4, 0, 0, 1, _lib.RNG_PHILOX, C.byref(h)) == -1  # HYD:137
