@@ -258,47 +258,10 @@ __device__ __forceinline__ float normal_from_word(const float *tz, const float *
 // PHILOX: the station-level draws of receive_car (CHS.hpp:1272-1303 / 1583-1614) do not depend on state, only their
 // use does: arrival count = table[slot of day][level]; queued car w stays iff level_w >= thr_renege[w]; arrival j stays
 // iff level_j <= thr_balk[line + j], i.e. iff line <= inv_balk[level_j] - j (thr_balk is non-increasing).  So one lane
-// per (station, env) unit draws them for the NEXT step, in extra blocks of the current k_slot launch (they overlap with
-// the slot work at no latency cost), and packs them into 64 bits:
+// per (station, env) unit draws them for the NEXT step, in extra blocks of the k_env launch.  Packed into 64 bits (the form
+// chub_step_tape takes them in from the caller, pk_tape):
 //   bits 0-9 renege pass bit per queue position, 10-13 arrivals n (<= 9), 14+4l (l = 0..10): how many of the n
 //   arrivals stay (balk pass, incl. the j <= S guard) if the queue holds l cars after the renege pass.
-__device__ __forceinline__ uint64_t draw_station_levels(const HubParams &hp, const Tables &tb, uint32_t tick_next,
-                                                        int t_next, int k, int64_t env) {
-    // Straight-line on purpose: the six Philox blocks and the ten table look-ups are independent, so issuing them
-    // all up front gives the (few, latency-bound) waves that run this the ILP to overlap them.
-    PhiloxCtx px{hp.key[0], hp.key[1], tick_next, (uint32_t) (hp.env_id0 + env)};
-    const U4 a0 = px.block(SITE_ARRIVE, (uint32_t) k, 0), a1 = px.block(SITE_ARRIVE, (uint32_t) k, 1),
-             a2 = px.block(SITE_ARRIVE, (uint32_t) k, 2);
-    const U4 r0 = px.block(SITE_RENEGE, (uint32_t) k, 0), r1 = px.block(SITE_RENEGE, (uint32_t) k, 1),
-             r2 = px.block(SITE_RENEGE, (uint32_t) k, 2);
-    int n_in = (int) tb.cnt[k][t_next * kLevels + (int) (a0.v[0] % 1000u)];
-    // arrival j uses word 1 + j of the ARRIVE stream
-    const uint32_t bw[9] = {a0.v[1], a0.v[2], a0.v[3], a1.v[0], a1.v[1], a1.v[2], a1.v[3], a2.v[0], a2.v[1]};
-    int lim[9];
-#pragma unroll
-    for (int j = 0; j < 9; j++) lim[j] = (int) tb.inv_balk[bw[j] % 1000u];
-    const uint32_t rw[10] = {r0.v[0], r0.v[1], r0.v[2], r0.v[3], r1.v[0], r1.v[1], r1.v[2], r1.v[3], r2.v[0], r2.v[1]};
-    uint32_t lo = 0;
-#pragma unroll
-    for (int w = 0; w < kMaxLine; w++) lo |= ((int) (rw[w] % 1000u) >= (int) tb.thr_renege[w]) ? (1u << w) : 0u;
-    n_in = n_in > 9 ? 9 : n_in;  // the tables top out at round(0.15*0.2*300) = 9
-    uint64_t pk = (uint64_t) (lo | ((uint32_t) n_in << 10));
-    const int S = hp.S[k];
-    int stay[kMaxLine + 1];
-#pragma unroll
-    for (int l = 0; l <= kMaxLine; l++) stay[l] = 0;
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-        const int top = lim[j] - j;  // arrival j stays iff line <= top (thr_balk is non-increasing)
-        const bool counts = j < n_in && j <= S;
-#pragma unroll
-        for (int l = 0; l <= kMaxLine; l++) stay[l] += (counts && l <= top) ? 1 : 0;
-    }
-#pragma unroll
-    for (int l = 0; l <= kMaxLine; l++) pk |= (uint64_t) stay[l] << (14 + 4 * l);
-    return pk;
-}
-
 // What those draws come to for a unit whose queue holds `line` cars (Station::line as the previous step left it): the renege
 // pass over the queue (CHS.hpp:1286-1293), the arrivals, and -- slow station -- those of them that stay given the queue just
 // thinned (CHS.hpp:1297-1306; the fast station records the un-thinned count, CHS.hpp:1617).  Decoded ONCE per unit, where the draws
@@ -309,6 +272,42 @@ __device__ __forceinline__ uint32_t dk_make(uint64_t pk, int line, bool fast) {
     const int n_in = (int) (pk >> 10) & 15;
     const int flow = fast ? n_in : (int) ((pk >> (14 + 4 * line)) & 15);
     return (uint32_t) (line + flow) | ((uint32_t) flow << 8);
+}
+// The same, drawn and decoded in one go where the queue length is known at draw time (the level blocks of k_env, k_draw_levels):
+// only what this queue length needs -- `line` renege tests instead of all ten, the balk tests at ONE queue length instead of the
+// whole table of eleven; the words: SITE_ARRIVE word 0 = arrival level, word 1 + j = balk level of arrival j; SITE_RENEGE word w = queue position w
+__device__ __forceinline__ uint32_t draw_decoded_levels(const HubParams &hp, const Tables &tb, uint32_t tick, int t, int k, int64_t env,
+                                                        int line, bool fast) {
+    PhiloxCtx px{hp.key[0], hp.key[1], tick, (uint32_t) (hp.env_id0 + env)};
+    const U4 a0 = px.block(SITE_ARRIVE, (uint32_t) k, 0);
+    const U4 r0 = px.block(SITE_RENEGE, (uint32_t) k, 0);
+    int n_in = (int) tb.cnt[k][t * kLevels + (int) (a0.v[0] % 1000u)];
+    n_in = n_in > 9 ? 9 : n_in;
+    uint32_t rw[10] = {r0.v[0], r0.v[1], r0.v[2], r0.v[3], 0u, 0u, 0u, 0u, 0u, 0u};
+    if (__any(line > 4)) {  // the words of queue positions 4-9 only where some unit of the wave has such a queue
+        const U4 r1 = px.block(SITE_RENEGE, (uint32_t) k, 1), r2 = px.block(SITE_RENEGE, (uint32_t) k, 2);
+        rw[4] = r1.v[0]; rw[5] = r1.v[1]; rw[6] = r1.v[2]; rw[7] = r1.v[3]; rw[8] = r2.v[0]; rw[9] = r2.v[1];
+    }
+    int stay_q = 0;
+#pragma unroll
+    for (int w = 0; w < kMaxLine; w++) stay_q += (w < line && (int) (rw[w] % 1000u) >= (int) tb.thr_renege[w]) ? 1 : 0;
+    int flow = n_in;
+    if (!fast && __any(n_in > 0)) {  // the slow station records what survives the balk pass at the queue length just computed
+        uint32_t bw[9] = {a0.v[1], a0.v[2], a0.v[3], 0u, 0u, 0u, 0u, 0u, 0u};
+        if (__any(n_in > 3)) {
+            const U4 a1 = px.block(SITE_ARRIVE, (uint32_t) k, 1), a2 = px.block(SITE_ARRIVE, (uint32_t) k, 2);
+            bw[3] = a1.v[0]; bw[4] = a1.v[1]; bw[5] = a1.v[2]; bw[6] = a1.v[3]; bw[7] = a2.v[0]; bw[8] = a2.v[1];
+        }
+        const int S = hp.S[k];
+        flow = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            if (j >= 3 && !__any(n_in > j)) break;
+            const int top = (int) tb.inv_balk[bw[j] % 1000u] - j;  // arrival j stays iff line <= top (thr_balk is non-increasing)
+            flow += (j < n_in && j <= S && stay_q <= top) ? 1 : 0;
+        }
+    }
+    return (uint32_t) (stay_q + flow) | ((uint32_t) flow << 8);
 }
 __device__ __forceinline__ int dk_want(uint32_t dk) { return (int) (dk & 255u); }
 __device__ __forceinline__ int dk_flow(uint32_t dk) { return (int) ((dk >> 8) & 255u); }
@@ -719,7 +718,7 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
             flow = fast ? (int) (int16_t) (pk_in & 0xFFFFu) : (int) ((pk_in >> 16) & 0xFFFFu);
             want = flow;
         } else {
-            // this step's station-level draws were made and decoded one launch ahead (draw_station_levels, dk_make)
+            // this step's station-level draws were made and decoded one launch ahead (draw_decoded_levels)
             want = dk_want(pk_in);
             flow = dk_flow(pk_in);
         }
@@ -1094,7 +1093,11 @@ __device__ __forceinline__ uint32_t sload_u32(const void *p, int i) { return ((c
 // RESET: evs_reset (CHS.hpp:1209-1231 / 1520-1542) on the same layout: no state comes in, the unit's initial occupancy was drawn
 // by k_reset_levels, every wave helps with the (many) new cars.  BIG: a station with more than 64 piles -- a unit then spans
 // several waves (its empties are counted over all of them) and its power sums need 64 bits.
-template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG>
+#ifndef CHUB_EPI_ALL
+#define CHUB_EPI_ALL 1  // 1: every wave of the workgroup takes its share of the new cars (a third barrier: -0.2 us at C4); 0: the last wave alone
+#endif
+// MASKED: per-env clocks (the launch serves the envs of a mask); the lock-step instantiation carries none of it
+template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED>
 __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, PackedArgs &pa, const Tables &tb,
                                                  const uint32_t block_local, uint32_t *q_cnt, uint32_t *q_new,
                                                  uint64_t *s_ball, int *s_acc, uint32_t *s_unit) {
@@ -1131,7 +1134,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         const int env = env_first + e_[j];
         valid[j] = e_[j] < epb && env < N;
         uint32_t served = 1u;  // per-env clocks: is the env served by this launch?  Requested with the state, looked at after it
-        if (pa.env_mask && valid[j]) served = pa.env_mask[env];
+        if (MASKED && valid[j]) served = pa.env_mask[env];
         sidx[j] = (uint32_t) (k_[j] ? N : 0) + (uint32_t) env;
         asm volatile("" : "=v"(s2[j]), "=v"(act[j]), "=v"(pk_in[j]));
         if (RESET) {
@@ -1145,7 +1148,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
             }
             pk_in[j] = CHUB_AT(const uint32_t, pa.pk, sidx[j] << 2);
         }
-        if (pa.env_mask && valid[j]) valid[j] = served != 0u;
+        if (MASKED && valid[j]) valid[j] = served != 0u;
     }
     if (!TAPE) {  // the new cars' Philox inputs: scalar registers from here on, requested behind the first loads
         pa.tick += sload_u32(pa.tick_base, 0);  // CHUB_TICK
@@ -1296,10 +1299,11 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
     // other waves are done (their wave slots go to the next workgroup instead of idling at a third barrier through the
     // Philox block and the dependent table read of the new cars).  RESET: about half of all slots get a car, so every wave
     // serves its share and the workgroup meets again in front of the records.
-    if (!RESET && wave != WAVES - 1) return;
+    constexpr bool ALL = RESET || CHUB_EPI_ALL;  // every wave takes new cars
+    if (!ALL && wave != WAVES - 1) return;
     // ---- add_car (CHS.hpp:864-877 / 1029-1042) for the workgroup's new cars, one lane per car
     const uint32_t n_adm = q_cnt[0];
-    for (uint32_t i = (uint32_t) (RESET ? tid : lane); i < n_adm; i += (RESET ? BLOCK : 64)) {
+    for (uint32_t i = (uint32_t) (ALL ? tid : lane); i < n_adm; i += (ALL ? BLOCK : 64)) {
         const int src = (int) q_new[i];
         const int s_e = (int) (((uint32_t) src * pa.magic) >> 20);
         const int s_hs = src - s_e * St;
@@ -1345,7 +1349,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
             }
         }
     }
-    if (RESET) {
+    if (ALL) {
         __syncthreads();
         if (wave != WAVES - 1) return;
     }
@@ -1357,7 +1361,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         const int e = i >> 1, k = i & 1;
         const int env = env_first + e;
         if (env >= N) continue;
-        if (pa.env_mask && pa.env_mask[env] == 0) continue;
+        if (MASKED && pa.env_mask[env] == 0) continue;
         const uint32_t su = (uint32_t) (k ? N : 0) + (uint32_t) env;
         if (!RESET && k == 0) {  // the env's tail actions sit in the lines this workgroup has just read: hand them to the tail kernel packed
             typedef float f32x2_ __attribute__((ext_vector_type(2)));
@@ -1400,7 +1404,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
 #undef CHUB_AT
 }
 
-template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG>
+template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED>
 __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in) {
     __shared__ uint32_t q_new[BLOCK * T];
     __shared__ uint32_t q_cnt[2];
@@ -1413,7 +1417,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_sl
     PackedArgs pa = pa_in;
     asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
                       "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
-    slot_body_packed<BLOCK, T, TAPE, RESET, BIG>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new, s_ball + 1, s_acc, s_unit);
+    slot_body_packed<BLOCK, T, TAPE, RESET, BIG, MASKED>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new, s_ball + 1, s_acc, s_unit);
 }
 
 // What the tail's first loads need, by value in the kernel arguments: one scalar load at the start of the wave instead
@@ -2065,8 +2069,8 @@ __device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, cons
         const int kk = u >= N ? 1 : 0;
         // drawn AND decoded here, against the queue the slot kernel of this launch has just left in the unit's record
         const int line_now = pkd_line(ctx->st.rec[4u * (uint32_t) u + 3u]);
-        ctx->st.pk[(sa.tick + 1u) & 1u][u] = dk_make(draw_station_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick + 1u), t_next, kk, u - (int64_t) kk * N),
-                                                     line_now, hp.type[kk] == 0);
+        ctx->st.pk[(sa.tick + 1u) & 1u][u] = draw_decoded_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick + 1u), t_next, kk, u - (int64_t) kk * N,
+                                                                 line_now, hp.type[kk] == 0);
     } else {
         // the per-env draws (same Philox sites and counters the tail would use itself)
         const uint32_t e = (uint32_t) (u - 2 * N);
@@ -2093,9 +2097,14 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     if (MODE == MODE_PHILOX && (int) blockIdx.x >= nb_env) {
         // the last blocks of the grid: next step's station-level draws, one lane per (station, env).
         // They are pure VALU work and fill the issue slots the latency-bound tail waves leave empty.
+#if !defined(CHUB_ABLATE_LEVELS)
         level_block<RESET, MULTI>(ctx, sa, (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x);
+#endif
         return;
     }
+#if defined(CHUB_ABLATE_TAIL)
+    if (!RESET) return;
+#endif
     const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
     env_tail<RESET, MODE, MULTI>(ctx, sa, env, env < (int) ta.n_envs && (!MULTI || in_group(sa, env)), s_pv, s_wd, s_pv_now, s_wd_now, s_hy,
                                  s_hv, s_out, (int) blockIdx.x, ta);
@@ -2321,9 +2330,10 @@ __global__ void k_draw_levels(const DevCtx *__restrict__ ctx, StepArgs sa) {
     const int64_t env = u - (int64_t) kk * N;
     if (!in_group(sa, env)) return;
     const int t = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;
-    // tape mode: the caller's recorded draws instead of this build's (same layout: draw_station_levels), decoded the same way
-    const uint64_t raw = sa.pk_tape ? sa.pk_tape[u] : draw_station_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick), t, kk, env);
-    ctx->st.pk[sa.tick & 1u][u] = dk_make(raw, pkd_line(ctx->st.rec[4u * (uint32_t) u + 3u]), hp.type[kk] == 0);
+    // tape mode: the caller's recorded draws instead of this build's (the 64-bit layout above), decoded the same way
+    const int line_now = pkd_line(ctx->st.rec[4u * (uint32_t) u + 3u]);
+    ctx->st.pk[sa.tick & 1u][u] = sa.pk_tape ? dk_make(sa.pk_tape[u], line_now, hp.type[kk] == 0)
+                                             : draw_decoded_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick), t, kk, env, line_now, hp.type[kk] == 0);
 }
 
 // ------------------------------------------------------------------------------------- launchers
@@ -2393,20 +2403,26 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             pa.env_mask = (CHUB_G(const uint8_t)) sa.env_mask;
             pa.tail_act = (CHUB_G(float)) pp.st->tail_act;
             const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
+#define CHUB_PACKED1(TAPE_, RESET_, BIG_, MASKED_) \
+    CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, TAPE_, RESET_, BIG_, MASKED_>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa)
 #define CHUB_PACKED(TAPE_, RESET_, BIG_) \
-    CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, TAPE_, RESET_, BIG_>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa)
+    do {                                                              \
+        if (sa.env_mask) CHUB_PACKED1(TAPE_, RESET_, BIG_, true);     \
+        else CHUB_PACKED1(TAPE_, RESET_, BIG_, false);                \
+    } while (0)
             const bool big = hp.S[0] > 64 || hp.S[1] > 64;
             if (reset) {
                 if (big) CHUB_PACKED(false, true, true);
                 else CHUB_PACKED(false, true, false);
             } else if (sa.car_tape) {
-                CHUB_PACKED(true, false, false);
+                CHUB_PACKED1(true, false, false, false);  // tape mode runs in lock-step
             } else if (big) {
                 CHUB_PACKED(false, false, true);
             } else {
                 CHUB_PACKED(false, false, false);
             }
 #undef CHUB_PACKED
+#undef CHUB_PACKED1
         } else if (reset) launch_slot_t<true, MODE_PHILOX>(hp, ctx, sa, stream, ev0, ev1);
         else launch_slot_t<false, MODE_PHILOX>(hp, ctx, sa, stream, ev0, ev1);
         return;
