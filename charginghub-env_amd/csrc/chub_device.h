@@ -43,6 +43,7 @@ constexpr int kSlotsPerLane = CHUB_SLOTS_PER_LANE;  // packed slot kernel: slots
 constexpr int kClsRow = 32;        // PHILOX: entries (power, t_soc) per arrival-SoC class = car_steps a car can take (stay_time <= 27 here)
 constexpr int kTapeClasses = 8192; // PHILOX: room for caller-registered arrival-SoC classes (tape mode)
 constexpr int kTelemCount = 24;
+constexpr int kFusedMaxBlocks = 1024;  // PHILOX lock-step steps of at most this many slot workgroups run as ONE launch (k_step_fused)
 
 // Philox draw sites (counter word 1 = site << 16 | index)
 enum Site : uint32_t {

@@ -1096,11 +1096,19 @@ __device__ __forceinline__ uint32_t sload_u32(const void *p, int i) { return ((c
 #ifndef CHUB_EPI_ALL
 #define CHUB_EPI_ALL 1  // 1: every wave of the workgroup takes its share of the new cars (a third barrier: -0.2 us at C4); 0: the last wave alone
 #endif
-// MASKED: per-env clocks (the launch serves the envs of a mask); the lock-step instantiation carries none of it
-template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED>
-__device__ __forceinline__ void slot_body_packed(const HubParams &hp, const StepArgs &sa, PackedArgs &pa, const Tables &tb,
-                                                 const uint32_t block_local, uint32_t *q_cnt, uint32_t *q_new,
-                                                 uint64_t *s_ball, int *s_acc, uint32_t *s_unit) {
+// MASKED: per-env clocks (the launch serves the envs of a mask); the lock-step instantiation carries none of it.
+// FUSED (k_step_fused, small batches): the workgroup goes on after the station records -- the body then returns what this wave
+// does next (0: done; w + 1: wave w < last; WAVES: the last wave, which has written the records, also into s_rec), does not
+// hand the tail actions over through memory, and calls hook.prefetch() behind its first loads / hook.park() in front of its
+// first barrier (the tail's table rows travel with the slot loads).
+struct NoHook {
+    __device__ __forceinline__ void prefetch() {}
+    __device__ __forceinline__ void park() {}
+};
+template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED, bool FUSED, typename Hook>
+__device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepArgs &sa, PackedArgs &pa, const Tables &tb,
+                                                const uint32_t block_local, uint32_t *q_cnt, uint32_t *q_new,
+                                                uint64_t *s_ball, int *s_acc, uint32_t *s_unit, Hook &hook, u32x4 *s_rec) {
     // T slots per lane: virtual lane v = tid + j * BLOCK (j < T), virtual wave = wave + j * (BLOCK / 64).  All T slots' loads
     // are in flight together and the barriers are shared.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1155,6 +1163,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         asm volatile("" : "+s"(pa.key[0]), "+s"(pa.key[1]), "+s"(pa.gid0), "+s"(pa.tick), "+s"(pa.late[0]), "+s"(pa.late[1]), "+s"(pa.late[2]),
                           "+s"(pa.late[3]), "+s"(pa.late[4]), "+s"(pa.late[5]), "+s"(pa.late[6]), "+s"(pa.late[7]));
     }
+    if (FUSED) hook.prefetch();
     if (tid == 0) q_cnt[0] = 0;
     for (int i = tid; i < (BIG ? 16 : 8) * epb; i += BLOCK) s_acc[i] = 0;
     long long *s_acc64 = (long long *) s_acc;  // BIG: {min, charge, max power, cars} as four 64-bit sums per unit
@@ -1185,6 +1194,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         be[j] = __ballot(empty[j]);
         if (lane == 0) s_ball[wave + j * WAVES] = be[j];
     }
+    if (FUSED) hook.park();
     __syncthreads();
     int line[T], flow[T];
     bool adm[T];
@@ -1299,8 +1309,8 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
     // other waves are done (their wave slots go to the next workgroup instead of idling at a third barrier through the
     // Philox block and the dependent table read of the new cars).  RESET: about half of all slots get a car, so every wave
     // serves its share and the workgroup meets again in front of the records.
-    constexpr bool ALL = RESET || CHUB_EPI_ALL;  // every wave takes new cars
-    if (!ALL && wave != WAVES - 1) return;
+    constexpr bool ALL = RESET || CHUB_EPI_ALL || FUSED;  // every wave takes new cars
+    if (!ALL && wave != WAVES - 1) return 0;
     // ---- add_car (CHS.hpp:864-877 / 1029-1042) for the workgroup's new cars, one lane per car
     const uint32_t n_adm = q_cnt[0];
     for (uint32_t i = (uint32_t) (ALL ? tid : lane); i < n_adm; i += (ALL ? BLOCK : 64)) {
@@ -1351,7 +1361,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
     }
     if (ALL) {
         __syncthreads();
-        if (wave != WAVES - 1) return;
+        if (wave != WAVES - 1) return FUSED ? wave + 1 : 0;
     }
     // the wave's own LDS atomics above are in program order with the reads below; nothing else touches s_acc any more
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1363,7 +1373,7 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
         if (env >= N) continue;
         if (MASKED && pa.env_mask[env] == 0) continue;
         const uint32_t su = (uint32_t) (k ? N : 0) + (uint32_t) env;
-        if (!RESET && k == 0) {  // the env's tail actions sit in the lines this workgroup has just read: hand them to the tail kernel packed
+        if (!RESET && !FUSED && k == 0) {  // the env's tail actions sit in the lines this workgroup has just read: hand them to the tail kernel packed
             typedef float f32x2_ __attribute__((ext_vector_type(2)));
             const uint32_t ai = ((uint32_t) env * (uint32_t) (St + 2) + (uint32_t) St) << 2;
             const f32x2_ tv = {CHUB_AT(const float, pa.actions, ai), CHUB_AT(const float, pa.actions, ai + 4u)};
@@ -1400,8 +1410,10 @@ __device__ __forceinline__ void slot_body_packed(const HubParams &hp, const Step
                        __float_as_uint((float) a64[2] * (1.0f / 524288.0f)), lf | ((uint32_t) a64[3] << 16)};
         }
         CHUB_AT(u32x4, pa.rec, su << 4) = rv;
+        if (FUSED) s_rec[i] = rv;
     }
 #undef CHUB_AT
+    return FUSED ? WAVES : 0;
 }
 
 template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED>
@@ -1417,7 +1429,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_sl
     PackedArgs pa = pa_in;
     asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
                       "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
-    slot_body_packed<BLOCK, T, TAPE, RESET, BIG, MASKED>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new, s_ball + 1, s_acc, s_unit);
+    NoHook hook;
+    (void) slot_body_packed<BLOCK, T, TAPE, RESET, BIG, MASKED, false, NoHook>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new, s_ball + 1, s_acc,
+                                                                               s_unit, hook, nullptr);
 }
 
 // What the tail's first loads need, by value in the kernel arguments: one scalar load at the start of the wave instead
@@ -1562,10 +1576,14 @@ constexpr int kEnvBlock = 256;  // compile-time (reading blockDim.x fetches the 
 
 // ---- the per-env tail of step() / reset() for one env per lane: the body of k_env (tables staged in LDS between the
 // load burst and the arithmetic).
-template <bool RESET, int MODE, bool MULTI>
+// FUSED (k_step_fused): one WAVE runs the tails of up to 64 envs of its workgroup right behind their station records: the table rows
+// are already in LDS (the caller's), the two records come from LDS (s_rec, [2 * local env + station]), `row` = the lane's place
+// among the wave's output rows, env0 = the env of row 0, and the only synchronisation is the wave's own.
+template <bool RESET, int MODE, bool MULTI, bool FUSED = false>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_pv_now, const double *s_wd_now,
-                                         const double *s_hy, const uint8_t *s_hv, float *s_out, const int env_block, const TailArgs &ta) {
+                                         const double *s_hy, const uint8_t *s_hv, float *s_out, const int env_block, const TailArgs &ta,
+                                         const u32x4 *s_rec = nullptr, const int local_env = 0, const int env0_fused = 0, const int rows_fused = 0) {
     const HubParams &hp = ctx->hp;
     const EnvArrays &ev = ctx->ev;
     const CompatRng &cr = ctx->cr;
@@ -1598,7 +1616,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     uint32_t st_hv = 0;
     const double sin_t = multi ? tb.sin96[t_next] : ta.sin_t;  // the observation's time feature
     const bool tel_on = hp.telemetry != 0;
-    {
+    if (!FUSED) {
         const int i = threadIdx.x;
         if (!multi) {  // lock-step: the rows of the launch's slot of the day
             if (i < 100) st_pv = ta.pv_row[i];
@@ -1626,7 +1644,11 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         ou_wd = ta.ou[n32 + e32];
         ou_price = ta.ou[2u * n32 + e32];
         in_price_noise = ta.price_noise[e32];
-        {
+        if (FUSED) {  // the records this workgroup has just written, from LDS
+            const u32x4 v0 = s_rec[2 * local_env], v1 = s_rec[2 * local_env + 1];
+            mn0 = __uint_as_float(v0.x); P0f = __uint_as_float(v0.y); mx0 = __uint_as_float(v0.z); ln0 = pkd_line(v0.w); F0i = pkd_flow(v0.w);
+            mn1 = __uint_as_float(v1.x); P1f = __uint_as_float(v1.y); mx1 = __uint_as_float(v1.z); ln1 = pkd_line(v1.w); F1i = pkd_flow(v1.w);
+        } else {
             const StationRec r0 = rec_load(ta.rec, e32), r1 = rec_load(ta.rec, n32 + e32);
             mn0 = r0.mn; P0f = r0.chg; mx0 = r0.mx; ln0 = pkd_line(r0.pkd); F0i = pkd_flow(r0.pkd);
             mn1 = r1.mn; P1f = r1.chg; mx1 = r1.mx; ln1 = pkd_line(r1.pkd); F1i = pkd_flow(r1.pkd);
@@ -1671,7 +1693,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     }
 
 
-    {
+    if (!FUSED) {
         // the table rows requested at the top arrive with the state loads; park them in LDS
         static_assert(kEnvBlock >= 150, "one table element per lane");
         const int i = threadIdx.x;
@@ -1695,6 +1717,17 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     // contiguous run of memory) with coalesced stores instead of 15 scattered 4-byte stores per lane
     const int row_w = sa.obs_stride;  // D (dense) or D + 2 (packed: obs, reward, done)
     auto flush_rows = [&]() {
+        if (FUSED) {  // the wave's own rows: wave-level synchronisation only
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float *dst = sa.obs + (size_t) env0_fused * (size_t) row_w;
+            const int total = rows_fused * row_w;
+            for (int i = (int) (threadIdx.x & 63u); i < total; i += 64) dst[i] = s_out[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // s_out is reused by the wave's next group of envs
+            return;
+        }
         __syncthreads();
         const int env0 = env_block * kEnvBlock;
         const int rows = (int) N - env0 < kEnvBlock ? (int) N - env0 : kEnvBlock;
@@ -1999,7 +2032,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     if (MODE == MODE_COMPAT && !RESET) rs.store(cr, env);
 
     // state_norm (MGR:318-342), written straight to the output row
-    float *obs = s_out + (int) threadIdx.x * row_w;
+    float *obs = s_out + (FUSED ? (int) (threadIdx.x & 63u) : (int) threadIdx.x) * row_w;
     double *o64 = tel_on ? (double *) ev.obs64 + (size_t) e32 * hp.obs_dim : nullptr;
     int n = 0;
 #define CHUB_OBS(v)                    \
@@ -2057,7 +2090,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 
 // Next step's state-independent draws, lane u: [0, 2N) the station-level variates of unit u, [2N, 3N) the per-env draws
 template <bool RESET, bool MULTI>
-__device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int64_t u) {
+__device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int64_t u, const int line_known = -1) {
     const HubParams &hp = ctx->hp;
     const int64_t N = hp.n_envs;
     if (u >= 3 * N) return;
@@ -2068,7 +2101,7 @@ __device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, cons
     if (u < 2 * N) {
         const int kk = u >= N ? 1 : 0;
         // drawn AND decoded here, against the queue the slot kernel of this launch has just left in the unit's record
-        const int line_now = pkd_line(ctx->st.rec[4u * (uint32_t) u + 3u]);
+        const int line_now = line_known >= 0 ? line_known : pkd_line(ctx->st.rec[4u * (uint32_t) u + 3u]);
         ctx->st.pk[(sa.tick + 1u) & 1u][u] = draw_decoded_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick + 1u), t_next, kk, u - (int64_t) kk * N,
                                                                  line_now, hp.type[kk] == 0);
     } else {
@@ -2108,6 +2141,96 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
     env_tail<RESET, MODE, MULTI>(ctx, sa, env, env < (int) ta.n_envs && (!MULTI || in_group(sa, env)), s_pv, s_wd, s_pv_now, s_wd_now, s_hy,
                                  s_hv, s_out, (int) blockIdx.x, ta);
+}
+
+// ---------------------------------------------------------------------------------------- k_step_fused: the whole step in ONE launch
+// Small batches (C2: 4096 envs; every shard of an 8-GPU strong-scaling run): both step kernels are launch- and latency-bound
+// there -- a handful of waves per CU, 4-5 us each of which 1.7 us is the kernel boundary -- and the chip has room for every
+// workgroup at once, which is what made the fused form lose at 65 536 envs (lingering tail waves taking wave slots from the
+// memory-bound slot work).  So: the packed slot body as it is, and behind the station records the workgroup goes on by itself --
+//   last wave:  the per-env tails of the workgroup's envs (env_tail, records from LDS, table rows prefetched with the slot loads)
+//   wave 0:     next step's station-level draws of the workgroup's units, decoded against the queue lengths just computed
+//   wave 1:     next step's per-env draws
+// Same functions, same Philox counters, same operations as k_slot_packed + k_env: bit-identical results
+// (tests: chub_options.fused_step forced on / off).  PHILOX, lock-step, stations of up to 64 piles.
+struct TailPrefetch {
+    const TailArgs &ta;
+    double *s_pv, *s_wd, *s_pv_now, *s_wd_now, *s_hy;
+    double r_pv, r_wd, r_pv_now, r_wd_now, r_hy;
+    __device__ __forceinline__ void prefetch() {
+        const int i = threadIdx.x;
+        r_pv = r_wd = r_pv_now = r_wd_now = r_hy = 0.0;
+        if (i < 100) {
+            r_pv = ta.pv_row[i];
+            r_pv_now = ta.pv_row_now[i];
+        }
+        if (i < 150) {
+            r_wd = ta.wd_row[i];
+            r_wd_now = ta.wd_row_now[i];
+        }
+        if (i < 102) r_hy = ta.hy_table[i];
+    }
+    __device__ __forceinline__ void park() {
+        const int i = threadIdx.x;
+        if (i < 100) {
+            s_pv[i] = r_pv;
+            s_pv_now[i] = r_pv_now;
+        }
+        if (i < 150) {
+            s_wd[i] = r_wd;
+            s_wd_now[i] = r_wd_now;
+        }
+        if (i < 102) s_hy[i] = r_hy;
+    }
+};
+
+template <int BLOCK, int T>
+__global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in, TailArgs ta) {
+    static_assert(BLOCK >= 150 && BLOCK / 64 >= 3, "one table element per lane; three waves with work of their own");
+    __shared__ uint32_t q_new[BLOCK * T];
+    __shared__ uint32_t q_cnt[2];
+    __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];
+    __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T];
+    __shared__ uint32_t s_unit[BLOCK * T / 2];
+    __shared__ __attribute__((aligned(16))) u32x4 s_rec[BLOCK * T / 2];
+    __shared__ double s_pv[100], s_wd[150], s_pv_now[100], s_wd_now[150], s_hy[102];
+    __shared__ __attribute__((aligned(16))) float s_out[64 * 16];
+    PackedArgs pa = pa_in;
+    asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
+                      "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
+    TailPrefetch hook{ta, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const int role = slot_body_packed<BLOCK, T, false, false, false, false, true, TailPrefetch>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
+                                                                                                s_ball + 1, s_acc, s_unit, hook, s_rec);
+    constexpr int WAVES = BLOCK / 64;
+    const int lane = threadIdx.x & 63;
+    const int epb = (int) pa.epb, N = (int) pa.n_envs, env_first = (int) blockIdx.x * epb;
+    if (role == 1) {
+        // next step's station-level draws of this workgroup's units, against the queue lengths the main pass left in s_unit
+        for (int i = lane; i < 2 * epb; i += 64) {
+            const int e = i >> 1, k = i & 1, env = env_first + e;
+            if (env >= N) continue;
+            int line;
+            if ((k ? pa.S[1] : pa.S[0]) == 0u) {  // a station without piles: its queue moves on as in the body's record pass
+                const int want = dk_want(pa.pk[(uint32_t) (k ? N : 0) + (uint32_t) env]);
+                line = want < kMaxLine ? want : kMaxLine;
+            } else {
+                line = pkd_line(s_unit[i]);
+            }
+            level_block<false, false>(ctx, sa, (int64_t) k * N + env, line);
+        }
+    } else if (role == 2) {
+        for (int i = lane; i < epb; i += 64)
+            if (env_first + i < N) level_block<false, false>(ctx, sa, 2 * (int64_t) N + env_first + i);
+    } else if (role == WAVES) {
+        for (int c = 0; c < epb; c += 64) {  // the workgroup's envs, 64 at a time (the wave's own LDS traffic: wave-level synchronisation)
+            const int le = c + lane, env = env_first + le;
+            const bool live = le < epb && env < N;
+            int rows = epb - c < 64 ? epb - c : 64;
+            rows = N - (env_first + c) < rows ? N - (env_first + c) : rows;
+            env_tail<false, MODE_PHILOX, false, true>(ctx, sa, env, live, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, nullptr, s_out, 0, ta, s_rec,
+                                                      live ? le : 0, env_first + c, rows > 0 ? rows : 0);
+        }
+    }
 }
 
 // COMPAT only: HySystem.__init__ (HYD:154-158) builds hy_power_speed_list with 101 REAL hy_step()s from the initial tank:
@@ -2370,6 +2493,8 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
     }
 }
 
+static PackedArgs make_packed_args(const HubParams &hp, const StepArgs &sa, const PackedPtrs &pp);
+
 void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
                  const PackedPtrs &pp, hipEvent_t ev0, hipEvent_t ev1) {
     if (hp.rng_mode == MODE_PHILOX && !reset && (sa.fresh || sa.pk_tape))
@@ -2378,30 +2503,7 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
         if (hp.packed && !sa.load_mode) {
             if (reset)
                 hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((8 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
-            PackedArgs pa;
-            for (int k = 0; k < 2; k++) {
-                pa.S[k] = (uint32_t) hp.S[k];
-                pa.type[k] = (uint32_t) hp.type[k];
-            }
-            pa.n_envs = (uint32_t) hp.n_envs;
-            pa.epb = (uint32_t) hp.epb;
-            pa.magic = (1u << 20) / (uint32_t) (hp.S[0] + hp.S[1]) + 1u;
-            pa.cls_delta = (uint32_t) ((const char *) pp.cls[1] - (const char *) pp.cls[0]);
-            pa.state = (CHUB_G(uint32_t)) pp.hot;
-            pa.rec = (CHUB_G(uint32_t)) pp.rec;
-            pa.pk = (CHUB_G(const uint32_t)) pp.pk[sa.tick & 1u];
-            pa.actions = (CHUB_G(const float)) sa.actions;
-            pa.cls0 = (CHUB_G(const float)) pp.cls[0];
-            pa.ttab2 = (CHUB_G(const float)) pp.ttab2;
-            pa.car_tape = (CHUB_G(const uint32_t)) sa.car_tape;
-            pa.key[0] = hp.key[0];
-            pa.key[1] = hp.key[1];
-            pa.gid0 = (uint32_t) hp.env_id0;
-            pa.tick = sa.tick;
-            pa.tick_base = hp.tick_base;
-            for (int j = 0; j < 8; j++) pa.late[j] = pp.late8[j];
-            pa.env_mask = (CHUB_G(const uint8_t)) sa.env_mask;
-            pa.tail_act = (CHUB_G(float)) pp.st->tail_act;
+            const PackedArgs pa = make_packed_args(hp, sa, pp);
             const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
 #define CHUB_PACKED1(TAPE_, RESET_, BIG_, MASKED_) \
     CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, TAPE_, RESET_, BIG_, MASKED_>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa)
@@ -2429,6 +2531,45 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
     }
     if (reset) launch_slot_t<true, MODE_COMPAT>(hp, ctx, sa, stream, ev0, ev1);
     else launch_slot_t<false, MODE_COMPAT>(hp, ctx, sa, stream, ev0, ev1);
+}
+
+static PackedArgs make_packed_args(const HubParams &hp, const StepArgs &sa, const PackedPtrs &pp) {
+    PackedArgs pa;
+    for (int k = 0; k < 2; k++) {
+        pa.S[k] = (uint32_t) hp.S[k];
+        pa.type[k] = (uint32_t) hp.type[k];
+    }
+    pa.n_envs = (uint32_t) hp.n_envs;
+    pa.epb = (uint32_t) hp.epb;
+    pa.magic = (1u << 20) / (uint32_t) (hp.S[0] + hp.S[1]) + 1u;
+    pa.cls_delta = (uint32_t) ((const char *) pp.cls[1] - (const char *) pp.cls[0]);
+    pa.state = (CHUB_G(uint32_t)) pp.hot;
+    pa.rec = (CHUB_G(uint32_t)) pp.rec;
+    pa.pk = (CHUB_G(const uint32_t)) pp.pk[sa.tick & 1u];
+    pa.actions = (CHUB_G(const float)) sa.actions;
+    pa.cls0 = (CHUB_G(const float)) pp.cls[0];
+    pa.ttab2 = (CHUB_G(const float)) pp.ttab2;
+    pa.car_tape = (CHUB_G(const uint32_t)) sa.car_tape;
+    pa.key[0] = hp.key[0];
+    pa.key[1] = hp.key[1];
+    pa.gid0 = (uint32_t) hp.env_id0;
+    pa.tick = sa.tick;
+    pa.tick_base = hp.tick_base;
+    for (int j = 0; j < 8; j++) pa.late[j] = pp.late8[j];
+    pa.env_mask = (CHUB_G(const uint8_t)) sa.env_mask;
+    pa.tail_act = (CHUB_G(float)) pp.st->tail_act;
+    return pa;
+}
+
+// the whole PHILOX lock-step step as ONE launch (k_step_fused): the caller has checked that the hub shape and the call allow it
+void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp, hipEvent_t ev0,
+                       hipEvent_t ev1) {
+    if (sa.fresh) hipLaunchKernelGGL(k_draw_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
+    const PackedArgs pa = make_packed_args(hp, sa, pp);
+    TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa, pp, false);
+    ta.tail_act = nullptr;  // the tails read their two actions from the action rows (the workgroup has just had them in cache)
+    const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
+    CHUB_LAUNCH((k_step_fused<kPackedBlock, kSlotsPerLane>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa, ta);
 }
 
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,

@@ -27,6 +27,8 @@ void launch_compat_ctor_sweep(const HubParams &hp, const DevCtx *ctx, hipStream_
 void launch_tick_advance(uint32_t *tick_base, uint32_t by, hipStream_t stream);
 void launch_fill_clocks(uint16_t *dst, int64_t n, uint16_t value, hipStream_t stream);
 void launch_expand_bits(const HubParams &hp, const uint64_t *d_bits, const float *d_tail, float *d_actions, hipStream_t stream);
+void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp, hipEvent_t ev0,
+                       hipEvent_t ev1);
 }  // namespace chub
 
 using namespace chub;
@@ -56,6 +58,7 @@ struct chub_env {
     CompatRng cr;
     Tables tb;
     int device;
+    bool fused;         // PHILOX lock-step steps of this handle run as ONE launch (k_step_fused): small batches
     DevCtx *d_ctx;      // device copy of {hp, sl, st, ev, cr, tb}
     bool ctx_dirty;
     // lock-step clock (MGR:137-140,299; CHS.hpp:1204; AGG:150-151; HYD:192-193 are three copies of it)
@@ -355,6 +358,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     memset(&opt, 0, sizeof opt);
     if (opt_in) opt = *opt_in;
     if (opt.slot_kernel < 0 || opt.slot_kernel > 2) return fail(CHUB_ERR_ARG, "chub_options.slot_kernel must be 0, 1 or 2");
+    if (opt.fused_step < 0 || opt.fused_step > 2) return fail(CHUB_ERR_ARG, "chub_options.fused_step must be 0, 1 or 2");
     *out = nullptr;
     if (n_envs <= 0) return fail(CHUB_ERR_ARG, "n_envs must be positive");
     if (n_envs * (int64_t) (cfg->station_list[0] + cfg->station_list[1] + 2) >= (int64_t) 1 << 31)
@@ -682,6 +686,14 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
                      (uint64_t) n_envs * (uint64_t) (St + 2) * 16u < ((uint64_t) 1 << 32) &&  // 32-bit byte offsets
                      opt.slot_kernel != 1) ? 1 : 0;
     }
+    {   // the whole step as one launch: where the two kernels are launch- and latency-bound and every workgroup finds room at once
+        const int64_t nb = (n_envs + hp.epb - 1) / hp.epb;
+        const bool can = hp.packed && hp.S[0] <= 64 && hp.S[1] <= 64;
+        e->fused = can && (opt.fused_step == 2 || (opt.fused_step == 0 && nb <= kFusedMaxBlocks));
+        if (opt.fused_step == 2 && !can)
+            return bail(fail(CHUB_ERR_UNSUPPORTED, "fused_step = 2: the single-launch step covers PHILOX handles on the packed slot kernel with "
+                                                   "stations of at most 64 piles"));
+    }
     build_hy_table(hp, e->hy_table);
     std::vector<double> hy_v(e->hy_table, e->hy_table + 102);
 
@@ -820,6 +832,7 @@ int chub_clock(const chub_env *e) {  // lock-step: the clock; per-env clocks: en
     return (int) (c & 127u);
 }
 int chub_uses_packed_kernel(const chub_env *e) { return e ? e->hp.packed : CHUB_ERR_ARG; }
+int chub_uses_fused_step(const chub_env *e) { return e ? (e->fused ? 1 : 0) : CHUB_ERR_ARG; }
 
 int chub_sync(chub_env *e) {
     if (!e) return fail(CHUB_ERR_ARG, "null handle");
@@ -1052,8 +1065,16 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     }
     // four events per profiled step: start / stop of the slot kernel, start / stop of the tail kernel
     hipEvent_t *pe = prof ? &e->prof_events[4 * e->prof_used] : nullptr;
-    launch_slot(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e), prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
-    launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
+    if (e->fused && !load_mode && !e->per_env && !sa.car_tape && !sa.pk_tape) {
+        launch_step_fused(e->hp, e->d_ctx, sa, s, packed_ptrs(e), prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
+        if (prof) {  // one kernel: the whole step is on the first pair of timestamps, the second pair spans nothing
+            HIP_TRY(hipEventRecord(pe[2], s));
+            HIP_TRY(hipEventRecord(pe[3], s));
+        }
+    } else {
+        launch_slot(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e), prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
+        launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
+    }
     if (prof) e->prof_used++;
     HIP_TRY(hipGetLastError());
     e->predrawn = served == 2;

@@ -46,7 +46,7 @@ def _ptr(a):
 
 class VecChargingHub(object):
     def __init__(self, n_envs, station_list, station_type_list, seed=0, rng="philox", device=0, env_id0=0,
-                 data_dir=None, slot_kernel="auto", no_arena=False, copy_outputs=True, **kwargs):
+                 data_dir=None, slot_kernel="auto", no_arena=False, copy_outputs=True, fused_step="auto", **kwargs):
         """slot_kernel: "auto" (the packed slot kernel wherever the hub shape allows), "wave" (the wave-local one for
         every step) or "packed"; no_arena: one device allocation per array (no snapshots) -- chub_options.
         copy_outputs=False: reset() / step() return the handle's own pinned arrays (valid until the next call) instead of
@@ -63,6 +63,7 @@ class VecChargingHub(object):
         opt = ChubOptions()
         opt.slot_kernel = _lib.SLOT_KERNELS[slot_kernel]
         opt.no_arena = int(bool(no_arena))
+        opt.fused_step = _lib.FUSED_STEP[fused_step]  # "auto": one launch per step for small batches; "off" / "on" (parity cross-check)
         self._copy_outputs = bool(copy_outputs)
         check(self._lib.chub_create_ex(C.byref(self.cfg), (data_dir or _lib.DATA_DIR).encode(), self.n_envs, int(env_id0),
                                        int(device), int(seed) & 0xFFFFFFFFFFFFFFFF, self.rng_mode, C.byref(opt), C.byref(h)))
@@ -292,6 +293,10 @@ class VecChargingHub(object):
     @property
     def uses_packed_kernel(self):
         return bool(self._lib.chub_uses_packed_kernel(self._h))
+
+    @property
+    def uses_fused_step(self):
+        return bool(self._lib.chub_uses_fused_step(self._h))
 
     @property
     def clock(self):

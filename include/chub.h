@@ -71,7 +71,10 @@ typedef struct chub_options {
     int32_t slot_kernel;  /* PHILOX steps: 0 = the packed slot kernel wherever the hub shape allows (default),
                              1 = the wave-local slot kernel for every step, 2 = same as 0 (kept for tests that name it) */
     int32_t no_arena;     /* 1: one hipMalloc per array instead of one arena (disables chub_get_state / chub_set_state) */
-    int32_t reserved[6];
+    int32_t fused_step;   /* PHILOX lock-step steps as ONE launch (slot work + per-env tail + next step's draws per workgroup):
+                             0 = for small batches, where the two step kernels are launch-bound (default), 1 = never, 2 = always
+                             (hub shapes the packed slot kernel covers, stations of at most 64 piles).  Results are bit-identical. */
+    int32_t reserved[5];
 } chub_options;
 
 /* telemetry column indices of chub_get_telemetry (names of the reference attributes, MGR:183-297) */
@@ -100,6 +103,7 @@ int chub_act_dim(const chub_env *env);  /* S + 2 (MGR:108-113) */
 int64_t chub_num_envs(const chub_env *env);
 int chub_clock(const chub_env *env);    /* 0..95: the slot of day, shared by all envs while they run in lock-step (env 0's otherwise) */
 int chub_uses_packed_kernel(const chub_env *env); /* 1: PHILOX steps of this handle run k_slot_packed (the production kernel) */
+int chub_uses_fused_step(const chub_env *env);    /* 1: its lock-step steps run as one launch (k_step_fused, small batches) */
 
 /* ---- hot path ------------------------------------------------------------------------------
  * chub_reset replaces EvcsspManagerEnv_v6.reset (MGR:304-316 -> AGG:157-175 evs_reset main.cpp:199,251,

@@ -171,6 +171,70 @@ def test_philox_other_slot_kernel(label, kernel):
     _philox_parity(label + "_" + kernel, kw, n, plan=(96, 30), slot_kernel=kernel)
 
 
+@pytest.mark.parametrize("label", ["c2", "c3", "c5", "ragged", "max64", "constant", "fcev_stuck", "small_fast"])
+@pytest.mark.parametrize("fused", ["on", "off"])
+def test_philox_single_launch_step(label, fused):
+    """PHILOX lock-step steps have two launch forms -- slot kernel + tail kernel, and ONE launch in which every workgroup also
+    runs the tails of its envs and draws their next step (k_step_fused: the default for small batches): force each one
+    (chub_options.fused_step) through the same parity check against the oracle"""
+    kw, n = next((c[1], c[2]) for c in PHILOX_CASES if c[0] == label)
+    _philox_parity(label + "_fused_" + fused, kw, n, plan=(96, 20), fused_step=fused)
+
+
+def test_single_launch_step_is_bit_identical_and_replays_in_graphs():
+    """the two launch forms of the step against each other over whole episodes (packed outputs bit for bit), the fused form also
+    as hipGraph replays; a handle too large for the default does not pick it"""
+    chub = hub()
+    from charginghub_env_amd import multi_gpu
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.02, renew_fluctuate=0.2, price_fluctuate=0.1)
+    n = 2000
+    res = {}
+    for form in ("off", "on", "graph"):
+        v = chub.VecChargingHub(n, seed=4, fused_step="off" if form == "off" else "on", **kw)
+        st = multi_gpu.Stream(0)
+        acts = [multi_gpu.DeviceBuffer(n * v.act_dim * 4) for _ in range(4)]
+        for b, a in enumerate(acts):
+            v.random_actions_device(a.ptr, 77, b, st.ptr)
+        packed = [multi_gpu.DeviceBuffer(n * (v.obs_dim + 2) * 4) for _ in range(2)]
+        obs0 = multi_gpu.DeviceBuffer(n * v.obs_dim * 4)
+
+        def steps(first, count):
+            for i in range(first, first + count):
+                if i % 96 == 0:
+                    v.reset_device(obs0.ptr, stream=st.ptr)
+                v.step_device_packed(acts[i % 4].ptr, packed[i & 1].ptr, stream=st.ptr)
+
+        trace = []
+        if form == "graph":
+            st.sync()
+            v.graph_begin(st.ptr)
+            steps(0, 192)
+            g = v.graph_end(st.ptr)
+            for _ in range(2):
+                v.graph_launch(g, st.ptr)
+                trace.append(packed[1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr))
+            v.graph_destroy(g)
+        else:
+            for rep in range(2):
+                steps(0, 192)
+                trace.append(packed[1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr))
+        steps(0, 7)
+        trace.append(packed[0].to_host(np.float32, (n, v.obs_dim + 2), st.ptr))
+        trace += [np.concatenate([x.reshape(n, -1) for x in v.slots()], axis=1), v.station_scalars().reshape(n, -1)]
+        res[form] = trace
+        v.close()
+        st.destroy()
+    for k in range(len(res["off"])):
+        assert np.array_equal(res["off"][k], res["on"][k]), ("fused vs two launches", k)
+        assert np.array_equal(res["off"][k], res["graph"][k]), ("fused in a graph vs two launches", k)
+    small = chub.VecChargingHub(4096, seed=1, station_list=[16, 0], station_type_list=["fast", "slow"], fcev_permeate=0.0)
+    large = chub.VecChargingHub(65536, seed=1, **kw)
+    assert small.uses_fused_step and not large.uses_fused_step
+    small.close()
+    large.close()
+
+
 @pytest.mark.parametrize("piles,types", [((4, 5), ("fast", "slow")), ((7, 13), ("slow", "fast")), ((33, 45), ("fast", "slow")),
                                          ((63, 64), ("slow", "fast")), ((5, 64), ("fast", "fast")), ((21, 4), ("slow", "slow")),
                                          ((10, 6), ("fast", "slow"))])
@@ -198,13 +262,15 @@ def test_philox_user_series(tmp_path):
     _philox_parity("user_series", kw, 96, data_dir=d, tables=tables, plan=[96, 20])
 
 
-def _philox_parity(label, kw, n, data_dir=None, tables=None, plan=(96, 96, 10, 30), slot_kernel="auto"):
+def _philox_parity(label, kw, n, data_dir=None, tables=None, plan=(96, 96, 10, 30), slot_kernel="auto", fused_step="auto"):
     chub = hub()
     kw = dict(kw)
     for k, d in (("constant_charging", False), ("renew_fluctuate", 0.0), ("price_fluctuate", 0.0), ("hydro_loss", 0.0)):
         kw.setdefault(k, d)
     seed, env_id0 = 0xC0FFEE12345, 1000
-    v = chub.VecChargingHub(n, seed=seed, rng="philox", env_id0=env_id0, data_dir=data_dir, slot_kernel=slot_kernel, **kw)
+    v = chub.VecChargingHub(n, seed=seed, rng="philox", env_id0=env_id0, data_dir=data_dir, slot_kernel=slot_kernel, fused_step=fused_step, **kw)
+    if fused_step != "auto":
+        assert v.uses_fused_step == (fused_step == "on")
     v.set_telemetry(True)
     cfg, h = _oracle_vec(kw, n, env_id0, seed, tables)
     D, A = v.obs_dim, v.act_dim

@@ -1,8 +1,8 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/all_configs.sh <tag> -- bench.py on every BASELINE.json config that fits one GPU,
-# one JSON line each, into gpurun_out/round2_<tag>_all_configs_1gpu.json (copy into profiles/ afterwards)
+# one JSON line each, into gpurun_out/round3_<tag>_all_configs_1gpu.json (copy into profiles/ afterwards)
 TAG=${1:-vX}
-OUT=gpurun_out/round2_${TAG}_all_configs_1gpu.json
+OUT=gpurun_out/round3_${TAG}_all_configs_1gpu.json
 : > $OUT
 for c in c2 c3 c4 c5; do
   python3 bench.py --config $c --steps 1920 --warmup 384 --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT

@@ -8,12 +8,12 @@ TAG=${1:-vX}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python3 bench.py > $OUT/round2_${TAG}_bench.json 2> $OUT/bench.err
-echo "bench done"; tail -c 400 $OUT/round2_${TAG}_bench.json; echo
-rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/round2_${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
-cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/round2_${TAG}_kernel_stats.csv
+python3 bench.py > $OUT/round3_${TAG}_bench.json 2> $OUT/bench.err
+echo "bench done"; tail -c 400 $OUT/round3_${TAG}_bench.json; echo
+rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 > $OUT/round3_${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
+cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/round3_${TAG}_kernel_stats.csv
 echo "kernel trace done"
-ARGS="--steps 96 --warmup 96 --no-cpu-baseline --no-events"
+ARGS="--steps 192 --warmup 96 --no-cpu-baseline --no-events"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch --output-format csv -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write --output-format csv -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_write.err
@@ -23,6 +23,10 @@ echo "sq pass done"
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_tcc --output-format csv -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_tcc.err
 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum -d $OUT/pmc_tcp --output-format csv -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_tcp.err
 echo "cache passes done"
+# the same two traffic passes on the working set that does not fit the Infinity Cache (bench.py's roofline_c5 block)
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_c5 --output-format csv -- python3 bench.py --config c5 $ARGS > /dev/null 2> $OUT/pmc_fetch_c5.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_c5 --output-format csv -- python3 bench.py --config c5 $ARGS > /dev/null 2> $OUT/pmc_write_c5.err
+echo "c5 traffic passes done"
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, sys
 from collections import defaultdict
@@ -52,15 +56,25 @@ build_id = chub.load_library().chub_build_id().decode()
 FETCH_FACTOR, WRITE_FACTOR = 2.0, 1.0
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* / TCC_* / TCP_* (separate passes), mean per dispatch over the step kernels "
                "of bench.py --steps 96 at 65536 envs x [20,25]; KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950",
-       "build_id": build_id, "envs": 65536,
+       "build_id": build_id, "envs": 65536, "hub": [20, 25],
        "calibration": {"fetch_factor": FETCH_FACTOR, "write_factor": WRITE_FACTOR}}
-for label, key in (("k_slot", ("k_slot_packed<256, 2, false, false",)), ("k_env", ("k_env<false",))):
+KEYS = (("k_slot", ("k_slot_packed<256, 2, false, false",)), ("k_env", ("k_env<false",)))
+for label, key in KEYS:
     f, w = pick(fe, key).get("FETCH_SIZE", 0.0), pick(wr, key).get("WRITE_SIZE", 0.0)
     res[label] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                   "traffic_bytes_per_launch": (f * FETCH_FACTOR + w * WRITE_FACTOR) * 1024.0}
     res[label + "_sq_counters_per_dispatch"] = pick(sq, key)
-json.dump(res, open("%s/round2_%s_pmc_traffic.json" % (out, tag), "w"), indent=1)
+json.dump(res, open("%s/round3_%s_pmc_traffic.json" % (out, tag), "w"), indent=1)
 print(json.dumps(res["k_slot"]))
+fe5, wr5 = collect(out + "/pmc_fetch_c5"), collect(out + "/pmc_write_c5")
+res5 = {"note": "the same FETCH_SIZE / WRITE_SIZE passes on bench.py --config c5 (262144 envs x [32,32]: 134 MB of slot state, beyond the "
+                "256 MB Infinity Cache together with the action batches): what bench.py's roofline_c5.traffic reports",
+        "build_id": build_id, "envs": 262144, "hub": [32, 32], "calibration": res["calibration"]}
+for label, key in KEYS:
+    f, w = pick(fe5, key).get("FETCH_SIZE", 0.0), pick(wr5, key).get("WRITE_SIZE", 0.0)
+    res5[label] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes_per_launch": (f * FETCH_FACTOR + w * WRITE_FACTOR) * 1024.0}
+json.dump(res5, open("%s/round3_%s_pmc_traffic_c5.json" % (out, tag), "w"), indent=1)
+print(json.dumps(res5["k_slot"]))
 PY
-rm -rf $OUT/kt $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_tcc $OUT/pmc_tcp
+rm -rf $OUT/kt $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_tcc $OUT/pmc_tcp $OUT/pmc_fetch_c5 $OUT/pmc_write_c5
 ls $OUT
