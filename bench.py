@@ -300,6 +300,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the untimed profiled day (no `roofline` block)")
     ap.add_argument("--no-c5", action="store_true", help="skip the secondary roofline_c5 block")
+    ap.add_argument("--fused", choices=["auto", "on", "off"], default="auto",
+                    help="the step as ONE launch (k_step_fused); auto: the library's choice (small batches)")
     ap.add_argument("--dry-run", action="store_true",
                     help="stop every rank before libchub is loaded and print who it is (launch plumbing check, runs without a GPU)")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="(tests) with --dry-run: this rank exits with status 3")
@@ -350,8 +352,9 @@ def main():
     per_graph = 96 * GRAPH_EPISODES
 
     comm = multi_gpu.Comm(rank, world, local_rank) if use_comm else None
-    v = chub.VecChargingHub(per, seed=SEED, rng="philox", device=local_rank, env_id0=rank * per, **hub_kw)
+    v = chub.VecChargingHub(per, seed=SEED, rng="philox", device=local_rank, env_id0=rank * per, fused_step=args.fused, **hub_kw)
     D, A, S = v.obs_dim, v.act_dim, v.n_slots
+    v_fused = v.uses_fused_step
     stream = multi_gpu.Stream(local_rank)
     row = (D + 2) * 4
     actions = [multi_gpu.DeviceBuffer(per * A * 4, local_rank) for _ in range(N_ACTION_BATCHES)]
@@ -489,7 +492,14 @@ def main():
         slot_b, env_b = algorithmic_bytes(S, D)
         build_id = lib.chub_build_id().decode()
         roofline = None
-        if n_prof:
+        if n_prof and v_fused:  # ONE kernel does the whole step: it is priced with the whole step's bytes
+            achieved = (slot_b + env_b) * per / (slot_us * 1e-6) / 1e9
+            roofline = {"bound": "hbm", "kernel": "k_step_fused", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                        "algorithmic_bytes_per_launch": (slot_b + env_b) * per, "avg_launch_us": slot_us, "launches_sampled": n_prof,
+                        "window": "one whole untimed day (reset + slots 0..95) issued call by call after the timed region",
+                        "env_kernel_avg_launch_us": 0.0}
+        elif n_prof:
             traffic, traffic_src = measured_traffic(build_id, per, total, hub_kw["station_list"])
             roofline = roofline_block(slot_us, env_us, slot_b, env_b, per, traffic, traffic_src, n_prof,
                                       "one whole untimed day (reset + slots 0..95) issued call by call after the timed region")
@@ -512,6 +522,7 @@ def main():
                                    % (total, hub_kw["station_list"][0], hub_kw["station_list"][1],
                                       {"c4": "configs[3]", "c5": "configs[4]"}.get(config, config), hub_kw["fcev_permeate"]),
                        "envs_per_gpu": per, "obs_dim": D, "act_dim": A, "launch": launch,
+                       "kernels_per_step": "1 (k_step_fused)" if v_fused else "2 (k_slot_packed + k_env)",
                        "window": "timed: slot %d of day %d .. slot %d of day %d; roofline: a whole untimed day afterwards" % (s0, d0, s1, d1),
                        "host_issue_ms_per_step": t_issue / steps * 1e3,
                        "collective": "none" if not use_comm else

@@ -1576,6 +1576,35 @@ constexpr int kEnvBlock = 256;  // compile-time (reading blockDim.x fetches the 
 
 // ---- the per-env tail of step() / reset() for one env per lane: the body of k_env (tables staged in LDS between the
 // load burst and the arithmetic).
+// What the tail of one env reads of its own state (PHILOX step).  k_step_fused requests it for the last wave's envs together with
+// the wave's first slot loads, a whole slot pass ahead of its use.
+struct TailIn {
+    double ou_pv, ou_wd, ou_price, price_noise, cap;
+    float a_el, a_fc;
+    int pv_day, wd_day, q_len, hv_line;
+    u32x4 drw;
+    uint32_t drw_n;
+};
+__device__ __forceinline__ void tail_prefetch(TailIn &in, const TailArgs &ta, const uint32_t e32, const bool predrawn) {
+    const uint32_t n32 = ta.n_envs;
+    in.ou_pv = ta.ou[e32];
+    in.ou_wd = ta.ou[n32 + e32];
+    in.ou_price = ta.ou[2u * n32 + e32];
+    in.price_noise = ta.price_noise[e32];
+    const uint32_t ai = e32 * ta.act_dim + ta.s_tot;
+    in.a_el = ta.actions[ai];
+    in.a_fc = ta.actions[ai + 1u];
+    in.cap = ta.cap[e32];
+    in.pv_day = ta.pv_day[e32];
+    in.wd_day = ta.wd_day[e32];
+    in.q_len = ta.q_len[e32];
+    in.hv_line = ta.hv_line[e32];
+    if (predrawn) {
+        in.drw = ((CHUB_G(const u32x4)) ta.drw)[e32];
+        in.drw_n = ta.drw_cnt[e32];
+    }
+}
+
 // FUSED (k_step_fused): one WAVE runs the tails of up to 64 envs of its workgroup right behind their station records: the table rows
 // are already in LDS (the caller's), the two records come from LDS (s_rec, [2 * local env + station]), `row` = the lane's place
 // among the wave's output rows, env0 = the env of row 0, and the only synchronisation is the wave's own.
@@ -1583,7 +1612,8 @@ template <bool RESET, int MODE, bool MULTI, bool FUSED = false>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_pv_now, const double *s_wd_now,
                                          const double *s_hy, const uint8_t *s_hv, float *s_out, const int env_block, const TailArgs &ta,
-                                         const u32x4 *s_rec = nullptr, const int local_env = 0, const int env0_fused = 0, const int rows_fused = 0) {
+                                         const u32x4 *s_rec, const int local_env, const int env0_fused, const int rows_fused,
+                                         const TailIn &pre, const bool use_pre) {
     const HubParams &hp = ctx->hp;
     const EnvArrays &ev = ctx->ev;
     const CompatRng &cr = ctx->cr;
@@ -1639,11 +1669,16 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     int pv_day = 0, wd_day = 0, q_len = 0, hv_line = 0, F0i = 0, F1i = 0, ln0 = 0, ln1 = 0, hv_lev = 0, hv_arrive = 0;
     u32x4 drw_raw = {0u, 0u, 0u, 0u};
     uint32_t drw_n = 0u;
+    const bool have_pre = FUSED && use_pre;  // the env's own state came in ahead of time (tail_prefetch)
     if (live) {
-        ou_pv = ta.ou[e32];
-        ou_wd = ta.ou[n32 + e32];
-        ou_price = ta.ou[2u * n32 + e32];
-        in_price_noise = ta.price_noise[e32];
+        if (have_pre) {
+            ou_pv = pre.ou_pv; ou_wd = pre.ou_wd; ou_price = pre.ou_price; in_price_noise = pre.price_noise;
+        } else {
+            ou_pv = ta.ou[e32];
+            ou_wd = ta.ou[n32 + e32];
+            ou_price = ta.ou[2u * n32 + e32];
+            in_price_noise = ta.price_noise[e32];
+        }
         if (FUSED) {  // the records this workgroup has just written, from LDS
             const u32x4 v0 = s_rec[2 * local_env], v1 = s_rec[2 * local_env + 1];
             mn0 = __uint_as_float(v0.x); P0f = __uint_as_float(v0.y); mx0 = __uint_as_float(v0.z); ln0 = pkd_line(v0.w); F0i = pkd_flow(v0.w);
@@ -1653,7 +1688,10 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             mn0 = r0.mn; P0f = r0.chg; mx0 = r0.mx; ln0 = pkd_line(r0.pkd); F0i = pkd_flow(r0.pkd);
             mn1 = r1.mn; P1f = r1.chg; mx1 = r1.mx; ln1 = pkd_line(r1.pkd); F1i = pkd_flow(r1.pkd);
         }
-        if (!RESET) {
+        if (!RESET && have_pre) {
+            a_el_f = pre.a_el; a_fc_f = pre.a_fc; cap = pre.cap;
+            pv_day = pre.pv_day; wd_day = pre.wd_day; q_len = pre.q_len; hv_line = pre.hv_line;
+        } else if (!RESET) {
             if (ta.tail_act) {
                 typedef float f32x2_ __attribute__((ext_vector_type(2)));
                 const f32x2_ tv = ((CHUB_G(const f32x2_)) ta.tail_act)[e32];
@@ -1673,8 +1711,13 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         if (MODE == MODE_PHILOX && !RESET && !sa.fresh) {
             // this step's state-independent env draws (three OU normals, FCEV arrival count) were made one launch ahead by
             // the level blocks of k_env (draw_env_levels): 350 dependent instructions less on this latency-bound chain
-            drw_raw = ((CHUB_G(const u32x4)) ta.drw)[e32];  // unpacked behind the table staging: no wait for it here
-            drw_n = ta.drw_cnt[e32];
+            if (have_pre) {
+                drw_raw = pre.drw;
+                drw_n = pre.drw_n;
+            } else {
+                drw_raw = ((CHUB_G(const u32x4)) ta.drw)[e32];  // unpacked behind the table staging: no wait for it here
+                drw_n = ta.drw_cnt[e32];
+            }
         } else if (MODE == MODE_PHILOX) {
             const U4 ow = px.block(SITE_OU, 0, 0);  // word 0 pv, 1 wind, 2 price
             z_pv = (double) normal_from_word(tb.normal_icdf, tb.normal_tail, ow.v[0]);
@@ -2139,8 +2182,9 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     if (!RESET) return;
 #endif
     const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
+    TailIn none;  // (the stand-alone tail loads its inputs itself)
     env_tail<RESET, MODE, MULTI>(ctx, sa, env, env < (int) ta.n_envs && (!MULTI || in_group(sa, env)), s_pv, s_wd, s_pv_now, s_wd_now, s_hy,
-                                 s_hv, s_out, (int) blockIdx.x, ta);
+                                 s_hv, s_out, (int) blockIdx.x, ta, nullptr, 0, 0, 0, none, false);
 }
 
 // ---------------------------------------------------------------------------------------- k_step_fused: the whole step in ONE launch
@@ -2157,8 +2201,12 @@ struct TailPrefetch {
     const TailArgs &ta;
     double *s_pv, *s_wd, *s_pv_now, *s_wd_now, *s_hy;
     double r_pv, r_wd, r_pv_now, r_wd_now, r_hy;
+    TailIn tin;          // the last wave: the state of its first 64 envs
+    int tail_env;        // ... of this env (-1: none)
+    bool predrawn;
     __device__ __forceinline__ void prefetch() {
         const int i = threadIdx.x;
+        if (tail_env >= 0) tail_prefetch(tin, ta, (uint32_t) tail_env, predrawn);
         r_pv = r_wd = r_pv_now = r_wd_now = r_hy = 0.0;
         if (i < 100) {
             r_pv = ta.pv_row[i];
@@ -2198,7 +2246,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
     PackedArgs pa = pa_in;
     asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
                       "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
-    TailPrefetch hook{ta, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, 0.0, 0.0, 0.0, 0.0, 0.0};
+    TailPrefetch hook{ta, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, 0.0, 0.0, 0.0, 0.0, 0.0, TailIn(), -1, sa.fresh == 0};
+    {   // the lanes of the last wave that will run a tail: which env's state to request up front
+        const int le = (int) (threadIdx.x & 63u), env = (int) blockIdx.x * (int) pa_in.epb + le;
+        if ((int) (threadIdx.x >> 6) == BLOCK / 64 - 1 && le < (int) pa_in.epb && env < (int) pa_in.n_envs) hook.tail_env = env;
+    }
     const int role = slot_body_packed<BLOCK, T, false, false, false, false, true, TailPrefetch>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
                                                                                                 s_ball + 1, s_acc, s_unit, hook, s_rec);
     constexpr int WAVES = BLOCK / 64;
@@ -2228,7 +2280,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
             int rows = epb - c < 64 ? epb - c : 64;
             rows = N - (env_first + c) < rows ? N - (env_first + c) : rows;
             env_tail<false, MODE_PHILOX, false, true>(ctx, sa, env, live, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, nullptr, s_out, 0, ta, s_rec,
-                                                      live ? le : 0, env_first + c, rows > 0 ? rows : 0);
+                                                      live ? le : 0, env_first + c, rows > 0 ? rows : 0, hook.tin, c == 0);
         }
     }
 }
