@@ -26,9 +26,10 @@ call by default (--graph on captures there too: RCCL inside the capture, verifie
 
 The per-kernel times behind `roofline` are NOT taken from the timed window (a short window is a time-of-day sample: the slot
 kernel's duration follows the arrival rate of the slot of day): after the timed region the run continues to the next episode
-boundary and then steps ONE WHOLE UNTIMED DAY (reset + 96 steps) call by call with the dispatch's own start / stop timestamps
-around both kernels of every step.  `roofline.avg_launch_us` is that day's average -- what `rocprofv3 --kernel-trace --stats`
-of whole days reports as AverageNs -- at any --steps.  `roofline_c5` does the same for 262 144 envs x hub [32, 32] (configs[4]'s
+boundary and then steps FIVE WHOLE UNTIMED DAYS with the dispatch's own start / stop timestamps around both kernels of every
+fifth step -- every slot of the day exactly once, with the kernels running back to back as in the timed region.
+`roofline.avg_launch_us` is that day average -- what `rocprofv3 --kernel-trace --stats` of whole days reports as AverageNs --
+at any --steps.  `roofline_c5` does the same for 262 144 envs x hub [32, 32] (configs[4]'s
 whole job on one GPU): a working set beyond the 256 MB Infinity Cache, i.e. genuinely HBM-resident.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the slot kernel) with ALGORITHMIC bytes (DESIGN.md
@@ -221,17 +222,25 @@ def launch_ranks(args):
     raise SystemExit(rc)
 
 
-def profiled_day(v, one_step, first_step):
-    """reset + 96 steps issued call by call from `first_step` (an episode boundary), the dispatch's own start / stop timestamps
-    around both kernels of every step -> (slot kernel us, env kernel us) averaged over the day, steps sampled, host wall seconds"""
+PROFILE_DAYS = 5  # whole days stepped for the per-kernel timestamps, every PROFILE_DAYS-th step sampled
+
+
+def profiled_days(v, span, first_step):
+    """PROFILE_DAYS whole days (reset + 96 steps each) issued from `first_step` (an episode boundary) with the dispatch's own start /
+    stop timestamps around both kernels of every PROFILE_DAYS-th step: 5 and 96 are coprime, so the 96 samples are every slot of
+    the day exactly once -- a day average -- while four steps in five go out as plain launches, so the kernels run back to back
+    as they do in the timed region (a timestamp pair on EVERY step slows the host below the GPU's pace, and kernels that start on
+    an idle chip measured 3 % shorter than the same kernels in a replayed graph).
+    -> (slot kernel us, env kernel us) averaged, steps sampled, host wall seconds per step"""
     assert first_step % 96 == 0
-    v.profile_begin(96, every=1)
+    n = 96 * PROFILE_DAYS
+    v.profile_begin(96, every=PROFILE_DAYS)
     t0 = time.perf_counter()
-    for j in range(96):
-        one_step(first_step + j)
+    span(first_step, n)
     slot_ms, env_ms, n_prof = v.profile_end()  # synchronises
     wall = time.perf_counter() - t0
-    return slot_ms / n_prof * 1e3, env_ms / n_prof * 1e3, n_prof, wall
+    assert n_prof == 96
+    return slot_ms / n_prof * 1e3, env_ms / n_prof * 1e3, n_prof, wall / n
 
 
 def roofline_block(slot_us, env_us, slot_b, env_b, per, traffic, traffic_src, n_prof, window):
@@ -258,26 +267,27 @@ def c5_roofline(chub, multi_gpu, lib, device, build_id):
     packed = [multi_gpu.DeviceBuffer(n * (D + 2) * 4, device) for _ in range(2)]
     reset_obs = multi_gpu.DeviceBuffer(n * D * 4, device)
 
-    def one_step(i):
-        if i % 96 == 0:
-            v.reset_device(reset_obs.ptr, stream=stream.ptr)
-        v.step_device_packed(acts[i & 1].ptr, packed[i & 1].ptr, stream=stream.ptr)
+    import ctypes as C
+    c_acts = (C.c_void_p * 2)(acts[0].ptr, acts[1].ptr)
+    c_packed = (C.c_void_p * 2)(packed[0].ptr, packed[1].ptr)
 
-    for i in range(96):
-        one_step(i)
+    def span(first, count):
+        chub._lib.check(lib.chub_run_steps(v._h, None, c_acts, 2, c_packed, None, reset_obs.ptr, first, count, stream.ptr))
+
+    span(0, 96)
     stream.sync()
-    slot_us, env_us, n_prof, wall = profiled_day(v, one_step, 96)
-    last = packed[(96 + 95) & 1].to_host(np.float32, (n, D + 2), stream.ptr)
+    slot_us, env_us, n_prof, wall_per_step = profiled_days(v, span, 96)
+    last = packed[1].to_host(np.float32, (n, D + 2), stream.ptr)
     assert np.isfinite(last).all() and (last[:, D + 1] > 0.5).all()
     slot_b, env_b = algorithmic_bytes(S, D)
     traffic, src = measured_traffic(build_id, n, n, kw["station_list"])
     out = roofline_block(slot_us, env_us, slot_b, env_b, n, traffic, src, n_prof,
-                         "one whole day (reset + slots 0..95) issued call by call after one warm-up day")
+                         "%d whole days after one warm-up day, every %dth step sampled: each slot of the day once" % (PROFILE_DAYS, PROFILE_DAYS))
     out["workload"] = "%d envs x hub [%d fast, %d slow] (BASELINE.json configs[4] on one GPU), renew / price fluctuate 0.3" % (
         n, kw["station_list"][0], kw["station_list"][1])
     out["state_bytes"] = n * S * 8
-    out["step_frac_call_by_call"] = (slot_b + env_b) * n * 96 / wall / 1e9 / HBM_PEAK_GBS
-    out["ms_per_step_call_by_call"] = wall / 96 * 1e3
+    out["step_frac_call_by_call"] = (slot_b + env_b) * n / wall_per_step / 1e9 / HBM_PEAK_GBS
+    out["ms_per_step_call_by_call"] = wall_per_step * 1e3
     v.close()
     for b in acts + packed + [reset_obs]:
         b.free()
@@ -399,6 +409,18 @@ def main():
         else:
             v.step_device_packed(actions[i % N_ACTION_BATCHES].ptr, packed[b].ptr, stream=stream.ptr)
 
+    # the same calls issued from C for a whole span of steps (chub_run_steps): no trip through Python per step
+    import ctypes as C
+    PtrArr = C.c_void_p * N_ACTION_BATCHES
+    c_actions = PtrArr(*[a.ptr for a in actions])
+    c_packed = (C.c_void_p * 2)(packed[0].ptr, packed[1].ptr)
+    c_gathered = (C.c_void_p * 2)(gathered[0].ptr, gathered[1].ptr) if (use_comm and rank == 0) else None
+
+    def span(first, n):
+        if n > 0:
+            chub._lib.check(lib.chub_run_steps(v._h, comm._h if use_comm else None, c_actions, N_ACTION_BATCHES, c_packed, c_gathered,
+                                               reset_obs.ptr, first, n, stream.ptr))
+
     def fence():
         stream.sync()
         if comm is not None:
@@ -429,9 +451,14 @@ def main():
                 v.graph_launch(episode_graph, stream.ptr)
                 i += per_graph
                 replayed[0] += per_graph
-            else:
-                one_step(i)
-                i += 1
+            else:  # up to the next place a replay fits (or the end): one C call for the whole span
+                j = end
+                if episode_graph is not None:
+                    nxt = ((i + 95) // 96) * 96
+                    if nxt > i and end - nxt >= per_graph:
+                        j = nxt
+                span(i, j - i)
+                i = j
 
     run(0, warmup)
     fence()
@@ -475,16 +502,15 @@ def main():
         assert ((g[:, D + 1] > 0.5) == (((warmup + steps) % 96) == 0)).all(), "a shard's done flags are out of step"
         assert (np.abs(g[:, :D]).sum(axis=1) > 0).all(), "a shard's rows never arrived"
 
-    # ---- untimed: on to the next episode boundary, then one whole day with per-kernel timestamps
+    # ---- untimed: on to the next episode boundary, then whole days with per-kernel timestamps on every slot of the day once
     slot_us = env_us = 0.0
     n_prof = 0
     i = warmup + steps
     if not args.no_events:
-        while i % 96:
-            one_step(i)
-            i += 1
-        slot_us, env_us, n_prof, _ = profiled_day(v, one_step, i)
-        i += 96
+        span(i, (-i) % 96)
+        i += (-i) % 96
+        slot_us, env_us, n_prof, _ = profiled_days(v, span, i)
+        i += 96 * PROFILE_DAYS
     fence()
 
     if rank == 0:
@@ -497,12 +523,12 @@ def main():
             roofline = {"bound": "hbm", "kernel": "k_step_fused", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                         "algorithmic_bytes_per_launch": (slot_b + env_b) * per, "avg_launch_us": slot_us, "launches_sampled": n_prof,
-                        "window": "one whole untimed day (reset + slots 0..95) issued call by call after the timed region",
+                        "window": "%d whole untimed days after the timed region, every %dth step sampled: each slot of the day once, kernels back to back" % (PROFILE_DAYS, PROFILE_DAYS),
                         "env_kernel_avg_launch_us": 0.0}
         elif n_prof:
             traffic, traffic_src = measured_traffic(build_id, per, total, hub_kw["station_list"])
             roofline = roofline_block(slot_us, env_us, slot_b, env_b, per, traffic, traffic_src, n_prof,
-                                      "one whole untimed day (reset + slots 0..95) issued call by call after the timed region")
+                                      "%d whole untimed days after the timed region, every %dth step sampled: each slot of the day once, kernels back to back" % (PROFILE_DAYS, PROFILE_DAYS))
         step_achieved = (slot_b + env_b) * total / (dt / steps) / 1e9 / world  # per GPU
         d0, s0 = divmod(warmup, 96)
         d1, s1 = divmod(warmup + steps - 1, 96)
@@ -523,7 +549,7 @@ def main():
                                       {"c4": "configs[3]", "c5": "configs[4]"}.get(config, config), hub_kw["fcev_permeate"]),
                        "envs_per_gpu": per, "obs_dim": D, "act_dim": A, "launch": launch,
                        "kernels_per_step": "1 (k_step_fused)" if v_fused else "2 (k_slot_packed + k_env)",
-                       "window": "timed: slot %d of day %d .. slot %d of day %d; roofline: a whole untimed day afterwards" % (s0, d0, s1, d1),
+                       "window": "timed: slot %d of day %d .. slot %d of day %d; roofline: whole untimed days afterwards" % (s0, d0, s1, d1),
                        "host_issue_ms_per_step": t_issue / steps * 1e3,
                        "collective": "none" if not use_comm else
                        "one grouped ncclSend/ncclRecv (RCCL) of [envs_per_gpu, %d] f32 per step to rank 0, on the step's stream" % (D + 2)},

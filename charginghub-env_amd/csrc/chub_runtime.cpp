@@ -1002,6 +1002,25 @@ int chub_step_gather(chub_env *e, chub_comm *comm, const float *d_actions, float
     return chub_comm_gather(comm, d_packed, d_gathered, e->hp.n_envs * (int64_t) (e->hp.obs_dim + 2) * (int64_t) sizeof(float), stream);
 }
 
+// A run of steps issued from C: what a host loop of chub_reset_device / chub_step_device_packed / chub_step_gather calls does, without
+// a trip through the host language per step (multi-GPU shards of a few thousand envs are otherwise bound by the host's issue rate)
+int chub_run_steps(chub_env *e, chub_comm *comm, const float *const *d_action_batches, int n_batches, float *const *d_packed2,
+                   float *const *d_gathered2, float *d_reset_obs, int64_t first_step, int64_t n_steps, void *stream) {
+    if (!e || !d_action_batches || n_batches <= 0 || !d_packed2 || !d_packed2[0] || !d_packed2[1] || !d_reset_obs || first_step < 0 ||
+        n_steps < 0)
+        return fail(CHUB_ERR_ARG, "bad argument");
+    for (int64_t i = first_step; i < first_step + n_steps; i++) {
+        int rc;
+        if (i % 96 == 0 && (rc = chub_reset_device(e, nullptr, nullptr, d_reset_obs, stream))) return rc;
+        const float *act = d_action_batches[i % n_batches];
+        float *packed = d_packed2[i & 1];
+        if (comm) rc = chub_step_gather(e, comm, act, packed, d_gathered2 ? d_gathered2[i & 1] : nullptr, stream);
+        else rc = chub_step_device_packed(e, act, nullptr, packed, stream);
+        if (rc) return rc;
+    }
+    return CHUB_OK;
+}
+
 int chub_step_load_device(chub_env *e, const float *d_actions, const double *d_exo_z, float *d_obs, float *d_reward,
                           uint8_t *d_done, void *stream) {
     if (!e || !d_actions || !d_obs || !d_reward || !d_done) return fail(CHUB_ERR_ARG, "null argument");

@@ -211,6 +211,13 @@ int chub_comm_ranks_seen(chub_comm *comm, int *out, void *stream);
 int chub_device_info(int device, int32_t *out4);
 int chub_step_gather(chub_env *env, chub_comm *comm, const float *d_actions, float *d_packed, float *d_gathered, void *stream);
 
+/* A run of n_steps steps issued from C, starting at step index first_step: before every step whose index is a multiple of 96 a
+ * chub_reset_device (into d_reset_obs), then chub_step_gather (comm != NULL; d_gathered2 may be NULL off rank 0) or
+ * chub_step_device_packed, with actions d_action_batches[i % n_batches] and outputs d_packed2[i & 1] / d_gathered2[i & 1].  Exactly
+ * the calls a host loop would make (PHILOX handles); returns after enqueueing. */
+int chub_run_steps(chub_env *env, chub_comm *comm, const float *const *d_action_batches, int n_batches, float *const *d_packed2,
+                   float *const *d_gathered2, float *d_reset_obs, int64_t first_step, int64_t n_steps, void *stream);
+
 /* Per-kernel timing of the step: between chub_profile_begin and chub_profile_end every `every`-th step (up to
  * max_steps samples) records HIP events on the launch stream around the slot kernel and the env kernel; _end
  * synchronises and returns the summed durations in milliseconds and the number of steps sampled. */
