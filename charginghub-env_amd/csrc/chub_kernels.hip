@@ -1093,6 +1093,10 @@ __device__ __forceinline__ uint32_t sload_u32(const void *p, int i) { return ((c
 // RESET: evs_reset (CHS.hpp:1209-1231 / 1520-1542) on the same layout: no state comes in, the unit's initial occupancy was drawn
 // by k_reset_levels, every wave helps with the (many) new cars.  BIG: a station with more than 64 piles -- a unit then spans
 // several waves (its empties are counted over all of them) and its power sums need 64 bits.
+#ifndef CHUB_ACC_COPIES
+#define CHUB_ACC_COPIES 2  // copies of a unit's LDS accumulators (lanes spread over them by lane number: fewer same-address atomics; 1 / 2 / 4: 21.28 / 20.95 / 21.12 us)
+#endif
+constexpr int kAccCopies = CHUB_ACC_COPIES;
 #ifndef CHUB_EPI_ALL
 #define CHUB_EPI_ALL 1  // 1: every wave of the workgroup takes its share of the new cars (a third barrier: -0.2 us at C4); 0: the last wave alone
 #endif
@@ -1165,7 +1169,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     }
     if (FUSED) hook.prefetch();
     if (tid == 0) q_cnt[0] = 0;
-    for (int i = tid; i < (BIG ? 16 : 8) * epb; i += BLOCK) s_acc[i] = 0;
+    for (int i = tid; i < (BIG ? 16 : 8 * kAccCopies) * epb; i += BLOCK) s_acc[i] = 0;
     long long *s_acc64 = (long long *) s_acc;  // BIG: {min, charge, max power, cars} as four 64-bit sums per unit
 
     // ---- second round trip, only for the slots whose car stays: where it is on its curve (entries n, n + 1 of its class
@@ -1275,7 +1279,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     for (int j = 0; j < T; j++) {
         asm volatile("" : "+v"(row[j]), "+v"(act[j]));
         const int u = 2 * e_[j] + k_[j];
-        int *acc = s_acc + 4 * u;  // the unit's {min, charge power | max power, cars}: two 64-bit LDS atomics per car
+        int *acc = s_acc + 4 * u + (BIG ? 0 : (lane & (kAccCopies - 1)) * 8 * epb);  // the unit's {min, charge power | max power, cars}: two 64-bit LDS atomics per car
         uint32_t w0n = 0u;
         if (stays[j]) {
             const float t_target = __uint_as_float(s2[j].y);
@@ -1348,7 +1352,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         if (st_ > 0) {
             const int q = (int) (e0.x * 524288.0f);
             if (!BIG) {
-                int *ac = s_acc + 4 * (2 * s_e + s_k);
+                int *ac = s_acc + 4 * (2 * s_e + s_k) + (lane & (kAccCopies - 1)) * 8 * epb;
                 atomicAdd((unsigned long long *) (ac + 2), (unsigned long long) (uint32_t) q | (1ull << 32));
                 if (must_charge(tt_, e0.y, st_)) atomicAdd(ac, q);
             } else {
@@ -1401,9 +1405,14 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         }
         u32x4 rv;
         if (!BIG) {
-            const int *acc = s_acc + 4 * i;
-            rv = u32x4{__float_as_uint(fixed_to_kw(acc[0])), __float_as_uint(fixed_to_kw(acc[1])), __float_as_uint(fixed_to_kw(acc[2])),
-                       lf | ((uint32_t) acc[3] << 16)};
+            int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int c = 0; c < kAccCopies; c++) {
+                const int *acc = s_acc + 4 * i + c * 8 * epb;
+                a0 += acc[0]; a1 += acc[1]; a2 += acc[2]; a3 += acc[3];
+            }
+            rv = u32x4{__float_as_uint(fixed_to_kw(a0)), __float_as_uint(fixed_to_kw(a1)), __float_as_uint(fixed_to_kw(a2)),
+                       lf | ((uint32_t) a3 << 16)};
         } else {
             const long long *a64 = s_acc64 + 4 * i;
             rv = u32x4{__float_as_uint((float) a64[0] * (1.0f / 524288.0f)), __float_as_uint((float) a64[1] * (1.0f / 524288.0f)),
@@ -1421,7 +1430,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_sl
     __shared__ uint32_t q_new[BLOCK * T];
     __shared__ uint32_t q_cnt[2];
     __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];                   // [1 + virtual wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
-    __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T];  // 2 epb <= BLOCK * T / 2 units x {min, charge, max power, cars} (BIG: as 64-bit sums, few units)
+    __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T * kAccCopies];  // 2 epb <= BLOCK * T / 2 units x {min, charge, max power, cars} (BIG: as 64-bit sums, few units)
     __shared__ uint32_t s_unit[BLOCK * T / 2];                        // per unit: line | flow << 8
     // all kernel arguments this wave needs, requested in ONE batch of scalar loads at its very start (the single asm
     // statement makes every one of them live here), instead of in a chain of dependent loads in front of the first
@@ -2238,7 +2247,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
     __shared__ uint32_t q_new[BLOCK * T];
     __shared__ uint32_t q_cnt[2];
     __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];
-    __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T];
+    __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T * kAccCopies];
     __shared__ uint32_t s_unit[BLOCK * T / 2];
     __shared__ __attribute__((aligned(16))) u32x4 s_rec[BLOCK * T / 2];
     __shared__ double s_pv[100], s_wd[150], s_pv_now[100], s_wd_now[150], s_hy[102];
