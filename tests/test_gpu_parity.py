@@ -892,6 +892,62 @@ def test_graph_replays_mixed_with_eager_calls():
                 assert not np.array_equal(ends[x][:, :-2], ends[y][:, :-2]), (name, "segments", x, y, "ended in the same state")
 
 
+def test_run_steps_issues_the_same_calls_from_c():
+    """chub_run_steps (a span of steps issued from C: resets at the day boundaries, packed outputs double-buffered) against the
+    same calls made one by one from Python: bit-identical outputs, state and clock -- with and without a hipGraph around it"""
+    chub = hub()
+    from charginghub_env_amd import multi_gpu
+    from charginghub_env_amd._lib import check
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.02)
+    n = 1200
+    res = []
+    for form in ("python", "c", "c_in_graph"):
+        v = chub.VecChargingHub(n, seed=12, **kw)
+        st = multi_gpu.Stream(0)
+        acts = [multi_gpu.DeviceBuffer(n * v.act_dim * 4) for _ in range(3)]
+        for b, a in enumerate(acts):
+            v.random_actions_device(a.ptr, 5, b, st.ptr)
+        packed = [multi_gpu.DeviceBuffer(n * (v.obs_dim + 2) * 4) for _ in range(2)]
+        obs0 = multi_gpu.DeviceBuffer(n * v.obs_dim * 4)
+        c_acts = (C.c_void_p * 3)(*[a.ptr for a in acts])
+        c_packed = (C.c_void_p * 2)(packed[0].ptr, packed[1].ptr)
+
+        def span(first, count):
+            if form == "python":
+                for i in range(first, first + count):
+                    if i % 96 == 0:
+                        v.reset_device(obs0.ptr, stream=st.ptr)
+                    v.step_device_packed(acts[i % 3].ptr, packed[i & 1].ptr, stream=st.ptr)
+            else:
+                check(v._lib.chub_run_steps(v._h, None, c_acts, 3, c_packed, None, obs0.ptr, first, count, st.ptr))
+
+        trace = []
+        span(0, 100)
+        trace.append(packed[1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr))
+        if form == "c_in_graph":
+            st.sync()
+            v.graph_begin(st.ptr)
+            span(100, 93)          # ... up to the end of the second day: 93 steps, no reset inside: + 1 below = an even count
+            span(193, 95 + 1 + 1)  # step 193 .. 289 crosses two day boundaries (resets at 288): 97 steps + 1 reset
+            g = v.graph_end(st.ptr)
+            v.graph_launch(g, st.ptr)
+            st.sync()
+            v.graph_destroy(g)
+        else:
+            span(100, 93)
+            span(193, 97)
+        trace.append(packed[(193 + 97 - 1) & 1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr))
+        trace += [np.concatenate([x.reshape(n, -1) for x in v.slots()], axis=1), v.station_scalars().reshape(n, -1), np.array([v.clock])]
+        res.append(trace)
+        v.close()
+        st.destroy()
+    for k in range(len(res[0])):
+        assert np.array_equal(res[0][k], res[1][k]), ("python vs c", k)
+        assert np.array_equal(res[0][k], res[2][k]), ("python vs c in a graph", k)
+    assert res[0][-1][0] == (193 + 97) % 96
+
+
 def test_full_size_c5_properties():
     """BASELINE.json configs[4] at its own size: 262 144 envs x hub [32 fast, 32 slow] with fluctuating price / PV / wind, one
     episode on the production (packed) kernel: 4-way shard independence (what the 8-GPU job relies on), the invariants the
