@@ -224,6 +224,7 @@ struct StepArgs {
     // theirs).  null: lock-step, the one clock above holds for every env.
     uint16_t *env_clk;
     const uint8_t *env_mask;   // [N] non-zero = the launch serves this env; null: every env
+    int32_t env_lo, env_hi;    // the first and the last env the launch serves (0 .. N - 1 without a mask): the grids cover that range
     // The state-independent draws of a PHILOX step (station levels, OU normals, FCEV arrival) are normally made one launch
     // ahead by the previous launch's level blocks.  fresh: this launch makes its own (k_draw_levels in front of the slot
     // kernel, the tail draws inline) and leaves none for the next -- same Philox counters, same values; used whenever the

@@ -37,6 +37,16 @@ __device__ __forceinline__ bool in_group(const StepArgs &sa, int64_t env) { retu
 __device__ __forceinline__ uint32_t env_clk(const StepArgs &sa, int64_t n_envs, int64_t env) {
     return sa.env_clk[(int64_t) (sa.tick & 1u) * n_envs + env];
 }
+// A call on a subset of the envs only launches work for the range of envs it names (StepArgs::env_lo .. env_hi: the first and the
+// last served env; every env in a lock-step call): lane i of a grid over `segments` copies of that range -> segment, env
+__device__ __forceinline__ int64_t range_len(const StepArgs &sa) { return (int64_t) sa.env_hi - sa.env_lo + 1; }
+__device__ __forceinline__ bool range_unit(const StepArgs &sa, int64_t i, int segments, int &seg, int64_t &env) {
+    const int64_t R = range_len(sa);
+    if (i >= (int64_t) segments * R) return false;
+    seg = (i >= R ? 1 : 0) + (i >= 2 * R ? 1 : 0);
+    env = sa.env_lo + (i - (int64_t) seg * R);
+    return true;
+}
 __device__ __forceinline__ int clk_t(uint32_t c) { return (int) (c & 127u); }
 __device__ __forceinline__ uint32_t clk_next(uint32_t c) {  // one step later: slot of day + 1 (mod 96), price_count + 1 (mod 4)
     return (uint32_t) ((clk_t(c) + 1) % 96) | ((((c >> 8) + 1u) & 3u) << 8);
@@ -1084,6 +1094,7 @@ struct PackedArgs {
     const uint32_t *tick_base;       // device-side tick offset (graph replays), added to tick
     uint32_t late[8];                // the first 8 thresholds of mk_late_time's table (late_from_word); beyond them with probability 0.3 %
     CHUB_G(const uint8_t) env_mask;  // per-env clocks: non-zero = the launch serves this env (null: every env)
+    uint32_t blk0;                   // ... and the first workgroup of the range of envs it names (the grid covers that range only)
     CHUB_G(float) tail_act;          // [N][2] out: the env's two tail actions, for the tail kernel (StationArrays::tail_act)
 };
 
@@ -1439,7 +1450,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_sl
     asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
                       "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
     NoHook hook;
-    (void) slot_body_packed<BLOCK, T, TAPE, RESET, BIG, MASKED, false, NoHook>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new, s_ball + 1, s_acc,
+    (void) slot_body_packed<BLOCK, T, TAPE, RESET, BIG, MASKED, false, NoHook>(ctx->hp, sa, pa, ctx->tb, blockIdx.x + (MASKED ? pa.blk0 : 0u), q_cnt, q_new, s_ball + 1, s_acc,
                                                                                s_unit, hook, nullptr);
 }
 
@@ -2182,18 +2193,17 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     if (MODE == MODE_PHILOX && (int) blockIdx.x >= nb_env) {
         // the last blocks of the grid: next step's station-level draws, one lane per (station, env).
         // They are pure VALU work and fill the issue slots the latency-bound tail waves leave empty.
-#if !defined(CHUB_ABLATE_LEVELS)
-        level_block<RESET, MULTI>(ctx, sa, (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x);
-#endif
+        int seg = 0;
+        int64_t env_ = 0;
+        if (range_unit(sa, (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x, 3, seg, env_))
+            level_block<RESET, MULTI>(ctx, sa, (int64_t) seg * ctx->hp.n_envs + env_);
         return;
     }
-#if defined(CHUB_ABLATE_TAIL)
-    if (!RESET) return;
-#endif
-    const int env = (int) (blockIdx.x * kEnvBlock + threadIdx.x);
+    const int blk = (int) blockIdx.x + (MULTI ? sa.env_lo / kEnvBlock : 0);  // a call on a subset: the blocks of its range of envs only
+    const int env = blk * kEnvBlock + (int) threadIdx.x;
     TailIn none;  // (the stand-alone tail loads its inputs itself)
     env_tail<RESET, MODE, MULTI>(ctx, sa, env, env < (int) ta.n_envs && (!MULTI || in_group(sa, env)), s_pv, s_wd, s_pv_now, s_wd_now, s_hy,
-                                 s_hv, s_out, (int) blockIdx.x, ta, nullptr, 0, 0, 0, none, false);
+                                 s_hv, s_out, blk, ta, nullptr, 0, 0, 0, none, false);
 }
 
 // ---------------------------------------------------------------------------------------- k_step_fused: the whole step in ONE launch
@@ -2474,11 +2484,11 @@ __global__ void k_reset_levels(const DevCtx *__restrict__ ctx, StepArgs sa) {
     const Tables &tb = ctx->tb;
     const int64_t N = hp.n_envs;
     const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t u = t >> 2;
     const int q = (int) (t & 3);
-    const bool live = u < 2 * N;
-    const int k = u >= N ? 1 : 0;
-    const int64_t env = live ? u - (int64_t) k * N : 0;
+    int k = 0;
+    int64_t env = 0;
+    const bool live = range_unit(sa, t >> 2, 2, k, env);  // the units of the envs the call names: both stations of env_lo .. env_hi
+    const int64_t u = (int64_t) k * N + env;
     const bool served = live && in_group(sa, env);
     const int S = hp.S[k], mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
     PhiloxCtx px{hp.key[0], hp.key[1], CHUB_TICK(hp, tick), (uint32_t) (hp.env_id0 + env)};
@@ -2508,16 +2518,22 @@ __global__ void k_reset_levels(const DevCtx *__restrict__ ctx, StepArgs sa) {
 __global__ void k_draw_levels(const DevCtx *__restrict__ ctx, StepArgs sa) {
     const HubParams &hp = ctx->hp;
     const int64_t N = hp.n_envs;
-    const int64_t u = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= 2 * N) return;
-    const int kk = u >= N ? 1 : 0;
-    const int64_t env = u - (int64_t) kk * N;
+    int kk = 0;
+    int64_t env = 0;
+    if (!range_unit(sa, (int64_t) blockIdx.x * blockDim.x + threadIdx.x, 2, kk, env)) return;
+    const int64_t u = (int64_t) kk * N + env;
     if (!in_group(sa, env)) return;
     const int t = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;
     // tape mode: the caller's recorded draws instead of this build's (the 64-bit layout above), decoded the same way
     const int line_now = pkd_line(ctx->st.rec[4u * (uint32_t) u + 3u]);
     ctx->st.pk[sa.tick & 1u][u] = sa.pk_tape ? dk_make(sa.pk_tape[u], line_now, hp.type[kk] == 0)
                                              : draw_decoded_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick), t, kk, env, line_now, hp.type[kk] == 0);
+}
+
+// per-env clocks, a call on a subset of the envs: the clocks of the envs outside the launched range move to the other buffer as they are
+__global__ void k_keep_clocks(uint16_t *dst, const uint16_t *src, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------- launchers
@@ -2540,7 +2556,7 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
     constexpr int BLOCK = 256;
     const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
     const bool big = hp.S[0] > 64 || hp.S[1] > 64;  // a unit of more than 64 piles is a workgroup of its own (k_slot_unit)
-    if (MODE == MODE_PHILOX && RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((8 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
+    if (MODE == MODE_PHILOX && RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((8 * ((int64_t) sa.env_hi - sa.env_lo + 1) + 255) / 256)), dim3(256), 0, stream, ctx, sa);
     if (MODE == MODE_PHILOX && !big) {
         CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, ev1, ctx, sa, nb0);
     } else {
@@ -2559,13 +2575,14 @@ static PackedArgs make_packed_args(const HubParams &hp, const StepArgs &sa, cons
 void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
                  const PackedPtrs &pp, hipEvent_t ev0, hipEvent_t ev1) {
     if (hp.rng_mode == MODE_PHILOX && !reset && (sa.fresh || sa.pk_tape))
-        hipLaunchKernelGGL(k_draw_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
+        hipLaunchKernelGGL(k_draw_levels, dim3((unsigned) ((2 * ((int64_t) sa.env_hi - sa.env_lo + 1) + 255) / 256)), dim3(256), 0, stream, ctx, sa);
     if (hp.rng_mode == MODE_PHILOX) {
         if (hp.packed && !sa.load_mode) {
             if (reset)
-                hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((8 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
+                hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((8 * ((int64_t) sa.env_hi - sa.env_lo + 1) + 255) / 256)), dim3(256), 0, stream, ctx, sa);
             const PackedArgs pa = make_packed_args(hp, sa, pp);
-            const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
+            // every workgroup of the batch, or (a call on a subset of the envs) those of the range of envs it names
+            const uint32_t nb = sa.env_mask ? (uint32_t) (sa.env_hi / hp.epb - sa.env_lo / hp.epb + 1) : (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
 #define CHUB_PACKED1(TAPE_, RESET_, BIG_, MASKED_) \
     CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, TAPE_, RESET_, BIG_, MASKED_>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa)
 #define CHUB_PACKED(TAPE_, RESET_, BIG_) \
@@ -2618,6 +2635,7 @@ static PackedArgs make_packed_args(const HubParams &hp, const StepArgs &sa, cons
     pa.tick_base = hp.tick_base;
     for (int j = 0; j < 8; j++) pa.late[j] = pp.late8[j];
     pa.env_mask = (CHUB_G(const uint8_t)) sa.env_mask;
+    pa.blk0 = sa.env_mask ? (uint32_t) (sa.env_lo / hp.epb) : 0u;
     pa.tail_act = (CHUB_G(float)) pp.st->tail_act;
     return pa;
 }
@@ -2625,7 +2643,7 @@ static PackedArgs make_packed_args(const HubParams &hp, const StepArgs &sa, cons
 // the whole PHILOX lock-step step as ONE launch (k_step_fused): the caller has checked that the hub shape and the call allow it
 void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp, hipEvent_t ev0,
                        hipEvent_t ev1) {
-    if (sa.fresh) hipLaunchKernelGGL(k_draw_levels, dim3((unsigned) ((2 * hp.n_envs + 255) / 256)), dim3(256), 0, stream, ctx, sa);
+    if (sa.fresh) hipLaunchKernelGGL(k_draw_levels, dim3((unsigned) ((2 * ((int64_t) sa.env_hi - sa.env_lo + 1) + 255) / 256)), dim3(256), 0, stream, ctx, sa);
     const PackedArgs pa = make_packed_args(hp, sa, pp);
     TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa, pp, false);
     ta.tail_act = nullptr;  // the tails read their two actions from the action rows (the workgroup has just had them in cache)
@@ -2636,10 +2654,18 @@ void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &s
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
                 hipEvent_t ev1, const PackedPtrs &pp) {
     const TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa, pp, reset);
-    const int nb_env = (int) ((hp.n_envs + kEnvBlock - 1) / kEnvBlock);
+    // the tail blocks of every env, or (per-env clocks) of the range of envs the call names
+    const int nb_env = sa.env_clk ? sa.env_hi / kEnvBlock - sa.env_lo / kEnvBlock + 1 : (int) ((hp.n_envs + kEnvBlock - 1) / kEnvBlock);
+    if (sa.env_clk && sa.env_mask) {
+        // the clocks are double-buffered by launch parity and the tail moves those of the envs of its blocks to the other buffer; the
+        // envs outside the range keep theirs: copied here
+        const int64_t N = hp.n_envs;
+        hipLaunchKernelGGL(k_keep_clocks, dim3((unsigned) ((N + 255) / 256)), dim3(256), 0, stream, sa.env_clk + (int64_t) ((sa.tick + 1u) & 1u) * N,
+                           (const uint16_t *) sa.env_clk + (int64_t) (sa.tick & 1u) * N, N);
+    }
     if (hp.rng_mode == MODE_PHILOX) {
         // + the level-draw workgroups: next step's state-independent variates (3 lanes per env: two stations, one env)
-        const unsigned nb = (unsigned) nb_env + (unsigned) ((3 * hp.n_envs + kEnvBlock - 1) / kEnvBlock);
+        const unsigned nb = (unsigned) nb_env + (unsigned) ((3 * ((int64_t) sa.env_hi - sa.env_lo + 1) + kEnvBlock - 1) / kEnvBlock);
         if (sa.env_clk) {  // per-env clocks: its own instantiation
             if (reset) CHUB_LAUNCH((k_env<true, MODE_PHILOX, true>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
             else CHUB_LAUNCH((k_env<false, MODE_PHILOX, true>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
@@ -2655,6 +2681,7 @@ void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepAr
 }
 
 __global__ void k_tick_advance(uint32_t *tick_base, uint32_t by) { *tick_base += by; }
+
 
 // chub_step_bits: the pile decisions arrive as one bit per pile (what action_to_real makes of the action row, MGR:384-393) and
 // the two tail actions as floats; this writes the [N, S + 2] f32 action rows the step kernels read: +1 / -1 for the piles (any

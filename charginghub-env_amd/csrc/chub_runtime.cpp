@@ -74,6 +74,7 @@ struct chub_env {
     hipEvent_t mask_done[2];        // recorded behind the launches that read d_mask[i]
     uint32_t mask_seq;
     const uint8_t *cur_mask;        // device copy of the mask of the call in progress
+    int64_t mask_lo, mask_hi;       // ... and the first / last env it names
     // a capture on per-env clocks: every masked call gets a device mask of its own (owned by the graph: a replay reads no host
     // memory), and the capture notes which launch of it served each env last (chub_env_clocks after a replay)
     std::vector<void *> cap_masks;
@@ -853,9 +854,21 @@ int chub_sync(chub_env *e) {
 static int serve_mask(chub_env *e, const uint8_t *mask, hipStream_t s, int &served) {
     const size_t N = (size_t) e->hp.n_envs;
     size_t n_masked = N;
+    e->mask_lo = 0;
+    e->mask_hi = (int64_t) N - 1;
     if (mask) {
         n_masked = 0;
-        for (size_t i = 0; i < N; i++) n_masked += mask[i] ? 1 : 0;
+        int64_t lo = -1, hi = -1;
+        for (size_t i = 0; i < N; i++)
+            if (mask[i]) {
+                n_masked++;
+                if (lo < 0) lo = (int64_t) i;
+                hi = (int64_t) i;
+            }
+        if (n_masked) {
+            e->mask_lo = lo;
+            e->mask_hi = hi;
+        }
     }
     served = n_masked == 0 ? 0 : (n_masked == N ? 2 : 1);
     if (served != 1) return CHUB_OK;
@@ -933,9 +946,15 @@ static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const d
     sa.exo_z = d_exo_z;
     sa.obs = d_obs;
     sa.obs_stride = e->hp.obs_dim;
+    sa.env_lo = 0;
+    sa.env_hi = (int32_t) (e->hp.n_envs - 1);
     if (e->per_env) {
         sa.env_clk = e->d_env_clk;
         sa.env_mask = served == 1 ? e->cur_mask : nullptr;
+        if (served == 1) {
+            sa.env_lo = (int32_t) e->mask_lo;
+            sa.env_hi = (int32_t) e->mask_hi;
+        }
     }
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
@@ -1067,9 +1086,15 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     sa.load_mode = load_mode;
     sa.pk_tape = e->tape_pk;
     sa.car_tape = e->tape_car;
+    sa.env_lo = 0;
+    sa.env_hi = (int32_t) (e->hp.n_envs - 1);
     if (e->per_env) {
         sa.env_clk = e->d_env_clk;
         sa.env_mask = served == 1 ? e->cur_mask : nullptr;
+        if (served == 1) {
+            sa.env_lo = (int32_t) e->mask_lo;
+            sa.env_hi = (int32_t) e->mask_hi;
+        }
     }
     // the state-independent draws of this step: left by the previous launch's level blocks if that launch served every env
     // (for the tick that is now this launch's), otherwise made by this launch itself (a graph's first step always makes its
@@ -1980,6 +2005,7 @@ int chub_compat_replay_constructor(chub_env *e) {
     StepArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.station_filter = -1;
+    sa.env_hi = (int32_t) (e->hp.n_envs - 1);
     launch_slot(true, e->hp, e->d_ctx, sa, nullptr, packed_ptrs(e), nullptr, nullptr);
     // (2) HySystem.__init__: 101 hy_step()s with live FCEV arrivals (HYD:154-157,168,250-259) -> the streams advance and
     //     every env gets the hy_power_speed_list the reference would have built from its draws
