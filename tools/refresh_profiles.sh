@@ -1,18 +1,13 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root):  tools/refresh_profiles.sh v3
-# Writes gpurun_out/profiles_<tag>/: the default bench line, the rocprofv3 kernel-trace stats of the same command, and the
-# FETCH_SIZE / WRITE_SIZE / SQ counter passes (each --pmc set in its own run) summarised into one JSON.
+# Writes gpurun_out/profiles_<tag>/: the FETCH_SIZE / WRITE_SIZE / SQ counter passes (each --pmc set in its own run) summarised
+# into one JSON, then the default bench line and the rocprofv3 kernel-trace stats of the same command.
 # Copy the files into profiles/ (tracked) afterwards.
 set -e
 TAG=${1:-vX}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python3 bench.py > $OUT/round3_${TAG}_bench.json 2> $OUT/bench.err
-echo "bench done"; tail -c 400 $OUT/round3_${TAG}_bench.json; echo
-rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 > $OUT/round3_${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
-cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/round3_${TAG}_kernel_stats.csv
-echo "kernel trace done"
 ARGS="--steps 192 --warmup 96 --no-cpu-baseline --no-events"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch --output-format csv -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err
 echo "fetch pass done"
@@ -76,5 +71,13 @@ for label, key in KEYS:
 json.dump(res5, open("%s/round3_%s_pmc_traffic_c5.json" % (out, tag), "w"), indent=1)
 print(json.dumps(res5["k_slot"]))
 PY
+# the traffic summaries go where bench.py looks for them (profiles/, matched by build id), so that the bench lines written next
+# carry `roofline.traffic` of this very build
+cp $OUT/round3_${TAG}_pmc_traffic.json $OUT/round3_${TAG}_pmc_traffic_c5.json profiles/
+python3 bench.py > $OUT/round3_${TAG}_bench.json 2> $OUT/bench.err
+echo "bench done"; tail -c 400 $OUT/round3_${TAG}_bench.json; echo
+rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 > $OUT/round3_${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
+cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/round3_${TAG}_kernel_stats.csv
+echo "kernel trace done"
 rm -rf $OUT/kt $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_tcc $OUT/pmc_tcp $OUT/pmc_fetch_c5 $OUT/pmc_write_c5
 ls $OUT
