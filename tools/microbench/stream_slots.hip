@@ -1,0 +1,93 @@
+// The slot kernel's memory streams without its work: per slot 8 B of state in, 4 B of action in (rows of S + 2 floats), 8 B of state
+// out; per (env, station) 4 B in and 16 B out.  65 536 envs x 45 slots, launched back to back like the step (the 47 MB of state
+// stay in the Infinity Cache from launch to launch, the action batches cycle through 8 x 12 MB).  What it prints is the floor a
+// kernel with these streams and nothing else reaches on this chip, for three shapes of workgroup.
+//   hipcc --offload-arch=gfx950 -O3 -o stream_slots tools/microbench/stream_slots.hip && ./stream_slots
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int BLOCK, int T>
+__global__ __launch_bounds__(BLOCK) void k_stream(u32x2 *__restrict__ state, const float *__restrict__ act, const uint32_t *__restrict__ pk,
+                                                  u32x4 *__restrict__ rec, int n_envs, int S, int epb, uint32_t magic) {
+    const int tid = threadIdx.x, env_first = blockIdx.x * epb;
+    u32x2 s[T];
+    float a[T];
+    bool ok[T];
+    uint32_t idx[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        const int v = tid + j * BLOCK, e = (int) (((uint32_t) v * magic) >> 20), env = env_first + e;
+        ok[j] = e < epb && env < n_envs;
+        idx[j] = (uint32_t) env_first * (uint32_t) S + (uint32_t) v;
+        if (ok[j]) {
+            s[j] = state[idx[j]];
+            a[j] = act[idx[j] + 2u * (uint32_t) env];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < T; j++)
+        if (ok[j]) {
+            s[j].x += a[j] > 0.0f ? 1u : 0u;
+            state[idx[j]] = s[j];
+        }
+    if (tid < 2 * epb) {
+        const int env = env_first + (tid >> 1);
+        if (env < n_envs) {
+            const uint32_t u = (uint32_t) (tid & 1) * (uint32_t) n_envs + (uint32_t) env;
+            const uint32_t p = pk[u];
+            rec[u] = u32x4{p, p + 1u, p + 2u, p + 3u};
+        }
+    }
+}
+
+template <int BLOCK, int T>
+static void run(const char *name, u32x2 *state, float **acts, uint32_t *pk, u32x4 *rec, int N, int S) {
+    const int epb = BLOCK * T / S;
+    const uint32_t magic = (1u << 20) / (uint32_t) S + 1u;
+    const int nb = (N + epb - 1) / epb;
+    hipStream_t st;
+    hipStreamCreate(&st);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 50; i++) hipLaunchKernelGGL((k_stream<BLOCK, T>), dim3(nb), dim3(BLOCK), 0, st, state, acts[i & 7], pk, rec, N, S, epb, magic);
+    const int R = 2000;
+    hipEventRecord(e0, st);
+    for (int i = 0; i < R; i++) hipLaunchKernelGGL((k_stream<BLOCK, T>), dim3(nb), dim3(BLOCK), 0, st, state, acts[i & 7], pk, rec, N, S, epb, magic);
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double) N * (S * 20.0 + 2 * 20.0);
+    printf("%-22s %5d workgroups: %.2f us per launch (back to back), %.0f GB/s of its %.1f MB\n", name, nb, ms / R * 1e3,
+           bytes / (ms / R * 1e-3) / 1e9, bytes / 1e6);
+    hipStreamDestroy(st);
+}
+
+int main(int argc, char **argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 65536, S = argc > 2 ? atoi(argv[2]) : 45;
+    u32x2 *state;
+    uint32_t *pk;
+    u32x4 *rec;
+    float *acts[8];
+    hipMalloc(&state, (size_t) N * S * 8);
+    hipMemset(state, 0, (size_t) N * S * 8);
+    hipMalloc(&pk, (size_t) N * 2 * 4);
+    hipMemset(pk, 0, (size_t) N * 2 * 4);
+    hipMalloc(&rec, (size_t) N * 2 * 16);
+    for (float *&a : acts) {
+        hipMalloc(&a, (size_t) N * (S + 2) * 4);
+        hipMemset(a, 0, (size_t) N * (S + 2) * 4);
+    }
+    hipDeviceSynchronize();
+    printf("%d envs x %d slots: state %.1f MB, one action batch %.1f MB\n", N, S, N * (double) S * 8 / 1e6, N * (S + 2.0) * 4 / 1e6);
+    run<256, 1>("256 lanes x 1 slot", state, acts, pk, rec, N, S);
+    run<256, 2>("256 lanes x 2 slots", state, acts, pk, rec, N, S);
+    run<256, 4>("256 lanes x 4 slots", state, acts, pk, rec, N, S);
+    run<512, 2>("512 lanes x 2 slots", state, acts, pk, rec, N, S);
+    return 0;
+}
