@@ -1,7 +1,8 @@
 // The slot kernel's memory streams without its work: per slot 8 B of state in, 4 B of action in (rows of S + 2 floats), 8 B of state
 // out; per (env, station) 4 B in and 16 B out.  65 536 envs x 45 slots, launched back to back like the step (the 47 MB of state
 // stay in the Infinity Cache from launch to launch, the action batches cycle through 8 x 12 MB).  What it prints is the floor a
-// kernel with these streams and nothing else reaches on this chip, for three shapes of workgroup.
+// kernel with these streams and nothing else reaches on this chip, for four shapes of workgroup -- and then the same with the
+// step's one scattered read added: 16 bytes of a 768 KB table (2 x 2048 class rows of 256 B, resident in L2) for 55 % of the slots.
 //   hipcc --offload-arch=gfx950 -O3 -o stream_slots tools/microbench/stream_slots.hip && ./stream_slots
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -10,9 +11,15 @@
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int BLOCK, int T>
+__device__ __forceinline__ uint32_t mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+template <int BLOCK, int T, int GATHER>
 __global__ __launch_bounds__(BLOCK) void k_stream(u32x2 *__restrict__ state, const float *__restrict__ act, const uint32_t *__restrict__ pk,
-                                                  u32x4 *__restrict__ rec, int n_envs, int S, int epb, uint32_t magic) {
+                                                  u32x4 *__restrict__ rec, int n_envs, int S, int epb, uint32_t magic,
+                                                  const u32x4 *__restrict__ table, uint32_t salt) {
     const int tid = threadIdx.x, env_first = blockIdx.x * epb;
     u32x2 s[T];
     float a[T];
@@ -27,6 +34,27 @@ __global__ __launch_bounds__(BLOCK) void k_stream(u32x2 *__restrict__ state, con
             s[j] = state[idx[j]];
             a[j] = act[idx[j] + 2u * (uint32_t) env];
         }
+    }
+    if (GATHER) {  // the occupied slots' class-row read: address known only when the state is here
+        u32x4 r[T];
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+            const uint32_t h = mix(idx[j] ^ salt ^ s[j].y);
+            r[j] = u32x4{0u, 0u, 0u, 0u};
+            if (ok[j] && h % 100u < 55u) {
+                const char *p = (const char *) table + ((h >> 8) % 4096u) * 256u + ((h >> 24) % 27u) * 8u;
+                if (GATHER == 1) r[j] = *(const u32x4 *) p;                                  // 16 bytes, as the step reads them
+                else if (GATHER == 2) { const u32x2 q = *(const u32x2 *) p; r[j].x = q.x; r[j].w = q.y; }  // 8 bytes
+                else if (GATHER == 3) r[j] = __builtin_nontemporal_load((const u32x4 *) p);  // 16 bytes, nt
+                else {                                                                        // 16 bytes past the vector L1 (agent scope)
+                    const uint64_t q0 = __hip_atomic_load((const uint64_t *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint64_t q1 = __hip_atomic_load((const uint64_t *) p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    r[j].x = (uint32_t) q0; r[j].w = (uint32_t) (q1 >> 32);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < T; j++) s[j].y += r[j].x + r[j].w;
     }
 #pragma unroll
     for (int j = 0; j < T; j++)
@@ -44,8 +72,8 @@ __global__ __launch_bounds__(BLOCK) void k_stream(u32x2 *__restrict__ state, con
     }
 }
 
-template <int BLOCK, int T>
-static void run(const char *name, u32x2 *state, float **acts, uint32_t *pk, u32x4 *rec, int N, int S) {
+template <int BLOCK, int T, int GATHER>
+static void run(const char *name, u32x2 *state, float **acts, uint32_t *pk, u32x4 *rec, int N, int S, const u32x4 *table) {
     const int epb = BLOCK * T / S;
     const uint32_t magic = (1u << 20) / (uint32_t) S + 1u;
     const int nb = (N + epb - 1) / epb;
@@ -54,17 +82,17 @@ static void run(const char *name, u32x2 *state, float **acts, uint32_t *pk, u32x
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 50; i++) hipLaunchKernelGGL((k_stream<BLOCK, T>), dim3(nb), dim3(BLOCK), 0, st, state, acts[i & 7], pk, rec, N, S, epb, magic);
+    for (int i = 0; i < 50; i++) hipLaunchKernelGGL((k_stream<BLOCK, T, GATHER>), dim3(nb), dim3(BLOCK), 0, st, state, acts[i & 7], pk, rec, N, S, epb, magic, table, (uint32_t) i * 2654435761u);
     const int R = 2000;
     hipEventRecord(e0, st);
-    for (int i = 0; i < R; i++) hipLaunchKernelGGL((k_stream<BLOCK, T>), dim3(nb), dim3(BLOCK), 0, st, state, acts[i & 7], pk, rec, N, S, epb, magic);
+    for (int i = 0; i < R; i++) hipLaunchKernelGGL((k_stream<BLOCK, T, GATHER>), dim3(nb), dim3(BLOCK), 0, st, state, acts[i & 7], pk, rec, N, S, epb, magic, table, (uint32_t) i * 2654435761u);
     hipEventRecord(e1, st);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const double bytes = (double) N * (S * 20.0 + 2 * 20.0);
-    printf("%-22s %5d workgroups: %.2f us per launch (back to back), %.0f GB/s of its %.1f MB\n", name, nb, ms / R * 1e3,
-           bytes / (ms / R * 1e-3) / 1e9, bytes / 1e6);
+    printf("%-20s %s %5d workgroups: %.2f us per launch (back to back), %.0f GB/s of its %.1f MB of streams\n", name,
+           GATHER == 0 ? "            " : GATHER == 1 ? "+ gather 16 " : GATHER == 2 ? "+ gather 8  " : GATHER == 3 ? "+ gather nt " : "+ gather sc1", nb, ms / R * 1e3, bytes / (ms / R * 1e-3) / 1e9, bytes / 1e6);
     hipStreamDestroy(st);
 }
 
@@ -85,9 +113,20 @@ int main(int argc, char **argv) {
     }
     hipDeviceSynchronize();
     printf("%d envs x %d slots: state %.1f MB, one action batch %.1f MB\n", N, S, N * (double) S * 8 / 1e6, N * (S + 2.0) * 4 / 1e6);
-    run<256, 1>("256 lanes x 1 slot", state, acts, pk, rec, N, S);
-    run<256, 2>("256 lanes x 2 slots", state, acts, pk, rec, N, S);
-    run<256, 4>("256 lanes x 4 slots", state, acts, pk, rec, N, S);
-    run<512, 2>("512 lanes x 2 slots", state, acts, pk, rec, N, S);
+    u32x4 *table;
+    hipMalloc(&table, 4096 * 256 + 256);
+    hipMemset(table, 1, 4096 * 256 + 256);
+    hipDeviceSynchronize();
+    run<256, 1, 0>("256 lanes x 1 slot", state, acts, pk, rec, N, S, table);
+    run<256, 2, 0>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
+    run<256, 4, 0>("256 lanes x 4 slots", state, acts, pk, rec, N, S, table);
+    run<512, 2, 0>("512 lanes x 2 slots", state, acts, pk, rec, N, S, table);
+    run<256, 1, 1>("256 lanes x 1 slot", state, acts, pk, rec, N, S, table);
+    run<256, 2, 1>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
+    run<256, 4, 1>("256 lanes x 4 slots", state, acts, pk, rec, N, S, table);
+    run<512, 2, 1>("512 lanes x 2 slots", state, acts, pk, rec, N, S, table);
+    run<256, 2, 2>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
+    run<256, 2, 3>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
+    run<256, 2, 4>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
     return 0;
 }
