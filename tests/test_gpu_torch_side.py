@@ -80,6 +80,23 @@ for t in range(100):
     assert np.array_equal(obs, ro) and np.array_equal(rew, rr) and np.array_equal(done, rd), t
 assert abs(hub.comm.max(2.5, hub.shard.stream.ptr) - 2.5) < 1e-12
 hub.comm.barrier(hub.shard.stream.ptr)
+# the same steps issued from C with the communicator (chub_run_steps: what bench.py calls at N > 1): steps 100 .. 199 of the run,
+# a reset at the day boundary inside the span, the last two gathered blocks against the single handle
+import ctypes as C
+sh = hub.shard
+c_acts = (C.c_void_p * 2)(acts[0].ptr, acts[1].ptr)
+c_packed = (C.c_void_p * 2)(sh.packed[0].ptr, sh.packed[1].ptr)
+c_gath = (C.c_void_p * 2)(sh.gathered[0].ptr, sh.gathered[1].ptr)
+multi_gpu.check(sh.vec._lib.chub_run_steps(sh.vec._h, hub.comm._h, c_acts, 2, c_packed, c_gath, sh.reset_obs.ptr, 100, 100, sh.stream.ptr))
+want = {}
+for t in range(100, 200):
+    if t == 192:
+        ref.reset()
+    want[t & 1] = ref.step(host_acts[t & 1])
+D = hub.obs_dim
+for b in (0, 1):
+    full = sh.gathered[b].to_host(np.float32, (n, D + 2), sh.stream.ptr)
+    assert np.array_equal(full[:, :D], want[b][0]) and np.array_equal(full[:, D], want[b][1]) and np.array_equal(full[:, D + 1] > 0.5, want[b][2]), b
 hub.close(); hub.comm.close(); ref.close()
 assert "torch" not in sys.modules
 print("NATIVE_RCCL_OK")
