@@ -1,0 +1,45 @@
+"""bench.py itself on the GPU box, in the short form the driver uses (--steps 20 --warmup 5): the one JSON line and what it must
+carry; and the N > 1 code path (communicator, per-step gather, steps issued from C) on a world of one."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*flags):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5"] + list(flags), cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_short_form_prints_the_contract_line():
+    d = _bench("--no-c5", "--no-cpu-baseline")
+    assert d["metric"].startswith("env-steps/sec") and d["unit"] == "env-steps/s" and d["n_gpus"] == 1
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "65536 envs x hub [20 fast, 25 slow]" in d["config"]["workload"]
+    assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["value"] > 5e8                      # an MI355X steps this workload at > 2 G env-steps/s; a tenth of that = broken
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.2 < r["frac"] < 1.0 and r["launches_sampled"] == 96
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the day average does not depend on where the 20 timed steps fell: the same number the long default run reports (+- box noise)
+    assert 15.0 < r["avg_launch_us"] < 30.0
+    assert d["build_id"] and d["config"]["kernels_per_step"].startswith("2")
+
+
+def test_bench_multi_rank_path_on_a_world_of_one():
+    d = _bench("--force-comm", "--graph", "off", "--no-c5", "--no-cpu-baseline", "--no-events")
+    assert d["n_ranks_seen"] == 1 and d["rccl_comm_count"] == 1 and len(d["ranks"]) == 1 and d["ranks"][0]["rank"] == 0
+    assert "ncclSend/ncclRecv" in d["config"]["collective"] and d["value"] > 2e8
+    assert d["roofline"] is None                  # --no-events: no per-kernel block, never a made-up one
