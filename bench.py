@@ -295,6 +295,74 @@ def c5_roofline(chub, multi_gpu, lib, device, build_id):
     return out
 
 
+def packed_actions_block(chub, multi_gpu, lib, device):
+    """Secondary: the same step with the pile decisions as ONE BIT PER PILE + the two tail floats (chub_step_bits_device; the packed
+    slot kernel reads the bits themselves) instead of the reference's float rows -- all that action_to_real (MGR:384-393) keeps of a
+    row.  Same random policy, same results (tests); 8 B per env and step of action input instead of 4 (S + 2).  Never `value`."""
+    import ctypes as C
+    import numpy as np
+
+    out = {"what": "env-steps/s with one bit per pile + two tail floats as the action input (chub_step_bits_device), hipGraph replays of 2 "
+                   "episodes; kernel times = day averages, calls back to back, every 5th step sampled; the float-row form of the same "
+                   "workloads is `value` / `roofline` (c4) and `roofline_c5`"}
+    for cfg in ("c4", "c5"):
+        n, kw = CONFIGS[cfg]
+        v = chub.VecChargingHub(n, seed=SEED, rng="philox", device=device, **kw)
+        h, A, D, W = v._h, v.act_dim, v.obs_dim, v.bit_words
+        st = multi_gpu.Stream(device)
+        bits, tails = [], []
+        for b in range(4):
+            a = multi_gpu.DeviceBuffer(n * A * 4, device)
+            v.random_actions_device(a.ptr, ACTION_KEY, b, st.ptr)
+            hb, ht = v.pack_actions(a.to_host(np.float32, (n, A), st.ptr))
+            a.free()
+            db, dt = multi_gpu.DeviceBuffer(n * W * 8, device), multi_gpu.DeviceBuffer(n * 2 * 4, device)
+            chub._lib.check(lib.chub_copy_to_device(device, db.ptr, hb.ctypes.data, n * W * 8, st.ptr))
+            chub._lib.check(lib.chub_copy_to_device(device, dt.ptr, ht.ctypes.data, n * 2 * 4, st.ptr))
+            st.sync()
+            bits.append(db)
+            tails.append(dt)
+        obs, rew, done = multi_gpu.DeviceBuffer(n * D * 4, device), multi_gpu.DeviceBuffer(n * 4, device), multi_gpu.DeviceBuffer(n, device)
+
+        def step(i):
+            if i % 96 == 0:
+                v.reset_device(obs.ptr, stream=st.ptr)
+            chub._lib.check(lib.chub_step_bits_device(h, bits[i % 4].ptr, tails[i % 4].ptr, None, obs.ptr, rew.ptr, done.ptr, st.ptr))
+
+        for i in range(192):
+            step(i)
+        st.sync()
+        v.graph_begin(st.ptr)
+        for i in range(192):
+            step(i)
+        g = v.graph_end(st.ptr)
+        v.graph_launch(g, st.ptr)
+        st.sync()
+        reps = 10 if cfg == "c4" else 4
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            v.graph_launch(g, st.ptr)
+        st.sync()
+        per_step = (time.perf_counter() - t0) / (reps * 192)
+        v.graph_destroy(g)
+        for rep in range(2):  # one untimed day, then PROFILE_DAYS days with the dispatch's own timestamps on every 5th step
+            if rep == 1:
+                v.profile_begin(96, every=PROFILE_DAYS)
+            for i in range(96 if rep == 0 else 96 * PROFILE_DAYS):
+                step(i)
+        slot_ms, env_ms, k = v.profile_end()
+        o = obs.to_host(np.float32, (n, D), st.ptr)
+        assert np.isfinite(o).all()
+        out[cfg] = {"value": n / per_step, "unit": "env-steps/s", "ms_per_step": per_step * 1e3, "envs": n, "hub": kw["station_list"],
+                    "slot_kernel_us": slot_ms / k * 1e3, "env_kernel_us": env_ms / k * 1e3, "launches_sampled": k,
+                    "action_bytes_per_env_step": 8 * W + 8}
+        v.close()
+        for buf in bits + tails + [obs, rew, done]:
+            buf.free()
+        st.destroy()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,6 +378,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the untimed profiled day (no `roofline` block)")
     ap.add_argument("--no-c5", action="store_true", help="skip the secondary roofline_c5 block")
+    ap.add_argument("--no-bits", action="store_true", help="skip the secondary packed_actions block (one bit per pile as the action input)")
     ap.add_argument("--fused", choices=["auto", "on", "off"], default="auto",
                     help="the step as ONE launch (k_step_fused); auto: the library's choice (small batches)")
     ap.add_argument("--dry-run", action="store_true",
@@ -573,6 +642,8 @@ def main():
     if rank == 0:
         if world == 1 and config == "c4" and not args.no_c5 and not args.no_events:
             out["roofline_c5"] = c5_roofline(chub, multi_gpu, lib, local_rank, out["build_id"])
+        if world == 1 and config == "c4" and not args.no_bits and not args.no_c5 and not args.no_events:
+            out["packed_actions"] = packed_actions_block(chub, multi_gpu, lib, local_rank)
         if not args.no_cpu_baseline and world == 1 and config == "c4":
             out["cpu_baseline"] = cpu_baseline(hub_kw, total)
         print(json.dumps(out))

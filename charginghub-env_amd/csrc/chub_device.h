@@ -208,6 +208,8 @@ struct StepArgs {
     double price_last;       // env_aggregator.price[-1] seen by this step's make_state
     double price_prev;       // ... and by the previous make_state of a lock-step run: the tariff of the slot before this one
     const float *actions;    // [N][A]
+    const uint64_t *act_bits; // or (chub_step_bits on the packed slot kernel): [N][ceil(S / 64)] one bit per pile, actions = null,
+    const float *act_tail;    //   and [N][2] the two tail actions
     const double *exo_z;     // [N][3] or null
     const int32_t *exo_days; // [N][2] or null (reset)
     float *obs;              // row i at obs + i*obs_stride (dense: stride D; packed: stride D+2)

@@ -1120,7 +1120,9 @@ struct NoHook {
     __device__ __forceinline__ void prefetch() {}
     __device__ __forceinline__ void park() {}
 };
-template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED, bool FUSED, typename Hook>
+// BITS: the pile decisions arrive as one bit per pile ([N][ceil(S / 64)] u64 behind pa.actions) instead of a row of floats:
+// 8 bytes per env and word instead of 4 per pile (chub_step_bits; the tail kernel reads the two tail actions from their own array).
+template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED, bool FUSED, typename Hook, bool BITS = false>
 __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepArgs &sa, PackedArgs &pa, const Tables &tb,
                                                 const uint32_t block_local, uint32_t *q_cnt, uint32_t *q_new,
                                                 uint64_t *s_ball, int *s_acc, uint32_t *s_unit, Hook &hook, u32x4 *s_rec) {
@@ -1146,6 +1148,8 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     uint32_t sidx[T];
     u32x2 s2[T];
     float act[T];
+    u32x2 actw[T];  // BITS: the word of the env's decision bits this slot's bit sits in
+    int hs_[T];
     uint32_t pk_in[T];
 #pragma unroll
     for (int j = 0; j < T; j++) {
@@ -1153,13 +1157,14 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         e_[j] = (int) (((uint32_t) v * pa.magic) >> 20);  // v / (S0 + S1) (magic = 2^20 / St + 1, checked on the host)
         const int hs = v - e_[j] * St;                    // hub slot
         k_[j] = hs >= S0 ? 1 : 0;
+        hs_[j] = hs;
         slot[j] = hs - (k_[j] ? S0 : 0);
         const int env = env_first + e_[j];
         valid[j] = e_[j] < epb && env < N;
         uint32_t served = 1u;  // per-env clocks: is the env served by this launch?  Requested with the state, looked at after it
         if (MASKED && valid[j]) served = pa.env_mask[env];
         sidx[j] = (uint32_t) (k_[j] ? N : 0) + (uint32_t) env;
-        asm volatile("" : "=v"(s2[j]), "=v"(act[j]), "=v"(pk_in[j]));
+        asm volatile("" : "=v"(s2[j]), "=v"(act[j]), "=v"(pk_in[j]), "=v"(actw[j]));
         if (RESET) {
             s2[j] = u32x2{0u, 0u};
             act[j] = 0.0f;
@@ -1167,7 +1172,8 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         if (valid[j]) {
             if (!RESET) {
                 s2[j] = CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) v) << 3);
-                act[j] = CHUB_AT(const float, pa.actions, (idx0 + (uint32_t) v + 2u * (uint32_t) env) << 2);  // row stride S0 + S1 + 2
+                if (BITS) actw[j] = CHUB_AT(const u32x2, pa.actions, ((uint32_t) env * (((uint32_t) St + 63u) >> 6) + ((uint32_t) hs >> 6)) << 3);
+                else act[j] = CHUB_AT(const float, pa.actions, (idx0 + (uint32_t) v + 2u * (uint32_t) env) << 2);  // row stride S0 + S1 + 2
             }
             pk_in[j] = CHUB_AT(const uint32_t, pa.pk, sidx[j] << 2);
         }
@@ -1288,14 +1294,16 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     // their share of calculate_output (CHS.hpp:1233-1261 / 1544-1572)
 #pragma unroll
     for (int j = 0; j < T; j++) {
-        asm volatile("" : "+v"(row[j]), "+v"(act[j]));
+        if (BITS) asm volatile("" : "+v"(row[j]), "+v"(actw[j]));
+        else asm volatile("" : "+v"(row[j]), "+v"(act[j]));
         const int u = 2 * e_[j] + k_[j];
         int *acc = s_acc + 4 * u + (BIG ? 0 : (lane & (kAccCopies - 1)) * 8 * epb);  // the unit's {min, charge power | max power, cars}: two 64-bit LDS atomics per car
         uint32_t w0n = 0u;
         if (stays[j]) {
             const float t_target = __uint_as_float(s2[j].y);
             // action_to_real (MGR:384-393), judge_feasibility (CHS.hpp:1404-1413)
-            const bool on = act[j] >= kActOnThreshold || must_charge(t_target, row[j].y, tl[j]);
+            const bool bit_on = BITS && ((((hs_[j] & 32) ? actw[j].y : actw[j].x) >> (hs_[j] & 31)) & 1u) != 0u;
+            const bool on = (BITS ? bit_on : act[j] >= kActOnThreshold) || must_charge(t_target, row[j].y, tl[j]);
             const float power = on ? row[j].z : row[j].x, t_soc = on ? row[j].w : row[j].y;  // car_step = the next entry of the class row
             const int q = (int) (power * 524288.0f);
             const bool urgent = must_charge(t_target, t_soc, tl[j] - 1);
@@ -1388,7 +1396,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         if (env >= N) continue;
         if (MASKED && pa.env_mask[env] == 0) continue;
         const uint32_t su = (uint32_t) (k ? N : 0) + (uint32_t) env;
-        if (!RESET && !FUSED && k == 0) {  // the env's tail actions sit in the lines this workgroup has just read: hand them to the tail kernel packed
+        if (!RESET && !FUSED && !BITS && k == 0) {  // the env's tail actions sit in the lines this workgroup has just read: hand them to the tail kernel packed
             typedef float f32x2_ __attribute__((ext_vector_type(2)));
             const uint32_t ai = ((uint32_t) env * (uint32_t) (St + 2) + (uint32_t) St) << 2;
             const f32x2_ tv = {CHUB_AT(const float, pa.actions, ai), CHUB_AT(const float, pa.actions, ai + 4u)};
@@ -1436,7 +1444,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     return FUSED ? WAVES : 0;
 }
 
-template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED>
+template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED, bool BITS = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in) {
     __shared__ uint32_t q_new[BLOCK * T];
     __shared__ uint32_t q_cnt[2];
@@ -1450,8 +1458,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_sl
     asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
                       "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
     NoHook hook;
-    (void) slot_body_packed<BLOCK, T, TAPE, RESET, BIG, MASKED, false, NoHook>(ctx->hp, sa, pa, ctx->tb, blockIdx.x + (MASKED ? pa.blk0 : 0u), q_cnt, q_new, s_ball + 1, s_acc,
-                                                                               s_unit, hook, nullptr);
+    (void) slot_body_packed<BLOCK, T, TAPE, RESET, BIG, MASKED, false, NoHook, BITS>(ctx->hp, sa, pa, ctx->tb, blockIdx.x + (MASKED ? pa.blk0 : 0u), q_cnt, q_new,
+                                                                                     s_ball + 1, s_acc, s_unit, hook, nullptr);
 }
 
 // What the tail's first loads need, by value in the kernel arguments: one scalar load at the start of the wave instead
@@ -1486,6 +1494,7 @@ inline TailArgs make_tail_args(const EnvArrays &ev, const StationArrays &st, con
     TailArgs ta;
     const int t_next = reset ? 0 : (sa.t + 1) % 96;
     ta.tail_act = (hp.rng_mode == MODE_PHILOX && hp.packed && !sa.load_mode && !reset) ? (CHUB_G(const float)) st.tail_act : nullptr;
+    if (sa.act_bits && !reset) ta.tail_act = (CHUB_G(const float)) sa.act_tail;  // packed actions: the caller's [N][2] array is that already
     ta.pv_row = (CHUB_G(const double)) (pp.tb->pvT + t_next * 100);
     ta.wd_row = (CHUB_G(const double)) (pp.tb->wdT + t_next * 150);
     ta.pv_row_now = (CHUB_G(const double)) (pp.tb->pvT + (reset ? 0 : sa.t) * 100);
@@ -1611,9 +1620,16 @@ __device__ __forceinline__ void tail_prefetch(TailIn &in, const TailArgs &ta, co
     in.ou_wd = ta.ou[n32 + e32];
     in.ou_price = ta.ou[2u * n32 + e32];
     in.price_noise = ta.price_noise[e32];
-    const uint32_t ai = e32 * ta.act_dim + ta.s_tot;
-    in.a_el = ta.actions[ai];
-    in.a_fc = ta.actions[ai + 1u];
+    if (ta.tail_act) {  // packed actions: the two tail actions have an array of their own
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        const f32x2_ tv = ((CHUB_G(const f32x2_)) ta.tail_act)[e32];
+        in.a_el = tv.x;
+        in.a_fc = tv.y;
+    } else {
+        const uint32_t ai = e32 * ta.act_dim + ta.s_tot;
+        in.a_el = ta.actions[ai];
+        in.a_fc = ta.actions[ai + 1u];
+    }
     in.cap = ta.cap[e32];
     in.pv_day = ta.pv_day[e32];
     in.wd_day = ta.wd_day[e32];
@@ -2251,7 +2267,7 @@ struct TailPrefetch {
     }
 };
 
-template <int BLOCK, int T>
+template <int BLOCK, int T, bool BITS = false>
 __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in, TailArgs ta) {
     static_assert(BLOCK >= 150 && BLOCK / 64 >= 3, "one table element per lane; three waves with work of their own");
     __shared__ uint32_t q_new[BLOCK * T];
@@ -2270,8 +2286,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
         const int le = (int) (threadIdx.x & 63u), env = (int) blockIdx.x * (int) pa_in.epb + le;
         if ((int) (threadIdx.x >> 6) == BLOCK / 64 - 1 && le < (int) pa_in.epb && env < (int) pa_in.n_envs) hook.tail_env = env;
     }
-    const int role = slot_body_packed<BLOCK, T, false, false, false, false, true, TailPrefetch>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
-                                                                                                s_ball + 1, s_acc, s_unit, hook, s_rec);
+    const int role = slot_body_packed<BLOCK, T, false, false, false, false, true, TailPrefetch, BITS>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
+                                                                                                      s_ball + 1, s_acc, s_unit, hook, s_rec);
     constexpr int WAVES = BLOCK / 64;
     const int lane = threadIdx.x & 63;
     const int epb = (int) pa.epb, N = (int) pa.n_envs, env_first = (int) blockIdx.x * epb;
@@ -2596,6 +2612,9 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
                 else CHUB_PACKED(false, true, false);
             } else if (sa.car_tape) {
                 CHUB_PACKED1(true, false, false, false);  // tape mode runs in lock-step
+            } else if (sa.act_bits) {  // one bit per pile (lock-step entry points only: no mask)
+                if (big) CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, false, false, true, false, true>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa);
+                else CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, false, false, false, false, true>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa);
             } else if (big) {
                 CHUB_PACKED(false, false, true);
             } else {
@@ -2624,7 +2643,7 @@ static PackedArgs make_packed_args(const HubParams &hp, const StepArgs &sa, cons
     pa.state = (CHUB_G(uint32_t)) pp.hot;
     pa.rec = (CHUB_G(uint32_t)) pp.rec;
     pa.pk = (CHUB_G(const uint32_t)) pp.pk[sa.tick & 1u];
-    pa.actions = (CHUB_G(const float)) sa.actions;
+    pa.actions = sa.act_bits ? (CHUB_G(const float)) (const void *) sa.act_bits : (CHUB_G(const float)) sa.actions;
     pa.cls0 = (CHUB_G(const float)) pp.cls[0];
     pa.ttab2 = (CHUB_G(const float)) pp.ttab2;
     pa.car_tape = (CHUB_G(const uint32_t)) sa.car_tape;
@@ -2646,8 +2665,13 @@ void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &s
     if (sa.fresh) hipLaunchKernelGGL(k_draw_levels, dim3((unsigned) ((2 * ((int64_t) sa.env_hi - sa.env_lo + 1) + 255) / 256)), dim3(256), 0, stream, ctx, sa);
     const PackedArgs pa = make_packed_args(hp, sa, pp);
     TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa, pp, false);
-    ta.tail_act = nullptr;  // the tails read their two actions from the action rows (the workgroup has just had them in cache)
     const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
+    if (sa.act_bits) {  // one bit per pile: the tails read their two actions from the caller's [N][2] array
+        ta.tail_act = (CHUB_G(const float)) sa.act_tail;
+        CHUB_LAUNCH((k_step_fused<kPackedBlock, kSlotsPerLane, true>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa, ta);
+        return;
+    }
+    ta.tail_act = nullptr;  // the tails read their two actions from the action rows (the workgroup has just had them in cache)
     CHUB_LAUNCH((k_step_fused<kPackedBlock, kSlotsPerLane>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa, ta);
 }
 

@@ -116,6 +116,8 @@ struct chub_env {
     int graph_t0, graph_pc0;
     bool graph_predrawn0;
     bool capturing;
+    const uint64_t *cur_bits;  // set for the duration of chub_step_bits_device on the packed slot kernel: the step reads the
+    const float *cur_tail;     //   decision bits and the tail actions themselves (no action rows)
     const uint64_t *tape_pk;   // set for the duration of chub_step_tape
     const uint32_t *tape_car;
     // optional per-kernel timing with HIP events on the launch stream (chub_profile_*)
@@ -674,6 +676,8 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->tape_classes = 0;
     e->tape_pk = nullptr;
     e->tape_car = nullptr;
+    e->cur_bits = nullptr;
+    e->cur_tail = nullptr;
     e->capturing = false;
     e->graph_base = 0;
     // packed slot kernel (k_slot_packed): the workgroup's virtual lanes laid over whole envs end to end
@@ -1076,6 +1080,8 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     sa.price_last = e->price[e->t];  // AGG:147
     sa.price_prev = e->price[(e->t + 95) % 96];  // what the make_state before this step saw there (the reset: price[95], AGG:171)
     sa.actions = d_actions;
+    sa.act_bits = e->cur_bits;
+    sa.act_tail = e->cur_tail;
     sa.exo_z = d_exo_z;
     sa.obs = d_obs;
     sa.obs_stride = obs_stride;
@@ -1341,8 +1347,9 @@ int chub_step(chub_env *e, const float *actions, const double *exo_z, float *obs
 }
 
 // ---- packed-action form of the host-pointer step: one bit per pile + the two tail floats (16 bytes per env for hubs of up to
-// 64 piles instead of 4 * (S + 2)): what action_to_real (MGR:384-393) keeps of an action row.  The bits are expanded on the
-// device into the action rows the step kernels read, so the step itself is the one chub_step runs, bit for bit.
+// 64 piles instead of 4 * (S + 2)): what action_to_real (MGR:384-393) keeps of an action row.  The packed slot kernel reads
+// the bits themselves (k_slot_packed<.., BITS>: the same step with another action load, bit for bit chub_step's results); for the
+// other kernels they are expanded on the device into the action rows those read.
 static int bits_path_init(chub_env *e) {
     int rc = host_path_init(e);
     if (rc || e->h_bits) return rc;
@@ -1370,6 +1377,15 @@ int chub_step_bits_device(chub_env *e, const uint64_t *d_pile_bits, const float 
     if (!e || !d_pile_bits || !d_tail || !d_obs || !d_reward || !d_done) return fail(CHUB_ERR_ARG, "null argument");
     if (e->tick == 0) return fail(CHUB_ERR_ARG, "step() before reset()");
     HIP_TRY(hipSetDevice(e->device));
+    if (e->hp.packed && e->hp.rng_mode == CHUB_RNG_PHILOX && !e->tape_pk) {
+        // the production kernel reads the bits themselves: 8 bytes per env and word instead of a row of floats (and no expansion)
+        e->cur_bits = d_pile_bits;
+        e->cur_tail = d_tail;
+        const int rc = step_common(e, nullptr, d_exo_z, d_obs, e->hp.obs_dim, d_reward, 1, d_done, nullptr, stream);
+        e->cur_bits = nullptr;
+        e->cur_tail = nullptr;
+        return rc;
+    }
     launch_expand_bits(e->hp, d_pile_bits, d_tail, e->d_actions, (hipStream_t) stream);
     HIP_TRY(hipGetLastError());
     return chub_step_device(e, e->d_actions, d_exo_z, d_obs, d_reward, d_done, stream);

@@ -125,7 +125,10 @@ int chub_host_actions(chub_env *env, float **out);
  * word w = hub slot 64 w + b: station 0's piles first, as in an action row; 1 = on) and tail [N, 2] f32 = the last two entries
  * of the action row, unchanged.  16 bytes per env for hubs of up to 64 piles instead of 4 (S + 2).  Results are bit for bit those of
  * chub_step on any action rows with the same bits and tail.  chub_host_bits: the handle's pinned staging for both arrays (fill in
- * place and pass these pointers to save a staging copy).  The _device form takes device pointers on `stream`. */
+ * place and pass these pointers to save a staging copy).  The _device form takes device pointers on `stream`: on the packed slot
+ * kernel (PHILOX handles; both launch forms, per-env clocks, recordable into graphs) the step reads the bits themselves -- 8 bytes
+ * per env and word of action input instead of a row of floats, and the tail kernel takes the two tail actions from d_tail; on the
+ * other kernels the bits are first expanded into action rows on the device. */
 int chub_step_bits(chub_env *env, const uint64_t *pile_bits, const float *tail, const double *exo_z, float *obs, float *reward,
                    uint8_t *done);
 int chub_host_bits(chub_env *env, uint64_t **pile_bits_out, float **tail_out);

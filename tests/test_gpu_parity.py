@@ -991,6 +991,83 @@ def test_full_size_c5_properties():
         p.close()
 
 
+@pytest.mark.parametrize("fused", ["auto", "off", "on"])
+def test_step_bits_on_the_device_in_every_launch_form(fused):
+    """chub_step_bits_device on the packed slot kernel reads the decision bits themselves (no action rows): the two-launch step,
+    the single-launch step, on per-env clocks after calls on subsets, and recorded into a graph -- always what chub_step_device
+    does with the float rows the bits were packed from"""
+    chub = hub()
+    from charginghub_env_amd import multi_gpu
+    from charginghub_env_amd._lib import check
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.02, renew_fluctuate=0.2, price_fluctuate=0.1)
+    n = 1300
+    a = chub.VecChargingHub(n, seed=5, fused_step=fused, **kw)
+    b = chub.VecChargingHub(n, seed=5, fused_step=fused, **kw)
+    assert a.uses_packed_kernel and a.uses_fused_step == (fused != "off")
+    lib, st = b._lib, multi_gpu.Stream(0)
+    A, D, W = a.act_dim, a.obs_dim, a.bit_words
+    rs = np.random.RandomState(8)
+    d_act = multi_gpu.DeviceBuffer(n * A * 4)
+    d_bits, d_tail = multi_gpu.DeviceBuffer(n * W * 8), multi_gpu.DeviceBuffer(n * 2 * 4)
+    outs = [[multi_gpu.DeviceBuffer(n * D * 4), multi_gpu.DeviceBuffer(n * 4), multi_gpu.DeviceBuffer(n)] for _ in range(2)]
+
+    def upload(act):
+        bits, tail = b.pack_actions(act)
+        check(lib.chub_copy_to_device(0, d_act.ptr, act.ctypes.data, act.nbytes, st.ptr))
+        check(lib.chub_copy_to_device(0, d_bits.ptr, bits.ctypes.data, bits.nbytes, st.ptr))
+        check(lib.chub_copy_to_device(0, d_tail.ptr, tail.ctypes.data, tail.nbytes, st.ptr))
+        st.sync()
+
+    def both_step():
+        check(lib.chub_step_device(a._h, d_act.ptr, None, outs[0][0].ptr, outs[0][1].ptr, outs[0][2].ptr, st.ptr))
+        check(lib.chub_step_bits_device(b._h, d_bits.ptr, d_tail.ptr, None, outs[1][0].ptr, outs[1][1].ptr, outs[1][2].ptr, st.ptr))
+
+    def same(where):
+        for x, y, dt, sh in zip(outs[0], outs[1], (np.float32, np.float32, np.uint8), ((n, D), (n,), (n,))):
+            assert np.array_equal(x.to_host(dt, sh, st.ptr), y.to_host(dt, sh, st.ptr)), where
+        assert all(np.array_equal(x, y) for x, y in zip(a.slots(), b.slots())), where
+        assert np.array_equal(a.station_scalars(), b.station_scalars()), where
+
+    a.reset_device(outs[0][0].ptr, stream=st.ptr)
+    b.reset_device(outs[1][0].ptr, stream=st.ptr)
+    for t in range(12):
+        upload(rs.uniform(-1, 1, size=(n, A)).astype(np.float32))
+        both_step()
+        same(("lock-step", t))
+    # calls on subsets put both handles on per-env clocks (float rows for both: the packed form has no masked entry point) ...
+    mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+    act = rs.uniform(-1, 1, size=(n, A)).astype(np.float32)
+    for v in (a, b):
+        v.reset_envs(mask.astype(bool))
+        v.step_envs((np.arange(n) % 5 != 0), act)
+    # ... on which a call on everybody is again the packed form's business
+    for t in range(6):
+        upload(rs.uniform(-1, 1, size=(n, A)).astype(np.float32))
+        both_step()
+        same(("per-env clocks", t))
+    assert a.clock_groups > 1 and np.array_equal(a.env_clocks(), b.env_clocks())
+    # recorded: four steps of the packed form as one graph, replayed twice, against the float form call by call
+    for v, o in ((a, outs[0]), (b, outs[1])):
+        v.reset_device(o[0].ptr, stream=st.ptr)
+    upload(rs.uniform(-1, 1, size=(n, A)).astype(np.float32))
+    b.graph_begin(st.ptr)
+    for _ in range(4):
+        check(lib.chub_step_bits_device(b._h, d_bits.ptr, d_tail.ptr, None, outs[1][0].ptr, outs[1][1].ptr, outs[1][2].ptr, st.ptr))
+    g = b.graph_end(st.ptr)
+    for rep in range(2):
+        if rep:  # a replay starts from the clock of the capture: a new day for both
+            for v, o in ((a, outs[0]), (b, outs[1])):
+                v.reset_device(o[0].ptr, stream=st.ptr)
+        b.graph_launch(g, st.ptr)
+        for _ in range(4):
+            check(lib.chub_step_device(a._h, d_act.ptr, None, outs[0][0].ptr, outs[0][1].ptr, outs[0][2].ptr, st.ptr))
+        same(("graph", rep))
+    b.graph_destroy(g)
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("label", ["c3", "big_100_70", "one_pile", "max64"])
 def test_step_bits_equals_step_on_the_thresholded_actions(label):
     """chub_step_bits (one bit per pile + the two tail floats over PCIe) against chub_step on the full f32 action rows: the same

@@ -32,7 +32,11 @@ __global__ __launch_bounds__(BLOCK) void k_stream(u32x2 *__restrict__ state, con
         idx[j] = (uint32_t) env_first * (uint32_t) S + (uint32_t) v;
         if (ok[j]) {
             s[j] = state[idx[j]];
-            a[j] = act[idx[j] + 2u * (uint32_t) env];
+            if (GATHER == 5) {  // the action row reduced to one bit per slot: 8 bytes per env
+                const uint64_t w = ((const uint64_t *) act)[env];
+                a[j] = ((w >> ((uint32_t) v - (uint32_t) e * (uint32_t) S)) & 1ull) ? 1.0f : -1.0f;
+            } else if (GATHER == 6) a[j] = __builtin_nontemporal_load(act + idx[j] + 2u * (uint32_t) env);  // the row is read once, ever
+            else a[j] = act[idx[j] + 2u * (uint32_t) env];
         }
     }
     if (GATHER) {  // the occupied slots' class-row read: address known only when the state is here
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(BLOCK) void k_stream(u32x2 *__restrict__ state, con
             r[j] = u32x4{0u, 0u, 0u, 0u};
             if (ok[j] && h % 100u < 55u) {
                 const char *p = (const char *) table + ((h >> 8) % 4096u) * 256u + ((h >> 24) % 27u) * 8u;
-                if (GATHER == 1) r[j] = *(const u32x4 *) p;                                  // 16 bytes, as the step reads them
+                if (GATHER == 1 || GATHER == 5 || GATHER == 6) r[j] = *(const u32x4 *) p;                                  // 16 bytes, as the step reads them
                 else if (GATHER == 2) { const u32x2 q = *(const u32x2 *) p; r[j].x = q.x; r[j].w = q.y; }  // 8 bytes
                 else if (GATHER == 3) r[j] = __builtin_nontemporal_load((const u32x4 *) p);  // 16 bytes, nt
                 else {                                                                        // 16 bytes past the vector L1 (agent scope)
@@ -92,7 +96,7 @@ static void run(const char *name, u32x2 *state, float **acts, uint32_t *pk, u32x
     hipEventElapsedTime(&ms, e0, e1);
     const double bytes = (double) N * (S * 20.0 + 2 * 20.0);
     printf("%-20s %s %5d workgroups: %.2f us per launch (back to back), %.0f GB/s of its %.1f MB of streams\n", name,
-           GATHER == 0 ? "            " : GATHER == 1 ? "+ gather 16 " : GATHER == 2 ? "+ gather 8  " : GATHER == 3 ? "+ gather nt " : "+ gather sc1", nb, ms / R * 1e3, bytes / (ms / R * 1e-3) / 1e9, bytes / 1e6);
+           GATHER == 0 ? "            " : GATHER == 1 ? "+ gather 16 " : GATHER == 2 ? "+ gather 8  " : GATHER == 3 ? "+ gather nt " : GATHER == 4 ? "+ gather sc1" : GATHER == 5 ? "+ gather 16, bit actions" : "+ gather 16, nt action loads", nb, ms / R * 1e3, bytes / (ms / R * 1e-3) / 1e9, bytes / 1e6);
     hipStreamDestroy(st);
 }
 
@@ -128,5 +132,8 @@ int main(int argc, char **argv) {
     run<256, 2, 2>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
     run<256, 2, 3>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
     run<256, 2, 4>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
+    run<256, 2, 5>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
+    run<256, 2, 6>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
+    run<256, 2, 1>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
     return 0;
 }
