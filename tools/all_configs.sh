@@ -5,12 +5,12 @@ TAG=${1:-vX}
 OUT=gpurun_out/round3_${TAG}_all_configs_1gpu.json
 : > $OUT
 for c in c2 c3 c4 c5; do
-  python3 bench.py --config $c --steps 1920 --warmup 384 --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT
+  python3 bench.py --config $c --steps 1920 --warmup 384 --no-cpu-baseline --no-c5 2>/dev/null | tail -1 >> $OUT
 done
 # the per-GPU share of the weak-scaling job (configs[4] over 8 GPUs: 32 768 envs x [32,32] per GPU)
 python3 bench.py --scaling weak --steps 1920 --warmup 384 --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT
 # the multi-GPU call pattern on one GPU: communicator of one rank, gather to itself
-python3 bench.py --force-comm --steps 1920 --warmup 384 --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT
+python3 bench.py --force-comm --steps 1920 --warmup 384 --no-cpu-baseline --no-c5 2>/dev/null | tail -1 >> $OUT
 python3 - $OUT <<'PY'
 import json, sys
 for line in open(sys.argv[1]):
@@ -20,3 +20,6 @@ for line in open(sys.argv[1]):
           % (d["value"] / 1e6, d["ms_per_step"] * 1e3, r["avg_launch_us"], r["env_kernel_avg_launch_us"], r["frac"],
              d["roofline_step"]["frac"], d["config"]["collective"][:30]))
 PY
+# the same workloads with one bit per pile as the action input (chub_step_bits_device), next to the float rows
+for c in c2 c3 c4 c5; do python3 tools/bits_device_rate.py $c; done > gpurun_out/round3_${TAG}_packed_actions.txt 2>&1
+cat gpurun_out/round3_${TAG}_packed_actions.txt
