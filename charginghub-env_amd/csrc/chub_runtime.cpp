@@ -1372,23 +1372,39 @@ int chub_host_bits(chub_env *e, uint64_t **bits_out, float **tail_out) {
     return CHUB_OK;
 }
 
-int chub_step_bits_device(chub_env *e, const uint64_t *d_pile_bits, const float *d_tail, const double *d_exo_z, float *d_obs,
-                          float *d_reward, uint8_t *d_done, void *stream) {
-    if (!e || !d_pile_bits || !d_tail || !d_obs || !d_reward || !d_done) return fail(CHUB_ERR_ARG, "null argument");
+// dense outputs (d_reward, d_done) or the packed block (d_packed: obs at stride D + 2, reward and done as floats behind each row)
+static int step_bits_device(chub_env *e, const uint64_t *d_pile_bits, const float *d_tail, const double *d_exo_z, float *d_obs,
+                            float *d_reward, uint8_t *d_done, float *d_packed, void *stream) {
     if (e->tick == 0) return fail(CHUB_ERR_ARG, "step() before reset()");
     HIP_TRY(hipSetDevice(e->device));
+    const int D = e->hp.obs_dim;
+    const float *rows = nullptr;
     if (e->hp.packed && e->hp.rng_mode == CHUB_RNG_PHILOX && !e->tape_pk) {
         // the production kernel reads the bits themselves: 8 bytes per env and word instead of a row of floats (and no expansion)
         e->cur_bits = d_pile_bits;
         e->cur_tail = d_tail;
-        const int rc = step_common(e, nullptr, d_exo_z, d_obs, e->hp.obs_dim, d_reward, 1, d_done, nullptr, stream);
-        e->cur_bits = nullptr;
-        e->cur_tail = nullptr;
-        return rc;
+    } else {
+        launch_expand_bits(e->hp, d_pile_bits, d_tail, e->d_actions, (hipStream_t) stream);
+        HIP_TRY(hipGetLastError());
+        rows = e->d_actions;
     }
-    launch_expand_bits(e->hp, d_pile_bits, d_tail, e->d_actions, (hipStream_t) stream);
-    HIP_TRY(hipGetLastError());
-    return chub_step_device(e, e->d_actions, d_exo_z, d_obs, d_reward, d_done, stream);
+    const int rc = d_packed ? step_common(e, rows, d_exo_z, d_packed, D + 2, d_packed + D, D + 2, nullptr, d_packed + D + 1, stream)
+                            : step_common(e, rows, d_exo_z, d_obs, D, d_reward, 1, d_done, nullptr, stream);
+    e->cur_bits = nullptr;
+    e->cur_tail = nullptr;
+    return rc;
+}
+
+int chub_step_bits_device(chub_env *e, const uint64_t *d_pile_bits, const float *d_tail, const double *d_exo_z, float *d_obs,
+                          float *d_reward, uint8_t *d_done, void *stream) {
+    if (!e || !d_pile_bits || !d_tail || !d_obs || !d_reward || !d_done) return fail(CHUB_ERR_ARG, "null argument");
+    return step_bits_device(e, d_pile_bits, d_tail, d_exo_z, d_obs, d_reward, d_done, nullptr, stream);
+}
+
+int chub_step_bits_device_packed(chub_env *e, const uint64_t *d_pile_bits, const float *d_tail, const double *d_exo_z, float *d_packed,
+                                 void *stream) {
+    if (!e || !d_pile_bits || !d_tail || !d_packed) return fail(CHUB_ERR_ARG, "null argument");
+    return step_bits_device(e, d_pile_bits, d_tail, d_exo_z, nullptr, nullptr, nullptr, d_packed, stream);
 }
 
 int chub_step_bits(chub_env *e, const uint64_t *pile_bits, const float *tail, const double *exo_z, float *obs, float *reward,

@@ -260,6 +260,14 @@ class VecChargingHub(object):
         """One [N, D+2] f32 output buffer: obs, reward, done -- what a shard sends in the per-step RCCL gather."""
         check(self._lib.chub_step_device_packed(self._h, d_actions, d_exo_z or None, d_packed, stream or None))
 
+    def step_bits_device(self, d_pile_bits, d_tail, d_obs, d_reward, d_done, d_exo_z=0, stream=0):
+        """the device-pointer step fed one bit per pile ([N, bit_words] u64) + the two tail floats ([N, 2] f32) instead of action rows:
+        on the packed slot kernel the step reads the bits themselves (chub_step_bits_device)"""
+        check(self._lib.chub_step_bits_device(self._h, d_pile_bits, d_tail, d_exo_z or None, d_obs, d_reward, d_done, stream or None))
+
+    def step_bits_device_packed(self, d_pile_bits, d_tail, d_packed, d_exo_z=0, stream=0):
+        check(self._lib.chub_step_bits_device_packed(self._h, d_pile_bits, d_tail, d_exo_z or None, d_packed, stream or None))
+
     def random_actions_device(self, d_actions, key, batch, stream=0):
         check(self._lib.chub_random_actions_device(self._h, int(key), int(batch), d_actions, stream or None))
 

@@ -275,6 +275,9 @@ class TorchHubVecEnv(object):
             raise AssertionError("actions must be a contiguous float32 CUDA tensor of shape (%d, %d)"
                                  % (self.num_envs, self.act_dim))
         self.vec.step_device_packed(a.data_ptr(), self._packed.data_ptr(), stream=self._stream())
+        return self._after_step()
+
+    def _after_step(self):
         D = self.obs_dim
         obs, reward, done = self._packed[:, :D], self._packed[:, D], self._packed[:, D + 1] > 0.5
         self._t += 1
@@ -283,6 +286,29 @@ class TorchHubVecEnv(object):
             reward, done = reward.clone(), done.clone()
             obs = self.reset()
         return obs, reward, done, {}
+
+    def pack_bits(self, actions):
+        """[N, A] float32 CUDA action rows -> (pile_bits [N, W] int64, tail [N, 2] float32), on the device: what action_to_real
+        (evcssp_manager.py:384-393) keeps of them (pile on iff a >= -2^-25).  A policy that samples on / off decisions can build
+        the bits itself and never materialise the rows."""
+        torch = self.torch
+        S, W = self.vec.n_slots, self.vec.bit_words
+        on = (actions[:, :S] >= -2.0 ** -25).to(torch.int64)
+        if S < 64 * W:
+            on = torch.nn.functional.pad(on, (0, 64 * W - S))
+        sh = torch.arange(64, device=actions.device, dtype=torch.int64)
+        bits = (on.view(-1, W, 64) << sh).sum(dim=2)  # bit 63 lands in the sign bit: the same 64 bits as the unsigned word
+        return bits.contiguous(), actions[:, S:].contiguous()
+
+    def step_bits(self, pile_bits, tail):
+        """step() fed one bit per pile + the two tail floats (pack_bits' layout) instead of action rows: 8 W + 8 bytes of action input
+        per env instead of 4 (S + 2); on the packed slot kernel the step reads the bits themselves"""
+        torch, N, W = self.torch, self.num_envs, self.vec.bit_words
+        if not (pile_bits.is_cuda and pile_bits.dtype == torch.int64 and pile_bits.is_contiguous() and tuple(pile_bits.shape) == (N, W)
+                and tail.is_cuda and tail.dtype == torch.float32 and tail.is_contiguous() and tuple(tail.shape) == (N, 2)):
+            raise AssertionError("pile_bits must be a contiguous int64 CUDA tensor of shape (%d, %d), tail float32 (%d, 2)" % (N, W, N))
+        self.vec.step_bits_device_packed(pile_bits.data_ptr(), tail.data_ptr(), self._packed.data_ptr(), stream=self._stream())
+        return self._after_step()
 
     def close(self):
         self.vec.close()

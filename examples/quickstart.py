@@ -80,6 +80,14 @@ def device_resident(n=65536):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("3. %d envs on the device: %.0f M env-steps/s, mean reward %.4f" % (n, n * steps / dt / 1e6, float(reward.mean())))
+    # a policy that emits on / off decisions hands over one bit per pile (+ the two tail floats) instead of a row of floats
+    bits, tail = env.pack_bits(actions)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        obs, reward, done, _ = env.step_bits(bits, tail)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("   the same decisions as bits: %.0f M env-steps/s" % (n * steps / dt / 1e6))
     env.close()
 
 

@@ -134,6 +134,9 @@ int chub_step_bits(chub_env *env, const uint64_t *pile_bits, const float *tail, 
 int chub_host_bits(chub_env *env, uint64_t **pile_bits_out, float **tail_out);
 int chub_step_bits_device(chub_env *env, const uint64_t *d_pile_bits, const float *d_tail, const double *d_exo_z, float *d_obs,
                           float *d_reward, uint8_t *d_done, void *stream);
+/* ... with the outputs of chub_step_device_packed: one [N, D + 2] f32 block (obs, reward, done as 0 / 1) */
+int chub_step_bits_device_packed(chub_env *env, const uint64_t *d_pile_bits, const float *d_tail, const double *d_exo_z, float *d_packed,
+                                 void *stream);
 
 /* Same, all pointers device memory, enqueued on `stream` (a hipStream_t, NULL = default stream);
  * returns after enqueueing.  This is the form the multi-GPU host and bench.py use. */

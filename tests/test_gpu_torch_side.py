@@ -135,6 +135,25 @@ for t in range(100):
         assert t == 95 and np.array_equal(tv.last_obs.cpu().numpy(), ro)
         ro = ref.reset()
     assert np.array_equal(obs.cpu().numpy(), ro), t
+# the packed-action form: bits built on the device from the same rows, the same results as step()
+tb = chub.TorchHubVecEnv(n, seed=3, **kw)
+ref.close()
+ref = chub.VecChargingHub(n, seed=3, **kw)      # a fresh handle: the Philox ticks count a handle's launches
+tb.reset(); ref.reset()
+for t in range(100):
+    a = torch.rand((n, 47), device="cuda", generator=g) * 2 - 1
+    if t % 7 == 0:
+        a[:, :45] = -2.0 ** -25 if t % 2 else float(np.nextafter(np.float32(-2.0 ** -25), np.float32(-1)))
+    bits, tail = tb.pack_bits(a)
+    hb, _ = ref.pack_actions(a.cpu().numpy())
+    assert np.array_equal(bits.cpu().numpy().view(np.uint64), hb), t
+    obs, rew, done, info = tb.step_bits(bits, tail)
+    ro, rr, rd, _ = ref.step(a.cpu().numpy())
+    assert np.array_equal(rew.cpu().numpy(), rr) and np.array_equal(done.cpu().numpy(), rd), t
+    if rd.all():
+        ro = ref.reset()
+    assert np.array_equal(obs.cpu().numpy(), ro), t
+tb.close()
 try:
     tv.step(torch.zeros((n, 46), device="cuda"))
     raise SystemExit("shape check missing")
