@@ -76,6 +76,76 @@ __global__ __launch_bounds__(BLOCK) void k_stream(u32x2 *__restrict__ state, con
     }
 }
 
+// What a 4-byte slot state would buy (and cost): 4 B in / out per slot instead of 8, the class-row gather as before, plus a 4-byte
+// read of a 4 KB table (the target time behind a 10-bit level: resident in the vector L1) for the same slots.
+template <int BLOCK, int T, bool BITS>
+__global__ __launch_bounds__(BLOCK) void k_stream4(uint32_t *__restrict__ state, const float *__restrict__ act, const uint32_t *__restrict__ pk,
+                                                   u32x4 *__restrict__ rec, int n_envs, int S, int epb, uint32_t magic,
+                                                   const u32x4 *__restrict__ table, const float *__restrict__ ttab, uint32_t salt) {
+    const int tid = threadIdx.x, env_first = blockIdx.x * epb;
+    uint32_t s[T], idx[T];
+    float a[T];
+    bool ok[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        const int v = tid + j * BLOCK, e = (int) (((uint32_t) v * magic) >> 20), env = env_first + e;
+        ok[j] = e < epb && env < n_envs;
+        idx[j] = (uint32_t) env_first * (uint32_t) S + (uint32_t) v;
+        if (ok[j]) {
+            s[j] = state[idx[j]];
+            if (BITS) {
+                const uint64_t w = ((const uint64_t *) act)[env];
+                a[j] = ((w >> ((uint32_t) v - (uint32_t) e * (uint32_t) S)) & 1ull) ? 1.0f : -1.0f;
+            } else a[j] = act[idx[j] + 2u * (uint32_t) env];
+        }
+    }
+    u32x4 r[T];
+    float tt[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        const uint32_t h = mix(idx[j] ^ salt ^ s[j]);
+        r[j] = u32x4{0u, 0u, 0u, 0u};
+        tt[j] = 0.0f;
+        if (ok[j] && h % 100u < 55u) {
+            r[j] = *(const u32x4 *) ((const char *) table + ((h >> 8) % 4096u) * 256u + ((h >> 24) % 27u) * 8u);
+            tt[j] = ttab[(h >> 4) % 1000u];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < T; j++)
+        if (ok[j]) state[idx[j]] = s[j] + r[j].x + r[j].w + (tt[j] + a[j] > 0.0f ? 1u : 0u);
+    if (tid < 2 * epb) {
+        const int env = env_first + (tid >> 1);
+        if (env < n_envs) {
+            const uint32_t u = (uint32_t) (tid & 1) * (uint32_t) n_envs + (uint32_t) env;
+            const uint32_t p = pk[u];
+            rec[u] = u32x4{p, p + 1u, p + 2u, p + 3u};
+        }
+    }
+}
+
+template <int BLOCK, int T, bool BITS>
+static void run4(const char *name, uint32_t *state, float **acts, uint32_t *pk, u32x4 *rec, int N, int S, const u32x4 *table, const float *ttab) {
+    const int epb = BLOCK * T / S;
+    const uint32_t magic = (1u << 20) / (uint32_t) S + 1u;
+    const int nb = (N + epb - 1) / epb;
+    hipStream_t st;
+    hipStreamCreate(&st);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 50; i++) hipLaunchKernelGGL((k_stream4<BLOCK, T, BITS>), dim3(nb), dim3(BLOCK), 0, st, state, acts[i & 7], pk, rec, N, S, epb, magic, table, ttab, (uint32_t) i);
+    const int R = 2000;
+    hipEventRecord(e0, st);
+    for (int i = 0; i < R; i++) hipLaunchKernelGGL((k_stream4<BLOCK, T, BITS>), dim3(nb), dim3(BLOCK), 0, st, state, acts[i & 7], pk, rec, N, S, epb, magic, table, ttab, (uint32_t) i * 2654435761u);
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-20s 4-byte state + gather 16 + 4 B of a 4 KB table%s %5d workgroups: %.2f us per launch\n", name, BITS ? ", bit actions" : "", nb, ms / R * 1e3);
+    hipStreamDestroy(st);
+}
+
 template <int BLOCK, int T, int GATHER>
 static void run(const char *name, u32x2 *state, float **acts, uint32_t *pk, u32x4 *rec, int N, int S, const u32x4 *table) {
     const int epb = BLOCK * T / S;
@@ -135,5 +205,11 @@ int main(int argc, char **argv) {
     run<256, 2, 5>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
     run<256, 2, 6>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
     run<256, 2, 1>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
+    float *ttab;
+    hipMalloc(&ttab, 4096);
+    hipMemset(ttab, 0, 4096);
+    hipDeviceSynchronize();
+    run4<256, 2, false>("256 lanes x 2 slots", (uint32_t *) state, acts, pk, rec, N, S, table, ttab);
+    run4<256, 2, true>("256 lanes x 2 slots", (uint32_t *) state, acts, pk, rec, N, S, table, ttab);
     return 0;
 }
