@@ -124,6 +124,67 @@ __global__ __launch_bounds__(BLOCK) void k_stream4(uint32_t *__restrict__ state,
     }
 }
 
+// Two ADJACENT slots per lane: one 16-byte state load and store and one 8-byte action load per lane instead of two of each
+// (the action pair is read as if no env boundary fell between the two slots: a floor, not a layout proposal).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_stream_adj(u32x4 *__restrict__ state2, const float *__restrict__ act, const uint32_t *__restrict__ pk,
+                                                     u32x4 *__restrict__ rec, int n_envs, int S, int epb, uint32_t magic,
+                                                     const u32x4 *__restrict__ table, uint32_t salt) {
+    const int tid = threadIdx.x, env_first = blockIdx.x * epb;
+    const int v = 2 * tid, e = (int) (((uint32_t) v * magic) >> 20), env = env_first + e;
+    const bool ok = e < epb && env < n_envs;
+    const uint32_t idx = (uint32_t) env_first * (uint32_t) S + (uint32_t) v;
+    u32x4 s = {0u, 0u, 0u, 0u};
+    float a0 = 0.0f, a1 = 0.0f;
+    if (ok) {
+        s = *(const u32x4 *) ((const char *) state2 + (size_t) idx * 8u);
+        const float *ap = act + idx + 2u * (uint32_t) env;
+        a0 = ap[0];
+        a1 = ap[1];
+    }
+    u32x4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+    const uint32_t h0 = mix(idx ^ salt ^ s.y), h1 = mix((idx + 1u) ^ salt ^ s.w);
+    if (ok && h0 % 100u < 55u) r0 = *(const u32x4 *) ((const char *) table + ((h0 >> 8) % 4096u) * 256u + ((h0 >> 24) % 27u) * 8u);
+    if (ok && h1 % 100u < 55u) r1 = *(const u32x4 *) ((const char *) table + ((h1 >> 8) % 4096u) * 256u + ((h1 >> 24) % 27u) * 8u);
+    if (ok) {
+        s.x += a0 > 0.0f ? 1u : 0u;
+        s.y += r0.x + r0.w;
+        s.z += a1 > 0.0f ? 1u : 0u;
+        s.w += r1.x + r1.w;
+        *(u32x4 *) ((char *) state2 + (size_t) idx * 8u) = s;
+    }
+    if (tid < 2 * epb) {
+        const int env2 = env_first + (tid >> 1);
+        if (env2 < n_envs) {
+            const uint32_t u = (uint32_t) (tid & 1) * (uint32_t) n_envs + (uint32_t) env2;
+            const uint32_t p = pk[u];
+            rec[u] = u32x4{p, p + 1u, p + 2u, p + 3u};
+        }
+    }
+}
+
+template <int BLOCK>
+static void run_adj(const char *name, u32x2 *state, float **acts, uint32_t *pk, u32x4 *rec, int N, int S, const u32x4 *table) {
+    const int epb = BLOCK * 2 / S;
+    const uint32_t magic = (1u << 20) / (uint32_t) S + 1u;
+    const int nb = (N + epb - 1) / epb;
+    hipStream_t st;
+    hipStreamCreate(&st);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 50; i++) hipLaunchKernelGGL((k_stream_adj<BLOCK>), dim3(nb), dim3(BLOCK), 0, st, (u32x4 *) state, acts[i & 7], pk, rec, N, S, epb, magic, table, (uint32_t) i);
+    const int R = 2000;
+    hipEventRecord(e0, st);
+    for (int i = 0; i < R; i++) hipLaunchKernelGGL((k_stream_adj<BLOCK>), dim3(nb), dim3(BLOCK), 0, st, (u32x4 *) state, acts[i & 7], pk, rec, N, S, epb, magic, table, (uint32_t) i * 2654435761u);
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-20s two ADJACENT slots per lane (16-byte state accesses) + gather 16 %5d workgroups: %.2f us per launch\n", name, nb, ms / R * 1e3);
+    hipStreamDestroy(st);
+}
+
 template <int BLOCK, int T, bool BITS>
 static void run4(const char *name, uint32_t *state, float **acts, uint32_t *pk, u32x4 *rec, int N, int S, const u32x4 *table, const float *ttab) {
     const int epb = BLOCK * T / S;
@@ -209,6 +270,7 @@ int main(int argc, char **argv) {
     hipMalloc(&ttab, 4096);
     hipMemset(ttab, 0, 4096);
     hipDeviceSynchronize();
+    run_adj<256>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
     run4<256, 2, false>("256 lanes x 2 slots", (uint32_t *) state, acts, pk, rec, N, S, table, ttab);
     run4<256, 2, true>("256 lanes x 2 slots", (uint32_t *) state, acts, pk, rec, N, S, table, ttab);
     return 0;
