@@ -74,7 +74,7 @@ struct SlotArrays {          // index = base_k + env*S_k + slot  (station-major)
     //   .z t_soc     soc_to_time(soc)      -- cached, what car_step and calculate_needed both need
     //   .w bits 0-6 stay_time - already_stay_time (0 = empty), bit 7 charging this step, bits 8-14 stay_time,
     //      bits 15-24 target-SoC level l (target = 80 + 20 * l / 999, CHS.hpp:35-44), bits 25-31 car_steps taken since arrival
-    CHUB_G(uint32_t) hot;    // COMPAT [NS][4], station-major; PHILOX [N][S0 + S1][2]: the 8-byte slot state described in
+    CHUB_G(uint32_t) hot;    // COMPAT [NS][4], station-major; PHILOX [2][N][S0 + S1] (plane 0: w0, plane 1: w1): the 8-byte slot state described in
                              // chub_kernels.hip, hub-major (station 0's piles, then station 1's, like an action row)
     // cold: written once per arriving car, read only by introspection.  Current SoC = arrival SoC advanced by the
     // recorded number of car_steps (k_replay_soc), target SoC from its level; slots without a car read as zeros.

@@ -47,6 +47,11 @@ __device__ __forceinline__ bool range_unit(const StepArgs &sa, int64_t i, int se
     env = sa.env_lo + (i - (int64_t) seg * R);
     return true;
 }
+// PHILOX slot state: the 8 bytes of a slot live in two planes of one array, [w0 of every slot][w1 of every slot] (slots hub-major in
+// both).  w0 changes every step of a car's stay; w1 (the target time) is written when the car is admitted and only read afterwards,
+// so a step moves 12 bytes of state per slot instead of 16.  The w1 of an empty slot is whatever its last car left: never looked at.
+__device__ __forceinline__ u32x2 ps_load(CHUB_G(const uint32_t) hot, uint32_t slots, uint32_t idx) { return u32x2{hot[idx], hot[slots + idx]}; }
+
 __device__ __forceinline__ int clk_t(uint32_t c) { return (int) (c & 127u); }
 __device__ __forceinline__ uint32_t clk_next(uint32_t c) {  // one step later: slot of day + 1 (mod 96), price_count + 1 (mod 4)
     return (uint32_t) ((clk_t(c) + 1) % 96) | ((((c >> 8) + 1u) & 3u) << 8);
@@ -675,7 +680,7 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     float a = 0.0f;
     if (unit_ok) pk_in = st.pk[sa.tick & 1u][sidx];
     if (!RESET && valid) {
-        s2 = ((CHUB_G(u32x2)) sl.hot)[idx];
+        s2 = ps_load(sl.hot, (uint32_t) N * (uint32_t) (hp.S[0] + hp.S[1]), idx);
         a = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot];
     }
     uint32_t w0 = s2.x, w1 = s2.y;
@@ -768,8 +773,8 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     const int cars = __popcll(__ballot(car) & unit_mask);
 
     if (valid) {
-        const u32x2 o2 = {w0, w1};
-        ((CHUB_G(u32x2)) sl.hot)[idx] = o2;
+        sl.hot[idx] = w0;
+        if (adm) sl.hot[(uint32_t) N * (uint32_t) (hp.S[0] + hp.S[1]) + idx] = w1;  // the target time: written once, at admission
     }
     if (unit_ok && slot == 0) {
         rec_store(st.rec, sidx, fixed_to_kw(i_min), fixed_to_kw(i_chg), fixed_to_kw(i_max), pkd_make(line, flow, cars));
@@ -821,7 +826,7 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
             tl = (int) (hot.w & 127u);
             meta = (int) (hot.w >> 8);
         } else {
-            const u32x2 s2 = ((CHUB_G(u32x2)) sl.hot)[idx];
+            const u32x2 s2 = ps_load(sl.hot, (uint32_t) N * (uint32_t) (hp.S[0] + hp.S[1]), idx);
             w0 = s2.x; w1 = s2.y;
             tl = ps_tl(w0);
             if (tl > 0) {
@@ -1035,8 +1040,8 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
             ((CHUB_G(u32x4)) sl.hot)[idx] = h2;
             if (adm) sl.init_soc[idx] = nc_soc;
         } else {
-            const u32x2 o2 = {w0, w1};
-            ((CHUB_G(u32x2)) sl.hot)[idx] = o2;
+            sl.hot[idx] = w0;
+            if (adm) sl.hot[(uint32_t) N * (uint32_t) (hp.S[0] + hp.S[1]) + idx] = w1;
         }
     }
     __syncthreads();
@@ -1081,7 +1086,7 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
 struct PackedArgs {
     uint32_t S[2], type[2];
     uint32_t n_envs, epb, magic, cls_delta;  // envs per workgroup; 2^20 / (S0 + S1) + 1; byte distance cls[1] - cls[0]
-    CHUB_G(uint32_t) state;          // [N][S0 + S1][2]
+    CHUB_G(uint32_t) state;          // [2][N][S0 + S1]: the w0 plane, then the w1 plane
     CHUB_G(uint32_t) rec;
     CHUB_G(const uint32_t) pk;       // this step's station draws per unit, decoded (dk_make); RESET: the raw initial-occupancy draws
     CHUB_G(const float) actions;
@@ -1171,7 +1176,8 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         }
         if (valid[j]) {
             if (!RESET) {
-                s2[j] = CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) v) << 3);
+                s2[j].x = CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) v) << 2);
+                s2[j].y = CHUB_AT(uint32_t, pa.state, ((uint32_t) N * (uint32_t) St + idx0 + (uint32_t) v) << 2);  // the w1 plane
                 if (BITS) actw[j] = CHUB_AT(const u32x2, pa.actions, ((uint32_t) env * (((uint32_t) St + 63u) >> 6) + ((uint32_t) hs >> 6)) << 3);
                 else act[j] = CHUB_AT(const float, pa.actions, (idx0 + (uint32_t) v + 2u * (uint32_t) env) << 2);  // row stride S0 + S1 + 2
             }
@@ -1321,10 +1327,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
                 if (on) atomicAdd(a64 + 1, (unsigned long long) q);
             }
         }
-        if (valid[j] && !adm[j]) {
-            const u32x2 o2 = {w0n, s2[j].y};
-            CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) (tid + j * BLOCK)) << 3) = o2;
-        }
+        if (valid[j] && !adm[j]) CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) (tid + j * BLOCK)) << 2) = w0n;  // w1 stays as it is
         if (valid[j] && slot[j] == 0) s_unit[u] = pkd_make(line[j], flow[j], 0);
     }
     __syncthreads();
@@ -1366,8 +1369,8 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         asm volatile("" : "+v"(e0), "+v"(tt_));  // both lookups in flight together
         int st_ = (int) ceilf(__fsub_rn(tt_, e0.y)) + late;  // calculate_min_charging_time + mk_late_time
         st_ = st_ > kMaxStay ? kMaxStay : st_;
-        const u32x2 o2 = {st_ > 0 ? ps_make(st_, c) : 0u, __float_as_uint(tt_)};
-        CHUB_AT(u32x2, pa.state, (idx0 + (uint32_t) src) << 3) = o2;
+        CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) src) << 2) = st_ > 0 ? ps_make(st_, c) : 0u;
+        CHUB_AT(uint32_t, pa.state, ((uint32_t) N * (uint32_t) St + idx0 + (uint32_t) src) << 2) = __float_as_uint(tt_);  // the w1 plane: written here only
         if (st_ > 0) {
             const int q = (int) (e0.x * 524288.0f);
             if (!BIG) {
@@ -2466,7 +2469,7 @@ __global__ void k_replay_soc(const DevCtx *__restrict__ ctx, float *out) {
     int n = 0;
     bool car;
     if (hp.rng_mode == MODE_PHILOX) {  // arrival SoC of the slot's class, car_steps from the state word
-        const uint32_t w0 = ctx->sl.hot[2 * idx];
+        const uint32_t w0 = ctx->sl.hot[idx];  // the w0 plane
         car = ps_tl(w0) != 0;
         if (car) {
             soc = ctx->tb.cls_soc0[k][ps_cls(w0)];

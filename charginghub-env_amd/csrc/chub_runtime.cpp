@@ -751,7 +751,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
     e->sl.init_soc = nullptr;
     if (rng_mode == CHUB_RNG_PHILOX) {
-        ALLOC(e->sl.hot, 2 * NS);  // 8-byte slot state
+        ALLOC(e->sl.hot, 2 * NS);  // 8-byte slot state, as two planes of 4 bytes per slot
     } else {
         ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.init_soc, NS);
     }
@@ -1703,8 +1703,8 @@ int chub_set_slots(chub_env *e, const int32_t *rows) {
                     r[4] >= kClsRow)
                     return fail(CHUB_ERR_ARG, "chub_set_slots: field out of range");
                 const size_t idx = env * S + (k ? (size_t) hp.S[0] : 0) + i;  // PHILOX state is hub-major
-                st[2 * idx] = (uint32_t) left | (r[5] ? 64u : 0u) | ((uint32_t) r[2] << 7) | ((uint32_t) r[4] << 13) | ((uint32_t) r[0] << 18);
-                memcpy(&st[2 * idx + 1], &e->h_ttab[k][(size_t) r[1]], 4);
+                st[idx] = (uint32_t) left | (r[5] ? 64u : 0u) | ((uint32_t) r[2] << 7) | ((uint32_t) r[4] << 13) | ((uint32_t) r[0] << 18);
+                memcpy(&st[N * S + idx], &e->h_ttab[k][(size_t) r[1]], 4);  // the w1 plane
             }
     HIP_TRY(hipMemcpy(e->sl.hot, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return CHUB_OK;
@@ -1810,7 +1810,7 @@ int chub_get_slots(chub_env *e, float *out) {
                 int left, stay, lev;
                 bool chg;
                 if (philox) {  // 8-byte state: everything else comes from the class row (see chub_kernels.hip)
-                    const uint32_t w0 = hot[2 * idx], w1 = hot[2 * idx + 1];
+                    const uint32_t w0 = hot[idx], w1 = hot[NS + idx];  // two planes (chub_kernels.hip, ps_load)
                     left = (int) (w0 & 63u); chg = (w0 & 64u) != 0; stay = (int) ((w0 >> 7) & 63u); lev = 0;
                     if (left > 0) {
                         const size_t c = (size_t) (w0 >> 18), at = (c * kClsRow + ((w0 >> 13) & 31u)) * 2;
