@@ -363,6 +363,76 @@ def packed_actions_block(chub, multi_gpu, lib, device):
     return out
 
 
+def dropin_block(chub, multi_gpu, lib, device):
+    """Secondary: the two paths a user of the reference's own class hits.  (i) EvcsspManagerEnv_v6.step() for ONE env (BASELINE.json
+    configs[0]: test/env_test.py's loop; the reference's CPU step takes about 220 us) in the reference-exact
+    COMPAT mode and with the device generator: microseconds per step() call, wall clock, whole episodes incl. their reset().
+    (ii) the reference-exact COMPAT mode as a batch: env-steps/s at 4 096 and 65 536 envs, device-resident inputs, call by call
+    (COMPAT takes its exogenous normals from the caller every step, so it is not graph-captured).  Never `value`."""
+    import numpy as np
+
+    out = {"what": "us per EvcsspManagerEnv_v6.step() at one env (whole episodes, wall clock, includes the Python host); COMPAT-mode "
+                   "(reference-exact streams) env-steps/s through the device-pointer entry points",
+           "reference_us_per_step": 220.0, "reference_source": "BASELINE.md section 2 (the reference's CPU step, one core)"}
+    kw = {k: v for k, v in HUB.items()}
+    for rng in ("compat", "philox"):
+        env = chub.EvcsspManagerEnv_v6(seed_rand=False, rng=rng, device=device, seed=SEED, **kw)
+        act = np.random.RandomState(0).uniform(-1, 1, size=(8, env.action_space.shape[0])).astype(np.float32)
+
+        def episode():
+            env.reset()
+            t0 = time.perf_counter()
+            for t in range(96):
+                _, _, done, _ = env.step(act[t & 7])
+            assert done
+            return (time.perf_counter() - t0) / 96
+
+        episode()
+        per = sorted(episode() for _ in range(10))
+        out["%s_us_per_step" % rng] = per[len(per) // 2] * 1e6
+        out["%s_us_per_step_min_max" % rng] = [per[0] * 1e6, per[-1] * 1e6]
+        env.close()
+    rates = {}
+    for n in (4096, 65536):
+        v = chub.VecChargingHub(n, seed=SEED, rng="compat", device=device, **kw)
+        v.compat_replay_constructor()
+        D, A = v.obs_dim, v.act_dim
+        st = multi_gpu.Stream(device)
+        rs = np.random.RandomState(1)
+        acts, zs = [], []
+        for b in range(2):
+            a = multi_gpu.DeviceBuffer(n * A * 4, device)
+            v.random_actions_device(a.ptr, ACTION_KEY, b, st.ptr)
+            z = multi_gpu.DeviceBuffer(n * 3 * 8, device)
+            z.from_host(rs.normal(size=(n, 3)), st.ptr)
+            acts.append(a)
+            zs.append(z)
+        days = multi_gpu.DeviceBuffer(n * 2 * 4, device)
+        days.from_host(np.stack([rs.randint(0, 100, n), rs.randint(0, 150, n)], axis=1).astype(np.int32), st.ptr)
+        obs, rew, done = multi_gpu.DeviceBuffer(n * D * 4, device), multi_gpu.DeviceBuffer(n * 4, device), multi_gpu.DeviceBuffer(n, device)
+
+        def day():
+            v.reset_device(obs.ptr, days.ptr, zs[0].ptr, stream=st.ptr)
+            for t in range(96):
+                v.step_device(acts[t & 1].ptr, obs.ptr, rew.ptr, done.ptr, d_exo_z=zs[t & 1].ptr, stream=st.ptr)
+            st.sync()
+
+        day()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            day()
+        dt = time.perf_counter() - t0
+        o = obs.to_host(np.float32, (n, D), st.ptr)
+        assert np.isfinite(o).all()
+        rates[str(n)] = {"value": n * 192 / dt, "unit": "env-steps/s", "ms_per_step": dt / 192 * 1e3}
+        v.close()
+        for b in acts + zs + [days, obs, rew, done]:
+            b.free()
+        st.destroy()
+    out["compat_mode"] = rates
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -379,6 +449,7 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="skip the untimed profiled day (no `roofline` block)")
     ap.add_argument("--no-c5", action="store_true", help="skip the secondary roofline_c5 block")
     ap.add_argument("--no-bits", action="store_true", help="skip the secondary packed_actions block (one bit per pile as the action input)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the secondary dropin_single_env block (the reference-shaped class at one env, COMPAT mode as a batch)")
     ap.add_argument("--fused", choices=["auto", "on", "off"], default="auto",
                     help="the step as ONE launch (k_step_fused); auto: the library's choice (small batches)")
     ap.add_argument("--dry-run", action="store_true",
@@ -644,6 +715,8 @@ def main():
             out["roofline_c5"] = c5_roofline(chub, multi_gpu, lib, local_rank, out["build_id"])
         if world == 1 and config == "c4" and not args.no_bits and not args.no_c5 and not args.no_events:
             out["packed_actions"] = packed_actions_block(chub, multi_gpu, lib, local_rank)
+        if world == 1 and config == "c4" and not args.no_dropin and not args.no_c5 and not args.no_events:
+            out["dropin_single_env"] = dropin_block(chub, multi_gpu, lib, local_rank)
         if not args.no_cpu_baseline and world == 1 and config == "c4":
             out["cpu_baseline"] = cpu_baseline(hub_kw, total)
         print(json.dumps(out))

@@ -11,11 +11,15 @@ DATA_DIR = os.path.join(_HERE, "data")
 
 CHUB_FAST, CHUB_SLOW = 0, 1
 RNG_COMPAT, RNG_PHILOX = 0, 1
-T_COUNT = 24
+T_COUNT = 38
 TELEMETRY_NAMES = ["hy_act", "hy_flow_speed", "all_power_second", "Store_SOC", "capacity", "total_mass_need", "hy_use",
                    "not_meet", "fc_power", "hy_to_use", "re_used_renew", "re_ev_power_0", "re_ev_power_1",
                    "re_hydrogen_power", "income", "reward", "re_pv_power", "re_wd_power", "price_next",
-                   "fcev_arrive_number", "fcev_line", "fcev_queue_len", "pv_day", "wd_day"]
+                   "fcev_arrive_number", "fcev_line", "fcev_queue_len", "pv_day", "wd_day",
+                   "ev_power_0_net", "ev_power_1_net", "ev_power_sum_net", "price_now",
+                   "min_power_0", "charge_power_0", "max_power_0", "line_0", "flow_in_0",
+                   "min_power_1", "charge_power_1", "max_power_1", "line_1", "flow_in_1"]
+T = {name: i for i, name in enumerate(TELEMETRY_NAMES)}
 
 
 class ChubOptions(C.Structure):
@@ -97,6 +101,7 @@ def load_library():
         "chub_profile_begin": (I, [P, I, I]), "chub_profile_end": (I, [P, P, P, P]),
         "chub_get_slots": (I, [P, P]), "chub_get_station_scalars": (I, [P, P]), "chub_get_telemetry": (I, [P, P]),
         "chub_get_obs_f64": (I, [P, P]), "chub_get_reward_f64": (I, [P, P]), "chub_set_telemetry": (I, [P, I]), "chub_fcev_stuck_count": (I, [P, P]),
+        "chub_telemetry_host": (I, [P, C.POINTER(P), C.POINTER(P), C.POINTER(P)]),
         "chub_set_rng_compat_seeds": (I, [P, P]), "chub_set_rng_compat_state": (I, [P, P]),
         "chub_get_rng_compat_state": (I, [P, P]), "chub_compat_replay_constructor": (I, [P]), "chub_set_ou_state": (I, [P, P]),
         "chub_state_size": (L, [P]), "chub_get_state": (I, [P, P, L]), "chub_set_state": (I, [P, P, L]),
@@ -108,7 +113,7 @@ def load_library():
         "chub_comm_ranks_seen": (I, [P, C.POINTER(C.c_int), P]), "chub_device_info": (I, [I, P]),
         "chub_step_gather": (I, [P, P, P, P, P, P]), "chub_run_steps": (I, [P, P, P, I, P, P, P, L, L, P]),
         "chub_tape_register_soc": (I, [P, P, C.c_int32, P]), "chub_set_slots": (I, [P, P]), "chub_set_station_queue": (I, [P, P]),
-        "chub_step_tape": (I, [P, P, P, P, P, P, P]),
+        "chub_step_tape": (I, [P, P, P, P, P, P, P]), "chub_reset_tape": (I, [P, P, P, P]),
         "chub_graph_begin": (I, [P, P]), "chub_graph_end": (I, [P, P, C.POINTER(P)]), "chub_graph_launch": (I, [P, P]),
         "chub_graph_destroy": (I, [P]),
         "chub_malloc_device": (I, [I, L, C.POINTER(P)]), "chub_free_device": (I, [I, P]), "chub_copy_to_host": (I, [I, P, P, L, P]),
@@ -131,7 +136,7 @@ EXPORTED = ["chub_create", "chub_create_ex", "chub_destroy", "chub_obs_dim", "ch
             "chub_state_size", "chub_get_state", "chub_set_state", "chub_get_hy_table", "chub_get_hy_table_env", "chub_set_hy_table", "chub_last_error", "chub_device_count", "chub_build_id",
             "chub_comm_unique_id", "chub_comm_create", "chub_comm_destroy", "chub_comm_world", "chub_comm_rank", "chub_comm_gather",
             "chub_comm_max_f64", "chub_comm_barrier", "chub_comm_ranks_seen", "chub_device_info", "chub_step_gather", "chub_run_steps", "chub_tape_register_soc", "chub_set_slots",
-            "chub_set_station_queue", "chub_step_tape", "chub_graph_begin", "chub_graph_end", "chub_graph_launch", "chub_graph_destroy",
+            "chub_set_station_queue", "chub_step_tape", "chub_reset_tape", "chub_telemetry_host", "chub_graph_begin", "chub_graph_end", "chub_graph_launch", "chub_graph_destroy",
             "chub_malloc_device", "chub_free_device", "chub_copy_to_host", "chub_copy_to_device", "chub_alloc_host", "chub_free_host", "chub_stream_create",
             "chub_stream_destroy", "chub_stream_sync"]
 

@@ -42,7 +42,7 @@ constexpr int kPackedBlock = CHUB_PACKED_BLOCK;  // workgroup size of the packed
 constexpr int kSlotsPerLane = CHUB_SLOTS_PER_LANE;  // packed slot kernel: slots per lane (kPackedBlock * kSlotsPerLane virtual lanes per workgroup)
 constexpr int kClsRow = 32;        // PHILOX: entries (power, t_soc) per arrival-SoC class = car_steps a car can take (stay_time <= 27 here)
 constexpr int kTapeClasses = 8192; // PHILOX: room for caller-registered arrival-SoC classes (tape mode)
-constexpr int kTelemCount = 24;
+constexpr int kTelemCount = 38;
 constexpr int kFusedMaxBlocks = 256;   // PHILOX lock-step steps of at most this many slot workgroups (one per CU) run as ONE launch (k_step_fused):
                                        // measured 8.2 vs 9.0 us per step at 128 workgroups (C2), 11.3 vs 11.0 at 745, 17.4 vs 13.7 at 1490
 
@@ -174,7 +174,7 @@ struct HubParams {
     float hv_rate;           // f32(f32(0.3) * f32(permeate))
     int32_t qcap;            // explicit FCEV waiting-list entries per env = max(1, 2 * (max arrivals per step) - 1)
     int32_t epb;             // packed slot kernel: whole envs per workgroup = kPackedBlock * kSlotsPerLane / (S0 + S1)
-    int32_t packed;          // PHILOX steps run k_slot_packed (the hub has >= 4 piles in all)
+    int32_t packed;          // PHILOX steps run k_slot_packed (any hub shape of up to 512 piles)
 };
 
 // Everything a kernel needs that does not change from step to step, kept in device memory and passed by pointer

@@ -7,7 +7,7 @@
 //           next row entry -> station sums (integer LDS atomics) -> last wave: add_car for the new cars, one 16-byte
 //           station record per unit.
 //   k_slot  the same phases with wave-local units (H = pow2 >= S_k lanes each): COMPAT streams (16-byte hot record, curves
-//           evaluated), PHILOX scalar-load control and hubs of 1-3 piles.
+//           evaluated), PHILOX scalar-load control.
 //   k_env   lane = environment.  The scalar tail of step(): electrolyser clamp against the grid limit, FCEV arrivals +
 //           SAE-J2601 fueling + the waiting list, electrolyser / compressor / tank, renewable netting, fuel cell, incomes and
 //           reward, done, exogenous update (PV / wind / price OU) and the normalised observation.  The J2601 breakpoints
@@ -232,6 +232,10 @@ __device__ __forceinline__ int dppi_mirror8(int v) { return __builtin_amdgcn_upd
 __device__ __forceinline__ int dppi_mirror16(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true); } // row_mirror
 // PHILOX-mode station sums are integer sums of slot powers in units of 2^-19 kW (see slot_body); back to kW in f32
 __device__ __forceinline__ float fixed_to_kw(int v) { return (float) v * (1.0f / 524288.0f); }
+// ... a slot power as that integer: the product with 2^19 is exact in f32, rounded to the nearest integer (ties to even), so a
+// car's contribution is within 2^-20 kW of its f32 power and the error of a sum has no sign (round 3 truncated: up to 1.9e-6 kW
+// per car, always downwards)
+__device__ __forceinline__ int kw_to_fixed(float p) { return (int) rintf(p * 524288.0f); }
 
 // PHILOX mode: mk_soc (CHS.hpp:804-814) from one 32-bit uniform by linear interpolation of the tabulated
 // inverse CDF of clip(N(7,3),1,10): 12 bits pick the cell, 20 bits interpolate (three f32 roundings)
@@ -647,8 +651,8 @@ __device__ void slot_body_compat(const HubParams &hp, const StepArgs &sa, const 
 }
 
 // ---------------------------------------------------------------------------------------- k_slot, PHILOX, wave-local units
-// The same phases on the 8-byte PHILOX slot state for what the packed kernel below does not cover: reset, the scalar-load
-// control mode, stations with 1-3 piles.  One unit = H = pow2 >= S_k lanes of one wave: ballot + prefix rank inside the wave,
+// The same phases on the 8-byte PHILOX slot state for what the packed kernel below does not cover: the scalar-load control mode
+// (and every step of a handle created with chub_options.slot_kernel = 1: the parity cross-check).  One unit = H = pow2 >= S_k lanes of one wave: ballot + prefix rank inside the wave,
 // integer DPP butterfly for the station sums.  Bit for bit the packed kernel's results (test_philox_other_slot_kernel runs
 // every step through this one).
 template <bool RESET, int BLOCK>
@@ -759,10 +763,10 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
         w1 = __float_as_uint(t_target);
     }
 
-    // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572): order-independent sums -- every slot power truncated to a
+    // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572): order-independent sums -- every slot power rounded to the nearest
     // multiple of 2^-19 kW, integer butterfly over the unit's H lanes, one rounding to f32
     const bool urgent = car && must_charge(t_target, t_soc, tl);
-    const int q = (int) (power * 524288.0f);
+    const int q = kw_to_fixed(power);
     int i_min = urgent ? q : 0, i_max = car ? q : 0, i_chg = charge ? q : 0;
     if (H > 1) { i_min += dppi_xor1(i_min); i_max += dppi_xor1(i_max); i_chg += dppi_xor1(i_chg); }
     if (H > 2) { i_min += dppi_xor2(i_min); i_max += dppi_xor2(i_max); i_chg += dppi_xor2(i_chg); }
@@ -1027,7 +1031,7 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
         s_b[tid] = charge ? power : 0.0f;
         s_c[tid] = car ? power : 0.0f;
     } else {
-        const int q = (int) (power * 524288.0f);
+        const int q = kw_to_fixed(power);
         s_u[tid] = (uint32_t) (urgent ? q : 0);
         s_v[tid] = (uint32_t) (charge ? q : 0);
         s_w[tid] = (uint32_t) (car ? q : 0);
@@ -1109,6 +1113,16 @@ __device__ __forceinline__ uint32_t sload_u32(const void *p, int i) { return ((c
 // RESET: evs_reset (CHS.hpp:1209-1231 / 1520-1542) on the same layout: no state comes in, the unit's initial occupancy was drawn
 // by k_reset_levels, every wave helps with the (many) new cars.  BIG: a station with more than 64 piles -- a unit then spans
 // several waves (its empties are counted over all of them) and its power sums need 64 bits.
+// The action rows are read exactly once: CHUB_ACT_NT = 1 loads them with the non-temporal hint, so that they do not push the slot state --
+// which the next step reads again -- out of the Infinity Cache (C5: 69 MB of rows per step next to 134 MB of state)
+#ifndef CHUB_ACT_NT
+#define CHUB_ACT_NT 0
+#endif
+#if CHUB_ACT_NT
+#define CHUB_ACT_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define CHUB_ACT_LOAD(p) (*(p))
+#endif
 #ifndef CHUB_ACC_COPIES
 #define CHUB_ACC_COPIES 2  // copies of a unit's LDS accumulators (lanes spread over them by lane number: fewer same-address atomics; 1 / 2 / 4: 21.28 / 20.95 / 21.12 us)
 #endif
@@ -1179,7 +1193,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
                 s2[j].x = CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) v) << 2);
                 s2[j].y = CHUB_AT(uint32_t, pa.state, ((uint32_t) N * (uint32_t) St + idx0 + (uint32_t) v) << 2);  // the w1 plane
                 if (BITS) actw[j] = CHUB_AT(const u32x2, pa.actions, ((uint32_t) env * (((uint32_t) St + 63u) >> 6) + ((uint32_t) hs >> 6)) << 3);
-                else act[j] = CHUB_AT(const float, pa.actions, (idx0 + (uint32_t) v + 2u * (uint32_t) env) << 2);  // row stride S0 + S1 + 2
+                else act[j] = CHUB_ACT_LOAD((CHUB_G(const float)) ((CHUB_G(const char)) pa.actions + (uint32_t) ((idx0 + (uint32_t) v + 2u * (uint32_t) env) << 2)));  // row stride S0 + S1 + 2
             }
             pk_in[j] = CHUB_AT(const uint32_t, pa.pk, sidx[j] << 2);
         }
@@ -1311,7 +1325,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
             const bool bit_on = BITS && ((((hs_[j] & 32) ? actw[j].y : actw[j].x) >> (hs_[j] & 31)) & 1u) != 0u;
             const bool on = (BITS ? bit_on : act[j] >= kActOnThreshold) || must_charge(t_target, row[j].y, tl[j]);
             const float power = on ? row[j].z : row[j].x, t_soc = on ? row[j].w : row[j].y;  // car_step = the next entry of the class row
-            const int q = (int) (power * 524288.0f);
+            const int q = kw_to_fixed(power);
             const bool urgent = must_charge(t_target, t_soc, tl[j] - 1);
             w0n = (w0[j] & ~64u) - 1u + (on ? ((1u << 13) | 64u) : 0u);
             if (!BIG) {
@@ -1372,7 +1386,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) src) << 2) = st_ > 0 ? ps_make(st_, c) : 0u;
         CHUB_AT(uint32_t, pa.state, ((uint32_t) N * (uint32_t) St + idx0 + (uint32_t) src) << 2) = __float_as_uint(tt_);  // the w1 plane: written here only
         if (st_ > 0) {
-            const int q = (int) (e0.x * 524288.0f);
+            const int q = kw_to_fixed(e0.x);
             if (!BIG) {
                 int *ac = s_acc + 4 * (2 * s_e + s_k) + (lane & (kAccCopies - 1)) * 8 * epb;
                 atomicAdd((unsigned long long *) (ac + 2), (unsigned long long) (uint32_t) q | (1ull << 32));
@@ -2086,6 +2100,9 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             CHUB_TEL(9, hy_to_use); CHUB_TEL(10, used_renew); CHUB_TEL(13, hydrogen_power);
             CHUB_TEL(14, income_hys + income_evs + income_evs_serve + hy_cost); CHUB_TEL(15, reward);
             CHUB_TEL(19, (double) arrive); CHUB_TEL(20, (double) hv_line); CHUB_TEL(21, (double) q_len + (double) fold_n);
+            // ev_power_list / ev_power_sum as the incomes and cumulated_draw_ele see them, after the fuel-cell rescale (MGR:219-224, 262)
+            CHUB_TEL(24, e0); CHUB_TEL(25, e1); CHUB_TEL(26, ev_power_sum);
+            CHUB_TEL(27, in_price_next);  // real_state[1] as this step found it: what real_price_dollar is a quarter of (MGR:234)
         }
         }
     }
@@ -2159,6 +2176,9 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         ev.reward64[e32] = reward;
         CHUB_TEL(3, store_soc); CHUB_TEL(16, re_pv); CHUB_TEL(17, re_wd); CHUB_TEL(18, price_next);
         CHUB_TEL(22, (double) pv_day); CHUB_TEL(23, (double) wd_day);
+        // the station scalars make_state puts into real_state (MGR:364-368) and the arrivals income_evs_serve counts (MGR:246)
+        CHUB_TEL(28, (double) mn0); CHUB_TEL(29, (double) P0f); CHUB_TEL(30, (double) mx0); CHUB_TEL(31, (double) ln0); CHUB_TEL(32, (double) F0i);
+        CHUB_TEL(33, (double) mn1); CHUB_TEL(34, (double) P1f); CHUB_TEL(35, (double) mx1); CHUB_TEL(36, (double) ln1); CHUB_TEL(37, (double) F1i);
     }
     } while (0);
     flush_rows();
@@ -2597,7 +2617,7 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
         hipLaunchKernelGGL(k_draw_levels, dim3((unsigned) ((2 * ((int64_t) sa.env_hi - sa.env_lo + 1) + 255) / 256)), dim3(256), 0, stream, ctx, sa);
     if (hp.rng_mode == MODE_PHILOX) {
         if (hp.packed && !sa.load_mode) {
-            if (reset)
+            if (reset && !sa.car_tape)  // (tape mode: the caller's occupancy draws are in pk already)
                 hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((8 * ((int64_t) sa.env_hi - sa.env_lo + 1) + 255) / 256)), dim3(256), 0, stream, ctx, sa);
             const PackedArgs pa = make_packed_args(hp, sa, pp);
             // every workgroup of the batch, or (a call on a subset of the envs) those of the range of envs it names
@@ -2610,11 +2630,15 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
         else CHUB_PACKED1(TAPE_, RESET_, BIG_, false);                \
     } while (0)
             const bool big = hp.S[0] > 64 || hp.S[1] > 64;
-            if (reset) {
+            if (reset && sa.car_tape) {  // tape mode runs in lock-step
+                if (big) CHUB_PACKED1(true, true, true, false);
+                else CHUB_PACKED1(true, true, false, false);
+            } else if (reset) {
                 if (big) CHUB_PACKED(false, true, true);
                 else CHUB_PACKED(false, true, false);
             } else if (sa.car_tape) {
-                CHUB_PACKED1(true, false, false, false);  // tape mode runs in lock-step
+                if (big) CHUB_PACKED1(true, false, true, false);
+                else CHUB_PACKED1(true, false, false, false);
             } else if (sa.act_bits) {  // one bit per pile (lock-step entry points only: no mask)
                 if (big) CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, false, false, true, false, true>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa);
                 else CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, false, false, false, false, true>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa);
@@ -2741,6 +2765,9 @@ __global__ void k_fill_clocks(uint16_t *dst, int64_t n, uint16_t value) {
 }
 void launch_fill_clocks(uint16_t *dst, int64_t n, uint16_t value, hipStream_t stream) {
     hipLaunchKernelGGL(k_fill_clocks, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, dst, n, value);
+}
+void launch_keep_clocks(uint16_t *dst, const uint16_t *src, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_keep_clocks, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, dst, src, n);
 }
 void launch_tick_advance(uint32_t *tick_base, uint32_t by, hipStream_t stream) {
     hipLaunchKernelGGL(k_tick_advance, dim3(1), dim3(1), 0, stream, tick_base, by);

@@ -26,6 +26,7 @@ void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, fl
 void launch_compat_ctor_sweep(const HubParams &hp, const DevCtx *ctx, hipStream_t stream);
 void launch_tick_advance(uint32_t *tick_base, uint32_t by, hipStream_t stream);
 void launch_fill_clocks(uint16_t *dst, int64_t n, uint16_t value, hipStream_t stream);
+void launch_keep_clocks(uint16_t *dst, const uint16_t *src, int64_t n, hipStream_t stream);
 void launch_expand_bits(const HubParams &hp, const uint64_t *d_bits, const float *d_tail, float *d_actions, hipStream_t stream);
 void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp, hipEvent_t ev0,
                        hipEvent_t ev1);
@@ -106,6 +107,7 @@ struct chub_env {
     uint64_t *h_bits, *d_bits;    // chub_step_bits: [N][ceil(S / 64)] pinned staging and its device copy
     float *h_tail, *d_tail;       //                 [N][2]
     float *d_packed;              // [N][D+2]
+    double *h_telem;    // telemetry block in pinned host memory, written by the tail kernel directly: telem [T][N], obs64 [N][D], reward64 [N]
     int tape_classes;   // PHILOX tape mode: caller-registered arrival-SoC classes so far
     uint32_t h_late8[8];
     double h_sin96[96];
@@ -405,6 +407,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->h_actions = e->h_packed = e->d_packed = nullptr;
     e->h_bits = e->d_bits = nullptr;
     e->h_tail = e->d_tail = nullptr;
+    e->h_telem = nullptr;
     e->prof_used = e->prof_cap = 0;
     e->prof_on = false;
     e->arena = nullptr;
@@ -684,10 +687,11 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     {
         const int pb = kPackedBlock * kSlotsPerLane, St = hp.S[0] + hp.S[1];
         hp.epb = pb / St > 0 ? pb / St : 1;
+        if (hp.epb > pb / 4) hp.epb = pb / 4;  // the workgroup's per-unit LDS areas hold 2 * pb / 4 units: hubs of 1-3 piles leave lanes idle
         bool magic_ok = true;  // the kernel divides lane numbers by S0 + S1 with a 20-bit reciprocal
         for (int l = 0; l < pb && magic_ok; l++)
             if ((((uint32_t) l * ((1u << 20) / (uint32_t) St + 1u)) >> 20) != (uint32_t) (l / St)) magic_ok = false;
-        hp.packed = (rng_mode == CHUB_RNG_PHILOX && St >= 4 && St <= pb && magic_ok &&
+        hp.packed = (rng_mode == CHUB_RNG_PHILOX && St >= 1 && St <= pb && magic_ok &&
                      (uint64_t) n_envs * (uint64_t) (St + 2) * 16u < ((uint64_t) 1 << 32) &&  // 32-bit byte offsets
                      opt.slot_kernel != 1) ? 1 : 0;
     }
@@ -813,6 +817,7 @@ int chub_destroy(chub_env *e) {
         for (hipEvent_t ev : e->mask_done)
             if (ev) (void) hipEventDestroy(ev);
         if (e->h_packed) (void) hipHostFree(e->h_packed);
+        if (e->h_telem) (void) hipHostFree(e->h_telem);
         if (e->h_bits) (void) hipHostFree(e->h_bits);  // h_tail / d_tail are the ends of the same blocks
         if (e->d_bits) (void) hipFree(e->d_bits);
         if (e->d_packed) (void) hipFree(e->d_packed);
@@ -950,6 +955,7 @@ static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const d
     sa.exo_z = d_exo_z;
     sa.obs = d_obs;
     sa.obs_stride = e->hp.obs_dim;
+    sa.car_tape = e->tape_car;  // chub_reset_tape: the unit's occupancy draws are in pk already, the cars' variates come from the tape
     sa.env_lo = 0;
     sa.env_hi = (int32_t) (e->hp.n_envs - 1);
     if (e->per_env) {
@@ -1563,6 +1569,15 @@ int chub_graph_launch(chub_graph *g, void *stream) {
     // runs on a tick an eager call has already used (nor the other way round).
     const uint32_t delta = (e->tick - e->graph_base) - g->arg0;
     if (delta != 0u) {
+        // The per-env clocks are double-buffered by the parity of that same argument: the graph's first launch reads buffer
+        // (arg0 + 1) & 1, while the live clocks -- after an odd number of eager calls -- sit in buffer (arg0 + delta + 1) & 1,
+        // the other one.  Bring them over before the base moves (every env would otherwise replay from a stale slot
+        // of day and price phase).
+        if (g->per_env_begin && (delta & 1u)) {
+            const size_t N = (size_t) e->hp.n_envs;
+            launch_keep_clocks(e->d_env_clk + (size_t) ((g->arg0 + 1u) & 1u) * N, e->d_env_clk + (size_t) (g->arg0 & 1u) * N, (int64_t) N,
+                               (hipStream_t) stream);
+        }
         launch_tick_advance(e->d_tick_base, delta, (hipStream_t) stream);
         HIP_TRY(hipGetLastError());
         e->graph_base += delta;
@@ -1725,6 +1740,9 @@ int chub_set_station_queue(chub_env *e, const int32_t *line) {
             w = (w & ~15u) | (uint32_t) line[env * 2 + k];
         }
     HIP_TRY(hipMemcpy(e->st.rec, rec.data(), rec.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // the next step's station draws were decoded one launch ahead against the queue lengths just overwritten: the next launch
+    // draws and decodes its own (k_draw_levels; same Philox counters)
+    e->predrawn = false;
     return CHUB_OK;
 }
 
@@ -1765,6 +1783,36 @@ int chub_step_tape(chub_env *e, const float *actions, const uint64_t *pk_tape, c
     if (hipMemcpy(obs, e->d_obs, N * (size_t) e->hp.obs_dim * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(done, e->d_done, N, hipMemcpyDeviceToHost) != hipSuccess)
+        return done_(fail(CHUB_ERR_HIP, "hipMemcpy failed"));
+    return done_(CHUB_OK);
+}
+
+int chub_reset_tape(chub_env *e, const uint32_t *occ_tape, const uint32_t *car_tape, float *obs) {
+    if (!e || !occ_tape || !car_tape || !obs) return fail(CHUB_ERR_ARG, "null argument");
+    if (e->hp.rng_mode != CHUB_RNG_PHILOX || !e->hp.packed)
+        return fail(CHUB_ERR_ARG, "tape mode drives the packed PHILOX slot kernel: the hub shape must be one it covers");
+    if (e->capturing) return fail(CHUB_ERR_ARG, "tape mode cannot be captured");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t) e->hp.n_envs, S = (size_t) (e->hp.S[0] + e->hp.S[1]);
+    uint32_t *d_ct = nullptr;
+    HIP_TRY(hipMalloc((void **) &d_ct, 2 * N * S * sizeof(uint32_t)));
+    auto done_ = [&](int code) {
+        (void) hipDeviceSynchronize();
+        (void) hipFree(d_ct);
+        return code;
+    };
+    // the reset is the launch with argument tick + 1 - base: its slot kernel reads the units' occupancy draws from pk[that & 1],
+    // where k_reset_levels would have left this build's own
+    const uint32_t arg = e->tick + 1u - e->graph_base;
+    if (hipMemcpy((void *) e->st.pk[arg & 1u], occ_tape, 2 * N * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ct, car_tape, 2 * N * S * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+        return done_(fail(CHUB_ERR_HIP, "hipMemcpy failed"));
+    e->tape_car = d_ct;
+    int rc = chub_reset_device(e, nullptr, nullptr, e->d_obs, nullptr);
+    e->tape_car = nullptr;
+    if (rc) return done_(rc);
+    if (hipMemcpy(obs, e->d_obs, N * (size_t) e->hp.obs_dim * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
         return done_(fail(CHUB_ERR_HIP, "hipMemcpy failed"));
     return done_(CHUB_OK);
 }
@@ -1877,12 +1925,18 @@ int chub_get_station_scalars(chub_env *e, double *out) {
 int chub_set_telemetry(chub_env *e, int enabled) {
     if (!e) return fail(CHUB_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(e->device));
-    if (enabled && !e->ev.telem) {
-        const size_t N = (size_t) e->hp.n_envs;
-        int rc;
-        if ((rc = dev_alloc(e, &e->ev.telem, N * kTelemCount))) return rc;
-        if ((rc = dev_alloc(e, &e->ev.obs64, N * (size_t) e->hp.obs_dim))) return rc;
-        if ((rc = dev_alloc(e, &e->ev.reward64, N))) return rc;
+    if (enabled && !e->h_telem) {
+        // one block of pinned host memory, mapped into the device's address space: the tail kernel's telemetry stores cross PCIe
+        // as posted writes while it runs, and reading them back is a host read -- no device read per step for the drop-in class
+        const size_t N = (size_t) e->hp.n_envs, D = (size_t) e->hp.obs_dim;
+        const size_t count = N * (size_t) kTelemCount + N * D + N;
+        HIP_TRY(hipHostMalloc((void **) &e->h_telem, count * sizeof(double), hipHostMallocDefault));
+        memset(e->h_telem, 0, count * sizeof(double));
+        void *dv = nullptr;
+        if (!device_view(e->h_telem, &dv)) return fail(CHUB_ERR_HIP, "pinned telemetry block is not visible to the device");
+        e->ev.telem = (double *) dv;
+        e->ev.obs64 = e->ev.telem + N * (size_t) kTelemCount;
+        e->ev.reward64 = e->ev.obs64 + N * D;
     }
     e->hp.telemetry = enabled ? 1 : 0;
     e->ctx_dirty = true;
@@ -1890,8 +1944,19 @@ int chub_set_telemetry(chub_env *e, int enabled) {
 }
 
 static int need_telemetry(chub_env *e) {
-    if (!e->ev.telem) return fail(CHUB_ERR_ARG, "telemetry is off: call chub_set_telemetry(env, 1) first");
+    if (!e->h_telem) return fail(CHUB_ERR_ARG, "telemetry is off: call chub_set_telemetry(env, 1) first");
     return 0;
+}
+
+int chub_telemetry_host(chub_env *e, double **telem, double **obs64, double **reward64) {
+    if (!e || !telem || !obs64 || !reward64) return fail(CHUB_ERR_ARG, "null argument");
+    int rc = need_telemetry(e);
+    if (rc) return rc;
+    const size_t N = (size_t) e->hp.n_envs, D = (size_t) e->hp.obs_dim;
+    *telem = e->h_telem;
+    *obs64 = e->h_telem + N * (size_t) kTelemCount;
+    *reward64 = *obs64 + N * D;
+    return CHUB_OK;
 }
 
 int chub_get_telemetry(chub_env *e, double *out) {
@@ -1901,8 +1966,7 @@ int chub_get_telemetry(chub_env *e, double *out) {
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t) e->hp.n_envs;
-    std::vector<double> t;
-    if ((rc = fetch(t, e->ev.telem, N * kTelemCount))) return rc;
+    const double *t = e->h_telem;
     for (size_t env = 0; env < N; env++)
         for (int i = 0; i < kTelemCount; i++) out[env * kTelemCount + i] = t[(size_t) i * N + env];
     return CHUB_OK;
@@ -1913,7 +1977,9 @@ int chub_get_obs_f64(chub_env *e, double *out) {
     int rc = need_telemetry(e);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemcpy(out, e->ev.obs64, (size_t) e->hp.n_envs * e->hp.obs_dim * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t) e->hp.n_envs;
+    memcpy(out, e->h_telem + N * (size_t) kTelemCount, N * (size_t) e->hp.obs_dim * sizeof(double));
     return CHUB_OK;
 }
 
@@ -1922,7 +1988,9 @@ int chub_get_reward_f64(chub_env *e, double *out) {
     int rc = need_telemetry(e);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemcpy(out, e->ev.reward64, (size_t) e->hp.n_envs * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t) e->hp.n_envs;
+    memcpy(out, e->h_telem + N * (size_t) kTelemCount + N * (size_t) e->hp.obs_dim, N * sizeof(double));
     return CHUB_OK;
 }
 

@@ -2,8 +2,15 @@
 (evcssp_env_cpp/envs/evcssp_manager.py:19-414) on top of the batched GPU runtime (N = 1).
 
 Same constructor kwargs, ``reset() -> ndarray``, ``step(action) -> (ndarray, float, bool, {})``, ``seed``,
-``action_space`` / ``observation_space`` bounds (MGR:74-118), ``render`` / ``close`` no-ops, and the telemetry
-attributes trainers read after ``step`` (``re_*``, ``income``, ``fc_power``, ``hy_act`` ..., MGR:183-297).
+``action_space`` / ``observation_space`` bounds (MGR:74-118), ``render`` / ``close`` no-ops, and every attribute the reference
+sets in ``reset`` / ``step`` that a trainer or an evaluation script reads afterwards: ``real_state`` (MGR:372), ``action_real``,
+``re_*``, ``income``, ``fc_power``, ``hy_act``, ``gen_hy`` (MGR:150-231), ``cumulated_income`` / ``cumulated_draw_ele`` (MGR:259-262),
+``acumulate_reward``, ``deviation``, ``test_penalty`` at the end of an episode (MGR:275-297), ``penalty`` / ``lagrangian_factor``
+(MGR:128, 314-315).  tests/test_gpu_parity.py holds them to the values recorded from the reference.
+
+One ``step()`` is ONE call into libchub and no device read: the actions go up from a pinned buffer, the kernels write the observation,
+reward, done flag and the telemetry block straight into pinned host memory (chub_telemetry_host), and everything above is read
+from there.
 
 Randomness: ``rng='compat'`` (default, like the reference) reproduces the reference's process-global streams
 for this env -- glibc ``rand()`` + ``std::minstd_rand0`` on the device, while the exogenous draws stay on
@@ -11,6 +18,7 @@ the host exactly where the reference makes them: ``random.randint`` for the PV /
 ``np.random.normal()`` for the three OU processes (REN:73-74).  So ``random.seed(s); np.random.seed(s)``
 before construction means what it means for the reference.  ``rng='philox'`` uses the device generator.
 """
+import ctypes as C
 import random
 
 import numpy as np
@@ -53,7 +61,10 @@ class EvcsspManagerEnv_v6(object):
     def __init__(self, station_list, station_type_list, constant_charging=False, hydro_prod_rate=None,
                  hydro_store_vlt=None, seed_rand=True, init_soc=0.5, fc_max_power=None, fcev_permeate=0.01,
                  use_lagrange=False, renew_fluctuate=0, price_fluctuate=0, hydro_loss=0, rng="compat", device=0,
-                 seed=None, data_dir=None):
+                 seed=None, data_dir=None, compat_seeds=None):
+        """Beyond the reference's kwargs (MGR:25-27): rng / device / seed / data_dir, and compat_seeds = (srand seed, e.seed()):
+        the state of the reference's two process-global C++ streams in front of the constructor (default: what
+        Change_Use_Seed(seed_rand) leaves, CHS.hpp:25-41)."""
         assert len(station_list) == len(station_type_list) == 2  # MGR:37
         self.fcev_permeate = fcev_permeate
         self.init_soc = init_soc
@@ -66,18 +77,20 @@ class EvcsspManagerEnv_v6(object):
                                    hydro_prod_rate=hydro_prod_rate, hydro_store_vlt=hydro_store_vlt,
                                    init_soc=init_soc, fc_max_power=fc_max_power, fcev_permeate=fcev_permeate,
                                    renew_fluctuate=renew_fluctuate, price_fluctuate=price_fluctuate,
-                                   hydro_loss=hydro_loss)
+                                   hydro_loss=hydro_loss, copy_outputs=False)
         self._vec.set_telemetry(True)
         if rng == "compat":
             # Change_Use_Seed (MGR:28, CHS.hpp:27-41): seed_rand=True -> srand(time) on first use;
             # False -> rand() keeps glibc's default seed 1.  `e` always starts from its default seed 1 (CHS.hpp:25).
-            if seed_rand:
+            if compat_seeds is not None:
+                gseed, eseed = int(compat_seeds[0]), int(compat_seeds[1])
+            elif seed_rand:
                 import time
 
-                gseed = int(time.time()) & 0xFFFFFFFF
+                gseed, eseed = int(time.time()) & 0xFFFFFFFF, 1
             else:
-                gseed = 1
-            self._vec.set_compat_seeds(np.array([[gseed, 1]], dtype=np.uint32))
+                gseed, eseed = 1, 1
+            self._vec.set_compat_seeds(np.array([[gseed, eseed]], dtype=np.uint32))
             # the reference's constructor consumes stream draws before its reset() (station constructors,
             # HySystem's sweep): replay them so that an episode after construction matches the reference's
             self._vec.compat_replay_constructor()
@@ -108,6 +121,30 @@ class EvcsspManagerEnv_v6(object):
             # random.seed(1) (REN:63 via MGR:30 and REN:34-35), so the first randint() pair of reset()
             # always starts from that state
             random.seed(1)
+        # ---- what one step() touches, set up once: the pinned action row, the exogenous draws, raw pointers, live views of the
+        # handle's pinned outputs and telemetry block
+        v = self._vec
+        self._S = sum(self.pile_number)
+        self._act = v.pinned_actions()                   # [1, S + 2] f32, pinned
+        self._z = np.zeros((1, 3))
+        tel, obs64, rew64 = v.telemetry_views()
+        self._tel, self._obs64, self._rew64 = tel[:, 0], obs64[0], rew64  # this env's column / row of the block: live views
+        self._p = [C.c_void_p(a.ctypes.data) for a in (self._act, self._z, v._obs, v._reward, v._done)]
+        self._chub_step = v._lib.chub_step
+        self._h = v._h
+        T = _lib.T
+        # real_state (MGR:364-370) as telemetry columns: [time, price_next, {min, charge, max power, line} per station with piles,
+        # Store_SOC, pv power, wind power]; entry 0 (a placeholder column here) is overwritten with the slot of day
+        cols = [0, T["price_next"]]
+        for k in (0, 1):
+            if self.pile_number[k] > 0:
+                cols += [T["min_power_%d" % k], T["charge_power_%d" % k], T["max_power_%d" % k], T["line_%d" % k]]
+        self._rs_cols = np.array(cols + [T["Store_SOC"], T["re_pv_power"], T["re_wd_power"]])
+        # HyStore (HYD:92-100): capacity_mass in g
+        self._capacity_mass = (0.089 * (200 / 1)) * ((5000 if hydro_store_vlt is None else hydro_store_vlt) * 1000)
+        self.real_time_max = 96
+        self.scale_pv = 5
+        self.scale_wd = 1
         self._pv_day = 0
         self._wd_day = 0
         self._price_count = 0
@@ -119,17 +156,31 @@ class EvcsspManagerEnv_v6(object):
         self.np_random = None
         self.seed()
         self.reset()  # MGR:120
+        self.real_state = []  # MGR:121-123: the constructor leaves these empty until the caller's own reset()
+        self.np_random = None
         self.state = None
+        self.acumulate_reward = 0
+        self.use_lagrangian = False
+        self.lagrangian_factor = None
+        self.penalty = 0
+        self.cumulated_income = 0
+        self.cumulated_draw_ele = 0
 
     def seed(self, seed=None):
         self.np_random = np.random.RandomState(seed if seed is not None else 0)
         return [seed]
 
+    def set_compat_seeds(self, glibc_seed, minstd_seed):
+        """rng='compat': install (srand seed, e.seed()) for this env's two reference streams -- what re-seeding the reference's
+        process-global generators in front of a reset() does"""
+        self._vec.set_compat_seeds(np.array([[int(glibc_seed), int(minstd_seed)]], dtype=np.uint32))
+
     # exogenous draws of one make_state (MGR:344-361), made on the host in the reference's order
     def _exo(self, time):
-        z = np.zeros((1, 3))
         if self._rng != "compat":
             return None
+        z = self._z
+        z[0, 0] = z[0, 1] = z[0, 2] = 0.0
         if self._pv[self._pv_day][time] > 0 and self._pv_day % 2 == 0:  # REN:40-41
             z[0, 0] = np.random.normal()
         z[0, 1] = np.random.normal()  # REN:47
@@ -138,51 +189,97 @@ class EvcsspManagerEnv_v6(object):
         self._price_count += 1
         return z
 
+    def _make_state(self, time):
+        """what make_state (MGR:344-373) leaves: real_state, state, the renewable powers and the price noise"""
+        tel = self._tel
+        rs = tel[self._rs_cols]  # fancy indexing: a fresh array
+        rs[0] = time
+        self.real_state = rs
+        self.re_pv_power = float(tel[16])
+        self.re_wd_power = float(tel[17])
+        self.state = np.array(self._obs64)
+
     def reset(self):
         self.cumulated_income = 0
         self.cumulated_draw_ele = 0
+        self.real_state = []
+        self.accumulate_reward = 0  # (sic, MGR:308: acumulate_reward is never reset)
         days = None
         if self._rng == "compat":
             self._pv_day = random.randint(0, 99)   # REN:51-53
             self._wd_day = random.randint(0, 149)
             days = np.array([[self._pv_day, self._wd_day]], dtype=np.int32)
-        obs = self._vec.reset(days, self._exo(0))
+        z = self._exo(0)
+        self._vec.reset(days, None if z is None else z.copy())
         self._price_count = 0  # MGR:313
         self._time = 0
-        self.state = self._vec.obs_f64()[0]
+        self._make_state(0)
+        self.lagrangian_factor = None
+        self.penalty = 0
         return np.array(self.state)
 
     def step(self, action):
-        S = sum(self.pile_number)
+        S = self._S
         if action is None:  # MGR:146-147
             action = np.append(np.ones(S), [0, 0], None)
         assert len(action) == S + 2  # MGR:148
-        a = np.asarray(action, dtype=np.float32).reshape(1, S + 2)
+        self.action_real = self.action_to_real(action)  # MGR:149-151
+        self._act[0, :] = action
         t_next = (self._time + 1) % 96
-        self._vec.step(a, self._exo(t_next))
-        self._time = t_next
-        self.state = self._vec.obs_f64()[0]
-        reward = float(self._vec.reward_f64()[0])
+        p = self._p
+        rc = self._chub_step(self._h, p[0], p[1] if self._exo(t_next) is not None else None, p[2], p[3], p[4])
+        if rc:
+            _lib.check(rc)
+        # chub_step returns completed: observation, reward, done and the telemetry block are in pinned host memory now
+        tel = self._tel
+        reward = float(self._rew64[0])
         done = bool(self._vec._done[0])
-        tel = self._vec.telemetry()[0]
-        for name, v in zip(_lib.TELEMETRY_NAMES, tel):
-            setattr(self, "_t_" + name, float(v))
         # reference attribute names (MGR:175-297)
-        self.hy_act = tel[0]
-        self.re_hy_gen = 900.0 * tel[1]
-        self.re_hydrogen_power_init = tel[2]
-        self.fc_power = tel[8]
-        self.re_hy_for_fc = tel[9]
-        self.re_used_renew = tel[10]
-        self.re_ev_power_list = [tel[11], tel[12]]
-        self.re_hydrogen_power = tel[13]
-        self.income = tel[14]
-        self.re_pv_power = tel[16]
-        self.re_wd_power = tel[17]
+        self.hy_act = float(tel[0])
+        self.gen_hy = bool(tel[1] > 0.5)                      # MGR:161,173-179
+        self.re_hy_gen = 15 * 60 * float(tel[1])              # hy_flow_speed_15, HYD:183
+        self.re_hydrogen_power_init = float(tel[2])
+        self.re_ev_power_list = [float(tel[11]), float(tel[12])]
+        self.re_used_renew = float(tel[10])
+        self.fc_power = float(tel[8])
+        self.re_hy_for_fc = float(tel[9])
+        ev0, ev1, hydrogen_power = float(tel[24]), float(tel[25]), float(tel[13])
+        self.real_charging_power = self.re_ev_power_sum = float(tel[26])
+        self.re_hydrogen_power = hydrogen_power
+        real_price_dollar = float(tel[27]) / 4                # MGR:234
+        self.re_price_dollar = real_price_dollar
+        P0, P1 = float(tel[29]), float(tel[34])
+        self.re_income_evs_cost = - real_price_dollar * (ev0 + ev1)
+        income_evs_serve = 0.8 * (int(tel[32]) + int(tel[37]))
+        self.re_income_evs_cost_list = [- real_price_dollar * ev0, - real_price_dollar * ev1]
+        self.re_income_evs_list = [0.42 / 4 * P0, 0.21 / 4 * P1]
+        self.re_income_evs_serve = income_evs_serve
+        self.re_income_hys = 6 / 1000 * float(tel[6])
+        self.re_hy_cost = -real_price_dollar * hydrogen_power
+        self.income = float(tel[14])
         self.cumulated_income += self.income
+        self.cumulated_draw_ele += ev0 + ev1 + hydrogen_power  # MGR:262
         self.acumulate_reward += reward
-        self.deviation = abs(tel[3] - self.hy_init_soc)
+        store_soc = float(tel[3])
+        if done:  # MGR:275-297 (its prints left out)
+            temp_deviation = abs(store_soc - self.hy_init_soc) * self._capacity_mass / 1000
+            temp_deviation = temp_deviation / 0.2
+            self.test_penalty = abs(temp_deviation)
+        self.deviation = abs(store_soc - self.hy_init_soc)
+        self._time = t_next
+        self._make_state(t_next)
+        for name, i in _lib.T.items():  # every telemetry column by name, for scripts that want more than the reference exposes
+            setattr(self, "_t_" + name, float(tel[i]))
         return self.state, reward, done, {}
+
+    @staticmethod
+    def action_to_real(action):
+        """MGR:384-404: one bit per pile, the two tail actions swapped"""
+        real_action = (np.array(action[:-2]) + 1) / 2
+        real_actions = [1.0 if act >= 0.5 else 0.0 for act in real_action]
+        real_actions.append((action[-1] + 1) / 2 if action[-1] is not None else action[-1])
+        real_actions.append((action[-2] + 1) / 2 if action[-2] is not None else action[-2])
+        return np.array(real_actions)
 
     def render(self, mode='human'):
         pass

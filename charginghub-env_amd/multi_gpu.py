@@ -114,6 +114,13 @@ def _rendezvous_dir():
     return d, True
 
 
+def _id_file_name():
+    """one id file per incarnation of the worker group: a launcher that restarts its workers (torchrun --max-restarts: same pid,
+    port and run id, TORCHELASTIC_RESTART_COUNT counts up) must not hand the new ranks the id of the group that crashed"""
+    n = os.environ.get("TORCHELASTIC_RESTART_COUNT", "")
+    return "rccl_id" + ("_r" + n if n.isdigit() and int(n) > 0 else "")
+
+
 def exchange_unique_id(rank, world, timeout=None, make_id=None):
     """rank 0 makes the RCCL id (chub_comm_unique_id) and publishes it; the others wait for it.
 
@@ -127,7 +134,7 @@ def exchange_unique_id(rank, world, timeout=None, make_id=None):
     if timeout is None:
         timeout = float(os.environ.get("CHUB_RENDEZVOUS_TIMEOUT", "120"))
     d, shared_tmp = _rendezvous_dir()
-    path = os.path.join(d, "rccl_id")
+    path = os.path.join(d, _id_file_name())
     not_before = _launcher_start_time() - 1.0 if shared_tmp else 0.0
     if rank == 0:
         if make_id is None:
@@ -173,10 +180,10 @@ def _rendezvous_cleanup():
     d = os.environ.get(RENDEZVOUS_ENV)
     try:
         if d:
-            os.unlink(os.path.join(d, "rccl_id"))  # the directory is the launcher's
+            os.unlink(os.path.join(d, _id_file_name()))  # the directory is the launcher's
         else:
             d, _ = _rendezvous_dir()
-            os.unlink(os.path.join(d, "rccl_id"))
+            os.unlink(os.path.join(d, _id_file_name()))
             os.rmdir(d)
     except OSError:
         pass

@@ -195,6 +195,13 @@ class VecChargingHub(object):
         q = np.ascontiguousarray(line, dtype=np.int32).reshape(self.n_envs, 2)
         check(self._lib.chub_set_station_queue(self._h, _ptr(q)))
 
+    def reset_tape(self, occ_tape, car_tape):
+        """evs_reset fed the reference's draws (chub_reset_tape): occ_tape [2, N] u32, car_tape [N, S, 2] u32"""
+        oc = np.ascontiguousarray(occ_tape, dtype=np.uint32).reshape(2, self.n_envs)
+        ct = np.ascontiguousarray(car_tape, dtype=np.uint32).reshape(self.n_envs, self.n_slots, 2)
+        check(self._lib.chub_reset_tape(self._h, _ptr(oc), _ptr(ct), _ptr(self._obs)))
+        return self._obs.copy() if self._copy_outputs else self._obs
+
     def step_tape(self, actions, pk_tape, car_tape):
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n_envs, self.act_dim)
         pk = np.ascontiguousarray(pk_tape, dtype=np.uint64).reshape(2, self.n_envs)
@@ -313,6 +320,19 @@ class VecChargingHub(object):
     # ---- introspection
     def set_telemetry(self, on=True):
         check(self._lib.chub_set_telemetry(self._h, int(bool(on))))
+        self._tel_views = None
+
+    def telemetry_views(self):
+        """the handle's telemetry block as live numpy views, no copy and no device read (chub_telemetry_host): telem [T_COUNT, N]
+        (one row per _lib.TELEMETRY_NAMES entry), obs64 [N, D], reward64 [N].  Current once the call that produced them has
+        completed: reset() / step() return completed; after a device-pointer call, sync() first."""
+        if getattr(self, "_tel_views", None) is None:
+            pt, po, pr = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            check(self._lib.chub_telemetry_host(self._h, C.byref(pt), C.byref(po), C.byref(pr)))
+            N, D, T = self.n_envs, self.obs_dim, _lib.T_COUNT
+            view = lambda p, n, shape: np.frombuffer((C.c_double * n).from_address(p.value), dtype=np.float64).reshape(shape)
+            self._tel_views = (view(pt, T * N, (T, N)), view(po, N * D, (N, D)), view(pr, N, (N,)))
+        return self._tel_views
 
     def slots(self):
         """list over stations of arrays [N, 9, piles_k]: car, charge, emergency, power, soc, init_soc, target_soc,
@@ -403,7 +423,7 @@ class VecChargingHub(object):
         if getattr(self, "_h", None):
             self._lib.chub_destroy(self._h)
             self._h = None
-            self._obs = self._reward = self._done = self._pinned = self._pinned_bits = None
+            self._obs = self._reward = self._done = self._pinned = self._pinned_bits = self._tel_views = None
             for p in self._host_allocs:
                 self._lib.chub_free_host(self._device, p)
             self._host_allocs = []

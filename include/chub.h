@@ -83,7 +83,13 @@ enum {
     CHUB_T_TOTAL_MASS_NEED, CHUB_T_HY_USE, CHUB_T_NOT_MEET, CHUB_T_FC_POWER, CHUB_T_HY_TO_USE,
     CHUB_T_USED_RENEW, CHUB_T_EV0, CHUB_T_EV1, CHUB_T_HYDROGEN_POWER, CHUB_T_INCOME, CHUB_T_REWARD,
     CHUB_T_RE_PV, CHUB_T_RE_WD, CHUB_T_PRICE_NEXT, CHUB_T_HV_ARRIVE, CHUB_T_HV_LINE, CHUB_T_QUEUE_LEN,
-    CHUB_T_PV_DAY, CHUB_T_WD_DAY, CHUB_T_COUNT
+    CHUB_T_PV_DAY, CHUB_T_WD_DAY,
+    /* ev_power_list / ev_power_sum after the fuel-cell rescale -- what the incomes and cumulated_draw_ele use (MGR:219-224, 262) --
+     * and real_state[1] as the step found it (MGR:234) */
+    CHUB_T_EV0_NET, CHUB_T_EV1_NET, CHUB_T_EV_SUM_NET, CHUB_T_PRICE_NOW,
+    /* per station what make_state puts into real_state (MGR:364-368) + flow_in_number[-1] (MGR:246); valid after reset too */
+    CHUB_T_MIN0, CHUB_T_CHG0, CHUB_T_MAX0, CHUB_T_LINE0, CHUB_T_FLOW0, CHUB_T_MIN1, CHUB_T_CHG1, CHUB_T_MAX1, CHUB_T_LINE1, CHUB_T_FLOW1,
+    CHUB_T_COUNT
 };
 
 /* ---- lifetime ------------------------------------------------------------------------------
@@ -245,6 +251,12 @@ int chub_get_telemetry(chub_env *env, double *out);
 int chub_get_obs_f64(chub_env *env, double *out);
 int chub_get_reward_f64(chub_env *env, double *out);
 int chub_set_telemetry(chub_env *env, int enabled); /* off by default: the hot path then skips those stores */
+/* The telemetry block lives in pinned host memory that the device writes directly (no copy back): *telem [CHUB_T_COUNT][N] (column-
+ * major: one row per CHUB_T_* index), *obs64 [N][D], *reward64 [N], all f64, owned by the handle, valid while telemetry stays on.
+ * Contents are current once the call that produced them has completed (any host-pointer entry point returns completed; after a
+ * device-pointer call: chub_sync / a stream synchronise).  This is how EvcsspManagerEnv_v6.step() reads everything the reference
+ * class exposes after a step (MGR:183-297, 364-372) without one device read. */
+int chub_telemetry_host(chub_env *env, double **telem, double **obs64, double **reward64);
 
 /* The FCEV waiting list is unbounded as in the reference (HYD:264-265): the entries a list that still gets served can
  * hold are kept one by one, and once no prefix of it fits into 15 minutes any more (HYD:270-276: nobody is served again
@@ -297,10 +309,11 @@ int chub_stream_sync(int device, void *stream);
 /* ---- tape mode: a parity instrument for the production (PHILOX) kernels ------------------------------------------------
  * The production streams are this build's own definition, so the kernels that run them cannot be compared with the
  * reference's recorded trajectories seed for seed.  Tape mode closes that gap: the caller supplies what the streams
- * would have drawn -- per (station, env) unit the step's packed station-level decisions (queue renege bits, arrivals,
- * balk survivors: the layout draw_station_levels packs, chub_kernels.hip) and per admitted car its arrival SoC, target
- * level and extra stay -- and the SAME packed slot kernel replays them.  Arbitrary arrival SoCs are registered as extra
- * classes of the class table first.  tests/test_gpu_tape.py replays the reference fixtures this way.
+ * would have drawn -- per (station, env) unit the step's packed station-level decisions (64 bits: bits 0-9 one renege-pass bit per
+ * queue position, 10-13 arrivals n <= 9, 14 + 4 l (l = 0..10) how many of the n arrivals stay if the queue holds l cars after the
+ * renege pass; k_draw_levels decodes the word against the unit's live queue, dk_make in chub_kernels.hip) and per admitted car its
+ * arrival SoC, target level and extra stay -- and the SAME packed slot kernel replays them.  Arbitrary arrival SoCs are registered as
+ * classes of the class table first.  tests/test_gpu_tape.py replays every reference fixture this way, evs_reset included.
  *   chub_tape_register_soc: soc[count] -> class_ids[count] (at most 8192 per handle).
  *   chub_set_slots:        rows [N][S][6] i32 in hub order (station 0's slots first): class (-1 = empty), target level,
  *                          stay_time, already_stay_time, car_steps taken, charging flag.
@@ -312,6 +325,10 @@ int chub_set_slots(chub_env *env, const int32_t *rows);
 int chub_set_station_queue(chub_env *env, const int32_t *line);
 int chub_step_tape(chub_env *env, const float *actions, const uint64_t *pk_tape, const uint32_t *car_tape, float *obs,
                    float *reward, uint8_t *done);
+/*   chub_reset_tape:       one reset of every env, evs_reset (CHS.hpp:1209-1231 / 1520-1542) fed the reference's draws: occ_tape [2][N] u32
+ *                          = what init_station_car_number and the balk pass of the empty queue came to per unit (arrivals as signed 16
+ *                          bits | arrivals that stay << 16: the word k_reset_levels leaves), car_tape as above for the cars admitted. */
+int chub_reset_tape(chub_env *env, const uint32_t *occ_tape, const uint32_t *car_tape, float *obs);
 
 /* Snapshot / restore of the whole simulation state (clock, streams, every slot and env variable): checkpoint /
  * resume, planners that branch from a state.  The reference cannot do this (pickling disabled, main.cpp:234; raw

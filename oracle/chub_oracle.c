@@ -568,7 +568,7 @@ static void calculate_output(orc_station *s) {
         for (int i = 0; i < s->n; i++) {
             if (!(s->car[i] > 0.5)) continue;
             number += 1;
-            int32_t q = (int32_t) (s->power[i] * 524288.0f);
+            int32_t q = (int32_t) rintf(s->power[i] * 524288.0f); /* exact product, nearest integer (ties to even): kw_to_fixed */
             amax += q;
             if (s->emergency[i] > 8) amin += q;
             if (s->charge[i] <= 1.1 && s->charge[i] >= 0.9) anow += q;
@@ -1224,6 +1224,10 @@ static void env_step_impl(orc_env *e, const float *action, const double *exo_z, 
     }
     double hy_loss = -6 / 1000.0 * e->hy_to_use;
     e->hydrogen_power_grid = hydrogen_power;
+    e->ev_net[0] = ev_list[0]; /* ... and what the incomes and cumulated_draw_ele use is the list AFTER it, MGR:219-224, 262 */
+    e->ev_net[1] = ev_list[1];
+    e->ev_sum_net = ev_power_sum; /* self.real_charging_power / self.re_ev_power_sum, MGR:229-231 */
+    e->price_now = e->price_next; /* real_state[1] as this step found it, MGR:234 */
     /* MGR:233-269 incomes and reward */
     double real_price_dollar = e->price_next / 4;
     double income_evs_fast = 0.42 / 4 * P[0] - real_price_dollar * ev_list[0];
@@ -1412,7 +1416,7 @@ int orc_env_q_overflow(const orc_env *e) { return e->q_overflow; }
 void orc_env_hy_table(const orc_env *e, double *out102) { memcpy(out102, e->hy_table, sizeof e->hy_table); }
 
 /* telemetry named after the reference attributes (MGR:183-297, HYD) */
-enum { ORC_TELEM_COUNT = 24 };
+enum { ORC_TELEM_COUNT = 38 };
 int orc_env_telemetry(const orc_env *e, double *out) {
     int i = 0;
     out[i++] = e->hy_act;              /* 0  self.hy_act */
@@ -1439,6 +1443,17 @@ int orc_env_telemetry(const orc_env *e, double *out) {
     out[i++] = (double) e->q_len;      /* 21 len(hvs.needed_time_list) */
     out[i++] = (double) e->pv_day;     /* 22 */
     out[i++] = (double) e->wd_day;     /* 23 */
+    out[i++] = e->ev_net[0];           /* 24 ev_power_list[0] after the fuel-cell rescale (MGR:219-224) */
+    out[i++] = e->ev_net[1];           /* 25 */
+    out[i++] = e->ev_sum_net;          /* 26 self.real_charging_power */
+    out[i++] = e->price_now;           /* 27 4 * self.re_price_dollar */
+    for (int k = 0; k < 2; k++) {      /* 28-37 what make_state reads off the stations (MGR:364-368) + flow_in_number[-1] */
+        out[i++] = e->st[k].min_power;
+        out[i++] = e->st[k].charge_power;
+        out[i++] = e->st[k].max_power;
+        out[i++] = (double) e->st[k].line;
+        out[i++] = (double) e->st[k].flow_in_last;
+    }
     return i;
 }
 

@@ -125,6 +125,7 @@ typedef struct {
     double time_now, price_next;
     /* last-step telemetry (MGR:183-269) */
     double used_renew, ev_list[2], hydrogen_power_grid, income, reward;
+    double ev_net[2], ev_sum_net, price_now; /* ev_power_list / ev_power_sum after the fuel cell, real_state[1] as the step found it */
     int obs_dim;
 } orc_env;
 

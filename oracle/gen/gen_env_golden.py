@@ -41,6 +41,25 @@ TELEM = ["hy_act", "hy_flow_speed", "all_power_second", "Store_SOC", "capacity",
          "reward", "re_pv_power", "re_wd_power", "price_next", "arrive_number", "hvs_line", "queue_len"]
 
 
+# attributes of the reference class that trainers and evaluation scripts read after step() (MGR:128-130, 229-297, 372): recorded
+# per step so that the drop-in class can be held to them
+ATTRS = ["cumulated_draw_ele", "cumulated_income", "acumulate_reward", "deviation", "test_penalty", "penalty", "re_price_dollar",
+         "real_charging_power", "re_ev_power_sum", "re_income_evs_cost", "re_income_evs_serve", "re_income_hys", "re_hy_cost",
+         "re_hy_gen", "re_hydrogen_power_init", "re_hy_for_fc", "gen_hy", "re_income_evs_list_0", "re_income_evs_list_1",
+         "re_income_evs_cost_list_0", "re_income_evs_cost_list_1"]
+
+
+def attributes(env):
+    out = []
+    for name in ATTRS:
+        if name[-2:] in ("_0", "_1") and name[:-2] in ("re_income_evs_list", "re_income_evs_cost_list"):
+            out.append(float(getattr(env, name[:-2])[int(name[-1])]))
+        else:
+            v = getattr(env, name, np.nan)  # test_penalty does not exist before the first episode end (MGR:290)
+            out.append(np.nan if v is None else float(v))
+    return out
+
+
 class Recorder:
     """Records every np.random.normal() draw and which OU channel consumed it."""
 
@@ -125,7 +144,8 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
     D = int(env.observation_space.shape[0])
     hy_table = np.array(env.hy_sys.hy_power_speed_list, dtype=np.float64)
     data = dict(obs=[], reward=[], done=[], action=[], exo_z=[], telem=[], stations=[], reset_obs=[], reset_days=[],
-                reset_z=[], reset_stations=[], slots0=[], slots1=[], seeds=[], reset_slots0=[], reset_slots1=[])
+                reset_z=[], reset_stations=[], slots0=[], slots1=[], seeds=[], reset_slots0=[], reset_slots1=[], attrs=[],
+                real_state=[], reset_real_state=[], action_real=[], reset_attrs=[])
     for ep in range(episodes):
         if seeds is not None and (ep == 0 or reseed_each_episode):
             g, m = seeds[0] + ep, seeds[1] + ep
@@ -137,6 +157,8 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
         data["reset_days"].append([env.renew.pv_day, env.renew.wd_day])
         data["reset_z"].append(rec.take())
         data["reset_stations"].append(station_block(env))
+        data["reset_real_state"].append(np.array(env.real_state, dtype=np.float64))
+        data["reset_attrs"].append([float(env.cumulated_income), float(env.cumulated_draw_ele), float(env.penalty)])
         data["reset_slots0"].append(env.env_aggregator.evcssp_evs_objects[0].slots())
         data["reset_slots1"].append(env.env_aggregator.evcssp_evs_objects[1].slots())
         for t in range(steps_per_episode):
@@ -159,6 +181,9 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
             data["exo_z"].append(rec.take())
             data["telem"].append(telemetry(env))
             data["stations"].append(station_block(env))
+            data["attrs"].append(attributes(env))
+            data["real_state"].append(np.array(env.real_state, dtype=np.float64))
+            data["action_real"].append(np.array(env.action_real, dtype=np.float64))
             sts = env.env_aggregator.evcssp_evs_objects
             data["slots0"].append(sts[0].slots())
             data["slots1"].append(sts[1].slots())
@@ -179,6 +204,7 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
     out["episodes"] = np.array(episodes)
     out["steps_per_episode"] = np.array(steps_per_episode)
     out["telem_names"] = np.array(TELEM)
+    out["attr_names"] = np.array(ATTRS)
     out["ret"] = np.array(float(np.sum(out["reward"][:steps_per_episode])))
     os.makedirs(GOLD, exist_ok=True)
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)

@@ -312,7 +312,7 @@ class OrcEnv:
         return obs, r.value, bool(d.value)
 
     def telemetry(self):
-        out = np.zeros(24)
+        out = np.zeros(38)
         orc.orc_env_telemetry(self.e, ptr(out))
         return out
 

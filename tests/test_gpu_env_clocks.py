@@ -484,6 +484,75 @@ def test_graph_replay_on_per_env_clocks(G):
     assert not np.array_equal(out[1][0][:, :-2], out[1][1][:, :-2]), "a replay is a new period, not the same one again"
 
 
+def test_graph_replay_on_per_env_clocks_after_an_odd_number_of_eager_calls():
+    """the per-env clocks are double-buffered by the parity of the launch argument the graph bakes in.  After an ODD
+    number of calls issued one by one -- between capture and replay, or between two replays -- the live clocks sit in the
+    buffer the graph's first launch does NOT read; chub_graph_launch brings them over.  Capture, replay, one masked step,
+    replay, one masked reset + two steps, replay: against the same calls issued one by one, env_clocks() included."""
+    chub = hub()
+    from charginghub_env_amd import multi_gpu
+    from charginghub_env_amd._lib import check
+    n = 200
+    grp = (np.arange(n) % 3)
+    out = []
+    for mode in ("eager", "graph"):
+        v = chub.VecChargingHub(n, seed=909, env_id0=5, **KW)
+        lib, h = v._lib, v._h
+        st = multi_gpu.Stream(0)
+        acts = [multi_gpu.DeviceBuffer(n * v.act_dim * 4) for _ in range(4)]
+        for b, a in enumerate(acts):
+            v.random_actions_device(a.ptr, 47, b, st.ptr)
+        packed = [multi_gpu.DeviceBuffer(n * (v.obs_dim + 2) * 4) for _ in range(2)]
+        obs = multi_gpu.DeviceBuffer(n * v.obs_dim * 4)
+        rew, done = multi_gpu.DeviceBuffer(n * 4), multi_gpu.DeviceBuffer(n)
+        v.reset_device(obs.ptr, stream=st.ptr)
+        for k in range(1, 8):  # three clocks, 0 / 3 / 7 slots ahead
+            m = np.ascontiguousarray(np.array([0, 3, 7])[grp] >= k, dtype=np.uint8)
+            check(lib.chub_step_envs_device(h, m.ctypes.data, acts[k % 4].ptr, None, obs.ptr, rew.ptr, done.ptr, st.ptr))
+        st.sync()
+        assert v.clock_groups == 3
+        m1 = np.ascontiguousarray(grp == 1, dtype=np.uint8)
+        m2 = np.ascontiguousarray(grp != 1, dtype=np.uint8)
+
+        def body():  # four launches: three steps of everybody, one masked step
+            v.step_device_packed(acts[0].ptr, packed[0].ptr, stream=st.ptr)
+            v.step_device_packed(acts[1].ptr, packed[1].ptr, stream=st.ptr)
+            check(lib.chub_step_envs_device(h, m2.ctypes.data, acts[2].ptr, None, obs.ptr, rew.ptr, done.ptr, st.ptr))
+            v.step_device_packed(acts[3].ptr, packed[1].ptr, stream=st.ptr)
+
+        g = None
+        if mode == "graph":
+            st.sync()
+            v.graph_begin(st.ptr)
+            body()
+            g = v.graph_end(st.ptr)
+        run = (lambda: v.graph_launch(g, st.ptr)) if g is not None else body
+        trace = []
+
+        def snap():
+            st.sync()
+            t, ticks = v.env_clocks(ticks=True)
+            trace.extend([t, ticks, packed[1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr), obs.to_host(np.float32, (n, v.obs_dim), st.ptr),
+                          np.concatenate([x.reshape(n, -1) for x in v.slots()], axis=1), v.station_scalars().reshape(n, -1)])
+
+        run(); snap()
+        check(lib.chub_step_envs_device(h, m1.ctypes.data, acts[1].ptr, None, obs.ptr, rew.ptr, done.ptr, st.ptr))  # ONE call: odd
+        run(); snap()
+        check(lib.chub_reset_envs_device(h, m1.ctypes.data, None, None, obs.ptr, st.ptr))  # three calls: odd again
+        v.step_device_packed(acts[2].ptr, packed[0].ptr, stream=st.ptr)
+        v.step_device_packed(acts[3].ptr, packed[1].ptr, stream=st.ptr)
+        run(); snap()
+        v.step_device_packed(acts[0].ptr, packed[1].ptr, stream=st.ptr)  # and on from there call by call
+        snap()
+        out.append(trace)
+        if g is not None:
+            v.graph_destroy(g)
+        v.close()
+        st.destroy()
+    for k, (a, b) in enumerate(zip(*out)):
+        assert np.array_equal(a, b), ("segment", k, a, b)
+
+
 @pytest.mark.parametrize("shape", ["auto", "big"])
 def test_masked_scalar_load_steps_match_the_oracle(shape):
     """chub_step_load_envs: evs_step(float) for a SUBSET of the envs (every reference station takes it on its own,

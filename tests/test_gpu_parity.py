@@ -307,10 +307,12 @@ def _philox_parity(label, kw, n, data_dir=None, tables=None, plan=(96, 96, 10, 3
                     ws = np.zeros(8)
                     orc.orc_station_scalars(orc.orc_env_station(env, k), ptr(ws))
                     assert np.array_equal(sc[e, k, :6], ws[:6]), (label, ep, t, e, k, sc[e, k], ws)
-                wt = np.zeros(24)
+                wt = np.zeros(38)
                 orc.orc_env_telemetry(env, ptr(wt))
                 assert np.array_equal(tel[e, 19:24], wt[19:24]), (label, ep, t, e, tel[e, 19:24], wt[19:24])
                 close(tel[e, :19], wt[:19], (label, "telemetry", ep, t, e), rtol=TIGHT, atol=1e-7)
+                close(tel[e, 24:28], wt[24:28], (label, "telemetry (after the fuel cell)", ep, t, e), rtol=TIGHT, atol=1e-7)
+                assert np.array_equal(tel[e, 28:38], wt[28:38]), (label, "telemetry (station scalars)", ep, t, e, tel[e, 28:38], wt[28:38])
                 assert orc.orc_env_q_overflow(env) == 0
             assert np.array_equal(done, o_done.astype(bool))
             close(v.obs_f64(), o_obs, (label, "obs", ep, t), rtol=TIGHT, atol=TIGHT)
@@ -401,10 +403,29 @@ def test_env_test_known_answer():
     v.close()
 
 
+def _check_dropin_attributes(env, g, i, what):
+    """every attribute the reference class exposes after step() (recorded per step by oracle/gen/gen_env_golden.py: `attrs`,
+    `real_state`, `action_real`) on the drop-in class"""
+    names = [str(x) for x in g["attr_names"]]
+    want = dict(zip(names, g["attrs"][i]))
+    for name in names:
+        if name[-2:] in ("_0", "_1") and name[:-2] in ("re_income_evs_list", "re_income_evs_cost_list"):
+            got = getattr(env, name[:-2])[int(name[-1])]
+        elif name == "test_penalty" and np.isnan(want[name]):
+            assert not hasattr(env, "test_penalty"), (what, i, "test_penalty exists only from the first episode end on (MGR:290)")
+            continue
+        else:
+            got = getattr(env, name)
+        close(float(got), want[name], (what, name, i), rtol=TIGHT, atol=TIGHT)
+    close(env.real_state, g["real_state"][i], (what, "real_state", i), rtol=TIGHT, atol=TIGHT)
+    assert np.array_equal(np.asarray(env.action_real, dtype=np.float64), g["action_real"][i]), (what, "action_real", i)
+
+
 def test_dropin_class_reproduces_env_test():
     """test/env_test.py through the drop-in class, nothing injected: EvcsspManagerEnv_v6(**env_kwargs) with
     seed_rand=False after random.seed(0); np.random.seed(0), reset(), step(action=None) until done.
-    Reference: return 34.858789741560585, final H2 SOC 0.1525, and the recorded per-step obs / rewards."""
+    Reference: return 34.858789741560585, final H2 SOC 0.1525, the recorded per-step obs / rewards, and every attribute the
+    reference class carries after a step (cumulated_draw_ele, real_state, test_penalty at the episode end, re_* ...)."""
     import random
     chub = hub()
     g = orclib.load_golden("env_c1_envtest")
@@ -415,19 +436,55 @@ def test_dropin_class_reproduces_env_test():
                                    fc_max_power=100, fcev_permeate=0.01, use_lagrange=False, renew_fluctuate=0.0,
                                    price_fluctuate=0.0, hydro_loss=0.0)
     assert env.observation_space.shape == (13,) and env.action_space.shape == (47,)
+    assert env.real_state == [] and env.state is None and env.penalty == 0 and env.cumulated_draw_ele == 0  # MGR:121-130
     o = env.reset()
     close(o, g["reset_obs"][0], "drop-in reset obs", rtol=TIGHT, atol=TIGHT)
+    close(env.real_state, g["reset_real_state"][0], "drop-in reset real_state", rtol=TIGHT, atol=TIGHT)
+    assert [env.cumulated_income, env.cumulated_draw_ele, env.penalty] == list(g["reset_attrs"][0]) and env.lagrangian_factor is None
     done, ret, i = False, 0.0, 0
     while not done:
         s_, r, done, info = env.step(action=None)
         close(s_, g["obs"][i], ("drop-in obs", i), rtol=TIGHT, atol=TIGHT)
         close(r, g["reward"][i], ("drop-in reward", i), rtol=TIGHT, atol=TIGHT)
         assert isinstance(r, float) and isinstance(done, bool) and info == {}
+        _check_dropin_attributes(env, g, i, "c1")
         ret += r
         i += 1
     assert i == 96
     assert abs(ret - 34.858789741560585) < 1e-9
     assert abs(env._t_Store_SOC - 0.1525) < 1e-12
+    assert env.test_penalty > 0 and env.cumulated_draw_ele > 0
+    env.close()
+
+
+def test_dropin_class_reproduces_c3_random():
+    """the drop-in class on the C3 / C4 hub under the recorded random actions, two episodes back to back (the second without
+    re-seeding, as recorded): observations, rewards and every reference attribute, step by step.  The reference's two C++ streams
+    are process globals seeded by the fixture's generator in front of the constructor and of the first reset(); the drop-in class
+    takes the same seeds for this env's own streams (compat_seeds, set_compat_seeds)."""
+    import random
+    chub = hub()
+    g = orclib.load_golden("env_c3_random")
+    random.seed(1)      # py_seed of the fixture (oracle/gen/gen_env_golden.py: main)
+    np.random.seed(1)
+    kw = kwargs_of(g)
+    env = chub.EvcsspManagerEnv_v6(seed_rand=False, use_lagrange=False, compat_seeds=[int(x) for x in g["ctor_seeds"]], **kw)
+    steps, i = int(g["steps_per_episode"]), 0
+    seeds = {int(r[0]): (int(r[1]), int(r[2])) for r in g["seeds"]}
+    for ep in range(int(g["episodes"])):
+        if ep in seeds:
+            env.set_compat_seeds(*seeds[ep])
+        o = env.reset()
+        close(o, g["reset_obs"][ep], ("c3 reset obs", ep), rtol=TIGHT, atol=TIGHT)
+        close(env.real_state, g["reset_real_state"][ep], ("c3 reset real_state", ep), rtol=TIGHT, atol=TIGHT)
+        assert [env.cumulated_income, env.cumulated_draw_ele, env.penalty] == list(g["reset_attrs"][ep])
+        for t in range(steps):
+            s_, r, done, info = env.step(g["action"][i])
+            close(s_, g["obs"][i], ("c3 obs", i), rtol=TIGHT, atol=TIGHT)
+            close(r, g["reward"][i], ("c3 reward", i), rtol=TIGHT, atol=TIGHT)
+            assert done == bool(g["done"][i])
+            _check_dropin_attributes(env, g, i, "c3")
+            i += 1
     env.close()
 
 

@@ -36,6 +36,7 @@ def test_env_trajectory_matches_reference(name):
     S0 = cfg.piles[0]
     i = 0
     ret = 0.0
+    draw = 0.0
     for ep in range(int(g["episodes"])):
         if ep in seeds:
             env.seed_compat(*seeds[ep])
@@ -58,6 +59,17 @@ def test_env_trajectory_matches_reference(name):
             _close(obs, g["obs"][i], (name, "obs", ep, t))
             _close(r, g["reward"][i], (name, "reward", ep, t))
             _close(tel[:19], g["telem"][i][:19], (name, "telem", ep, t), rtol=1e-11, atol=1e-9)
+            # what the reference class carries after the step beyond that (recorded as `attrs`): ev_power_list / ev_power_sum after
+            # the fuel cell through the attributes made of them, and real_state
+            at = dict(zip([str(x) for x in g["attr_names"]], g["attrs"][i]))
+            rpd = tel[27] / 4
+            _close([tel[26], rpd, -rpd * tel[24], -rpd * tel[25], 0.42 / 4 * tel[29], 0.21 / 4 * tel[34], 0.8 * (tel[32] + tel[37])],
+                   [at["real_charging_power"], at["re_price_dollar"], at["re_income_evs_cost_list_0"], at["re_income_evs_cost_list_1"],
+                    at["re_income_evs_list_0"], at["re_income_evs_list_1"], at["re_income_evs_serve"]], (name, "attrs", ep, t), rtol=1e-11, atol=1e-9)
+            draw = (draw if t else 0.0) + (tel[24] + tel[25] + tel[13])
+            _close(draw, at["cumulated_draw_ele"], (name, "cumulated_draw_ele", ep, t), rtol=1e-11, atol=1e-9)
+            cols = [18] + [c for k in (0, 1) if int(g["kw_station_list"][k]) > 0 for c in range(28 + 5 * k, 32 + 5 * k)] + [3, 16, 17]
+            _close(tel[cols], g["real_state"][i][1:], (name, "real_state", ep, t), rtol=1e-11, atol=1e-9)
             if ep == 0:
                 ret += r
             i += 1

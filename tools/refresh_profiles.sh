@@ -5,6 +5,7 @@
 # Copy the files into profiles/ (tracked) afterwards.
 set -e
 TAG=${1:-vX}
+ROUND=${ROUND:-round4}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -22,10 +23,10 @@ echo "cache passes done"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_c5 --output-format csv -- python3 bench.py --config c5 $ARGS > /dev/null 2> $OUT/pmc_fetch_c5.err
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_c5 --output-format csv -- python3 bench.py --config c5 $ARGS > /dev/null 2> $OUT/pmc_write_c5.err
 echo "c5 traffic passes done"
-python3 - "$OUT" "$TAG" <<'PY'
+python3 - "$OUT" "$TAG" "$ROUND" "$ARGS" <<'PY'
 import csv, glob, json, sys
 from collections import defaultdict
-out, tag = sys.argv[1], sys.argv[2]
+out, tag, rnd, bench_args = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
 def collect(d):
     acc = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -50,7 +51,8 @@ build_id = chub.load_library().chub_build_id().decode()
 # reports half of the bytes fetched (128-byte requests tallied at 64 bytes), WRITE_SIZE is exact; both in KiB
 FETCH_FACTOR, WRITE_FACTOR = 2.0, 1.0
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* / TCC_* / TCP_* (separate passes), mean per dispatch over the step kernels "
-               "of bench.py --steps 96 at 65536 envs x [20,25]; KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950",
+               "of bench.py " + bench_args + " at 65536 envs x [20,25] (the timed steps of such a run go out as hipGraph replays: the sampled "
+               "dispatches are graph-launched kernels); KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950",
        "build_id": build_id, "envs": 65536, "hub": [20, 25],
        "calibration": {"fetch_factor": FETCH_FACTOR, "write_factor": WRITE_FACTOR}}
 KEYS = (("k_slot", ("k_slot_packed<256, 2, false, false",)), ("k_env", ("k_env<false",)))
@@ -59,7 +61,7 @@ for label, key in KEYS:
     res[label] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                   "traffic_bytes_per_launch": (f * FETCH_FACTOR + w * WRITE_FACTOR) * 1024.0}
     res[label + "_sq_counters_per_dispatch"] = pick(sq, key)
-json.dump(res, open("%s/round3_%s_pmc_traffic.json" % (out, tag), "w"), indent=1)
+json.dump(res, open("%s/%s_%s_pmc_traffic.json" % (out, rnd, tag), "w"), indent=1)
 print(json.dumps(res["k_slot"]))
 fe5, wr5 = collect(out + "/pmc_fetch_c5"), collect(out + "/pmc_write_c5")
 res5 = {"note": "the same FETCH_SIZE / WRITE_SIZE passes on bench.py --config c5 (262144 envs x [32,32]: 134 MB of slot state, beyond the "
@@ -68,16 +70,16 @@ res5 = {"note": "the same FETCH_SIZE / WRITE_SIZE passes on bench.py --config c5
 for label, key in KEYS:
     f, w = pick(fe5, key).get("FETCH_SIZE", 0.0), pick(wr5, key).get("WRITE_SIZE", 0.0)
     res5[label] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes_per_launch": (f * FETCH_FACTOR + w * WRITE_FACTOR) * 1024.0}
-json.dump(res5, open("%s/round3_%s_pmc_traffic_c5.json" % (out, tag), "w"), indent=1)
+json.dump(res5, open("%s/%s_%s_pmc_traffic_c5.json" % (out, rnd, tag), "w"), indent=1)
 print(json.dumps(res5["k_slot"]))
 PY
 # the traffic summaries go where bench.py looks for them (profiles/, matched by build id), so that the bench lines written next
 # carry `roofline.traffic` of this very build
-cp $OUT/round3_${TAG}_pmc_traffic.json $OUT/round3_${TAG}_pmc_traffic_c5.json profiles/
-python3 bench.py > $OUT/round3_${TAG}_bench.json 2> $OUT/bench.err
-echo "bench done"; tail -c 400 $OUT/round3_${TAG}_bench.json; echo
-rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 > $OUT/round3_${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
-cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/round3_${TAG}_kernel_stats.csv
+cp $OUT/${ROUND}_${TAG}_pmc_traffic.json $OUT/${ROUND}_${TAG}_pmc_traffic_c5.json profiles/
+python3 bench.py > $OUT/${ROUND}_${TAG}_bench.json 2> $OUT/bench.err
+echo "bench done"; tail -c 400 $OUT/${ROUND}_${TAG}_bench.json; echo
+rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 > $OUT/${ROUND}_${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
+cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats.csv
 echo "kernel trace done"
 rm -rf $OUT/kt $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_tcc $OUT/pmc_tcp $OUT/pmc_fetch_c5 $OUT/pmc_write_c5
 ls $OUT
