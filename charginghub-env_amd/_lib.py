@@ -24,11 +24,12 @@ T = {name: i for i, name in enumerate(TELEMETRY_NAMES)}
 
 class ChubOptions(C.Structure):
     """chub_options of include/chub.h (all zero = defaults; the library reads no environment variables)"""
-    _fields_ = [("slot_kernel", C.c_int32), ("no_arena", C.c_int32), ("fused_step", C.c_int32), ("reserved", C.c_int32 * 5)]
+    _fields_ = [("slot_kernel", C.c_int32), ("no_arena", C.c_int32), ("fused_step", C.c_int32), ("tile", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 SLOT_KERNELS = {"auto": 0, "wave": 1, "packed": 2}
 FUSED_STEP = {"auto": 0, "off": 1, "on": 2}
+TILES = {"auto": 0, "small": 1, "large": 2}
 
 
 class ChubError(RuntimeError):
@@ -113,7 +114,7 @@ def load_library():
         "chub_comm_ranks_seen": (I, [P, C.POINTER(C.c_int), P]), "chub_device_info": (I, [I, P]),
         "chub_step_gather": (I, [P, P, P, P, P, P]), "chub_run_steps": (I, [P, P, P, I, P, P, P, L, L, P]),
         "chub_tape_register_soc": (I, [P, P, C.c_int32, P]), "chub_set_slots": (I, [P, P]), "chub_set_station_queue": (I, [P, P]),
-        "chub_step_tape": (I, [P, P, P, P, P, P, P]), "chub_reset_tape": (I, [P, P, P, P]),
+        "chub_step_tape": (I, [P, P, P, P, P, P, P]), "chub_reset_tape": (I, [P, P, P, P]), "chub_tape_clear_soc": (I, [P]),
         "chub_graph_begin": (I, [P, P]), "chub_graph_end": (I, [P, P, C.POINTER(P)]), "chub_graph_launch": (I, [P, P]),
         "chub_graph_destroy": (I, [P]),
         "chub_malloc_device": (I, [I, L, C.POINTER(P)]), "chub_free_device": (I, [I, P]), "chub_copy_to_host": (I, [I, P, P, L, P]),
@@ -121,7 +122,12 @@ def load_library():
         "chub_stream_sync": (I, [I, P]),
     }
     for name, (res, args) in sig.items():
-        fn = getattr(lib, name)  # AttributeError here == ABI drift between chub.h and the library
+        try:
+            fn = getattr(lib, name)  # AttributeError here == ABI drift between chub.h and the library
+        except AttributeError:
+            if os.environ.get("CHUB_LIB"):  # an older build loaded on purpose (A/B timing): it simply lacks the newer entry points
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     _lib = lib
@@ -136,7 +142,7 @@ EXPORTED = ["chub_create", "chub_create_ex", "chub_destroy", "chub_obs_dim", "ch
             "chub_state_size", "chub_get_state", "chub_set_state", "chub_get_hy_table", "chub_get_hy_table_env", "chub_set_hy_table", "chub_last_error", "chub_device_count", "chub_build_id",
             "chub_comm_unique_id", "chub_comm_create", "chub_comm_destroy", "chub_comm_world", "chub_comm_rank", "chub_comm_gather",
             "chub_comm_max_f64", "chub_comm_barrier", "chub_comm_ranks_seen", "chub_device_info", "chub_step_gather", "chub_run_steps", "chub_tape_register_soc", "chub_set_slots",
-            "chub_set_station_queue", "chub_step_tape", "chub_reset_tape", "chub_telemetry_host", "chub_graph_begin", "chub_graph_end", "chub_graph_launch", "chub_graph_destroy",
+            "chub_set_station_queue", "chub_step_tape", "chub_reset_tape", "chub_tape_clear_soc", "chub_telemetry_host", "chub_graph_begin", "chub_graph_end", "chub_graph_launch", "chub_graph_destroy",
             "chub_malloc_device", "chub_free_device", "chub_copy_to_host", "chub_copy_to_device", "chub_alloc_host", "chub_free_host", "chub_stream_create",
             "chub_stream_destroy", "chub_stream_sync"]
 

@@ -40,8 +40,19 @@ constexpr int kSlotBlock = 256;    // workgroup size of the slot kernels
 #endif
 constexpr int kPackedBlock = CHUB_PACKED_BLOCK;  // workgroup size of the packed slot kernel
 constexpr int kSlotsPerLane = CHUB_SLOTS_PER_LANE;  // packed slot kernel: slots per lane (kPackedBlock * kSlotsPerLane virtual lanes per workgroup)
+// ... and its second tile, for handles whose slot state + action rows stream from HBM instead of living in the caches: 512 lanes x 4
+// slots = 2048 slots per workgroup, 8 KB runs of state and of action rows.  Measured (262 144 envs x [32, 32], float rows):
+// 256 x 2: 102.9 us, 512 x 2: 97.3, 1024 x 2: 94.1, 512 x 3: 92.4, 512 x 4: 90.5, 512 x 6: 96.3, 1024 x 4: 131; at 65 536 x [20, 25]
+// (cache-resident) 256 x 2 / x 3 / x 4 and 512 x 2 all take 20.8 us, 512 x 4 21.7
+#ifndef CHUB_BIG_BLOCK
+#define CHUB_BIG_BLOCK 512
+#endif
+#ifndef CHUB_BIG_SLOTS_PER_LANE
+#define CHUB_BIG_SLOTS_PER_LANE 4
+#endif
+constexpr int kBigBlock = CHUB_BIG_BLOCK, kBigSlotsPerLane = CHUB_BIG_SLOTS_PER_LANE;
+constexpr int64_t kBigTileSlots = (int64_t) 10 << 20;  // handles of at least this many charger slots take the second tile (chub_options.tile overrides)
 constexpr int kClsRow = 32;        // PHILOX: entries (power, t_soc) per arrival-SoC class = car_steps a car can take (stay_time <= 27 here)
-constexpr int kTapeClasses = 8192; // PHILOX: room for caller-registered arrival-SoC classes (tape mode)
 constexpr int kTelemCount = 38;
 constexpr int kFusedMaxBlocks = 256;   // PHILOX lock-step steps of at most this many slot workgroups (one per CU) run as ONE launch (k_step_fused):
                                        // measured 8.2 vs 9.0 us per step at 128 workgroups (C2), 11.3 vs 11.0 at 745, 17.4 vs 13.7 at 1490
@@ -74,11 +85,12 @@ struct SlotArrays {          // index = base_k + env*S_k + slot  (station-major)
     //   .z t_soc     soc_to_time(soc)      -- cached, what car_step and calculate_needed both need
     //   .w bits 0-6 stay_time - already_stay_time (0 = empty), bit 7 charging this step, bits 8-14 stay_time,
     //      bits 15-24 target-SoC level l (target = 80 + 20 * l / 999, CHS.hpp:35-44), bits 25-31 car_steps taken since arrival
-    CHUB_G(uint32_t) hot;    // COMPAT [NS][4], station-major; PHILOX [2][N][S0 + S1] (plane 0: w0, plane 1: w1): the 8-byte slot state described in
+    CHUB_G(uint32_t) hot;    // COMPAT [NS][4], station-major; PHILOX [N][S0 + S1]: the 4-byte slot state described in
                              // chub_kernels.hip, hub-major (station 0's piles, then station 1's, like an action row)
     // cold: written once per arriving car, read only by introspection.  Current SoC = arrival SoC advanced by the
     // recorded number of car_steps (k_replay_soc), target SoC from its level; slots without a car read as zeros.
-    CHUB_G(float) init_soc;  // arrival SoC
+    CHUB_G(float) init_soc;  // arrival SoC (COMPAT)
+    CHUB_G(uint8_t) stay8;   // PHILOX [N][S0 + S1]: Station::stay_time of the car in the slot (CHS.hpp:245), written when it is admitted
 };
 
 struct StationArrays {       // unit index u = k*N + env
@@ -141,9 +153,9 @@ struct Tables {
     CHUB_G(const double) sin96;       // [96]   sin(2*pi*t/96), the time feature of the observation (MGR:319-320)
     CHUB_G(const float) ttab[2];      // [1000] soc_to_time(target level k) of station k's curve (target = 80 + 20*k/999)
     CHUB_G(const float) ttab2;        // [2][1024] the same two tables in one padded buffer (packed slot kernel: LDS staging)
-    CHUB_G(const float) cls[2];       // [kSocLevels + kTapeClasses + 1][kClsRow][2] PHILOX: per arrival-SoC class of station k's curve:
+    CHUB_G(const float) cls[2];       // [kSocLevels + 1][kClsRow][2] PHILOX: per arrival-SoC class of station k's curve:
                                       //   (power, t_soc) after n = 0 .. kClsRow-1 car_steps (entry 0 = what add_car derives, CHS.hpp:864-877)
-    CHUB_G(const float) cls_soc0[2];  // [kSocLevels + kTapeClasses] the class's arrival SoC (introspection)
+    CHUB_G(const float) cls_soc0[2];  // [kSocLevels] the class's arrival SoC (introspection); tape mode overwrites rows of both tables
 };
 
 struct HubParams {
@@ -173,7 +185,8 @@ struct HubParams {
     double rc_cells, rc_cap_mass, rc_vm60k, rc_price_std, rc_half_range[2];
     float hv_rate;           // f32(f32(0.3) * f32(permeate))
     int32_t qcap;            // explicit FCEV waiting-list entries per env = max(1, 2 * (max arrivals per step) - 1)
-    int32_t epb;             // packed slot kernel: whole envs per workgroup = kPackedBlock * kSlotsPerLane / (S0 + S1)
+    int32_t epb;             // packed slot kernel: whole envs per workgroup = pblock * pslots / (S0 + S1)
+    int32_t pblock, pslots;  // packed slot kernel: the handle's tile, (kPackedBlock, kSlotsPerLane) or (kBigBlock, kBigSlotsPerLane)
     int32_t packed;          // PHILOX steps run k_slot_packed (any hub shape of up to 512 piles)
 };
 
@@ -193,6 +206,7 @@ struct PackedPtrs {
     const EnvArrays *ev;      // host copies of the array tables (launch_env / k_step build TailArgs from them)
     const StationArrays *st;
     uint32_t *hot, *rec;
+    uint8_t *stay8;
     uint32_t *pk[2];
     const float *cls[2], *ttab[2], *ttab2;
     uint32_t late8[8];        // the first 8 thresholds of Tables::late_thr, passed to the packed kernel by value

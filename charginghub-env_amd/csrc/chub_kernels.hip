@@ -1,7 +1,7 @@
 // chub_kernels.hip -- the per-step hot path of the charging-hub environment as CDNA4 (gfx950) kernels.
 //
 //   k_slot_packed   2 charger slots per lane, every PHILOX step and reset (production).  The workgroup's 512 virtual lanes are
-//           laid over whole envs end to end (hub-major 8-byte slot state, like the action rows); phases in the reference's
+//           laid over whole envs end to end (hub-major 4-byte slot state, like the action rows); phases in the reference's
 //           order (CHS.hpp:1188-1207 / 1499-1518): departures -> arrivals (pre-drawn levels, renege, balk) -> admission by
 //           ballot + prefix rank (across waves through LDS) in the shadow of the class-row reads -> on/off, car_step = the
 //           next row entry -> station sums (integer LDS atomics) -> last wave: add_car for the new cars, one 16-byte
@@ -47,10 +47,6 @@ __device__ __forceinline__ bool range_unit(const StepArgs &sa, int64_t i, int se
     env = sa.env_lo + (i - (int64_t) seg * R);
     return true;
 }
-// PHILOX slot state: the 8 bytes of a slot live in two planes of one array, [w0 of every slot][w1 of every slot] (slots hub-major in
-// both).  w0 changes every step of a car's stay; w1 (the target time) is written when the car is admitted and only read afterwards,
-// so a step moves 12 bytes of state per slot instead of 16.  The w1 of an empty slot is whatever its last car left: never looked at.
-__device__ __forceinline__ u32x2 ps_load(CHUB_G(const uint32_t) hot, uint32_t slots, uint32_t idx) { return u32x2{hot[idx], hot[slots + idx]}; }
 
 __device__ __forceinline__ int clk_t(uint32_t c) { return (int) (c & 127u); }
 __device__ __forceinline__ uint32_t clk_next(uint32_t c) {  // one step later: slot of day + 1 (mod 96), price_count + 1 (mod 4)
@@ -335,24 +331,28 @@ __device__ __forceinline__ int dk_flow(uint32_t dk) { return (int) ((dk >> 8) & 
 // COMPAT keeps, per slot, the 16-byte hot record of SlotArrays (power, t_target, t_soc, meta) and evaluates the charge
 // curves in the step (the reference's streams make the arrival SoC a continuous value).
 //
-// PHILOX keeps 8 bytes per slot and no curve is evaluated in the step at all.  The arrival SoC takes one of kSocLevels
+// PHILOX keeps FOUR bytes per slot and no curve is evaluated in the step at all.  The arrival SoC takes one of kSocLevels
 // classes, and a car's whole charging history is the deterministic chain soc -> soc_to_time -> +1 slot -> time_to_soc /
 // time_to_power (car_step, CHS.hpp:900-905 / 1065-1070) from that class: Tables::cls[k] holds, per class, (power, t_soc)
-// after n = 0 .. kClsRow-1 car_steps, built once on the host with the same curve functions (chub_curves.h).  The slot keeps
-//   w0: bits 0-5 stay_time - already_stay_time (0 = empty), bit 6 charging this step, bits 7-12 stay_time,
-//       bits 13-17 n = car_steps taken since arrival, bits 18-31 arrival-SoC class
-//   w1: soc_to_time(target SoC), f32 -- one of the 1000 values of Tables::ttab (target = 80 + 20 * l / 999, CHS.hpp:35-44),
-//       looked up once, when the car is admitted
-// and everything the step needs follows from one 16-byte row read (entries n and n + 1: where the car is on its curve and
-// where one more car_step takes it).
-__device__ __forceinline__ int ps_tl(uint32_t w0) { return (int) (w0 & 63u); }
-__device__ __forceinline__ uint32_t ps_n(uint32_t w0) { return (w0 >> 13) & 31u; }
-__device__ __forceinline__ uint32_t ps_cls(uint32_t w0) { return w0 >> 18; }
-__device__ __forceinline__ uint32_t ps_make(int stay, uint32_t cls) {  // a car that has just arrived
-    return (uint32_t) stay | ((uint32_t) stay << 7) | (cls << 18);
+// after n = 0 .. kClsRow-1 car_steps, built once on the host with the same curve functions (chub_curves.h).  The slot keeps ONE word:
+//   bits 0-4   stay_time - already_stay_time (0 = empty)        bit 5      charging this step
+//   bits 6-10  n = car_steps taken since arrival                 bits 11-21 arrival-SoC class
+//   bits 22-31 target-SoC level l (target = 80 + 20 * l / 999, CHS.hpp:35-44)
+// and everything the step needs follows from two reads issued together once the word is there: one 16-byte row read (entries n
+// and n + 1: where the car is on its curve and where one more car_step takes it) and soc_to_time(target) = Tables::ttab2[k][l], 4
+// bytes of a 4 KB table that lives in every CU's vector L1.  Round 3 kept that f32 in a second state word (8 bytes per slot, 12 B
+// read + 4 B written per slot and step); now a step reads 4 B and writes 4 B of state per slot.  stay_time itself (introspection
+// only: Station::stay_time, CHS.hpp:245) goes to a cold byte array when the car is admitted.
+__device__ __forceinline__ int ps_tl(uint32_t w) { return (int) (w & 31u); }
+__device__ __forceinline__ uint32_t ps_n(uint32_t w) { return (w >> 6) & 31u; }
+__device__ __forceinline__ uint32_t ps_cls(uint32_t w) { return (w >> 11) & 2047u; }
+__device__ __forceinline__ uint32_t ps_lev(uint32_t w) { return w >> 22; }
+__device__ __forceinline__ uint32_t ps_make(int stay, uint32_t cls, uint32_t lev) {  // a car that has just arrived
+    return (uint32_t) stay | (cls << 11) | (lev << 22);
 }
-static_assert(kSocLevels + kTapeClasses <= (1 << 14), "the class id has 14 bits of the state word");
-constexpr int kMaxStay = 63;  // 6-bit fields; chub_create checks that no reachable stay_time comes near it
+constexpr uint32_t kPsChg = 32u, kPsStep = 64u;  // the charging flag; one more car_step
+static_assert(kSocLevels <= (1 << 11) && kLevels <= (1 << 10) && kClsRow <= 32, "field widths of the state word");
+constexpr int kMaxStay = 31;  // 5-bit fields; chub_create refuses curves whose stays could exceed it
 
 // car_step (CHS.hpp:900-905 / 1065-1070): soc and power one slot further along the curve, evaluated together.  Same
 // expressions as time_to_soc / time_to_power (chub_curves.h), but the powers of x are shared between the two
@@ -651,7 +651,7 @@ __device__ void slot_body_compat(const HubParams &hp, const StepArgs &sa, const 
 }
 
 // ---------------------------------------------------------------------------------------- k_slot, PHILOX, wave-local units
-// The same phases on the 8-byte PHILOX slot state for what the packed kernel below does not cover: the scalar-load control mode
+// The same phases on the 4-byte PHILOX slot state for what the packed kernel below does not cover: the scalar-load control mode
 // (and every step of a handle created with chub_options.slot_kernel = 1: the parity cross-check).  One unit = H = pow2 >= S_k lanes of one wave: ballot + prefix rank inside the wave,
 // integer DPP butterfly for the station sums.  Bit for bit the packed kernel's results (test_philox_other_slot_kernel runs
 // every step through this one).
@@ -680,21 +680,20 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     CHUB_G(const float) cls = tb.cls[k];
 
     uint32_t pk_in = 0;
-    u32x2 s2 = {0u, 0u};
+    uint32_t w0 = 0u;
     float a = 0.0f;
     if (unit_ok) pk_in = st.pk[sa.tick & 1u][sidx];
     if (!RESET && valid) {
-        s2 = ps_load(sl.hot, (uint32_t) N * (uint32_t) (hp.S[0] + hp.S[1]), idx);
+        w0 = sl.hot[idx];
         a = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot];
     }
-    uint32_t w0 = s2.x, w1 = s2.y;
     int tl = ps_tl(w0);
     bool car = tl > 0;
     f32x4 row = {0.0f, 0.0f, 0.0f, 0.0f};
     float t_target = 0.0f;
     if (car) {
         row = *(CHUB_G(const f32x4)) ((CHUB_G(const char)) cls + ((size_t) ps_cls(w0) * (kClsRow * 8u) + ps_n(w0) * 8u));
-        t_target = __uint_as_float(w1);
+        t_target = tb.ttab[k][ps_lev(w0)];
     }
     float power = row.x, t_soc = row.y;
     int on_override = -1;
@@ -706,9 +705,9 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     if (step) {  // car_step (CHS.hpp:900-905 / 1065-1070) = the next entry of the class row
         power = row.z;
         t_soc = row.w;
-        w0 += 1u << 13;
+        w0 += kPsStep;
     }
-    w0 &= ~64u;
+    w0 &= ~kPsChg;
     if (car) {  // remove_car (CHS.hpp:912-923 / 1077-1088)
         tl -= 1;
         w0 -= 1u;
@@ -719,7 +718,7 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
         }
     }
     const bool charge = on && car;
-    if (charge) w0 |= 64u;
+    if (charge) w0 |= kPsChg;
     if (RESET) w0 = 0u;
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): arrivals, renege, balk, admission
@@ -759,8 +758,8 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
         t_soc = e0.y;
         tl = stay;
         car = tl > 0;
-        w0 = car ? ps_make(stay, c) : 0u;
-        w1 = __float_as_uint(t_target);
+        w0 = car ? ps_make(stay, c, lev) : 0u;
+        sl.stay8[idx] = (uint8_t) stay;
     }
 
     // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572): order-independent sums -- every slot power rounded to the nearest
@@ -776,10 +775,7 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     if (H > 32) { i_min += __shfl_xor(i_min, 32); i_max += __shfl_xor(i_max, 32); i_chg += __shfl_xor(i_chg, 32); }
     const int cars = __popcll(__ballot(car) & unit_mask);
 
-    if (valid) {
-        sl.hot[idx] = w0;
-        if (adm) sl.hot[(uint32_t) N * (uint32_t) (hp.S[0] + hp.S[1]) + idx] = w1;  // the target time: written once, at admission
-    }
+    if (valid) sl.hot[idx] = w0;
     if (unit_ok && slot == 0) {
         rec_store(st.rec, sidx, fixed_to_kw(i_min), fixed_to_kw(i_chg), fixed_to_kw(i_max), pkd_make(line, flow, cars));
     }
@@ -821,7 +817,7 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
     // ---- the slot as the previous step left it
     float power = 0.0f, t_target = 0.0f, t_soc = 0.0f, a = 0.0f, next_power = 0.0f, next_t_soc = 0.0f;
     int tl = 0, meta = 0;
-    uint32_t w0 = 0u, w1 = 0u;
+    uint32_t w0 = 0u;
     if (!RESET && valid) {
         a = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot];
         if (MODE == MODE_COMPAT) {
@@ -830,13 +826,12 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
             tl = (int) (hot.w & 127u);
             meta = (int) (hot.w >> 8);
         } else {
-            const u32x2 s2 = ps_load(sl.hot, (uint32_t) N * (uint32_t) (hp.S[0] + hp.S[1]), idx);
-            w0 = s2.x; w1 = s2.y;
+            w0 = sl.hot[idx];
             tl = ps_tl(w0);
             if (tl > 0) {
                 const f32x4 row = *(CHUB_G(const f32x4)) ((CHUB_G(const char)) cls + ((size_t) ps_cls(w0) * (kClsRow * 8u) + ps_n(w0) * 8u));
                 power = row.x; t_soc = row.y; next_power = row.z; next_t_soc = row.w;
-                t_target = __uint_as_float(w1);
+                t_target = tb.ttab[k][ps_lev(w0)];
             }
         }
     }
@@ -910,9 +905,9 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
         if (on && tl > 1) {  // a car that leaves this step is wiped right after its car_step (CHS.hpp:1196-1201)
             power = next_power;
             t_soc = next_t_soc;
-            w0 += 1u << 13;
+            w0 += kPsStep;
         }
-        w0 &= ~64u;
+        w0 &= ~kPsChg;
         if (car) {
             tl -= 1;
             w0 -= 1u;
@@ -925,7 +920,7 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
         if (RESET) w0 = 0u;
     }
     const bool charge = on && car;
-    if (MODE == MODE_PHILOX && charge) w0 |= 64u;
+    if (MODE == MODE_PHILOX && charge) w0 |= kPsChg;
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): empties over the whole unit, admission rank = empties below the slot
     const bool empty = valid && !car;
@@ -1015,8 +1010,8 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
             stay = stay > kMaxStay ? kMaxStay : stay;
             power = e0.x; t_soc = e0.y; tl = stay;
             car = tl > 0;
-            w0 = car ? ps_make(stay, c) : 0u;
-            w1 = __float_as_uint(t_target);
+            w0 = car ? ps_make(stay, c, lev) : 0u;
+            sl.stay8[idx] = (uint8_t) stay;
         }
     } else if (MODE == MODE_COMPAT && (leave || RESET)) {
         meta = 0;
@@ -1045,7 +1040,6 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
             if (adm) sl.init_soc[idx] = nc_soc;
         } else {
             sl.hot[idx] = w0;
-            if (adm) sl.hot[(uint32_t) N * (uint32_t) (hp.S[0] + hp.S[1]) + idx] = w1;
         }
     }
     __syncthreads();
@@ -1081,7 +1075,7 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
 // written once.  A unit = one (env, station) = S_k consecutive virtual lanes; units may straddle a wave boundary, so every
 // (virtual) wave publishes its ballot of empty slots in LDS (admission rank = empties of the unit in the previous wave +
 // empties below the lane in its own wave), and the station sums are integer LDS atomics (order-independent by definition).
-// A slot is empty after this step iff its stay is over, which the 8-byte state says by itself: the ballots, the barrier,
+// A slot is empty after this step iff its stay is over, which the state word says by itself: the ballots, the barrier,
 // the renege / balk / admission arithmetic and the queueing of the admitted lanes all run while the class-row reads are
 // still in flight.  The new cars of the workgroup (a handful) and the station records are the last wave's business, one
 // lane per car / per unit; the other waves are done after the second barrier.
@@ -1090,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
 struct PackedArgs {
     uint32_t S[2], type[2];
     uint32_t n_envs, epb, magic, cls_delta;  // envs per workgroup; 2^20 / (S0 + S1) + 1; byte distance cls[1] - cls[0]
-    CHUB_G(uint32_t) state;          // [2][N][S0 + S1]: the w0 plane, then the w1 plane
+    CHUB_G(uint32_t) state;          // [N][S0 + S1]: one word per slot
     CHUB_G(uint32_t) rec;
     CHUB_G(const uint32_t) pk;       // this step's station draws per unit, decoded (dk_make); RESET: the raw initial-occupancy draws
     CHUB_G(const float) actions;
@@ -1105,6 +1099,7 @@ struct PackedArgs {
     CHUB_G(const uint8_t) env_mask;  // per-env clocks: non-zero = the launch serves this env (null: every env)
     uint32_t blk0;                   // ... and the first workgroup of the range of envs it names (the grid covers that range only)
     CHUB_G(float) tail_act;          // [N][2] out: the env's two tail actions, for the tail kernel (StationArrays::tail_act)
+    CHUB_G(uint8_t) stay8;           // [N][S0 + S1] out, per admitted car: its stay_time (introspection only)
 };
 
 typedef const uint32_t __attribute__((address_space(4))) *chub_sptr;  // constant address space: scalar loads
@@ -1165,7 +1160,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     int e_[T], k_[T], slot[T];
     bool valid[T];
     uint32_t sidx[T];
-    u32x2 s2[T];
+    uint32_t s2[T];
     float act[T];
     u32x2 actw[T];  // BITS: the word of the env's decision bits this slot's bit sits in
     int hs_[T];
@@ -1185,13 +1180,12 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         sidx[j] = (uint32_t) (k_[j] ? N : 0) + (uint32_t) env;
         asm volatile("" : "=v"(s2[j]), "=v"(act[j]), "=v"(pk_in[j]), "=v"(actw[j]));
         if (RESET) {
-            s2[j] = u32x2{0u, 0u};
+            s2[j] = 0u;
             act[j] = 0.0f;
         }
         if (valid[j]) {
             if (!RESET) {
-                s2[j].x = CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) v) << 2);
-                s2[j].y = CHUB_AT(uint32_t, pa.state, ((uint32_t) N * (uint32_t) St + idx0 + (uint32_t) v) << 2);  // the w1 plane
+                s2[j] = CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) v) << 2);
                 if (BITS) actw[j] = CHUB_AT(const u32x2, pa.actions, ((uint32_t) env * (((uint32_t) St + 63u) >> 6) + ((uint32_t) hs >> 6)) << 3);
                 else act[j] = CHUB_ACT_LOAD((CHUB_G(const float)) ((CHUB_G(const char)) pa.actions + (uint32_t) ((idx0 + (uint32_t) v + 2u * (uint32_t) env) << 2)));  // row stride S0 + S1 + 2
             }
@@ -1210,20 +1204,25 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     long long *s_acc64 = (long long *) s_acc;  // BIG: {min, charge, max power, cars} as four 64-bit sums per unit
 
     // ---- second round trip, only for the slots whose car stays: where it is on its curve (entries n, n + 1 of its class
-    // row).  A car that leaves this step is wiped right after its car_step (CHS.hpp:1196-1201): nothing of it is needed, and
-    // a slot is empty after remove_car (CHS.hpp:912-923 / 1077-1088) iff it had at most one slot of stay left
+    // row) and the time its target SoC stands for (4 bytes of a table that sits in the vector L1), both in flight together.  A
+    // car that leaves this step is wiped right after its car_step (CHS.hpp:1196-1201): nothing of it is needed, and a slot is
+    // empty after remove_car (CHS.hpp:912-923 / 1077-1088) iff it had at most one slot of stay left
     uint32_t w0[T];
     int tl[T];
     bool stays[T];
     f32x4 row[T];
+    float ttg[T];
 #pragma unroll
     for (int j = 0; j < T; j++) {
         asm volatile("" : "+v"(s2[j]));
-        w0[j] = valid[j] ? s2[j].x : 0u;
+        w0[j] = valid[j] ? s2[j] : 0u;
         tl[j] = ps_tl(w0[j]);
         stays[j] = tl[j] > 1;
-        asm volatile("" : "=v"(row[j]));
-        if (stays[j]) row[j] = CHUB_AT(const f32x4, pa.cls0, (k_[j] ? pa.cls_delta : 0u) + (ps_cls(w0[j]) << 8) + (ps_n(w0[j]) << 3));
+        asm volatile("" : "=v"(row[j]), "=v"(ttg[j]));
+        if (stays[j]) {
+            row[j] = CHUB_AT(const f32x4, pa.cls0, (k_[j] ? pa.cls_delta : 0u) + (ps_cls(w0[j]) << 8) + (ps_n(w0[j]) << 3));
+            ttg[j] = CHUB_AT(const float, pa.ttab2, (k_[j] ? 4096u : 0u) + (ps_lev(w0[j]) << 2));
+        }
     }
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627) while those are in flight
@@ -1314,20 +1313,20 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     // their share of calculate_output (CHS.hpp:1233-1261 / 1544-1572)
 #pragma unroll
     for (int j = 0; j < T; j++) {
-        if (BITS) asm volatile("" : "+v"(row[j]), "+v"(actw[j]));
-        else asm volatile("" : "+v"(row[j]), "+v"(act[j]));
+        if (BITS) asm volatile("" : "+v"(row[j]), "+v"(ttg[j]), "+v"(actw[j]));
+        else asm volatile("" : "+v"(row[j]), "+v"(ttg[j]), "+v"(act[j]));
         const int u = 2 * e_[j] + k_[j];
         int *acc = s_acc + 4 * u + (BIG ? 0 : (lane & (kAccCopies - 1)) * 8 * epb);  // the unit's {min, charge power | max power, cars}: two 64-bit LDS atomics per car
         uint32_t w0n = 0u;
         if (stays[j]) {
-            const float t_target = __uint_as_float(s2[j].y);
+            const float t_target = ttg[j];
             // action_to_real (MGR:384-393), judge_feasibility (CHS.hpp:1404-1413)
             const bool bit_on = BITS && ((((hs_[j] & 32) ? actw[j].y : actw[j].x) >> (hs_[j] & 31)) & 1u) != 0u;
             const bool on = (BITS ? bit_on : act[j] >= kActOnThreshold) || must_charge(t_target, row[j].y, tl[j]);
             const float power = on ? row[j].z : row[j].x, t_soc = on ? row[j].w : row[j].y;  // car_step = the next entry of the class row
             const int q = kw_to_fixed(power);
             const bool urgent = must_charge(t_target, t_soc, tl[j] - 1);
-            w0n = (w0[j] & ~64u) - 1u + (on ? ((1u << 13) | 64u) : 0u);
+            w0n = (w0[j] & ~kPsChg) - 1u + (on ? (kPsStep | kPsChg) : 0u);
             if (!BIG) {
                 atomicAdd((unsigned long long *) (acc + 2), (unsigned long long) (uint32_t) q | (1ull << 32));
                 if (on || urgent)
@@ -1341,7 +1340,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
                 if (on) atomicAdd(a64 + 1, (unsigned long long) q);
             }
         }
-        if (valid[j] && !adm[j]) CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) (tid + j * BLOCK)) << 2) = w0n;  // w1 stays as it is
+        if (valid[j] && !adm[j]) CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) (tid + j * BLOCK)) << 2) = w0n;
         if (valid[j] && slot[j] == 0) s_unit[u] = pkd_make(line[j], flow[j], 0);
     }
     __syncthreads();
@@ -1383,8 +1382,8 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         asm volatile("" : "+v"(e0), "+v"(tt_));  // both lookups in flight together
         int st_ = (int) ceilf(__fsub_rn(tt_, e0.y)) + late;  // calculate_min_charging_time + mk_late_time
         st_ = st_ > kMaxStay ? kMaxStay : st_;
-        CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) src) << 2) = st_ > 0 ? ps_make(st_, c) : 0u;
-        CHUB_AT(uint32_t, pa.state, ((uint32_t) N * (uint32_t) St + idx0 + (uint32_t) src) << 2) = __float_as_uint(tt_);  // the w1 plane: written here only
+        CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) src) << 2) = st_ > 0 ? ps_make(st_, c, lev) : 0u;
+        CHUB_AT(uint8_t, pa.stay8, idx0 + (uint32_t) src) = (uint8_t) st_;
         if (st_ > 0) {
             const int q = kw_to_fixed(e0.x);
             if (!BIG) {
@@ -2489,7 +2488,7 @@ __global__ void k_replay_soc(const DevCtx *__restrict__ ctx, float *out) {
     int n = 0;
     bool car;
     if (hp.rng_mode == MODE_PHILOX) {  // arrival SoC of the slot's class, car_steps from the state word
-        const uint32_t w0 = ctx->sl.hot[idx];  // the w0 plane
+        const uint32_t w0 = ctx->sl.hot[idx];
         car = ps_tl(w0) != 0;
         if (car) {
             soc = ctx->tb.cls_soc0[k][ps_cls(w0)];
@@ -2622,8 +2621,14 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             const PackedArgs pa = make_packed_args(hp, sa, pp);
             // every workgroup of the batch, or (a call on a subset of the envs) those of the range of envs it names
             const uint32_t nb = sa.env_mask ? (uint32_t) (sa.env_hi / hp.epb - sa.env_lo / hp.epb + 1) : (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
-#define CHUB_PACKED1(TAPE_, RESET_, BIG_, MASKED_) \
-    CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, TAPE_, RESET_, BIG_, MASKED_>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa)
+#define CHUB_PACKED2(TAPE_, RESET_, BIG_, MASKED_, BITS_) \
+    do {                                                                                                                              \
+        if (hp.pblock == kBigBlock)                                                                                                   \
+            CHUB_LAUNCH((k_slot_packed<kBigBlock, kBigSlotsPerLane, TAPE_, RESET_, BIG_, MASKED_, BITS_>), dim3(nb), dim3(kBigBlock), stream, ev0, ev1, ctx, sa, pa); \
+        else                                                                                                                          \
+            CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, TAPE_, RESET_, BIG_, MASKED_, BITS_>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa); \
+    } while (0)
+#define CHUB_PACKED1(TAPE_, RESET_, BIG_, MASKED_) CHUB_PACKED2(TAPE_, RESET_, BIG_, MASKED_, false)
 #define CHUB_PACKED(TAPE_, RESET_, BIG_) \
     do {                                                              \
         if (sa.env_mask) CHUB_PACKED1(TAPE_, RESET_, BIG_, true);     \
@@ -2640,8 +2645,8 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
                 if (big) CHUB_PACKED1(true, false, true, false);
                 else CHUB_PACKED1(true, false, false, false);
             } else if (sa.act_bits) {  // one bit per pile (lock-step entry points only: no mask)
-                if (big) CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, false, false, true, false, true>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa);
-                else CHUB_LAUNCH((k_slot_packed<kPackedBlock, kSlotsPerLane, false, false, false, false, true>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa);
+                if (big) CHUB_PACKED2(false, false, true, false, true);
+                else CHUB_PACKED2(false, false, false, false, true);
             } else if (big) {
                 CHUB_PACKED(false, false, true);
             } else {
@@ -2649,6 +2654,7 @@ void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepA
             }
 #undef CHUB_PACKED
 #undef CHUB_PACKED1
+#undef CHUB_PACKED2
         } else if (reset) launch_slot_t<true, MODE_PHILOX>(hp, ctx, sa, stream, ev0, ev1);
         else launch_slot_t<false, MODE_PHILOX>(hp, ctx, sa, stream, ev0, ev1);
         return;
@@ -2683,6 +2689,7 @@ static PackedArgs make_packed_args(const HubParams &hp, const StepArgs &sa, cons
     pa.env_mask = (CHUB_G(const uint8_t)) sa.env_mask;
     pa.blk0 = sa.env_mask ? (uint32_t) (sa.env_lo / hp.epb) : 0u;
     pa.tail_act = (CHUB_G(float)) pp.st->tail_act;
+    pa.stay8 = (CHUB_G(uint8_t)) pp.stay8;
     return pa;
 }
 

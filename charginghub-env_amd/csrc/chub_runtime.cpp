@@ -306,6 +306,7 @@ static PackedPtrs packed_ptrs(const chub_env *e) {
     p.ev = &e->ev;
     p.st = &e->st;
     p.hot = (uint32_t *) e->sl.hot;
+    p.stay8 = (uint8_t *) e->sl.stay8;
     p.rec = (uint32_t *) e->st.rec;
     p.cls[0] = e->tb.cls[0];
     p.cls[1] = e->tb.cls[1];
@@ -364,6 +365,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if (opt_in) opt = *opt_in;
     if (opt.slot_kernel < 0 || opt.slot_kernel > 2) return fail(CHUB_ERR_ARG, "chub_options.slot_kernel must be 0, 1 or 2");
     if (opt.fused_step < 0 || opt.fused_step > 2) return fail(CHUB_ERR_ARG, "chub_options.fused_step must be 0, 1 or 2");
+    if (opt.tile < 0 || opt.tile > 2) return fail(CHUB_ERR_ARG, "chub_options.tile must be 0, 1 or 2");
     *out = nullptr;
     if (n_envs <= 0) return fail(CHUB_ERR_ARG, "n_envs must be positive");
     if (n_envs * (int64_t) (cfg->station_list[0] + cfg->station_list[1] + 2) >= (int64_t) 1 << 31)
@@ -462,7 +464,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         const size_t S_tot = (size_t) (cfg->station_list[0] + cfg->station_list[1]);
         const size_t per_env = S_tot * 40 + 1024 + (size_t) qcap * 16 + (rng_mode == CHUB_RNG_COMPAT ? 102 * 8 + 33 * 4 + 256 : 0);
         const size_t want = (size_t) n_envs * per_env + ((size_t) 8 << 20) +
-                            (rng_mode == CHUB_RNG_PHILOX ? 2 * ((size_t) kSocLevels + kTapeClasses + 2) * (kClsRow * 8 + 4) : 0);
+                            (rng_mode == CHUB_RNG_PHILOX ? 2 * ((size_t) kSocLevels + 2) * (kClsRow * 8 + 4) : 0);
         void *q = nullptr;
         if (!opt.no_arena && hipMalloc(&q, want) == hipSuccess) {
             e->arena = (char *) q;
@@ -643,7 +645,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     std::vector<double> sin96(96);
     for (int t = 0; t < 96; t++) sin96[t] = sin((2 * M_PI / 96) * (double) t);  // np.sin(k * time), MGR:319-320
     std::vector<float> ttab[2], cls[2], cls_soc0[2];
-    const size_t n_classes = (size_t) kSocLevels + kTapeClasses;
+    const size_t n_classes = (size_t) kSocLevels;
     for (int s = 0; s < 2; s++) {
         const bool fast = hp.type[s] == CHUB_FAST, cpw = hp.constant_charging != 0;
         ttab[s].resize(kLevels);
@@ -671,10 +673,10 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
             build_class_row(fast, cpw, hp.cc, soc, row);
             ts_min = row[1] < ts_min ? row[1] : ts_min;
         }
-        // stay_time = ceil(soc_to_time(target) - soc_to_time(soc)) + late (late <= 15): the state word has 6 bits for it and a
-        // class row kClsRow entries (a car takes at most stay_time - 1 car_steps)
+        // stay_time = ceil(soc_to_time(target) - soc_to_time(soc)) + late (late <= 15): the state word has 5 bits for what is left
+        // of it and for the car_steps taken (a car takes at most stay_time - 1), a class row kClsRow = 32 entries
         const int max_stay = (int) ceilf(tt_max - ts_min) + 15;
-        if (max_stay > kClsRow) return bail(fail(CHUB_ERR_UNSUPPORTED, "charge curves yield stays longer than a class row"));
+        if (max_stay > 31) return bail(fail(CHUB_ERR_UNSUPPORTED, "charge curves yield stays longer than 31 slots (the 5-bit fields of the slot state)"));
     }
     e->tape_classes = 0;
     e->tape_pk = nullptr;
@@ -685,7 +687,12 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->graph_base = 0;
     // packed slot kernel (k_slot_packed): the workgroup's virtual lanes laid over whole envs end to end
     {
-        const int pb = kPackedBlock * kSlotsPerLane, St = hp.S[0] + hp.S[1];
+        const int St = hp.S[0] + hp.S[1];
+        // the workgroup tile: the small one while state and action rows live in the caches, the large one once they stream from HBM
+        const bool big_tile = opt.tile == 2 || (opt.tile == 0 && n_envs * (int64_t) St >= kBigTileSlots);
+        hp.pblock = big_tile ? kBigBlock : kPackedBlock;
+        hp.pslots = big_tile ? kBigSlotsPerLane : kSlotsPerLane;
+        const int pb = hp.pblock * hp.pslots;
         hp.epb = pb / St > 0 ? pb / St : 1;
         if (hp.epb > pb / 4) hp.epb = pb / 4;  // the workgroup's per-unit LDS areas hold 2 * pb / 4 units: hubs of 1-3 piles leave lanes idle
         bool magic_ok = true;  // the kernel divides lane numbers by S0 + S1 with a 20-bit reciprocal
@@ -697,7 +704,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     }
     {   // the whole step as one launch: where the two kernels are launch- and latency-bound and every workgroup finds room at once
         const int64_t nb = (n_envs + hp.epb - 1) / hp.epb;
-        const bool can = hp.packed && hp.S[0] <= 64 && hp.S[1] <= 64;
+        const bool can = hp.packed && hp.S[0] <= 64 && hp.S[1] <= 64 && hp.pblock == kPackedBlock;
         e->fused = can && (opt.fused_step == 2 || (opt.fused_step == 0 && nb <= kFusedMaxBlocks));
         if (opt.fused_step == 2 && !can)
             return bail(fail(CHUB_ERR_UNSUPPORTED, "fused_step = 2: the single-launch step covers PHILOX handles on the packed slot kernel with "
@@ -742,10 +749,6 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
             e->h_cls[s] = cls[s];
             e->h_soc0[s] = cls_soc0[s];
             e->h_ttab[s] = ttab[s];
-            // the slot state keeps soc_to_time(target) itself and chub_get_slots finds the level back by its value
-            for (int l = 1; l < kLevels; l++)
-                if (!(ttab[s][(size_t) l] > ttab[s][(size_t) l - 1]))
-                    return bail(fail(CHUB_ERR_UNSUPPORTED, "soc_to_time is not strictly increasing over the target-SoC levels"));
         }
     }
 
@@ -754,8 +757,10 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
 #define ALLOC(ptr, count)                                        \
     if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
     e->sl.init_soc = nullptr;
+    e->sl.stay8 = nullptr;
     if (rng_mode == CHUB_RNG_PHILOX) {
-        ALLOC(e->sl.hot, 2 * NS);  // 8-byte slot state, as two planes of 4 bytes per slot
+        ALLOC(e->sl.hot, NS);  // 4-byte slot state
+        ALLOC(e->sl.stay8, NS);
     } else {
         ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.init_soc, NS);
     }
@@ -1678,12 +1683,15 @@ int chub_stream_sync(int device, void *stream) {
 int chub_tape_register_soc(chub_env *e, const float *soc, int32_t count, uint32_t *class_ids) {
     if (!e || !soc || !class_ids || count < 0) return fail(CHUB_ERR_ARG, "bad argument");
     if (e->hp.rng_mode != CHUB_RNG_PHILOX) return fail(CHUB_ERR_ARG, "tape mode needs a PHILOX handle");
-    if (e->tape_classes + count > kTapeClasses) return fail(CHUB_ERR_UNSUPPORTED, "too many tape classes");
+    if (e->tape_classes + count > kSocLevels) return fail(CHUB_ERR_UNSUPPORTED, "too many tape classes (chub_tape_clear_soc starts over)");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
+    // The state word has room for kSocLevels classes and the production kernel is the one to be replayed, so the caller's arrival
+    // SoCs take the PLACE of this build's own classes, first come first row: from here on the handle is a tape handle (cars that a
+    // Philox step or reset admits would be given the caller's SoCs)
     const bool cp = e->hp.constant_charging != 0;
     std::vector<float> rows((size_t) count * kClsRow * 2);
-    const size_t first = (size_t) kSocLevels + (size_t) e->tape_classes;
+    const size_t first = (size_t) e->tape_classes;
     for (int k = 0; k < 2; k++) {
         const bool fast = e->hp.type[k] == CHUB_FAST;
         for (int i = 0; i < count; i++) build_class_row(fast, cp, e->hp.cc, soc[i], &rows[(size_t) i * kClsRow * 2]);
@@ -1699,6 +1707,12 @@ int chub_tape_register_soc(chub_env *e, const float *soc, int32_t count, uint32_
     return CHUB_OK;
 }
 
+int chub_tape_clear_soc(chub_env *e) {
+    if (!e) return fail(CHUB_ERR_ARG, "null handle");
+    e->tape_classes = 0;  // the next chub_tape_register_soc starts at class 0 again (the slots must not hold cars of the old classes)
+    return CHUB_OK;
+}
+
 int chub_set_slots(chub_env *e, const int32_t *rows) {
     if (!e || !rows) return fail(CHUB_ERR_ARG, "null argument");
     if (e->hp.rng_mode != CHUB_RNG_PHILOX) return fail(CHUB_ERR_ARG, "chub_set_slots needs a PHILOX handle");
@@ -1706,22 +1720,25 @@ int chub_set_slots(chub_env *e, const int32_t *rows) {
     HIP_TRY(hipDeviceSynchronize());
     const HubParams &hp = e->hp;
     const size_t N = (size_t) hp.n_envs, S = (size_t) (hp.S[0] + hp.S[1]);
-    const uint32_t n_classes = (uint32_t) kSocLevels + (uint32_t) e->tape_classes;
-    std::vector<uint32_t> st(2 * N * S, 0u);
+    const uint32_t n_classes = (uint32_t) kSocLevels;
+    std::vector<uint32_t> st(N * S, 0u);
+    std::vector<uint8_t> stay(N * S, 0);
     for (size_t env = 0; env < N; env++)
         for (int k = 0; k < 2; k++)
             for (size_t i = 0; i < (size_t) hp.S[k]; i++) {
                 const int32_t *r = rows + (env * S + (k ? (size_t) hp.S[0] : 0) + i) * 6;
                 if (r[0] < 0) continue;  // empty slot
                 const int left = r[2] - r[3];
-                if ((uint32_t) r[0] >= n_classes || r[1] < 0 || r[1] >= kLevels || r[2] < 1 || r[2] > 63 || left < 1 || r[4] < 0 ||
+                if ((uint32_t) r[0] >= n_classes || r[1] < 0 || r[1] >= kLevels || r[2] < 1 || r[2] > 31 || left < 1 || r[4] < 0 ||
                     r[4] >= kClsRow)
                     return fail(CHUB_ERR_ARG, "chub_set_slots: field out of range");
                 const size_t idx = env * S + (k ? (size_t) hp.S[0] : 0) + i;  // PHILOX state is hub-major
-                st[idx] = (uint32_t) left | (r[5] ? 64u : 0u) | ((uint32_t) r[2] << 7) | ((uint32_t) r[4] << 13) | ((uint32_t) r[0] << 18);
-                memcpy(&st[N * S + idx], &e->h_ttab[k][(size_t) r[1]], 4);  // the w1 plane
+                // the state word of chub_kernels.hip: what is left of the stay, charging flag, car_steps taken, class, target level
+                st[idx] = (uint32_t) left | (r[5] ? 32u : 0u) | ((uint32_t) r[4] << 6) | ((uint32_t) r[0] << 11) | ((uint32_t) r[1] << 22);
+                stay[idx] = (uint8_t) r[2];
             }
     HIP_TRY(hipMemcpy(e->sl.hot, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->sl.stay8, stay.data(), stay.size(), hipMemcpyHostToDevice));
     return CHUB_OK;
 }
 
@@ -1846,8 +1863,10 @@ int chub_get_slots(chub_env *e, float *out) {
         (void) hipFree(d_soc);
         if (rc) return rc;
     }
-    if ((rc = fetch(hot, (const uint32_t *) e->sl.hot, (philox ? 2 : 4) * NS))) return rc;
+    std::vector<uint8_t> stay8;
+    if ((rc = fetch(hot, (const uint32_t *) e->sl.hot, (philox ? 1 : 4) * NS))) return rc;
     if (!philox && (rc = fetch(init_soc, (const float *) e->sl.init_soc, NS))) return rc;
+    if (philox && (rc = fetch(stay8, (const uint8_t *) e->sl.stay8, NS))) return rc;
     for (size_t env = 0; env < N; env++) {
         float *o = out + env * 9 * S;
         for (int k = 0; k < 2; k++) {
@@ -1857,14 +1876,13 @@ int chub_get_slots(chub_env *e, float *out) {
                 float power = 0, t_target = 0, t_soc = 0, arrive = 0;
                 int left, stay, lev;
                 bool chg;
-                if (philox) {  // 8-byte state: everything else comes from the class row (see chub_kernels.hip)
-                    const uint32_t w0 = hot[idx], w1 = hot[NS + idx];  // two planes (chub_kernels.hip, ps_load)
-                    left = (int) (w0 & 63u); chg = (w0 & 64u) != 0; stay = (int) ((w0 >> 7) & 63u); lev = 0;
+                if (philox) {  // 4-byte state: everything else comes from the class row and the table of target times (see chub_kernels.hip)
+                    const uint32_t w0 = hot[idx];
+                    left = (int) (w0 & 31u); chg = (w0 & 32u) != 0; stay = (int) stay8[idx]; lev = (int) (w0 >> 22);
                     if (left > 0) {
-                        const size_t c = (size_t) (w0 >> 18), at = (c * kClsRow + ((w0 >> 13) & 31u)) * 2;
+                        const size_t c = (size_t) ((w0 >> 11) & 2047u), at = (c * kClsRow + ((w0 >> 6) & 31u)) * 2;
                         power = cls[k][at]; t_soc = cls[k][at + 1]; arrive = soc0[k][c];
-                        memcpy(&t_target, &w1, 4);  // the state keeps soc_to_time(target) itself: its level is its place in the table
-                        lev = (int) (std::lower_bound(ttab[k].begin(), ttab[k].end(), t_target) - ttab[k].begin());
+                        t_target = ttab[k][(size_t) lev];
                     }
                 } else {
                     memcpy(&power, &hot[4 * idx + 0], 4);

@@ -46,7 +46,7 @@ def _ptr(a):
 
 class VecChargingHub(object):
     def __init__(self, n_envs, station_list, station_type_list, seed=0, rng="philox", device=0, env_id0=0,
-                 data_dir=None, slot_kernel="auto", no_arena=False, copy_outputs=True, fused_step="auto", **kwargs):
+                 data_dir=None, slot_kernel="auto", no_arena=False, copy_outputs=True, fused_step="auto", tile="auto", **kwargs):
         """slot_kernel: "auto" (the packed slot kernel wherever the hub shape allows), "wave" (the wave-local one for
         every step) or "packed"; no_arena: one device allocation per array (no snapshots) -- chub_options.
         copy_outputs=False: reset() / step() return the handle's own pinned arrays (valid until the next call) instead of
@@ -64,6 +64,7 @@ class VecChargingHub(object):
         opt.slot_kernel = _lib.SLOT_KERNELS[slot_kernel]
         opt.no_arena = int(bool(no_arena))
         opt.fused_step = _lib.FUSED_STEP[fused_step]  # "auto": one launch per step for small batches; "off" / "on" (parity cross-check)
+        opt.tile = _lib.TILES[tile]  # packed slot kernel: "auto" (by working-set size), "small" (256 x 2) or "large" (512 x 4)
         self._copy_outputs = bool(copy_outputs)
         check(self._lib.chub_create_ex(C.byref(self.cfg), (data_dir or _lib.DATA_DIR).encode(), self.n_envs, int(env_id0),
                                        int(device), int(seed) & 0xFFFFFFFFFFFFFFFF, self.rng_mode, C.byref(opt), C.byref(h)))
@@ -186,6 +187,9 @@ class VecChargingHub(object):
         ids = np.zeros(s.size, dtype=np.uint32)
         check(self._lib.chub_tape_register_soc(self._h, _ptr(s), int(s.size), _ptr(ids)))
         return ids
+
+    def tape_clear_soc(self):
+        check(self._lib.chub_tape_clear_soc(self._h))
 
     def set_slots(self, rows):
         r = np.ascontiguousarray(rows, dtype=np.int32).reshape(self.n_envs, self.n_slots, 6)

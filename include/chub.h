@@ -74,7 +74,9 @@ typedef struct chub_options {
     int32_t fused_step;   /* PHILOX lock-step steps as ONE launch (slot work + per-env tail + next step's draws per workgroup):
                              0 = for small batches, where the two step kernels are launch-bound (default), 1 = never, 2 = always
                              (hub shapes the packed slot kernel covers, stations of at most 64 piles).  Results are bit-identical. */
-    int32_t reserved[5];
+    int32_t tile;         /* workgroup tile of the packed slot kernel: 0 = by working-set size (default), 1 = 256 lanes x 2 slots (state
+                             and action rows live in the caches), 2 = 512 lanes x 4 slots (they stream from HBM).  Results are bit-identical. */
+    int32_t reserved[4];
 } chub_options;
 
 /* telemetry column indices of chub_get_telemetry (names of the reference attributes, MGR:183-297) */
@@ -314,13 +316,17 @@ int chub_stream_sync(int device, void *stream);
  * renege pass; k_draw_levels decodes the word against the unit's live queue, dk_make in chub_kernels.hip) and per admitted car its
  * arrival SoC, target level and extra stay -- and the SAME packed slot kernel replays them.  Arbitrary arrival SoCs are registered as
  * classes of the class table first.  tests/test_gpu_tape.py replays every reference fixture this way, evs_reset included.
- *   chub_tape_register_soc: soc[count] -> class_ids[count] (at most 8192 per handle).
+ *   chub_tape_register_soc: soc[count] -> class_ids[count].  The caller's arrival SoCs take the place of the handle's own 2048
+ *                          classes, first come first row (the slot state has 11 bits for the class), so a handle that registers
+ *                          any is a tape handle from then on.  chub_tape_clear_soc starts over at class 0 (between episodes, once
+ *                          no slot holds a car of the old classes).
  *   chub_set_slots:        rows [N][S][6] i32 in hub order (station 0's slots first): class (-1 = empty), target level,
- *                          stay_time, already_stay_time, car_steps taken, charging flag.
+ *                          stay_time (<= 31), already_stay_time, car_steps taken, charging flag.
  *   chub_set_station_queue: line [N][2] i32 (Station::line).
  *   chub_step_tape:        one step; pk_tape [2][N] u64, car_tape [N][S][2] u32 in hub order = class, level | late << 16
  *                          (read only for slots that admit a car this step).  Host pointers. */
 int chub_tape_register_soc(chub_env *env, const float *soc, int32_t count, uint32_t *class_ids);
+int chub_tape_clear_soc(chub_env *env);
 int chub_set_slots(chub_env *env, const int32_t *rows);
 int chub_set_station_queue(chub_env *env, const int32_t *line);
 int chub_step_tape(chub_env *env, const float *actions, const uint64_t *pk_tape, const uint32_t *car_tape, float *obs,

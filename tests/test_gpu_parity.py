@@ -235,6 +235,57 @@ def test_single_launch_step_is_bit_identical_and_replays_in_graphs():
     large.close()
 
 
+@pytest.mark.parametrize("piles", [(20, 25), (32, 32), (3, 0), (0, 7), (100, 70), (256, 1)])
+def test_large_tile_is_bit_identical(piles):
+    """the packed slot kernel's second workgroup tile (512 lanes x 4 slots: handles whose state streams from HBM, chub_options.tile) against
+    the default 256 x 2 on the same handle arguments: resets and steps over whole days, a masked reset and masked steps (per-env clocks),
+    steps fed one bit per pile, stations without piles and of more than 64 -- packed outputs, slot state and station records bit for bit"""
+    chub = hub()
+    from charginghub_env_amd import multi_gpu
+    from charginghub_env_amd._lib import check
+    kw = dict(station_list=list(piles), station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.02, renew_fluctuate=0.2, price_fluctuate=0.1)
+    n = 1500 if sum(piles) < 128 else 300
+    res = {}
+    for tile in ("small", "large"):
+        v = chub.VecChargingHub(n, seed=6, tile=tile, fused_step="off", **kw)
+        lib, h = v._lib, v._h
+        st = multi_gpu.Stream(0)
+        acts = [multi_gpu.DeviceBuffer(n * v.act_dim * 4) for _ in range(4)]
+        for b, a in enumerate(acts):
+            v.random_actions_device(a.ptr, 78, b, st.ptr)
+        packed = [multi_gpu.DeviceBuffer(n * (v.obs_dim + 2) * 4) for _ in range(2)]
+        obs, rew, done = multi_gpu.DeviceBuffer(n * v.obs_dim * 4), multi_gpu.DeviceBuffer(n * 4), multi_gpu.DeviceBuffer(n)
+        trace = []
+        for i in range(110):
+            if i % 96 == 0:
+                v.reset_device(obs.ptr, stream=st.ptr)
+                trace.append(obs.to_host(np.float32, (n, v.obs_dim), st.ptr))
+            v.step_device_packed(acts[i % 4].ptr, packed[i & 1].ptr, stream=st.ptr)
+            if i % 13 == 0:
+                trace.append(packed[i & 1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr))
+        hb, ht = v.pack_actions(acts[1].to_host(np.float32, (n, v.act_dim), st.ptr))  # one bit per pile
+        db, dt = multi_gpu.DeviceBuffer(hb.nbytes), multi_gpu.DeviceBuffer(ht.nbytes)
+        db.from_host(hb, st.ptr)
+        dt.from_host(ht, st.ptr)
+        v.step_bits_device(db.ptr, dt.ptr, obs.ptr, rew.ptr, done.ptr, stream=st.ptr)
+        trace.append(obs.to_host(np.float32, (n, v.obs_dim), st.ptr))
+        rs = np.random.RandomState(3)
+        for k in range(6):  # per-env clocks: masked resets and steps
+            m = np.ascontiguousarray(rs.uniform(size=n) < 0.4, dtype=np.uint8)
+            if k == 1:
+                check(lib.chub_reset_envs_device(h, m.ctypes.data, None, None, obs.ptr, st.ptr))
+            else:
+                check(lib.chub_step_envs_device(h, m.ctypes.data, acts[k % 4].ptr, None, obs.ptr, rew.ptr, done.ptr, st.ptr))
+            trace.append(obs.to_host(np.float32, (n, v.obs_dim), st.ptr))
+        trace += [np.concatenate([x.reshape(n, -1) for x in v.slots()], axis=1), v.station_scalars().reshape(n, -1), v.env_clocks()]
+        res[tile] = trace
+        v.close()
+        st.destroy()
+    for k, (a, b) in enumerate(zip(res["small"], res["large"])):
+        assert np.array_equal(a, b), ("large tile vs small tile", piles, k)
+
+
 @pytest.mark.parametrize("piles,types", [((4, 5), ("fast", "slow")), ((7, 13), ("slow", "fast")), ((33, 45), ("fast", "slow")),
                                          ((63, 64), ("slow", "fast")), ((5, 64), ("fast", "fast")), ((21, 4), ("slow", "slow")),
                                          ((10, 6), ("fast", "slow"))])

@@ -8,23 +8,29 @@ import charginghub_env_amd as chub
 from charginghub_env_amd import multi_gpu
 n = int(os.environ.get("AB_ENVS", "65536"))
 kw = dict(station_list=[20,25], station_type_list=["fast","slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
-v = chub.VecChargingHub(n, seed=1, **kw)
-acts = [multi_gpu.DeviceBuffer(n * 47 * 4) for _ in range(4)]
+STEPS, WARM = 1920, 960
+if os.environ.get("AB_CONFIG") == "c5":  # 262 144 envs x [32, 32]: the working set beyond the Infinity Cache
+    n = int(os.environ.get("AB_ENVS", "262144"))
+    kw.update(station_list=[32, 32], renew_fluctuate=0.3, price_fluctuate=0.3)
+    STEPS, WARM = 480, 192
+v = chub.VecChargingHub(n, seed=1, tile=os.environ.get("AB_TILE", "auto"), **kw)
+A = v.act_dim
+acts = [multi_gpu.DeviceBuffer(n * A * 4) for _ in range(4)]
 for b, a in enumerate(acts): v.random_actions_device(a.ptr, 123, b, 0)
 packed = multi_gpu.DeviceBuffer(n * 15 * 4); obs0 = multi_gpu.DeviceBuffer(n * 13 * 4)
-for i in range(960):
+for i in range(WARM):
     if i % 96 == 0: v.reset_device(obs0.ptr)
     v.step_device_packed(acts[i%4].ptr, packed.ptr)
 v.sync()
-v.profile_begin(1920, every=2)
+v.profile_begin(STEPS, every=2)
 import time
 t0 = time.perf_counter()
-for i in range(1920):
+for i in range(STEPS):
     if i % 96 == 0: v.reset_device(obs0.ptr)
     v.step_device_packed(acts[i%4].ptr, packed.ptr)
 a, b, k = v.profile_end()
 dt = time.perf_counter() - t0
 import numpy as np
 chk = float(packed.to_host(np.float32, (n, 15)).astype(np.float64).sum())  # same seeds, same result whatever the build
-print(os.environ.get("CHUB_LIB","")[-12:], "slot_us %.2f env_us %.2f step_us %.2f  checksum %.6f" % (a/k*1e3, b/k*1e3, dt/1920*1e6, chk))
+print(os.environ.get("CHUB_LIB","")[-12:], os.environ.get("AB_TILE", ""), n, kw["station_list"], "slot_us %.2f env_us %.2f step_us %.2f  checksum %.6f" % (a/k*1e3, b/k*1e3, dt/STEPS*1e6, chk))
 v.close()
