@@ -628,6 +628,7 @@ def main():
     t_issue = time.perf_counter() - t0  # host time to issue the whole timed region
     fence()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if comm is not None:
         dt = comm.max(dt, stream.ptr)
     # sanity on the last outputs (rank-local): finite, done flag consistent with the clock
@@ -652,6 +653,23 @@ def main():
         slot_us, env_us, n_prof, _ = profiled_days(v, span, i)
         i += 96 * PROFILE_DAYS
     fence()
+    # ---- with a communicator: the step taken apart per rank, so that a measured point explains itself -- this rank's kernels (the
+    # day averages above), the gather alone (HIP events around 100 of them back to back), the host's issue time per step in the
+    # timed region, the rank's own wall clock per step -- gathered to rank 0 through the communicator
+    phases = None
+    if comm is not None:
+        g_us = comm.gather_us(packed[0].ptr, gathered[0].ptr if rank == 0 else 0, per * row, stream.ptr, reps=100)
+        mine = np.array([rank, slot_us, env_us, g_us, t_issue / steps * 1e6, dt_local / steps * 1e6], dtype=np.float64)
+        d_mine = multi_gpu.DeviceBuffer(mine.nbytes, local_rank)
+        d_everyone = multi_gpu.DeviceBuffer(mine.nbytes * world, local_rank) if rank == 0 else None
+        d_mine.from_host(mine, stream.ptr)
+        comm.gather(d_mine.ptr, d_everyone.ptr if d_everyone else 0, mine.nbytes, stream.ptr)
+        if rank == 0:
+            phases = d_everyone.to_host(np.float64, (world, mine.size), stream.ptr)
+            d_everyone.free()
+        else:
+            stream.sync()
+        d_mine.free()
 
     if rank == 0:
         value = total * steps / dt
@@ -691,6 +709,9 @@ def main():
                        "kernels_per_step": "1 (k_step_fused)" if v_fused else "2 (k_slot_packed + k_env)",
                        "window": "timed: slot %d of day %d .. slot %d of day %d; roofline: whole untimed days afterwards" % (s0, d0, s1, d1),
                        "host_issue_ms_per_step": t_issue / steps * 1e3,
+                       "graph": ("on" if (span_graph is not None or episode_graph is not None) else
+                                 "off (--graph on captures the RCCL gather with the step kernels; verified on a world of one only, so N > 1 "
+                                 "issues every step as a call by default)" if use_comm else "off"),
                        "collective": "none" if not use_comm else
                        "one grouped ncclSend/ncclRecv (RCCL) of [envs_per_gpu, %d] f32 per step to rank 0, on the step's stream" % (D + 2)},
             "n_ranks_seen": n_ranks_seen, "rccl_comm_count": comm_count, "ranks": rank_devices,
@@ -700,6 +721,22 @@ def main():
                               "algorithmic_bytes_per_env_step": slot_b + env_b},
             "build_id": build_id,
         }
+        if phases is not None:
+            # what the builder expects of this configuration, from its own parts: a step cannot be shorter than the slowest rank's
+            # kernels + one gather (GPU side) nor than the slowest rank's host issue time (call by call, the host issues two kernel
+            # launches and one grouped ncclSend / ncclRecv per step); the measured ms_per_step reads against the larger of the two
+            gpu_us = float((phases[:, 1] + phases[:, 2] + phases[:, 3]).max())
+            host_us = float(phases[:, 4].max())
+            graphed = span_graph is not None or episode_graph is not None
+            out["phases"] = {
+                "what": "per rank, microseconds: kernels = day averages of the dispatch timestamps (every 5th step of 5 untimed days), gather = "
+                        "HIP events around 100 gathers back to back, host_issue = host time per step to issue the timed region, wall = the "
+                        "rank's own wall clock per timed step",
+                "per_rank": [{"rank": int(r[0]), "slot_kernel_us": r[1], "env_kernel_us": r[2], "gather_us": r[3], "host_issue_us": r[4],
+                              "wall_us_per_step": r[5]} for r in phases],
+                "expected_ms_per_step": (gpu_us if graphed else max(gpu_us, host_us)) / 1e3,
+                "expected_bound": "gpu (kernels + gather)" if (graphed or gpu_us >= host_us) else "host issue (call by call)",
+                "measured_ms_per_step": dt / steps * 1e3}
     for g in (episode_graph, span_graph):
         if g is not None:
             v.graph_destroy(g)

@@ -240,6 +240,12 @@ class Comm(object):
     def gather(self, d_send, d_recv, nbytes, stream=0):
         check(self._lib.chub_comm_gather(self._h, d_send, d_recv or None, int(nbytes), stream or None))
 
+    def gather_us(self, d_send, d_recv, nbytes, stream=0, reps=100):
+        """microseconds per gather, `reps` of them back to back between two HIP events (chub_comm_gather_timed); every rank calls it"""
+        us = C.c_double(0.0)
+        check(self._lib.chub_comm_gather_timed(self._h, d_send, d_recv or None, int(nbytes), stream or None, int(reps), C.byref(us)))
+        return us.value
+
     def max(self, value, stream=0):
         v = C.c_double(float(value))
         check(self._lib.chub_comm_max_f64(self._h, C.byref(v), stream or None))

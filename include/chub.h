@@ -208,6 +208,8 @@ int chub_sync(chub_env *env);
  *   chub_step_gather:    chub_step_device_packed + chub_comm_gather of the packed block on one stream -- the multi-GPU step.
  *   chub_comm_max_f64 / chub_comm_barrier: max over ranks of one host double / rendezvous (both synchronise `stream`);
  *                        what bench.py brackets its timed region with.
+ *   chub_comm_gather_timed: the same gather `reps` times back to back between two HIP events on `stream`: microseconds per gather
+ *                        (the per-phase split bench.py prints at N > 1; every rank calls it; synchronises).
  *   chub_comm_world:     the communicator's size as RCCL reports it (ncclCommCount).
  *   chub_comm_ranks_seen: all-reduce sum of one 1 per rank: the number of processes RCCL actually moved data between.
  *   chub_device_info:    out[4] = PCI domain, bus, device of HIP device `device` and its compute-unit count (which physical GPU a
@@ -219,6 +221,7 @@ int chub_comm_destroy(chub_comm *comm);
 int chub_comm_world(const chub_comm *comm);
 int chub_comm_rank(const chub_comm *comm);
 int chub_comm_gather(chub_comm *comm, const void *d_send, void *d_recv, int64_t bytes, void *stream);
+int chub_comm_gather_timed(chub_comm *comm, const void *d_send, void *d_recv, int64_t bytes, void *stream, int reps, double *us_per_gather);
 int chub_comm_max_f64(chub_comm *comm, double *value, void *stream);
 int chub_comm_barrier(chub_comm *comm, void *stream);
 int chub_comm_ranks_seen(chub_comm *comm, int *out, void *stream);
