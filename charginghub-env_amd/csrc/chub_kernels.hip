@@ -1168,8 +1168,10 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
 #pragma unroll
     for (int j = 0; j < T; j++) {
         const int v = tid + j * BLOCK;
-        e_[j] = (int) (((uint32_t) v * pa.magic) >> 20);  // v / (S0 + S1) (magic = 2^20 / St + 1, checked on the host)
-        const int hs = v - e_[j] * St;                    // hub slot
+        // v / (S0 + S1) (magic = 2^20 / St + 1, checked on the host); 24-bit multiplies (full rate; v < 2^11, magic <= 2^20 + 1, the
+        // product below 2^32): the 32-bit v_mul_lo_u32 is a quarter-rate instruction
+        e_[j] = (int) (__umul24((uint32_t) v, pa.magic) >> 20);
+        const int hs = v - (int) __umul24((uint32_t) e_[j], (uint32_t) St);  // hub slot
         k_[j] = hs >= S0 ? 1 : 0;
         hs_[j] = hs;
         slot[j] = hs - (k_[j] ? S0 : 0);
@@ -1354,8 +1356,8 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     const uint32_t n_adm = q_cnt[0];
     for (uint32_t i = (uint32_t) (ALL ? tid : lane); i < n_adm; i += (ALL ? BLOCK : 64)) {
         const int src = (int) q_new[i];
-        const int s_e = (int) (((uint32_t) src * pa.magic) >> 20);
-        const int s_hs = src - s_e * St;
+        const int s_e = (int) (__umul24((uint32_t) src, pa.magic) >> 20);
+        const int s_hs = src - (int) __umul24((uint32_t) s_e, (uint32_t) St);
         const int s_k = s_hs >= S0 ? 1 : 0;
         uint32_t c, lev;
         int late;

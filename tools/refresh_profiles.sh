@@ -67,7 +67,8 @@ fe5, wr5 = collect(out + "/pmc_fetch_c5"), collect(out + "/pmc_write_c5")
 res5 = {"note": "the same FETCH_SIZE / WRITE_SIZE passes on bench.py --config c5 (262144 envs x [32,32]: 134 MB of slot state, beyond the "
                 "256 MB Infinity Cache together with the action batches): what bench.py's roofline_c5.traffic reports",
         "build_id": build_id, "envs": 262144, "hub": [32, 32], "calibration": res["calibration"]}
-for label, key in KEYS:
+KEYS5 = (("k_slot", ("k_slot_packed<512, 4, false, false",)), ("k_env", ("k_env<false",)))  # this working set runs on the second tile
+for label, key in KEYS5:
     f, w = pick(fe5, key).get("FETCH_SIZE", 0.0), pick(wr5, key).get("WRITE_SIZE", 0.0)
     res5[label] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes_per_launch": (f * FETCH_FACTOR + w * WRITE_FACTOR) * 1024.0}
 json.dump(res5, open("%s/%s_%s_pmc_traffic_c5.json" % (out, rnd, tag), "w"), indent=1)
