@@ -794,6 +794,17 @@ def test_error_paths_on_gpu():
     c.close()
     with pytest.raises(ChubError):
         chub.VecChargingHub(8, seed=1, device=99, **kw)
+    with pytest.raises(ChubError, match="fused_step = 2"):
+        chub.VecChargingHub(8, seed=1, tile="large", fused_step="on", **kw)  # the single-launch step runs on the small tile
+    big = chub.VecChargingHub(8, seed=1, tile="large", **kw)
+    assert big.uses_packed_kernel and not big.uses_fused_step              # "auto" would have fused a handle this small
+    big.close()
+    with pytest.raises(ChubError, match="too many tape classes"):
+        v.tape_register_soc(np.linspace(25.0, 70.0, 2049, dtype=np.float32))  # the state word has 11 bits for the class
+    with pytest.raises(ChubError, match="out of range"):
+        rows = np.full((8, 45, 6), -1, dtype=np.int32)
+        rows[0, 0] = [0, 0, 40, 0, 0, 0]                                   # a stay of 40 slots does not fit the 5-bit fields
+        v.set_slots(rows)
     v.close()
 
 
