@@ -151,3 +151,31 @@ def test_rendezvous_refuses_a_symlinked_directory(monkeypatch, tmp_path):
             multi_gpu._rendezvous_dir()
     finally:
         os.unlink(d)
+
+
+def test_restarted_worker_group_does_not_read_the_crashed_groups_id(monkeypatch):
+    """a launcher that restarts its workers (torchrun --max-restarts: same pid, port and run id) leaves the crashed
+    group's id file behind, and it is NEWER than the launcher -- so the time filter lets it through.  The file name carries the
+    restart count: the new group's readers wait for the new group's rank 0 instead."""
+    sys.path.insert(0, ROOT)
+    from charginghub_env_amd import multi_gpu
+    from charginghub_env_amd._lib import ChubError
+
+    monkeypatch.delenv("CHUB_RENDEZVOUS_DIR", raising=False)
+    monkeypatch.setenv("MASTER_PORT", str(20000 + os.getpid() % 20000))
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "restart%d" % time.time_ns())
+    monkeypatch.delenv("TORCHELASTIC_RESTART_COUNT", raising=False)
+    d, _ = multi_gpu._rendezvous_dir()
+    try:
+        old = multi_gpu.exchange_unique_id(0, 2, make_id=lambda: b"\x03" * 128)   # incarnation 0 publishes, then "crashes"
+        assert multi_gpu.exchange_unique_id(1, 2, timeout=5.0) == old
+        monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")                       # the same launcher restarts the group
+        with pytest.raises(ChubError):
+            multi_gpu.exchange_unique_id(1, 2, timeout=0.3)                         # the leftover is not this incarnation's
+        new = multi_gpu.exchange_unique_id(0, 2, make_id=lambda: b"\x04" * 128)
+        assert multi_gpu.exchange_unique_id(1, 2, timeout=5.0) == new != old
+        multi_gpu._rendezvous_cleanup()
+        monkeypatch.delenv("TORCHELASTIC_RESTART_COUNT")
+    finally:
+        multi_gpu._rendezvous_cleanup()
+    assert not os.path.exists(d)
