@@ -36,6 +36,24 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED) == names, "ctypes binding out of sync with include/chub.h"
 
 
+def test_telemetry_columns_and_option_struct_match_the_header():
+    """the CHUB_T_* enum of include/chub.h, the device-side column count and the Python names are one list; chub_options is the
+    same 8 ints on both sides"""
+    from charginghub_env_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "chub.h")).read()
+    body = hdr[hdr.index("CHUB_T_HY_ACT = 0"):hdr.index("CHUB_T_COUNT")]
+    cols = re.findall(r"\bCHUB_T_[A-Z0-9_]+", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert len(cols) == _lib.T_COUNT == len(_lib.TELEMETRY_NAMES) == len(set(_lib.TELEMETRY_NAMES))
+    dev = open(os.path.join(ROOT, "charginghub-env_amd", "csrc", "chub_device.h")).read()
+    assert int(re.search(r"kTelemCount = (\d+);", dev).group(1)) == _lib.T_COUNT
+    assert cols[_lib.T["Store_SOC"]] == "CHUB_T_STORE_SOC" and cols[_lib.T["price_now"]] == "CHUB_T_PRICE_NOW"
+    assert cols[_lib.T["flow_in_1"]] == "CHUB_T_FLOW1" and cols[-1] == "CHUB_T_FLOW1"
+    opt = hdr[hdr.index("typedef struct chub_options"):hdr.index("} chub_options;")]
+    fields = re.findall(r"int32_t (\w+)(?:\[(\d+)\])?;", opt)
+    assert [(n, int(k or 1)) for n, k in fields] == [(n, getattr(t, "_length_", 1)) for n, t in _lib.ChubOptions._fields_]
+    assert C.sizeof(_lib.ChubOptions) == 32
+
+
 def test_create_fails_loudly_without_gpu_and_validates_arguments():
     m = chub()
     lib = m.load_library()
