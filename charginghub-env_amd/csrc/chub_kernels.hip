@@ -1125,11 +1125,78 @@ constexpr int kAccCopies = CHUB_ACC_COPIES;
 #ifndef CHUB_EPI_ALL
 #define CHUB_EPI_ALL 1  // 1: every wave of the workgroup takes its share of the new cars (a third barrier: -0.2 us at C4); 0: the last wave alone
 #endif
+// The station records of a workgroup of the packed kernel, one lane of ONE wave per unit (the caller has passed the workgroup's last
+// barrier: every car's LDS atomics are in).  FUSED: also into s_rec, for the tails that follow in the same workgroup.
+#define CHUB_AT(T_, base, byte_off) (*(CHUB_G(T_)) ((CHUB_G(char)) (base) + (uint32_t) (byte_off)))
+template <int BLOCK, int T, bool RESET, bool BIG, bool MASKED, bool FUSED, bool BITS>
+__device__ __forceinline__ void packed_records(const PackedArgs &pa, const uint32_t block_local, int *s_acc, const uint32_t *s_unit, u32x4 *s_rec) {
+    const int lane = threadIdx.x & 63;
+    const int S0 = (int) pa.S[0], S1 = (int) pa.S[1], St = S0 + S1;
+    const int epb = (int) pa.epb, N = (int) pa.n_envs;
+    const int env_first = (int) block_local * epb;
+    const long long *s_acc64 = (const long long *) s_acc;
+    // the wave's own LDS atomics above are in program order with the reads below; nothing else touches s_acc any more
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = lane; i < 2 * epb; i += 64) {  // one station record per unit
+        const int e = i >> 1, k = i & 1;
+        const int env = env_first + e;
+        if (env >= N) continue;
+        if (MASKED && pa.env_mask[env] == 0) continue;
+        const uint32_t su = (uint32_t) (k ? N : 0) + (uint32_t) env;
+        if (!RESET && !FUSED && !BITS && k == 0) {  // the env's tail actions sit in the lines this workgroup has just read: hand them to the tail kernel packed
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+            const uint32_t ai = ((uint32_t) env * (uint32_t) (St + 2) + (uint32_t) St) << 2;
+            const f32x2_ tv = {CHUB_AT(const float, pa.actions, ai), CHUB_AT(const float, pa.actions, ai + 4u)};
+            CHUB_AT(f32x2_, pa.tail_act, (uint32_t) env << 3) = tv;
+        }
+        uint32_t lf = s_unit[i];
+        if ((k ? S1 : S0) == 0) {
+            // a station without piles still queues, reneges and balks (receive_car runs on it as on any other, CHS.hpp:1272-1316 /
+            // 1583-1627; nobody is ever admitted): its queue length and arrival count move on here, power sums and cars stay 0
+            const uint32_t pk = CHUB_AT(const uint32_t, pa.pk, su << 2);
+            const bool fast = (k ? pa.type[1] : pa.type[0]) == 0;
+            int want, fl;
+            if (RESET) {  // evs_reset of a station without piles: init_station_car_number(0, 3) arrivals, nobody queues
+                fl = fast ? (int) (int16_t) (pk & 0xFFFFu) : (int) ((pk >> 16) & 0xFFFFu);
+                want = fl;
+            } else {
+                want = dk_want(pk);
+                fl = dk_flow(pk);
+            }
+            // assign_car (CHS.hpp:417-430) with no empty slot: min(line + flow, 0) cars are assigned, the rest queue
+            const int as = want < 0 ? want : 0;
+            int ln = want - as;
+            ln = ln < kMaxLine ? ln : kMaxLine;
+            lf = pkd_make(ln, fl, 0);
+        }
+        u32x4 rv;
+        if (!BIG) {
+            int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int c = 0; c < kAccCopies; c++) {
+                const int *acc = s_acc + 4 * i + c * 8 * epb;
+                a0 += acc[0]; a1 += acc[1]; a2 += acc[2]; a3 += acc[3];
+            }
+            rv = u32x4{__float_as_uint(fixed_to_kw(a0)), __float_as_uint(fixed_to_kw(a1)), __float_as_uint(fixed_to_kw(a2)),
+                       lf | ((uint32_t) a3 << 16)};
+        } else {
+            const long long *a64 = s_acc64 + 4 * i;
+            rv = u32x4{__float_as_uint((float) a64[0] * (1.0f / 524288.0f)), __float_as_uint((float) a64[1] * (1.0f / 524288.0f)),
+                       __float_as_uint((float) a64[2] * (1.0f / 524288.0f)), lf | ((uint32_t) a64[3] << 16)};
+        }
+        CHUB_AT(u32x4, pa.rec, su << 4) = rv;
+        if (FUSED) s_rec[i] = rv;
+    }
+}
+#undef CHUB_AT
+
 // MASKED: per-env clocks (the launch serves the envs of a mask); the lock-step instantiation carries none of it.
-// FUSED (k_step_fused, small batches): the workgroup goes on after the station records -- the body then returns what this wave
-// does next (0: done; w + 1: wave w < last; WAVES: the last wave, which has written the records, also into s_rec), does not
-// hand the tail actions over through memory, and calls hook.prefetch() behind its first loads / hook.park() in front of its
-// first barrier (the tail's table rows travel with the slot loads).
+// FUSED (k_step_fused, small batches): the workgroup goes on by itself -- the body then returns IN FRONT of its third barrier with what
+// this wave does next (w + 1: wave w < last; WAVES: the last wave, which will write the records, also into s_rec, between the two
+// halves of its tails), does not hand the tail actions over through memory, and calls hook.prefetch() behind its first loads /
+// hook.park() in front of its first barrier (the tail's table rows travel with the slot loads).
 struct NoHook {
     __device__ __forceinline__ void prefetch() {}
     __device__ __forceinline__ void park() {}
@@ -1400,66 +1467,16 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
             }
         }
     }
+    // FUSED (k_step_fused): the workgroup's third barrier and the station records are the caller's business from here (its last wave
+    // runs the first half of its envs' tails in front of them): every wave returns its role, the last wave WAVES
+    if (FUSED) return wave == WAVES - 1 ? WAVES : wave + 1;
     if (ALL) {
         __syncthreads();
-        if (wave != WAVES - 1) return FUSED ? wave + 1 : 0;
+        if (wave != WAVES - 1) return 0;
     }
-    // the wave's own LDS atomics above are in program order with the reads below; nothing else touches s_acc any more
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int i = lane; i < 2 * epb; i += 64) {  // one station record per unit
-        const int e = i >> 1, k = i & 1;
-        const int env = env_first + e;
-        if (env >= N) continue;
-        if (MASKED && pa.env_mask[env] == 0) continue;
-        const uint32_t su = (uint32_t) (k ? N : 0) + (uint32_t) env;
-        if (!RESET && !FUSED && !BITS && k == 0) {  // the env's tail actions sit in the lines this workgroup has just read: hand them to the tail kernel packed
-            typedef float f32x2_ __attribute__((ext_vector_type(2)));
-            const uint32_t ai = ((uint32_t) env * (uint32_t) (St + 2) + (uint32_t) St) << 2;
-            const f32x2_ tv = {CHUB_AT(const float, pa.actions, ai), CHUB_AT(const float, pa.actions, ai + 4u)};
-            CHUB_AT(f32x2_, pa.tail_act, (uint32_t) env << 3) = tv;
-        }
-        uint32_t lf = s_unit[i];
-        if ((k ? S1 : S0) == 0) {
-            // a station without piles still queues, reneges and balks (receive_car runs on it as on any other, CHS.hpp:1272-1316 /
-            // 1583-1627; nobody is ever admitted): its queue length and arrival count move on here, power sums and cars stay 0
-            const uint32_t pk = CHUB_AT(const uint32_t, pa.pk, su << 2);
-            const bool fast = (k ? pa.type[1] : pa.type[0]) == 0;
-            int want, fl;
-            if (RESET) {  // evs_reset of a station without piles: init_station_car_number(0, 3) arrivals, nobody queues
-                fl = fast ? (int) (int16_t) (pk & 0xFFFFu) : (int) ((pk >> 16) & 0xFFFFu);
-                want = fl;
-            } else {
-                want = dk_want(pk);
-                fl = dk_flow(pk);
-            }
-            // assign_car (CHS.hpp:417-430) with no empty slot: min(line + flow, 0) cars are assigned, the rest queue
-            const int as = want < 0 ? want : 0;
-            int ln = want - as;
-            ln = ln < kMaxLine ? ln : kMaxLine;
-            lf = pkd_make(ln, fl, 0);
-        }
-        u32x4 rv;
-        if (!BIG) {
-            int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-            for (int c = 0; c < kAccCopies; c++) {
-                const int *acc = s_acc + 4 * i + c * 8 * epb;
-                a0 += acc[0]; a1 += acc[1]; a2 += acc[2]; a3 += acc[3];
-            }
-            rv = u32x4{__float_as_uint(fixed_to_kw(a0)), __float_as_uint(fixed_to_kw(a1)), __float_as_uint(fixed_to_kw(a2)),
-                       lf | ((uint32_t) a3 << 16)};
-        } else {
-            const long long *a64 = s_acc64 + 4 * i;
-            rv = u32x4{__float_as_uint((float) a64[0] * (1.0f / 524288.0f)), __float_as_uint((float) a64[1] * (1.0f / 524288.0f)),
-                       __float_as_uint((float) a64[2] * (1.0f / 524288.0f)), lf | ((uint32_t) a64[3] << 16)};
-        }
-        CHUB_AT(u32x4, pa.rec, su << 4) = rv;
-        if (FUSED) s_rec[i] = rv;
-    }
+    packed_records<BLOCK, T, RESET, BIG, MASKED, false, BITS>(pa, block_local, s_acc, s_unit, nullptr);
+    return 0;
 #undef CHUB_AT
-    return FUSED ? WAVES : 0;
 }
 
 template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED, bool BITS = false>
@@ -1662,12 +1679,19 @@ __device__ __forceinline__ void tail_prefetch(TailIn &in, const TailArgs &ta, co
 // FUSED (k_step_fused): one WAVE runs the tails of up to 64 envs of its workgroup right behind their station records: the table rows
 // are already in LDS (the caller's), the two records come from LDS (s_rec, [2 * local env + station]), `row` = the lane's place
 // among the wave's output rows, env0 = the env of row 0, and the only synchronisation is the wave's own.
-template <bool RESET, int MODE, bool MULTI, bool FUSED = false>
+// The tail has two halves: what does not look at the station records (the slot's exogenous values, the FCEV forecourt, the exogenous
+// update for the next slot) and what does (clamp, hydrogen step, netting, fuel cell, money, observation).  mid() is called between
+// them by every lane: nothing in k_env; in k_step_fused the workgroup's third barrier and the record pass, so that the last wave's
+// first half runs while the workgroup's first wave is still busy with the new cars.
+struct NoMid {
+    __device__ __forceinline__ void operator()() {}
+};
+template <bool RESET, int MODE, bool MULTI, bool FUSED = false, typename Mid = NoMid>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_pv_now, const double *s_wd_now,
                                          const double *s_hy, const uint8_t *s_hv, float *s_out, const int env_block, const TailArgs &ta,
                                          const u32x4 *s_rec, const int local_env, const int env0_fused, const int rows_fused,
-                                         const TailIn &pre, const bool use_pre) {
+                                         const TailIn &pre, const bool use_pre, Mid &mid) {
     const HubParams &hp = ctx->hp;
     const EnvArrays &ev = ctx->ev;
     const CompatRng &cr = ctx->cr;
@@ -1733,11 +1757,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             ou_price = ta.ou[2u * n32 + e32];
             in_price_noise = ta.price_noise[e32];
         }
-        if (FUSED) {  // the records this workgroup has just written, from LDS
-            const u32x4 v0 = s_rec[2 * local_env], v1 = s_rec[2 * local_env + 1];
-            mn0 = __uint_as_float(v0.x); P0f = __uint_as_float(v0.y); mx0 = __uint_as_float(v0.z); ln0 = pkd_line(v0.w); F0i = pkd_flow(v0.w);
-            mn1 = __uint_as_float(v1.x); P1f = __uint_as_float(v1.y); mx1 = __uint_as_float(v1.z); ln1 = pkd_line(v1.w); F1i = pkd_flow(v1.w);
-        } else {
+        if (!FUSED) {  // (FUSED: the records are read from LDS behind mid(), where this workgroup writes them)
             const StationRec r0 = rec_load(ta.rec, e32), r1 = rec_load(ta.rec, n32 + e32);
             mn0 = r0.mn; P0f = r0.chg; mx0 = r0.mx; ln0 = pkd_line(r0.pkd); F0i = pkd_flow(r0.pkd);
             mn1 = r1.mn; P1f = r1.chg; mx1 = r1.mx; ln1 = pkd_line(r1.pkd); F1i = pkd_flow(r1.pkd);
@@ -1843,18 +1863,21 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             for (int i = threadIdx.x; i < total; i += kEnvBlock) dst[i] = s_out[i];
         }
     };
-    // one pass of a do/while so that lanes without an env skip the work but still reach the workgroup barrier of
-    // flush_rows() at the same program point as everybody else
+    // what the first half hands to the second
+    const double *hy_env = MODE == MODE_COMPAT ? (const double *) ev.hy_env + (size_t) e32 * 102u : nullptr;
+    (void) hy_env;
+    const double cap_mass = hp.cap_mass;
+    double store_soc = 0.0, reward = 0.0, in_re_pv = 0.0, in_re_wd = 0.0, in_price_next = 0.0, total_mass_need = 0.0;
+    double re_pv = 0.0, re_wd = 0.0, price_next = 0.0;
+    int arrive = 0;
+    uint32_t fold_n = 0;
+    // ---- first half.  One pass of a do/while (here and below) so that lanes without an env skip the work but still reach mid()
+    // and the workgroup barrier of flush_rows() at the same program point as everybody else
     do {
     if (!live) break;
 
     CompatStream rs;
     if (MODE == MODE_COMPAT && !RESET) rs.load(cr, env);
-    const double *hy_env = MODE == MODE_COMPAT ? (const double *) ev.hy_env + (size_t) e32 * 102u : nullptr;
-    (void) hy_env;
-
-    const double cap_mass = hp.cap_mass;
-    double store_soc, reward = 0.0;
 
     if (RESET) {
         // renew_reset (REN:51-53) + hy_reset (HYD:197-208)
@@ -1874,14 +1897,9 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         store_soc = hp.init_soc;
         CHUB_TEL(4, cap);
     } else {
-        const double a_el = ((double) a_el_f + 1) / 2;  // action_real[-1] <- action[-2]  (MGR:400-403)
-        const double a_fc = ((double) a_fc_f + 1) / 2;  // action_real[-2] <- action[-1]  (MGR:395-398)
-        const double P0 = (double) P0f, P1 = (double) P1f;
-        const double F0 = (double) F0i, F1 = (double) F1i;
         // What the previous make_state (MGR:344-361: the end of the previous step, or reset) produced for THIS slot is not kept as
         // state but re-derived, operation for operation, from what it was computed from: the table rows of this slot of the day,
         // the OU states as that make_state left them (the values loaded above), the price noise and the tariff it saw last.
-        double in_re_pv, in_re_wd;
         {
             double tp = TAB_PV_NOW(pv_day);
             if (tp > 0 && (pv_day % 2) == 0) tp += ou_pv * hp.renew_fluct1;  // REN:38-43
@@ -1890,21 +1908,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             tw += ou_wd * hp.renew_fluct1;                                    // REN:45-49
             in_re_wd = (tw > 0 ? tw : 0.0) * 1;
         }
-        const double in_price_next = price_prev + in_price_noise;            // MGR:354-359
-        double re_new_power = in_re_wd + in_re_pv;    // MGR:143
-        const double charging_power = 0.0 + P0 + P1;  // MGR:157
-        // ---- electrolyser request clamp against the grid limit (MGR:160-180)
-        double hy_power_limit = 2000 + re_new_power - charging_power;
-        hy_power_limit = hy_power_limit > 0 ? hy_power_limit : 0.0;
-        double act_el = a_el;
-        int req = (int) ceil(a_el * 100);
-        req = req < 0 ? 0 : (req > 101 ? 101 : req);  // actions outside [-1,1] would index out of the table
-        if (TAB_HY(req) > hy_power_limit) {
-            int ind = 0;
-            while (ind < 102 && !(TAB_HY(ind) >= hy_power_limit)) ind++;
-            // hy_power_speed_list_input[ind - 1]; python index -1 wraps to the last entry (1.0)
-            act_el = (ind >= 102 || ind == 0) ? 0.01 * 100 : 0.01 * (ind - 1);
-        }
+        in_price_next = price_prev + in_price_noise;            // MGR:354-359
         // ---- hvs_step (HYD:253-285): FCEV arrivals -> J2601 -> 15-minute FIFO.  The reference's waiting list is unbounded.
         // Here: up to hp.qcap explicit entries, which is all a list that still gets served can hold (after a partial serve
         // it keeps at most arrive - 1 of the step's arrivals, HYD:270-279), plus -- once no prefix fits any more (nobody is
@@ -1913,7 +1917,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         const int qcap = hp.qcap;
         double *qt = (double *) ev.q_time + (size_t) e32 * (size_t) qcap, *qm = (double *) ev.q_mass + (size_t) e32 * (size_t) qcap;
         if (MODE == MODE_COMPAT) hv_lev = rs.level();
-        const int arrive = MODE == MODE_COMPAT ? (int) TAB_HV(hv_lev) : hv_arrive;
+        arrive = MODE == MODE_COMPAT ? (int) TAB_HV(hv_lev) : hv_arrive;
         double total_mass = 0.0;
         const bool fcev_pre = MODE == MODE_PHILOX && !RESET && !sa.fresh;
         // the first arrival's SoC was drawn one launch ahead with the other env draws (level_block: same Philox counter); its
@@ -1922,7 +1926,6 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         if (fcev_pre && arrive > 0) fcev_time_mass(__uint_as_float(drw_raw.w), pre_tn, pre_mn);
         bool stuck = (hv_line & 128) != 0;
         hv_line &= 127;
-        uint32_t fold_n = 0;
         if (fcev_pre && q_len == 0 && !stuck && arrive == 1 && pre_tn <= 15.0) {
             // the common case by far: an empty FIFO, one arrival, served within the slot (hvs_step leaves the FIFO empty and
             // the line at 0, HYD:281-283) -- nothing to read from or write to the queue arrays
@@ -2006,7 +2009,63 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             ev.hv_line[e32] = 0;  // empty FIFO, no arrivals: total time 0 <= 15 -> line = 0 (HYD:281-283)
             hv_line = 0;
         }
-        const double total_mass_need = total_mass;
+        total_mass_need = total_mass;
+    }
+
+    // ---- make_state (MGR:344-361), the exogenous update for the NEXT slot: it looks at neither records nor actions, so it sits in
+    // the first half (same operations in the same order as when it followed the reward: every chain is its own)
+    {
+        double temp = TAB_PV(pv_day);
+        if (temp > 0 && (pv_day % 2) == 0) {  // REN:38-43
+            temp += ou_sample(ou_pv, .01, 1., z_pv) * hp.renew_fluct1;
+            ev.ou[e32] = ou_pv;
+        }
+        re_pv = (temp > 0 ? temp : 0.0) * 5;
+        temp = TAB_WD(wd_day);
+        temp += ou_sample(ou_wd, .01, 1.5, z_wd) * hp.renew_fluct1;  // REN:45-49
+        ev.ou[n32 + e32] = ou_wd;
+        re_wd = (temp > 0 ? temp : 0.0) * 1;
+        if (draw_price) {  // MGR:354-357
+            price_next = ou_sample(ou_price, .1, 0.005, z_pr) * hp.price_fluct1;
+            ev.ou[2u * n32 + e32] = ou_price;
+            ev.price_noise[e32] = price_next;
+            price_next += price_last;
+        } else {
+            price_next = price_last + in_price_noise;
+        }
+    }
+    if (MODE == MODE_COMPAT && !RESET) rs.store(cr, env);
+    } while (0);
+
+    mid();  // k_step_fused: the workgroup's third barrier + the station records (by this wave); nothing elsewhere
+    if (FUSED && live) {  // the records this workgroup has just written, from LDS
+        const u32x4 v0 = s_rec[2 * local_env], v1 = s_rec[2 * local_env + 1];
+        mn0 = __uint_as_float(v0.x); P0f = __uint_as_float(v0.y); mx0 = __uint_as_float(v0.z); ln0 = pkd_line(v0.w); F0i = pkd_flow(v0.w);
+        mn1 = __uint_as_float(v1.x); P1f = __uint_as_float(v1.y); mx1 = __uint_as_float(v1.z); ln1 = pkd_line(v1.w); F1i = pkd_flow(v1.w);
+    }
+
+    // ---- second half
+    do {
+    if (!live) break;
+    if (!RESET) {
+        const double a_el = ((double) a_el_f + 1) / 2;  // action_real[-1] <- action[-2]  (MGR:400-403)
+        const double a_fc = ((double) a_fc_f + 1) / 2;  // action_real[-2] <- action[-1]  (MGR:395-398)
+        const double P0 = (double) P0f, P1 = (double) P1f;
+        const double F0 = (double) F0i, F1 = (double) F1i;
+        double re_new_power = in_re_wd + in_re_pv;    // MGR:143
+        const double charging_power = 0.0 + P0 + P1;  // MGR:157
+        // ---- electrolyser request clamp against the grid limit (MGR:160-180)
+        double hy_power_limit = 2000 + re_new_power - charging_power;
+        hy_power_limit = hy_power_limit > 0 ? hy_power_limit : 0.0;
+        double act_el = a_el;
+        int req = (int) ceil(a_el * 100);
+        req = req < 0 ? 0 : (req > 101 ? 101 : req);  // actions outside [-1,1] would index out of the table
+        if (TAB_HY(req) > hy_power_limit) {
+            int ind = 0;
+            while (ind < 102 && !(TAB_HY(ind) >= hy_power_limit)) ind++;
+            // hy_power_speed_list_input[ind - 1]; python index -1 wraps to the last entry (1.0)
+            act_el = (ind >= 102 || ind == 0) ? 0.01 * 100 : 0.01 * (ind - 1);
+        }
         {
         // ---- hy_step (HYD:160-195): production clamp, electrolyser + compressor power, tank
         double must_chg = cap_mass * 0.1 - cap;
@@ -2108,30 +2167,9 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         }
     }
 
-    // ---- make_state (MGR:344-373): exogenous update for the NEXT slot, then the observation
-    double temp = TAB_PV(pv_day);
-    if (temp > 0 && (pv_day % 2) == 0) {  // REN:38-43
-        temp += ou_sample(ou_pv, .01, 1., z_pv) * hp.renew_fluct1;
-        ev.ou[e32] = ou_pv;
-    }
-    const double re_pv = (temp > 0 ? temp : 0.0) * 5;
-    temp = TAB_WD(wd_day);
-    temp += ou_sample(ou_wd, .01, 1.5, z_wd) * hp.renew_fluct1;  // REN:45-49
-    ev.ou[n32 + e32] = ou_wd;
-    const double re_wd = (temp > 0 ? temp : 0.0) * 1;
-    double price_next;
-    if (draw_price) {  // MGR:354-357
-        price_next = ou_sample(ou_price, .1, 0.005, z_pr) * hp.price_fluct1;
-        ev.ou[2u * n32 + e32] = ou_price;
-        ev.price_noise[e32] = price_next;
-        price_next += price_last;
-    } else {
-        price_next = price_last + in_price_noise;
-    }
     ev.cap[e32] = cap;
-    if (MODE == MODE_COMPAT && !RESET) rs.store(cr, env);
 
-    // state_norm (MGR:318-342), written straight to the output row
+    // state_norm (MGR:318-342) of what make_state (MGR:362-373) collects, written straight to the output row
     float *obs = s_out + (FUSED ? (int) (threadIdx.x & 63u) : (int) threadIdx.x) * row_w;
     double *o64 = tel_on ? (double *) ev.obs64 + (size_t) e32 * hp.obs_dim : nullptr;
     int n = 0;
@@ -2242,8 +2280,9 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     const int blk = (int) blockIdx.x + (MULTI ? sa.env_lo / kEnvBlock : 0);  // a call on a subset: the blocks of its range of envs only
     const int env = blk * kEnvBlock + (int) threadIdx.x;
     TailIn none;  // (the stand-alone tail loads its inputs itself)
+    NoMid nomid;
     env_tail<RESET, MODE, MULTI>(ctx, sa, env, env < (int) ta.n_envs && (!MULTI || in_group(sa, env)), s_pv, s_wd, s_pv_now, s_wd_now, s_hy,
-                                 s_hv, s_out, blk, ta, nullptr, 0, 0, 0, none, false);
+                                 s_hv, s_out, blk, ta, nullptr, 0, 0, 0, none, false, nomid);
 }
 
 // ---------------------------------------------------------------------------------------- k_step_fused: the whole step in ONE launch
@@ -2315,6 +2354,26 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
     constexpr int WAVES = BLOCK / 64;
     const int lane = threadIdx.x & 63;
     const int epb = (int) pa.epb, N = (int) pa.n_envs, env_first = (int) blockIdx.x * epb;
+    // The body has returned in front of the workgroup's third barrier (behind it every new car is in its slot and in the LDS sums).
+    // The last wave runs the first half of its first 64 envs' tails before it goes there -- the half that needs no station record --
+    // while the first wave is still busy with the new cars' Philox blocks; then the barrier, the records (by the last wave), the
+    // second half.  The other waves pass the barrier and go on to next step's draws.
+    struct RecordsMid {
+        const PackedArgs &pa;
+        int *s_acc;
+        const uint32_t *s_unit;
+        u32x4 *s_rec;
+        bool first;  // the first group of envs: the barrier and the records are still ahead
+        __device__ __forceinline__ void operator()() {
+            if (!first) return;
+            __syncthreads();
+            packed_records<BLOCK, T, false, false, false, true, BITS>(pa, blockIdx.x, s_acc, s_unit, s_rec);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // s_rec was written by other lanes of this wave
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
+    if (role != WAVES) __syncthreads();
     if (role == 1) {
         // next step's station-level draws of this workgroup's units, against the queue lengths the main pass left in s_unit
         for (int i = lane; i < 2 * epb; i += 64) {
@@ -2338,8 +2397,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
             const bool live = le < epb && env < N;
             int rows = epb - c < 64 ? epb - c : 64;
             rows = N - (env_first + c) < rows ? N - (env_first + c) : rows;
-            env_tail<false, MODE_PHILOX, false, true>(ctx, sa, env, live, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, nullptr, s_out, 0, ta, s_rec,
-                                                      live ? le : 0, env_first + c, rows > 0 ? rows : 0, hook.tin, c == 0);
+            RecordsMid mid{pa, s_acc, s_unit, s_rec, c == 0};
+            env_tail<false, MODE_PHILOX, false, true, RecordsMid>(ctx, sa, env, live, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, nullptr, s_out, 0, ta, s_rec,
+                                                                  live ? le : 0, env_first + c, rows > 0 ? rows : 0, hook.tin, c == 0, mid);
         }
     }
 }

@@ -13,11 +13,14 @@ if os.environ.get("AB_CONFIG") == "c5":  # 262 144 envs x [32, 32]: the working 
     n = int(os.environ.get("AB_ENVS", "262144"))
     kw.update(station_list=[32, 32], renew_fluctuate=0.3, price_fluctuate=0.3)
     STEPS, WARM = 480, 192
-v = chub.VecChargingHub(n, seed=1, tile=os.environ.get("AB_TILE", "auto"), **kw)
+if os.environ.get("AB_CONFIG") == "c2":  # 4096 envs x [16, 0]: the single-launch step
+    n = int(os.environ.get("AB_ENVS", "4096"))
+    kw.update(station_list=[16, 0], fcev_permeate=0.0)
+v = chub.VecChargingHub(n, seed=1, tile=os.environ.get("AB_TILE", "auto"), fused_step=os.environ.get("AB_FUSED", "auto"), **kw)
 A = v.act_dim
 acts = [multi_gpu.DeviceBuffer(n * A * 4) for _ in range(4)]
 for b, a in enumerate(acts): v.random_actions_device(a.ptr, 123, b, 0)
-packed = multi_gpu.DeviceBuffer(n * 15 * 4); obs0 = multi_gpu.DeviceBuffer(n * 13 * 4)
+packed = multi_gpu.DeviceBuffer(n * 15 * 4); obs0 = multi_gpu.DeviceBuffer(n * 13 * 4); D2 = v.obs_dim + 2
 for i in range(WARM):
     if i % 96 == 0: v.reset_device(obs0.ptr)
     v.step_device_packed(acts[i%4].ptr, packed.ptr)
@@ -31,6 +34,22 @@ for i in range(STEPS):
 a, b, k = v.profile_end()
 dt = time.perf_counter() - t0
 import numpy as np
-chk = float(packed.to_host(np.float32, (n, 15)).astype(np.float64).sum())  # same seeds, same result whatever the build
-print(os.environ.get("CHUB_LIB","")[-12:], os.environ.get("AB_TILE", ""), n, kw["station_list"], "slot_us %.2f env_us %.2f step_us %.2f  checksum %.6f" % (a/k*1e3, b/k*1e3, dt/STEPS*1e6, chk))
+# the same steps as hipGraph replays of two episodes (what bench.py times at N = 1): microseconds per step without the host
+st = multi_gpu.Stream(0)
+pk2 = [multi_gpu.DeviceBuffer(n * D2 * 4) for _ in range(2)]
+def two_days():
+    for i in range(192):
+        if i % 96 == 0: v.reset_device(obs0.ptr, stream=st.ptr)
+        v.step_device_packed(acts[i%4].ptr, pk2[i&1].ptr, stream=st.ptr)
+v.sync(); two_days(); st.sync()
+v.graph_begin(st.ptr); two_days(); g = v.graph_end(st.ptr)
+v.graph_launch(g, st.ptr); st.sync()
+reps = 20 if n <= 65536 else 5
+t0 = time.perf_counter()
+for _ in range(reps): v.graph_launch(g, st.ptr)
+st.sync()
+graph_us = (time.perf_counter() - t0) / (reps * 192) * 1e6
+v.graph_destroy(g)
+chk = float(packed.to_host(np.float32, (n, D2)).astype(np.float64).sum())  # same seeds, same result whatever the build
+print(os.environ.get("CHUB_LIB","")[-12:], os.environ.get("AB_TILE", ""), os.environ.get("AB_FUSED", ""), n, kw["station_list"], "slot_us %.2f env_us %.2f step_us %.2f graph_us %.2f  checksum %.6f" % (a/k*1e3, b/k*1e3, dt/STEPS*1e6, graph_us, chk))
 v.close()
