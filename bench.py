@@ -285,7 +285,7 @@ def c5_roofline(chub, multi_gpu, lib, device, build_id):
                          "%d whole days after one warm-up day, every %dth step sampled: each slot of the day once" % (PROFILE_DAYS, PROFILE_DAYS))
     out["workload"] = "%d envs x hub [%d fast, %d slow] (BASELINE.json configs[4] on one GPU), renew / price fluctuate 0.3" % (
         n, kw["station_list"][0], kw["station_list"][1])
-    out["state_bytes"] = n * S * 8
+    out["state_bytes"] = n * S * 4  # one 32-bit word per charger slot
     out["step_frac_call_by_call"] = (slot_b + env_b) * n / wall_per_step / 1e9 / HBM_PEAK_GBS
     out["ms_per_step_call_by_call"] = wall_per_step * 1e3
     v.close()

@@ -29,8 +29,8 @@ def test_algorithmic_bytes_are_the_survey_formula():
 def test_traffic_profiles_are_matched_by_build_and_workload():
     """a PMC profile counts as this build's traffic only with the same build id (sources + kernel knobs) and workload"""
     b = _bench()
-    profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "round3_*_pmc_traffic.json")))
-    assert profs, "no round-3 traffic profile committed"
+    profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")))  # the last one: the latest round's final set
+    assert profs and os.path.basename(profs[-1]).startswith("round4_"), "no round-4 traffic profile committed"
     rec = json.load(open(profs[-1]))
     got, src = b.measured_traffic(rec["build_id"], 65536, 65536, [20, 25])
     assert src == os.path.basename(profs[-1]) and abs(got - rec["k_slot"]["traffic_bytes_per_launch"]) < 1.0
@@ -38,7 +38,7 @@ def test_traffic_profiles_are_matched_by_build_and_workload():
     assert abs(half - got / 2) < 1.0
     assert b.measured_traffic("not-a-build", 65536, 65536, [20, 25]) == (None, None)
     assert b.measured_traffic(rec["build_id"], 65536, 65536, [32, 32]) == (None, None)  # another hub is another workload
-    c5 = sorted(glob.glob(os.path.join(ROOT, "profiles", "round3_*_pmc_traffic_c5.json")))
+    c5 = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic_c5.json")))
     if c5:
         r5 = json.load(open(c5[-1]))
         assert b.measured_traffic(r5["build_id"], 262144, 262144, [32, 32])[1] == os.path.basename(c5[-1])
@@ -53,8 +53,8 @@ def test_traffic_profiles_are_matched_by_build_and_workload():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "round3_*_bench.json")))
-    assert lines
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_bench.json")))
+    assert lines and os.path.basename(lines[-1]).startswith("round4_")
     d = json.load(open(lines[-1]))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline", "n_ranks_seen"):
@@ -68,4 +68,6 @@ def test_committed_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "env-steps/s" and c["sample"]
     assert abs(d["value"] - 65536 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
-    assert "roofline_c5" in d and d["roofline_c5"]["state_bytes"] == 262144 * 64 * 8
+    assert "roofline_c5" in d and d["roofline_c5"]["state_bytes"] == 262144 * 64 * 4  # one 32-bit word per slot since round 4
+    assert d["roofline"]["traffic"] and d["roofline"]["traffic_source"] == os.path.basename(lines[-1]).replace("_bench.json", "_pmc_traffic.json")
+    assert d["dropin_single_env"]["compat_us_per_step"] < d["dropin_single_env"]["reference_us_per_step"]
