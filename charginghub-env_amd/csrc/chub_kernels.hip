@@ -491,7 +491,7 @@ __device__ __forceinline__ bool load_mode_on(const HubParams &hp, const StepArgs
 // consumption order; station sums in the reference's sequential f32 order.  Pinned against the recorded reference
 // trajectories (tests/golden).
 template <int TYPE, bool RESET, int BLOCK>
-__device__ void slot_body_compat(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
+__device__ __forceinline__ void slot_body_compat(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
                                  const CompatRng &cr, const Tables &tb, const int k, const int64_t block_local,
                                  float *lds_f, uint32_t *lds_u) {
     constexpr int WAVES = BLOCK / 64;
@@ -2285,6 +2285,36 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
                                  s_hv, s_out, blk, ta, nullptr, 0, 0, 0, none, false, nomid);
 }
 
+// ---------------------------------------------------------------------------------------- k_compat_small: COMPAT, a handful of envs, ONE launch
+// The reference-exact mode is what the drop-in class runs, one env at a time (EvcsspManagerEnv_v6: test/env_test.py's loop), and there
+// a step is nothing but launch latency: station 0, station 1 (the env's two reference streams are consumed in that order, so they are
+// passes, not lanes) and the tail were three launches.  When every env of the handle fits ONE workgroup for both stations, the same
+// three bodies run back to back in one launch -- slot_body_compat (k = 0), slot_body_compat (k = 1), env_tail -- with the stream
+// state and the station records handed over through memory as before (a release / acquire pair at agent scope around the workgroup
+// barrier: the next pass reads what the last one stored).  Same functions, same order: the results are those of the three launches.
+template <bool RESET>
+__global__ __launch_bounds__(kSlotBlock) void k_compat_small(const DevCtx *__restrict__ ctx, StepArgs sa, TailArgs ta) {
+    static_assert(kSlotBlock == kEnvBlock, "one workgroup shape for the slot passes and the tail");
+    __shared__ float lds_f[kSlotBlock];
+    __shared__ uint32_t lds_u[2 * kSlotBlock];
+    __shared__ double s_pv[100], s_wd[150], s_pv_now[100], s_wd_now[150], s_hy[102];
+    __shared__ __attribute__((aligned(16))) uint8_t s_hv[kLevels];
+    __shared__ __attribute__((aligned(16))) float s_out[kEnvBlock * 16];
+    const HubParams &hp = ctx->hp;
+    for (int k = 0; k < 2; k++) {
+        if (hp.type[k] == 0) slot_body_compat<0, RESET, kSlotBlock>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, 0, lds_f, lds_u);
+        else slot_body_compat<1, RESET, kSlotBlock>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, 0, lds_f, lds_u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    const int env = (int) threadIdx.x;
+    TailIn none;
+    NoMid nomid;
+    env_tail<RESET, MODE_COMPAT, false>(ctx, sa, env, env < (int) ta.n_envs, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, s_hv, s_out, 0, ta, nullptr, 0, 0, 0,
+                                        none, false, nomid);
+}
+
 // ---------------------------------------------------------------------------------------- k_step_fused: the whole step in ONE launch
 // Small batches (C2: 4096 envs; every shard of an 8-GPU strong-scaling run): both step kernels are launch- and latency-bound
 // there -- a handful of waves per CU, 4-5 us each of which 1.7 us is the kernel boundary -- and the chip has room for every
@@ -2769,6 +2799,13 @@ void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &s
     }
     ta.tail_act = nullptr;  // the tails read their two actions from the action rows (the workgroup has just had them in cache)
     CHUB_LAUNCH((k_step_fused<kPackedBlock, kSlotsPerLane>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa, ta);
+}
+
+// COMPAT lock-step reset / step of a handle whose envs all fit one workgroup (the caller has checked): one launch
+void launch_compat_small(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp) {
+    const TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa, pp, reset);
+    if (reset) hipLaunchKernelGGL(k_compat_small<true>, dim3(1), dim3(kSlotBlock), 0, stream, ctx, sa, ta);
+    else hipLaunchKernelGGL(k_compat_small<false>, dim3(1), dim3(kSlotBlock), 0, stream, ctx, sa, ta);
 }
 
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,

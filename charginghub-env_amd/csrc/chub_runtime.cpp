@@ -30,6 +30,7 @@ void launch_keep_clocks(uint16_t *dst, const uint16_t *src, int64_t n, hipStream
 void launch_expand_bits(const HubParams &hp, const uint64_t *d_bits, const float *d_tail, float *d_actions, hipStream_t stream);
 void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp, hipEvent_t ev0,
                        hipEvent_t ev1);
+void launch_compat_small(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp);
 }  // namespace chub
 
 using namespace chub;
@@ -60,6 +61,7 @@ struct chub_env {
     Tables tb;
     int device;
     bool fused;         // PHILOX lock-step steps of this handle run as ONE launch (k_step_fused): small batches
+    bool compat_small;  // COMPAT: every env fits one workgroup for both stations: lock-step resets and steps are ONE launch (k_compat_small)
     DevCtx *d_ctx;      // device copy of {hp, sl, st, ev, cr, tb}
     bool ctx_dirty;
     // lock-step clock (MGR:137-140,299; CHS.hpp:1204; AGG:150-151; HYD:192-193 are three copies of it)
@@ -710,6 +712,10 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
             return bail(fail(CHUB_ERR_UNSUPPORTED, "fused_step = 2: the single-launch step covers PHILOX handles on the packed slot kernel with "
                                                    "stations of at most 64 piles"));
     }
+    {   // the reference-exact mode at a handful of envs (the drop-in class: one): both station passes and the tail in one launch
+        const int64_t fit = std::min<int64_t>((kSlotBlock / 64) * (64 / hp.H[0]), (kSlotBlock / 64) * (64 / hp.H[1]));
+        e->compat_small = rng_mode == CHUB_RNG_COMPAT && opt.fused_step != 1 && hp.S[0] <= 64 && hp.S[1] <= 64 && n_envs <= fit;
+    }
     build_hy_table(hp, e->hy_table);
     std::vector<double> hy_v(e->hy_table, e->hy_table + 102);
 
@@ -847,7 +853,7 @@ int chub_clock(const chub_env *e) {  // lock-step: the clock; per-env clocks: en
     return (int) (c & 127u);
 }
 int chub_uses_packed_kernel(const chub_env *e) { return e ? e->hp.packed : CHUB_ERR_ARG; }
-int chub_uses_fused_step(const chub_env *e) { return e ? (e->fused ? 1 : 0) : CHUB_ERR_ARG; }
+int chub_uses_fused_step(const chub_env *e) { return e ? ((e->fused || e->compat_small) ? 1 : 0) : CHUB_ERR_ARG; }
 
 int chub_sync(chub_env *e) {
     if (!e) return fail(CHUB_ERR_ARG, "null handle");
@@ -973,8 +979,12 @@ static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const d
     }
     int rc_ = sync_ctx(e, s);
     if (rc_) return rc_;
-    launch_slot(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e), nullptr, nullptr);
-    launch_env(true, e->hp, e->d_ctx, sa, s, nullptr, nullptr, packed_ptrs(e));
+    if (e->compat_small && !e->per_env) {
+        launch_compat_small(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e));
+    } else {
+        launch_slot(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e), nullptr, nullptr);
+        launch_env(true, e->hp, e->d_ctx, sa, s, nullptr, nullptr, packed_ptrs(e));
+    }
     HIP_TRY(hipGetLastError());
     e->predrawn = served == 2;  // the launch's level blocks left the next step's draws of every env it served
     if (served == 2) {  // everybody starts a new day: one clock again (the launch itself still ran on the envs' own clocks)
@@ -1126,7 +1136,12 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     }
     // four events per profiled step: start / stop of the slot kernel, start / stop of the tail kernel
     hipEvent_t *pe = prof ? &e->prof_events[4 * e->prof_used] : nullptr;
-    if (e->fused && !load_mode && !e->per_env && !sa.car_tape && !sa.pk_tape) {
+    if (e->compat_small && !load_mode && !e->per_env) {
+        launch_compat_small(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e));
+        if (prof) {  // one kernel, no dispatch timestamps: the sample spans nothing
+            for (int i = 0; i < 4; i++) HIP_TRY(hipEventRecord(pe[i], s));
+        }
+    } else if (e->fused && !load_mode && !e->per_env && !sa.car_tape && !sa.pk_tape) {
         launch_step_fused(e->hp, e->d_ctx, sa, s, packed_ptrs(e), prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
         if (prof) {  // one kernel: the whole step is on the first pair of timestamps, the second pair spans nothing
             HIP_TRY(hipEventRecord(pe[2], s));
@@ -1335,19 +1350,29 @@ int chub_step(chub_env *e, const float *actions, const double *exo_z, float *obs
     if (rc) return rc;
     const size_t N = (size_t) e->hp.n_envs, A = (size_t) e->hp.act_dim, D = (size_t) e->hp.obs_dim;
     hipStream_t s = e->host_stream;
+    // A handful of envs (the drop-in class: one): inputs that sit in pinned host memory are READ BY THE KERNELS where they are -- a
+    // few hundred bytes over PCIe -- instead of going through a copy engine first: the step is then one launch set and one
+    // stream synchronisation, no copy in either direction.  Larger batches and pageable memory take the DMA as before.
+    const bool tiny = N * A * sizeof(float) <= 16384;
+    const double *d_z = e->d_exo_z;
     if (e->hp.rng_mode == CHUB_RNG_COMPAT) {
         if (!exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
-        HIP_TRY(hipMemcpyAsync(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+        void *vz = nullptr;
+        if (tiny && device_view((void *) exo_z, &vz)) d_z = (const double *) vz;
+        else HIP_TRY(hipMemcpyAsync(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     }
-    // from the handle's pinned buffer (chub_host_actions) this is one DMA; any other host pointer is staged by the HIP runtime
-    HIP_TRY(hipMemcpyAsync(e->d_actions, actions, N * A * sizeof(float), hipMemcpyHostToDevice, s));
+    const float *d_act = e->d_actions;
+    void *va = nullptr;
+    if (tiny && device_view((void *) actions, &va)) d_act = (const float *) va;
+    else  // from the handle's pinned buffer (chub_host_actions) this is one DMA; any other host pointer is staged by the HIP runtime
+        HIP_TRY(hipMemcpyAsync(e->d_actions, actions, N * A * sizeof(float), hipMemcpyHostToDevice, s));
     void *v_obs = nullptr, *v_rew = nullptr, *v_done = nullptr;
     if (device_view(obs, &v_obs) && device_view(reward, &v_rew) && device_view(done, &v_done)) {
         // pinned output arrays: the tail kernel stores into them directly (see device_view)
-        rc = chub_step_device(e, e->d_actions, e->d_exo_z, (float *) v_obs, (float *) v_rew, (uint8_t *) v_done, s);
+        rc = chub_step_device(e, d_act, d_z, (float *) v_obs, (float *) v_rew, (uint8_t *) v_done, s);
         if (rc) return rc;
     } else {
-        rc = chub_step_device(e, e->d_actions, e->d_exo_z, e->d_obs, e->d_reward, e->d_done, s);
+        rc = chub_step_device(e, d_act, d_z, e->d_obs, e->d_reward, e->d_done, s);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(obs, e->d_obs, N * D * sizeof(float), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost, s));

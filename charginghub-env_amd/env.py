@@ -126,7 +126,7 @@ class EvcsspManagerEnv_v6(object):
         v = self._vec
         self._S = sum(self.pile_number)
         self._act = v.pinned_actions()                   # [1, S + 2] f32, pinned
-        self._z = np.zeros((1, 3))
+        self._z = v._pinned_array((1, 3), np.float64)    # the step's exogenous normals (COMPAT), pinned: read by the kernel where they are
         tel, obs64, rew64 = v.telemetry_views()
         self._tel, self._obs64, self._rew64 = tel[:, 0], obs64[0], rew64  # this env's column / row of the block: live views
         self._p = [C.c_void_p(a.ctypes.data) for a in (self._act, self._z, v._obs, v._reward, v._done)]

@@ -73,7 +73,9 @@ typedef struct chub_options {
     int32_t no_arena;     /* 1: one hipMalloc per array instead of one arena (disables chub_get_state / chub_set_state) */
     int32_t fused_step;   /* PHILOX lock-step steps as ONE launch (slot work + per-env tail + next step's draws per workgroup):
                              0 = for small batches, where the two step kernels are launch-bound (default), 1 = never, 2 = always
-                             (hub shapes the packed slot kernel covers, stations of at most 64 piles).  Results are bit-identical. */
+                             (hub shapes the packed slot kernel covers, stations of at most 64 piles).  Results are bit-identical.
+                             COMPAT handles whose envs all fit one workgroup (the drop-in class: one env) run reset and step as one
+                             launch too -- station 0, station 1, tail back to back -- unless this is 1. */
     int32_t tile;         /* workgroup tile of the packed slot kernel: 0 = by working-set size (default), 1 = 256 lanes x 2 slots (state
                              and action rows live in the caches), 2 = 512 lanes x 4 slots (they stream from HBM).  Results are bit-identical. */
     int32_t reserved[4];
@@ -111,7 +113,7 @@ int chub_act_dim(const chub_env *env);  /* S + 2 (MGR:108-113) */
 int64_t chub_num_envs(const chub_env *env);
 int chub_clock(const chub_env *env);    /* 0..95: the slot of day, shared by all envs while they run in lock-step (env 0's otherwise) */
 int chub_uses_packed_kernel(const chub_env *env); /* 1: PHILOX steps of this handle run k_slot_packed (the production kernel) */
-int chub_uses_fused_step(const chub_env *env);    /* 1: its lock-step steps run as one launch (k_step_fused, small batches) */
+int chub_uses_fused_step(const chub_env *env);    /* 1: its lock-step steps run as one launch (k_step_fused / k_compat_small, small batches) */
 
 /* ---- hot path ------------------------------------------------------------------------------
  * chub_reset replaces EvcsspManagerEnv_v6.reset (MGR:304-316 -> AGG:157-175 evs_reset main.cpp:199,251,

@@ -68,8 +68,15 @@ ALL_FIXTURES = ["env_c1_envtest", "env_c3_random", "env_c2_random", "env_c5_rand
                 "env_fcev_queue", "env_constant", "env_small_fast_neg", "env_fcev_queue_deep", "env_big_100_70"]
 
 
+@pytest.mark.parametrize("name", ["env_c5_random", "env_big_100_70", "env_small_fast_neg"])
+def test_large_tile_replays_reference_fixture(name):
+    """the second workgroup tile of the packed kernel (512 lanes x 4 slots: what handles of 10 M slots and more run) against the
+    reference directly: the same replay on a handle forced onto it"""
+    test_packed_kernel_replays_reference_fixture(name, tile="large")
+
+
 @pytest.mark.parametrize("name", ALL_FIXTURES)
-def test_packed_kernel_replays_reference_fixture(name):
+def test_packed_kernel_replays_reference_fixture(name, tile="small"):
     """Every reference fixture through the production kernel, evs_reset included: the k_slot_packed instantiations for steps and
     resets, stations of up to 64 piles and beyond (BIG: env_big_100_70), a station without piles (env_c2_random,
     env_slow_only_fcev), a 3-pile hub whose reset records a negative flow_in (env_small_fast_neg)."""
@@ -83,7 +90,7 @@ def test_packed_kernel_replays_reference_fixture(name):
               init_soc=float(g["kw_init_soc"]), fc_max_power=float(g["kw_fc_max_power"]),
               fcev_permeate=float(g["kw_fcev_permeate"]))
     n_envs = 3                                                   # every env replays the same tape
-    v = chub.VecChargingHub(n_envs, seed=1, rng="philox", slot_kernel="packed", **kw)
+    v = chub.VecChargingHub(n_envs, seed=1, rng="philox", slot_kernel="packed", tile=tile, fused_step="off" if tile == "large" else "auto", **kw)
     assert v.uses_packed_kernel
     S0, S1 = piles
     S = S0 + S1
