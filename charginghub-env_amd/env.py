@@ -231,36 +231,36 @@ class EvcsspManagerEnv_v6(object):
         if rc:
             _lib.check(rc)
         # chub_step returns completed: observation, reward, done and the telemetry block are in pinned host memory now
-        tel = self._tel
+        tel = self._tel.tolist()  # one conversion of the 38 columns to Python floats
         reward = float(self._rew64[0])
         done = bool(self._vec._done[0])
         # reference attribute names (MGR:175-297)
-        self.hy_act = float(tel[0])
-        self.gen_hy = bool(tel[1] > 0.5)                      # MGR:161,173-179
-        self.re_hy_gen = 15 * 60 * float(tel[1])              # hy_flow_speed_15, HYD:183
-        self.re_hydrogen_power_init = float(tel[2])
-        self.re_ev_power_list = [float(tel[11]), float(tel[12])]
-        self.re_used_renew = float(tel[10])
-        self.fc_power = float(tel[8])
-        self.re_hy_for_fc = float(tel[9])
-        ev0, ev1, hydrogen_power = float(tel[24]), float(tel[25]), float(tel[13])
-        self.real_charging_power = self.re_ev_power_sum = float(tel[26])
+        self.hy_act = tel[0]
+        self.gen_hy = tel[1] > 0.5                            # MGR:161,173-179
+        self.re_hy_gen = 15 * 60 * tel[1]                     # hy_flow_speed_15, HYD:183
+        self.re_hydrogen_power_init = tel[2]
+        self.re_ev_power_list = [tel[11], tel[12]]
+        self.re_used_renew = tel[10]
+        self.fc_power = tel[8]
+        self.re_hy_for_fc = tel[9]
+        ev0, ev1, hydrogen_power = tel[24], tel[25], tel[13]
+        self.real_charging_power = self.re_ev_power_sum = tel[26]
         self.re_hydrogen_power = hydrogen_power
-        real_price_dollar = float(tel[27]) / 4                # MGR:234
+        real_price_dollar = tel[27] / 4                       # MGR:234
         self.re_price_dollar = real_price_dollar
-        P0, P1 = float(tel[29]), float(tel[34])
+        P0, P1 = tel[29], tel[34]
         self.re_income_evs_cost = - real_price_dollar * (ev0 + ev1)
         income_evs_serve = 0.8 * (int(tel[32]) + int(tel[37]))
         self.re_income_evs_cost_list = [- real_price_dollar * ev0, - real_price_dollar * ev1]
         self.re_income_evs_list = [0.42 / 4 * P0, 0.21 / 4 * P1]
         self.re_income_evs_serve = income_evs_serve
-        self.re_income_hys = 6 / 1000 * float(tel[6])
+        self.re_income_hys = 6 / 1000 * tel[6]
         self.re_hy_cost = -real_price_dollar * hydrogen_power
-        self.income = float(tel[14])
+        self.income = tel[14]
         self.cumulated_income += self.income
         self.cumulated_draw_ele += ev0 + ev1 + hydrogen_power  # MGR:262
         self.acumulate_reward += reward
-        store_soc = float(tel[3])
+        store_soc = tel[3]
         if done:  # MGR:275-297 (its prints left out)
             temp_deviation = abs(store_soc - self.hy_init_soc) * self._capacity_mass / 1000
             temp_deviation = temp_deviation / 0.2
@@ -268,18 +268,31 @@ class EvcsspManagerEnv_v6(object):
         self.deviation = abs(store_soc - self.hy_init_soc)
         self._time = t_next
         self._make_state(t_next)
-        for name, i in _lib.T.items():  # every telemetry column by name, for scripts that want more than the reference exposes
-            setattr(self, "_t_" + name, float(tel[i]))
         return self.state, reward, done, {}
+
+    def __getattr__(self, name):
+        # every telemetry column of the last step by name (env._t_Store_SOC, env._t_hy_use ...: _lib.TELEMETRY_NAMES), read from the
+        # pinned block on demand, for scripts that want more than the reference exposes
+        if name.startswith("_t_") and name[3:] in _lib.T:
+            return float(self.__dict__["_tel"][_lib.T[name[3:]]])
+        raise AttributeError(name)
 
     @staticmethod
     def action_to_real(action):
-        """MGR:384-404: one bit per pile, the two tail actions swapped"""
-        real_action = (np.array(action[:-2]) + 1) / 2
-        real_actions = [1.0 if act >= 0.5 else 0.0 for act in real_action]
-        real_actions.append((action[-1] + 1) / 2 if action[-1] is not None else action[-1])
-        real_actions.append((action[-2] + 1) / 2 if action[-2] is not None else action[-2])
-        return np.array(real_actions)
+        """MGR:384-404: one bit per pile, the two tail actions swapped (the same values as the reference's element-by-element loop,
+        computed on the whole row at once)"""
+        if action[-1] is None or action[-2] is None:  # the reference passes a None through (an object array)
+            real_action = (np.array(action[:-2]) + 1) / 2
+            real_actions = [1.0 if act >= 0.5 else 0.0 for act in real_action]
+            real_actions.append((action[-1] + 1) / 2 if action[-1] is not None else action[-1])
+            real_actions.append((action[-2] + 1) / 2 if action[-2] is not None else action[-2])
+            return np.array(real_actions)
+        n = len(action) - 2
+        out = np.empty(n + 2)
+        out[:n] = (np.asarray(action[:-2]) + 1) / 2 >= 0.5
+        out[n] = (action[-1] + 1) / 2
+        out[n + 1] = (action[-2] + 1) / 2
+        return out
 
     def render(self, mode='human'):
         pass
