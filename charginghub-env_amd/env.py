@@ -3,7 +3,9 @@
 
 Same constructor kwargs, ``reset() -> ndarray``, ``step(action) -> (ndarray, float, bool, {})``, ``seed``,
 ``action_space`` / ``observation_space`` bounds (MGR:74-118), ``render`` / ``close`` no-ops, and every attribute the reference
-sets in ``reset`` / ``step`` that a trainer or an evaluation script reads afterwards: ``real_state`` (MGR:372), ``action_real``,
+sets in ``reset`` / ``step`` that a trainer or an evaluation script reads afterwards -- and read-only views of the sub-objects such
+scripts reach into (``env.hy_sys.sty.Store_SOC``, ``env.hy_sys.hvs.total_mass_need``, ``env.hfc.hy_to_use``,
+``env.env_aggregator.evcssp_evs_objects[k].charge_power``, ``env.renew.pv_day`` ...): ``real_state`` (MGR:372), ``action_real``,
 ``re_*``, ``income``, ``fc_power``, ``hy_act``, ``gen_hy`` (MGR:150-231), ``cumulated_income`` / ``cumulated_draw_ele`` (MGR:259-262),
 ``acumulate_reward``, ``deviation``, ``test_penalty`` at the end of an episode (MGR:275-297), ``penalty`` / ``lagrangian_factor``
 (MGR:128, 314-315).  tests/test_gpu_parity.py holds them to the values recorded from the reference.
@@ -55,6 +57,105 @@ def _space(low, high, shape=None):
         return Box(low, high, shape, np.float32)
 
 
+class _QueueLen(object):
+    """stands in for HyFCEVStation.needed_time_list / needed_hy_list (HYD:264-265): the reference's scripts only ever take its len()"""
+
+    def __init__(self, n):
+        self._n = int(n)
+
+    def __len__(self):
+        return self._n
+
+
+class _StationView(object):
+    """read-only stand-in for env.env_aggregator.evcssp_evs_objects[k] (the Boost-bound Fast / SlowChargeStation, MAIN:186-290): the
+    scalars the reference's host reads off a station (AGG:198-218, MGR:364-368)"""
+
+    def __init__(self, env, k):
+        self._env, self._k = env, k
+        self.charge_number = env.pile_number[k]
+        const_power = 36.44764034125146 if env._types[k] == "fast" else 5.254973139368931
+        self.transformer_limit = float(np.float32(np.float32(const_power) * np.float32(self.charge_number)))  # CHS.hpp:1133-1134 / 1443-1444
+
+    def _col(self, name):
+        return self._env._last_tel[_lib.T["%s_%d" % (name, self._k)]]
+
+    min_power = property(lambda self: self._col("min_power"))
+    charge_power = property(lambda self: self._col("charge_power"))
+    max_power = property(lambda self: self._col("max_power"))
+    line = property(lambda self: int(self._col("line")))
+    flow_in_number = property(lambda self: [int(self._col("flow_in"))])         # the reference reads [-1] (AGG:218)
+    station_time_hole = property(lambda self: self._env._time)
+    car_number = property(lambda self: int(self._env._vec.station_scalars()[0, self._k, 3]))  # (one device read: not in the telemetry block)
+
+
+class _Views(object):
+    """read-only stand-ins for the sub-objects evaluation scripts reach into: env.env_aggregator (AGG), env.hy_sys / .sty / .hvs /
+    .ele (HYD), env.hfc (HYD:394-430), env.renew (REN) -- attribute names of the reference, values from the telemetry block of the
+    last reset() / step()"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _live(cls_name, fields):
+    """a small class whose attributes are computed from the env's last telemetry row on access"""
+    return type(cls_name, (object,), dict({"__init__": lambda self, env: setattr(self, "_env", env)},
+                                          **{k: property(f) for k, f in fields.items()}))
+
+
+_T = _lib.T
+_Store = _live("HyStoreView", {
+    "Store_SOC": lambda s: s._env._last_tel[_T["Store_SOC"]], "capacity": lambda s: s._env._last_tel[_T["capacity"]],
+    "hy_use": lambda s: s._env._last_tel[_T["hy_use"]], "not_meet": lambda s: s._env._last_tel[_T["not_meet"]],
+    "capacity_mass": lambda s: s._env._capacity_mass, "init_soc_": lambda s: s._env.hy_init_soc,
+    "h_v_max": lambda s: s._env._capacity_mass / (0.089 * (200 / 1)) / 1000, "density": lambda s: 0.089 * (200 / 1)})
+_Hvs = _live("HyFCEVStationView", {
+    "total_mass_need": lambda s: s._env._last_tel[_T["total_mass_need"]], "arrive_number": lambda s: int(s._env._last_tel[_T["fcev_arrive_number"]]),
+    "line": lambda s: int(s._env._last_tel[_T["fcev_line"]]), "needed_time_list": lambda s: _QueueLen(s._env._last_tel[_T["fcev_queue_len"]]),
+    "needed_hy_list": lambda s: _QueueLen(s._env._last_tel[_T["fcev_queue_len"]])})
+_Hfc = _live("HFCView", {"hy_to_use": lambda s: s._env._last_tel[_T["hy_to_use"]], "cell_number": lambda s: s._env._fc_cells})
+_Renew = _live("ReNewView", {"pv_day": lambda s: int(s._env._last_tel[_T["pv_day"]]), "wd_day": lambda s: int(s._env._last_tel[_T["wd_day"]])})
+
+
+class _HySys(object):
+    def __init__(self, env):
+        self._env = env
+        self.sty, self.hvs = _Store(env), _Hvs(env)
+
+    hy_flow_speed = property(lambda s: s._env._last_tel[_T["hy_flow_speed"]])
+    hy_flow_speed_15 = property(lambda s: 15 * 60 * s._env._last_tel[_T["hy_flow_speed"]])
+    all_power_second = property(lambda s: s._env._last_tel[_T["all_power_second"]])
+    all_power_15 = property(lambda s: s._env._last_tel[_T["all_power_second"]] * 15 * 60)
+    sys_time = property(lambda s: s._env._time)
+    hy_power_speed_list = property(lambda s: s._env._vec.hy_table(env=0).tolist())               # HYD:154-157
+    hy_power_speed_list_input = property(lambda s: [0.01 * i for i in range(101)] + [0.01 * 100])
+
+
+class _Aggregator(object):
+    def __init__(self, env, station_list, station_type_list, constant_charging):
+        self._env = env
+        self.station_list = self.pile_number = list(station_list)
+        self.station_type_list = list(station_type_list)
+        self.station_number = 2
+        self.constant_charging, self.wait = constant_charging, True
+        self.price_constant = list(env._price)
+        self.price = [] + self.price_constant
+        self.price_max, self.price_min = max(self.price), min(self.price)
+        self.evcssp_evs_objects = [_StationView(env, 0), _StationView(env, 1)]
+        self.total_max_power = 0
+        for station in self.evcssp_evs_objects:
+            self.total_max_power += station.transformer_limit
+
+    aggregator_time_hole = property(lambda s: s._env._time)
+    evcssp_charge_power = property(lambda s: [st.charge_power for st in s.evcssp_evs_objects])
+    evcssp_max_demand = property(lambda s: [st.max_power for st in s.evcssp_evs_objects])
+    evcssp_min_demand = property(lambda s: [st.min_power for st in s.evcssp_evs_objects])
+    ag_flow_in_number = property(lambda s: [st.flow_in_number[-1] for st in s.evcssp_evs_objects])
+    ag_car_number = property(lambda s: [st.car_number for st in s.evcssp_evs_objects])
+    ag_full = property(lambda s: [st.car_number >= st.charge_number for st in s.evcssp_evs_objects])
+
+
 class EvcsspManagerEnv_v6(object):
     metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': 30}
 
@@ -95,6 +196,8 @@ class EvcsspManagerEnv_v6(object):
             # HySystem's sweep): replay them so that an episode after construction matches the reference's
             self._vec.compat_replay_constructor()
         self.pile_number = [int(station_list[0]), int(station_list[1])]
+        self._types = list(station_type_list)
+        self._fc_cells = 100 if fc_max_power is None else fc_max_power  # HFC.cell_number (HYD:401-404)
         data = data_dir or _lib.DATA_DIR
         self._price = np.fromfile(data + "/price_96.f64", dtype="<f8")
         self._pv = np.fromfile(data + "/pv_100x96.f64", dtype="<f8").reshape(100, 96)
@@ -153,6 +256,10 @@ class EvcsspManagerEnv_v6(object):
         self.cumulated_income = 0
         self.cumulated_draw_ele = 0
         self.hy_init_soc = init_soc
+        self._last_tel = [0.0] * _lib.T_COUNT
+        # the sub-objects of the reference class that scripts reach into, as read-only views (values of the last reset() / step())
+        self.env_aggregator = _Aggregator(self, station_list, station_type_list, constant_charging)
+        self.hy_sys, self.hfc, self.renew = _HySys(self), _Hfc(self), _Renew(self)
         self.np_random = None
         self.seed()
         self.reset()  # MGR:120
@@ -189,14 +296,14 @@ class EvcsspManagerEnv_v6(object):
         self._price_count += 1
         return z
 
-    def _make_state(self, time):
+    def _make_state(self, time, tel=None):
         """what make_state (MGR:344-373) leaves: real_state, state, the renewable powers and the price noise"""
-        tel = self._tel
-        rs = tel[self._rs_cols]  # fancy indexing: a fresh array
+        self._last_tel = tel = self._tel.tolist() if tel is None else tel
+        rs = self._tel[self._rs_cols]  # fancy indexing: a fresh array
         rs[0] = time
         self.real_state = rs
-        self.re_pv_power = float(tel[16])
-        self.re_wd_power = float(tel[17])
+        self.re_pv_power = tel[16]
+        self.re_wd_power = tel[17]
         self.state = np.array(self._obs64)
 
     def reset(self):
@@ -213,6 +320,7 @@ class EvcsspManagerEnv_v6(object):
         self._vec.reset(days, None if z is None else z.copy())
         self._price_count = 0  # MGR:313
         self._time = 0
+        self.env_aggregator.price = [] + self.env_aggregator.price_constant  # AGG:171
         self._make_state(0)
         self.lagrangian_factor = None
         self.penalty = 0
@@ -266,8 +374,9 @@ class EvcsspManagerEnv_v6(object):
             temp_deviation = temp_deviation / 0.2
             self.test_penalty = abs(temp_deviation)
         self.deviation = abs(store_soc - self.hy_init_soc)
+        self.env_aggregator.price.append(self.env_aggregator.price_constant[self._time])  # AGG:147
         self._time = t_next
-        self._make_state(t_next)
+        self._make_state(t_next, tel)
         return self.state, reward, done, {}
 
     def __getattr__(self, name):

@@ -473,6 +473,22 @@ def _check_dropin_attributes(env, g, i, what):
         close(float(got), want[name], (what, name, i), rtol=TIGHT, atol=TIGHT)
     close(env.real_state, g["real_state"][i], (what, "real_state", i), rtol=TIGHT, atol=TIGHT)
     assert np.array_equal(np.asarray(env.action_real, dtype=np.float64), g["action_real"][i]), (what, "action_real", i)
+    # the sub-objects scripts reach into, through the very expressions the fixture generator applied to the reference object
+    # (oracle/gen/gen_env_golden.py: telemetry(), station_block()): env.hy_sys / .sty / .hvs, env.hfc, env.env_aggregator.evcssp_evs_objects
+    h = env.hy_sys
+    tel = [env.hy_act, h.hy_flow_speed, h.all_power_second, h.sty.Store_SOC, h.sty.capacity, h.hvs.total_mass_need, h.sty.hy_use,
+           h.sty.not_meet, env.fc_power, env.hfc.hy_to_use, env.re_used_renew, env.re_ev_power_list[0], env.re_ev_power_list[1],
+           env.re_hydrogen_power, env.income, g["reward"][i], env.re_pv_power, env.re_wd_power, float(env.real_state[1]),
+           h.hvs.arrive_number, h.hvs.line, len(h.hvs.needed_time_list)]
+    close(tel[:19], g["telem"][i][:19], (what, "sub-object telemetry", i), rtol=TIGHT, atol=1e-7)
+    assert tel[19:] == list(g["telem"][i][19:22]), (what, "fcev ints", i, tel[19:], g["telem"][i][19:22])
+    blk = []
+    for st in env.env_aggregator.evcssp_evs_objects:
+        blk += [st.min_power, st.charge_power, st.max_power, st.car_number, st.line, st.flow_in_number[-1]]
+    assert np.array_equal(np.array(blk), g["stations"][i]), (what, "stations", i, blk, g["stations"][i])
+    ag = env.env_aggregator
+    assert ag.evcssp_charge_power == [blk[1], blk[7]] and ag.ag_flow_in_number == [blk[5], blk[11]] and ag.aggregator_time_hole == env.real_state[0]
+    assert len(ag.price) == 96 + (i % int(g["steps_per_episode"])) + 1 and h.sys_time == env.real_state[0]  # AGG:147,171
 
 
 def test_dropin_class_reproduces_env_test():
