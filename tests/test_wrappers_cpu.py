@@ -293,3 +293,26 @@ def test_user_arrival_cdf_through_the_oracle_parser(tmp_path):
             got = orc.orc_arrival_index(t, time, k)
             assert abs(got - want) <= 1, (time, k, got, want)     # 1-ulp parser effects may move a boundary cell
             assert abs(got - rates[time]) < 6 * np.sqrt(rates[time]) + 2 or k in (0, 999)
+
+
+def test_action_to_real_row_at_once_equals_element_by_element():
+    """EvcsspManagerEnv_v6.action_to_real works on the whole row at once; the reference decides pile by pile (MGR:384-404): on / off iff
+    (a + 1) / 2 >= 0.5 in the array's own precision, the two tail entries swapped and mapped to [0, 1].  Same values, values at and
+    next to the f32 threshold -2^-25 included; a None in the tail is passed through as the reference does."""
+    from charginghub_env_amd.env import EvcsspManagerEnv_v6 as E
+
+    rs = np.random.RandomState(5)
+    edge = np.float32(-2.0 ** -25)
+    rows = [rs.uniform(-1, 1, 47).astype(np.float32) for _ in range(20)]
+    rows.append(np.array([edge, np.nextafter(edge, np.float32(-1)), np.nextafter(edge, np.float32(1)), 0.0, -0.0, 1.0, -1.0, 0.25, -0.5],
+                         dtype=np.float32))
+    rows.append(rs.uniform(-1, 1, 12))                      # a float64 row decides in float64
+    rows.append(list(rs.uniform(-1, 1, 9)))                 # a plain list
+    for a in rows:
+        got = E.action_to_real(a)
+        want = [1.0 if (np.asarray(a[:-2])[i] + 1) / 2 >= 0.5 else 0.0 for i in range(len(a) - 2)]
+        want += [(a[-1] + 1) / 2, (a[-2] + 1) / 2]
+        assert got.dtype == np.float64 and np.array_equal(got, np.array(want)), (a, got, want)
+    with_none = list(rows[0][:5]) + [None, 0.5]
+    got = E.action_to_real(with_none)
+    assert got[-1] is None and got[-2] == 0.75 and list(got[:3]) == [1.0 if (x + 1) / 2 >= 0.5 else 0.0 for x in rows[0][:3]]
