@@ -247,6 +247,9 @@ def roofline_block(slot_us, env_us, slot_b, env_b, per, traffic, traffic_src, n_
     achieved = slot_b * per / (slot_us * 1e-6) / 1e9
     return {"bound": "hbm", "kernel": "k_slot_packed", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            # the bytes the counters saw move per launch over the same duration (L2's memory side; Infinity-Cache hits included):
+            # what the kernel really streams, next to the algorithmic figure the fraction is made of
+            "traffic_GBps": (traffic / (slot_us * 1e-6) / 1e9) if traffic else None,
             "algorithmic_bytes_per_launch": slot_b * per, "avg_launch_us": slot_us, "launches_sampled": n_prof,
             "window": window, "env_kernel_avg_launch_us": env_us, "env_kernel_algorithmic_bytes_per_launch": env_b * per,
             "env_kernel_frac": env_b * per / (env_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
