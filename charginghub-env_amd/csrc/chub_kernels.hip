@@ -182,8 +182,10 @@ __device__ __forceinline__ float emergency_of(float t_target, float t_soc, int t
 // emergency > 8 (CHS.hpp:1248) -- reduce to the "must charge" branch: otherwise emergency = (need/left)^2 with
 // left > ceil(need) >= need, i.e. < 1.  So the hot path only needs this predicate, no division.
 __device__ __forceinline__ bool must_charge(float t_target, float t_soc, int tl) {
+    // need > 0 && tl <= ceil(need) (CHS.hpp:883-890): for an integer tl >= 1, ceil(need) >= tl exactly when need > tl - 1 (both
+    // sides are exact in f32), and that implies need > 0.  tl <= 0 does not occur: an empty slot is never asked.
     const float need = __fsub_rn(t_target, t_soc);
-    return need > 0.0f && (float) tl <= ceilf(need);
+    return need > (float) (tl - 1);
 }
 
 __device__ __forceinline__ float arrive_soc_from(double normal73) {  // mk_soc, CHS.hpp:804-814
@@ -1206,7 +1208,7 @@ struct NoHook {
 template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED, bool FUSED, typename Hook, bool BITS = false>
 __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepArgs &sa, PackedArgs &pa, const Tables &tb,
                                                 const uint32_t block_local, uint32_t *q_cnt, uint32_t *q_new,
-                                                uint64_t *s_ball, int *s_acc, uint32_t *s_unit, Hook &hook, u32x4 *s_rec) {
+                                                uint64_t *s_ball, int *s_acc, uint32_t *s_unit, Hook &hook, u32x4 *s_rec, uint32_t *s_uinfo) {
     // T slots per lane: virtual lane v = tid + j * BLOCK (j < T), virtual wave = wave + j * (BLOCK / 64).  All T slots' loads
     // are in flight together and the barriers are shared.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1305,6 +1307,66 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     }
     if (FUSED) hook.park();
     __syncthreads();
+    // ---- every unit's empties, ONCE per unit: a lane per unit reads the ballots of the (at most two) virtual waves the unit lies in
+    // and leaves, in one word, the empties in front of the unit inside its first wave, the unit's empties in that wave, its empties in
+    // all, and which wave that is.  (Rounds 2-3 had every LANE work its unit's 64-bit masks out for itself, two popcounts and an LDS
+    // read each: a third of the kernel's vector instructions.)  Stations of more than 64 piles keep that form below.
+    if (!BIG) {
+        for (int u = tid; u < 2 * epb; u += BLOCK) {
+            const int e = u >> 1, k = u & 1;
+            const int Sk = k ? S1 : S0;
+            const int U0 = e * St + (k ? S0 : 0), U1 = U0 + Sk;  // the unit's virtual lanes [U0, U1) of the workgroup
+            const int wv = U0 >> 6, lo = U0 & 63;
+            const int hi0 = (U1 - (wv << 6)) < 64 ? (U1 - (wv << 6)) : 64;
+            uint32_t info = (uint32_t) wv << 24;
+            if (Sk > 0) {
+                const uint64_t b0 = s_ball[wv];
+                const uint64_t below_lo = lo ? (~0ull >> (64 - lo)) : 0ull, below_hi = ~0ull >> (64 - hi0);
+                const int start_e = __popcll(b0 & below_lo), cnt0 = __popcll(b0 & below_hi & ~below_lo);
+                const int over = U1 - ((wv + 1) << 6);  // lanes of the unit in the next virtual wave
+                const int cnt1 = over > 0 ? __popcll(s_ball[wv + 1] & (~0ull >> (64 - over))) : 0;
+                info |= (uint32_t) start_e | ((uint32_t) cnt0 << 8) | ((uint32_t) (cnt0 + cnt1) << 16);
+            }
+            s_uinfo[u] = info;
+        }
+    }
+
+    // ---- the occupied slots' step: urgency, feasibility / on-off, car_step, departure (CHS.hpp:1188-1202 / 1499-1513) and
+    // their share of calculate_output (CHS.hpp:1233-1261 / 1544-1572) -- nothing here waits for the admission
+    uint32_t w0n[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        if (BITS) asm volatile("" : "+v"(row[j]), "+v"(ttg[j]), "+v"(actw[j]));
+        else asm volatile("" : "+v"(row[j]), "+v"(ttg[j]), "+v"(act[j]));
+        const int u = 2 * e_[j] + k_[j];
+        int *acc = s_acc + 4 * u + (BIG ? 0 : (lane & (kAccCopies - 1)) * 8 * epb);  // the unit's {min, charge power | max power, cars}: two 64-bit LDS atomics per car
+        w0n[j] = 0u;
+        if (stays[j]) {
+            const float t_target = ttg[j];
+            // action_to_real (MGR:384-393), judge_feasibility (CHS.hpp:1404-1413)
+            const bool bit_on = BITS && ((((hs_[j] & 32) ? actw[j].y : actw[j].x) >> (hs_[j] & 31)) & 1u) != 0u;
+            const bool on = (BITS ? bit_on : act[j] >= kActOnThreshold) || must_charge(t_target, row[j].y, tl[j]);
+            const float power = on ? row[j].z : row[j].x, t_soc = on ? row[j].w : row[j].y;  // car_step = the next entry of the class row
+            const int q = kw_to_fixed(power);
+            const bool urgent = must_charge(t_target, t_soc, tl[j] - 1);
+            w0n[j] = (w0[j] & ~kPsChg) - 1u + (on ? (kPsStep | kPsChg) : 0u);
+            if (!BIG) {
+                atomicAdd((unsigned long long *) (acc + 2), (unsigned long long) (uint32_t) q | (1ull << 32));
+                if (on || urgent)
+                    atomicAdd((unsigned long long *) acc,
+                              (unsigned long long) (urgent ? (uint32_t) q : 0u) | ((unsigned long long) (on ? (uint32_t) q : 0u) << 32));
+            } else {
+                unsigned long long *a64 = (unsigned long long *) (s_acc64 + 4 * u);
+                atomicAdd(a64 + 2, (unsigned long long) q);
+                atomicAdd(a64 + 3, 1ull);
+                if (urgent) atomicAdd(a64 + 0, (unsigned long long) q);
+                if (on) atomicAdd(a64 + 1, (unsigned long long) q);
+            }
+        }
+    }
+    if (!BIG) __syncthreads();  // the units' words are in
+
+    // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): admission
     int line[T], flow[T];
     bool adm[T];
     uint64_t ba[T];
@@ -1312,19 +1374,17 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
 #pragma unroll
     for (int j = 0; j < T; j++) {
         const int vw = wave + j * WAVES;
-        const int Sk = k_[j] ? S1 : S0;
-        // ballot masks of the unit's lanes [ub, ue) of the workgroup
-        const int ub = e_[j] * St + (k_[j] ? S0 : 0) - vw * 64, ue = ub + Sk;  // relative to this wave's lane 0
         int empties, rank;
         if (!BIG) {
-            // in this (virtual) wave, and in the neighbouring wave the unit began in or runs over into (S_k <= 64: at most one)
-            const bool b_prev = ub < 0, b_next = ue > 64;
-            const uint64_t mA = (~0ull >> (b_next ? 0 : 64 - ue)) & (~0ull << (b_prev ? 0 : ub));
-            const uint64_t mB = b_prev ? (~0ull << (64 + ub)) : (b_next ? (~0ull >> (128 - ue)) : 0ull);
-            const int cntB = __popcll(s_ball[b_prev ? vw - 1 : vw + 1] & mB);  // its empties there (mB = 0: no lanes there)
-            empties = __popcll(be[j] & mA) + cntB;
-            rank = prefix_count(be[j] & mA) + (b_prev ? cntB : 0);
+            // rank = the unit's empties in front of this lane: inside the unit's first wave, empties of the wave below the lane minus
+            // those in front of the unit; in its second wave, the unit's empties of the first wave + those below the lane
+            const uint32_t info = valid[j] ? s_uinfo[2 * e_[j] + k_[j]] : 0u;  // (lanes past the workgroup's last env hold no unit)
+            const int m = prefix_count(be[j]);
+            empties = (int) ((info >> 16) & 255u);
+            rank = (int) (info >> 24) == vw ? m - (int) (info & 255u) : m + (int) ((info >> 8) & 255u);
         } else {
+            const int Sk = k_[j] ? S1 : S0;
+            const int ub = e_[j] * St + (k_[j] ? S0 : 0) - vw * 64, ue = ub + Sk;  // relative to this wave's lane 0
             // a unit of up to 256 lanes: its empties in every virtual wave it touches; those in earlier waves come before this lane
             empties = 0;
             rank = 0;
@@ -1377,40 +1437,10 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
             base += (uint32_t) __popcll(ba[j]);
         }
     }
-
-    // ---- the occupied slots' step: urgency, feasibility / on-off, car_step, departure (CHS.hpp:1188-1202 / 1499-1513) and
-    // their share of calculate_output (CHS.hpp:1233-1261 / 1544-1572)
 #pragma unroll
     for (int j = 0; j < T; j++) {
-        if (BITS) asm volatile("" : "+v"(row[j]), "+v"(ttg[j]), "+v"(actw[j]));
-        else asm volatile("" : "+v"(row[j]), "+v"(ttg[j]), "+v"(act[j]));
-        const int u = 2 * e_[j] + k_[j];
-        int *acc = s_acc + 4 * u + (BIG ? 0 : (lane & (kAccCopies - 1)) * 8 * epb);  // the unit's {min, charge power | max power, cars}: two 64-bit LDS atomics per car
-        uint32_t w0n = 0u;
-        if (stays[j]) {
-            const float t_target = ttg[j];
-            // action_to_real (MGR:384-393), judge_feasibility (CHS.hpp:1404-1413)
-            const bool bit_on = BITS && ((((hs_[j] & 32) ? actw[j].y : actw[j].x) >> (hs_[j] & 31)) & 1u) != 0u;
-            const bool on = (BITS ? bit_on : act[j] >= kActOnThreshold) || must_charge(t_target, row[j].y, tl[j]);
-            const float power = on ? row[j].z : row[j].x, t_soc = on ? row[j].w : row[j].y;  // car_step = the next entry of the class row
-            const int q = kw_to_fixed(power);
-            const bool urgent = must_charge(t_target, t_soc, tl[j] - 1);
-            w0n = (w0[j] & ~kPsChg) - 1u + (on ? (kPsStep | kPsChg) : 0u);
-            if (!BIG) {
-                atomicAdd((unsigned long long *) (acc + 2), (unsigned long long) (uint32_t) q | (1ull << 32));
-                if (on || urgent)
-                    atomicAdd((unsigned long long *) acc,
-                              (unsigned long long) (urgent ? (uint32_t) q : 0u) | ((unsigned long long) (on ? (uint32_t) q : 0u) << 32));
-            } else {
-                unsigned long long *a64 = (unsigned long long *) (s_acc64 + 4 * u);
-                atomicAdd(a64 + 2, (unsigned long long) q);
-                atomicAdd(a64 + 3, 1ull);
-                if (urgent) atomicAdd(a64 + 0, (unsigned long long) q);
-                if (on) atomicAdd(a64 + 1, (unsigned long long) q);
-            }
-        }
-        if (valid[j] && !adm[j]) CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) (tid + j * BLOCK)) << 2) = w0n;
-        if (valid[j] && slot[j] == 0) s_unit[u] = pkd_make(line[j], flow[j], 0);
+        if (valid[j] && !adm[j]) CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) (tid + j * BLOCK)) << 2) = w0n[j];
+        if (valid[j] && slot[j] == 0) s_unit[2 * e_[j] + k_[j]] = pkd_make(line[j], flow[j], 0);
     }
     __syncthreads();
     // Everything left -- the workgroup's new cars and, after them, the station records -- is the last wave's business: the
@@ -1486,6 +1516,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_sl
     __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];                   // [1 + virtual wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
     __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T * kAccCopies];  // 2 epb <= BLOCK * T / 2 units x {min, charge, max power, cars} (BIG: as 64-bit sums, few units)
     __shared__ uint32_t s_unit[BLOCK * T / 2];                        // per unit: line | flow << 8
+    __shared__ uint32_t s_uinfo[BLOCK * T / 2];                       // per unit: where its empties are (the admission's unit pass)
     // all kernel arguments this wave needs, requested in ONE batch of scalar loads at its very start (the single asm
     // statement makes every one of them live here), instead of in a chain of dependent loads in front of the first
     // vector load
@@ -1494,7 +1525,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_sl
                       "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
     NoHook hook;
     (void) slot_body_packed<BLOCK, T, TAPE, RESET, BIG, MASKED, false, NoHook, BITS>(ctx->hp, sa, pa, ctx->tb, blockIdx.x + (MASKED ? pa.blk0 : 0u), q_cnt, q_new,
-                                                                                     s_ball + 1, s_acc, s_unit, hook, nullptr);
+                                                                                     s_ball + 1, s_acc, s_unit, hook, nullptr, s_uinfo);
 }
 
 // What the tail's first loads need, by value in the kernel arguments: one scalar load at the start of the wave instead
@@ -2368,6 +2399,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
     __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];
     __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T * kAccCopies];
     __shared__ uint32_t s_unit[BLOCK * T / 2];
+    __shared__ uint32_t s_uinfo[BLOCK * T / 2];
     __shared__ __attribute__((aligned(16))) u32x4 s_rec[BLOCK * T / 2];
     __shared__ double s_pv[100], s_wd[150], s_pv_now[100], s_wd_now[150], s_hy[102];
     __shared__ __attribute__((aligned(16))) float s_out[64 * 16];
@@ -2380,7 +2412,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
         if ((int) (threadIdx.x >> 6) == BLOCK / 64 - 1 && le < (int) pa_in.epb && env < (int) pa_in.n_envs) hook.tail_env = env;
     }
     const int role = slot_body_packed<BLOCK, T, false, false, false, false, true, TailPrefetch, BITS>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
-                                                                                                      s_ball + 1, s_acc, s_unit, hook, s_rec);
+                                                                                                      s_ball + 1, s_acc, s_unit, hook, s_rec, s_uinfo);
     constexpr int WAVES = BLOCK / 64;
     const int lane = threadIdx.x & 63;
     const int epb = (int) pa.epb, N = (int) pa.n_envs, env_first = (int) blockIdx.x * epb;
