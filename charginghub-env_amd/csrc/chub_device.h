@@ -63,7 +63,7 @@ enum Site : uint32_t {
     SITE_ARRIVE = 1,  // index = station; word 0 = arrival level, word 1+j = balk level of arrival j
     SITE_INIT = 2,    // index = station; polar trials for the initial-occupancy normal (reset)
     SITE_RENEGE = 3,  // index = station; word w = renege level of queued car w
-    SITE_SOC = 5,     // index = station | admission rank << 1 (car_index): word 0 arrival-SoC class, 1 target level, 2 extra stay
+    SITE_SOC = 5,     // index = hub slot; polar trials for the arrival SoC normal
     SITE_TGT = 6,     // index = hub slot; word 0 = target-SoC level
     SITE_LATE = 7,    // index = hub slot; polar trials for the extra-stay normal
     SITE_HV = 8,      // word 0 = FCEV arrival level

@@ -92,12 +92,6 @@ struct PhiloxCtx {
     }
 };
 
-// The variates of a car that is admitted (arrival-SoC class, target level, extra stay: one Philox block, SITE_SOC) are keyed by the
-// station it enters and by its ADMISSION RANK in that station and launch -- the r-th car the unit admits, in slot order -- not by
-// the slot it ends up in: who gets which slot depends on the step's departures, the r-th admission of a unit does not, so the blocks of
-// a workgroup's units can be computed before anything about the step is known (k_slot_packed does, while its first loads are in flight).
-__device__ __forceinline__ uint32_t car_index(int k, int rank) { return (uint32_t) k | ((uint32_t) rank << 1); }
-
 // ------------------------------------------------------------- reference streams (COMPAT), one lane
 struct CompatStream {
     uint32_t *g;  // 32 words: ring[31] + front index
@@ -755,7 +749,7 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     const bool adm = empty && rank < assign;
     if (adm) {  // add_car (CHS.hpp:864-877 / 1029-1042): one Philox block per new car, word 0 SoC class, 1 target level, 2 extra stay
         PhiloxCtx px{hp.key[0], hp.key[1], CHUB_TICK(hp, sa.tick), (uint32_t) (hp.env_id0 + env)};
-        const U4 o = px.block(SITE_SOC, car_index(k, rank), 0);
+        const U4 o = px.block(SITE_SOC, (uint32_t) hub_slot, 0);
         const uint32_t c = o.v[0] >> kSocLevelShift, lev = o.v[1] % 1000u;
         const f32x2 e0 = *(CHUB_G(const f32x2)) ((CHUB_G(const char)) cls + (size_t) c * (kClsRow * 8u));
         t_target = tb.ttab[k][lev];
@@ -1009,7 +1003,7 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
             meta = nc.stay | (nc.lev << 7);
         } else {
             PhiloxCtx px{hp.key[0], hp.key[1], CHUB_TICK(hp, sa.tick), (uint32_t) (hp.env_id0 + env)};
-            const U4 o = px.block(SITE_SOC, car_index(k, rank), 0);
+            const U4 o = px.block(SITE_SOC, (uint32_t) hub_slot, 0);
             const uint32_t c = o.v[0] >> kSocLevelShift, lev = o.v[1] % 1000u;
             const f32x2 e0 = *(CHUB_G(const f32x2)) ((CHUB_G(const char)) cls + (size_t) c * (kClsRow * 8u));
             t_target = tb.ttab[k][lev];
@@ -1373,7 +1367,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     if (!BIG) __syncthreads();  // the units' words are in
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): admission
-    int line[T], flow[T], rank_[T];
+    int line[T], flow[T];
     bool adm[T];
     uint64_t ba[T];
     uint32_t n_push = 0;
@@ -1430,7 +1424,6 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
             line[j] = line[j] < kMaxLine ? line[j] : kMaxLine;
         }
         adm[j] = empty[j] && rank < assign;
-        rank_[j] = rank;
         ba[j] = __ballot(adm[j]);
         n_push += (uint32_t) __popcll(ba[j]);
     }
@@ -1440,7 +1433,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         base = __shfl(base, 0);
 #pragma unroll
         for (int j = 0; j < T; j++) {
-            if (adm[j]) q_new[base + prefix_count(ba[j])] = (uint32_t) (tid + j * BLOCK) | ((uint32_t) rank_[j] << 12);  // virtual lane | admission rank
+            if (adm[j]) q_new[base + prefix_count(ba[j])] = (uint32_t) (tid + j * BLOCK);
             base += (uint32_t) __popcll(ba[j]);
         }
     }
@@ -1459,7 +1452,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     // ---- add_car (CHS.hpp:864-877 / 1029-1042) for the workgroup's new cars, one lane per car
     const uint32_t n_adm = q_cnt[0];
     for (uint32_t i = (uint32_t) (ALL ? tid : lane); i < n_adm; i += (ALL ? BLOCK : 64)) {
-        const int src = (int) (q_new[i] & 4095u), s_rank = (int) (q_new[i] >> 12);
+        const int src = (int) q_new[i];
         const int s_e = (int) (__umul24((uint32_t) src, pa.magic) >> 20);
         const int s_hs = src - (int) __umul24((uint32_t) s_e, (uint32_t) St);
         const int s_k = s_hs >= S0 ? 1 : 0;
@@ -1472,7 +1465,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
             late = (int) (tp.y >> 16);
         } else {
             PhiloxCtx p2{pa.key[0], pa.key[1], pa.tick, pa.gid0 + (uint32_t) (env_first + s_e)};
-            const U4 o = p2.block(SITE_SOC, car_index(s_k, s_rank), 0);  // word 0 SoC class, 1 target level, 2 extra stay
+            const U4 o = p2.block(SITE_SOC, (uint32_t) s_hs, 0);  // word 0 SoC class, 1 target level, 2 extra stay
             c = o.v[0] >> kSocLevelShift;
             lev = o.v[1] % 1000u;
             late = 0;  // late_from_word, the first 8 thresholds from registers
