@@ -135,9 +135,54 @@ def cpu_baseline(hub_kw, total_envs, target_seconds=12.0):
     if n == total_envs:  # whole workload fits: add whole episodes until the sample is ~target_seconds long
         steps = 96 * max(1, min(4, int(round(rate * target_seconds / (n * 96.0)))))
     rate = run(n, steps)
-    return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d steps of the same hub (oracle/chub_oracle.c, Philox streams, %d pthreads)"
-                      % (n, steps, cores)}
+    out = {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": "%d envs x %d steps of the same hub (oracle/chub_oracle.c, Philox streams, %d pthreads)"
+                     % (n, steps, cores)}
+    ref = reference_stations_rate(hub_kw)
+    if ref:
+        out["reference_stations"] = ref
+    return out
+
+
+def reference_stations_rate(hub_kw, target_seconds=3.0):
+    """The reference's OWN native core timed beside the port, where its build travelled with the snapshot (oracle/_ref/libchs_ref.so =
+    the unmodified CHS.hpp behind oracle/ref_driver.cpp): the hub's two stations stepped with random on / off rows and reset every 96
+    steps (Fast/SlowChargeStation::evs_step / evs_reset, CHS.hpp:1188-1231 / 1499-1542) on ONE core -- the reference is single-threaded
+    with process-global RNG state.  Stations only: the Python half of the reference env (about half of its 220 us step)
+    cannot travel.  None where the library is absent."""
+    import ctypes as C
+
+    import numpy as np
+
+    import orclib
+
+    if not orclib.ref_available():
+        return None
+    try:
+        ref = orclib.ref()
+    except (OSError, AssertionError):
+        return None
+    piles, types = hub_kw["station_list"], hub_kw["station_type_list"]
+    ref.ref_seed(1, 1)
+    st = [ref.ref_station_new(0 if types[k] == "fast" else 1, int(piles[k]), 1, 0) for k in range(2) if piles[k] > 0]
+    rs = np.random.RandomState(0)
+    rows = [[np.ascontiguousarray(rs.choice([0.0, 1.0], size=int(p)).astype(np.float32)) for p in piles if p > 0] for _ in range(16)]
+    steps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < target_seconds:
+        for h in st:
+            ref.ref_station_reset(h)
+        for t in range(96):
+            r = rows[t % 16]
+            for i, h in enumerate(st):
+                ref.ref_station_step(h, r[i].ctypes.data_as(C.c_void_p), r[i].size)
+        steps += 96
+    dt = time.perf_counter() - t0
+    for h in st:
+        ref.ref_station_free(h)
+    return {"value": steps / dt, "unit": "hub-steps/s", "cores": 1, "kind": "reference",
+            "sample": "%d steps of the hub's two stations alone (the unmodified CHS.hpp, oracle/_ref), random on / off rows, reset every 96 "
+                      "steps; the Python half of the reference env is not in it" % steps}
 
 
 # ------------------------------------------------------------------------------------------------ the launcher (N > 1, no WORLD_SIZE)

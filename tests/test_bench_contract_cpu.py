@@ -71,3 +71,20 @@ def test_committed_bench_line_has_the_contract_fields():
     assert "roofline_c5" in d and d["roofline_c5"]["state_bytes"] == 262144 * 64 * 4  # one 32-bit word per slot since round 4
     assert d["roofline"]["traffic"] and d["roofline"]["traffic_source"] == os.path.basename(lines[-1]).replace("_bench.json", "_pmc_traffic.json")
     assert d["dropin_single_env"]["compat_us_per_step"] < d["dropin_single_env"]["reference_us_per_step"]
+
+
+def test_reference_stations_rate_is_timed_where_the_reference_build_exists():
+    """cpu_baseline.reference_stations: the unmodified CHS.hpp (oracle/_ref) timed on one core beside the port -- present wherever the
+    library travelled, a plausible rate (the survey measured 12.8 k hub-steps/s for this hub on one core of this container)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orclib
+    b = _bench()
+    r = b.reference_stations_rate(dict(station_list=[20, 25], station_type_list=["fast", "slow"], fcev_permeate=0.01), target_seconds=0.5)
+    if not orclib.ref_available():
+        assert r is None
+        return
+    assert r["kind"] == "reference" and r["cores"] == 1 and r["unit"] == "hub-steps/s" and 1e3 < r["value"] < 1e6 and "CHS.hpp" in r["sample"]
+    # a hub with a station without piles times the other station alone
+    r0 = b.reference_stations_rate(dict(station_list=[16, 0], station_type_list=["fast", "slow"], fcev_permeate=0.0), target_seconds=0.3)
+    assert r0["value"] > r["value"]
