@@ -54,6 +54,9 @@ constexpr int kBigBlock = CHUB_BIG_BLOCK, kBigSlotsPerLane = CHUB_BIG_SLOTS_PER_
 constexpr int64_t kBigTileSlots = (int64_t) 10 << 20;  // handles of at least this many charger slots take the second tile (chub_options.tile overrides)
 constexpr int kClsRow = 32;        // PHILOX: entries (power, t_soc) per arrival-SoC class = car_steps a car can take (stay_time <= 27 here)
 constexpr int kTelemCount = 38;
+constexpr int64_t kCompatSplitEnvs = 8192;  // COMPAT handles of at least this many envs run the split step.  Measured, us per step, split vs one kernel per
+                                            // station: 60.2 vs 51.8 at 2048 envs, 64.5 vs 55.6 at 4096, 68.3 vs 70.2 at 8192, 74.8 vs 103.5 at 16 384,
+                                            // 91.7 vs 162.9 at 32 768, 124 vs 279 at 65 536 ([20, 25] hub)
 constexpr int kFusedMaxBlocks = 384;   // PHILOX lock-step steps of at most this many slot workgroups run as ONE launch (k_step_fused).  Measured, us per step
                                        // as graph replays, one launch vs two: 8.08 vs 8.82 at 128 workgroups (C2), 8.50 vs 9.30 at 256, 9.42 vs 9.79 at 373,
                                        // 10.79 vs 10.61 at 745, 11.71 vs 11.38 at 1024, 17.9 vs 13.1 at 1490
@@ -92,6 +95,8 @@ struct SlotArrays {          // index = base_k + env*S_k + slot  (station-major)
     // recorded number of car_steps (k_replay_soc), target SoC from its level; slots without a car read as zeros.
     CHUB_G(float) init_soc;  // arrival SoC (COMPAT)
     CHUB_G(uint8_t) stay8;   // PHILOX [N][S0 + S1]: Station::stay_time of the car in the slot (CHS.hpp:245), written when it is admitted
+    CHUB_G(uint32_t) var;    // COMPAT, split step [N][S0 + S1][2], hub-major by admission rank: what the stream walk (k_compat_walk) drew for the
+                             // r-th car a unit admits this step: arrival SoC (f32 bits), target level | extra stay << 16
 };
 
 struct StationArrays {       // unit index u = k*N + env
@@ -100,6 +105,8 @@ struct StationArrays {       // unit index u = k*N + env
     CHUB_G(float) tail_act;      // [N][2] PHILOX: the env's two tail actions (electrolyser, fuel cell), copied by the packed slot kernel
                                  // out of the action row it has just read: the tail kernel reads 8 contiguous bytes per env
                                  // instead of one 128-byte line per env of the [N, S+2] action matrix
+    CHUB_G(uint8_t) empt;        // COMPAT, split step [2N]: the unit's empty slots once this step's departures are out (k_compat_empties)
+    CHUB_G(uint32_t) fa;         // COMPAT, split step [2N]: what the unit's walk came to: flow_in (16 bits, signed) | cars admitted << 16 | queue << 24
     CHUB_G(uint32_t) pk[2];      // PHILOX, double-buffered by tick parity: what a unit's station-level draws of a step come to,
                                  // decoded one launch ahead against the queue the previous step left (dk_make): bits 0-7 queue after
                                  // the renege pass + arrivals that stay = the cars that want a slot, bits 8-15 flow_in.  For a reset:
@@ -189,6 +196,7 @@ struct HubParams {
     int32_t epb;             // packed slot kernel: whole envs per workgroup = pblock * pslots / (S0 + S1)
     int32_t pblock, pslots;  // packed slot kernel: the handle's tile, (kPackedBlock, kSlotsPerLane) or (kBigBlock, kBigSlotsPerLane)
     int32_t packed;          // PHILOX steps run k_slot_packed (any hub shape of up to 512 piles)
+    int32_t compat_split;    // COMPAT resets / steps run empties -> walk (lane = env) -> slots instead of one kernel per station
 };
 
 // Everything a kernel needs that does not change from step to step, kept in device memory and passed by pointer

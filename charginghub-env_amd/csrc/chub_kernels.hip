@@ -492,7 +492,10 @@ __device__ __forceinline__ bool load_mode_on(const HubParams &hp, const StepArgs
 // (CHS.hpp:1188-1207 / 1499-1518).  The unit's first lane walks the env's two reference streams in the reference's
 // consumption order; station sums in the reference's sequential f32 order.  Pinned against the recorded reference
 // trajectories (tests/golden).
-template <int TYPE, bool RESET, int BLOCK>
+// SPLIT (the split step of large batches): the walk was done by k_compat_walk, one ENV per lane (here one lane per UNIT walks while
+// the other lanes of the wave idle); this body then only fetches what it came to -- flow, cars admitted, queue -- and the admitted
+// lanes their car's variates.  Same draws in the same order, same arithmetic: bit-identical.
+template <int TYPE, bool RESET, int BLOCK, bool SPLIT = false>
 __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
                                  const CompatRng &cr, const Tables &tb, const int k, const int64_t block_local,
                                  float *lds_f, uint32_t *lds_u) {
@@ -566,7 +569,13 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     const int lbase = wave * 64 + (uiw << logH);
     int2 fa = make_int2(0, 0);
     int new_line = line;
-    if (unit_ok && slot == 0) {
+    if (SPLIT) {
+        if (unit_ok && slot == 0) {
+            const uint32_t w = st.fa[sidx];
+            fa = make_int2((int) (int16_t) (w & 0xFFFFu), (int) ((w >> 16) & 255u));
+            new_line = (int) (w >> 24);
+        }
+    } else if (unit_ok && slot == 0) {
         CompatStream rs;
         rs.load(cr, env);
         int n_in;
@@ -611,9 +620,20 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     const bool adm = empty && rank < assign;
     float nc_soc = 0.0f;
     if (adm) {
-        const int lev = (int) lds_lev[lbase + rank];
+        int lev, late_;
+        float soc_;
+        if (SPLIT) {
+            const u32x2 vv = ((CHUB_G(const u32x2)) sl.var)[(uint32_t) env * (uint32_t) (hp.S[0] + hp.S[1]) + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank];
+            soc_ = __uint_as_float(vv.x);
+            lev = (int) (vv.y & 0xFFFFu);
+            late_ = (int) (vv.y >> 16);
+        } else {
+            lev = (int) lds_lev[lbase + rank];
+            soc_ = lds_soc[lbase + rank];
+            late_ = (int) lds_late[lbase + rank];
+        }
         const float target = uniform_level(lev, 80.0f, 100.0f);
-        const NewCar nc = make_car<TYPE>(lds_soc[lbase + rank], lev, soc_to_time<TYPE>(target, cp), (int) lds_late[lbase + rank], cp);
+        const NewCar nc = make_car<TYPE>(soc_, lev, soc_to_time<TYPE>(target, cp), late_, cp);
         nc_soc = nc.soc;
         t_target = nc.t_target;
         t_soc = nc.t_soc;
@@ -1608,6 +1628,104 @@ __global__ __launch_bounds__(BLOCK, 7) void k_slot(const DevCtx *__restrict__ ct
     if (MODE == MODE_PHILOX) slot_body_wave<RESET, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->tb, k, bl, lds_f, lds_u);
     else if (hp.type[k] == 0) slot_body_compat<0, RESET, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
     else slot_body_compat<1, RESET, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
+}
+
+// ---------------------------------------------------------------------------------------- COMPAT, the split step
+// One kernel per station with the unit's first lane walking the env's streams keeps 2 of a wave's 64 lanes busy through the longest
+// part of the step (every polar normal of the reference's std::normal_distribution costs a lane about a microsecond): 250 of the
+// 279 us of a step at 65 536 envs.  Large batches therefore run
+//   k_compat_empties  lane = slot: how many slots of each unit are empty once this step's departures are out (a slot is empty after
+//                     remove_car iff it had at most one slot of stay left, CHS.hpp:912-923 / 1077-1088) -- all the walk needs of the slots
+//   k_compat_walk     lane = ENV, 64 walks per wave: station 0's draws, then station 1's, in the reference's consumption order
+//                     (receive_car, CHS.hpp:1272-1316 / 1583-1627; the forecourt's follow in the tail kernel as before), leaving per
+//                     unit flow / cars admitted / queue and per admitted car its three variates
+//   k_slot_split      lane = slot, both stations in ONE launch: everything else (slot_body_compat<.., SPLIT>)
+// Same streams, same order, same arithmetic as the one-kernel-per-station form (chub_options.slot_kernel = 1 keeps that one:
+// the parity cross-check; handles of a few envs run k_compat_small).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_compat_empties(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0) {
+    const HubParams &hp = ctx->hp;
+    const int64_t bid = blockIdx.x;
+    const int k = (bid >= nb0) ? 1 : 0;
+    const int64_t bl = k ? bid - nb0 : bid;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = hp.H[k], S = hp.S[k], logH = hp.logH[k];
+    const int upw = 64 >> logH, uiw = lane >> logH, slot = lane & (H - 1);
+    const int env = (int) bl * ((BLOCK / 64) * upw) + wave * upw + uiw;
+    const bool unit_ok = env < (int) hp.n_envs && in_group(sa, env);
+    const bool valid = unit_ok && slot < S;
+    const uint64_t unit_mask = (H == 64) ? ~0ull : (((1ull << H) - 1ull) << (uiw << logH));
+    uint32_t w = 0u;
+    if (valid) w = ctx->sl.hot[4u * ((uint32_t) hp.base[k] + (uint32_t) env * (uint32_t) S + (uint32_t) slot) + 3u];
+    const bool empty = valid && (int) (w & 127u) <= 1;
+    const uint64_t be = __ballot(empty) & unit_mask;
+    if (unit_ok && slot == 0) ctx->st.empt[(uint32_t) k * (uint32_t) hp.n_envs + (uint32_t) env] = (uint8_t) __popcll(be);
+}
+
+template <bool RESET>
+__global__ __launch_bounds__(256) void k_compat_walk(const DevCtx *__restrict__ ctx, StepArgs sa) {
+    const HubParams &hp = ctx->hp;
+    const Tables &tb = ctx->tb;
+    const StationArrays &st = ctx->st;
+    const int64_t N = hp.n_envs;
+    const int env = (int) (blockIdx.x * 256u + threadIdx.x);
+    if (env >= (int) N || !in_group(sa, env)) return;
+    CompatStream rs;
+    rs.load(ctx->cr, env);
+    const uint32_t St = (uint32_t) (hp.S[0] + hp.S[1]);
+    for (int k = 0; k < 2; k++) {
+        const int S = hp.S[k];
+        const bool fast = hp.type[k] == 0;
+        const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
+        const int line = RESET ? 0 : pkd_line(st.rec[4u * sidx + 3u]);
+        const int empties = RESET ? S : (int) st.empt[sidx];
+        const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
+        int n_in;
+        if (RESET) {
+            const float cn = rs.normal_f((float) mu, 1.0f);
+            int temp = (int) roundf(cn);
+            temp = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
+            n_in = temp;
+        } else {
+            const int t_env = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;  // per-env clocks: the env's own slot of day
+            n_in = (int) tb.cnt[k][t_env * kLevels + rs.level()];
+        }
+        int tline = 0;
+        for (int w = 0; w < line; w++) tline += (rs.level() >= (int) tb.thr_renege[w]) ? 1 : 0;
+        int new_line = tline;
+        int true_in = 0;
+        for (int j = 0; j < n_in; j++) {
+            const int m = new_line + j;
+            const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
+            true_in += (rs.level() <= thr && j <= S) ? 1 : 0;
+        }
+        const int fl = fast ? n_in : true_in;
+        const int as = (new_line + fl) < empties ? (new_line + fl) : empties;
+        new_line = new_line + fl - as;
+        new_line = new_line < kMaxLine ? new_line : kMaxLine;
+        CHUB_G(u32x2) var = (CHUB_G(u32x2)) ctx->sl.var + ((uint32_t) env * St + (uint32_t) (k ? hp.S[0] : 0));
+        for (int rr = 0; rr < as; rr++) {  // ascending slot order == ascending rank
+            const float soc = arrive_soc_from(rs.normal_d(7.0, 3.0));
+            const uint32_t lev = (uint32_t) rs.level();
+            int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
+            late = late < 0 ? 0 : late;
+            var[rr] = u32x2{__float_as_uint(soc), lev | ((uint32_t) late << 16)};
+        }
+        st.fa[sidx] = ((uint32_t) fl & 0xFFFFu) | ((uint32_t) (as > 0 ? as : 0) << 16) | ((uint32_t) new_line << 24);
+    }
+    rs.store(ctx->cr, env);
+}
+
+template <bool RESET, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 7) void k_slot_split(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0) {
+    const HubParams &hp = ctx->hp;
+    const int64_t bid = blockIdx.x;
+    const int k = (bid >= nb0) ? 1 : 0;
+    const int64_t bl = k ? bid - nb0 : bid;
+    __shared__ float lds_f[BLOCK];  // (the scalar-load mode's rank pass: the only user of the scratch areas here)
+    __shared__ uint32_t lds_u[2 * BLOCK];
+    if (hp.type[k] == 0) slot_body_compat<0, RESET, BLOCK, true>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
+    else slot_body_compat<1, RESET, BLOCK, true>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
 }
 
 // ----------------------------------------------------------------------------------------- k_env
@@ -2721,6 +2839,11 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
     if (MODE == MODE_PHILOX && RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((8 * ((int64_t) sa.env_hi - sa.env_lo + 1) + 255) / 256)), dim3(256), 0, stream, ctx, sa);
     if (MODE == MODE_PHILOX && !big) {
         CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, ev1, ctx, sa, nb0);
+    } else if (MODE == MODE_COMPAT && !big && hp.compat_split) {
+        // the split step: empties -> the stream walks, one env per lane -> the slots of both stations in one launch
+        if (!RESET) CHUB_LAUNCH((k_compat_empties<BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, (hipEvent_t) nullptr, ctx, sa, nb0);
+        CHUB_LAUNCH((k_compat_walk<RESET>), dim3((unsigned) ((hp.n_envs + 255) / 256)), dim3(256), stream, RESET ? ev0 : (hipEvent_t) nullptr, (hipEvent_t) nullptr, ctx, sa);
+        CHUB_LAUNCH((k_slot_split<RESET, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, (hipEvent_t) nullptr, ev1, ctx, sa, nb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
             StepArgs s2 = sa;

@@ -715,6 +715,10 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     {   // the reference-exact mode at a handful of envs (the drop-in class: one): both station passes and the tail in one launch
         const int64_t fit = std::min<int64_t>((kSlotBlock / 64) * (64 / hp.H[0]), (kSlotBlock / 64) * (64 / hp.H[1]));
         e->compat_small = rng_mode == CHUB_RNG_COMPAT && opt.fused_step != 1 && hp.S[0] <= 64 && hp.S[1] <= 64 && n_envs <= fit;
+        // ... and large batches as the split step (empties -> stream walks, one env per lane -> slots); below kCompatSplitEnvs one kernel per
+        // station with the unit's first lane walking is the shorter chain (slot_kernel = 1 / 2 force either form: the parity cross-check)
+        hp.compat_split = (rng_mode == CHUB_RNG_COMPAT && hp.S[0] <= 64 && hp.S[1] <= 64 &&
+                           (opt.slot_kernel == 2 || (opt.slot_kernel == 0 && n_envs >= kCompatSplitEnvs))) ? 1 : 0;
     }
     build_hy_table(hp, e->hy_table);
     std::vector<double> hy_v(e->hy_table, e->hy_table + 102);
@@ -764,11 +768,16 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
     e->sl.init_soc = nullptr;
     e->sl.stay8 = nullptr;
+    e->sl.var = nullptr;
+    e->st.empt = nullptr;
+    e->st.fa = nullptr;
     if (rng_mode == CHUB_RNG_PHILOX) {
         ALLOC(e->sl.hot, NS);  // 4-byte slot state
         ALLOC(e->sl.stay8, NS);
     } else {
         ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.init_soc, NS);
+        ALLOC(e->sl.var, 2 * NS);  // the split step's per-admission variates
+        ALLOC(e->st.empt, 2 * N); ALLOC(e->st.fa, 2 * N);
     }
     ALLOC(e->st.rec, 8 * N); ALLOC(e->st.pk[0], 2 * N); ALLOC(e->st.pk[1], 2 * N); ALLOC(e->st.tail_act, 2 * N);
     ALLOC(e->ev.cap, N); ALLOC(e->ev.store_soc, N); ALLOC(e->ev.ou, 3 * N); ALLOC(e->ev.price_noise, N);

@@ -69,7 +69,10 @@ typedef struct chub_env chub_env;
  * environment variables). */
 typedef struct chub_options {
     int32_t slot_kernel;  /* PHILOX steps: 0 = the packed slot kernel wherever the hub shape allows (default),
-                             1 = the wave-local slot kernel for every step, 2 = same as 0 (kept for tests that name it) */
+                             1 = the wave-local slot kernel for every step, 2 = same as 0 (kept for tests that name it).
+                             COMPAT resets / steps: 0 = by batch size: from 8192 envs the split form (empties, then the stream walks one ENV
+                             per lane, then the slots of both stations in one launch), below one kernel per station with the unit's first
+                             lane walking; 1 = always the latter, 2 = always the former (bit-identical) */
     int32_t no_arena;     /* 1: one hipMalloc per array instead of one arena (disables chub_get_state / chub_set_state) */
     int32_t fused_step;   /* PHILOX lock-step steps as ONE launch (slot work + per-env tail + next step's draws per workgroup):
                              0 = for small batches, where the two step kernels are launch-bound (default), 1 = never, 2 = always

@@ -296,8 +296,9 @@ def test_staggered_hub_on_one_handle():
     ref.close()
 
 
+@pytest.mark.parametrize("form", ["wave", "packed"])  # one kernel per station / the split step of large batches (chub_options.slot_kernel)
 @pytest.mark.parametrize("name", ["env_c3_random", "env_slow_only_fcev", "env_small_fast_neg", "env_fcev_queue"])
-def test_compat_envs_replay_the_reference_fixture_on_their_own_clocks(name):
+def test_compat_envs_replay_the_reference_fixture_on_their_own_clocks(name, form):
     """The reference's own recorded trajectories, with every env of ONE handle on its own clock: env e runs the fixture's
     sequence of calls (the constructor's reset, then per episode reseed / reset / steps) `lag[e]` calls behind env 0, so at
     most library calls some envs are reset while others step, each at its own slot of day -- and every env must still equal
@@ -308,7 +309,7 @@ def test_compat_envs_replay_the_reference_fixture_on_their_own_clocks(name):
     kw = kwargs_of(g)
     lags = [0, 3, 7, 20]
     n = len(lags)
-    v = chub.VecChargingHub(n, rng="compat", **kw)
+    v = chub.VecChargingHub(n, rng="compat", slot_kernel=form, **kw)
     scratch = chub.VecChargingHub(1, rng="compat", **kw)  # turns a seed pair into stream states
     v.set_telemetry(True)
     A, D = v.act_dim, v.obs_dim

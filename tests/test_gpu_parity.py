@@ -53,7 +53,7 @@ def check_slots(got, want, what):
 
 
 @pytest.mark.parametrize("name", orclib.GOLDEN_ENV)
-@pytest.mark.parametrize("n_envs,migrate", [(1, False), (5, False), (3, True)], ids=["1", "5", "3_restored"])
+@pytest.mark.parametrize("n_envs,migrate", [(1, False), (5, False), (3, True), (4, False)], ids=["1", "5", "3_restored", "4_per_station"])
 def test_compat_matches_reference_golden(name, n_envs, migrate):
     """COMPAT streams: the GPU reproduces the reference trajectories (every env of the batch is given the
     same seeds / tape, so each must equal the recorded single-env run).  migrate: in the middle of every episode the state is
@@ -63,8 +63,11 @@ def test_compat_matches_reference_golden(name, n_envs, migrate):
     g = orclib.load_golden(name)
     kw = kwargs_of(g)
     # a handful of COMPAT envs run reset / step as ONE launch (k_compat_small: both station passes and the tail back to back); the
-    # batch of 5 is kept on the three-launch form, so that every fixture pins both
-    kw["fused_step"] = "off" if n_envs == 5 else "auto"
+    # batch of 5 is kept on the form of large batches (the split step: empties, stream walks one env per lane, slots), the batch of 4 on
+    # one kernel per station with the unit's first lane walking -- every fixture pins all three
+    kw["fused_step"] = "off" if n_envs in (4, 5) else "auto"
+    if n_envs in (4, 5):
+        kw["slot_kernel"] = "wave" if n_envs == 4 else "packed"  # (COMPAT handles: one kernel per station / the split step, whatever the size)
     v = chub.VecChargingHub(n_envs, rng="compat", **kw)
     v.set_telemetry(True)
     S0, S1 = kw["station_list"]
@@ -604,7 +607,10 @@ def test_scalar_load_mode_matches_oracle(piles, rng, cc):
               init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01, constant_charging=cc, renew_fluctuate=0.0,
               price_fluctuate=0.0, hydro_loss=0.0)
     n, seed = (70, 99) if piles == (20, 25) else (9, 99)
-    v = chub.VecChargingHub(n, seed=seed, rng=rng, **kw)
+    # (COMPAT handles have two launch forms, chosen by batch size: the constant-power run takes the split step of large batches, the other one
+    # kernel per station)
+    form = ("packed" if cc else "wave") if rng == "compat" and piles == (20, 25) else "auto"
+    v = chub.VecChargingHub(n, seed=seed, rng=rng, slot_kernel=form, **kw)
     v.set_telemetry(True)
     cfg = orclib.make_config(piles=kw["station_list"], types=kw["station_type_list"], constant_charging=cc,
                              hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
