@@ -54,9 +54,6 @@ constexpr int kBigBlock = CHUB_BIG_BLOCK, kBigSlotsPerLane = CHUB_BIG_SLOTS_PER_
 constexpr int64_t kBigTileSlots = (int64_t) 10 << 20;  // handles of at least this many charger slots take the second tile (chub_options.tile overrides)
 constexpr int kClsRow = 32;        // PHILOX: entries (power, t_soc) per arrival-SoC class = car_steps a car can take (stay_time <= 27 here)
 constexpr int kTelemCount = 38;
-constexpr int64_t kCompatSplitEnvs = 8192;  // COMPAT handles of at least this many envs run the split step.  Measured, us per step, split vs one kernel per
-                                            // station: 60.2 vs 51.8 at 2048 envs, 64.5 vs 55.6 at 4096, 68.3 vs 70.2 at 8192, 74.8 vs 103.5 at 16 384,
-                                            // 91.7 vs 162.9 at 32 768, 124 vs 279 at 65 536 ([20, 25] hub)
 constexpr int kFusedMaxBlocks = 384;   // PHILOX lock-step steps of at most this many slot workgroups run as ONE launch (k_step_fused).  Measured, us per step
                                        // as graph replays, one launch vs two: 8.08 vs 8.82 at 128 workgroups (C2), 8.50 vs 9.30 at 256, 9.42 vs 9.79 at 373,
                                        // 10.79 vs 10.61 at 745, 11.71 vs 11.38 at 1024, 17.9 vs 13.1 at 1490
@@ -105,7 +102,8 @@ struct StationArrays {       // unit index u = k*N + env
     CHUB_G(float) tail_act;      // [N][2] PHILOX: the env's two tail actions (electrolyser, fuel cell), copied by the packed slot kernel
                                  // out of the action row it has just read: the tail kernel reads 8 contiguous bytes per env
                                  // instead of one 128-byte line per env of the [N, S+2] action matrix
-    CHUB_G(uint8_t) empt;        // COMPAT, split step [2N]: the unit's empty slots once this step's departures are out (k_compat_empties)
+    CHUB_G(uint8_t) empt;        // COMPAT, split step [2N]: the unit's empty slots once the NEXT step's departures are out: slots with at most one slot
+                                 // of stay left (k_slot_split at its end, or k_compat_empties)
     CHUB_G(uint32_t) fa;         // COMPAT, split step [2N]: what the unit's walk came to: flow_in (16 bits, signed) | cars admitted << 16 | queue << 24
     CHUB_G(uint32_t) pk[2];      // PHILOX, double-buffered by tick parity: what a unit's station-level draws of a step come to,
                                  // decoded one launch ahead against the queue the previous step left (dk_make): bits 0-7 queue after
@@ -255,6 +253,10 @@ struct StepArgs {
     // kernel, the tail draws inline) and leaves none for the next -- same Philox counters, same values; used whenever the
     // previous launch was not the previous step of every env it serves (per-env clocks, the first lock-step launch after them).
     int32_t fresh;
+    // COMPAT, split step: the units' empty-slot counts (StationArrays::empt) are normally left by the previous split pass (k_slot_split
+    // knows every slot's remaining stay when it ends); empt_fresh: this launch counts them itself first (k_compat_empties) -- after
+    // create, chub_set_state, a pass in another launch form, and inside graph captures
+    int32_t empt_fresh;
 };
 
 }  // namespace chub

@@ -93,31 +93,47 @@ struct PhiloxCtx {
 };
 
 // ------------------------------------------------------------- reference streams (COMPAT), one lane
-struct CompatStream {
-    uint32_t *g;  // 32 words: ring[31] + front index
+// The ring lives in global memory (RingGlobal: every kernel but the split step's walk) or, for the walk of the split step, parked in LDS
+// (RingLds: word w of the workgroup's lane l at s[w * 256 + l] -- a draw is then two LDS reads instead of two dependent global round trips)
+struct RingGlobal {
+    uint32_t *g;
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return g[i]; }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { g[i] = v; }
+};
+struct RingLds {
+    uint32_t *s;
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return s[i * 256u]; }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { s[i * 256u] = v; }
+};
+template <typename Ring>
+struct CompatStreamT {
+    Ring r;  // 32 words: ring[31] + front index
     uint32_t gf, gr, x;
-    __device__ void load(const CompatRng &cr, int64_t env) {
-        g = cr.g + env * 32;
-        gf = g[31];
+    __device__ void load(const CompatRng &cr, int64_t env) {  // (RingGlobal)
+        r.g = cr.g + env * 32;
+        gf = r.get(31);
         gr = (gf + 28u) % 31u;
         x = cr.minstd[env];
     }
     __device__ void store(const CompatRng &cr, int64_t env) {
-        g[31] = gf;
+        r.set(31, gf);
         cr.minstd[env] = x;
     }
     // glibc random_r TYPE_3: *f += *r; result = *f >> 1  (rand(), CHS.hpp:41)
     __device__ uint32_t rand31() {
-        uint32_t v = g[gf] + g[gr];
-        g[gf] = v;
+        uint32_t v = r.get(gf) + r.get(gr);
+        r.set(gf, v);
         gf = (gf + 1u == 31u) ? 0u : gf + 1u;
         gr = (gr + 1u == 31u) ? 0u : gr + 1u;
         return v >> 1;
     }
     __device__ int level() { return (int) (rand31() % 1000u); }
-    // std::minstd_rand0 (CHS.hpp:25)
+    // std::minstd_rand0 (CHS.hpp:25): x * 16807 mod (2^31 - 1).  2^31 = 1 (mod 2^31 - 1), so the 46-bit product folds as low 31 bits +
+    // the rest, minus the modulus once if need be: the same residue as the 64-bit modulo (x is never 0: the modulus is prime)
     __device__ uint32_t minstd() {
-        x = (uint32_t) (((uint64_t) x * 16807ull) % 2147483647ull);
+        const uint64_t p = (uint64_t) x * 16807ull;
+        uint32_t v = (uint32_t) (p & 0x7FFFFFFFull) + (uint32_t) (p >> 31);
+        x = v >= 2147483647u ? v - 2147483647u : v;
         return x;
     }
     // libstdc++ generate_canonical<double,53>: two draws
@@ -159,6 +175,7 @@ struct CompatStream {
         return __fadd_rn(__fmul_rn(__fmul_rn(y_, mult), sd), mean);
     }
 };
+typedef CompatStreamT<RingGlobal> CompatStream;
 
 // ------------------------------------------------------------------------------- small arithmetic
 // RandomUtil::uniform_rand(a, b) at level k (CHS.hpp:35-44): two f32 roundings after the division
@@ -649,11 +666,25 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     // (CHS.hpp:1244-1255): same order, same roundings
     const bool urgent = car && must_charge(t_target, t_soc, tl);
     const float v_min = urgent ? power : 0.0f, v_max = car ? power : 0.0f, v_chg = charge ? power : 0.0f;
+    // every lane parks its three terms in the wave's own scratch area and the unit's first lane -- the only one that needs the sums --
+    // adds them up in slot order (each lane fetching its S neighbours' terms by cross-lane reads cost 3 S of those per wave)
     float r_min = 0.0f, r_max = 0.0f, r_chg = 0.0f;
-    for (int i = 0; i < S; i++) {
-        r_max = __fadd_rn(r_max, __shfl(v_max, leader + i));
-        r_min = __fadd_rn(r_min, __shfl(v_min, leader + i));
-        r_chg = __fadd_rn(r_chg, __shfl(v_chg, leader + i));
+    {
+        __builtin_amdgcn_wave_barrier();  // (the admitted lanes' reads of the walk's variates above are done)
+        float *t_max = lds_f + wave * 64, *t_min = (float *) lds_u + wave * 64, *t_chg = (float *) lds_u + BLOCK + wave * 64;
+        t_max[lane] = v_max;
+        t_min[lane] = v_min;
+        t_chg[lane] = v_chg;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (unit_ok && slot == 0) {
+            for (int i = 0; i < S; i++) {
+                r_max = __fadd_rn(r_max, t_max[leader + i]);
+                r_min = __fadd_rn(r_min, t_min[leader + i]);
+                r_chg = __fadd_rn(r_chg, t_chg[leader + i]);
+            }
+        }
     }
     const int cars = __popcll(__ballot(car) & unit_mask);
 
@@ -669,6 +700,10 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     }
     if (unit_ok && slot == 0) {
         rec_store(st.rec, sidx, r_min, r_chg, r_max, pkd_make(line, flow, cars));
+    }
+    if (SPLIT) {  // what the next step's walk needs of the slots: a slot is empty after remove_car iff it has at most one slot of stay left
+        const int n_empty = __popcll(__ballot(valid && tl <= 1) & unit_mask);
+        if (unit_ok && slot == 0) st.empt[sidx] = (uint8_t) n_empty;
     }
 }
 
@@ -1634,8 +1669,9 @@ __global__ __launch_bounds__(BLOCK, 7) void k_slot(const DevCtx *__restrict__ ct
 // One kernel per station with the unit's first lane walking the env's streams keeps 2 of a wave's 64 lanes busy through the longest
 // part of the step (every polar normal of the reference's std::normal_distribution costs a lane about a microsecond): 250 of the
 // 279 us of a step at 65 536 envs.  Large batches therefore run
-//   k_compat_empties  lane = slot: how many slots of each unit are empty once this step's departures are out (a slot is empty after
-//                     remove_car iff it had at most one slot of stay left, CHS.hpp:912-923 / 1077-1088) -- all the walk needs of the slots
+//   (k_compat_empties lane = slot: how many slots of each unit are empty once this step's departures are out -- a slot is empty after
+//                     remove_car iff it had at most one slot of stay left, CHS.hpp:912-923 / 1077-1088 -- all the walk needs of the slots;
+//                     only where the previous pass was not a split one: k_slot_split leaves the counts for the next step itself)
 //   k_compat_walk     lane = ENV, 64 walks per wave: station 0's draws, then station 1's, in the reference's consumption order
 //                     (receive_car, CHS.hpp:1272-1316 / 1583-1627; the forecourt's follow in the tail kernel as before), leaving per
 //                     unit flow / cars admitted / queue and per admitted car its three variates
@@ -1668,52 +1704,83 @@ __global__ __launch_bounds__(256) void k_compat_walk(const DevCtx *__restrict__ 
     const Tables &tb = ctx->tb;
     const StationArrays &st = ctx->st;
     const int64_t N = hp.n_envs;
-    const int env = (int) (blockIdx.x * 256u + threadIdx.x);
-    if (env >= (int) N || !in_group(sa, env)) return;
-    CompatStream rs;
-    rs.load(ctx->cr, env);
-    const uint32_t St = (uint32_t) (hp.S[0] + hp.S[1]);
-    for (int k = 0; k < 2; k++) {
-        const int S = hp.S[k];
-        const bool fast = hp.type[k] == 0;
-        const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
-        const int line = RESET ? 0 : pkd_line(st.rec[4u * sidx + 3u]);
-        const int empties = RESET ? S : (int) st.empt[sidx];
-        const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
-        int n_in;
-        if (RESET) {
-            const float cn = rs.normal_f((float) mu, 1.0f);
-            int temp = (int) roundf(cn);
-            temp = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
-            n_in = temp;
-        } else {
-            const int t_env = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;  // per-env clocks: the env's own slot of day
-            n_in = (int) tb.cnt[k][t_env * kLevels + rs.level()];
+    // the glibc rings of the workgroup's 256 envs (32 KB, one contiguous run of memory) are parked in LDS for the walk: transposed, so that
+    // the lanes of a wave hit different banks when each reads a word of its own ring
+    __shared__ uint32_t s_ring[32 * 256];
+    const uint32_t env0 = blockIdx.x * 256u;
+    const uint32_t n_here = (uint32_t) N - env0 < 256u ? (uint32_t) N - env0 : 256u;
+    {
+        const u32x4 *src = (const u32x4 *) (ctx->cr.g + (size_t) env0 * 32u);
+        for (uint32_t j = threadIdx.x; j < n_here * 8u; j += 256u) {
+            const u32x4 q = src[j];
+            const uint32_t l = j >> 3, w = (j & 7u) << 2;
+            s_ring[(w + 0u) * 256u + l] = q.x;
+            s_ring[(w + 1u) * 256u + l] = q.y;
+            s_ring[(w + 2u) * 256u + l] = q.z;
+            s_ring[(w + 3u) * 256u + l] = q.w;
         }
-        int tline = 0;
-        for (int w = 0; w < line; w++) tline += (rs.level() >= (int) tb.thr_renege[w]) ? 1 : 0;
-        int new_line = tline;
-        int true_in = 0;
-        for (int j = 0; j < n_in; j++) {
-            const int m = new_line + j;
-            const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
-            true_in += (rs.level() <= thr && j <= S) ? 1 : 0;
-        }
-        const int fl = fast ? n_in : true_in;
-        const int as = (new_line + fl) < empties ? (new_line + fl) : empties;
-        new_line = new_line + fl - as;
-        new_line = new_line < kMaxLine ? new_line : kMaxLine;
-        CHUB_G(u32x2) var = (CHUB_G(u32x2)) ctx->sl.var + ((uint32_t) env * St + (uint32_t) (k ? hp.S[0] : 0));
-        for (int rr = 0; rr < as; rr++) {  // ascending slot order == ascending rank
-            const float soc = arrive_soc_from(rs.normal_d(7.0, 3.0));
-            const uint32_t lev = (uint32_t) rs.level();
-            int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
-            late = late < 0 ? 0 : late;
-            var[rr] = u32x2{__float_as_uint(soc), lev | ((uint32_t) late << 16)};
-        }
-        st.fa[sidx] = ((uint32_t) fl & 0xFFFFu) | ((uint32_t) (as > 0 ? as : 0) << 16) | ((uint32_t) new_line << 24);
     }
-    rs.store(ctx->cr, env);
+    __syncthreads();
+    // (64 walks per wave: fewer -- 32 or 16 envs per wave, more waves -- measured slower: 115 / 129 vs 110 us per step at 65 536 envs)
+    const int env = (int) (env0 + threadIdx.x);
+    if (env < (int) N && in_group(sa, env)) {
+        CompatStreamT<RingLds> rs;
+        rs.r.s = s_ring + threadIdx.x;
+        rs.gf = rs.r.get(31);
+        rs.gr = (rs.gf + 28u) % 31u;
+        rs.x = ctx->cr.minstd[env];
+        const uint32_t St = (uint32_t) (hp.S[0] + hp.S[1]);
+        for (int k = 0; k < 2; k++) {
+            const int S = hp.S[k];
+            const bool fast = hp.type[k] == 0;
+            const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
+            const int line = RESET ? 0 : pkd_line(st.rec[4u * sidx + 3u]);
+            const int empties = RESET ? S : (int) st.empt[sidx];
+            const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
+            int n_in;
+            if (RESET) {
+                const float cn = rs.normal_f((float) mu, 1.0f);
+                int temp = (int) roundf(cn);
+                temp = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
+                n_in = temp;
+            } else {
+                const int t_env = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;  // per-env clocks: the env's own slot of day
+                n_in = (int) tb.cnt[k][t_env * kLevels + rs.level()];
+            }
+            int tline = 0;
+            for (int w = 0; w < line; w++) tline += (rs.level() >= (int) tb.thr_renege[w]) ? 1 : 0;
+            int new_line = tline;
+            int true_in = 0;
+            for (int j = 0; j < n_in; j++) {
+                const int m = new_line + j;
+                const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
+                true_in += (rs.level() <= thr && j <= S) ? 1 : 0;
+            }
+            const int fl = fast ? n_in : true_in;
+            const int as = (new_line + fl) < empties ? (new_line + fl) : empties;
+            new_line = new_line + fl - as;
+            new_line = new_line < kMaxLine ? new_line : kMaxLine;
+            CHUB_G(u32x2) var = (CHUB_G(u32x2)) ctx->sl.var + ((uint32_t) env * St + (uint32_t) (k ? hp.S[0] : 0));
+            for (int rr = 0; rr < as; rr++) {  // ascending slot order == ascending rank
+                const float soc = arrive_soc_from(rs.normal_d(7.0, 3.0));
+                const uint32_t lev = (uint32_t) rs.level();
+                int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
+                late = late < 0 ? 0 : late;
+                var[rr] = u32x2{__float_as_uint(soc), lev | ((uint32_t) late << 16)};
+            }
+            st.fa[sidx] = ((uint32_t) fl & 0xFFFFu) | ((uint32_t) (as > 0 ? as : 0) << 16) | ((uint32_t) new_line << 24);
+        }
+        rs.r.set(31, rs.gf);
+        ctx->cr.minstd[env] = rs.x;
+    }
+    __syncthreads();
+    {
+        u32x4 *dst = (u32x4 *) (ctx->cr.g + (size_t) env0 * 32u);
+        for (uint32_t j = threadIdx.x; j < n_here * 8u; j += 256u) {
+            const uint32_t l = j >> 3, w = (j & 7u) << 2;
+            dst[j] = u32x4{s_ring[(w + 0u) * 256u + l], s_ring[(w + 1u) * 256u + l], s_ring[(w + 2u) * 256u + l], s_ring[(w + 3u) * 256u + l]};
+        }
+    }
 }
 
 template <bool RESET, int BLOCK>
@@ -2841,8 +2908,13 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
         CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, ev1, ctx, sa, nb0);
     } else if (MODE == MODE_COMPAT && !big && hp.compat_split) {
         // the split step: empties -> the stream walks, one env per lane -> the slots of both stations in one launch
-        if (!RESET) CHUB_LAUNCH((k_compat_empties<BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, (hipEvent_t) nullptr, ctx, sa, nb0);
-        CHUB_LAUNCH((k_compat_walk<RESET>), dim3((unsigned) ((hp.n_envs + 255) / 256)), dim3(256), stream, RESET ? ev0 : (hipEvent_t) nullptr, (hipEvent_t) nullptr, ctx, sa);
+        const bool count_first = !RESET && sa.empt_fresh;
+        if (count_first) {  // of every unit, whatever envs the call names: the counts are then good for whoever is stepped next
+            StepArgs all = sa;
+            all.env_mask = nullptr;
+            CHUB_LAUNCH((k_compat_empties<BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, (hipEvent_t) nullptr, ctx, all, nb0);
+        }
+        CHUB_LAUNCH((k_compat_walk<RESET>), dim3((unsigned) ((hp.n_envs + 255) / 256)), dim3(256), stream, count_first ? (hipEvent_t) nullptr : ev0, (hipEvent_t) nullptr, ctx, sa);
         CHUB_LAUNCH((k_slot_split<RESET, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, (hipEvent_t) nullptr, ev1, ctx, sa, nb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1

@@ -62,6 +62,7 @@ struct chub_env {
     int device;
     bool fused;         // PHILOX lock-step steps of this handle run as ONE launch (k_step_fused): small batches
     bool compat_small;  // COMPAT: every env fits one workgroup for both stations: lock-step resets and steps are ONE launch (k_compat_small)
+    bool empt_valid;    // COMPAT, split step: StationArrays::empt holds every unit's empty-slot count for the next step (left by the last split pass)
     DevCtx *d_ctx;      // device copy of {hp, sl, st, ev, cr, tb}
     bool ctx_dirty;
     // lock-step clock (MGR:137-140,299; CHS.hpp:1204; AGG:150-151; HYD:192-193 are three copies of it)
@@ -412,6 +413,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->h_bits = e->d_bits = nullptr;
     e->h_tail = e->d_tail = nullptr;
     e->h_telem = nullptr;
+    e->empt_valid = false;
     e->prof_used = e->prof_cap = 0;
     e->prof_on = false;
     e->arena = nullptr;
@@ -715,10 +717,10 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     {   // the reference-exact mode at a handful of envs (the drop-in class: one): both station passes and the tail in one launch
         const int64_t fit = std::min<int64_t>((kSlotBlock / 64) * (64 / hp.H[0]), (kSlotBlock / 64) * (64 / hp.H[1]));
         e->compat_small = rng_mode == CHUB_RNG_COMPAT && opt.fused_step != 1 && hp.S[0] <= 64 && hp.S[1] <= 64 && n_envs <= fit;
-        // ... and large batches as the split step (empties -> stream walks, one env per lane -> slots); below kCompatSplitEnvs one kernel per
-        // station with the unit's first lane walking is the shorter chain (slot_kernel = 1 / 2 force either form: the parity cross-check)
-        hp.compat_split = (rng_mode == CHUB_RNG_COMPAT && hp.S[0] <= 64 && hp.S[1] <= 64 &&
-                           (opt.slot_kernel == 2 || (opt.slot_kernel == 0 && n_envs >= kCompatSplitEnvs))) ? 1 : 0;
+        // ... and everything else as the split step (stream walks, one env per lane -> slots of both stations in one launch) unless
+        // slot_kernel = 1 asks for one kernel per station with the unit's first lane walking (the parity cross-check).  Measured, us per
+        // step, split vs per station: 47.1 vs 51.1 at 1024 envs, 49.7 vs 50.9 at 4096, 54 vs 70 at 8192, 100 vs 279 at 65 536 ([20, 25] hub)
+        hp.compat_split = (rng_mode == CHUB_RNG_COMPAT && hp.S[0] <= 64 && hp.S[1] <= 64 && opt.slot_kernel != 1) ? 1 : 0;
     }
     build_hy_table(hp, e->hy_table);
     std::vector<double> hy_v(e->hy_table, e->hy_table + 102);
@@ -990,9 +992,12 @@ static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const d
     if (rc_) return rc_;
     if (e->compat_small && !e->per_env) {
         launch_compat_small(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e));
+        e->empt_valid = false;
     } else {
         launch_slot(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e), nullptr, nullptr);
         launch_env(true, e->hp, e->d_ctx, sa, s, nullptr, nullptr, packed_ptrs(e));
+        // (a split reset leaves the counts of the units it served; those of the others are as good as they were)
+        e->empt_valid = e->hp.compat_split != 0 && (served == 2 || e->empt_valid) && !e->capturing;
     }
     HIP_TRY(hipGetLastError());
     e->predrawn = served == 2;  // the launch's level blocks left the next step's draws of every env it served
@@ -1145,7 +1150,9 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     }
     // four events per profiled step: start / stop of the slot kernel, start / stop of the tail kernel
     hipEvent_t *pe = prof ? &e->prof_events[4 * e->prof_used] : nullptr;
+    sa.empt_fresh = (e->hp.compat_split && (!e->empt_valid || e->capturing)) ? 1 : 0;
     if (e->compat_small && !load_mode && !e->per_env) {
+        e->empt_valid = false;
         launch_compat_small(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e));
         if (prof) {  // one kernel, no dispatch timestamps: the sample spans nothing
             for (int i = 0; i < 4; i++) HIP_TRY(hipEventRecord(pe[i], s));
@@ -1159,6 +1166,7 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     } else {
         launch_slot(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e), prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
         launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
+        e->empt_valid = e->hp.compat_split != 0 && !e->capturing;  // (counted for every unit in front of the walk, or good already; the pass left the served units')
     }
     if (prof) e->prof_used++;
     HIP_TRY(hipGetLastError());
@@ -2159,6 +2167,7 @@ int chub_compat_replay_constructor(chub_env *e) {
     sa.station_filter = -1;
     sa.env_hi = (int32_t) (e->hp.n_envs - 1);
     launch_slot(true, e->hp, e->d_ctx, sa, nullptr, packed_ptrs(e), nullptr, nullptr);
+    e->empt_valid = e->hp.compat_split != 0;
     // (2) HySystem.__init__: 101 hy_step()s with live FCEV arrivals (HYD:154-157,168,250-259) -> the streams advance and
     //     every env gets the hy_power_speed_list the reference would have built from its draws
     launch_compat_ctor_sweep(e->hp, e->d_ctx, nullptr);
@@ -2239,6 +2248,7 @@ int chub_set_state(chub_env *e, const void *buf, int64_t size) {
     // device pointers inside the arena are position-dependent: restore only into the handle's own layout, which the
     // checks above guarantee is the same; the DevCtx block (pointers, flags) is rewritten from the host copy
     HIP_TRY(hipMemcpy(e->arena, (const char *) buf + sizeof h, e->arena_used, hipMemcpyHostToDevice));
+    e->empt_valid = false;  // (the restored slot state has not been counted)
     e->t = h.t;
     e->price_count = h.price_count;
     e->tick = h.tick;

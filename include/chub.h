@@ -70,9 +70,9 @@ typedef struct chub_env chub_env;
 typedef struct chub_options {
     int32_t slot_kernel;  /* PHILOX steps: 0 = the packed slot kernel wherever the hub shape allows (default),
                              1 = the wave-local slot kernel for every step, 2 = same as 0 (kept for tests that name it).
-                             COMPAT resets / steps: 0 = by batch size: from 8192 envs the split form (empties, then the stream walks one ENV
-                             per lane, then the slots of both stations in one launch), below one kernel per station with the unit's first
-                             lane walking; 1 = always the latter, 2 = always the former (bit-identical) */
+                             COMPAT resets / steps of handles beyond a handful of envs: 0 / 2 = the split form (the stream walks one ENV per
+                             lane, then the slots of both stations in one launch, which also leaves the next step's count of empty slots),
+                             1 = one kernel per station with the unit's first lane walking (bit-identical; the parity cross-check) */
     int32_t no_arena;     /* 1: one hipMalloc per array instead of one arena (disables chub_get_state / chub_set_state) */
     int32_t fused_step;   /* PHILOX lock-step steps as ONE launch (slot work + per-env tail + next step's draws per workgroup):
                              0 = for small batches, where the two step kernels are launch-bound (default), 1 = never, 2 = always

@@ -1267,3 +1267,66 @@ def test_copy_outputs_false_returns_the_pinned_arrays():
         assert ob is first                                 # the same array object every step
     a_.close()
     b_.close()
+
+
+def test_compat_split_step_is_bit_identical_through_restores_and_masked_calls():
+    """COMPAT handles have two launch forms for what k_compat_small does not take: one kernel per station with the unit's first lane walking
+    the env's streams, and (large batches) the split step -- the walks one ENV per lane between a count of the units' empty slots and one
+    slot pass over both stations, the pass leaving the next step's counts.  Same program of calls on both (forced by chub_options.slot_kernel):
+    whole-batch resets and steps, a snapshot restored into a FRESH handle (its counts have to be made again), steps and a reset of a
+    subset of the envs (per-env clocks), scalar-load steps -- observations, rewards, slot state, station records and the streams
+    themselves bit for bit."""
+    chub = hub()
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.02)
+    n = 300
+    out = {}
+    for form in ("wave", "packed"):
+        rs = np.random.RandomState(12)
+        v = chub.VecChargingHub(n, rng="compat", slot_kernel=form, **kw)
+        v.set_compat_seeds(np.stack([rs.randint(1, 2**31 - 1, n), rs.randint(1, 2**31 - 1, n)], axis=1).astype(np.uint32))
+        v.compat_replay_constructor()
+        trace = []
+
+        def note(obs, rew=None):
+            trace.append(np.array(obs))
+            if rew is not None:
+                trace.append(np.array(rew))
+
+        days = lambda: np.stack([rs.randint(0, 100, n), rs.randint(0, 150, n)], axis=1).astype(np.int32)
+        act = lambda: rs.uniform(-1, 1, size=(n, v.act_dim)).astype(np.float32)
+        note(v.reset(days(), rs.normal(size=(n, 3))))
+        for t in range(30):
+            o, r, d, _ = v.step(act(), rs.normal(size=(n, 3)))
+            note(o, r)
+        snap = v.get_state()
+        v.close()
+        v = chub.VecChargingHub(n, rng="compat", slot_kernel=form, **kw)
+        v.set_state(snap)
+        for t in range(10):
+            o, r, d, _ = v.step(act(), rs.normal(size=(n, 3)))
+            note(o, r)
+        mask = (rs.uniform(size=n) < 0.4).astype(np.uint8)
+        for t in range(5):
+            o, r, d = v.step_envs(mask, act(), rs.normal(size=(n, 3)))[:3]
+            note(np.asarray(o)[mask != 0], np.asarray(r)[mask != 0])
+        other = (rs.uniform(size=n) < 0.3).astype(np.uint8)
+        note(np.asarray(v.reset_envs(other, days(), rs.normal(size=(n, 3))))[other != 0])
+        for t in range(5):
+            o, r, d = v.step_envs(1 - mask, act(), rs.normal(size=(n, 3)))[:3]
+            note(np.asarray(o)[mask == 0], np.asarray(r)[mask == 0])
+        sc = v.station_scalars()
+        for t in range(4):
+            loads = np.stack([rs.uniform(0, 1.2, n) * (sc[:, 0, 2] + 1.0), rs.uniform(0, 1.2, n) * (sc[:, 1, 2] + 1.0)], axis=1).astype(np.float32)
+            o, r, d = v.step_load_envs(np.ones(n, dtype=np.uint8), loads, rs.uniform(-1, 1, size=(n, 2)).astype(np.float32), rs.normal(size=(n, 3)))[:3]
+            note(o, r)
+        note(v.reset(days(), rs.normal(size=(n, 3))))
+        for t in range(6):
+            o, r, d, _ = v.step(act(), rs.normal(size=(n, 3)))
+            note(o, r)
+        trace += [np.concatenate([x.reshape(n, -1) for x in v.slots()], axis=1), v.station_scalars().reshape(n, -1), v.compat_state()]
+        out[form] = trace
+        v.close()
+    assert len(out["wave"]) == len(out["packed"])
+    for k, (a, b) in enumerate(zip(out["wave"], out["packed"])):
+        assert np.array_equal(a, b, equal_nan=True), k
