@@ -47,8 +47,9 @@ def _ptr(a):
 class VecChargingHub(object):
     def __init__(self, n_envs, station_list, station_type_list, seed=0, rng="philox", device=0, env_id0=0,
                  data_dir=None, slot_kernel="auto", no_arena=False, copy_outputs=True, fused_step="auto", tile="auto", **kwargs):
-        """slot_kernel: "auto" (the packed slot kernel wherever the hub shape allows), "wave" (the wave-local one for
-        every step) or "packed"; no_arena: one device allocation per array (no snapshots) -- chub_options.
+        """slot_kernel: PHILOX handles: "auto" (the packed slot kernel wherever the hub shape allows), "wave" (the wave-local one for
+        every step) or "packed"; COMPAT handles: "auto" / "packed" the split step (stream walks one env per lane, one slot pass over both
+        stations), "wave" one kernel per station (bit-identical); no_arena: one device allocation per array (no snapshots) -- chub_options.
         copy_outputs=False: reset() / step() return the handle's own pinned arrays (valid until the next call) instead of
         fresh copies -- at 65 536 envs the copies are a third of a host-pointer step."""
         kwargs.pop("seed_rand", None)
