@@ -34,7 +34,7 @@ with contextlib.redirect_stdout(io.StringIO()):
     from evcssp_env_cpp.envs.evcssp_manager import EvcsspManagerEnv_v6  # noqa: E402
 import orclib  # noqa: E402
 
-GOLD = os.path.join(ROOT, "tests", "golden")
+GOLD = os.environ.get("CHUB_GOLD_OUT", os.path.join(ROOT, "tests", "golden"))  # (a scratch directory: compare before replacing fixtures)
 
 TELEM = ["hy_act", "hy_flow_speed", "all_power_second", "Store_SOC", "capacity", "total_mass_need", "hy_use",
          "not_meet", "fc_power", "hy_to_use", "re_used_renew", "ev0", "ev1", "re_hydrogen_power", "income",
@@ -260,6 +260,20 @@ def main():
     # stations of more than 64 piles (the reference takes any size, CHS:1148, 1458): 100 fast + 70 slow, a big electrolyser
     run("env_big_100_70", base_kwargs(station_list=[100, 70], hydro_prod_rate=2000, hydro_store_vlt=5000, init_soc=0.5,
                                       fcev_permeate=0.02), 2, 60, "random", (2121, 2222), py_seed=11)
+    # ---- round 4, second batch (appended: the fixtures above come out as before) ----
+    # both stations of the same kind (two slow stations; two fast ones with fluctuating exogenous series and tank loss)
+    run("env_slow_slow", base_kwargs(station_list=[10, 12], station_type_list=["slow", "slow"]), 1, 96, "random", (2323, 2424), py_seed=12)
+    run("env_fast_fast", base_kwargs(station_list=[8, 6], station_type_list=["fast", "fast"], renew_fluctuate=0.2, price_fluctuate=0.2,
+                                     hydro_loss=0.01), 2, 60, "random", (2525, 2626), py_seed=13)
+    # no electrolyser at all (Electrolyser.cell_number == 0, HYD:39-40): the tank only drains
+    run("env_no_electrolyser", base_kwargs(hydro_prod_rate=0, init_soc=0.8, fcev_permeate=0.03), 1, 96, "random", (2727, 2828), py_seed=14)
+    # a permeability above 1 falls back to 0.01 in the arrival lookup (CHS:765-775)
+    run("env_permeate_cap", base_kwargs(fcev_permeate=1.5), 1, 48, "random", (2929, 3030), py_seed=15)
+    # one pile per station
+    run("env_one_pile", base_kwargs(station_list=[1, 1]), 2, 96, "random", (3131, 3232), py_seed=16)
+    # constant-power fleet, slow / fast order swapped, fluctuating renewables
+    run("env_constant_swapped", base_kwargs(station_list=[7, 9], station_type_list=["slow", "fast"], constant_charging=True,
+                                            renew_fluctuate=0.1), 1, 96, "random", (3333, 3434), py_seed=17)
 
 
 if __name__ == "__main__":

@@ -275,7 +275,10 @@ def golden_config(g):
 
 GOLDEN_ENV = ["env_c1_envtest", "env_c3_random", "env_c2_random", "env_c5_random", "env_slow_only_fcev",
               "env_clamp", "env_full_tank", "env_constant", "env_fcev_queue", "env_small_fast_neg", "env_fcev_queue_deep",
-              "env_big_100_70"]
+              "env_big_100_70",
+              # round 4, second batch: two stations of the same kind, no electrolyser, a permeability above 1, one pile per station,
+              # constant-power fleet on swapped station kinds
+              "env_slow_slow", "env_fast_fast", "env_no_electrolyser", "env_permeate_cap", "env_one_pile", "env_constant_swapped"]
 
 
 class OrcEnv:

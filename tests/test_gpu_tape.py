@@ -5,7 +5,7 @@ seed.  Tape mode (include/chub.h) feeds the SAME kernel what the reference's str
 queue / arrival / admission decisions, per admitted car its arrival SoC, target SoC and stay -- all derived here from
 the golden fixtures (tests/golden/env_*.npz, recorded from the unmodified reference): the per-slot state the kernel then
 produces must be the reference's bit for bit, the station counts exactly, and the station power sums (computed through
-the production 2^-19 kW integer path) within 1e-5 relative (+ 1e-6 kW) of the reference's sequential f32 sums.  All 12 fixtures;
+the production 2^-19 kW integer path) within 1e-5 relative (+ 1e-6 kW) of the reference's sequential f32 sums.  All 18 fixtures;
 the resets run the same way (chub_reset_tape: evs_reset through k_slot_packed<.., RESET, ..>).
 """
 import numpy as np
@@ -65,7 +65,9 @@ def _pk_word(n, prev_slots, cur_slots, line_before, line_after, flow):
 
 
 ALL_FIXTURES = ["env_c1_envtest", "env_c3_random", "env_c2_random", "env_c5_random", "env_slow_only_fcev", "env_clamp", "env_full_tank",
-                "env_fcev_queue", "env_constant", "env_small_fast_neg", "env_fcev_queue_deep", "env_big_100_70"]
+                "env_fcev_queue", "env_constant", "env_small_fast_neg", "env_fcev_queue_deep", "env_big_100_70",
+                "env_slow_slow", "env_fast_fast", "env_no_electrolyser", "env_permeate_cap", "env_one_pile", "env_constant_swapped"]
+assert sorted(ALL_FIXTURES) == sorted(orclib.GOLDEN_ENV)
 
 
 @pytest.mark.parametrize("name", ["env_c5_random", "env_big_100_70", "env_small_fast_neg"])
