@@ -530,16 +530,26 @@ def test_dropin_class_reproduces_env_test():
     env.close()
 
 
-def test_dropin_class_reproduces_c3_random():
-    """the drop-in class on the C3 / C4 hub under the recorded random actions, two episodes back to back (the second without
-    re-seeding, as recorded): observations, rewards and every reference attribute, step by step.  The reference's two C++ streams
-    are process globals seeded by the fixture's generator in front of the constructor and of the first reset(); the drop-in class
-    takes the same seeds for this env's own streams (compat_seeds, set_compat_seeds)."""
+# the seed the fixture's generator gave Python's and numpy's global generators in front of the constructor (oracle/gen/gen_env_golden.py:
+# main): the drop-in class draws its exogenous variates from them where the reference does
+PY_SEEDS = {"env_c3_random": 1, "env_c2_random": 2, "env_c5_random": 3, "env_slow_only_fcev": 4, "env_clamp": 5, "env_full_tank": 6,
+            "env_constant": 7, "env_fcev_queue": 8, "env_small_fast_neg": 9, "env_fcev_queue_deep": 10, "env_big_100_70": 11,
+            "env_slow_slow": 12, "env_fast_fast": 13, "env_no_electrolyser": 14, "env_permeate_cap": 15, "env_one_pile": 16,
+            "env_constant_swapped": 17}
+
+
+@pytest.mark.parametrize("name", sorted(PY_SEEDS))
+def test_dropin_class_reproduces_reference_fixture(name):
+    """the drop-in class under the recorded random actions of EVERY fixture (hub shapes from one pile per station to 100 + 70, stations
+    without piles, swapped and equal station kinds, the constant-power fleet, no electrolyser, stuck forecourts; episodes back to back,
+    re-seeded or not, cut short or not, as recorded): observations, rewards and every reference attribute, step by step.  The
+    reference's two C++ streams are process globals seeded by the fixture's generator in front of the constructor and of the
+    reset()s; the drop-in class takes the same seeds for this env's own streams (compat_seeds, set_compat_seeds)."""
     import random
     chub = hub()
-    g = orclib.load_golden("env_c3_random")
-    random.seed(1)      # py_seed of the fixture (oracle/gen/gen_env_golden.py: main)
-    np.random.seed(1)
+    g = orclib.load_golden(name)
+    random.seed(PY_SEEDS[name])
+    np.random.seed(PY_SEEDS[name])
     kw = kwargs_of(g)
     env = chub.EvcsspManagerEnv_v6(seed_rand=False, use_lagrange=False, compat_seeds=[int(x) for x in g["ctor_seeds"]], **kw)
     steps, i = int(g["steps_per_episode"]), 0
@@ -548,15 +558,15 @@ def test_dropin_class_reproduces_c3_random():
         if ep in seeds:
             env.set_compat_seeds(*seeds[ep])
         o = env.reset()
-        close(o, g["reset_obs"][ep], ("c3 reset obs", ep), rtol=TIGHT, atol=TIGHT)
-        close(env.real_state, g["reset_real_state"][ep], ("c3 reset real_state", ep), rtol=TIGHT, atol=TIGHT)
+        close(o, g["reset_obs"][ep], (name, "reset obs", ep), rtol=TIGHT, atol=TIGHT)
+        close(env.real_state, g["reset_real_state"][ep], (name, "reset real_state", ep), rtol=TIGHT, atol=TIGHT)
         assert [env.cumulated_income, env.cumulated_draw_ele, env.penalty] == list(g["reset_attrs"][ep])
         for t in range(steps):
             s_, r, done, info = env.step(g["action"][i])
-            close(s_, g["obs"][i], ("c3 obs", i), rtol=TIGHT, atol=TIGHT)
-            close(r, g["reward"][i], ("c3 reward", i), rtol=TIGHT, atol=TIGHT)
+            close(s_, g["obs"][i], (name, "obs", i), rtol=TIGHT, atol=TIGHT)
+            close(r, g["reward"][i], (name, "reward", i), rtol=TIGHT, atol=TIGHT)
             assert done == bool(g["done"][i])
-            _check_dropin_attributes(env, g, i, "c3")
+            _check_dropin_attributes(env, g, i, name)
             i += 1
     env.close()
 
