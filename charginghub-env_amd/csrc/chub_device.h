@@ -171,6 +171,7 @@ struct HubParams {
     int32_t type[2];
     int32_t H[2];            // lanes per (env, station) unit: pow2 >= max(1, S_k), <= 64
     int32_t logH[2];
+    int32_t U[2];            // lanes per unit of the COMPAT wave-local kernels: max(1, min(S_k, 64)) -- floor(64 / U) units per wave
     int64_t base[2];         // slot-array offset of station k
     int32_t obs_dim, act_dim;
     int32_t constant_charging;

@@ -452,10 +452,9 @@ __device__ __forceinline__ NewCar make_car(float arrive_soc, int lev, float t_ta
 template <int BLOCK>
 __device__ __forceinline__ bool load_mode_on(const HubParams &hp, const StepArgs &sa, const StationArrays &st, const int k,
                                              const int env, const bool unit_ok, const bool valid, const int slot, const bool car0,
-                                             const float pw0, const float em0, float *lds_f, uint32_t *lds_u) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int S = hp.S[k], logH = hp.logH[k];
-    const int uiw = lane >> logH;
+                                             const float pw0, const float em0, float *lds_f, uint32_t *lds_u, const int ubase) {
+    const int wave = threadIdx.x >> 6;
+    const int S = hp.S[k];
     const uint32_t sidx = (uint32_t) k * (uint32_t) hp.n_envs + (uint32_t) env;
     const bool cp = hp.constant_charging != 0;
     // catch_load (CHS.hpp:358-366): clamp to [min_power, max_power] of the previous calculate_output
@@ -466,8 +465,7 @@ __device__ __forceinline__ bool load_mode_on(const HubParams &hp, const StepArgs
         if (load > pr.mx) load = pr.mx;
         else if (load < pr.mn) load = pr.mn;
     }
-    // std::multimap keyed by -emergency (CHS.hpp:1324-1336): emergency descending, ties by slot index
-    const int ubase = uiw << logH;
+    // std::multimap keyed by -emergency (CHS.hpp:1324-1336): emergency descending, ties by slot index (ubase: the unit's first lane)
     int rk = 0;
     for (int j = 0; j < S; j++) {
         const float ej = __shfl(em0, ubase + j);
@@ -519,17 +517,20 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     constexpr int WAVES = BLOCK / 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int H = hp.H[k], S = hp.S[k], logH = hp.logH[k];
-    const int upw = 64 >> logH;
-    const int uiw = lane >> logH;
-    const int slot = lane & (H - 1);
+    // a unit takes U = S lanes (1 for a station without piles), floor(64 / U) units per wave, the rest of the wave idle: 3 units of 20
+    // piles or 2 of 25 per wave (units of the next power of two left 38 % / 22 % of the lanes idle)
+    const int U = hp.U[k], S = hp.S[k];
+    const int upw = 64 / U;
+    const int uiw = lane / U;
+    const int slot = lane - uiw * U;
     const int64_t N = hp.n_envs;
     // 32-bit indices: n_envs * (piles + 2) < 2^31 is checked at create
     const int env_first = (int) block_local * (WAVES * upw);
     const int env = env_first + wave * upw + uiw;
-    const bool unit_ok = env < (int) N && in_group(sa, env);
+    const bool unit_ok = uiw < upw && env < (int) N && in_group(sa, env);
     const bool valid = unit_ok && slot < S;
-    const uint64_t unit_mask = (H == 64) ? ~0ull : (((1ull << H) - 1ull) << (uiw << logH));
+    const int leader = uiw < upw ? uiw * U : 63;  // the unit's first lane
+    const uint64_t unit_mask = (U == 64) ? ~0ull : (uiw < upw ? (((1ull << U) - 1ull) << leader) : 0ull);
     const uint32_t idx = (uint32_t) hp.base[k] + (uint32_t) env * (uint32_t) S + (uint32_t) slot;
     const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
     const int hub_slot = (k ? hp.S[0] : 0) + slot;
@@ -551,7 +552,7 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     int on_override = -1;
     if (!RESET && sa.load_mode)
         on_override = load_mode_on<BLOCK>(hp, sa, st, k, env, unit_ok, valid, slot, car, power,
-                                          car ? emergency_of(t_target, t_soc, tl) : 0.0f, lds_f, lds_u) ? 1 : 0;
+                                          car ? emergency_of(t_target, t_soc, tl) : 0.0f, lds_f, lds_u, leader) ? 1 : 0;
     // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373); action_to_real (MGR:384-393)
     const bool on = on_override >= 0 ? (car && on_override != 0) : (car && (a >= kActOnThreshold || must_charge(t_target, t_soc, tl)));
     if (on) {  // car_step (CHS.hpp:900-905 / 1065-1070)
@@ -583,7 +584,7 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     // variates in LDS, indexed by admission rank
     float *lds_soc = lds_f;
     uint32_t *lds_lev = lds_u, *lds_late = lds_u + BLOCK;
-    const int lbase = wave * 64 + (uiw << logH);
+    const int lbase = wave * 64 + leader;
     int2 fa = make_int2(0, 0);
     int new_line = line;
     if (SPLIT) {
@@ -627,7 +628,6 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
         rs.store(cr, env);
         fa = make_int2(fl, as);
     }
-    const int leader = uiw << logH;
     const int flow = __shfl(fa.x, leader);
     const int assign = __shfl(fa.y, leader);
     line = __shfl(new_line, leader);
@@ -756,7 +756,7 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     int on_override = -1;
     if (!RESET && sa.load_mode)
         on_override = load_mode_on<BLOCK>(hp, sa, st, k, env, unit_ok, valid, slot, car, power,
-                                          car ? emergency_of(t_target, t_soc, tl) : 0.0f, lds_f, lds_u) ? 1 : 0;
+                                          car ? emergency_of(t_target, t_soc, tl) : 0.0f, lds_f, lds_u, uiw << logH) ? 1 : 0;
     const bool on = on_override >= 0 ? (car && on_override != 0) : (car && (a >= kActOnThreshold || must_charge(t_target, t_soc, tl)));
     const bool step = on && tl > 1;  // a car that leaves this step is wiped right after its car_step (CHS.hpp:1196-1201)
     if (step) {  // car_step (CHS.hpp:900-905 / 1065-1070) = the next entry of the class row
@@ -1685,12 +1685,12 @@ __global__ __launch_bounds__(BLOCK) void k_compat_empties(const DevCtx *__restri
     const int k = (bid >= nb0) ? 1 : 0;
     const int64_t bl = k ? bid - nb0 : bid;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int H = hp.H[k], S = hp.S[k], logH = hp.logH[k];
-    const int upw = 64 >> logH, uiw = lane >> logH, slot = lane & (H - 1);
+    const int U = hp.U[k], S = hp.S[k];  // (the unit layout of slot_body_compat)
+    const int upw = 64 / U, uiw = lane / U, slot = lane - uiw * U;
     const int env = (int) bl * ((BLOCK / 64) * upw) + wave * upw + uiw;
-    const bool unit_ok = env < (int) hp.n_envs && in_group(sa, env);
+    const bool unit_ok = uiw < upw && env < (int) hp.n_envs && in_group(sa, env);
     const bool valid = unit_ok && slot < S;
-    const uint64_t unit_mask = (H == 64) ? ~0ull : (((1ull << H) - 1ull) << (uiw << logH));
+    const uint64_t unit_mask = (U == 64) ? ~0ull : (uiw < upw ? (((1ull << U) - 1ull) << (uiw * U)) : 0ull);
     uint32_t w = 0u;
     if (valid) w = ctx->sl.hot[4u * ((uint32_t) hp.base[k] + (uint32_t) env * (uint32_t) S + (uint32_t) slot) + 3u];
     const bool empty = valid && (int) (w & 127u) <= 1;
@@ -2901,7 +2901,8 @@ template <bool RESET, int MODE>
 static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
                           hipEvent_t ev1) {
     constexpr int BLOCK = 256;
-    const int64_t nb0 = blocks_for(hp.n_envs, hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.H[1], BLOCK);
+    // (COMPAT units take exactly S lanes, the PHILOX wave-local kernel's the next power of two: its sums are DPP butterflies)
+    const int64_t nb0 = blocks_for(hp.n_envs, MODE == MODE_COMPAT ? hp.U[0] : hp.H[0], BLOCK), nb1 = blocks_for(hp.n_envs, MODE == MODE_COMPAT ? hp.U[1] : hp.H[1], BLOCK);
     const bool big = hp.S[0] > 64 || hp.S[1] > 64;  // a unit of more than 64 piles is a workgroup of its own (k_slot_unit)
     if (MODE == MODE_PHILOX && RESET) hipLaunchKernelGGL(k_reset_levels, dim3((unsigned) ((8 * ((int64_t) sa.env_hi - sa.env_lo + 1) + 255) / 256)), dim3(256), 0, stream, ctx, sa);
     if (MODE == MODE_PHILOX && !big) {

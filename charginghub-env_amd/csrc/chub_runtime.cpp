@@ -488,6 +488,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         hp.H[k] = pow2_ge(hp.S[k] > 0 ? (hp.S[k] < 64 ? hp.S[k] : 64) : 1);  // wave-local kernels: units of at most one wave
         hp.logH[k] = 0;
         while ((1 << hp.logH[k]) < hp.H[k]) hp.logH[k]++;
+        hp.U[k] = hp.S[k] > 0 ? (hp.S[k] < 64 ? hp.S[k] : 64) : 1;  // COMPAT wave-local kernels: units of exactly S lanes
         active += hp.S[k] > 0;
         // transformer_limit = constant_power * charge_number in f32 (CHS.hpp:1133-1134, 1443-1444)
         float constant_power = hp.type[k] == CHUB_FAST ? (float) 36.44764034125146 : (float) 5.254973139368931;
@@ -715,7 +716,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
                                                    "stations of at most 64 piles"));
     }
     {   // the reference-exact mode at a handful of envs (the drop-in class: one): both station passes and the tail in one launch
-        const int64_t fit = std::min<int64_t>((kSlotBlock / 64) * (64 / hp.H[0]), (kSlotBlock / 64) * (64 / hp.H[1]));
+        const int64_t fit = std::min<int64_t>((kSlotBlock / 64) * (64 / hp.U[0]), (kSlotBlock / 64) * (64 / hp.U[1]));
         e->compat_small = rng_mode == CHUB_RNG_COMPAT && opt.fused_step != 1 && hp.S[0] <= 64 && hp.S[1] <= 64 && n_envs <= fit;
         // ... and everything else as the split step (stream walks, one env per lane -> slots of both stations in one launch) unless
         // slot_kernel = 1 asks for one kernel per station with the unit's first lane walking (the parity cross-check).  Measured, us per
