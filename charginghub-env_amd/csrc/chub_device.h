@@ -256,7 +256,7 @@ struct StepArgs {
     int32_t fresh;
     // COMPAT, split step: the units' empty-slot counts (StationArrays::empt) are normally left by the previous split pass (k_slot_split
     // knows every slot's remaining stay when it ends); empt_fresh: this launch counts them itself first (k_compat_empties) -- after
-    // create, chub_set_state, a pass in another launch form, and inside graph captures
+    // create, chub_set_state and a pass in another launch form (k_compat_small)
     int32_t empt_fresh;
 };
 

@@ -1692,7 +1692,7 @@ __global__ __launch_bounds__(BLOCK) void k_compat_empties(const DevCtx *__restri
     const bool valid = unit_ok && slot < S;
     const uint64_t unit_mask = (U == 64) ? ~0ull : (uiw < upw ? (((1ull << U) - 1ull) << (uiw * U)) : 0ull);
     uint32_t w = 0u;
-    if (valid) w = ctx->sl.hot[4u * ((uint32_t) hp.base[k] + (uint32_t) env * (uint32_t) S + (uint32_t) slot) + 3u];
+    if (valid) w = ctx->sl.hot[4 * ((size_t) hp.base[k] + (size_t) env * (size_t) S + (size_t) slot) + 3];  // (slot indices go up to 2^31: 64-bit word index)
     const bool empty = valid && (int) (w & 127u) <= 1;
     const uint64_t be = __ballot(empty) & unit_mask;
     if (unit_ok && slot == 0) ctx->st.empt[(uint32_t) k * (uint32_t) hp.n_envs + (uint32_t) env] = (uint8_t) __popcll(be);
