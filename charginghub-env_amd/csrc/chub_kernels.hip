@@ -510,13 +510,18 @@ __device__ __forceinline__ bool load_mode_on(const HubParams &hp, const StepArgs
 // SPLIT (the split step of large batches): the walk was done by k_compat_walk, one ENV per lane (here one lane per UNIT walks while
 // the other lanes of the wave idle); this body then only fetches what it came to -- flow, cars admitted, queue -- and the admitted
 // lanes their car's variates.  Same draws in the same order, same arithmetic: bit-identical.
-template <int TYPE, bool RESET, int BLOCK, bool SPLIT = false>
+// wave0 / mid (k_compat_small): the station's units start at workgroup wave `wave0`, and mid() is called by every lane in front of the
+// first look at what the walk came to (there: the workgroup barrier behind which the walker wave's results are in).
+struct NoSlotMid {
+    __device__ __forceinline__ void operator()() {}
+};
+template <int TYPE, bool RESET, int BLOCK, bool SPLIT = false, typename SlotMid = NoSlotMid>
 __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
                                  const CompatRng &cr, const Tables &tb, const int k, const int64_t block_local,
-                                 float *lds_f, uint32_t *lds_u) {
+                                 float *lds_f, uint32_t *lds_u, const int wave0 = 0, SlotMid mid = SlotMid()) {
     constexpr int WAVES = BLOCK / 64;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave_abs = tid >> 6, wave = wave_abs - wave0;  // wave: among the station's waves (env mapping); wave_abs: the LDS areas
     // a unit takes U = S lanes (1 for a station without piles), floor(64 / U) units per wave, the rest of the wave idle: 3 units of 20
     // piles or 2 of 25 per wave (units of the next power of two left 38 % / 22 % of the lanes idle)
     const int U = hp.U[k], S = hp.S[k];
@@ -584,10 +589,11 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     // variates in LDS, indexed by admission rank
     float *lds_soc = lds_f;
     uint32_t *lds_lev = lds_u, *lds_late = lds_u + BLOCK;
-    const int lbase = wave * 64 + leader;
+    const int lbase = wave_abs * 64 + leader;
     int2 fa = make_int2(0, 0);
     int new_line = line;
     if (SPLIT) {
+        mid();
         if (unit_ok && slot == 0) {
             const uint32_t w = st.fa[sidx];
             fa = make_int2((int) (int16_t) (w & 0xFFFFu), (int) ((w >> 16) & 255u));
@@ -671,7 +677,7 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     float r_min = 0.0f, r_max = 0.0f, r_chg = 0.0f;
     {
         __builtin_amdgcn_wave_barrier();  // (the admitted lanes' reads of the walk's variates above are done)
-        float *t_max = lds_f + wave * 64, *t_min = (float *) lds_u + wave * 64, *t_chg = (float *) lds_u + BLOCK + wave * 64;
+        float *t_max = lds_f + wave_abs * 64, *t_min = (float *) lds_u + wave_abs * 64, *t_chg = (float *) lds_u + BLOCK + wave_abs * 64;
         t_max[lane] = v_max;
         t_min[lane] = v_min;
         t_chg[lane] = v_chg;
@@ -1698,12 +1704,60 @@ __global__ __launch_bounds__(BLOCK) void k_compat_empties(const DevCtx *__restri
     if (unit_ok && slot == 0) ctx->st.empt[(uint32_t) k * (uint32_t) hp.n_envs + (uint32_t) env] = (uint8_t) __popcll(be);
 }
 
-template <bool RESET>
-__global__ __launch_bounds__(256) void k_compat_walk(const DevCtx *__restrict__ ctx, StepArgs sa) {
+// The walk of ONE env: station 0's draws, then station 1's, in the reference's consumption order (receive_car, CHS.hpp:1272-1316 /
+// 1583-1627), leaving per unit flow / cars admitted / queue (StationArrays::fa) and per admitted car its three variates (SlotArrays::var)
+template <bool RESET, typename Stream>
+__device__ __forceinline__ void compat_walk_env(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, Stream &rs) {
     const HubParams &hp = ctx->hp;
     const Tables &tb = ctx->tb;
     const StationArrays &st = ctx->st;
     const int64_t N = hp.n_envs;
+    const uint32_t St = (uint32_t) (hp.S[0] + hp.S[1]);
+    for (int k = 0; k < 2; k++) {
+        const int S = hp.S[k];
+        const bool fast = hp.type[k] == 0;
+        const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
+        const int line = RESET ? 0 : pkd_line(st.rec[4u * sidx + 3u]);
+        const int empties = RESET ? S : (int) st.empt[sidx];
+        const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
+        int n_in;
+        if (RESET) {
+            const float cn = rs.normal_f((float) mu, 1.0f);
+            int temp = (int) roundf(cn);
+            temp = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
+            n_in = temp;
+        } else {
+            const int t_env = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;  // per-env clocks: the env's own slot of day
+            n_in = (int) tb.cnt[k][t_env * kLevels + rs.level()];
+        }
+        int tline = 0;
+        for (int w = 0; w < line; w++) tline += (rs.level() >= (int) tb.thr_renege[w]) ? 1 : 0;
+        int new_line = tline;
+        int true_in = 0;
+        for (int j = 0; j < n_in; j++) {
+            const int m = new_line + j;
+            const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
+            true_in += (rs.level() <= thr && j <= S) ? 1 : 0;
+        }
+        const int fl = fast ? n_in : true_in;
+        const int as = (new_line + fl) < empties ? (new_line + fl) : empties;
+        new_line = new_line + fl - as;
+        new_line = new_line < kMaxLine ? new_line : kMaxLine;
+        CHUB_G(u32x2) var = (CHUB_G(u32x2)) ctx->sl.var + ((uint32_t) env * St + (uint32_t) (k ? hp.S[0] : 0));
+        for (int rr = 0; rr < as; rr++) {  // ascending slot order == ascending rank
+            const float soc = arrive_soc_from(rs.normal_d(7.0, 3.0));
+            const uint32_t lev = (uint32_t) rs.level();
+            int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
+            late = late < 0 ? 0 : late;
+            var[rr] = u32x2{__float_as_uint(soc), lev | ((uint32_t) late << 16)};
+        }
+        st.fa[sidx] = ((uint32_t) fl & 0xFFFFu) | ((uint32_t) (as > 0 ? as : 0) << 16) | ((uint32_t) new_line << 24);
+    }
+}
+
+template <bool RESET>
+__global__ __launch_bounds__(256) void k_compat_walk(const DevCtx *__restrict__ ctx, StepArgs sa) {
+    const int64_t N = ctx->hp.n_envs;
     // the glibc rings of the workgroup's 256 envs (32 KB, one contiguous run of memory) are parked in LDS for the walk: transposed, so that
     // the lanes of a wave hit different banks when each reads a word of its own ring
     __shared__ uint32_t s_ring[32 * 256];
@@ -1729,47 +1783,7 @@ __global__ __launch_bounds__(256) void k_compat_walk(const DevCtx *__restrict__ 
         rs.gf = rs.r.get(31);
         rs.gr = (rs.gf + 28u) % 31u;
         rs.x = ctx->cr.minstd[env];
-        const uint32_t St = (uint32_t) (hp.S[0] + hp.S[1]);
-        for (int k = 0; k < 2; k++) {
-            const int S = hp.S[k];
-            const bool fast = hp.type[k] == 0;
-            const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
-            const int line = RESET ? 0 : pkd_line(st.rec[4u * sidx + 3u]);
-            const int empties = RESET ? S : (int) st.empt[sidx];
-            const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
-            int n_in;
-            if (RESET) {
-                const float cn = rs.normal_f((float) mu, 1.0f);
-                int temp = (int) roundf(cn);
-                temp = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
-                n_in = temp;
-            } else {
-                const int t_env = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;  // per-env clocks: the env's own slot of day
-                n_in = (int) tb.cnt[k][t_env * kLevels + rs.level()];
-            }
-            int tline = 0;
-            for (int w = 0; w < line; w++) tline += (rs.level() >= (int) tb.thr_renege[w]) ? 1 : 0;
-            int new_line = tline;
-            int true_in = 0;
-            for (int j = 0; j < n_in; j++) {
-                const int m = new_line + j;
-                const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
-                true_in += (rs.level() <= thr && j <= S) ? 1 : 0;
-            }
-            const int fl = fast ? n_in : true_in;
-            const int as = (new_line + fl) < empties ? (new_line + fl) : empties;
-            new_line = new_line + fl - as;
-            new_line = new_line < kMaxLine ? new_line : kMaxLine;
-            CHUB_G(u32x2) var = (CHUB_G(u32x2)) ctx->sl.var + ((uint32_t) env * St + (uint32_t) (k ? hp.S[0] : 0));
-            for (int rr = 0; rr < as; rr++) {  // ascending slot order == ascending rank
-                const float soc = arrive_soc_from(rs.normal_d(7.0, 3.0));
-                const uint32_t lev = (uint32_t) rs.level();
-                int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
-                late = late < 0 ? 0 : late;
-                var[rr] = u32x2{__float_as_uint(soc), lev | ((uint32_t) late << 16)};
-            }
-            st.fa[sidx] = ((uint32_t) fl & 0xFFFFu) | ((uint32_t) (as > 0 ? as : 0) << 16) | ((uint32_t) new_line << 24);
-        }
+        compat_walk_env<RESET>(ctx, sa, env, rs);
         rs.r.set(31, rs.gf);
         ctx->cr.minstd[env] = rs.x;
     }
@@ -1902,7 +1916,8 @@ __device__ __forceinline__ void tail_prefetch(TailIn &in, const TailArgs &ta, co
 struct NoMid {
     __device__ __forceinline__ void operator()() {}
 };
-template <bool RESET, int MODE, bool MULTI, bool FUSED = false, typename Mid = NoMid>
+// EB: lanes of the workgroup that calls it (k_env: kEnvBlock; k_compat_small: its 512)
+template <bool RESET, int MODE, bool MULTI, bool FUSED = false, typename Mid = NoMid, int EB = kEnvBlock>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_pv_now, const double *s_wd_now,
                                          const double *s_hy, const uint8_t *s_hv, float *s_out, const int env_block, const TailArgs &ta,
@@ -2028,7 +2043,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 
     if (!FUSED) {
         // the table rows requested at the top arrive with the state loads; park them in LDS
-        static_assert(kEnvBlock >= 150, "one table element per lane");
+        static_assert(EB >= 150, "one table element per lane");
         const int i = threadIdx.x;
         if (i < 100) ((double *) s_pv)[i] = st_pv;
         if (i < 150) ((double *) s_wd)[i] = st_wd;
@@ -2062,21 +2077,21 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             return;
         }
         __syncthreads();
-        const int env0 = env_block * kEnvBlock;
-        const int rows = (int) N - env0 < kEnvBlock ? (int) N - env0 : kEnvBlock;
+        const int env0 = env_block * EB;
+        const int rows = (int) N - env0 < EB ? (int) N - env0 : EB;
         float *dst = sa.obs + (size_t) env0 * (size_t) row_w;
         const int total = rows * row_w;
         // per-env clocks: only the rows of the envs this launch serves (whole block served: the plain path)
         if (MULTI && sa.env_mask && !__syncthreads_and((live || env >= (int) N) ? 1 : 0)) {
-            for (int i = threadIdx.x; i < total; i += kEnvBlock)
+            for (int i = threadIdx.x; i < total; i += EB)
                 if (in_group(sa, env0 + i / row_w)) dst[i] = s_out[i];
         } else if ((((uintptr_t) dst) & 15u) == 0) {  // 16 bytes per lane and store: a quarter of the store instructions
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const int quads = total >> 2;
-            for (int i = threadIdx.x; i < quads; i += kEnvBlock) ((f32x4 *) dst)[i] = ((const f32x4 *) s_out)[i];
-            for (int i = (quads << 2) + threadIdx.x; i < total; i += kEnvBlock) dst[i] = s_out[i];
+            for (int i = threadIdx.x; i < quads; i += EB) ((f32x4 *) dst)[i] = ((const f32x4 *) s_out)[i];
+            for (int i = (quads << 2) + threadIdx.x; i < total; i += EB) dst[i] = s_out[i];
         } else {
-            for (int i = threadIdx.x; i < total; i += kEnvBlock) dst[i] = s_out[i];
+            for (int i = threadIdx.x; i < total; i += EB) dst[i] = s_out[i];
         }
     };
     // what the first half hands to the second
@@ -2503,32 +2518,72 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
 
 // ---------------------------------------------------------------------------------------- k_compat_small: COMPAT, a handful of envs, ONE launch
 // The reference-exact mode is what the drop-in class runs, one env at a time (EvcsspManagerEnv_v6: test/env_test.py's loop), and there
-// a step is nothing but launch latency: station 0, station 1 (the env's two reference streams are consumed in that order, so they are
-// passes, not lanes) and the tail were three launches.  When every env of the handle fits ONE workgroup for both stations, the same
-// three bodies run back to back in one launch -- slot_body_compat (k = 0), slot_body_compat (k = 1), env_tail -- with the stream
-// state and the station records handed over through memory as before (a release / acquire pair at agent scope around the workgroup
-// barrier: the next pass reads what the last one stored).  Same functions, same order: the results are those of the three launches.
-template <bool RESET>
-__global__ __launch_bounds__(kSlotBlock) void k_compat_small(const DevCtx *__restrict__ ctx, StepArgs sa, TailArgs ta) {
-    static_assert(kSlotBlock == kEnvBlock, "one workgroup shape for the slot passes and the tail");
-    __shared__ float lds_f[kSlotBlock];
-    __shared__ uint32_t lds_u[2 * kSlotBlock];
-    __shared__ double s_pv[100], s_wd[150], s_pv_now[100], s_wd_now[150], s_hy[102];
-    __shared__ __attribute__((aligned(16))) uint8_t s_hv[kLevels];
-    __shared__ __attribute__((aligned(16))) float s_out[kEnvBlock * 16];
-    const HubParams &hp = ctx->hp;
-    for (int k = 0; k < 2; k++) {
-        if (hp.type[k] == 0) slot_body_compat<0, RESET, kSlotBlock>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, 0, lds_f, lds_u);
-        else slot_body_compat<1, RESET, kSlotBlock>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, 0, lds_f, lds_u);
+// a step is nothing but launch latency and the serial walk of the env's two reference streams.  When every env of the handle fits ONE
+// workgroup, the split step (k_compat_walk -> k_slot_split -> k_env) runs inside one launch of kCompatSmallBlock lanes, its parts as
+// ROLES of the workgroup's waves:
+//   wave 0             lane = env: the walk (compat_walk_env: station 0's draws, then station 1's), later the tail
+//   waves 1 .. 3       station 0's units, waves 4 .. 7 station 1's (slot_body_compat<.., SPLIT>): loads, on / off, car_step along the
+//                      curves and the departures run WHILE wave 0 walks; the bodies stop at the workgroup barrier in front of their
+//                      first look at what the walk came to
+// then the admissions, sums and records, another barrier, and env_tail (its forecourt draws continue the env's streams where the walk
+// left them).  What crosses waves goes through memory as between the three launches (release / acquire at agent scope around the
+// workgroup barriers).  Same functions, same order of draws: the results are those of the three launches.
+static_assert(64 * (1 + kCompatSmallWaves0 + kCompatSmallWaves1) == kCompatSmallBlock, "wave roles of k_compat_small");
+struct SmallMid {
+    __device__ __forceinline__ void operator()() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+};
+template <bool RESET>
+__global__ __launch_bounds__(kCompatSmallBlock) void k_compat_small(const DevCtx *__restrict__ ctx, StepArgs sa, TailArgs ta) {
+    constexpr int BLOCK = kCompatSmallBlock;
+    __shared__ float lds_f[BLOCK];
+    __shared__ uint32_t lds_u[2 * BLOCK];
+    __shared__ double s_pv[100], s_wd[150], s_pv_now[100], s_wd_now[150], s_hy[102];
+    __shared__ __attribute__((aligned(16))) uint8_t s_hv[kLevels];
+    __shared__ __attribute__((aligned(16))) float s_out[kEnvBlock * 16];
+    const HubParams &hp = ctx->hp;
+    const int wave = (int) (threadIdx.x >> 6);
+    const int k = wave <= kCompatSmallWaves0 ? 0 : 1, wave0 = k ? 1 + kCompatSmallWaves0 : 1;
+    SmallMid mid;
+    if (!RESET && sa.empt_fresh) {
+        // the units' empty-slot counts are not the previous pass's (the first step after create / chub_set_state): counted here
+        if (wave >= 1) {
+            const int lane = (int) (threadIdx.x & 63u), U = hp.U[k], S = hp.S[k];
+            const int upw = 64 / U, uiw = lane / U, slot = lane - uiw * U;
+            const int env = (wave - wave0) * upw + uiw;
+            const bool unit_ok = uiw < upw && env < (int) hp.n_envs;
+            const bool valid = unit_ok && slot < S;
+            const uint64_t unit_mask = (U == 64) ? ~0ull : (uiw < upw ? (((1ull << U) - 1ull) << (uiw * U)) : 0ull);
+            uint32_t w = 0u;
+            if (valid) w = ctx->sl.hot[4 * ((size_t) hp.base[k] + (size_t) env * (size_t) S + (size_t) slot) + 3];
+            const uint64_t be = __ballot(valid && (int) (w & 127u) <= 1) & unit_mask;
+            if (unit_ok && slot == 0) ctx->st.empt[(uint32_t) k * (uint32_t) hp.n_envs + (uint32_t) env] = (uint8_t) __popcll(be);
+        }
+        mid();
+    }
+    if (wave == 0) {
+        const int env = (int) threadIdx.x;
+        if (env < (int) hp.n_envs) {
+            CompatStream rs;
+            rs.load(ctx->cr, env);
+            compat_walk_env<RESET>(ctx, sa, env, rs);
+            rs.store(ctx->cr, env);
+        }
+        mid();  // (the barrier the slot waves reach inside their bodies)
+    } else if (hp.type[k] == 0) {
+        slot_body_compat<0, RESET, BLOCK, true, SmallMid>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, 0, lds_f, lds_u, wave0, mid);
+    } else {
+        slot_body_compat<1, RESET, BLOCK, true, SmallMid>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, 0, lds_f, lds_u, wave0, mid);
+    }
+    mid();  // the station records are in
     const int env = (int) threadIdx.x;
     TailIn none;
     NoMid nomid;
-    env_tail<RESET, MODE_COMPAT, false>(ctx, sa, env, env < (int) ta.n_envs, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, s_hv, s_out, 0, ta, nullptr, 0, 0, 0,
-                                        none, false, nomid);
+    env_tail<RESET, MODE_COMPAT, false, false, NoMid, BLOCK>(ctx, sa, env, env < (int) ta.n_envs, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, s_hv, s_out, 0, ta,
+                                                                    nullptr, 0, 0, 0, none, false, nomid);
 }
 
 // ---------------------------------------------------------------------------------------- k_step_fused: the whole step in ONE launch
@@ -3032,8 +3087,8 @@ void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &s
 // COMPAT lock-step reset / step of a handle whose envs all fit one workgroup (the caller has checked): one launch
 void launch_compat_small(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp) {
     const TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa, pp, reset);
-    if (reset) hipLaunchKernelGGL(k_compat_small<true>, dim3(1), dim3(kSlotBlock), 0, stream, ctx, sa, ta);
-    else hipLaunchKernelGGL(k_compat_small<false>, dim3(1), dim3(kSlotBlock), 0, stream, ctx, sa, ta);
+    if (reset) hipLaunchKernelGGL(k_compat_small<true>, dim3(1), dim3(kCompatSmallBlock), 0, stream, ctx, sa, ta);
+    else hipLaunchKernelGGL(k_compat_small<false>, dim3(1), dim3(kCompatSmallBlock), 0, stream, ctx, sa, ta);
 }
 
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,

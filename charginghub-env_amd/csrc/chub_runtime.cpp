@@ -716,7 +716,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
                                                    "stations of at most 64 piles"));
     }
     {   // the reference-exact mode at a handful of envs (the drop-in class: one): both station passes and the tail in one launch
-        const int64_t fit = std::min<int64_t>((kSlotBlock / 64) * (64 / hp.U[0]), (kSlotBlock / 64) * (64 / hp.U[1]));
+        const int64_t fit = std::min<int64_t>(64, std::min<int64_t>(kCompatSmallWaves0 * (64 / hp.U[0]), kCompatSmallWaves1 * (64 / hp.U[1])));
         e->compat_small = rng_mode == CHUB_RNG_COMPAT && opt.fused_step != 1 && hp.S[0] <= 64 && hp.S[1] <= 64 && n_envs <= fit;
         // ... and everything else as the split step (stream walks, one env per lane -> slots of both stations in one launch) unless
         // slot_kernel = 1 asks for one kernel per station with the unit's first lane walking (the parity cross-check).  Measured, us per
@@ -993,7 +993,7 @@ static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const d
     if (rc_) return rc_;
     if (e->compat_small && !e->per_env) {
         launch_compat_small(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e));
-        e->empt_valid = false;
+        e->empt_valid = true;  // (k_compat_small is the split step in one launch: its slot waves leave the counts)
     } else {
         launch_slot(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e), nullptr, nullptr);
         launch_env(true, e->hp, e->d_ctx, sa, s, nullptr, nullptr, packed_ptrs(e));
@@ -1151,10 +1151,11 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     }
     // four events per profiled step: start / stop of the slot kernel, start / stop of the tail kernel
     hipEvent_t *pe = prof ? &e->prof_events[4 * e->prof_used] : nullptr;
-    sa.empt_fresh = (e->hp.compat_split && (!e->empt_valid || e->capturing)) ? 1 : 0;
-    if (e->compat_small && !load_mode && !e->per_env) {
-        e->empt_valid = false;
+    const bool small_step = e->compat_small && !load_mode && !e->per_env;
+    sa.empt_fresh = ((small_step || e->hp.compat_split) && (!e->empt_valid || e->capturing)) ? 1 : 0;
+    if (small_step) {
         launch_compat_small(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e));
+        e->empt_valid = true;
         if (prof) {  // one kernel, no dispatch timestamps: the sample spans nothing
             for (int i = 0; i < 4; i++) HIP_TRY(hipEventRecord(pe[i], s));
         }
