@@ -245,6 +245,11 @@ struct StepArgs {
     // tape mode (PHILOX, packed kernel): the step's station-level draws and the per-admission variates come from the caller
     const uint64_t *pk_tape;   // [2N] packed station draws of this step (layout of StationArrays::pk), or null
     const uint32_t *car_tape;  // [NS][2] per slot: arrival-SoC class, target level | extra stay << 16, or null
+    // ... and (tail_tape != 0) the per-env tail takes ITS variates from the caller as well: the three exogenous normals from exo_z (f64, as
+    // the reference's numpy drew them), a reset's PV / wind days from exo_days, and the forecourt's arrivals from hv_tape
+    const uint32_t *hv_tape;   // [N][hv_w] per env: word 0 = FCEV arrivals of this step, word 1 + j = arrival j's SoC (f32 bits; CarArriveRandom.mk_soc, HYD:259)
+    int32_t hv_w;
+    int32_t tail_tape;
     // per-env clocks (chub_reset_envs / chub_step_envs): the clock is per-env state, [2][N] u16 (bits 0-6 slot of day, bits 8-9
     // price_count & 3): a launch reads [tick & 1] and writes [(tick + 1) & 1] for EVERY env (the envs it does not serve keep
     // theirs).  null: lock-step, the one clock above holds for every env.

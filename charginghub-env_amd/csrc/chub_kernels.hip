@@ -1917,7 +1917,10 @@ struct NoMid {
     __device__ __forceinline__ void operator()() {}
 };
 // EB: lanes of the workgroup that calls it (k_env: kEnvBlock; k_compat_small: its 512)
-template <bool RESET, int MODE, bool MULTI, bool FUSED = false, typename Mid = NoMid, int EB = kEnvBlock>
+// TAPE (the parity instrument of include/chub.h, PHILOX handles): the tail's variates come from the caller -- the exogenous normals
+// (sa.exo_z, f64 as the reference's numpy drew them), a reset's days (sa.exo_days), the forecourt's arrivals and their SoCs (sa.hv_tape) --
+// and everything else is the production tail, instruction for instruction.
+template <bool RESET, int MODE, bool MULTI, bool FUSED = false, typename Mid = NoMid, int EB = kEnvBlock, bool TAPE = false>
 __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, const bool live,
                                          const double *s_pv, const double *s_wd, const double *s_pv_now, const double *s_wd_now,
                                          const double *s_hy, const uint8_t *s_hv, float *s_out, const int env_block, const TailArgs &ta,
@@ -2013,7 +2016,12 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             q_len = ta.q_len[e32];
             hv_line = ta.hv_line[e32];
         }
-        if (MODE == MODE_PHILOX && !RESET && !sa.fresh) {
+        if (TAPE) {
+            z_pv = sa.exo_z[e32 * 3u + 0u];
+            z_wd = sa.exo_z[e32 * 3u + 1u];
+            z_pr = sa.exo_z[e32 * 3u + 2u];
+            if (!RESET) hv_arrive = (int) sa.hv_tape[e32 * (uint32_t) sa.hv_w];
+        } else if (MODE == MODE_PHILOX && !RESET && !sa.fresh) {
             // this step's state-independent env draws (three OU normals, FCEV arrival count) were made one launch ahead by
             // the level blocks of k_env (draw_env_levels): 350 dependent instructions less on this latency-bound chain
             if (have_pre) {
@@ -2055,7 +2063,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         }
         __syncthreads();
     }
-    if (MODE == MODE_PHILOX && !RESET && !sa.fresh) {
+    if (!TAPE && MODE == MODE_PHILOX && !RESET && !sa.fresh) {
         z_pv = (double) __uint_as_float(drw_raw.x);
         z_wd = (double) __uint_as_float(drw_raw.y);
         z_pr = (double) __uint_as_float(drw_raw.z);
@@ -2112,7 +2120,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 
     if (RESET) {
         // renew_reset (REN:51-53) + hy_reset (HYD:197-208)
-        if (MODE == MODE_COMPAT) {
+        if (MODE == MODE_COMPAT || TAPE) {
             pv_day = sa.exo_days[e32 * 2u + 0u];
             wd_day = sa.exo_days[e32 * 2u + 1u];
         } else {
@@ -2150,7 +2158,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         if (MODE == MODE_COMPAT) hv_lev = rs.level();
         arrive = MODE == MODE_COMPAT ? (int) TAB_HV(hv_lev) : hv_arrive;
         double total_mass = 0.0;
-        const bool fcev_pre = MODE == MODE_PHILOX && !RESET && !sa.fresh;
+        const bool fcev_pre = !TAPE && MODE == MODE_PHILOX && !RESET && !sa.fresh;
         // the first arrival's SoC was drawn one launch ahead with the other env draws (level_block: same Philox counter); its
         // fueling time and mass follow from it alone
         double pre_tn = 0.0, pre_mn = 0.0;
@@ -2183,7 +2191,8 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
                     mn = pre_mn;
                 } else {
                     float socf;
-                    if (MODE == MODE_COMPAT) socf = arrive_soc_from(rs.normal_d(7.0, 3.0));
+                    if (TAPE) socf = __uint_as_float(sa.hv_tape[e32 * (uint32_t) sa.hv_w + 1u + (uint32_t) j]);
+                    else if (MODE == MODE_COMPAT) socf = arrive_soc_from(rs.normal_d(7.0, 3.0));
                     else socf = soc_from_word(tb.soc_d_icdf, px.block(SITE_HVSOC, (uint32_t) j, 0).v[0]);
                     fcev_time_mass(socf, tn, mn);
                 }
@@ -2494,7 +2503,7 @@ __device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, cons
     }
 }
 
-template <bool RESET, int MODE, bool MULTI>
+template <bool RESET, int MODE, bool MULTI, bool TAPE = false>
 __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ctx, StepArgs sa, TailArgs ta, int nb_env) {
     __shared__ double s_pv[100], s_wd[150], s_pv_now[100], s_wd_now[150], s_hy[102];
     __shared__ __attribute__((aligned(16))) uint8_t s_hv[kLevels];
@@ -2512,8 +2521,8 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     const int env = blk * kEnvBlock + (int) threadIdx.x;
     TailIn none;  // (the stand-alone tail loads its inputs itself)
     NoMid nomid;
-    env_tail<RESET, MODE, MULTI>(ctx, sa, env, env < (int) ta.n_envs && (!MULTI || in_group(sa, env)), s_pv, s_wd, s_pv_now, s_wd_now, s_hy,
-                                 s_hv, s_out, blk, ta, nullptr, 0, 0, 0, none, false, nomid);
+    env_tail<RESET, MODE, MULTI, false, NoMid, kEnvBlock, TAPE>(ctx, sa, env, env < (int) ta.n_envs && (!MULTI || in_group(sa, env)), s_pv, s_wd, s_pv_now,
+                                                                s_wd_now, s_hy, s_hv, s_out, blk, ta, nullptr, 0, 0, 0, none, false, nomid);
 }
 
 // ---------------------------------------------------------------------------------------- k_compat_small: COMPAT, a handful of envs, ONE launch
@@ -2631,7 +2640,7 @@ struct TailPrefetch {
     }
 };
 
-template <int BLOCK, int T, bool BITS = false>
+template <int BLOCK, int T, bool BITS = false, bool TAPE = false>
 __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in, TailArgs ta) {
     static_assert(BLOCK >= 150 && BLOCK / 64 >= 3, "one table element per lane; three waves with work of their own");
     __shared__ uint32_t q_new[BLOCK * T];
@@ -2646,12 +2655,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
     PackedArgs pa = pa_in;
     asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
                       "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
-    TailPrefetch hook{ta, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, 0.0, 0.0, 0.0, 0.0, 0.0, TailIn(), -1, sa.fresh == 0};
+    TailPrefetch hook{ta, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, 0.0, 0.0, 0.0, 0.0, 0.0, TailIn(), -1, sa.fresh == 0 && !TAPE};
     {   // the lanes of the last wave that will run a tail: which env's state to request up front
         const int le = (int) (threadIdx.x & 63u), env = (int) blockIdx.x * (int) pa_in.epb + le;
         if ((int) (threadIdx.x >> 6) == BLOCK / 64 - 1 && le < (int) pa_in.epb && env < (int) pa_in.n_envs) hook.tail_env = env;
     }
-    const int role = slot_body_packed<BLOCK, T, false, false, false, false, true, TailPrefetch, BITS>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
+    const int role = slot_body_packed<BLOCK, T, TAPE, false, false, false, true, TailPrefetch, BITS>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
                                                                                                       s_ball + 1, s_acc, s_unit, hook, s_rec, s_uinfo);
     constexpr int WAVES = BLOCK / 64;
     const int lane = threadIdx.x & 63;
@@ -2700,8 +2709,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
             int rows = epb - c < 64 ? epb - c : 64;
             rows = N - (env_first + c) < rows ? N - (env_first + c) : rows;
             RecordsMid mid{pa, s_acc, s_unit, s_rec, c == 0};
-            env_tail<false, MODE_PHILOX, false, true, RecordsMid>(ctx, sa, env, live, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, nullptr, s_out, 0, ta, s_rec,
-                                                                  live ? le : 0, env_first + c, rows > 0 ? rows : 0, hook.tin, c == 0, mid);
+            env_tail<false, MODE_PHILOX, false, true, RecordsMid, kEnvBlock, TAPE>(ctx, sa, env, live, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, nullptr, s_out, 0, ta,
+                                                                                   s_rec, live ? le : 0, env_first + c, rows > 0 ? rows : 0, hook.tin, c == 0, mid);
         }
     }
 }
@@ -3071,10 +3080,15 @@ static PackedArgs make_packed_args(const HubParams &hp, const StepArgs &sa, cons
 // the whole PHILOX lock-step step as ONE launch (k_step_fused): the caller has checked that the hub shape and the call allow it
 void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp, hipEvent_t ev0,
                        hipEvent_t ev1) {
-    if (sa.fresh) hipLaunchKernelGGL(k_draw_levels, dim3((unsigned) ((2 * ((int64_t) sa.env_hi - sa.env_lo + 1) + 255) / 256)), dim3(256), 0, stream, ctx, sa);
+    if (sa.fresh || sa.pk_tape) hipLaunchKernelGGL(k_draw_levels, dim3((unsigned) ((2 * ((int64_t) sa.env_hi - sa.env_lo + 1) + 255) / 256)), dim3(256), 0, stream, ctx, sa);
     const PackedArgs pa = make_packed_args(hp, sa, pp);
     TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa, pp, false);
     const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
+    if (sa.tail_tape) {  // tape mode (the caller has checked: station draws, car variates and the tail's variates all come from the tape)
+        ta.tail_act = nullptr;
+        CHUB_LAUNCH((k_step_fused<kPackedBlock, kSlotsPerLane, false, true>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa, ta);
+        return;
+    }
     if (sa.act_bits) {  // one bit per pile: the tails read their two actions from the caller's [N][2] array
         ta.tail_act = (CHUB_G(const float)) sa.act_tail;
         CHUB_LAUNCH((k_step_fused<kPackedBlock, kSlotsPerLane, true>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa, ta);
@@ -3106,7 +3120,10 @@ void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepAr
     if (hp.rng_mode == MODE_PHILOX) {
         // + the level-draw workgroups: next step's state-independent variates (3 lanes per env: two stations, one env)
         const unsigned nb = (unsigned) nb_env + (unsigned) ((3 * ((int64_t) sa.env_hi - sa.env_lo + 1) + kEnvBlock - 1) / kEnvBlock);
-        if (sa.env_clk) {  // per-env clocks: its own instantiation
+        if (sa.tail_tape) {  // tape mode (lock-step): the tail's variates from the caller
+            if (reset) CHUB_LAUNCH((k_env<true, MODE_PHILOX, false, true>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
+            else CHUB_LAUNCH((k_env<false, MODE_PHILOX, false, true>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
+        } else if (sa.env_clk) {  // per-env clocks: its own instantiation
             if (reset) CHUB_LAUNCH((k_env<true, MODE_PHILOX, true>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
             else CHUB_LAUNCH((k_env<false, MODE_PHILOX, true>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
         } else if (reset) CHUB_LAUNCH((k_env<true, MODE_PHILOX, false>), dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);

@@ -125,6 +125,9 @@ struct chub_env {
     const float *cur_tail;     //   decision bits and the tail actions themselves (no action rows)
     const uint64_t *tape_pk;   // set for the duration of chub_step_tape
     const uint32_t *tape_car;
+    const uint32_t *tape_hv = nullptr;  // ... and, with them, the tail's tape (chub_step_tape_env / chub_reset_tape_env): FCEV arrivals per env
+    int tape_hv_w = 0;
+    bool tape_tail = false;     // the tail of the call in flight takes its variates from the caller (exo_z, exo_days, tape_hv)
     // optional per-kernel timing with HIP events on the launch stream (chub_profile_*)
     std::vector<hipEvent_t> prof_events;
     size_t prof_used, prof_cap;
@@ -979,6 +982,7 @@ static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const d
     sa.obs = d_obs;
     sa.obs_stride = e->hp.obs_dim;
     sa.car_tape = e->tape_car;  // chub_reset_tape: the unit's occupancy draws are in pk already, the cars' variates come from the tape
+    sa.tail_tape = e->tape_tail ? 1 : 0;  // chub_reset_tape_env: the tail's days and normals from the caller as well
     sa.env_lo = 0;
     sa.env_hi = (int32_t) (e->hp.n_envs - 1);
     if (e->per_env) {
@@ -1128,6 +1132,9 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     sa.load_mode = load_mode;
     sa.pk_tape = e->tape_pk;
     sa.car_tape = e->tape_car;
+    sa.hv_tape = e->tape_hv;
+    sa.hv_w = e->tape_hv_w;
+    sa.tail_tape = e->tape_tail ? 1 : 0;
     sa.env_lo = 0;
     sa.env_hi = (int32_t) (e->hp.n_envs - 1);
     if (e->per_env) {
@@ -1159,7 +1166,8 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
         if (prof) {  // one kernel, no dispatch timestamps: the sample spans nothing
             for (int i = 0; i < 4; i++) HIP_TRY(hipEventRecord(pe[i], s));
         }
-    } else if (e->fused && !load_mode && !e->per_env && !sa.car_tape && !sa.pk_tape) {
+    } else if (e->fused && !load_mode && !e->per_env && ((!sa.car_tape && !sa.pk_tape) || (sa.car_tape && sa.pk_tape && sa.tail_tape))) {
+        // (tape mode: the one-launch form replays only a complete tape -- station draws, car variates and the tail's variates)
         launch_step_fused(e->hp, e->d_ctx, sa, s, packed_ptrs(e), prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
         if (prof) {  // one kernel: the whole step is on the first pair of timestamps, the second pair spans nothing
             HIP_TRY(hipEventRecord(pe[2], s));
@@ -1809,19 +1817,44 @@ int chub_set_station_queue(chub_env *e, const int32_t *line) {
 
 int chub_step_tape(chub_env *e, const float *actions, const uint64_t *pk_tape, const uint32_t *car_tape, float *obs, float *reward,
                    uint8_t *done) {
+    return chub_step_tape_env(e, actions, pk_tape, car_tape, nullptr, nullptr, 0, obs, reward, done);
+}
+
+// ... the whole step from the tape: the per-env tail (k_env<.., TAPE> / the tail half of k_step_fused<.., TAPE>) takes the step's exogenous
+// normals and the forecourt's arrivals from the caller as well
+int chub_step_tape_env(chub_env *e, const float *actions, const uint64_t *pk_tape, const uint32_t *car_tape, const double *exo_z,
+                       const uint32_t *hv_tape, int32_t hv_w, float *obs, float *reward, uint8_t *done) {
     if (!e || !actions || !pk_tape || !car_tape || !obs || !reward || !done) return fail(CHUB_ERR_ARG, "null argument");
     if (e->hp.rng_mode != CHUB_RNG_PHILOX || !e->hp.packed)
         return fail(CHUB_ERR_ARG, "tape mode drives the packed PHILOX slot kernel: the hub shape must be one it covers");
+    if ((exo_z != nullptr) != (hv_tape != nullptr) || (hv_tape && hv_w < 1)) return fail(CHUB_ERR_ARG, "the tail's tape is exo_z [N][3] AND hv_tape [N][hv_w >= 1]");
     HIP_TRY(hipSetDevice(e->device));
     const size_t N = (size_t) e->hp.n_envs, S = (size_t) (e->hp.S[0] + e->hp.S[1]);
+    uint32_t *d_hv = nullptr;
+    if (hv_tape) {
+        // at most as many arrivals per step as the handle's forecourt can see from its own tables (the waiting list's explicit entries
+        // are sized for that, chub_create), each with its SoC on the tape
+        const uint32_t most = (uint32_t) ((e->hp.qcap + 1) / 2);
+        for (size_t i = 0; i < N; i++)
+            if (hv_tape[i * (size_t) hv_w] > most || hv_tape[i * (size_t) hv_w] > (uint32_t) (hv_w - 1))
+                return fail(CHUB_ERR_ARG, "hv_tape: more FCEV arrivals in one step than the handle's forecourt (or the tape's width) takes");
+        HIP_TRY(hipMalloc((void **) &d_hv, N * (size_t) hv_w * sizeof(uint32_t)));
+        hipError_t he1 = hipMemcpy(d_hv, hv_tape, N * (size_t) hv_w * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (he1 == hipSuccess) he1 = hipMemcpy(e->d_exo_z, exo_z, N * 3 * sizeof(double), hipMemcpyHostToDevice);
+        if (he1 != hipSuccess) {
+            (void) hipFree(d_hv);
+            return fail(CHUB_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(he1));
+        }
+    }
     // the car tape is in hub order [N][S][2] (station 0's slots first), which is the kernel's own slot order
     const std::vector<uint32_t> ct(car_tape, car_tape + 2 * N * S);
     uint64_t *d_pk = nullptr;
     uint32_t *d_ct = nullptr;
-    HIP_TRY(hipMalloc((void **) &d_pk, 2 * N * sizeof(uint64_t)));
-    hipError_t he = hipMalloc((void **) &d_ct, ct.size() * sizeof(uint32_t));
+    hipError_t he = hipMalloc((void **) &d_pk, 2 * N * sizeof(uint64_t));
+    if (he == hipSuccess) he = hipMalloc((void **) &d_ct, ct.size() * sizeof(uint32_t));
     if (he != hipSuccess) {
         (void) hipFree(d_pk);
+        (void) hipFree(d_hv);
         return fail(CHUB_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(he));
     }
     int rc = CHUB_OK;
@@ -1829,6 +1862,7 @@ int chub_step_tape(chub_env *e, const float *actions, const uint64_t *pk_tape, c
         (void) hipDeviceSynchronize();
         (void) hipFree(d_pk);
         (void) hipFree(d_ct);
+        (void) hipFree(d_hv);
         return code;
     };
     if (hipMemcpy(d_pk, pk_tape, 2 * N * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess ||
@@ -1837,9 +1871,15 @@ int chub_step_tape(chub_env *e, const float *actions, const uint64_t *pk_tape, c
         return done_(fail(CHUB_ERR_HIP, "hipMemcpy failed"));
     e->tape_pk = d_pk;
     e->tape_car = d_ct;
-    rc = chub_step_device(e, e->d_actions, nullptr, e->d_obs, e->d_reward, e->d_done, nullptr);
+    e->tape_hv = d_hv;
+    e->tape_hv_w = hv_w;
+    e->tape_tail = d_hv != nullptr;
+    rc = chub_step_device(e, e->d_actions, d_hv ? e->d_exo_z : nullptr, e->d_obs, e->d_reward, e->d_done, nullptr);
     e->tape_pk = nullptr;
     e->tape_car = nullptr;
+    e->tape_hv = nullptr;
+    e->tape_hv_w = 0;
+    e->tape_tail = false;
     if (rc) return done_(rc);
     if (hipMemcpy(obs, e->d_obs, N * (size_t) e->hp.obs_dim * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(reward, e->d_reward, N * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
@@ -1849,7 +1889,18 @@ int chub_step_tape(chub_env *e, const float *actions, const uint64_t *pk_tape, c
 }
 
 int chub_reset_tape(chub_env *e, const uint32_t *occ_tape, const uint32_t *car_tape, float *obs) {
+    return chub_reset_tape_env(e, occ_tape, car_tape, nullptr, nullptr, obs);
+}
+
+// ... the whole reset from the tape: the tail (k_env<RESET, .., TAPE>) takes renew_reset's days (REN:51-53) and make_state's normals
+// (MGR:344-361) from the caller
+int chub_reset_tape_env(chub_env *e, const uint32_t *occ_tape, const uint32_t *car_tape, const int32_t *exo_days, const double *exo_z, float *obs) {
     if (!e || !occ_tape || !car_tape || !obs) return fail(CHUB_ERR_ARG, "null argument");
+    if ((exo_days != nullptr) != (exo_z != nullptr)) return fail(CHUB_ERR_ARG, "the tail's tape of a reset is exo_days [N][2] AND exo_z [N][3]");
+    if (exo_days)
+        for (size_t i = 0; i < (size_t) e->hp.n_envs; i++)
+            if (exo_days[2 * i] < 0 || exo_days[2 * i] >= 100 || exo_days[2 * i + 1] < 0 || exo_days[2 * i + 1] >= 150)
+                return fail(CHUB_ERR_ARG, "exo_days out of range");
     if (e->hp.rng_mode != CHUB_RNG_PHILOX || !e->hp.packed)
         return fail(CHUB_ERR_ARG, "tape mode drives the packed PHILOX slot kernel: the hub shape must be one it covers");
     if (e->capturing) return fail(CHUB_ERR_ARG, "tape mode cannot be captured");
@@ -1869,9 +1920,14 @@ int chub_reset_tape(chub_env *e, const uint32_t *occ_tape, const uint32_t *car_t
     if (hipMemcpy((void *) e->st.pk[arg & 1u], occ_tape, 2 * N * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d_ct, car_tape, 2 * N * S * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
         return done_(fail(CHUB_ERR_HIP, "hipMemcpy failed"));
+    if (exo_days && (hipMemcpy(e->d_exo_days, exo_days, 2 * N * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+                     hipMemcpy(e->d_exo_z, exo_z, 3 * N * sizeof(double), hipMemcpyHostToDevice) != hipSuccess))
+        return done_(fail(CHUB_ERR_HIP, "hipMemcpy failed"));
     e->tape_car = d_ct;
-    int rc = chub_reset_device(e, nullptr, nullptr, e->d_obs, nullptr);
+    e->tape_tail = exo_days != nullptr;
+    int rc = chub_reset_device(e, exo_days ? e->d_exo_days : nullptr, exo_days ? e->d_exo_z : nullptr, e->d_obs, nullptr);
     e->tape_car = nullptr;
+    e->tape_tail = false;
     if (rc) return done_(rc);
     if (hipMemcpy(obs, e->d_obs, N * (size_t) e->hp.obs_dim * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
         return done_(fail(CHUB_ERR_HIP, "hipMemcpy failed"));

@@ -200,18 +200,33 @@ class VecChargingHub(object):
         q = np.ascontiguousarray(line, dtype=np.int32).reshape(self.n_envs, 2)
         check(self._lib.chub_set_station_queue(self._h, _ptr(q)))
 
-    def reset_tape(self, occ_tape, car_tape):
-        """evs_reset fed the reference's draws (chub_reset_tape): occ_tape [2, N] u32, car_tape [N, S, 2] u32"""
+    def reset_tape(self, occ_tape, car_tape, exo_days=None, exo_z=None):
+        """evs_reset fed the reference's draws (chub_reset_tape): occ_tape [2, N] u32, car_tape [N, S, 2] u32; with exo_days [N, 2] and
+        exo_z [N, 3] the tail takes renew_reset's days and make_state's normals from the caller too (chub_reset_tape_env)"""
         oc = np.ascontiguousarray(occ_tape, dtype=np.uint32).reshape(2, self.n_envs)
         ct = np.ascontiguousarray(car_tape, dtype=np.uint32).reshape(self.n_envs, self.n_slots, 2)
-        check(self._lib.chub_reset_tape(self._h, _ptr(oc), _ptr(ct), _ptr(self._obs)))
+        if exo_days is None and exo_z is None:
+            check(self._lib.chub_reset_tape(self._h, _ptr(oc), _ptr(ct), _ptr(self._obs)))
+        else:
+            d = np.ascontiguousarray(exo_days, dtype=np.int32).reshape(self.n_envs, 2)
+            z = np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)).reshape(self.n_envs, 3)
+            check(self._lib.chub_reset_tape_env(self._h, _ptr(oc), _ptr(ct), _ptr(d), _ptr(z), _ptr(self._obs)))
         return self._obs.copy() if self._copy_outputs else self._obs
 
-    def step_tape(self, actions, pk_tape, car_tape):
+    def step_tape(self, actions, pk_tape, car_tape, exo_z=None, hv_tape=None):
+        """one step from the tape (chub_step_tape); with exo_z [N, 3] f64 and hv_tape [N, W] u32 (word 0 = FCEV arrivals, word 1 + j =
+        arrival j's SoC as f32 bits) the per-env tail replays the reference's draws as well (chub_step_tape_env)"""
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n_envs, self.act_dim)
         pk = np.ascontiguousarray(pk_tape, dtype=np.uint64).reshape(2, self.n_envs)
         ct = np.ascontiguousarray(car_tape, dtype=np.uint32).reshape(self.n_envs, self.n_slots, 2)
-        check(self._lib.chub_step_tape(self._h, _ptr(a), _ptr(pk), _ptr(ct), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
+        if exo_z is None and hv_tape is None:
+            check(self._lib.chub_step_tape(self._h, _ptr(a), _ptr(pk), _ptr(ct), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
+        else:
+            z = np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)).reshape(self.n_envs, 3)
+            hv = np.ascontiguousarray(hv_tape, dtype=np.uint32)
+            hv = hv.reshape(self.n_envs, hv.size // self.n_envs)
+            check(self._lib.chub_step_tape_env(self._h, _ptr(a), _ptr(pk), _ptr(ct), _ptr(z), _ptr(hv), int(hv.shape[1]), _ptr(self._obs),
+                                               _ptr(self._reward), _ptr(self._done)))
         return self._out()
 
     # ---- per-env clocks (every reference env owns its clock, MGR:137-140, 304-316): reset / step a subset of the envs

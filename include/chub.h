@@ -343,6 +343,21 @@ int chub_step_tape(chub_env *env, const float *actions, const uint64_t *pk_tape,
  *                          = what init_station_car_number and the balk pass of the empty queue came to per unit (arrivals as signed 16
  *                          bits | arrivals that stay << 16: the word k_reset_levels leaves), car_tape as above for the cars admitted. */
 int chub_reset_tape(chub_env *env, const uint32_t *occ_tape, const uint32_t *car_tape, float *obs);
+/* The WHOLE step / reset from the tape (round 5): the per-env tail of the production step -- k_env<.., PHILOX>, or the tail half of the
+ * one-launch step k_step_fused -- takes its variates from the caller as well, where the reference draws them:
+ *   exo_z    [N][3] f64  the normals of the PV, wind and price OU processes (np.random.normal inside OU_Noise.sample, renewable.py:71-76,
+ *                        evcssp_manager.py:344-361), as the reference's numpy drew them; entries of processes that do not draw are not read
+ *   hv_tape  [N][hv_w] u32  the forecourt: word 0 = FCEV arrivals of this step (PoissonNumber.hv_car_number_wrt_poisson, hydro_sys.py:251),
+ *                        word 1 + j = arrival j's SoC, f32 bits (CarArriveRandom.mk_soc, hydro_sys.py:259)
+ *   exo_days [N][2] i32  a reset's PV / wind days (random.randint inside ReNew.renew_reset, renewable.py:25,51-53)
+ * With chub_set_hy_table (hy_power_speed_list as the reference's constructor built it) the observation, reward and every telemetry
+ * column of the PRODUCTION kernels can be held to the reference's recorded values directly: tests/test_gpu_tape.py does, on every
+ * fixture, in both launch forms (k_slot_packed + k_env, and k_step_fused).  exo_z / hv_tape (exo_days / exo_z) both null: the tail
+ * keeps this build's own Philox draws, as chub_step_tape / chub_reset_tape. */
+int chub_step_tape_env(chub_env *env, const float *actions, const uint64_t *pk_tape, const uint32_t *car_tape, const double *exo_z,
+                       const uint32_t *hv_tape, int32_t hv_w, float *obs, float *reward, uint8_t *done);
+int chub_reset_tape_env(chub_env *env, const uint32_t *occ_tape, const uint32_t *car_tape, const int32_t *exo_days, const double *exo_z,
+                        float *obs);
 
 /* Snapshot / restore of the whole simulation state (clock, streams, every slot and env variable): checkpoint /
  * resume, planners that branch from a state.  The reference cannot do this (pickling disabled, main.cpp:234; raw

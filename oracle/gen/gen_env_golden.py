@@ -146,6 +146,7 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
     data = dict(obs=[], reward=[], done=[], action=[], exo_z=[], telem=[], stations=[], reset_obs=[], reset_days=[],
                 reset_z=[], reset_stations=[], slots0=[], slots1=[], seeds=[], reset_slots0=[], reset_slots1=[], attrs=[],
                 real_state=[], reset_real_state=[], action_real=[], reset_attrs=[])
+    hv_soc = []  # per step: the arrival SoCs hvs_step drew for its FCEV arrivals (HYD:258-260), in order
     for ep in range(episodes):
         if seeds is not None and (ep == 0 or reseed_each_episode):
             g, m = seeds[0] + ep, seeds[1] + ep
@@ -180,6 +181,8 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
             data["done"].append(d)
             data["exo_z"].append(rec.take())
             data["telem"].append(telemetry(env))
+            hv_soc.append([float(x) for x in env.hy_sys.hvs.arrive_soc_ini_list])
+            assert len(hv_soc[-1]) == env.hy_sys.hvs.arrive_number
             data["stations"].append(station_block(env))
             data["attrs"].append(attributes(env))
             data["real_state"].append(np.array(env.real_state, dtype=np.float64))
@@ -191,6 +194,10 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
     out = {k: np.array(v) for k, v in data.items() if k not in ("slots0", "slots1", "reset_slots0", "reset_slots1")}
     for key in ("slots0", "slots1", "reset_slots0", "reset_slots1"):
         out[key] = np.array(data[key], dtype=np.float32)
+    out["hv_soc"] = np.full((len(hv_soc), max(1, max(len(x) for x in hv_soc))), np.nan, dtype=np.float32)
+    for i_, x in enumerate(hv_soc):
+        out["hv_soc"][i_, :len(x)] = x
+        assert np.array_equal(out["hv_soc"][i_, :len(x)].astype(np.float64), np.array(x)), "mk_soc returns C floats"
     out["hy_table"] = hy_table
     out["ctor_seeds"] = np.array(ctor_seeds if ctor_seeds is not None else (1, 1))  # c1: the process defaults (CHS:25,35-44)
     out["ctor_days"] = np.array(ctor_days)
@@ -274,6 +281,12 @@ def main():
     # constant-power fleet, slow / fast order swapped, fluctuating renewables
     run("env_constant_swapped", base_kwargs(station_list=[7, 9], station_type_list=["slow", "fast"], constant_charging=True,
                                             renew_fluctuate=0.1), 1, 96, "random", (3333, 3434), py_seed=17)
+    # ---- round 5 (appended: the fixtures above come out as before) ----
+    # stepping past `done` without a reset (MGR:271-299: the clock wraps, price_count keeps counting, the aggregator's price list keeps
+    # growing AGG:147; evcssp_env_cpp/__init__.py:6 registers max_episode_steps=999): ONE episode of 250 steps on the C3 hub with
+    # fluctuating series and tank loss, and one of 200 steps on the C2 hub
+    run("env_past_done", base_kwargs(renew_fluctuate=0.3, price_fluctuate=0.3, hydro_loss=0.01), 1, 250, "random", (3535, 3636), py_seed=18)
+    run("env_past_done_c2", base_kwargs(station_list=[16, 0], fcev_permeate=0.0), 1, 200, "random", (3737, 3838), py_seed=19)
 
 
 if __name__ == "__main__":

@@ -278,7 +278,10 @@ GOLDEN_ENV = ["env_c1_envtest", "env_c3_random", "env_c2_random", "env_c5_random
               "env_big_100_70",
               # round 4, second batch: two stations of the same kind, no electrolyser, a permeability above 1, one pile per station,
               # constant-power fleet on swapped station kinds
-              "env_slow_slow", "env_fast_fast", "env_no_electrolyser", "env_permeate_cap", "env_one_pile", "env_constant_swapped"]
+              "env_slow_slow", "env_fast_fast", "env_no_electrolyser", "env_permeate_cap", "env_one_pile", "env_constant_swapped",
+              # round 5: stepping past `done` without a reset (MGR:271-299; the registered horizon is 999 steps, evcssp_env_cpp/__init__.py:6):
+              # one episode of 250 steps (C3 hub, fluctuating series, tank loss) and one of 200 (C2 hub)
+              "env_past_done", "env_past_done_c2"]
 
 
 class OrcEnv:

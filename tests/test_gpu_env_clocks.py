@@ -297,7 +297,7 @@ def test_staggered_hub_on_one_handle():
 
 
 @pytest.mark.parametrize("form", ["wave", "packed"])  # one kernel per station / the split step of large batches (chub_options.slot_kernel)
-@pytest.mark.parametrize("name", ["env_c3_random", "env_slow_only_fcev", "env_small_fast_neg", "env_fcev_queue"])
+@pytest.mark.parametrize("name", ["env_c3_random", "env_slow_only_fcev", "env_small_fast_neg", "env_fcev_queue", "env_past_done", "env_past_done_c2"])
 def test_compat_envs_replay_the_reference_fixture_on_their_own_clocks(name, form):
     """The reference's own recorded trajectories, with every env of ONE handle on its own clock: env e runs the fixture's
     sequence of calls (the constructor's reset, then per episode reseed / reset / steps) `lag[e]` calls behind env 0, so at

@@ -7,6 +7,13 @@ the golden fixtures (tests/golden/env_*.npz, recorded from the unmodified refere
 produces must be the reference's bit for bit, the station counts exactly, and the station power sums (computed through
 the production 2^-19 kW integer path) within 1e-5 relative (+ 1e-6 kW) of the reference's sequential f32 sums.  All 18 fixtures;
 the resets run the same way (chub_reset_tape: evs_reset through k_slot_packed<.., RESET, ..>).
+
+Round 5: the tape goes through the per-env TAIL as well (chub_step_tape_env / chub_reset_tape_env): the exogenous normals numpy drew for
+the reference, renew_reset's days, the forecourt's arrivals and their SoCs, and hy_power_speed_list as the reference's constructor built it,
+all from the fixture -- so observation, reward, done and every telemetry column of k_env<.., PHILOX> (and of the tail half of the one-launch
+step k_step_fused) are held to the reference's recorded values directly, not through the oracle.  Columns that do not depend on the station
+power sums must agree to 1e-9; those that do inherit the production sums' distance from the reference's sequential f32 sums (the north
+star's 1e-5 relative; the integer sums are the more exact of the two).
 """
 import numpy as np
 import pytest
@@ -66,8 +73,32 @@ def _pk_word(n, prev_slots, cur_slots, line_before, line_after, flow):
 
 ALL_FIXTURES = ["env_c1_envtest", "env_c3_random", "env_c2_random", "env_c5_random", "env_slow_only_fcev", "env_clamp", "env_full_tank",
                 "env_fcev_queue", "env_constant", "env_small_fast_neg", "env_fcev_queue_deep", "env_big_100_70",
-                "env_slow_slow", "env_fast_fast", "env_no_electrolyser", "env_permeate_cap", "env_one_pile", "env_constant_swapped"]
+                "env_slow_slow", "env_fast_fast", "env_no_electrolyser", "env_permeate_cap", "env_one_pile", "env_constant_swapped",
+                "env_past_done", "env_past_done_c2"]
 assert sorted(ALL_FIXTURES) == sorted(orclib.GOLDEN_ENV)
+
+
+TIGHT = 1e-9
+# telemetry columns (charginghub-env_amd/_lib.py: TELEMETRY_NAMES) that no station power sum reaches: the exogenous series, the price, the
+# forecourt's demand.  (The hydrogen system is not among them: the electrolyser clamp MGR:160-180 and the fuel cell's draw on the tank,
+# capped by the EV load HYD:409-430, both look at the station sums.)
+TEL_EXO = [5, 16, 17, 18]               # total_mass_need, re_pv_power, re_wd_power, price_next
+
+
+def _check_tail(v, g, i, name, n_envs, what):
+    """observation / reward / done / telemetry of the production tail against the reference's record of step i"""
+    o64, r64, tel = v.obs_f64(), v.reward_f64(), v.telemetry()
+    D = o64.shape[1]
+    want_o, want_t = g["obs"][i], g["telem"][i]
+    # observation layout (MGR:364-373): [sin t, price, {min, charge, max, line / 5} per station with piles, H2 SOC, pv, wd]
+    exact_cols = [0, 1, D - 2, D - 1] + [c for c in range(2, D - 3) if (c - 2) % 4 == 3]
+    for e in range(n_envs):
+        assert np.allclose(o64[e, exact_cols], want_o[exact_cols], rtol=TIGHT, atol=TIGHT), (name, what, "obs (exogenous, price, queues)", o64[e], want_o)
+        assert np.allclose(o64[e], want_o, rtol=1e-5, atol=2e-6), (name, what, "obs", o64[e], want_o)
+        assert np.allclose(r64[e], g["reward"][i], rtol=1e-5, atol=2e-6), (name, what, "reward", r64[e], g["reward"][i])
+        assert np.array_equal(tel[e, 19:22], want_t[19:22]), (name, what, "fcev ints", tel[e, 19:22], want_t[19:22])
+        assert np.allclose(tel[e, TEL_EXO], want_t[TEL_EXO], rtol=TIGHT, atol=TIGHT), (name, what, "telemetry (exogenous)", tel[e], want_t)
+        assert np.allclose(tel[e, :19], want_t[:19], rtol=1e-5, atol=2e-5), (name, what, "telemetry", tel[e, :19], want_t[:19])
 
 
 @pytest.mark.parametrize("name", ["env_c5_random", "env_big_100_70", "env_small_fast_neg"])
@@ -77,8 +108,15 @@ def test_large_tile_replays_reference_fixture(name):
     test_packed_kernel_replays_reference_fixture(name, tile="large")
 
 
+@pytest.mark.parametrize("name", [n for n in ALL_FIXTURES if n != "env_big_100_70"])  # (stations of more than 64 piles never take the one-launch form)
+def test_single_launch_step_replays_reference_fixture(name):
+    """the same replay with the steps as ONE launch (k_step_fused<.., TAPE>: slot body, station records and the tails of the workgroup's
+    envs in one kernel) -- what every PHILOX batch of up to 384 slot workgroups runs"""
+    test_packed_kernel_replays_reference_fixture(name, fused="on")
+
+
 @pytest.mark.parametrize("name", ALL_FIXTURES)
-def test_packed_kernel_replays_reference_fixture(name, tile="small"):
+def test_packed_kernel_replays_reference_fixture(name, tile="small", fused="off"):
     """Every reference fixture through the production kernel, evs_reset included: the k_slot_packed instantiations for steps and
     resets, stations of up to 64 piles and beyond (BIG: env_big_100_70), a station without piles (env_c2_random,
     env_slow_only_fcev), a 3-pile hub whose reset records a negative flow_in (env_small_fast_neg)."""
@@ -90,10 +128,14 @@ def test_packed_kernel_replays_reference_fixture(name, tile="small"):
     kw = dict(station_list=piles, station_type_list=["fast" if t == 0 else "slow" for t in types], constant_charging=cp,
               hydro_prod_rate=float(g["kw_hydro_prod_rate"]), hydro_store_vlt=float(g["kw_hydro_store_vlt"]),
               init_soc=float(g["kw_init_soc"]), fc_max_power=float(g["kw_fc_max_power"]),
-              fcev_permeate=float(g["kw_fcev_permeate"]))
+              fcev_permeate=float(g["kw_fcev_permeate"]), renew_fluctuate=float(g["kw_renew_fluctuate"]),
+              price_fluctuate=float(g["kw_price_fluctuate"]), hydro_loss=float(g["kw_hydro_loss"]))
     n_envs = 3                                                   # every env replays the same tape
-    v = chub.VecChargingHub(n_envs, seed=1, rng="philox", slot_kernel="packed", tile=tile, fused_step="off" if tile == "large" else "auto", **kw)
-    assert v.uses_packed_kernel
+    v = chub.VecChargingHub(n_envs, seed=1, rng="philox", slot_kernel="packed", tile=tile, fused_step=fused, **kw)
+    assert v.uses_packed_kernel and v.uses_fused_step == (fused == "on")
+    v.set_telemetry(True)
+    v.set_hy_table(g["hy_table"])                                # hy_power_speed_list as the reference's constructor built it (HYD:154-157)
+    hv_w = 1 + g["hv_soc"].shape[1]
     S0, S1 = piles
     S = S0 + S1
     levels = _levels()
@@ -111,6 +153,9 @@ def test_packed_kernel_replays_reference_fixture(name, tile="small"):
         cls_of = {np.float32(s).tobytes(): int(i) for s, i in zip(socs, ids)}
     rep = lambda a: np.repeat(np.asarray(a)[None], n_envs, axis=0)
     steps = int(g["steps_per_episode"])
+    S_ = sum(piles)
+    # the reference's constructor runs one reset() (MGR:120): its exogenous draws shape the OU states the first episode starts from
+    v.reset_tape(np.zeros((2, n_envs), dtype=np.uint32), np.zeros((n_envs, S_, 2), dtype=np.uint32), rep(g["ctor_days"]), rep(g["ctor_z"]))
 
     def compare(cur, st, what):
         sl = v.slots()
@@ -150,8 +195,9 @@ def test_packed_kernel_replays_reference_fixture(name, tile="small"):
                 car[off + s] = [cls_of[np.float32(prev[k][5, s]).tobytes()], lev | (late << 16)]
                 n_new += 1
         if name == "env_constant" and ep == 0:
-            # (the other way in, kept covered: a Philox reset overwritten through chub_set_slots / chub_set_station_queue)
-            v.reset()
+            # (the other way in, kept covered: the slots of a reset overwritten through chub_set_slots / chub_set_station_queue; the tail's
+            # side of the reset -- days, OU states, tank -- from the tape all the same, on an empty hub)
+            v.reset_tape(np.zeros((2, n_envs), dtype=np.uint32), np.zeros((n_envs, S, 2), dtype=np.uint32), rep(g["reset_days"][ep]), rep(g["reset_z"][ep]))
             rows = np.full((S, 6), -1, dtype=np.int32)
             for k, off, n in ((0, 0, S0), (1, S0, S1)):
                 for s in np.nonzero(prev[k][0] > 0.5)[0]:
@@ -160,8 +206,17 @@ def test_packed_kernel_replays_reference_fixture(name, tile="small"):
             v.set_slots(rep(rows))
             v.set_station_queue(rep([int(rst[4]), int(rst[10])]))
         else:
-            v.reset_tape(occ, rep(car))
+            v.reset_tape(occ, rep(car), rep(g["reset_days"][ep]), rep(g["reset_z"][ep]))
             compare(prev, rst, ("reset", ep))
+        o64 = v.obs_f64()
+        D_ = o64.shape[1]
+        cols = [0, 1, D_ - 3, D_ - 2, D_ - 1] + [c for c in range(2, D_ - 3) if (c - 2) % 4 == 3]
+        via_set_slots = name == "env_constant" and ep == 0     # (the reset there ran on an empty hub: only the columns no station reaches)
+        if via_set_slots:
+            cols = [0, 1, D_ - 3, D_ - 2, D_ - 1]
+        for e in range(n_envs):
+            assert np.allclose(o64[e, cols], g["reset_obs"][ep][cols], rtol=TIGHT, atol=TIGHT), (name, "reset obs", ep, o64[e], g["reset_obs"][ep])
+            assert via_set_slots or np.allclose(o64[e], g["reset_obs"][ep], rtol=1e-5, atol=2e-6), (name, "reset obs", ep, o64[e], g["reset_obs"][ep])
         line = [int(rst[4]), int(rst[10])]
         for t in range(steps):
             cur = [g["slots0"][i], g["slots1"][i]]
@@ -177,8 +232,13 @@ def test_packed_kernel_replays_reference_fixture(name, tile="small"):
                     car[off + s] = [cls_of[np.float32(cur[k][5, s]).tobytes()], lev | (late << 16)]
                     n_new += 1
                 line[k] = line_after
-            v.step_tape(rep(g["action"][i]), pk, rep(car))
+            hv = np.zeros(hv_w, dtype=np.uint32)
+            hv[0] = int(g["telem"][i][19])                      # hvs.arrive_number
+            hv[1:1 + hv[0]] = g["hv_soc"][i][:hv[0]].view(np.uint32)
+            _, _, done = v.step_tape(rep(g["action"][i]), pk, rep(car), rep(g["exo_z"][i]), rep(hv))[:3]
             compare(cur, st, (ep, t))
+            assert all(bool(d) == bool(g["done"][i]) for d in done)
+            _check_tail(v, g, i, name, n_envs, (ep, t))
             prev = cur
             i += 1
     assert n_new > 40                                            # the tape really admitted cars
