@@ -104,7 +104,8 @@ def cpu_baseline(hub_kw, total_envs, target_seconds=12.0):
     import orclib
     from orclib import orc, ptr
 
-    cores = min(len(os.sched_getaffinity(0)), 16)  # a one-GPU box's CPU share
+    host_cores = len(os.sched_getaffinity(0))
+    cores = min(host_cores, 16)  # threads used: a one-GPU box's CPU share is 16 (the pool's process guard sizes worker pools to it)
     cfg = orclib.make_config(piles=hub_kw["station_list"], types=hub_kw["station_type_list"], hydro_prod_rate=100.0,
                              hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=hub_kw["fcev_permeate"])
     D = orc.orc_env_obs_dim(C.byref(cfg))
@@ -135,9 +136,9 @@ def cpu_baseline(hub_kw, total_envs, target_seconds=12.0):
     if n == total_envs:  # whole workload fits: add whole episodes until the sample is ~target_seconds long
         steps = 96 * max(1, min(4, int(round(rate * target_seconds / (n * 96.0)))))
     rate = run(n, steps)
-    out = {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
-           "sample": "%d envs x %d steps of the same hub (oracle/chub_oracle.c, Philox streams, %d pthreads)"
-                     % (n, steps, cores)}
+    out = {"value": rate, "unit": "env-steps/s", "cores": cores, "host_cores": host_cores, "kind": "port",
+           "sample": "%d envs x %d steps of the same hub (oracle/chub_oracle.c, Philox streams, %d pthreads = min(the %d cores this "
+                     "process may run on, the 16 of a one-GPU box's CPU share))" % (n, steps, cores, host_cores)}
     ref = reference_stations_rate(hub_kw)
     if ref:
         out["reference_stations"] = ref
@@ -288,10 +289,25 @@ def profiled_days(v, span, first_step):
     return slot_ms / n_prof * 1e3, env_ms / n_prof * 1e3, n_prof, wall / n
 
 
-def roofline_block(slot_us, env_us, slot_b, env_b, per, traffic, traffic_src, n_prof, window):
+def layout_bytes(S):
+    """What THIS build's layout must move per env and slot-kernel launch: per charger slot 4 B of state read + 4 B
+    written + 4 B of action row; per (station, env) unit the 16-byte record written + the 4 decoded-draw bytes read; per env the two
+    tail actions handed over (8 B).  The class-table rows are read-only tables (L2-resident), excluded like SURVEY 8(d)'s tables."""
+    return 12 * S + 2 * (16 + 4) + 8
+
+
+def roofline_block(slot_us, env_us, slot_b, env_b, per, traffic, traffic_src, n_prof, window, S=None, cache_resident=True):
     achieved = slot_b * per / (slot_us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": "k_slot_packed", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    lay = layout_bytes(S) * per if S is not None else None
+    # `bound` keeps the contract's vocabulary: the roofline the kernel is priced against (`peak`).  `limited_by`: what the counters say
+    # limits it (DESIGN.md 6.3) -- at the cache-resident headline size VALU issue and memory latency share the time (SQ_WAIT_ANY 50 %
+    # of the wave cycles, the streams come from the Infinity Cache); beyond the 256 MB Infinity Cache the streams come from HBM
+    return {"bound": "hbm", "limited_by": "latency/issue (cache-resident streams)" if cache_resident else "hbm",
+            "kernel": "k_slot_packed", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            # the layout's own compulsory bytes per launch and the fraction of the roofline they come to: how much is left to gain
+            # by moving bytes faster (the contract's `frac` prices SURVEY 8(d)'s 36 B per slot, which this layout no longer moves)
+            "layout_bytes_per_launch": lay, "frac_of_layout": (lay / (slot_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if lay else None,
             # the bytes the counters saw move per launch over the same duration (L2's memory side; Infinity-Cache hits included):
             # what the kernel really streams, next to the algorithmic figure the fraction is made of
             "traffic_GBps": (traffic / (slot_us * 1e-6) / 1e9) if traffic else None,
@@ -330,7 +346,8 @@ def c5_roofline(chub, multi_gpu, lib, device, build_id):
     slot_b, env_b = algorithmic_bytes(S, D)
     traffic, src = measured_traffic(build_id, n, n, kw["station_list"])
     out = roofline_block(slot_us, env_us, slot_b, env_b, n, traffic, src, n_prof,
-                         "%d whole days after one warm-up day, every %dth step sampled: each slot of the day once" % (PROFILE_DAYS, PROFILE_DAYS))
+                         "%d whole days after one warm-up day, every %dth step sampled: each slot of the day once" % (PROFILE_DAYS, PROFILE_DAYS),
+                         S=S, cache_resident=False)
     out["workload"] = "%d envs x hub [%d fast, %d slow] (BASELINE.json configs[4] on one GPU), renew / price fluctuate 0.3" % (
         n, kw["station_list"][0], kw["station_list"][1])
     out["state_bytes"] = n * S * 4  # one 32-bit word per charger slot
@@ -473,6 +490,26 @@ def dropin_block(chub, multi_gpu, lib, device):
         o = obs.to_host(np.float32, (n, D), st.ptr)
         assert np.isfinite(o).all()
         rates[str(n)] = {"value": n * 192 / dt, "unit": "env-steps/s", "ms_per_step": dt / 192 * 1e3}
+        if n == 65536:
+            # the reference-exact mode against the same roofline: SURVEY 8(d) bytes over the day averages of its launches (the dispatch
+            # timestamps span k_compat_walk -> k_slot_split, and k_env<COMPAT>), every 5th step of 5 days: each slot of the day once
+            v.profile_begin(96, every=PROFILE_DAYS)
+            for _ in range(PROFILE_DAYS):
+                day()
+            slot_ms, env_ms, k = v.profile_end()
+            assert k == 96
+            slot_b, env_b = algorithmic_bytes(v.n_slots, D)
+            slot_us, env_us = slot_ms / k * 1e3, env_ms / k * 1e3
+            ach = (slot_b + env_b) * n / ((slot_us + env_us) * 1e-6) / 1e9
+            out["roofline_compat"] = {
+                "what": "the reference-exact COMPAT step (the reference's own glibc rand() / minstd_rand0 streams walked per env, the charge curves "
+                        "evaluated in f64 in the reference's order) at the headline size, priced like `roofline_step`",
+                "bound": "hbm", "limited_by": "valu (f64 curve evaluation) + issue (the serial stream walk, one wave per SIMD)",
+                "kernels": "k_compat_walk + k_slot_split (one pair of dispatch timestamps) + k_env<COMPAT>",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_step": (slot_b + env_b) * n, "walk_and_slot_pass_us": slot_us, "env_kernel_us": env_us,
+                "launches_sampled": k, "frac_call_by_call": (slot_b + env_b) * n / (dt / 192) / 1e9 / HBM_PEAK_GBS,
+                "workload": "%d envs x hub [20 fast, 25 slow], COMPAT streams, device-resident actions and normals, call by call" % n}
         v.close()
         for b in acts + zs + [days, obs, rew, done]:
             b.free()
@@ -706,18 +743,25 @@ def main():
     # timed region, the rank's own wall clock per step -- gathered to rank 0 through the communicator
     phases = None
     if comm is not None:
-        g_us = comm.gather_us(packed[0].ptr, gathered[0].ptr if rank == 0 else 0, per * row, stream.ptr, reps=100)
-        mine = np.array([rank, slot_us, env_us, g_us, t_issue / steps * 1e6, dt_local / steps * 1e6], dtype=np.float64)
-        d_mine = multi_gpu.DeviceBuffer(mine.nbytes, local_rank)
-        d_everyone = multi_gpu.DeviceBuffer(mine.nbytes * world, local_rank) if rank == 0 else None
-        d_mine.from_host(mine, stream.ptr)
-        comm.gather(d_mine.ptr, d_everyone.ptr if d_everyone else 0, mine.nbytes, stream.ptr)
-        if rank == 0:
-            phases = d_everyone.to_host(np.float64, (world, mine.size), stream.ptr)
-            d_everyone.free()
-        else:
-            stream.sync()
-        d_mine.free()
+        # (a rank that fails in here leaves the others inside a collective that never completes: it says so and exits non-zero at once,
+        # and the launcher -- this file's, or torch.distributed.run -- stops the rest instead of waiting for its timeout)
+        try:
+            g_us = comm.gather_us(packed[0].ptr, gathered[0].ptr if rank == 0 else 0, per * row, stream.ptr, reps=100)
+            mine = np.array([rank, slot_us, env_us, g_us, t_issue / steps * 1e6, dt_local / steps * 1e6], dtype=np.float64)
+            d_mine = multi_gpu.DeviceBuffer(mine.nbytes, local_rank)
+            d_everyone = multi_gpu.DeviceBuffer(mine.nbytes * world, local_rank) if rank == 0 else None
+            d_mine.from_host(mine, stream.ptr)
+            comm.gather(d_mine.ptr, d_everyone.ptr if d_everyone else 0, mine.nbytes, stream.ptr)
+            if rank == 0:
+                phases = d_everyone.to_host(np.float64, (world, mine.size), stream.ptr)
+                d_everyone.free()
+            else:
+                stream.sync()
+            d_mine.free()
+        except Exception as exc:  # noqa: BLE001
+            sys.stderr.write("bench.py rank %d: the per-phase block failed (%s): exiting 1 so that the launcher stops the other ranks\n" % (rank, exc))
+            sys.stderr.flush()
+            os._exit(1)
 
     if rank == 0:
         value = total * steps / dt
@@ -726,7 +770,7 @@ def main():
         roofline = None
         if n_prof and v_fused:  # ONE kernel does the whole step: it is priced with the whole step's bytes
             achieved = (slot_b + env_b) * per / (slot_us * 1e-6) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_step_fused", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"bound": "hbm", "limited_by": "launch + latency", "kernel": "k_step_fused", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                         "algorithmic_bytes_per_launch": (slot_b + env_b) * per, "avg_launch_us": slot_us, "launches_sampled": n_prof,
                         "window": "%d whole untimed days after the timed region, every %dth step sampled: each slot of the day once, kernels back to back" % (PROFILE_DAYS, PROFILE_DAYS),
@@ -734,7 +778,8 @@ def main():
         elif n_prof:
             traffic, traffic_src = measured_traffic(build_id, per, total, hub_kw["station_list"])
             roofline = roofline_block(slot_us, env_us, slot_b, env_b, per, traffic, traffic_src, n_prof,
-                                      "%d whole untimed days after the timed region, every %dth step sampled: each slot of the day once, kernels back to back" % (PROFILE_DAYS, PROFILE_DAYS))
+                                      "%d whole untimed days after the timed region, every %dth step sampled: each slot of the day once, kernels back to back" % (PROFILE_DAYS, PROFILE_DAYS),
+                                      S=S, cache_resident=per * S * 8 + per * A * 4 <= 256 << 20)
         step_achieved = (slot_b + env_b) * total / (dt / steps) / 1e9 / world  # per GPU
         d0, s0 = divmod(warmup, 96)
         d1, s1 = divmod(warmup + steps - 1, 96)
@@ -802,6 +847,8 @@ def main():
             out["packed_actions"] = packed_actions_block(chub, multi_gpu, lib, local_rank)
         if world == 1 and config == "c4" and not args.no_dropin and not args.no_c5 and not args.no_events:
             out["dropin_single_env"] = dropin_block(chub, multi_gpu, lib, local_rank)
+            if "roofline_compat" in out["dropin_single_env"]:
+                out["roofline_compat"] = out["dropin_single_env"].pop("roofline_compat")
         if not args.no_cpu_baseline and world == 1 and config == "c4":
             out["cpu_baseline"] = cpu_baseline(hub_kw, total)
         print(json.dumps(out))

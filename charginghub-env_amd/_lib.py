@@ -127,7 +127,10 @@ def load_library():
         try:
             fn = getattr(lib, name)  # AttributeError here == ABI drift between chub.h and the library
         except AttributeError:
-            if os.environ.get("CHUB_LIB"):  # an older build loaded on purpose (A/B timing): it simply lacks the newer entry points
+            if os.environ.get("CHUB_LIB"):  # an older build loaded on purpose (A/B timing): it lacks the newer entry points --
+                def missing(*_a, _name=name, _path=path):  # ... and says so where one of them is first used
+                    raise ChubError("%s is not exported by the library CHUB_LIB names (%s): an older build" % (_name, _path))
+                setattr(lib, name, missing)
                 continue
             raise
         fn.restype = res

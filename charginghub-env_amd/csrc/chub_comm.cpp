@@ -183,9 +183,12 @@ int chub_comm_gather_timed(chub_comm *c, const void *d_send, void *d_recv, int64
     if (!c || !us_per_gather || reps <= 0) return comm_fail(CHUB_ERR_ARG, "bad argument");
     hipStream_t s = (hipStream_t) stream;
     HIPC_TRY(hipSetDevice(c->device));
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPC_TRY(hipEventCreate(&e0));
-    HIPC_TRY(hipEventCreate(&e1));
+    if (hipEventCreate(&e1) != hipSuccess) {
+        (void) hipEventDestroy(e0);
+        return comm_fail(CHUB_ERR_HIP, "hipEventCreate failed");
+    }
     int rc = chub_comm_gather(c, d_send, d_recv, bytes, stream);  // one untimed: connections set up, buffers touched
     if (!rc && hipEventRecord(e0, s) != hipSuccess) rc = comm_fail(CHUB_ERR_HIP, "hipEventRecord failed");
     for (int i = 0; i < reps && !rc; i++) rc = chub_comm_gather(c, d_send, d_recv, bytes, stream);

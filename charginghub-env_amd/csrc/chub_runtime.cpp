@@ -111,7 +111,11 @@ struct chub_env {
     float *h_tail, *d_tail;       //                 [N][2]
     float *d_packed;              // [N][D+2]
     double *h_telem;    // telemetry block in pinned host memory, written by the tail kernel directly: telem [T][N], obs64 [N][D], reward64 [N]
+                        // (handles of a few envs: the drop-in class); larger handles keep the block in device memory:
+    double *d_telem = nullptr;
     int tape_classes;   // PHILOX tape mode: caller-registered arrival-SoC classes so far
+    bool tape_stale = false;  // chub_tape_clear_soc since the last reset: the slots may hold cars of classes that are gone
+    bool tape_only = false;  // ... and once there are any, the handle's class rows are the caller's: only tape resets / steps may admit cars
     uint32_t h_late8[8];
     double h_sin96[96];
     std::vector<float> h_cls[2], h_soc0[2], h_ttab[2];  // host copies of the class tables (introspection)
@@ -844,6 +848,7 @@ int chub_destroy(chub_env *e) {
             if (ev) (void) hipEventDestroy(ev);
         if (e->h_packed) (void) hipHostFree(e->h_packed);
         if (e->h_telem) (void) hipHostFree(e->h_telem);
+        if (e->d_telem) (void) hipFree(e->d_telem);
         if (e->h_bits) (void) hipHostFree(e->h_bits);  // h_tail / d_tail are the ends of the same blocks
         if (e->d_bits) (void) hipFree(e->d_bits);
         if (e->d_packed) (void) hipFree(e->d_packed);
@@ -1018,6 +1023,8 @@ static int reset_masked(chub_env *e, const uint8_t *mask, const int32_t *d_exo_d
     if (!e || !d_obs) return fail(CHUB_ERR_ARG, "null argument");
     if (e->hp.rng_mode == CHUB_RNG_COMPAT && (!d_exo_days || !d_exo_z))
         return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_days and exo_z");
+    if (e->tape_only && !e->tape_car)
+        return fail(CHUB_ERR_ARG, "a handle with registered tape classes resets through chub_reset_tape / chub_reset_tape_env only");
     HIP_TRY(hipSetDevice(e->device));
     (void) hipGetLastError();  // a stale error of an earlier, unrelated call must not be reported as this step's
     hipStream_t s = (hipStream_t) stream;
@@ -1191,6 +1198,9 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
 static int step_masked(chub_env *e, const uint8_t *mask, const float *d_actions, const double *d_exo_z, float *d_obs, int obs_stride,
                        float *d_reward, int reward_stride, uint8_t *d_done, float *d_done_f32, void *stream, int load_mode) {
     if (e->tick == 0) return fail(CHUB_ERR_ARG, "step() before reset()");
+    if (e->tape_only && !e->tape_pk)
+        return fail(CHUB_ERR_ARG, "a handle with registered tape classes steps through chub_step_tape / chub_step_tape_env only (its class "
+                                  "rows hold the caller's arrival SoCs: cars admitted by this build's own draws would be given them)");
     if (e->hp.rng_mode == CHUB_RNG_COMPAT && !d_exo_z) return fail(CHUB_ERR_ARG, "COMPAT mode needs exo_z");
     HIP_TRY(hipSetDevice(e->device));
     (void) hipGetLastError();  // a stale error of an earlier, unrelated call must not be reported as this step's
@@ -1439,6 +1449,9 @@ int chub_host_bits(chub_env *e, uint64_t **bits_out, float **tail_out) {
 static int step_bits_device(chub_env *e, const uint64_t *d_pile_bits, const float *d_tail, const double *d_exo_z, float *d_obs,
                             float *d_reward, uint8_t *d_done, float *d_packed, void *stream) {
     if (e->tick == 0) return fail(CHUB_ERR_ARG, "step() before reset()");
+    if (e->tape_only && !e->tape_pk)
+        return fail(CHUB_ERR_ARG, "a handle with registered tape classes steps through chub_step_tape / chub_step_tape_env only (its class "
+                                  "rows hold the caller's arrival SoCs: cars admitted by this build's own draws would be given them)");
     HIP_TRY(hipSetDevice(e->device));
     const int D = e->hp.obs_dim;
     const float *rows = nullptr;
@@ -1744,6 +1757,20 @@ int chub_tape_register_soc(chub_env *e, const float *soc, int32_t count, uint32_
     const bool cp = e->hp.constant_charging != 0;
     std::vector<float> rows((size_t) count * kClsRow * 2);
     const size_t first = (size_t) e->tape_classes;
+    for (int k = 0; k < 2; k++) {  // (checked for the whole batch before anything is overwritten)
+        const bool fast = e->hp.type[k] == CHUB_FAST;
+        float tt_max = 0.0f;
+        for (float t : e->h_ttab[k]) tt_max = t > tt_max ? t : tt_max;
+        for (int i = 0; i < count; i++) {
+            // stay_time = ceil(soc_to_time(target) - soc_to_time(soc)) + late (late <= 15) must fit the state word's 5-bit fields, as
+            // chub_create checks for the build's own classes: an arrival SoC whose stay could not is refused, not clamped
+            float row[kClsRow * 2];
+            build_class_row(fast, cp, e->hp.cc, soc[i], row);
+            if (!(soc[i] >= 0.0f && soc[i] <= 100.0f) || (int) ceilf(tt_max - row[1]) + 15 > 31)
+                return fail(CHUB_ERR_ARG, "chub_tape_register_soc: an arrival SoC whose stay could exceed 31 slots (or outside 0 .. 100)");
+        }
+    }
+    e->tape_only = e->tape_only || count > 0;
     for (int k = 0; k < 2; k++) {
         const bool fast = e->hp.type[k] == CHUB_FAST;
         for (int i = 0; i < count; i++) build_class_row(fast, cp, e->hp.cc, soc[i], &rows[(size_t) i * kClsRow * 2]);
@@ -1761,7 +1788,13 @@ int chub_tape_register_soc(chub_env *e, const float *soc, int32_t count, uint32_
 
 int chub_tape_clear_soc(chub_env *e) {
     if (!e) return fail(CHUB_ERR_ARG, "null handle");
-    e->tape_classes = 0;  // the next chub_tape_register_soc starts at class 0 again (the slots must not hold cars of the old classes)
+    // the next chub_tape_register_soc starts at class 0 again.  Cars of the old classes still in their slots would be re-read against the
+    // new rows: the caller clears between episodes, right in front of the chub_reset_tape that wipes every slot (evs_reset, CHS.hpp:1209-1231),
+    // and chub_step_tape refuses to run until that reset has happened
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    e->tape_classes = 0;
+    e->tape_stale = true;
     return CHUB_OK;
 }
 
@@ -1828,6 +1861,7 @@ int chub_step_tape_env(chub_env *e, const float *actions, const uint64_t *pk_tap
     if (e->hp.rng_mode != CHUB_RNG_PHILOX || !e->hp.packed)
         return fail(CHUB_ERR_ARG, "tape mode drives the packed PHILOX slot kernel: the hub shape must be one it covers");
     if ((exo_z != nullptr) != (hv_tape != nullptr) || (hv_tape && hv_w < 1)) return fail(CHUB_ERR_ARG, "the tail's tape is exo_z [N][3] AND hv_tape [N][hv_w >= 1]");
+    if (e->tape_stale) return fail(CHUB_ERR_ARG, "chub_tape_clear_soc was called: reset (chub_reset_tape) before the next tape step");
     HIP_TRY(hipSetDevice(e->device));
     const size_t N = (size_t) e->hp.n_envs, S = (size_t) (e->hp.S[0] + e->hp.S[1]);
     uint32_t *d_hv = nullptr;
@@ -1929,6 +1963,7 @@ int chub_reset_tape_env(chub_env *e, const uint32_t *occ_tape, const uint32_t *c
     e->tape_car = nullptr;
     e->tape_tail = false;
     if (rc) return done_(rc);
+    e->tape_stale = false;  // evs_reset has wiped every slot
     if (hipMemcpy(obs, e->d_obs, N * (size_t) e->hp.obs_dim * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
         return done_(fail(CHUB_ERR_HIP, "hipMemcpy failed"));
     return done_(CHUB_OK);
@@ -2043,16 +2078,36 @@ int chub_get_station_scalars(chub_env *e, double *out) {
 int chub_set_telemetry(chub_env *e, int enabled) {
     if (!e) return fail(CHUB_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(e->device));
-    if (enabled && !e->h_telem) {
-        // one block of pinned host memory, mapped into the device's address space: the tail kernel's telemetry stores cross PCIe
-        // as posted writes while it runs, and reading them back is a host read -- no device read per step for the drop-in class
+    if (enabled && !e->h_telem && !e->d_telem) {
         const size_t N = (size_t) e->hp.n_envs, D = (size_t) e->hp.obs_dim;
         const size_t count = N * (size_t) kTelemCount + N * D + N;
-        HIP_TRY(hipHostMalloc((void **) &e->h_telem, count * sizeof(double), hipHostMallocDefault));
-        memset(e->h_telem, 0, count * sizeof(double));
-        void *dv = nullptr;
-        if (!device_view(e->h_telem, &dv)) return fail(CHUB_ERR_HIP, "pinned telemetry block is not visible to the device");
-        e->ev.telem = (double *) dv;
+        double *base = nullptr;
+        if (N * (size_t) e->hp.act_dim * sizeof(float) <= 16384) {
+            // handles of a few envs (the bound chub_step uses for reading the caller's arrays in place: the drop-in class): one block of
+            // pinned host memory, mapped into the device's address space -- the tail kernel's telemetry stores cross PCIe as posted
+            // writes while it runs, and reading them back is a host read: no device read per step
+            HIP_TRY(hipHostMalloc((void **) &e->h_telem, count * sizeof(double), hipHostMallocDefault));
+            memset(e->h_telem, 0, count * sizeof(double));
+            void *dv = nullptr;
+            if (!device_view(e->h_telem, &dv)) {
+                (void) hipHostFree(e->h_telem);
+                e->h_telem = nullptr;
+                return fail(CHUB_ERR_HIP, "pinned telemetry block is not visible to the device");
+            }
+            base = (double *) dv;
+        } else {
+            // a batch: 27 MB per step at 65 536 envs would stall the tail on posted PCIe writes -- the block stays in HBM (outside the
+            // arena: a snapshot does not carry it) and the getters copy
+            HIP_TRY(hipMalloc((void **) &e->d_telem, count * sizeof(double)));
+            hipError_t he = hipMemset(e->d_telem, 0, count * sizeof(double));
+            if (he != hipSuccess) {
+                (void) hipFree(e->d_telem);
+                e->d_telem = nullptr;
+                return fail(CHUB_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(he));
+            }
+            base = e->d_telem;
+        }
+        e->ev.telem = base;
         e->ev.obs64 = e->ev.telem + N * (size_t) kTelemCount;
         e->ev.reward64 = e->ev.obs64 + N * D;
     }
@@ -2062,7 +2117,7 @@ int chub_set_telemetry(chub_env *e, int enabled) {
 }
 
 static int need_telemetry(chub_env *e) {
-    if (!e->h_telem) return fail(CHUB_ERR_ARG, "telemetry is off: call chub_set_telemetry(env, 1) first");
+    if (!e->h_telem && !e->d_telem) return fail(CHUB_ERR_ARG, "telemetry is off: call chub_set_telemetry(env, 1) first");
     return 0;
 }
 
@@ -2070,6 +2125,9 @@ int chub_telemetry_host(chub_env *e, double **telem, double **obs64, double **re
     if (!e || !telem || !obs64 || !reward64) return fail(CHUB_ERR_ARG, "null argument");
     int rc = need_telemetry(e);
     if (rc) return rc;
+    if (!e->h_telem)
+        return fail(CHUB_ERR_UNSUPPORTED, "the telemetry block of a handle of this size lives in device memory: read it with chub_get_telemetry / "
+                                          "chub_get_obs_f64 / chub_get_reward_f64");
     const size_t N = (size_t) e->hp.n_envs, D = (size_t) e->hp.obs_dim;
     *telem = e->h_telem;
     *obs64 = e->h_telem + N * (size_t) kTelemCount;
@@ -2077,14 +2135,23 @@ int chub_telemetry_host(chub_env *e, double **telem, double **obs64, double **re
     return CHUB_OK;
 }
 
-int chub_get_telemetry(chub_env *e, double *out) {
-    if (!e || !out) return fail(CHUB_ERR_ARG, "null argument");
+// `count` doubles of the telemetry block from `offset` on, wherever the block lives (the work in flight is waited for)
+static int telem_fetch(chub_env *e, size_t offset, size_t count, double *dst) {
     int rc = need_telemetry(e);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
+    if (e->h_telem) memcpy(dst, e->h_telem + offset, count * sizeof(double));
+    else HIP_TRY(hipMemcpy(dst, e->d_telem + offset, count * sizeof(double), hipMemcpyDeviceToHost));
+    return CHUB_OK;
+}
+
+int chub_get_telemetry(chub_env *e, double *out) {
+    if (!e || !out) return fail(CHUB_ERR_ARG, "null argument");
     const size_t N = (size_t) e->hp.n_envs;
-    const double *t = e->h_telem;
+    std::vector<double> t(N * (size_t) kTelemCount);
+    int rc = telem_fetch(e, 0, t.size(), t.data());
+    if (rc) return rc;
     for (size_t env = 0; env < N; env++)
         for (int i = 0; i < kTelemCount; i++) out[env * kTelemCount + i] = t[(size_t) i * N + env];
     return CHUB_OK;
@@ -2092,24 +2159,14 @@ int chub_get_telemetry(chub_env *e, double *out) {
 
 int chub_get_obs_f64(chub_env *e, double *out) {
     if (!e || !out) return fail(CHUB_ERR_ARG, "null argument");
-    int rc = need_telemetry(e);
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t) e->hp.n_envs;
-    memcpy(out, e->h_telem + N * (size_t) kTelemCount, N * (size_t) e->hp.obs_dim * sizeof(double));
-    return CHUB_OK;
+    return telem_fetch(e, N * (size_t) kTelemCount, N * (size_t) e->hp.obs_dim, out);
 }
 
 int chub_get_reward_f64(chub_env *e, double *out) {
     if (!e || !out) return fail(CHUB_ERR_ARG, "null argument");
-    int rc = need_telemetry(e);
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t) e->hp.n_envs;
-    memcpy(out, e->h_telem + N * (size_t) kTelemCount + N * (size_t) e->hp.obs_dim, N * sizeof(double));
-    return CHUB_OK;
+    return telem_fetch(e, N * (size_t) kTelemCount + N * (size_t) e->hp.obs_dim, N, out);
 }
 
 int chub_set_rng_compat_seeds(chub_env *e, const uint32_t *seeds) {

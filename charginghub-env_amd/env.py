@@ -21,6 +21,7 @@ the host exactly where the reference makes them: ``random.randint`` for the PV /
 before construction means what it means for the reference.  ``rng='philox'`` uses the device generator.
 """
 import ctypes as C
+import os
 import random
 
 import numpy as np
@@ -274,7 +275,11 @@ class EvcsspManagerEnv_v6(object):
         self.cumulated_draw_ele = 0
 
     def seed(self, seed=None):
-        self.np_random = np.random.RandomState(seed if seed is not None else 0)
+        # MGR:132-134: `self.np_random, seed = seeding.np_random(seed); return [seed]` -- gym generates a seed when none is given and
+        # returns the one it used (the simulation itself never draws from np_random)
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "big")
+        self.np_random = np.random.RandomState(int(seed) % (1 << 32))
         return [seed]
 
     def set_compat_seeds(self, glibc_seed, minstd_seed):
@@ -306,7 +311,12 @@ class EvcsspManagerEnv_v6(object):
         self.re_wd_power = tel[17]
         self.state = np.array(self._obs64)
 
+    def _live(self):
+        if self.__dict__.get("_h") is None:
+            raise _lib.ChubError("this EvcsspManagerEnv_v6 has been closed (its libchub handle and pinned buffers are gone)")
+
     def reset(self):
+        self._live()
         self.cumulated_income = 0
         self.cumulated_draw_ele = 0
         self.real_state = []
@@ -327,6 +337,7 @@ class EvcsspManagerEnv_v6(object):
         return np.array(self.state)
 
     def step(self, action):
+        self._live()
         S = self._S
         if action is None:  # MGR:146-147
             action = np.append(np.ones(S), [0, 0], None)
@@ -383,7 +394,10 @@ class EvcsspManagerEnv_v6(object):
         # every telemetry column of the last step by name (env._t_Store_SOC, env._t_hy_use ...: _lib.TELEMETRY_NAMES), read from the
         # pinned block on demand, for scripts that want more than the reference exposes
         if name.startswith("_t_") and name[3:] in _lib.T:
-            return float(self.__dict__["_tel"][_lib.T[name[3:]]])
+            tel = self.__dict__.get("_tel")  # (absent while the constructor is still running, gone after close())
+            if tel is None:
+                raise AttributeError("%s: no telemetry block (the env is not constructed yet, or closed)" % name)
+            return float(tel[_lib.T[name[3:]]])
         raise AttributeError(name)
 
     @staticmethod
@@ -407,7 +421,12 @@ class EvcsspManagerEnv_v6(object):
         pass
 
     def close(self):
-        self._vec.close()
+        # the views and raw pointers into handle-owned pinned memory go first: after chub_destroy they would dangle
+        for name in ("_tel", "_obs64", "_rew64", "_p", "_h", "_act", "_z"):
+            self.__dict__[name] = None
+        vec = self.__dict__.get("_vec")
+        if vec is not None:
+            vec.close()
 
     def show_situation(self):
         return self._vec.slots()

@@ -261,8 +261,11 @@ int chub_get_telemetry(chub_env *env, double *out);
 int chub_get_obs_f64(chub_env *env, double *out);
 int chub_get_reward_f64(chub_env *env, double *out);
 int chub_set_telemetry(chub_env *env, int enabled); /* off by default: the hot path then skips those stores */
-/* The telemetry block lives in pinned host memory that the device writes directly (no copy back): *telem [CHUB_T_COUNT][N] (column-
+/* Handles of a few envs (action rows of at most 16 KB in all: the drop-in class runs ONE env) keep the telemetry block in pinned host
+ * memory that the device writes directly (no copy back): *telem [CHUB_T_COUNT][N] (column-
  * major: one row per CHUB_T_* index), *obs64 [N][D], *reward64 [N], all f64, owned by the handle, valid while telemetry stays on.
+ * Larger handles keep the block in device memory (posted PCIe writes of 27 MB per step at 65 536 envs would stall the tail kernel):
+ * CHUB_ERR_UNSUPPORTED here, chub_get_telemetry / chub_get_obs_f64 / chub_get_reward_f64 copy.
  * Contents are current once the call that produced them has completed (any host-pointer entry point returns completed; after a
  * device-pointer call: chub_sync / a stream synchronise).  This is how EvcsspManagerEnv_v6.step() reads everything the reference
  * class exposes after a step (MGR:183-297, 364-372) without one device read. */
@@ -326,8 +329,11 @@ int chub_stream_sync(int device, void *stream);
  * classes of the class table first.  tests/test_gpu_tape.py replays every reference fixture this way, evs_reset included.
  *   chub_tape_register_soc: soc[count] -> class_ids[count].  The caller's arrival SoCs take the place of the handle's own 2048
  *                          classes, first come first row (the slot state has 11 bits for the class), so a handle that registers
- *                          any is a tape handle from then on.  chub_tape_clear_soc starts over at class 0 (between episodes, once
- *                          no slot holds a car of the old classes).
+ *                          any is a tape handle from then on: chub_reset / chub_step and their device / masked / bits forms return
+ *                          CHUB_ERR_ARG on it (cars admitted by the build's own draws would be given the caller's SoCs).  An SoC outside
+ *                          0 .. 100, or one whose stay could exceed the state word's 31 slots, is refused.  chub_tape_clear_soc starts
+ *                          over at class 0 (between episodes): the next call must be the chub_reset_tape that wipes every slot --
+ *                          chub_step_tape returns CHUB_ERR_ARG until then.
  *   chub_set_slots:        rows [N][S][6] i32 in hub order (station 0's slots first): class (-1 = empty), target level,
  *                          stay_time (<= 31), already_stay_time, car_steps taken, charging flag.
  *   chub_set_station_queue: line [N][2] i32 (Station::line).

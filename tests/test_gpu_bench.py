@@ -33,6 +33,9 @@ def test_bench_short_form_prints_the_contract_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.2 < r["frac"] < 1.0 and r["launches_sampled"] == 96
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the layout's own compulsory bytes (12 B per slot + 48 B per env) next to SURVEY 8(d)'s, and what the counters say limits the kernel
+    assert r["layout_bytes_per_launch"] == 65536 * (12 * 45 + 48) and r["limited_by"].startswith("latency/issue")
+    assert abs(r["frac_of_layout"] - r["layout_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 8e12) < 1e-12 and r["frac_of_layout"] < r["frac"]
     # the day average does not depend on where the 20 timed steps fell: the same number the long default run reports (+- box noise)
     assert 15.0 < r["avg_launch_us"] < 30.0
     assert d["build_id"] and d["config"]["kernels_per_step"].startswith("2")

@@ -243,3 +243,35 @@ def test_packed_kernel_replays_reference_fixture(name, tile="small", fused="off"
             i += 1
     assert n_new > 40                                            # the tape really admitted cars
     v.close()
+
+
+def test_tape_handles_refuse_what_would_mix_the_two_sets_of_classes():
+    """a handle whose class rows hold the caller's arrival SoCs admits cars through the tape only; cleared classes need a reset first;
+    SoCs no stay of which fits the state word are refused"""
+    import charginghub_env_amd as chub
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2,
+              fc_max_power=100.0, fcev_permeate=0.01)
+    n = 2
+    v = chub.VecChargingHub(n, seed=1, rng="philox", slot_kernel="packed", **kw)
+    v.reset()                                                    # (a production handle until classes are registered)
+    v.step(np.zeros((n, v.act_dim), dtype=np.float32))
+    with pytest.raises(chub.ChubError):
+        v.tape_register_soc(np.array([50.0, -5.0], dtype=np.float32))
+    v.step(np.zeros((n, v.act_dim), dtype=np.float32))           # the refused batch changed nothing
+    ids = v.tape_register_soc(np.array([30.0, 50.0], dtype=np.float32))
+    assert list(ids) == [0, 1]
+    for call in (lambda: v.reset(), lambda: v.step(np.zeros((n, v.act_dim), dtype=np.float32)),
+                 lambda: v.step_bits(*v.pack_actions(np.zeros((n, v.act_dim), dtype=np.float32)))):
+        with pytest.raises(chub.ChubError):
+            call()
+    S = v.n_slots
+    occ, car, pk = np.zeros((2, n), dtype=np.uint32), np.zeros((n, S, 2), dtype=np.uint32), np.zeros((2, n), dtype=np.uint64)
+    v.reset_tape(occ, car)
+    v.step_tape(np.zeros((n, v.act_dim), dtype=np.float32), pk, car)
+    v.tape_clear_soc()
+    with pytest.raises(chub.ChubError):
+        v.step_tape(np.zeros((n, v.act_dim), dtype=np.float32), pk, car)
+    v.tape_register_soc(np.array([40.0], dtype=np.float32))
+    v.reset_tape(occ, car)
+    v.step_tape(np.zeros((n, v.act_dim), dtype=np.float32), pk, car)
+    v.close()
