@@ -111,8 +111,6 @@ struct StationArrays {       // unit index u = k*N + env
                                  // decoded one launch ahead against the queue the previous step left (dk_make): bits 0-7 queue after
                                  // the renege pass + arrivals that stay = the cars that want a slot, bits 8-15 flow_in.  For a reset:
                                  // the raw initial-occupancy draws of k_reset_levels (arrivals, signed 16 bits | arrivals that stay << 16)
-    CHUB_G(uint32_t) car_pre[2]; // PHILOX [2N][8], double-buffered like pk: add_car's variates of the first 8 cars a unit admits in a step (by
-                                 // admission rank), drawn one launch ahead with the unit's levels: class | target level << 11 | extra stay << 21
 };
 
 struct EnvArrays {           // index = env (or field*N + env)
@@ -220,7 +218,6 @@ struct PackedPtrs {
     uint32_t *hot, *rec;
     uint8_t *stay8;
     uint32_t *pk[2];
-    uint32_t *car_pre[2];
     const float *cls[2], *ttab[2], *ttab2;
     uint32_t late8[8];        // the first 8 thresholds of Tables::late_thr, passed to the packed kernel by value
     const Tables *tb;         // host copy of the table pointers

@@ -346,22 +346,6 @@ __device__ __forceinline__ uint32_t draw_decoded_levels(const HubParams &hp, con
 __device__ __forceinline__ int dk_want(uint32_t dk) { return (int) (dk & 255u); }
 __device__ __forceinline__ int dk_flow(uint32_t dk) { return (int) ((dk >> 8) & 255u); }
 
-// add_car's three variates (CHS.hpp:864-877 / 1029-1042) are ONE Philox block per new car -- word 0 arrival-SoC class, word 1 target
-// level, word 2 extra stay -- keyed by (station, admission rank): the cars a unit admits in a step, in ascending slot order
-// (assign_car, CHS.hpp:426-429).  Keyed like that (rounds 1-4: by the slot the car lands in) a step's blocks do not depend on where
-// the empty slots are, only on how many cars the unit may admit at most -- queue after the renege pass + arrivals that stay, which
-// the level draws know one launch ahead -- so the first kPreCars of a unit are computed THERE, in the issue slots the latency-bound
-// tail waves leave idle (StationArrays::car_pre, 4 bytes per car: class | level << 11 | extra stay << 21), and the slot kernel's
-// new-car pass -- 40 quarter-rate multiplies per car on the workgroup's critical path, 3 us of 20.7 at 65 536 envs by ablation --
-// becomes one 4-byte read.  Ranks beyond kPreCars, resets and fresh launches compute the same block in place.
-constexpr int kPreCars = 8;
-constexpr int kPreLdsWords = 1024;  // packed slot kernel: LDS for its units' predrawn cars (workgroups of up to 64 units; larger ones read the words where they are)
-__device__ __forceinline__ uint32_t car_index(int k, int rank) { return ((uint32_t) k << 9) | (uint32_t) rank; }
-__device__ __forceinline__ uint32_t car_word(uint32_t c, uint32_t lev, int late) { return c | (lev << 11) | ((uint32_t) late << 21); }
-__device__ __forceinline__ uint32_t cw_cls(uint32_t w) { return w & 2047u; }
-__device__ __forceinline__ uint32_t cw_lev(uint32_t w) { return (w >> 11) & 1023u; }
-__device__ __forceinline__ int cw_late(uint32_t w) { return (int) (w >> 21); }
-
 // ---------------------------------------------------------------------------------------- slot state
 // COMPAT keeps, per slot, the 16-byte hot record of SlotArrays (power, t_target, t_soc, meta) and evaluates the charge
 // curves in the step (the reference's streams make the arrival SoC a continuous value).
@@ -826,7 +810,7 @@ __device__ void slot_body_wave(const HubParams &hp, const StepArgs &sa, const Sl
     const bool adm = empty && rank < assign;
     if (adm) {  // add_car (CHS.hpp:864-877 / 1029-1042): one Philox block per new car, word 0 SoC class, 1 target level, 2 extra stay
         PhiloxCtx px{hp.key[0], hp.key[1], CHUB_TICK(hp, sa.tick), (uint32_t) (hp.env_id0 + env)};
-        const U4 o = px.block(SITE_SOC, car_index(k, rank), 0);  // keyed by (station, admission rank)
+        const U4 o = px.block(SITE_SOC, (uint32_t) hub_slot, 0);
         const uint32_t c = o.v[0] >> kSocLevelShift, lev = o.v[1] % 1000u;
         const f32x2 e0 = *(CHUB_G(const f32x2)) ((CHUB_G(const char)) cls + (size_t) c * (kClsRow * 8u));
         t_target = tb.ttab[k][lev];
@@ -1080,7 +1064,7 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
             meta = nc.stay | (nc.lev << 7);
         } else {
             PhiloxCtx px{hp.key[0], hp.key[1], CHUB_TICK(hp, sa.tick), (uint32_t) (hp.env_id0 + env)};
-            const U4 o = px.block(SITE_SOC, car_index(k, rank), 0);  // keyed by (station, admission rank)
+            const U4 o = px.block(SITE_SOC, (uint32_t) hub_slot, 0);
             const uint32_t c = o.v[0] >> kSocLevelShift, lev = o.v[1] % 1000u;
             const f32x2 e0 = *(CHUB_G(const f32x2)) ((CHUB_G(const char)) cls + (size_t) c * (kClsRow * 8u));
             t_target = tb.ttab[k][lev];
@@ -1170,7 +1154,6 @@ struct PackedArgs {
     CHUB_G(const float) cls0;        // station 0's class table; station 1's is cls_delta bytes further
     CHUB_G(const float) ttab2;       // [2][1024] soc_to_time(target level) of both stations' curves (1000 used)
     CHUB_G(const uint32_t) car_tape; // TAPE: [N][S0 + S1][2] per slot, used if the slot admits a car this step: class, level | late << 16
-    CHUB_G(const uint32_t) car_pre;  // [2N][kPreCars] this step's first new cars per unit, drawn one launch ahead (car_word), or null: drawn in place
     // add_car's Philox block (the new cars come last in the workgroup, behind two barriers: nothing of theirs should wait
     // for a load that could have been issued at the start of the wave)
     uint32_t key[2], gid0, tick;     // Philox key, global id of env 0, host tick
@@ -1286,8 +1269,7 @@ struct NoHook {
 template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED, bool FUSED, typename Hook, bool BITS = false>
 __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepArgs &sa, PackedArgs &pa, const Tables &tb,
                                                 const uint32_t block_local, uint32_t *q_cnt, uint32_t *q_new,
-                                                uint64_t *s_ball, int *s_acc, uint32_t *s_unit, Hook &hook, u32x4 *s_rec, uint32_t *s_uinfo,
-                                                uint32_t *s_pre) {
+                                                uint64_t *s_ball, int *s_acc, uint32_t *s_unit, Hook &hook, u32x4 *s_rec, uint32_t *s_uinfo) {
     // T slots per lane: virtual lane v = tid + j * BLOCK (j < T), virtual wave = wave + j * (BLOCK / 64).  All T slots' loads
     // are in flight together and the barriers are shared.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1348,16 +1330,6 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         asm volatile("" : "+s"(pa.key[0]), "+s"(pa.key[1]), "+s"(pa.gid0), "+s"(pa.tick), "+s"(pa.late[0]), "+s"(pa.late[1]), "+s"(pa.late[2]),
                           "+s"(pa.late[3]), "+s"(pa.late[4]), "+s"(pa.late[5]), "+s"(pa.late[6]), "+s"(pa.late[7]));
     }
-    // the units' predrawn new cars (32 bytes per unit) travel with the first loads and are parked in LDS in front of the first barrier:
-    // the new-car pass, two barriers on, reads its car's word from there
-    constexpr bool PRE = !TAPE && !RESET;
-    const bool pre_lds = PRE && pa.car_pre != nullptr && 2 * epb * kPreCars <= kPreLdsWords;
-    u32x4 pre_a = {0u, 0u, 0u, 0u}, pre_b = {0u, 0u, 0u, 0u};
-    if (pre_lds && tid < 2 * epb && env_first + (tid >> 1) < N) {
-        const uint32_t su = (uint32_t) ((tid & 1) ? N : 0) + (uint32_t) (env_first + (tid >> 1));
-        pre_a = CHUB_AT(const u32x4, pa.car_pre, su << 5);
-        pre_b = CHUB_AT(const u32x4, pa.car_pre, (su << 5) + 16u);
-    }
     if (FUSED) hook.prefetch();
     if (tid == 0) q_cnt[0] = 0;
     for (int i = tid; i < (BIG ? 16 : 8 * kAccCopies) * epb; i += BLOCK) s_acc[i] = 0;
@@ -1395,10 +1367,6 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         if (lane == 0) s_ball[wave + j * WAVES] = be[j];
     }
     if (FUSED) hook.park();
-    if (pre_lds && tid < 2 * epb) {
-        ((u32x4 *) s_pre)[2 * tid] = pre_a;
-        ((u32x4 *) s_pre)[2 * tid + 1] = pre_b;
-    }
     __syncthreads();
     // ---- every unit's empties, ONCE per unit: a lane per unit reads the ballots of the (at most two) virtual waves the unit lies in
     // and leaves, in one word, the empties in front of the unit inside its first wave, the unit's empties in that wave, its empties in
@@ -1462,7 +1430,6 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): admission
     int line[T], flow[T];
     bool adm[T];
-    int arank[T];  // admission rank: the unit's empties in front of the slot
     uint64_t ba[T];
     uint32_t n_push = 0;
 #pragma unroll
@@ -1518,7 +1485,6 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
             line[j] = line[j] < kMaxLine ? line[j] : kMaxLine;
         }
         adm[j] = empty[j] && rank < assign;
-        arank[j] = rank;
         ba[j] = __ballot(adm[j]);
         n_push += (uint32_t) __popcll(ba[j]);
     }
@@ -1528,7 +1494,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         base = __shfl(base, 0);
 #pragma unroll
         for (int j = 0; j < T; j++) {
-            if (adm[j]) q_new[base + prefix_count(ba[j])] = (uint32_t) (tid + j * BLOCK) | ((uint32_t) arank[j] << 16);
+            if (adm[j]) q_new[base + prefix_count(ba[j])] = (uint32_t) (tid + j * BLOCK);
             base += (uint32_t) __popcll(ba[j]);
         }
     }
@@ -1547,8 +1513,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     // ---- add_car (CHS.hpp:864-877 / 1029-1042) for the workgroup's new cars, one lane per car
     const uint32_t n_adm = q_cnt[0];
     for (uint32_t i = (uint32_t) (ALL ? tid : lane); i < n_adm; i += (ALL ? BLOCK : 64)) {
-        const uint32_t ent = q_new[i];
-        const int src = (int) (ent & 0xFFFFu), s_rank = (int) (ent >> 16);
+        const int src = (int) q_new[i];
         const int s_e = (int) (__umul24((uint32_t) src, pa.magic) >> 20);
         const int s_hs = src - (int) __umul24((uint32_t) s_e, (uint32_t) St);
         const int s_k = s_hs >= S0 ? 1 : 0;
@@ -1560,28 +1525,17 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
             lev = tp.y & 0xFFFFu;
             late = (int) (tp.y >> 16);
         } else {
-            // the unit's first kPreCars cars of this step were drawn one launch ahead (the level workgroups of k_env): one 4-byte read
-            const bool pre = !RESET && pa.car_pre != nullptr && s_rank < kPreCars;
-            uint32_t cw = 0u;
-            if (pre) {
-                if (pre_lds) cw = s_pre[(2 * s_e + s_k) * kPreCars + s_rank];
-                else cw = CHUB_AT(const uint32_t, pa.car_pre, ((((uint32_t) (s_k ? N : 0) + (uint32_t) (env_first + s_e)) << 3) + (uint32_t) s_rank) << 2);
-            }
-            if (!pre) {  // ... the others here: the same block (RESET, fresh launches, a unit's cars beyond the kPreCars-th)
-                PhiloxCtx p2{pa.key[0], pa.key[1], pa.tick, pa.gid0 + (uint32_t) (env_first + s_e)};
-                const U4 o = p2.block(SITE_SOC, car_index(s_k, s_rank), 0);  // word 0 SoC class, 1 target level, 2 extra stay
-                int lt = 0;  // late_from_word, the first 8 thresholds from registers
+            PhiloxCtx p2{pa.key[0], pa.key[1], pa.tick, pa.gid0 + (uint32_t) (env_first + s_e)};
+            const U4 o = p2.block(SITE_SOC, (uint32_t) s_hs, 0);  // word 0 SoC class, 1 target level, 2 extra stay
+            c = o.v[0] >> kSocLevelShift;
+            lev = o.v[1] % 1000u;
+            late = 0;  // late_from_word, the first 8 thresholds from registers
 #pragma unroll
-                for (int j = 0; j < 8; j++) lt += (o.v[2] >= pa.late[j]) ? 1 : 0;
-                if (__any(o.v[2] >= pa.late[7])) {
+            for (int j = 0; j < 8; j++) late += (o.v[2] >= pa.late[j]) ? 1 : 0;
+            if (__any(o.v[2] >= pa.late[7])) {
 #pragma unroll
-                    for (int j = 8; j < 16; j++) lt += (o.v[2] >= tb.late_thr[j]) ? 1 : 0;
-                }
-                cw = car_word(o.v[0] >> kSocLevelShift, o.v[1] % 1000u, lt);
+                for (int j = 8; j < 16; j++) late += (o.v[2] >= tb.late_thr[j]) ? 1 : 0;
             }
-            c = cw_cls(cw);
-            lev = cw_lev(cw);
-            late = cw_late(cw);
         }
         f32x2 e0 = CHUB_AT(const f32x2, pa.cls0, (s_k ? pa.cls_delta : 0u) + (c << 8));
         float tt_ = CHUB_AT(const float, pa.ttab2, (s_k ? 4096u : 0u) + (lev << 2));  // soc_to_time(target), CHS.hpp:867 / 1032
@@ -1624,7 +1578,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_sl
     __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T * kAccCopies];  // 2 epb <= BLOCK * T / 2 units x {min, charge, max power, cars} (BIG: as 64-bit sums, few units)
     __shared__ uint32_t s_unit[BLOCK * T / 2];                        // per unit: line | flow << 8
     __shared__ uint32_t s_uinfo[BLOCK * T / 2];                       // per unit: where its empties are (the admission's unit pass)
-    __shared__ __attribute__((aligned(16))) uint32_t s_pre[kPreLdsWords];  // per unit: its first kPreCars new cars of this step, drawn one launch ahead
     // all kernel arguments this wave needs, requested in ONE batch of scalar loads at its very start (the single asm
     // statement makes every one of them live here), instead of in a chain of dependent loads in front of the first
     // vector load
@@ -1633,7 +1586,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_sl
                       "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
     NoHook hook;
     (void) slot_body_packed<BLOCK, T, TAPE, RESET, BIG, MASKED, false, NoHook, BITS>(ctx->hp, sa, pa, ctx->tb, blockIdx.x + (MASKED ? pa.blk0 : 0u), q_cnt, q_new,
-                                                                                     s_ball + 1, s_acc, s_unit, hook, nullptr, s_uinfo, s_pre);
+                                                                                     s_ball + 1, s_acc, s_unit, hook, nullptr, s_uinfo);
 }
 
 // What the tail's first loads need, by value in the kernel arguments: one scalar load at the start of the wave instead
@@ -2517,23 +2470,21 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
 }
 
 // Next step's state-independent draws, lane u: [0, 2N) the station-level variates of unit u, [2N, 3N) the per-env draws
-// -> a unit lane: the cars the unit may admit at most next step (queue after the renege pass + arrivals that stay); otherwise 0
 template <bool RESET, bool MULTI>
-__device__ __forceinline__ int level_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int64_t u, const int line_known = -1) {
+__device__ __forceinline__ void level_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int64_t u, const int line_known = -1) {
     const HubParams &hp = ctx->hp;
     const int64_t N = hp.n_envs;
-    if (u >= 3 * N) return 0;
+    if (u >= 3 * N) return;
     const int64_t env_ = u < N ? u : (u < 2 * N ? u - N : u - 2 * N);
-    if (MULTI && !in_group(sa, env_)) return 0;
+    if (MULTI && !in_group(sa, env_)) return;
     // the slot of day the draws are for: the one after this launch's, on the env's own clock
     const int t_next = RESET ? 0 : ((MULTI ? clk_t(env_clk(sa, N, env_)) : sa.t) + 1) % 96;
     if (u < 2 * N) {
         const int kk = u >= N ? 1 : 0;
         // drawn AND decoded here, against the queue the slot kernel of this launch has just left in the unit's record
         const int line_now = line_known >= 0 ? line_known : pkd_line(ctx->st.rec[4u * (uint32_t) u + 3u]);
-        const uint32_t dk = draw_decoded_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick + 1u), t_next, kk, u - (int64_t) kk * N, line_now, hp.type[kk] == 0);
-        ctx->st.pk[(sa.tick + 1u) & 1u][u] = dk;
-        return hp.S[kk] > 0 ? dk_want(dk) : 0;  // (a station without piles admits nobody)
+        ctx->st.pk[(sa.tick + 1u) & 1u][u] = draw_decoded_levels(hp, ctx->tb, CHUB_TICK(hp, sa.tick + 1u), t_next, kk, u - (int64_t) kk * N,
+                                                                 line_now, hp.type[kk] == 0);
     } else {
         // the per-env draws (same Philox sites and counters the tail would use itself)
         const uint32_t e = (uint32_t) (u - 2 * N);
@@ -2550,44 +2501,6 @@ __device__ __forceinline__ int level_block(const DevCtx *__restrict__ ctx, const
         ((CHUB_G(u32x4)) ctx->ev.drw[(sa.tick + 1u) & 1u])[e] = d;
         ctx->ev.drw_cnt[(sa.tick + 1u) & 1u][e] = (uint8_t) cnt;
     }
-    return 0;
-}
-
-// Next step's new cars, one WAVE's share: every lane brings its unit u and the cars it may admit at most (`want`; 0: not a unit lane),
-// the (unit, rank) pairs with rank < min(want, kPreCars) are queued in the wave's piece of LDS (`list`: 64 * kPreCars entries + a
-// counter) and worked off 64 at a time, one Philox block per lane: pure VALU work, no lane idles on a unit that admits fewer cars.
-constexpr int kCarListWords = 64 * kPreCars;
-__device__ __forceinline__ void predraw_cars_wave(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int64_t u, const int want, uint32_t *list,
-                                                  uint32_t *cnt) {
-    const HubParams &hp = ctx->hp;
-    const Tables &tb = ctx->tb;
-    const uint32_t N = (uint32_t) hp.n_envs;
-    const int lane = (int) (threadIdx.x & 63u);
-    if (lane == 0) *cnt = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int n = want < kPreCars ? (want > 0 ? want : 0) : kPreCars;
-    if (n > 0) {
-        const uint32_t base = atomicAdd(cnt, (uint32_t) n);
-        for (int r = 0; r < n; r++) list[base + (uint32_t) r] = ((uint32_t) u << 3) | (uint32_t) r;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t total = *cnt;
-    const uint32_t tick = CHUB_TICK(hp, sa.tick + 1u);
-    CHUB_G(uint32_t) out = ctx->st.car_pre[(sa.tick + 1u) & 1u];
-    for (uint32_t i = (uint32_t) lane; i < total; i += 64u) {
-        const uint32_t ent = list[i];
-        const uint32_t uu = ent >> 3, r = ent & 7u;
-        const uint32_t kk = uu >= N ? 1u : 0u, env = uu - kk * N;
-        PhiloxCtx px{hp.key[0], hp.key[1], tick, (uint32_t) hp.env_id0 + env};
-        const U4 o = px.block(SITE_SOC, car_index((int) kk, (int) r), 0);
-        out[uu * (uint32_t) kPreCars + r] = car_word(o.v[0] >> kSocLevelShift, o.v[1] % 1000u, late_from_word(tb.late_thr, o.v[2]));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // (the list is reused by the wave's next group of units)
 }
 
 template <bool RESET, int MODE, bool MULTI, bool TAPE = false>
@@ -2598,16 +2511,10 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     if (MODE == MODE_PHILOX && (int) blockIdx.x >= nb_env) {
         // the last blocks of the grid: next step's station-level draws, one lane per (station, env).
         // They are pure VALU work and fill the issue slots the latency-bound tail waves leave empty.
-        int seg = 0, want = 0;
-        int64_t env_ = 0, u = 0;
-        if (range_unit(sa, (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x, 3, seg, env_)) {
-            u = (int64_t) seg * ctx->hp.n_envs + env_;
-            want = level_block<RESET, MULTI>(ctx, sa, u);
-        }
-        // ... and the first new cars of next step's units (the output rows' LDS is free in these workgroups)
-        static_assert(sizeof(s_out) >= (kEnvBlock / 64) * (kCarListWords + 8) * sizeof(uint32_t), "one car list per wave");
-        uint32_t *list = (uint32_t *) s_out + (threadIdx.x >> 6) * (kCarListWords + 8);
-        predraw_cars_wave(ctx, sa, u, want, list, list + kCarListWords);
+        int seg = 0;
+        int64_t env_ = 0;
+        if (range_unit(sa, (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x, 3, seg, env_))
+            level_block<RESET, MULTI>(ctx, sa, (int64_t) seg * ctx->hp.n_envs + env_);
         return;
     }
     const int blk = (int) blockIdx.x + (MULTI ? sa.env_lo / kEnvBlock : 0);  // a call on a subset: the blocks of its range of envs only
@@ -2742,7 +2649,6 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
     __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T * kAccCopies];
     __shared__ uint32_t s_unit[BLOCK * T / 2];
     __shared__ uint32_t s_uinfo[BLOCK * T / 2];
-    __shared__ __attribute__((aligned(16))) uint32_t s_pre[kPreLdsWords];
     __shared__ __attribute__((aligned(16))) u32x4 s_rec[BLOCK * T / 2];
     __shared__ double s_pv[100], s_wd[150], s_pv_now[100], s_wd_now[150], s_hy[102];
     __shared__ __attribute__((aligned(16))) float s_out[64 * 16];
@@ -2755,7 +2661,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
         if ((int) (threadIdx.x >> 6) == BLOCK / 64 - 1 && le < (int) pa_in.epb && env < (int) pa_in.n_envs) hook.tail_env = env;
     }
     const int role = slot_body_packed<BLOCK, T, TAPE, false, false, false, true, TailPrefetch, BITS>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
-                                                                                                      s_ball + 1, s_acc, s_unit, hook, s_rec, s_uinfo, s_pre);
+                                                                                                      s_ball + 1, s_acc, s_unit, hook, s_rec, s_uinfo);
     constexpr int WAVES = BLOCK / 64;
     const int lane = threadIdx.x & 63;
     const int epb = (int) pa.epb, N = (int) pa.n_envs, env_first = (int) blockIdx.x * epb;
@@ -2781,23 +2687,17 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
     if (role != WAVES) __syncthreads();
     if (role == 1) {
         // next step's station-level draws of this workgroup's units, against the queue lengths the main pass left in s_unit
-        // (q_new is free from the workgroup's third barrier on: this wave's car list; its units 64 at a time, every lane to the end)
-        static_assert(BLOCK * T >= kCarListWords, "the car list of the level wave");
-        for (int i0 = 0; i0 < 2 * epb; i0 += 64) {
-            const int i = i0 + lane;
+        for (int i = lane; i < 2 * epb; i += 64) {
             const int e = i >> 1, k = i & 1, env = env_first + e;
-            int want_next = 0;
-            if (i < 2 * epb && env < N) {
-                int line;
-                if ((k ? pa.S[1] : pa.S[0]) == 0u) {  // a station without piles: its queue moves on as in the body's record pass
-                    const int want = dk_want(pa.pk[(uint32_t) (k ? N : 0) + (uint32_t) env]);
-                    line = want < kMaxLine ? want : kMaxLine;
-                } else {
-                    line = pkd_line(s_unit[i]);
-                }
-                want_next = level_block<false, false>(ctx, sa, (int64_t) k * N + env, line);
+            if (env >= N) continue;
+            int line;
+            if ((k ? pa.S[1] : pa.S[0]) == 0u) {  // a station without piles: its queue moves on as in the body's record pass
+                const int want = dk_want(pa.pk[(uint32_t) (k ? N : 0) + (uint32_t) env]);
+                line = want < kMaxLine ? want : kMaxLine;
+            } else {
+                line = pkd_line(s_unit[i]);
             }
-            predraw_cars_wave(ctx, sa, (int64_t) k * N + env, want_next, q_new, q_cnt + 1);
+            level_block<false, false>(ctx, sa, (int64_t) k * N + env, line);
         }
     } else if (role == 2) {
         for (int i = lane; i < epb; i += 64)
@@ -3164,8 +3064,6 @@ static PackedArgs make_packed_args(const HubParams &hp, const StepArgs &sa, cons
     pa.cls0 = (CHUB_G(const float)) pp.cls[0];
     pa.ttab2 = (CHUB_G(const float)) pp.ttab2;
     pa.car_tape = (CHUB_G(const uint32_t)) sa.car_tape;
-    // the first new cars of every unit: left by the previous launch's level workgroups unless this launch makes its own draws
-    pa.car_pre = (sa.fresh || sa.pk_tape) ? nullptr : (CHUB_G(const uint32_t)) pp.car_pre[sa.tick & 1u];
     pa.key[0] = hp.key[0];
     pa.key[1] = hp.key[1];
     pa.gid0 = (uint32_t) hp.env_id0;

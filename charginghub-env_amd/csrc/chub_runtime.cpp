@@ -328,8 +328,6 @@ static PackedPtrs packed_ptrs(const chub_env *e) {
     p.sin96 = e->h_sin96;
     p.pk[0] = (uint32_t *) e->st.pk[0];
     p.pk[1] = (uint32_t *) e->st.pk[1];
-    p.car_pre[0] = (uint32_t *) e->st.car_pre[0];
-    p.car_pre[1] = (uint32_t *) e->st.car_pre[1];
     return p;
 }
 
@@ -475,7 +473,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
 
     {   // arena: generous upper bound of everything allocated below (telemetry buffers come later, separately)
         const size_t S_tot = (size_t) (cfg->station_list[0] + cfg->station_list[1]);
-        const size_t per_env = S_tot * 40 + 1024 + 128 + (size_t) qcap * 16 + (rng_mode == CHUB_RNG_COMPAT ? 102 * 8 + 33 * 4 + 256 : 0);
+        const size_t per_env = S_tot * 40 + 1024 + (size_t) qcap * 16 + (rng_mode == CHUB_RNG_COMPAT ? 102 * 8 + 33 * 4 + 256 : 0);
         const size_t want = (size_t) n_envs * per_env + ((size_t) 8 << 20) +
                             (rng_mode == CHUB_RNG_PHILOX ? 2 * ((size_t) kSocLevels + 2) * (kClsRow * 8 + 4) : 0);
         void *q = nullptr;
@@ -782,12 +780,10 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->sl.stay8 = nullptr;
     e->sl.var = nullptr;
     e->st.empt = nullptr;
-    e->st.car_pre[0] = e->st.car_pre[1] = nullptr;
     e->st.fa = nullptr;
     if (rng_mode == CHUB_RNG_PHILOX) {
         ALLOC(e->sl.hot, NS);  // 4-byte slot state
         ALLOC(e->sl.stay8, NS);
-        ALLOC(e->st.car_pre[0], 2 * N * 8); ALLOC(e->st.car_pre[1], 2 * N * 8);  // a unit's first 8 new cars, drawn one launch ahead
     } else {
         ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.init_soc, NS);
         ALLOC(e->sl.var, 2 * NS);  // the split step's per-admission variates

@@ -611,19 +611,18 @@ static void remove_car(orc_station *s, int i) {
 }
 
 /* CHS:864-877 / 1029-1042 add_car (+ calculate_min_charging_time CHS:933-937 / 1098-1102) */
-static void add_car(orc_station *s, orc_rng *r, const orc_tables *t, int i, int rank) {
+static void add_car(orc_station *s, orc_rng *r, const orc_tables *t, int i) {
     int cc = s->constant_charging;
+    int slot = s->slot_base + i;
     int late;
     if (r->mode == ORC_RNG_COMPAT) {
         s->p_arrive_soc[i] = orc_mk_soc(r);
         s->p_current_soc[i] = s->p_arrive_soc[i];
         s->p_target_soc[i] = orc_uniform_level((int) (orc_glibc_rand(r) % 1000u), 80, 100);
     } else {
-        /* PHILOX: one block per admitted car, keyed by (station, admission rank: the cars of a step in ascending slot order, CHS:426-429) --
-         * word 0 arrival SoC, word 1 target level, word 2 extra stay.  Keyed by rank (not by the slot the car lands in) the blocks of a
-         * step can be computed before the slots are known: the device draws the first 8 per unit one launch ahead. */
+        /* PHILOX: one block per admitted slot -- word 0 arrival SoC, word 1 target level, word 2 extra stay */
         uint32_t o[4];
-        philox_block(r, ORC_PU_SOC, (s->index << 9) | rank, 0, o);
+        philox_block(r, ORC_PU_SOC, slot, 0, o);
         s->p_arrive_soc[i] = orc_soc_level_from_word(t, o[0]);
         s->p_current_soc[i] = s->p_arrive_soc[i];
         s->p_target_soc[i] = orc_uniform_level((int) (o[1] % 1000u), 80, 100);
@@ -692,9 +691,8 @@ static void receive_car(orc_station *s, orc_rng *r, const orc_tables *t, int res
     s->flow_in_last = s->type == ORC_FAST ? in_car : true_in_car;
     s->has_flow = 1;
     assign_car(s);
-    int rank = 0;
     for (int i = 0; i < s->n; i++)
-        if (s->assign[i] > 0.5) add_car(s, r, t, i, rank++);
+        if (s->assign[i] > 0.5) add_car(s, r, t, i);
     for (int i = 0; i < s->n; i++) s->assign[i] = 0;
 }
 
