@@ -1,0 +1,12 @@
+# A/B inside one GPU call: libchub_a.so (baseline build) against the tree's libchub.so; AB_WHAT selects the sizes
+mkdir -p gpurun_out/$1
+A=$PWD/charginghub-env_amd/libchub_a.so
+for rep in 1 2; do
+  for cfg in ${AB_WHAT:-c4 c5}; do
+    case $cfg in
+      c4) E="";; c5) E="AB_CONFIG=c5";; c2) E="AB_CONFIG=c2";; *) E="AB_ENVS=$cfg";;
+    esac
+    env $E CHUB_LIB=$A python tools/ab_step_times.py; env $E python tools/ab_step_times.py
+  done
+done > gpurun_out/$1/ab.log 2>&1
+cat gpurun_out/$1/ab.log
