@@ -31,6 +31,9 @@ constexpr int kSocLevels = 2048;   // PHILOX: equiprobable classes of the EV arr
                                    // tables of both stations (768 KB) stay resident in every XCD's L2 next to the streamed state
 constexpr int kSocLevelShift = 21;
 constexpr int kPolarMaxTrials = 32;
+#ifndef CHUB_TRACE
+#define CHUB_TRACE 0
+#endif
 #ifndef CHUB_SLOTS_PER_LANE
 #define CHUB_SLOTS_PER_LANE 2
 #endif
@@ -54,6 +57,13 @@ constexpr int kBigBlock = CHUB_BIG_BLOCK, kBigSlotsPerLane = CHUB_BIG_SLOTS_PER_
 constexpr int64_t kBigTileSlots = (int64_t) 10 << 20;  // handles of at least this many charger slots take the second tile (chub_options.tile overrides)
 constexpr int kClsRow = 32;        // PHILOX: entries (power, t_soc) per arrival-SoC class = car_steps a car can take (stay_time <= 27 here)
 constexpr int kTelemCount = 38;
+#ifndef CHUB_SPLIT_BLOCK
+#define CHUB_SPLIT_BLOCK 512
+#endif
+#ifndef CHUB_SPLIT_COMPACT
+#define CHUB_SPLIT_COMPACT 1
+#endif
+constexpr int kSplitBlock = CHUB_SPLIT_BLOCK;  // workgroup size of the split COMPAT step's slot pass (k_slot_split)
 constexpr int kCompatSmallBlock = 512;  // k_compat_small: wave 0 walks the envs' streams, ...
 constexpr int kCompatSmallWaves0 = 3, kCompatSmallWaves1 = 4;  // ... these many waves hold station 0's / station 1's units
 constexpr int kFusedMaxBlocks = 384;   // PHILOX lock-step steps of at most this many slot workgroups run as ONE launch (k_step_fused).  Measured, us per step
@@ -265,6 +275,11 @@ struct StepArgs {
     // knows every slot's remaining stay when it ends); empt_fresh: this launch counts them itself first (k_compat_empties) -- after
     // create, chub_set_state and a pass in another launch form (k_compat_small)
     int32_t empt_fresh;
+#if CHUB_TRACE
+    // measurement builds only (make KFLAGS=-DCHUB_TRACE=1, tools/experiments/phase_stamps.py): s_memtime stamps at the phase boundaries of
+    // the packed slot kernel and of the tail kernel (16 words per workgroup each); null: none taken
+    unsigned long long *stamps_slot, *stamps_env;
+#endif
 };
 
 }  // namespace chub

@@ -218,6 +218,19 @@ __device__ __forceinline__ int prefix_count(uint64_t m) {
 }
 
 constexpr int MODE_COMPAT = 0, MODE_PHILOX = 1;
+
+// Phase timestamps of measurement builds (KFLAGS=-DCHUB_TRACE=1; nothing in a product build): the shader clock when the wave gets here
+// -- a stamp waits for scalar results only, so a phase's share shows where the wave stood, not what it overlapped
+#if CHUB_TRACE
+#define CHUB_STAMP_DECL(n) unsigned long long stamp_[n] = {}
+#define CHUB_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_[i] = t_; } while (0)
+// ... and the constant 100 MHz clock all XCDs share (every XCD has a shader-clock counter of its own): calibrates the stamps' rate
+#define CHUB_STAMP_REAL(i) do { unsigned long long t_; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_[i] = t_; } while (0)
+#else
+#define CHUB_STAMP_REAL(i) do {} while (0)
+#define CHUB_STAMP_DECL(n) do {} while (0)
+#define CHUB_STAMP(i) do {} while (0)
+#endif
 // action_to_real (MGR:384-393) switches a pile on iff (a + 1) / 2 >= 0.5 on the f32 array.  In round-to-nearest-even f32
 // that is exactly a >= -2^-25 (a + 1 rounds to 1 from -2^-25 upwards, the tie going to the even 1.0; checked against the
 // two-step form on every f32 around the threshold and a stride over all others), so one compare replaces add, mul, compare.
@@ -515,10 +528,15 @@ __device__ __forceinline__ bool load_mode_on(const HubParams &hp, const StepArgs
 struct NoSlotMid {
     __device__ __forceinline__ void operator()() {}
 };
-template <int TYPE, bool RESET, int BLOCK, bool SPLIT = false, typename SlotMid = NoSlotMid>
+// COMPACT (k_slot_split): the f64 curve work -- car_step of the cars that charge (a third of the lanes under a random policy), add_car of
+// the new cars (one lane in fifteen) -- is what this mode's step costs, and a wave pays for it in full however few of its lanes need it.
+// So the workgroup gathers those lanes' inputs in LDS (cq: 8 + 6 * BLOCK words), its first waves evaluate them densely packed -- the same
+// device functions on the same inputs: the same bits -- and every lane picks its results up again: 3 of 8 waves evaluate car_step
+// instead of 8, one evaluates add_car instead of 8.
+template <int TYPE, bool RESET, int BLOCK, bool SPLIT = false, typename SlotMid = NoSlotMid, bool COMPACT = false>
 __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
                                  const CompatRng &cr, const Tables &tb, const int k, const int64_t block_local,
-                                 float *lds_f, uint32_t *lds_u, const int wave0 = 0, SlotMid mid = SlotMid()) {
+                                 float *lds_f, uint32_t *lds_u, const int wave0 = 0, SlotMid mid = SlotMid(), uint32_t *cq = nullptr) {
     constexpr int WAVES = BLOCK / 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave_abs = tid >> 6, wave = wave_abs - wave0;  // wave: among the station's waves (env mapping); wave_abs: the LDS areas
@@ -560,7 +578,41 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
                                           car ? emergency_of(t_target, t_soc, tl) : 0.0f, lds_f, lds_u, leader) ? 1 : 0;
     // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373); action_to_real (MGR:384-393)
     const bool on = on_override >= 0 ? (car && on_override != 0) : (car && (a >= kActOnThreshold || must_charge(t_target, t_soc, tl)));
-    if (on) {  // car_step (CHS.hpp:900-905 / 1065-1070)
+    // the workgroup's gathering areas (COMPACT): two counters, inputs, origins (+ the new cars' level and extra stay), four result arrays by origin
+    uint32_t *cq_cnt = cq, *cq_src = cq + 8 + BLOCK;
+    float *cq_in = (float *) (cq + 8), *cq_r0 = (float *) (cq + 8 + 2 * BLOCK), *cq_r1 = (float *) (cq + 8 + 3 * BLOCK),
+          *cq_r2 = (float *) (cq + 8 + 4 * BLOCK);
+    uint32_t *cq_r3 = cq + 8 + 5 * BLOCK;
+    if (COMPACT) {
+        if (tid < 2) cq_cnt[tid] = 0u;
+        __syncthreads();
+    }
+    if (COMPACT && !RESET) {  // car_step (CHS.hpp:900-905 / 1065-1070), gathered
+        const uint64_t bon = __ballot(on);
+        uint32_t base = 0u;
+        if (lane == 0 && bon) base = atomicAdd(&cq_cnt[0], (uint32_t) __popcll(bon));
+        base = __shfl(base, 0);
+        if (on) {
+            const uint32_t p = base + (uint32_t) prefix_count(bon);
+            cq_in[p] = __fadd_rn(t_soc, 1.0f);
+            cq_src[p] = (uint32_t) tid;
+        }
+        __syncthreads();
+        const uint32_t n_on = cq_cnt[0];
+        for (uint32_t i = (uint32_t) tid; i < n_on; i += (uint32_t) BLOCK) {
+            float soc_new, pw;
+            car_step_curves<TYPE>(cq_in[i], cp, hp.cc, soc_new, pw);
+            const uint32_t src = cq_src[i];
+            cq_r0[src] = pw;
+            cq_r1[src] = soc_to_time<TYPE>(soc_new, cp);
+        }
+        __syncthreads();
+        if (on) {
+            meta += 1 << 17;
+            power = cq_r0[tid];
+            t_soc = cq_r1[tid];
+        }
+    } else if (on) {  // car_step (CHS.hpp:900-905 / 1065-1070)
         meta += 1 << 17;  // one more car_step on this car's account (its SoC is replayed from it on demand)
         float soc_new;
         car_step_curves<TYPE>(__fadd_rn(t_soc, 1.0f), cp, hp.cc, soc_new, power);
@@ -642,7 +694,45 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const bool adm = empty && rank < assign;
     float nc_soc = 0.0f;
-    if (adm) {
+    if (COMPACT) {  // add_car (CHS.hpp:864-877 / 1029-1042), gathered (SPLIT: the cars' variates are the walk's)
+        static_assert(!COMPACT || SPLIT, "the gathered form reads the walk's variates");
+        u32x2 vv = {0u, 0u};
+        if (adm) vv = ((CHUB_G(const u32x2)) sl.var)[(uint32_t) env * (uint32_t) (hp.S[0] + hp.S[1]) + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank];
+        const uint64_t badm = __ballot(adm);
+        uint32_t base = 0u;
+        if (lane == 0 && badm) base = atomicAdd(&cq_cnt[1], (uint32_t) __popcll(badm));
+        base = __shfl(base, 0);
+        if (adm) {
+            const uint32_t p = base + (uint32_t) prefix_count(badm);
+            cq_in[p] = __uint_as_float(vv.x);
+            cq_src[p] = (uint32_t) tid | ((vv.y & 0x3FFu) << 12) | ((vv.y >> 16) << 22);  // origin, target level (< 1000), extra stay (< 1024)
+        }
+        __syncthreads();
+        const uint32_t n_new = cq_cnt[1];
+        for (uint32_t i = (uint32_t) tid; i < n_new; i += (uint32_t) BLOCK) {
+            const uint32_t w = cq_src[i], src = w & 4095u;
+            const int lev = (int) ((w >> 12) & 1023u);
+            const float target = uniform_level(lev, 80.0f, 100.0f);
+            const NewCar nc = make_car<TYPE>(cq_in[i], lev, soc_to_time<TYPE>(target, cp), (int) (w >> 22), cp);
+            cq_r0[src] = nc.power;
+            cq_r1[src] = nc.t_soc;
+            cq_r2[src] = nc.t_target;
+            cq_r3[src] = (uint32_t) nc.stay;
+        }
+        __syncthreads();
+        if (adm) {
+            const int lev = (int) (vv.y & 0xFFFFu);
+            nc_soc = __uint_as_float(vv.x);
+            t_target = cq_r2[tid];
+            t_soc = cq_r1[tid];
+            tl = (int) cq_r3[tid];
+            power = cq_r0[tid];
+            car = tl > 0;
+            meta = tl | (lev << 7);
+        } else if (leave || RESET) {
+            meta = 0;
+        }
+    } else if (adm) {
         int lev, late_;
         float soc_;
         if (SPLIT) {
@@ -1281,6 +1371,9 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     const int epb = (int) pa.epb, N = (int) pa.n_envs;
     const int env_first = (int) block_local * epb;
     const uint32_t idx0 = (uint32_t) env_first * (uint32_t) St;
+    CHUB_STAMP_DECL(16);
+    CHUB_STAMP_REAL(12);
+    CHUB_STAMP(0);
     // every array reached from here is < 4 GiB (checked at create), so addresses are a uniform base + a 32-bit byte offset
     // per lane: the loads and stores take the base from SGPRs and need no 64-bit address arithmetic
 #define CHUB_AT(T_, base, byte_off) (*(CHUB_G(T_)) ((CHUB_G(char)) (base) + (uint32_t) (byte_off)))
@@ -1330,6 +1423,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         asm volatile("" : "+s"(pa.key[0]), "+s"(pa.key[1]), "+s"(pa.gid0), "+s"(pa.tick), "+s"(pa.late[0]), "+s"(pa.late[1]), "+s"(pa.late[2]),
                           "+s"(pa.late[3]), "+s"(pa.late[4]), "+s"(pa.late[5]), "+s"(pa.late[6]), "+s"(pa.late[7]));
     }
+    CHUB_STAMP(1);  // first loads issued
     if (FUSED) hook.prefetch();
     if (tid == 0) q_cnt[0] = 0;
     for (int i = tid; i < (BIG ? 16 : 8 * kAccCopies) * epb; i += BLOCK) s_acc[i] = 0;
@@ -1357,6 +1451,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         }
     }
 
+    CHUB_STAMP(2);  // state words here, class-row / target-time reads issued
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627) while those are in flight
     bool empty[T];
     uint64_t be[T];
@@ -1367,7 +1462,9 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         if (lane == 0) s_ball[wave + j * WAVES] = be[j];
     }
     if (FUSED) hook.park();
+    CHUB_STAMP(3);
     __syncthreads();
+    CHUB_STAMP(4);  // barrier 1 passed
     // ---- every unit's empties, ONCE per unit: a lane per unit reads the ballots of the (at most two) virtual waves the unit lies in
     // and leaves, in one word, the empties in front of the unit inside its first wave, the unit's empties in that wave, its empties in
     // all, and which wave that is.  (Rounds 2-3 had every LANE work its unit's 64-bit masks out for itself, two popcounts and an LDS
@@ -1425,7 +1522,9 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
             }
         }
     }
+    CHUB_STAMP(5);  // rows consumed, sums added
     if (!BIG) __syncthreads();  // the units' words are in
+    CHUB_STAMP(6);  // barrier 2 passed
 
     // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): admission
     int line[T], flow[T];
@@ -1503,7 +1602,9 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         if (valid[j] && !adm[j]) CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) (tid + j * BLOCK)) << 2) = w0n[j];
         if (valid[j] && slot[j] == 0) s_unit[2 * e_[j] + k_[j]] = pkd_make(line[j], flow[j], 0);
     }
+    CHUB_STAMP(7);  // admission done, state stores issued
     __syncthreads();
+    CHUB_STAMP(8);  // barrier 3 passed
     // Everything left -- the workgroup's new cars and, after them, the station records -- is the last wave's business: the
     // other waves are done (their wave slots go to the next workgroup instead of idling at a third barrier through the
     // Philox block and the dependent table read of the new cars).  RESET: about half of all slots get a car, so every wave
@@ -1558,14 +1659,29 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
             }
         }
     }
+    CHUB_STAMP(9);  // new cars done
     // FUSED (k_step_fused): the workgroup's third barrier and the station records are the caller's business from here (its last wave
     // runs the first half of its envs' tails in front of them): every wave returns its role, the last wave WAVES
     if (FUSED) return wave == WAVES - 1 ? WAVES : wave + 1;
     if (ALL) {
         __syncthreads();
+        CHUB_STAMP(10);  // barrier 4 passed
+        CHUB_STAMP_REAL(13);
+#if CHUB_TRACE
+        if (sa.stamps_slot && tid == 0) {
+            for (int i = 0; i <= 10; i++) sa.stamps_slot[(size_t) block_local * 16 + i] = stamp_[i];
+            sa.stamps_slot[(size_t) block_local * 16 + 12] = stamp_[12];
+            sa.stamps_slot[(size_t) block_local * 16 + 13] = stamp_[13];
+        }
+#endif
         if (wave != WAVES - 1) return 0;
     }
     packed_records<BLOCK, T, RESET, BIG, MASKED, false, BITS>(pa, block_local, s_acc, s_unit, nullptr);
+#if CHUB_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CHUB_STAMP(11);  // records stored: the workgroup is done
+    if (sa.stamps_slot && lane == 0) sa.stamps_slot[(size_t) block_local * 16 + 11] = stamp_[11];
+#endif
     return 0;
 #undef CHUB_AT
 }
@@ -1798,15 +1914,17 @@ __global__ __launch_bounds__(256) void k_compat_walk(const DevCtx *__restrict__ 
 }
 
 template <bool RESET, int BLOCK>
-__global__ __launch_bounds__(BLOCK, 7) void k_slot_split(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0) {
+__global__ __launch_bounds__(BLOCK) void k_slot_split(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0) {
     const HubParams &hp = ctx->hp;
     const int64_t bid = blockIdx.x;
     const int k = (bid >= nb0) ? 1 : 0;
     const int64_t bl = k ? bid - nb0 : bid;
-    __shared__ float lds_f[BLOCK];  // (the scalar-load mode's rank pass: the only user of the scratch areas here)
+    __shared__ float lds_f[BLOCK];  // (the scalar-load mode's rank pass and the sums' terms)
     __shared__ uint32_t lds_u[2 * BLOCK];
-    if (hp.type[k] == 0) slot_body_compat<0, RESET, BLOCK, true>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
-    else slot_body_compat<1, RESET, BLOCK, true>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
+    __shared__ uint32_t cq[8 + 6 * BLOCK];  // the gathered curve work (COMPACT)
+    constexpr bool CQ = CHUB_SPLIT_COMPACT != 0;
+    if (hp.type[k] == 0) slot_body_compat<0, RESET, BLOCK, true, NoSlotMid, CQ>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u, 0, NoSlotMid(), cq);
+    else slot_body_compat<1, RESET, BLOCK, true, NoSlotMid, CQ>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u, 0, NoSlotMid(), cq);
 }
 
 // ----------------------------------------------------------------------------------------- k_env
@@ -1952,6 +2070,14 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     // words that do not depend on state (FCEV arrival level, the three OU normals) are drawn here too, so the
     // memory latencies of this latency-bound kernel overlap instead of queueing behind one another.
     const uint32_t e32 = (uint32_t) env, n32 = ta.n_envs;
+    CHUB_STAMP_DECL(16);
+    CHUB_STAMP_REAL(8);
+    CHUB_STAMP(0);
+    {
+        uint32_t n_ = n32;
+        asm volatile("" : "+s"(n_));
+        CHUB_STAMP(1);  // kernel arguments here
+    }
     // the table rows of this slot of the day (PV, wind, hy_table; COMPAT: FCEV counts) go out first, one element per lane, in
     // the same burst as the state loads: one memory round trip for everything (they are parked in LDS further down)
     double st_pv = 0.0, st_wd = 0.0, st_hy = 0.0, st_pv_now = 0.0, st_wd_now = 0.0;
@@ -2052,6 +2178,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     if (!FUSED) {
         // the table rows requested at the top arrive with the state loads; park them in LDS
         static_assert(EB >= 150, "one table element per lane");
+        CHUB_STAMP(2);  // load burst issued
         const int i = threadIdx.x;
         if (i < 100) ((double *) s_pv)[i] = st_pv;
         if (i < 150) ((double *) s_wd)[i] = st_wd;
@@ -2063,6 +2190,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         }
         __syncthreads();
     }
+    CHUB_STAMP(3);  // rows parked, barrier passed: the loads have landed
     if (!TAPE && MODE == MODE_PHILOX && !RESET && !sa.fresh) {
         z_pv = (double) __uint_as_float(drw_raw.x);
         z_wd = (double) __uint_as_float(drw_raw.y);
@@ -2277,6 +2405,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     if (MODE == MODE_COMPAT && !RESET) rs.store(cr, env);
     } while (0);
 
+    CHUB_STAMP(4);  // first half (exogenous values, forecourt, next slot's exogenous update) done
     mid();  // k_step_fused: the workgroup's third barrier + the station records (by this wave); nothing elsewhere
     if (FUSED && live) {  // the records this workgroup has just written, from LDS
         const u32x4 v0 = s_rec[2 * local_env], v1 = s_rec[2 * local_env + 1];
@@ -2460,7 +2589,15 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         CHUB_TEL(33, (double) mn1); CHUB_TEL(34, (double) P1f); CHUB_TEL(35, (double) mx1); CHUB_TEL(36, (double) ln1); CHUB_TEL(37, (double) F1i);
     }
     } while (0);
+    CHUB_STAMP(5);  // second half (clamp, hydrogen step, netting, fuel cell, money, observation) done
     flush_rows();
+#if CHUB_TRACE
+    CHUB_STAMP(6);  // rows flushed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CHUB_STAMP(7);  // stores drained
+    CHUB_STAMP_REAL(9);
+    if (!FUSED && sa.stamps_env && threadIdx.x == 0) for (int i = 0; i < 10; i++) sa.stamps_env[(size_t) env_block * 16 + i] = stamp_[i];
+#endif
 #undef TAB_PV
 #undef TAB_WD
 #undef TAB_PV_NOW
@@ -2980,7 +3117,10 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
             CHUB_LAUNCH((k_compat_empties<BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, (hipEvent_t) nullptr, ctx, all, nb0);
         }
         CHUB_LAUNCH((k_compat_walk<RESET>), dim3((unsigned) ((hp.n_envs + 255) / 256)), dim3(256), stream, count_first ? (hipEvent_t) nullptr : ev0, (hipEvent_t) nullptr, ctx, sa);
-        CHUB_LAUNCH((k_slot_split<RESET, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, (hipEvent_t) nullptr, ev1, ctx, sa, nb0);
+        // (workgroups of 8 waves: the more waves share one gathering, the fewer of them evaluate curves)
+        constexpr int SB = kSplitBlock;
+        const int64_t sb0 = blocks_for(hp.n_envs, hp.U[0], SB), sb1 = blocks_for(hp.n_envs, hp.U[1], SB);
+        CHUB_LAUNCH((k_slot_split<RESET, SB>), dim3((unsigned) (sb0 + sb1)), dim3(SB), stream, (hipEvent_t) nullptr, ev1, ctx, sa, sb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
             StepArgs s2 = sa;

@@ -341,6 +341,10 @@ static int sync_ctx(chub_env *e, hipStream_t s) {
     return 0;
 }
 
+#if CHUB_TRACE
+static void *g_stamps_slot = nullptr, *g_stamps_env = nullptr;
+extern "C" void chub_debug_stamps(void *slot, void *env) { g_stamps_slot = slot; g_stamps_env = env; }  // measurement builds only
+#endif
 extern "C" {
 
 const char *chub_last_error(void) { return g_err.c_str(); }
@@ -1139,6 +1143,10 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     sa.load_mode = load_mode;
     sa.pk_tape = e->tape_pk;
     sa.car_tape = e->tape_car;
+#if CHUB_TRACE
+    sa.stamps_slot = (unsigned long long *) g_stamps_slot;
+    sa.stamps_env = (unsigned long long *) g_stamps_env;
+#endif
     sa.hv_tape = e->tape_hv;
     sa.hv_w = e->tape_hv_w;
     sa.tail_tape = e->tape_tail ? 1 : 0;
