@@ -57,13 +57,6 @@ constexpr int kBigBlock = CHUB_BIG_BLOCK, kBigSlotsPerLane = CHUB_BIG_SLOTS_PER_
 constexpr int64_t kBigTileSlots = (int64_t) 10 << 20;  // handles of at least this many charger slots take the second tile (chub_options.tile overrides)
 constexpr int kClsRow = 32;        // PHILOX: entries (power, t_soc) per arrival-SoC class = car_steps a car can take (stay_time <= 27 here)
 constexpr int kTelemCount = 38;
-#ifndef CHUB_SPLIT_BLOCK
-#define CHUB_SPLIT_BLOCK 512
-#endif
-#ifndef CHUB_SPLIT_COMPACT
-#define CHUB_SPLIT_COMPACT 1
-#endif
-constexpr int kSplitBlock = CHUB_SPLIT_BLOCK;  // workgroup size of the split COMPAT step's slot pass (k_slot_split)
 constexpr int kCompatSmallBlock = 512;  // k_compat_small: wave 0 walks the envs' streams, ...
 constexpr int kCompatSmallWaves0 = 3, kCompatSmallWaves1 = 4;  // ... these many waves hold station 0's / station 1's units
 constexpr int kFusedMaxBlocks = 384;   // PHILOX lock-step steps of at most this many slot workgroups run as ONE launch (k_step_fused).  Measured, us per step

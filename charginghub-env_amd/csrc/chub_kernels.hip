@@ -528,15 +528,10 @@ __device__ __forceinline__ bool load_mode_on(const HubParams &hp, const StepArgs
 struct NoSlotMid {
     __device__ __forceinline__ void operator()() {}
 };
-// COMPACT (k_slot_split): the f64 curve work -- car_step of the cars that charge (a third of the lanes under a random policy), add_car of
-// the new cars (one lane in fifteen) -- is what this mode's step costs, and a wave pays for it in full however few of its lanes need it.
-// So the workgroup gathers those lanes' inputs in LDS (cq: 8 + 6 * BLOCK words), its first waves evaluate them densely packed -- the same
-// device functions on the same inputs: the same bits -- and every lane picks its results up again: 3 of 8 waves evaluate car_step
-// instead of 8, one evaluates add_car instead of 8.
-template <int TYPE, bool RESET, int BLOCK, bool SPLIT = false, typename SlotMid = NoSlotMid, bool COMPACT = false>
+template <int TYPE, bool RESET, int BLOCK, bool SPLIT = false, typename SlotMid = NoSlotMid>
 __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
                                  const CompatRng &cr, const Tables &tb, const int k, const int64_t block_local,
-                                 float *lds_f, uint32_t *lds_u, const int wave0 = 0, SlotMid mid = SlotMid(), uint32_t *cq = nullptr) {
+                                 float *lds_f, uint32_t *lds_u, const int wave0 = 0, SlotMid mid = SlotMid()) {
     constexpr int WAVES = BLOCK / 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave_abs = tid >> 6, wave = wave_abs - wave0;  // wave: among the station's waves (env mapping); wave_abs: the LDS areas
@@ -578,41 +573,7 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
                                           car ? emergency_of(t_target, t_soc, tl) : 0.0f, lds_f, lds_u, leader) ? 1 : 0;
     // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373); action_to_real (MGR:384-393)
     const bool on = on_override >= 0 ? (car && on_override != 0) : (car && (a >= kActOnThreshold || must_charge(t_target, t_soc, tl)));
-    // the workgroup's gathering areas (COMPACT): two counters, inputs, origins (+ the new cars' level and extra stay), four result arrays by origin
-    uint32_t *cq_cnt = cq, *cq_src = cq + 8 + BLOCK;
-    float *cq_in = (float *) (cq + 8), *cq_r0 = (float *) (cq + 8 + 2 * BLOCK), *cq_r1 = (float *) (cq + 8 + 3 * BLOCK),
-          *cq_r2 = (float *) (cq + 8 + 4 * BLOCK);
-    uint32_t *cq_r3 = cq + 8 + 5 * BLOCK;
-    if (COMPACT) {
-        if (tid < 2) cq_cnt[tid] = 0u;
-        __syncthreads();
-    }
-    if (COMPACT && !RESET) {  // car_step (CHS.hpp:900-905 / 1065-1070), gathered
-        const uint64_t bon = __ballot(on);
-        uint32_t base = 0u;
-        if (lane == 0 && bon) base = atomicAdd(&cq_cnt[0], (uint32_t) __popcll(bon));
-        base = __shfl(base, 0);
-        if (on) {
-            const uint32_t p = base + (uint32_t) prefix_count(bon);
-            cq_in[p] = __fadd_rn(t_soc, 1.0f);
-            cq_src[p] = (uint32_t) tid;
-        }
-        __syncthreads();
-        const uint32_t n_on = cq_cnt[0];
-        for (uint32_t i = (uint32_t) tid; i < n_on; i += (uint32_t) BLOCK) {
-            float soc_new, pw;
-            car_step_curves<TYPE>(cq_in[i], cp, hp.cc, soc_new, pw);
-            const uint32_t src = cq_src[i];
-            cq_r0[src] = pw;
-            cq_r1[src] = soc_to_time<TYPE>(soc_new, cp);
-        }
-        __syncthreads();
-        if (on) {
-            meta += 1 << 17;
-            power = cq_r0[tid];
-            t_soc = cq_r1[tid];
-        }
-    } else if (on) {  // car_step (CHS.hpp:900-905 / 1065-1070)
+    if (on) {  // car_step (CHS.hpp:900-905 / 1065-1070)
         meta += 1 << 17;  // one more car_step on this car's account (its SoC is replayed from it on demand)
         float soc_new;
         car_step_curves<TYPE>(__fadd_rn(t_soc, 1.0f), cp, hp.cc, soc_new, power);
@@ -694,45 +655,7 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const bool adm = empty && rank < assign;
     float nc_soc = 0.0f;
-    if (COMPACT) {  // add_car (CHS.hpp:864-877 / 1029-1042), gathered (SPLIT: the cars' variates are the walk's)
-        static_assert(!COMPACT || SPLIT, "the gathered form reads the walk's variates");
-        u32x2 vv = {0u, 0u};
-        if (adm) vv = ((CHUB_G(const u32x2)) sl.var)[(uint32_t) env * (uint32_t) (hp.S[0] + hp.S[1]) + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank];
-        const uint64_t badm = __ballot(adm);
-        uint32_t base = 0u;
-        if (lane == 0 && badm) base = atomicAdd(&cq_cnt[1], (uint32_t) __popcll(badm));
-        base = __shfl(base, 0);
-        if (adm) {
-            const uint32_t p = base + (uint32_t) prefix_count(badm);
-            cq_in[p] = __uint_as_float(vv.x);
-            cq_src[p] = (uint32_t) tid | ((vv.y & 0x3FFu) << 12) | ((vv.y >> 16) << 22);  // origin, target level (< 1000), extra stay (< 1024)
-        }
-        __syncthreads();
-        const uint32_t n_new = cq_cnt[1];
-        for (uint32_t i = (uint32_t) tid; i < n_new; i += (uint32_t) BLOCK) {
-            const uint32_t w = cq_src[i], src = w & 4095u;
-            const int lev = (int) ((w >> 12) & 1023u);
-            const float target = uniform_level(lev, 80.0f, 100.0f);
-            const NewCar nc = make_car<TYPE>(cq_in[i], lev, soc_to_time<TYPE>(target, cp), (int) (w >> 22), cp);
-            cq_r0[src] = nc.power;
-            cq_r1[src] = nc.t_soc;
-            cq_r2[src] = nc.t_target;
-            cq_r3[src] = (uint32_t) nc.stay;
-        }
-        __syncthreads();
-        if (adm) {
-            const int lev = (int) (vv.y & 0xFFFFu);
-            nc_soc = __uint_as_float(vv.x);
-            t_target = cq_r2[tid];
-            t_soc = cq_r1[tid];
-            tl = (int) cq_r3[tid];
-            power = cq_r0[tid];
-            car = tl > 0;
-            meta = tl | (lev << 7);
-        } else if (leave || RESET) {
-            meta = 0;
-        }
-    } else if (adm) {
+    if (adm) {
         int lev, late_;
         float soc_;
         if (SPLIT) {
@@ -1914,17 +1837,15 @@ __global__ __launch_bounds__(256) void k_compat_walk(const DevCtx *__restrict__ 
 }
 
 template <bool RESET, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_slot_split(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0) {
+__global__ __launch_bounds__(BLOCK, 7) void k_slot_split(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0) {
     const HubParams &hp = ctx->hp;
     const int64_t bid = blockIdx.x;
     const int k = (bid >= nb0) ? 1 : 0;
     const int64_t bl = k ? bid - nb0 : bid;
-    __shared__ float lds_f[BLOCK];  // (the scalar-load mode's rank pass and the sums' terms)
+    __shared__ float lds_f[BLOCK];  // (the scalar-load mode's rank pass: the only user of the scratch areas here)
     __shared__ uint32_t lds_u[2 * BLOCK];
-    __shared__ uint32_t cq[8 + 6 * BLOCK];  // the gathered curve work (COMPACT)
-    constexpr bool CQ = CHUB_SPLIT_COMPACT != 0;
-    if (hp.type[k] == 0) slot_body_compat<0, RESET, BLOCK, true, NoSlotMid, CQ>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u, 0, NoSlotMid(), cq);
-    else slot_body_compat<1, RESET, BLOCK, true, NoSlotMid, CQ>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u, 0, NoSlotMid(), cq);
+    if (hp.type[k] == 0) slot_body_compat<0, RESET, BLOCK, true>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
+    else slot_body_compat<1, RESET, BLOCK, true>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds_f, lds_u);
 }
 
 // ----------------------------------------------------------------------------------------- k_env
@@ -2073,11 +1994,13 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     CHUB_STAMP_DECL(16);
     CHUB_STAMP_REAL(8);
     CHUB_STAMP(0);
+#if CHUB_TRACE
     {
         uint32_t n_ = n32;
         asm volatile("" : "+s"(n_));
         CHUB_STAMP(1);  // kernel arguments here
     }
+#endif
     // the table rows of this slot of the day (PV, wind, hy_table; COMPAT: FCEV counts) go out first, one element per lane, in
     // the same burst as the state loads: one memory round trip for everything (they are parked in LDS further down)
     double st_pv = 0.0, st_wd = 0.0, st_hy = 0.0, st_pv_now = 0.0, st_wd_now = 0.0;
@@ -3117,10 +3040,7 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
             CHUB_LAUNCH((k_compat_empties<BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, (hipEvent_t) nullptr, ctx, all, nb0);
         }
         CHUB_LAUNCH((k_compat_walk<RESET>), dim3((unsigned) ((hp.n_envs + 255) / 256)), dim3(256), stream, count_first ? (hipEvent_t) nullptr : ev0, (hipEvent_t) nullptr, ctx, sa);
-        // (workgroups of 8 waves: the more waves share one gathering, the fewer of them evaluate curves)
-        constexpr int SB = kSplitBlock;
-        const int64_t sb0 = blocks_for(hp.n_envs, hp.U[0], SB), sb1 = blocks_for(hp.n_envs, hp.U[1], SB);
-        CHUB_LAUNCH((k_slot_split<RESET, SB>), dim3((unsigned) (sb0 + sb1)), dim3(SB), stream, (hipEvent_t) nullptr, ev1, ctx, sa, sb0);
+        CHUB_LAUNCH((k_slot_split<RESET, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, (hipEvent_t) nullptr, ev1, ctx, sa, nb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
             StepArgs s2 = sa;
