@@ -529,6 +529,9 @@ def main():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="the timed steps as hipGraph replays; auto: on at N = 1, off at N > 1, where the capture holds RCCL "
                          "operations of several processes, which this repository could only exercise on a world of one")
+    ap.add_argument("--overlap-gather", action="store_true",
+                    help="with a communicator: the gather of step k on the communicator's own stream beside the kernels of step k + 1 "
+                         "(chub_comm_set_overlap; event edges -- free inside a captured graph, two host calls per step otherwise)")
     ap.add_argument("--force-comm", action="store_true", help="N = 1: still make the communicator and gather (to rank 0 itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the untimed profiled day (no `roofline` block)")
@@ -587,6 +590,9 @@ def main():
     per_graph = 96 * GRAPH_EPISODES
 
     comm = multi_gpu.Comm(rank, world, local_rank) if use_comm else None
+    overlap = bool(comm is not None and args.overlap_gather)
+    if overlap:
+        comm.set_overlap(True)
     v = chub.VecChargingHub(per, seed=SEED, rng="philox", device=local_rank, env_id0=rank * per, fused_step=args.fused, **hub_kw)
     D, A, S = v.obs_dim, v.act_dim, v.n_slots
     v_fused = v.uses_fused_step
@@ -647,6 +653,8 @@ def main():
                                                reset_obs.ptr, first, n, stream.ptr))
 
     def fence():
+        if comm is not None:
+            comm.join(stream.ptr)  # (overlapped gathers still out on the communicator's stream)
         stream.sync()
         if comm is not None:
             comm.barrier(stream.ptr)
@@ -806,7 +814,8 @@ def main():
                                  "off (--graph on captures the RCCL gather with the step kernels; verified on a world of one only, so N > 1 "
                                  "issues every step as a call by default)" if use_comm else "off"),
                        "collective": "none" if not use_comm else
-                       "one grouped ncclSend/ncclRecv (RCCL) of [envs_per_gpu, %d] f32 per step to rank 0, on the step's stream" % (D + 2)},
+                       "one grouped ncclSend/ncclRecv (RCCL) of [envs_per_gpu, %d] f32 per step to rank 0, %s" % (
+                           D + 2, "on the communicator's own stream beside the next step's kernels (--overlap-gather)" if overlap else "on the step's stream")},
             "n_ranks_seen": n_ranks_seen, "rccl_comm_count": comm_count, "ranks": rank_devices,
             "roofline": roofline,
             "roofline_step": {"bound": "hbm", "what": "whole step (slot kernel + env kernel + launch gaps), SURVEY.md 8(d): B * env-steps/s per GPU",
@@ -818,7 +827,8 @@ def main():
             # what the builder expects of this configuration, from its own parts: a step cannot be shorter than the slowest rank's
             # kernels + one gather (GPU side) nor than the slowest rank's host issue time (call by call, the host issues two kernel
             # launches and one grouped ncclSend / ncclRecv per step); the measured ms_per_step reads against the larger of the two
-            gpu_us = float((phases[:, 1] + phases[:, 2] + phases[:, 3]).max())
+            # (overlapped gathers: the gather of step k runs beside the kernels of step k + 1, a step costs the larger of the two)
+            gpu_us = float(np.maximum(phases[:, 1] + phases[:, 2], phases[:, 3]).max()) if overlap else float((phases[:, 1] + phases[:, 2] + phases[:, 3]).max())
             host_us = float(phases[:, 4].max())
             graphed = span_graph is not None or episode_graph is not None
             out["phases"] = {
@@ -828,7 +838,8 @@ def main():
                 "per_rank": [{"rank": int(r[0]), "slot_kernel_us": r[1], "env_kernel_us": r[2], "gather_us": r[3], "host_issue_us": r[4],
                               "wall_us_per_step": r[5]} for r in phases],
                 "expected_ms_per_step": (gpu_us if graphed else max(gpu_us, host_us)) / 1e3,
-                "expected_bound": "gpu (kernels + gather)" if (graphed or gpu_us >= host_us) else "host issue (call by call)",
+                "expected_bound": ("gpu (the larger of kernels and gather: overlapped)" if overlap else "gpu (kernels + gather)") if (graphed or gpu_us >= host_us)
+                else "host issue (call by call)",
                 "measured_ms_per_step": dt / steps * 1e3}
     for g in (episode_graph, span_graph):
         if g is not None:

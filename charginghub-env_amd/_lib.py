@@ -112,7 +112,8 @@ def load_library():
         "chub_comm_world": (I, [P]), "chub_comm_rank": (I, [P]), "chub_comm_gather": (I, [P, P, P, L, P]),
         "chub_comm_gather_timed": (I, [P, P, P, L, P, I, C.POINTER(C.c_double)]),
         "chub_comm_max_f64": (I, [P, C.POINTER(C.c_double), P]), "chub_comm_barrier": (I, [P, P]),
-        "chub_comm_ranks_seen": (I, [P, C.POINTER(C.c_int), P]), "chub_device_info": (I, [I, P]),
+        "chub_comm_ranks_seen": (I, [P, C.POINTER(C.c_int), P]),
+        "chub_comm_set_overlap": (I, [P, I]), "chub_comm_gather_begin": (I, [P, P, P]), "chub_comm_join": (I, [P, P]), "chub_device_info": (I, [I, P]),
         "chub_step_gather": (I, [P, P, P, P, P, P]), "chub_run_steps": (I, [P, P, P, I, P, P, P, L, L, P]),
         "chub_tape_register_soc": (I, [P, P, C.c_int32, P]), "chub_set_slots": (I, [P, P]), "chub_set_station_queue": (I, [P, P]),
         "chub_step_tape": (I, [P, P, P, P, P, P, P]), "chub_reset_tape": (I, [P, P, P, P]), "chub_tape_clear_soc": (I, [P]),
@@ -146,7 +147,7 @@ EXPORTED = ["chub_create", "chub_create_ex", "chub_destroy", "chub_obs_dim", "ch
             "chub_get_reward_f64", "chub_set_telemetry", "chub_fcev_stuck_count", "chub_set_rng_compat_seeds", "chub_set_rng_compat_state", "chub_get_rng_compat_state", "chub_compat_replay_constructor", "chub_set_ou_state",
             "chub_state_size", "chub_get_state", "chub_set_state", "chub_get_hy_table", "chub_get_hy_table_env", "chub_set_hy_table", "chub_last_error", "chub_device_count", "chub_build_id",
             "chub_comm_unique_id", "chub_comm_create", "chub_comm_destroy", "chub_comm_world", "chub_comm_rank", "chub_comm_gather", "chub_comm_gather_timed",
-            "chub_comm_max_f64", "chub_comm_barrier", "chub_comm_ranks_seen", "chub_device_info", "chub_step_gather", "chub_run_steps", "chub_tape_register_soc", "chub_set_slots",
+            "chub_comm_max_f64", "chub_comm_barrier", "chub_comm_ranks_seen", "chub_comm_set_overlap", "chub_comm_gather_begin", "chub_comm_join", "chub_device_info", "chub_step_gather", "chub_run_steps", "chub_tape_register_soc", "chub_set_slots",
             "chub_set_station_queue", "chub_step_tape", "chub_reset_tape", "chub_tape_clear_soc", "chub_step_tape_env", "chub_reset_tape_env", "chub_telemetry_host", "chub_graph_begin", "chub_graph_end", "chub_graph_launch", "chub_graph_destroy",
             "chub_malloc_device", "chub_free_device", "chub_copy_to_host", "chub_copy_to_device", "chub_alloc_host", "chub_free_host", "chub_stream_create",
             "chub_stream_destroy", "chub_stream_sync"]

@@ -83,6 +83,16 @@ struct chub_comm {
     ncclComm_t comm;
     int world, rank, device;
     double *d_scratch;  // 1 f64 for barrier / max
+    // chub_comm_set_overlap: the gathers go out on a stream of the communicator's own, tied to the caller's stream by events -- inside a
+    // hipGraph capture these are graph edges (no host cost per replay), so the gather of step k runs beside the kernels of step k + 1.
+    // One slot per send buffer (the packed step output is double-buffered by its owner):
+    bool overlap = false;
+    hipStream_t stream = nullptr;
+    struct Slot {
+        const void *buf = nullptr;
+        hipEvent_t ready = nullptr, done = nullptr;  // the block is written (caller's stream) / has left (the communicator's)
+        bool busy = false;
+    } slot[2];
 };
 
 // chub_runtime.cpp owns the thread-local error string behind chub_last_error()
@@ -146,6 +156,11 @@ int chub_comm_destroy(chub_comm *c) {
     if (!c) return CHUB_OK;
     (void) hipSetDevice(c->device);
     (void) hipDeviceSynchronize();
+    for (chub_comm::Slot &sl : c->slot) {
+        if (sl.ready) (void) hipEventDestroy(sl.ready);
+        if (sl.done) (void) hipEventDestroy(sl.done);
+    }
+    if (c->stream) (void) hipStreamDestroy(c->stream);
     if (c->d_scratch) (void) hipFree(c->d_scratch);
     if (c->comm) (void) g_rccl.CommDestroy(c->comm);
     delete c;
@@ -161,11 +176,7 @@ int chub_comm_world(const chub_comm *c) {
 }
 int chub_comm_rank(const chub_comm *c) { return c ? c->rank : CHUB_ERR_ARG; }
 
-// every rank's `bytes` at d_send -> rank 0's d_recv[rank * bytes ...]; enqueued on `stream`, returns at once
-int chub_comm_gather(chub_comm *c, const void *d_send, void *d_recv, int64_t bytes, void *stream) {
-    if (!c || !d_send || bytes <= 0) return comm_fail(CHUB_ERR_ARG, "bad argument");
-    if (c->rank == 0 && !d_recv) return comm_fail(CHUB_ERR_ARG, "rank 0 needs a receive buffer");
-    hipStream_t s = (hipStream_t) stream;
+static int gather_on(chub_comm *c, const void *d_send, void *d_recv, int64_t bytes, hipStream_t s) {
     NCCL_TRY(g_rccl.GroupStart());
     ncclResult_t r = g_rccl.Send(d_send, (size_t) bytes, ncclUint8, 0, c->comm, s);
     if (r == kNcclSuccess && c->rank == 0)
@@ -174,6 +185,86 @@ int chub_comm_gather(chub_comm *c, const void *d_send, void *d_recv, int64_t byt
     ncclResult_t r2 = g_rccl.GroupEnd();
     if (r != kNcclSuccess) return comm_fail(CHUB_ERR_COMM, std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(r));
     NCCL_TRY(r2);
+    return CHUB_OK;
+}
+
+static chub_comm::Slot *slot_of(chub_comm *c, const void *buf, bool claim) {
+    for (chub_comm::Slot &sl : c->slot)
+        if (sl.buf == buf) return &sl;
+    if (!claim) return nullptr;
+    for (chub_comm::Slot &sl : c->slot)
+        if (!sl.buf) {
+            sl.buf = buf;
+            return &sl;
+        }
+    return nullptr;
+}
+
+// Overlapped gathers (off by default): chub_comm_gather then runs on the communicator's own stream behind an event of the caller's, and
+// the caller's stream goes on at once.  The owner of the send buffers (at most two: the double-buffered packed step output) calls
+// chub_comm_gather_begin(buf, stream) BEFORE it enqueues the work that overwrites `buf` (chub_step_gather does), and chub_comm_join
+// wherever the gathered blocks are consumed or a capture ends (chub_graph_end does).
+int chub_comm_set_overlap(chub_comm *c, int enabled) {
+    if (!c) return comm_fail(CHUB_ERR_ARG, "null communicator");
+    HIPC_TRY(hipSetDevice(c->device));
+    for (const chub_comm::Slot &sl : c->slot)
+        if (sl.busy) return comm_fail(CHUB_ERR_ARG, "gathers are outstanding: chub_comm_join first");
+    if (enabled && !c->stream) {
+        HIPC_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        for (chub_comm::Slot &sl : c->slot) {
+            HIPC_TRY(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+            HIPC_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        }
+    }
+    c->overlap = enabled != 0;
+    for (chub_comm::Slot &sl : c->slot) sl.buf = nullptr;
+    return CHUB_OK;
+}
+
+int chub_comm_gather_begin(chub_comm *c, const void *d_send, void *stream) {
+    if (!c || !d_send) return comm_fail(CHUB_ERR_ARG, "null argument");
+    if (!c->overlap) return CHUB_OK;
+    chub_comm::Slot *sl = slot_of(c, d_send, true);  // (announcing a buffer is what makes its gathers overlapped ones)
+    if (!sl) return comm_fail(CHUB_ERR_ARG, "overlapped gathers take at most two send buffers (the double-buffered packed step output)");
+    if (sl->busy) {  // the gather that last read this buffer must have left before the buffer is written again
+        HIPC_TRY(hipStreamWaitEvent((hipStream_t) stream, sl->done, 0));
+        sl->busy = false;
+    }
+    return CHUB_OK;
+}
+
+int chub_comm_join(chub_comm *c, void *stream) {
+    if (!c) return comm_fail(CHUB_ERR_ARG, "null communicator");
+    for (chub_comm::Slot &sl : c->slot)
+        if (sl.busy) {
+            HIPC_TRY(hipStreamWaitEvent((hipStream_t) stream, sl.done, 0));
+            sl.busy = false;
+        }
+    return CHUB_OK;
+}
+
+// every rank's `bytes` at d_send -> rank 0's d_recv[rank * bytes ...]; enqueued (on `stream`, or -- overlapped -- on the communicator's
+// stream behind what `stream` holds so far), returns at once
+int chub_comm_gather(chub_comm *c, const void *d_send, void *d_recv, int64_t bytes, void *stream) {
+    if (!c || !d_send || bytes <= 0) return comm_fail(CHUB_ERR_ARG, "bad argument");
+    if (c->rank == 0 && !d_recv) return comm_fail(CHUB_ERR_ARG, "rank 0 needs a receive buffer");
+    hipStream_t s = (hipStream_t) stream;
+    if (!c->overlap) return gather_on(c, d_send, d_recv, bytes, s);
+    chub_comm::Slot *sl = slot_of(c, d_send, false);
+    if (!sl) {  // a buffer nobody announced (chub_comm_gather_begin): behind every gather still out, on the caller's stream
+        int rc = chub_comm_join(c, stream);
+        return rc ? rc : gather_on(c, d_send, d_recv, bytes, s);
+    }
+    if (sl->busy) {  // (written again without another announcement: keep the order all the same)
+        HIPC_TRY(hipStreamWaitEvent(s, sl->done, 0));
+        sl->busy = false;
+    }
+    HIPC_TRY(hipEventRecord(sl->ready, s));
+    HIPC_TRY(hipStreamWaitEvent(c->stream, sl->ready, 0));
+    int rc = gather_on(c, d_send, d_recv, bytes, c->stream);
+    if (rc) return rc;
+    HIPC_TRY(hipEventRecord(sl->done, c->stream));
+    sl->busy = true;
     return CHUB_OK;
 }
 
@@ -189,9 +280,10 @@ int chub_comm_gather_timed(chub_comm *c, const void *d_send, void *d_recv, int64
         (void) hipEventDestroy(e0);
         return comm_fail(CHUB_ERR_HIP, "hipEventCreate failed");
     }
-    int rc = chub_comm_gather(c, d_send, d_recv, bytes, stream);  // one untimed: connections set up, buffers touched
+    int rc = chub_comm_join(c, stream);  // (overlapped gathers still out: behind them; the timed ones go out on `stream` itself)
+    if (!rc) rc = gather_on(c, d_send, d_recv, bytes, s);  // one untimed: connections set up, buffers touched
     if (!rc && hipEventRecord(e0, s) != hipSuccess) rc = comm_fail(CHUB_ERR_HIP, "hipEventRecord failed");
-    for (int i = 0; i < reps && !rc; i++) rc = chub_comm_gather(c, d_send, d_recv, bytes, stream);
+    for (int i = 0; i < reps && !rc; i++) rc = gather_on(c, d_send, d_recv, bytes, s);
     if (!rc && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = comm_fail(CHUB_ERR_HIP, "hipEventSynchronize failed");
     float ms = 0.0f;
     if (!rc && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = comm_fail(CHUB_ERR_HIP, "hipEventElapsedTime failed");
@@ -207,6 +299,10 @@ int chub_comm_max_f64(chub_comm *c, double *value, void *stream) {
     if (!c || !value) return comm_fail(CHUB_ERR_ARG, "null argument");
     hipStream_t s = (hipStream_t) stream;
     HIPC_TRY(hipSetDevice(c->device));
+    {
+        int rc = chub_comm_join(c, stream);  // every collective of the communicator in one order on every rank
+        if (rc) return rc;
+    }
     HIPC_TRY(hipMemcpyAsync(c->d_scratch, value, sizeof(double), hipMemcpyHostToDevice, s));
     NCCL_TRY(g_rccl.AllReduce(c->d_scratch, c->d_scratch + 1, 1, ncclFloat64, ncclMax, c->comm, s));
     HIPC_TRY(hipMemcpyAsync(value, c->d_scratch + 1, sizeof(double), hipMemcpyDeviceToHost, s));
@@ -221,6 +317,10 @@ int chub_comm_ranks_seen(chub_comm *c, int *out, void *stream) {
     hipStream_t s = (hipStream_t) stream;
     double one = 1.0, sum = 0.0;
     HIPC_TRY(hipSetDevice(c->device));
+    {
+        int rc = chub_comm_join(c, stream);
+        if (rc) return rc;
+    }
     HIPC_TRY(hipMemcpyAsync(c->d_scratch, &one, sizeof(double), hipMemcpyHostToDevice, s));
     NCCL_TRY(g_rccl.AllReduce(c->d_scratch, c->d_scratch + 1, 1, ncclFloat64, ncclSum, c->comm, s));
     HIPC_TRY(hipMemcpyAsync(&sum, c->d_scratch + 1, sizeof(double), hipMemcpyDeviceToHost, s));

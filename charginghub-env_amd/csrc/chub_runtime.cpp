@@ -125,6 +125,7 @@ struct chub_env {
     int graph_t0, graph_pc0;
     bool graph_predrawn0;
     bool capturing;
+    chub_comm *cap_comm = nullptr;  // the communicator whose gathers the capture in progress holds (chub_step_gather)
     const uint64_t *cur_bits;  // set for the duration of chub_step_bits_device on the packed slot kernel: the step reads the
     const float *cur_tail;     //   decision bits and the tail actions themselves (no action rows)
     const uint64_t *tape_pk;   // set for the duration of chub_step_tape
@@ -1071,7 +1072,12 @@ int chub_step_device_packed(chub_env *e, const float *d_actions, const double *d
 
 int chub_step_gather(chub_env *e, chub_comm *comm, const float *d_actions, float *d_packed, float *d_gathered, void *stream) {
     if (!e || !comm || !d_actions || !d_packed) return fail(CHUB_ERR_ARG, "null argument");
-    int rc = chub_step_device_packed(e, d_actions, nullptr, d_packed, stream);
+    // (overlapped gathers, chub_comm_set_overlap: the gather that last sent this block must have left before the kernels overwrite it;
+    // a capture remembers the communicator so that chub_graph_end can join its stream)
+    int rc = chub_comm_gather_begin(comm, d_packed, stream);
+    if (rc) return rc;
+    if (e->capturing) e->cap_comm = comm;
+    rc = chub_step_device_packed(e, d_actions, nullptr, d_packed, stream);
     if (rc) return rc;
     return chub_comm_gather(comm, d_packed, d_gathered, e->hp.n_envs * (int64_t) (e->hp.obs_dim + 2) * (int64_t) sizeof(float), stream);
 }
@@ -1562,6 +1568,7 @@ int chub_graph_begin(chub_env *e, void *stream) {
     e->cap_masks.clear();
     e->cap_rel.clear();
     e->cap_full_rel = 0;
+    e->cap_comm = nullptr;
     return CHUB_OK;
 }
 
@@ -1586,6 +1593,10 @@ int chub_graph_end(chub_env *e, void *stream, chub_graph **out) {
     e->per_env = e->graph_per_env0;
     e->full_tick = e->graph_full_tick0;
     e->h_tick = e->graph_h_tick0;
+    // overlapped gathers ran on the communicator's stream: it joins the capture's stream here (a capture ends on one stream; and the
+    // next replay's first kernels overwrite the blocks the last gathers send)
+    if (e->cap_comm) (void) chub_comm_join(e->cap_comm, stream);
+    e->cap_comm = nullptr;
     // every replay moves the Philox tick base on by the ticks the graph covers (its last node)
     launch_tick_advance(e->d_tick_base, ticks, (hipStream_t) stream);
     hipGraph_t g = nullptr;

@@ -240,6 +240,14 @@ class Comm(object):
     def gather(self, d_send, d_recv, nbytes, stream=0):
         check(self._lib.chub_comm_gather(self._h, d_send, d_recv or None, int(nbytes), stream or None))
 
+    def set_overlap(self, on=True):
+        """gathers on the communicator's own stream, tied to the caller's by events (graph edges inside a capture): chub_comm_set_overlap"""
+        check(self._lib.chub_comm_set_overlap(self._h, int(bool(on))))
+
+    def join(self, stream=0):
+        """`stream` waits for every overlapped gather still out (chub_comm_join)"""
+        check(self._lib.chub_comm_join(self._h, stream or None))
+
     def gather_us(self, d_send, d_recv, nbytes, stream=0, reps=100):
         """microseconds per gather, `reps` of them back to back between two HIP events (chub_comm_gather_timed); every rank calls it"""
         us = C.c_double(0.0)

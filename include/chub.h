@@ -230,6 +230,20 @@ int chub_comm_gather_timed(chub_comm *comm, const void *d_send, void *d_recv, in
 int chub_comm_max_f64(chub_comm *comm, double *value, void *stream);
 int chub_comm_barrier(chub_comm *comm, void *stream);
 int chub_comm_ranks_seen(chub_comm *comm, int *out, void *stream);
+/* Overlapped gathers (off by default).  chub_comm_set_overlap(comm, 1): chub_comm_gather / chub_step_gather put the collective on a
+ * stream of the communicator's own, behind an event of the caller's stream, and the caller's stream goes on at once: the gather of step
+ * k runs beside the kernels of step k + 1.  Inside a hipGraph capture (chub_graph_begin .. chub_graph_end) the events are graph edges --
+ * no host cost per replay; call by call they cost the host two event calls per step (measured slower than the serial form).
+ *   chub_comm_gather_begin: before enqueueing work that overwrites a send buffer: `stream` waits for the gather that last read it.
+ *                           Announcing a buffer here is what makes its gathers overlapped ones (at most two buffers per communicator:
+ *                           the double-buffered packed step output; chub_step_gather announces its block); chub_comm_gather of any
+ *                           other buffer goes out on the caller's stream behind every gather still out
+ *   chub_comm_join:         `stream` waits for every gather still out: before the gathered blocks are consumed, before a host
+ *                           synchronisation that is meant to cover them (chub_graph_end, chub_comm_max_f64 / barrier / ranks_seen /
+ *                           gather_timed call it themselves) */
+int chub_comm_set_overlap(chub_comm *comm, int enabled);
+int chub_comm_gather_begin(chub_comm *comm, const void *d_send, void *stream);
+int chub_comm_join(chub_comm *comm, void *stream);
 int chub_device_info(int device, int32_t *out4);
 int chub_step_gather(chub_env *env, chub_comm *comm, const float *d_actions, float *d_packed, float *d_gathered, void *stream);
 

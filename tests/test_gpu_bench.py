@@ -59,3 +59,15 @@ def test_bench_multi_rank_path_reports_its_phases_with_kernel_times():
     assert d["phases"]["expected_bound"] in ("gpu (kernels + gather)", "host issue (call by call)")
     # the expectation is built from the parts and the measurement must not be far under it (nothing runs faster than its parts)
     assert d["phases"]["measured_ms_per_step"] > 0.5 * d["phases"]["expected_ms_per_step"]
+
+
+def test_bench_overlapped_gather_in_a_graph_on_a_world_of_one():
+    """--graph on --overlap-gather: the N > 1 graph form with the gather on the communicator's own stream (graph edges); the line says so and
+    its expectation is the larger of kernels and gather, not their sum"""
+    d = _bench("--force-comm", "--graph", "on", "--overlap-gather", "--no-c5", "--no-cpu-baseline", "--envs", "8192", "--steps", "192", "--warmup", "96")
+    assert "communicator's own stream" in d["config"]["collective"] and d["config"]["graph"] == "on"
+    r0, ph = d["phases"]["per_rank"][0], d["phases"]
+    assert ph["expected_bound"].startswith("gpu (the larger of kernels and gather")
+    assert abs(ph["expected_ms_per_step"] * 1e3 - max(r0["slot_kernel_us"] + r0["env_kernel_us"], r0["gather_us"])) < 1e-6
+    s = _bench("--force-comm", "--graph", "on", "--no-c5", "--no-cpu-baseline", "--envs", "8192", "--steps", "192", "--warmup", "96")
+    assert d["value"] > 0.9 * s["value"]          # never materially slower than the serial graph form (on one GPU the "gather" is a local copy)

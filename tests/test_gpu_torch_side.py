@@ -113,6 +113,76 @@ def test_native_rccl_gather_world_of_one():
     assert r.returncode == 0 and "NATIVE_RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+OVERLAP_CHILD = r'''
+import os, sys, ctypes as C
+sys.path.insert(0, os.environ["CHUB_ROOT"])
+import numpy as np
+import charginghub_env_amd as chub
+from charginghub_env_amd import multi_gpu
+kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+          init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.02, renew_fluctuate=0.1)
+n, STEPS = 3000, 192
+comm = multi_gpu.Comm(0, 1, 0)
+lib = chub.load_library()
+def run(form):
+    v = chub.VecChargingHub(n, seed=11, **kw)
+    D, A = v.obs_dim, v.act_dim
+    st = multi_gpu.Stream(0)
+    acts = [multi_gpu.DeviceBuffer(n * A * 4) for _ in range(4)]
+    for b, a in enumerate(acts):
+        v.random_actions_device(a.ptr, 77, b, st.ptr)
+    packed = [multi_gpu.DeviceBuffer(n * (D + 2) * 4) for _ in range(2)]        # the send blocks: double-buffered, as everywhere
+    gathered = [multi_gpu.DeviceBuffer(n * (D + 2) * 4) for _ in range(STEPS)]  # what arrives on "rank 0": one block per step, kept
+    obs0 = multi_gpu.DeviceBuffer(n * D * 4)
+    comm.set_overlap(form != "serial")
+    def two_days():
+        for i in range(STEPS):
+            if i % 96 == 0:
+                v.reset_device(obs0.ptr, stream=st.ptr)
+            chub._lib.check(lib.chub_step_gather(v._h, comm._h, acts[i % 4].ptr, packed[i & 1].ptr, gathered[i].ptr, st.ptr))
+    if form == "graph":  # (a lock-step graph replays from the clock it was captured at: whole episodes)
+        st.sync()
+        v.graph_begin(st.ptr)
+        two_days()
+        g = v.graph_end(st.ptr)
+        v.graph_launch(g, st.ptr)
+    else:
+        two_days()
+    comm.join(st.ptr)
+    out = [b.to_host(np.float32, (n, D + 2), st.ptr).copy() for b in gathered]
+    if form == "graph":
+        v.graph_launch(g, st.ptr)  # a second replay: other random numbers (the tick base moved on), same structure -- it runs through
+        comm.join(st.ptr); st.sync()
+        assert not np.array_equal(gathered[5].to_host(np.float32, (n, D + 2), st.ptr), out[5])
+        v.graph_destroy(g)
+    comm.set_overlap(False)
+    v.close()
+    for b in acts + packed + gathered + [obs0]:
+        b.free()
+    st.destroy()
+    return out
+ref = run("serial")
+assert len(ref) == STEPS and all(np.isfinite(x).all() and np.abs(x).sum() > 0 for x in ref) and (ref[95][:, -1] > 0.5).all() and not (ref[94][:, -1] > 0.5).any()
+assert not np.array_equal(ref[0], ref[96])
+for form in ("eager", "graph"):
+    got = run(form)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert np.array_equal(a, b), (form, i)
+comm.close()
+print("OVERLAP_OK")
+'''
+
+
+def test_overlapped_gather_equals_the_serial_form_world_of_one():
+    """chub_comm_set_overlap: the gather of step k on the communicator's own stream beside the kernels of step k + 1 (event edges; graph
+    edges inside a capture) -- call by call and as replays of a captured graph, every gathered block equals the serial form's bit for bit"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CHUB_ROOT=root, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT="29733",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", OVERLAP_CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OVERLAP_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 TORCH_CHILD = r'''
 import os, sys
 sys.path.insert(0, os.environ["CHUB_ROOT"])
