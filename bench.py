@@ -787,7 +787,7 @@ def main():
             traffic, traffic_src = measured_traffic(build_id, per, total, hub_kw["station_list"])
             roofline = roofline_block(slot_us, env_us, slot_b, env_b, per, traffic, traffic_src, n_prof,
                                       "%d whole untimed days after the timed region, every %dth step sampled: each slot of the day once, kernels back to back" % (PROFILE_DAYS, PROFILE_DAYS),
-                                      S=S, cache_resident=per * S * 8 + per * A * 4 <= 256 << 20)
+                                      S=S, cache_resident=per * S < 10 << 20)  # (the library's own size rule: the second tile from 10 M slots)
         step_achieved = (slot_b + env_b) * total / (dt / steps) / 1e9 / world  # per GPU
         d0, s0 = divmod(warmup, 96)
         d1, s1 = divmod(warmup + steps - 1, 96)

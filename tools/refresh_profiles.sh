@@ -5,7 +5,7 @@
 # Copy the files into profiles/ (tracked) afterwards.
 set -e
 TAG=${1:-vX}
-ROUND=${ROUND:-round4}
+ROUND=${ROUND:-round5}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -82,5 +82,48 @@ echo "bench done"; tail -c 400 $OUT/${ROUND}_${TAG}_bench.json; echo
 rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 > $OUT/${ROUND}_${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats.csv
 echo "kernel trace done"
-rm -rf $OUT/kt $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_tcc $OUT/pmc_tcp $OUT/pmc_fetch_c5 $OUT/pmc_write_c5
+# ---- round 5: the two workloads whose fractions the bench line quotes without a rocprof summary so far
+# (1) C5 as the bench's own workload (262 144 envs x [32, 32]): kernel-trace stats, to check roofline_c5.avg_launch_us against
+rocprofv3 --kernel-trace --stats -d $OUT/kt5 --output-format csv -- python3 bench.py --config c5 --no-cpu-baseline > $OUT/${ROUND}_${TAG}_bench_c5_under_rocprof.json 2> $OUT/kt5.err
+cp $(find $OUT/kt5 -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats_c5.csv
+echo "c5 kernel trace done"
+# (2) the reference-exact COMPAT mode at the headline size (tools/compat_rate.py: 65 536 envs x [20, 25], 2 days call by call): kernel-trace
+# stats + one counter set per pass for k_compat_walk / k_slot_split / k_env<COMPAT>, to check roofline_compat against
+rocprofv3 --kernel-trace --stats -d $OUT/ktc --output-format csv -- python3 tools/compat_rate.py > $OUT/compat_rate_under_rocprof.txt 2> $OUT/ktc.err
+cp $(find $OUT/ktc -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats_compat.csv
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_compat --output-format csv -- python3 tools/compat_rate.py > /dev/null 2> $OUT/pmc_fetch_compat.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_compat --output-format csv -- python3 tools/compat_rate.py > /dev/null 2> $OUT/pmc_write_compat.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmc_sq_compat --output-format csv -- python3 tools/compat_rate.py > /dev/null 2> $OUT/pmc_sq_compat.err
+echo "compat passes done"
+python3 - "$OUT" "$TAG" "$ROUND" <<'PY'
+import csv, glob, json, os, sys
+from collections import defaultdict
+out, tag, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
+def collect(d):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return acc
+def pick(acc, key):
+    for name in acc:
+        if key in name:
+            return {c: sum(v) / len(v) for c, v in acc[name].items()}
+    return {}
+sys.path.insert(0, os.getcwd())
+import charginghub_env_amd as chub
+fe, wr, sq = collect(out + "/pmc_fetch_compat"), collect(out + "/pmc_write_compat"), collect(out + "/pmc_sq_compat")
+res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes), mean per dispatch over the COMPAT step kernels of "
+               "tools/compat_rate.py (65536 envs x [20,25], reference streams, device-resident actions and normals, call by call); KiB; FETCH_SIZE "
+               "doubled as MI355X_MICROARCH.md prescribes for gfx950",
+       "build_id": chub.load_library().chub_build_id().decode(), "envs": 65536, "hub": [20, 25], "mode": "compat",
+       "calibration": {"fetch_factor": 2.0, "write_factor": 1.0}}
+for label, key in (("k_compat_walk", "k_compat_walk<false>"), ("k_slot_split", "k_slot_split<false"), ("k_env_compat", "k_env<false, 0")):
+    f, w = pick(fe, key).get("FETCH_SIZE", 0.0), pick(wr, key).get("WRITE_SIZE", 0.0)
+    res[label] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes_per_launch": (f * 2.0 + w) * 1024.0}
+    res[label + "_sq_counters_per_dispatch"] = pick(sq, key)
+json.dump(res, open("%s/%s_%s_pmc_compat.json" % (out, rnd, tag), "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k.startswith("k_") and not k.endswith("dispatch")}))
+PY
+rm -rf $OUT/kt $OUT/kt5 $OUT/ktc $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_tcc $OUT/pmc_tcp $OUT/pmc_fetch_c5 $OUT/pmc_write_c5 $OUT/pmc_fetch_compat $OUT/pmc_write_compat $OUT/pmc_sq_compat
 ls $OUT
