@@ -79,6 +79,8 @@ assert sorted(ALL_FIXTURES) == sorted(orclib.GOLDEN_ENV)
 
 
 TIGHT = 1e-9
+# (CHUB_TAPE_TOL scales the bar of the columns downstream of the station power sums: how DESIGN.md's "observed" figures were found)
+TOL = float(__import__("os").environ.get("CHUB_TAPE_TOL", "1"))
 # telemetry columns (charginghub-env_amd/_lib.py: TELEMETRY_NAMES) that no station power sum reaches: the exogenous series, the price, the
 # forecourt's demand.  (The hydrogen system is not among them: the electrolyser clamp MGR:160-180 and the fuel cell's draw on the tank,
 # capped by the EV load HYD:409-430, both look at the station sums.)
@@ -94,11 +96,11 @@ def _check_tail(v, g, i, name, n_envs, what):
     exact_cols = [0, 1, D - 2, D - 1] + [c for c in range(2, D - 3) if (c - 2) % 4 == 3]
     for e in range(n_envs):
         assert np.allclose(o64[e, exact_cols], want_o[exact_cols], rtol=TIGHT, atol=TIGHT), (name, what, "obs (exogenous, price, queues)", o64[e], want_o)
-        assert np.allclose(o64[e], want_o, rtol=1e-5, atol=2e-6), (name, what, "obs", o64[e], want_o)
-        assert np.allclose(r64[e], g["reward"][i], rtol=1e-5, atol=2e-6), (name, what, "reward", r64[e], g["reward"][i])
+        assert np.allclose(o64[e], want_o, rtol=1e-5 * TOL, atol=2e-6 * TOL), (name, what, "obs", o64[e], want_o)
+        assert np.allclose(r64[e], g["reward"][i], rtol=1e-5 * TOL, atol=2e-6 * TOL), (name, what, "reward", r64[e], g["reward"][i])
         assert np.array_equal(tel[e, 19:22], want_t[19:22]), (name, what, "fcev ints", tel[e, 19:22], want_t[19:22])
         assert np.allclose(tel[e, TEL_EXO], want_t[TEL_EXO], rtol=TIGHT, atol=TIGHT), (name, what, "telemetry (exogenous)", tel[e], want_t)
-        assert np.allclose(tel[e, :19], want_t[:19], rtol=1e-5, atol=2e-5), (name, what, "telemetry", tel[e, :19], want_t[:19])
+        assert np.allclose(tel[e, :19], want_t[:19], rtol=1e-5 * TOL, atol=2e-5 * TOL), (name, what, "telemetry", tel[e, :19], want_t[:19])
 
 
 @pytest.mark.parametrize("name", ["env_c5_random", "env_big_100_70", "env_small_fast_neg"])
