@@ -30,7 +30,7 @@ def test_traffic_profiles_are_matched_by_build_and_workload():
     """a PMC profile counts as this build's traffic only with the same build id (sources + kernel knobs) and workload"""
     b = _bench()
     profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")))  # the last one: the latest round's final set
-    assert profs and os.path.basename(profs[-1]).startswith("round4_"), "no round-4 traffic profile committed"
+    assert profs and os.path.basename(profs[-1]).startswith("round5_"), "no round-5 traffic profile committed"
     rec = json.load(open(profs[-1]))
     got, src = b.measured_traffic(rec["build_id"], 65536, 65536, [20, 25])
     assert src == os.path.basename(profs[-1]) and abs(got - rec["k_slot"]["traffic_bytes_per_launch"]) < 1.0
@@ -54,7 +54,7 @@ def test_traffic_profiles_are_matched_by_build_and_workload():
 
 def test_committed_bench_line_has_the_contract_fields():
     lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_bench.json")))
-    assert lines and os.path.basename(lines[-1]).startswith("round4_")
+    assert lines and os.path.basename(lines[-1]).startswith("round5_")
     d = json.load(open(lines[-1]))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline", "n_ranks_seen"):
@@ -71,6 +71,16 @@ def test_committed_bench_line_has_the_contract_fields():
     assert "roofline_c5" in d and d["roofline_c5"]["state_bytes"] == 262144 * 64 * 4  # one 32-bit word per slot since round 4
     assert d["roofline"]["traffic"] and d["roofline"]["traffic_source"] == os.path.basename(lines[-1]).replace("_bench.json", "_pmc_traffic.json")
     assert d["dropin_single_env"]["compat_us_per_step"] < d["dropin_single_env"]["reference_us_per_step"]
+    # round 5: the layout's own compulsory bytes next to SURVEY 8(d)'s, what the counters say limits the kernel, the COMPAT step priced
+    assert r["layout_bytes_per_launch"] == 65536 * (12 * 45 + 48) and r["limited_by"].startswith("latency/issue")
+    assert abs(r["frac_of_layout"] - r["layout_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 8e12) < 1e-12
+    assert d["roofline_c5"]["limited_by"] == "hbm" and d["roofline_c5"]["layout_bytes_per_launch"] == 262144 * (12 * 64 + 48)
+    rc = d["roofline_compat"]
+    assert rc["bound"] == "hbm" and abs(rc["frac"] - 1941 * 65536 / ((rc["walk_and_slot_pass_us"] + rc["env_kernel_us"]) * 1e-6) / 8e12) < 1e-9
+    assert d["cpu_baseline"]["host_cores"] >= d["cpu_baseline"]["cores"]
+    # ... and the rocprofv3 summaries the three fractions can be recomputed from are committed next to the line
+    for name in ("_kernel_stats.csv", "_kernel_stats_c5.csv", "_kernel_stats_compat.csv", "_pmc_compat.json", "_pmc_traffic_c5.json"):
+        assert os.path.exists(lines[-1].replace("_bench.json", name)), name
 
 
 def test_reference_stations_rate_is_timed_where_the_reference_build_exists():
