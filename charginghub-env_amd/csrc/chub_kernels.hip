@@ -2573,8 +2573,20 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
         // They are pure VALU work and fill the issue slots the latency-bound tail waves leave empty.
         int seg = 0;
         int64_t env_ = 0;
+#if CHUB_TRACE
+        CHUB_STAMP_DECL(16);
+        CHUB_STAMP_REAL(8);
+#endif
         if (range_unit(sa, (int64_t) ((int) blockIdx.x - nb_env) * kEnvBlock + threadIdx.x, 3, seg, env_))
             level_block<RESET, MULTI>(ctx, sa, (int64_t) seg * ctx->hp.n_envs + env_);
+#if CHUB_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CHUB_STAMP_REAL(9);
+        if (sa.stamps_env && threadIdx.x == 0) {  // (the level workgroups' rows follow the tail workgroups': entry and exit on the shared clock)
+            sa.stamps_env[(size_t) blockIdx.x * 16 + 8] = stamp_[8];
+            sa.stamps_env[(size_t) blockIdx.x * 16 + 9] = stamp_[9];
+        }
+#endif
         return;
     }
     const int blk = (int) blockIdx.x + (MULTI ? sa.env_lo / kEnvBlock : 0);  // a call on a subset: the blocks of its range of envs only

@@ -34,9 +34,10 @@ S = v.n_slots
 tile = 2048 if (os.environ.get("AB_TILE") == "large" or (os.environ.get("AB_TILE", "auto") == "auto" and n * S >= 10 << 20)) else 512
 nb_slot = (n + tile // S - 1) // (tile // S)
 nb_env = (n + 255) // 256
-st_slot, st_env = multi_gpu.DeviceBuffer(nb_slot * 16 * 8), multi_gpu.DeviceBuffer(nb_env * 16 * 8)
+nb_lvl = (3 * n + 255) // 256  # the level workgroups of k_env (next step's draws) follow the tail workgroups in its grid
+st_slot, st_env = multi_gpu.DeviceBuffer(nb_slot * 16 * 8), multi_gpu.DeviceBuffer((nb_env + nb_lvl) * 16 * 8)
 st_slot.from_host(np.zeros(nb_slot * 16, dtype=np.uint64))
-st_env.from_host(np.zeros(nb_env * 16, dtype=np.uint64))
+st_env.from_host(np.zeros((nb_env + nb_lvl) * 16, dtype=np.uint64))
 v.reset_device(obs0.ptr)
 for i in range(40):
     v.step_device_packed(acts[i % 4].ptr, packed.ptr)
@@ -49,14 +50,16 @@ for i in range(40, 40 + 24):
     v.step_device_packed(acts[i % 4].ptr, packed.ptr)
     v.sync()
     acc_s.append(st_slot.to_host(np.uint64, (nb_slot, 16)).astype(np.int64))
-    acc_e.append(st_env.to_host(np.uint64, (nb_env, 16)).astype(np.int64))
+    acc_e.append(st_env.to_host(np.uint64, (nb_env + nb_lvl, 16)).astype(np.int64))
 lib.chub_debug_stamps(None, None)
 v.profile_begin(64, every=1)
 for i in range(64):
     v.step_device_packed(acts[i % 4].ptr, packed.ptr)
 x, y, k = v.profile_end()
 slot_us, env_us = x / k * 1e3, y / k * 1e3
-s, e = np.stack(acc_s), np.stack(acc_e)  # [steps, blocks, words]: shader-clock stamps + two stamps of the 100 MHz clock all XCDs share
+s, e_all = np.stack(acc_s), np.stack(acc_e)  # [steps, blocks, words]
+# (shader-clock stamps + two stamps of the 100 MHz clock all XCDs share)
+e, lv = e_all[:, :nb_env], e_all[:, nb_env:]
 ok_s, ok_e = (s[:, :, :14] > 0).all(axis=(0, 2)), (e[:, :, :10] > 0).all(axis=(0, 2))
 print("%d envs x %s; dispatch timestamps: slot kernel %.2f us, tail kernel %.2f us" % (n, kw["station_list"], slot_us, env_us))
 print("workgroups with a complete set of stamps: %d of %d (slot kernel), %d of %d (tail kernel)" % (ok_s.sum(), ok_s.size, ok_e.sum(), ok_e.size))
@@ -85,4 +88,8 @@ for i, nm in enumerate(names_e):
 start_e = (e[:, :, 8] - e[:, :, 8].min(axis=1, keepdims=True)).astype(np.float64) / 100.0
 print("  workgroup entry times (shared clock): median %.2f us, last %.2f us after the first; last exit %.2f us" % (
     np.median(start_e), start_e.max(axis=1).mean(), ((e[:, :, 9].max(axis=1) - e[:, :, 8].min(axis=1)) / 100.0).mean()))
+t0 = e[:, :, 8].min(axis=1, keepdims=True)
+print("  level workgroups (%d, next step's draws): entry median %.2f us / last %.2f us after the first tail workgroup's entry; exit median %.2f us, LAST EXIT %.2f us (tail workgroups' last exit: %.2f us)" % (
+    nb_lvl, np.median((lv[:, :, 8] - t0) / 100.0), ((lv[:, :, 8] - t0) / 100.0).max(axis=1).mean(), np.median((lv[:, :, 9] - t0) / 100.0),
+    ((lv[:, :, 9] - t0) / 100.0).max(axis=1).mean(), ((e[:, :, 9] - t0) / 100.0).max(axis=1).mean()))
 v.close()
