@@ -135,6 +135,8 @@ struct EnvArrays {           // index = env (or field*N + env)
     CHUB_G(uint32_t) drw[2];     // [N][4] PHILOX: a step's state-independent env draws, made one launch ahead (double-buffered by
                                  // tick parity): three OU normals (f32 bits: pv, wind, price) and the first FCEV arrival's SoC (f32 bits)
     CHUB_G(uint8_t) drw_cnt[2];  // [N]    ... and the FCEV arrival count
+    CHUB_G(uint32_t) hv_pre[2];  // COMPAT, split step [N][HubParams::hv_w], double-buffered by tick parity: the forecourt's draws of a step as the walk
+                                 // made them behind the stations' (hvs_step, HYD:250-260): word 0 arrivals, word 1 + j arrival j's SoC (f32 bits)
     CHUB_G(double) q_time;       // [N][qcap]
     CHUB_G(double) q_mass;
     CHUB_G(double) obs64;        // [N][D]  (telemetry only)
@@ -145,6 +147,11 @@ struct EnvArrays {           // index = env (or field*N + env)
 struct CompatRng {           // reference streams, per env
     CHUB_G(uint32_t) g;          // [N][32]: 31-word glibc TYPE_3 ring + front index in word 31
     CHUB_G(uint32_t) minstd;     // [N]
+    // the split step: the walk (k_compat_walk, lane = env) leaves the streams' state behind its draws HERE, and the slot pass of the step
+    // those draws belong to (k_slot_split) commits it to g / minstd -- so a walk may run ahead of its step (beside the previous step's
+    // tail, one launch: k_env_walk) and a reset that comes instead of that step simply never sees it
+    CHUB_G(uint32_t) g_next;     // [N][32]
+    CHUB_G(uint32_t) minstd_next;  // [N]
 };
 
 struct Tables {
@@ -197,6 +204,7 @@ struct HubParams {
     double rc_cells, rc_cap_mass, rc_vm60k, rc_price_std, rc_half_range[2];
     float hv_rate;           // f32(f32(0.3) * f32(permeate))
     int32_t qcap;            // explicit FCEV waiting-list entries per env = max(1, 2 * (max arrivals per step) - 1)
+    int32_t hv_w;            // words per env of EnvArrays::hv_pre: 1 + max arrivals per step
     int32_t epb;             // packed slot kernel: whole envs per workgroup = pblock * pslots / (S0 + S1)
     int32_t pblock, pslots;  // packed slot kernel: the handle's tile, (kPackedBlock, kSlotsPerLane) or (kBigBlock, kBigSlotsPerLane)
     int32_t packed;          // PHILOX steps run k_slot_packed (any hub shape of up to 512 piles)
@@ -268,6 +276,10 @@ struct StepArgs {
     // knows every slot's remaining stay when it ends); empt_fresh: this launch counts them itself first (k_compat_empties) -- after
     // create, chub_set_state and a pass in another launch form (k_compat_small)
     int32_t empt_fresh;
+    // COMPAT, split step: commit_rng: this slot pass commits the streams' state the walk left in CompatRng::g_next (always, when a walk
+    // kernel made this step's draws); hv_tape / hv_w above then also carry the forecourt's draws of that walk to the tail
+    int32_t commit_rng;
+    int32_t walked;          // ... and this step's walk has run already (beside the previous step's tails, k_env_walk): the slot launch skips it
 #if CHUB_TRACE
     // measurement builds only (make KFLAGS=-DCHUB_TRACE=1, tools/experiments/phase_stamps.py): s_memtime stamps at the phase boundaries of
     // the packed slot kernel and of the tail kernel (16 words per workgroup each); null: none taken

@@ -723,6 +723,19 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     if (SPLIT) {  // what the next step's walk needs of the slots: a slot is empty after remove_car iff it has at most one slot of stay left
         const int n_empty = __popcll(__ballot(valid && tl <= 1) & unit_mask);
         if (unit_ok && slot == 0) st.empt[sidx] = (uint8_t) n_empty;
+        // ... and the step's draws are now taken: the streams' state the walk left behind them becomes the env's (station 0's unit of the
+        // env does it: every env has one, with or without piles)
+        if (sa.commit_rng && k == 0 && unit_ok && slot == 0) {
+            const u32x4 *src = (const u32x4 *) (cr.g_next + (size_t) env * 32u);
+            u32x4 *dst = (u32x4 *) (cr.g + (size_t) env * 32u);
+            u32x4 q[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) q[j] = src[j];
+            const uint32_t x = cr.minstd_next[env];
+#pragma unroll
+            for (int j = 0; j < 8; j++) dst[j] = q[j];
+            cr.minstd[env] = x;
+        }
     }
 }
 
@@ -1745,7 +1758,10 @@ __global__ __launch_bounds__(BLOCK) void k_compat_empties(const DevCtx *__restri
 
 // The walk of ONE env: station 0's draws, then station 1's, in the reference's consumption order (receive_car, CHS.hpp:1272-1316 /
 // 1583-1627), leaving per unit flow / cars admitted / queue (StationArrays::fa) and per admitted car its three variates (SlotArrays::var)
-template <bool RESET, typename Stream>
+// FORECOURT (k_compat_walk / k_env_walk): the env's forecourt draws of the step follow the stations' in the streams (hvs_step inside hy_step,
+// HYD:250-260, behind both evs_step calls, MGR:149-180): the arrival level, then one mk_soc per arrival -- made here as well and left in
+// EnvArrays::hv_pre for the tail, which then does not touch the streams at all
+template <bool RESET, typename Stream, bool FORECOURT = false>
 __device__ __forceinline__ void compat_walk_env(const DevCtx *__restrict__ ctx, const StepArgs &sa, const int env, Stream &rs) {
     const HubParams &hp = ctx->hp;
     const Tables &tb = ctx->tb;
@@ -1792,15 +1808,23 @@ __device__ __forceinline__ void compat_walk_env(const DevCtx *__restrict__ ctx, 
         }
         st.fa[sidx] = ((uint32_t) fl & 0xFFFFu) | ((uint32_t) (as > 0 ? as : 0) << 16) | ((uint32_t) new_line << 24);
     }
+    if (FORECOURT && !RESET) {
+        const int t_env = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;
+        CHUB_G(uint32_t) hv = ctx->ev.hv_pre[sa.tick & 1u] + (uint32_t) env * (uint32_t) hp.hv_w;
+        const int arrive = (int) tb.cnt_hv[(uint32_t) t_env * (uint32_t) kLevels + (uint32_t) rs.level()];
+        hv[0] = (uint32_t) arrive;
+        for (int j = 0; j < arrive; j++) hv[1 + j] = __float_as_uint(arrive_soc_from(rs.normal_d(7.0, 3.0)));  // (arrive < hv_w: chub_create)
+    }
 }
 
+// One workgroup's 256 walks: the rings parked in LDS, walked, and the streams' state behind the draws written to the SHADOW (g_next /
+// minstd_next): the slot pass of the step the draws belong to commits it.
 template <bool RESET>
-__global__ __launch_bounds__(256) void k_compat_walk(const DevCtx *__restrict__ ctx, StepArgs sa) {
+__device__ __forceinline__ void compat_walk_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const uint32_t blk, uint32_t *s_ring) {
     const int64_t N = ctx->hp.n_envs;
     // the glibc rings of the workgroup's 256 envs (32 KB, one contiguous run of memory) are parked in LDS for the walk: transposed, so that
     // the lanes of a wave hit different banks when each reads a word of its own ring
-    __shared__ uint32_t s_ring[32 * 256];
-    const uint32_t env0 = blockIdx.x * 256u;
+    const uint32_t env0 = blk * 256u;
     const uint32_t n_here = (uint32_t) N - env0 < 256u ? (uint32_t) N - env0 : 256u;
     {
         const u32x4 *src = (const u32x4 *) (ctx->cr.g + (size_t) env0 * 32u);
@@ -1822,18 +1846,24 @@ __global__ __launch_bounds__(256) void k_compat_walk(const DevCtx *__restrict__ 
         rs.gf = rs.r.get(31);
         rs.gr = (rs.gf + 28u) % 31u;
         rs.x = ctx->cr.minstd[env];
-        compat_walk_env<RESET>(ctx, sa, env, rs);
+        compat_walk_env<RESET, CompatStreamT<RingLds>, true>(ctx, sa, env, rs);
         rs.r.set(31, rs.gf);
-        ctx->cr.minstd[env] = rs.x;
+        ctx->cr.minstd_next[env] = rs.x;
     }
     __syncthreads();
     {
-        u32x4 *dst = (u32x4 *) (ctx->cr.g + (size_t) env0 * 32u);
+        u32x4 *dst = (u32x4 *) (ctx->cr.g_next + (size_t) env0 * 32u);
         for (uint32_t j = threadIdx.x; j < n_here * 8u; j += 256u) {
             const uint32_t l = j >> 3, w = (j & 7u) << 2;
             dst[j] = u32x4{s_ring[(w + 0u) * 256u + l], s_ring[(w + 1u) * 256u + l], s_ring[(w + 2u) * 256u + l], s_ring[(w + 3u) * 256u + l]};
         }
     }
+}
+
+template <bool RESET>
+__global__ __launch_bounds__(256) void k_compat_walk(const DevCtx *__restrict__ ctx, StepArgs sa) {
+    __shared__ uint32_t s_ring[32 * 256];
+    compat_walk_block<RESET>(ctx, sa, blockIdx.x, s_ring);
 }
 
 template <bool RESET, int BLOCK>
@@ -2166,8 +2196,11 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     do {
     if (!live) break;
 
+    // COMPAT: the forecourt's draws either continue the env's streams here (one kernel per station, k_compat_small), or -- the split step --
+    // were made by the walk behind the stations' and wait in sa.hv_tape (the tail then does not touch the streams)
+    const bool hv_walked = MODE == MODE_COMPAT && sa.hv_tape != nullptr;
     CompatStream rs;
-    if (MODE == MODE_COMPAT && !RESET) rs.load(cr, env);
+    if (MODE == MODE_COMPAT && !RESET && !hv_walked) rs.load(cr, env);
 
     if (RESET) {
         // renew_reset (REN:51-53) + hy_reset (HYD:197-208)
@@ -2206,8 +2239,8 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         // the reference's left-to-right order, so that sum(needed_time_list) / sum(needed_hy_list) stay bit-identical.
         const int qcap = hp.qcap;
         double *qt = (double *) ev.q_time + (size_t) e32 * (size_t) qcap, *qm = (double *) ev.q_mass + (size_t) e32 * (size_t) qcap;
-        if (MODE == MODE_COMPAT) hv_lev = rs.level();
-        arrive = MODE == MODE_COMPAT ? (int) TAB_HV(hv_lev) : hv_arrive;
+        if (MODE == MODE_COMPAT && !hv_walked) hv_lev = rs.level();
+        arrive = MODE == MODE_COMPAT ? (hv_walked ? (int) sa.hv_tape[e32 * (uint32_t) sa.hv_w] : (int) TAB_HV(hv_lev)) : hv_arrive;
         double total_mass = 0.0;
         const bool fcev_pre = !TAPE && MODE == MODE_PHILOX && !RESET && !sa.fresh;
         // the first arrival's SoC was drawn one launch ahead with the other env draws (level_block: same Philox counter); its
@@ -2242,7 +2275,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
                     mn = pre_mn;
                 } else {
                     float socf;
-                    if (TAPE) socf = __uint_as_float(sa.hv_tape[e32 * (uint32_t) sa.hv_w + 1u + (uint32_t) j]);
+                    if (TAPE || hv_walked) socf = __uint_as_float(sa.hv_tape[e32 * (uint32_t) sa.hv_w + 1u + (uint32_t) j]);
                     else if (MODE == MODE_COMPAT) socf = arrive_soc_from(rs.normal_d(7.0, 3.0));
                     else socf = soc_from_word(tb.soc_d_icdf, px.block(SITE_HVSOC, (uint32_t) j, 0).v[0]);
                     fcev_time_mass(socf, tn, mn);
@@ -2325,7 +2358,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             price_next = price_last + in_price_noise;
         }
     }
-    if (MODE == MODE_COMPAT && !RESET) rs.store(cr, env);
+    if (MODE == MODE_COMPAT && !RESET && !hv_walked) rs.store(cr, env);
     } while (0);
 
     CHUB_STAMP(4);  // first half (exogenous values, forecourt, next slot's exogenous update) done
@@ -2595,6 +2628,30 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
     NoMid nomid;
     env_tail<RESET, MODE, MULTI, false, NoMid, kEnvBlock, TAPE>(ctx, sa, env, env < (int) ta.n_envs && (!MULTI || in_group(sa, env)), s_pv, s_wd, s_pv_now,
                                                                 s_wd_now, s_hy, s_hv, s_out, blk, ta, nullptr, 0, 0, 0, none, false, nomid);
+}
+
+// ---------------------------------------------------------------------------------------- k_env_walk: COMPAT, the split step's second launch
+// The tails of step i and the stream walks of step i + 1 in ONE launch (lock-step steps of every env): both are one wave per SIMD --
+// the tail a latency chain that waits two thirds of its time, the walk bound by instruction issue -- and they do not depend on each other:
+// the walk needs the queue lengths and empty-slot counts the slot pass of step i has just left, and reads the streams as that slot pass
+// committed them (the tail does not touch them: its forecourt draws were made by step i's walk); it writes the streams' state behind its
+// draws to the shadow, so if a reset comes instead of step i + 1 nothing has happened.  Workgroups [0, nb_env): env_tail; the others: walks.
+__global__ __launch_bounds__(256) void k_env_walk(const DevCtx *__restrict__ ctx, StepArgs sa, TailArgs ta, StepArgs sw, int nb_env) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[32 * 256];  // the walk's rings (32 KB) / the tail's table rows and output rows (22 KB)
+    if ((int) blockIdx.x >= nb_env) {
+        __builtin_amdgcn_s_setprio(3);  // the walks are the launch's long pole: the tail wave on the same SIMD takes the issue slots they leave
+        compat_walk_block<false>(ctx, sw, blockIdx.x - (uint32_t) nb_env, lds);
+        return;
+    }
+    double *s_pv = (double *) lds, *s_wd = s_pv + 100, *s_pv_now = s_wd + 150, *s_wd_now = s_pv_now + 100, *s_hy = s_wd_now + 150;  // 602 doubles
+    uint8_t *s_hv = (uint8_t *) (s_hy + 102 + 2);                                                                                   // kLevels bytes, 16-byte aligned
+    float *s_out = (float *) (s_hv + 1008);                                                                                          // kEnvBlock * 16 floats
+    static_assert((602 + 2) * 8 + 1008 + kEnvBlock * 16 * 4 <= 32 * 256 * 4 && kLevels <= 1008, "the tail's LDS inside the walk's");
+    const int env = (int) blockIdx.x * kEnvBlock + (int) threadIdx.x;
+    TailIn none;
+    NoMid nomid;
+    env_tail<false, MODE_COMPAT, false>(ctx, sa, env, env < (int) ta.n_envs, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, s_hv, s_out, (int) blockIdx.x, ta, nullptr, 0, 0,
+                                        0, none, false, nomid);
 }
 
 // ---------------------------------------------------------------------------------------- k_compat_small: COMPAT, a handful of envs, ONE launch
@@ -3045,14 +3102,16 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
         CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, ev1, ctx, sa, nb0);
     } else if (MODE == MODE_COMPAT && !big && hp.compat_split) {
         // the split step: empties -> the stream walks, one env per lane -> the slots of both stations in one launch
-        const bool count_first = !RESET && sa.empt_fresh;
+        const bool count_first = !RESET && sa.empt_fresh && !sa.walked;
         if (count_first) {  // of every unit, whatever envs the call names: the counts are then good for whoever is stepped next
             StepArgs all = sa;
             all.env_mask = nullptr;
             CHUB_LAUNCH((k_compat_empties<BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, (hipEvent_t) nullptr, ctx, all, nb0);
         }
-        CHUB_LAUNCH((k_compat_walk<RESET>), dim3((unsigned) ((hp.n_envs + 255) / 256)), dim3(256), stream, count_first ? (hipEvent_t) nullptr : ev0, (hipEvent_t) nullptr, ctx, sa);
-        CHUB_LAUNCH((k_slot_split<RESET, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, (hipEvent_t) nullptr, ev1, ctx, sa, nb0);
+        const bool walk_now = RESET || !sa.walked;  // (otherwise the walk ran beside the previous step's tails, k_env_walk)
+        if (walk_now)
+            CHUB_LAUNCH((k_compat_walk<RESET>), dim3((unsigned) ((hp.n_envs + 255) / 256)), dim3(256), stream, count_first ? (hipEvent_t) nullptr : ev0, (hipEvent_t) nullptr, ctx, sa);
+        CHUB_LAUNCH((k_slot_split<RESET, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, walk_now ? (hipEvent_t) nullptr : ev0, ev1, ctx, sa, nb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
             StepArgs s2 = sa;
@@ -3207,6 +3266,15 @@ void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepAr
         } else if (reset) CHUB_LAUNCH((k_env<true, MODE_COMPAT, false>), dim3((unsigned) nb_env), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
         else CHUB_LAUNCH((k_env<false, MODE_COMPAT, false>), dim3((unsigned) nb_env), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, nb_env);
     }
+}
+
+// COMPAT split step, lock-step: the tails of step `sa` + the walks of the step after it (`sw`: its clock and tick)
+void launch_env_walk(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, const StepArgs &sw, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                     const PackedPtrs &pp) {
+    const TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa, pp, false);
+    const int nb_env = (int) ((hp.n_envs + kEnvBlock - 1) / kEnvBlock);
+    const unsigned nb = (unsigned) nb_env + (unsigned) ((hp.n_envs + 255) / 256);
+    CHUB_LAUNCH(k_env_walk, dim3(nb), dim3(kEnvBlock), stream, ev0, ev1, ctx, sa, ta, sw, nb_env);
 }
 
 __global__ void k_tick_advance(uint32_t *tick_base, uint32_t by) { *tick_base += by; }

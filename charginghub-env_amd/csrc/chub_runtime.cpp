@@ -31,6 +31,8 @@ void launch_expand_bits(const HubParams &hp, const uint64_t *d_bits, const float
 void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp, hipEvent_t ev0,
                        hipEvent_t ev1);
 void launch_compat_small(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp);
+void launch_env_walk(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, const StepArgs &sw, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                     const PackedPtrs &pp);
 }  // namespace chub
 
 using namespace chub;
@@ -61,6 +63,8 @@ struct chub_env {
     Tables tb;
     int device;
     bool fused;         // PHILOX lock-step steps of this handle run as ONE launch (k_step_fused): small batches
+    bool no_walk_ahead = false;  // chub_options.walk_ahead = 1: the split COMPAT step never walks ahead (A/B, parity cross-check)
+    uint32_t walked_tick = 0;  // COMPAT split step: the tick whose stream walk has run already, beside the previous step's tails (0: none)
     bool compat_small;  // COMPAT: every env fits one workgroup for both stations: lock-step resets and steps are ONE launch (k_compat_small)
     bool empt_valid;    // COMPAT, split step: StationArrays::empt holds every unit's empty-slot count for the next step (left by the last split pass)
     DevCtx *d_ctx;      // device copy of {hp, sl, st, ev, cr, tb}
@@ -381,6 +385,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if (opt.slot_kernel < 0 || opt.slot_kernel > 2) return fail(CHUB_ERR_ARG, "chub_options.slot_kernel must be 0, 1 or 2");
     if (opt.fused_step < 0 || opt.fused_step > 2) return fail(CHUB_ERR_ARG, "chub_options.fused_step must be 0, 1 or 2");
     if (opt.tile < 0 || opt.tile > 2) return fail(CHUB_ERR_ARG, "chub_options.tile must be 0, 1 or 2");
+    if (opt.walk_ahead < 0 || opt.walk_ahead > 1) return fail(CHUB_ERR_ARG, "chub_options.walk_ahead must be 0 or 1");
     *out = nullptr;
     if (n_envs <= 0) return fail(CHUB_ERR_ARG, "n_envs must be positive");
     if (n_envs * (int64_t) (cfg->station_list[0] + cfg->station_list[1] + 2) >= (int64_t) 1 << 31)
@@ -478,7 +483,8 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
 
     {   // arena: generous upper bound of everything allocated below (telemetry buffers come later, separately)
         const size_t S_tot = (size_t) (cfg->station_list[0] + cfg->station_list[1]);
-        const size_t per_env = S_tot * 40 + 1024 + (size_t) qcap * 16 + (rng_mode == CHUB_RNG_COMPAT ? 102 * 8 + 33 * 4 + 256 : 0);
+        const size_t per_env = S_tot * 40 + 1024 + (size_t) qcap * 16 +
+                               (rng_mode == CHUB_RNG_COMPAT ? 102 * 8 + 2 * 33 * 4 + 2 * 4 * (size_t) (1 + hv_max_arrive) + 1024 : 0);
         const size_t want = (size_t) n_envs * per_env + ((size_t) 8 << 20) +
                             (rng_mode == CHUB_RNG_PHILOX ? 2 * ((size_t) kSocLevels + 2) * (kClsRow * 8 + 4) : 0);
         void *q = nullptr;
@@ -514,6 +520,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     hp.rng_mode = rng_mode;
     hp.telemetry = 0;
     hp.qcap = qcap;
+    hp.hv_w = 1 + hv_max_arrive;
     hp.key[0] = (uint32_t) seed;
     hp.key[1] = (uint32_t) (seed >> 32);
     hp.cc = make_curve_consts();
@@ -729,6 +736,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     }
     {   // the reference-exact mode at a handful of envs (the drop-in class: one): both station passes and the tail in one launch
         const int64_t fit = std::min<int64_t>(64, std::min<int64_t>(kCompatSmallWaves0 * (64 / hp.U[0]), kCompatSmallWaves1 * (64 / hp.U[1])));
+        e->no_walk_ahead = opt.walk_ahead == 1;
         e->compat_small = rng_mode == CHUB_RNG_COMPAT && opt.fused_step != 1 && hp.S[0] <= 64 && hp.S[1] <= 64 && n_envs <= fit;
         // ... and everything else as the split step (stream walks, one env per lane -> slots of both stations in one launch) unless
         // slot_kernel = 1 asks for one kernel per station with the unit's first lane walking (the parity cross-check).  Measured, us per
@@ -802,8 +810,12 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     ALLOC(e->ev.drw[0], 4 * N); ALLOC(e->ev.drw[1], 4 * N); ALLOC(e->ev.drw_cnt[0], N); ALLOC(e->ev.drw_cnt[1], N);
     e->ev.obs64 = nullptr; e->ev.reward64 = nullptr; e->ev.telem = nullptr;
     e->cr.g = nullptr; e->cr.minstd = nullptr;
+    e->cr.g_next = nullptr; e->cr.minstd_next = nullptr;
+    e->ev.hv_pre[0] = e->ev.hv_pre[1] = nullptr;
     if (rng_mode == CHUB_RNG_COMPAT) {
         ALLOC(e->cr.g, N * 32); ALLOC(e->cr.minstd, N); ALLOC(e->ev.hy_env, N * 102);
+        ALLOC(e->cr.g_next, N * 32); ALLOC(e->cr.minstd_next, N);  // the walk's shadow of the streams (committed by the slot pass)
+        ALLOC(e->ev.hv_pre[0], N * (size_t) hp.hv_w); ALLOC(e->ev.hv_pre[1], N * (size_t) hp.hv_w);
         std::vector<double> rep(N * 102);  // until chub_compat_replay_constructor: every env the zero-demand table
         for (size_t i = 0; i < N; i++) memcpy(&rep[i * 102], e->hy_table, sizeof e->hy_table);
         HIP_TRY(hipMemcpy(e->ev.hy_env, rep.data(), rep.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -993,6 +1005,9 @@ static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const d
     sa.obs_stride = e->hp.obs_dim;
     sa.car_tape = e->tape_car;  // chub_reset_tape: the unit's occupancy draws are in pk already, the cars' variates come from the tape
     sa.tail_tape = e->tape_tail ? 1 : 0;  // chub_reset_tape_env: the tail's days and normals from the caller as well
+    // COMPAT split reset: the walk's draws are committed by the slot pass (k_compat_small walks the streams in place: nothing to commit)
+    sa.commit_rng = (e->hp.compat_split != 0 && !(e->compat_small && !e->per_env)) ? 1 : 0;
+    e->walked_tick = 0;                   // (a walk that ran ahead for a step that now does not come: its shadow is simply overwritten)
     sa.env_lo = 0;
     sa.env_hi = (int32_t) (e->hp.n_envs - 1);
     if (e->per_env) {
@@ -1156,6 +1171,14 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     sa.hv_tape = e->tape_hv;
     sa.hv_w = e->tape_hv_w;
     sa.tail_tape = e->tape_tail ? 1 : 0;
+    const bool split_step = e->hp.compat_split != 0 && !(e->compat_small && !load_mode && !e->per_env);
+    if (split_step) {  // COMPAT split step: the slot pass commits the walk's draws, the tail reads the forecourt's from where the walk left them
+        sa.commit_rng = 1;
+        sa.hv_tape = (const uint32_t *) e->ev.hv_pre[sa.tick & 1u];
+        sa.hv_w = e->hp.hv_w;
+        sa.walked = (e->walked_tick == e->tick && served == 2 && !e->per_env) ? 1 : 0;
+    }
+    e->walked_tick = 0;
     sa.env_lo = 0;
     sa.env_hi = (int32_t) (e->hp.n_envs - 1);
     if (e->per_env) {
@@ -1196,7 +1219,17 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
         }
     } else {
         launch_slot(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e), prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
-        launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
+        if (split_step && served == 2 && !e->per_env && !e->no_walk_ahead) {
+            // lock-step COMPAT steps of every env: the tails of this step and the stream walks of the NEXT one in one launch (k_env_walk) --
+            // if the next call is that step, its walk has run; if it is anything else, the walk's shadow is never committed
+            StepArgs sw = sa;
+            sw.t = (e->t + 1) % 96;
+            sw.tick = sa.tick + 1u;
+            launch_env_walk(e->hp, e->d_ctx, sa, sw, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
+            e->walked_tick = e->tick + 1u;
+        } else {
+            launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
+        }
         e->empt_valid = e->hp.compat_split != 0 && !e->capturing;  // (counted for every unit in front of the walk, or good already; the pass left the served units')
     }
     if (prof) e->prof_used++;
@@ -1848,6 +1881,7 @@ int chub_set_slots(chub_env *e, const int32_t *rows) {
 
 int chub_set_station_queue(chub_env *e, const int32_t *line) {
     if (!e || !line) return fail(CHUB_ERR_ARG, "null argument");
+    e->walked_tick = 0;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t) e->hp.n_envs;
@@ -2190,6 +2224,7 @@ int chub_get_reward_f64(chub_env *e, double *out) {
 
 int chub_set_rng_compat_seeds(chub_env *e, const uint32_t *seeds) {
     if (!e || !seeds) return fail(CHUB_ERR_ARG, "null argument");
+    e->walked_tick = 0;  // (a walk that ran ahead drew from the streams as they were)
     if (e->hp.rng_mode != CHUB_RNG_COMPAT) return fail(CHUB_ERR_ARG, "handle is not in COMPAT mode");
     HIP_TRY(hipSetDevice(e->device));
     const size_t N = (size_t) e->hp.n_envs;
@@ -2223,6 +2258,7 @@ int chub_set_rng_compat_seeds(chub_env *e, const uint32_t *seeds) {
 
 int chub_set_rng_compat_state(chub_env *e, const uint32_t *state) {
     if (!e || !state) return fail(CHUB_ERR_ARG, "null argument");
+    e->walked_tick = 0;  // (a walk that ran ahead of its step is void)
     if (e->hp.rng_mode != CHUB_RNG_COMPAT) return fail(CHUB_ERR_ARG, "handle is not in COMPAT mode");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
@@ -2291,6 +2327,7 @@ int chub_profile_end(chub_env *e, double *slot_ms_sum, double *env_ms_sum, int *
 
 int chub_compat_replay_constructor(chub_env *e) {
     if (!e) return fail(CHUB_ERR_ARG, "null handle");
+    e->walked_tick = 0;  // (a walk that ran ahead of its step is void)
     if (e->hp.rng_mode != CHUB_RNG_COMPAT) return fail(CHUB_ERR_ARG, "handle is not in COMPAT mode");
     HIP_TRY(hipSetDevice(e->device));
     int rc = sync_ctx(e, nullptr);
@@ -2300,6 +2337,7 @@ int chub_compat_replay_constructor(chub_env *e) {
     memset(&sa, 0, sizeof sa);
     sa.station_filter = -1;
     sa.env_hi = (int32_t) (e->hp.n_envs - 1);
+    sa.commit_rng = e->hp.compat_split;  // (the split form's walk leaves the streams' state in the shadow: the slot pass commits it)
     launch_slot(true, e->hp, e->d_ctx, sa, nullptr, packed_ptrs(e), nullptr, nullptr);
     e->empt_valid = e->hp.compat_split != 0;
     // (2) HySystem.__init__: 101 hy_step()s with live FCEV arrivals (HYD:154-157,168,250-259) -> the streams advance and
@@ -2368,6 +2406,7 @@ int chub_get_state(chub_env *e, void *buf, int64_t size) {
 
 int chub_set_state(chub_env *e, const void *buf, int64_t size) {
     if (!e || !buf) return fail(CHUB_ERR_ARG, "null argument");
+    e->walked_tick = 0;  // (a walk that ran ahead of its step is void)
     const int64_t need = chub_state_size(e);
     if (need < 0) return (int) need;
     SnapshotHeader h;

@@ -81,7 +81,11 @@ typedef struct chub_options {
                              launch too -- station 0, station 1, tail back to back -- unless this is 1. */
     int32_t tile;         /* workgroup tile of the packed slot kernel: 0 = by working-set size (default), 1 = 256 lanes x 2 slots (state
                              and action rows live in the caches), 2 = 512 lanes x 4 slots (they stream from HBM).  Results are bit-identical. */
-    int32_t reserved[4];
+    int32_t walk_ahead;   /* COMPAT split step: 0 = lock-step steps of every env run the tails of step i and the stream walks of step i + 1 in ONE
+                             launch (the walk writes a shadow of the streams that the slot pass of step i + 1 commits: a reset that comes
+                             instead never sees it) (default), 1 = never (every step walks its own streams first: the parity cross-check).
+                             Results are bit-identical. */
+    int32_t reserved[3];
 } chub_options;
 
 /* telemetry column indices of chub_get_telemetry (names of the reference attributes, MGR:183-297) */

@@ -53,7 +53,7 @@ def check_slots(got, want, what):
 
 
 @pytest.mark.parametrize("name", orclib.GOLDEN_ENV)
-@pytest.mark.parametrize("n_envs,migrate", [(1, False), (5, False), (3, True), (4, False)], ids=["1", "5", "3_restored", "4_per_station"])
+@pytest.mark.parametrize("n_envs,migrate", [(1, False), (5, False), (3, True), (4, False), (6, False)], ids=["1", "5", "3_restored", "4_per_station", "6_own_walks"])
 def test_compat_matches_reference_golden(name, n_envs, migrate):
     """COMPAT streams: the GPU reproduces the reference trajectories (every env of the batch is given the
     same seeds / tape, so each must equal the recorded single-env run).  migrate: in the middle of every episode the state is
@@ -65,9 +65,13 @@ def test_compat_matches_reference_golden(name, n_envs, migrate):
     # a handful of COMPAT envs run reset / step as ONE launch (k_compat_small: both station passes and the tail back to back); the
     # batch of 5 is kept on the form of large batches (the split step: empties, stream walks one env per lane, slots), the batch of 4 on
     # one kernel per station with the unit's first lane walking -- every fixture pins all three
-    kw["fused_step"] = "off" if n_envs in (4, 5) else "auto"
-    if n_envs in (4, 5):
+    # (round 5: the split step walks step i + 1's streams beside step i's tails, k_env_walk; the batch of 6 keeps every step's walk in its own
+    # call, chub_options.walk_ahead = 1)
+    kw["fused_step"] = "off" if n_envs in (4, 5, 6) else "auto"
+    if n_envs in (4, 5, 6):
         kw["slot_kernel"] = "wave" if n_envs == 4 else "packed"  # (COMPAT handles: one kernel per station / the split step, whatever the size)
+    if n_envs == 6:
+        kw["walk_ahead"] = "off"
     v = chub.VecChargingHub(n_envs, rng="compat", **kw)
     v.set_telemetry(True)
     S0, S1 = kw["station_list"]
