@@ -203,7 +203,18 @@ def run(name, kwargs, episodes, steps_per_episode, action_kind, seeds, py_seed=0
     out["ctor_days"] = np.array(ctor_days)
     out["ctor_z"] = np.array(ctor_z)
     out["obs_dim"] = np.array(D)
-    kw = dict(kwargs)
+    # what the constructor was actually given, and -- for kwargs left to their defaults -- the values the reference object ended up with
+    # (HySystem: hydro_prod_rate None -> 430 HYD:140-143; HyStore: None -> 5000 HYD:96; HFC: None -> 100 HYD:401-404; MGR:25-27)
+    out["ctor_kwargs_names"] = np.array(sorted(kwargs))
+    eff = {"constant_charging": False, "seed_rand": True, "hydro_prod_rate": env.hy_sys.F_h_max, "hydro_store_vlt": env.hy_sys.sty.h_v_max,
+           "init_soc": env.hy_sys.sty.init_soc_, "fc_max_power": env.hfc.cell_number, "fcev_permeate": env.fcev_permeate,
+           "use_lagrange": False, "renew_fluctuate": env.renew.renew_fluctuate if hasattr(env.renew, "renew_fluctuate") else 0.0,
+           "price_fluctuate": env.price_fluctuate, "hydro_loss": env.hy_sys.sty.hydro_loss}
+    kw = dict(eff)
+    kw.update(kwargs)
+    for k_, v_ in eff.items():  # explicit kwargs must be what the object holds, too
+        if k_ in kwargs and k_ not in ("seed_rand", "use_lagrange", "constant_charging"):
+            assert float(kwargs[k_]) == float(v_), (k_, kwargs[k_], v_)
     out["kw_station_list"] = np.array(kw.pop("station_list"))
     out["kw_station_type"] = np.array([0 if t == "fast" else 1 for t in kw.pop("station_type_list")])
     for k, v in kw.items():
@@ -287,6 +298,9 @@ def main():
     # fluctuating series and tank loss, and one of 200 steps on the C2 hub
     run("env_past_done", base_kwargs(renew_fluctuate=0.3, price_fluctuate=0.3, hydro_loss=0.01), 1, 250, "random", (3535, 3636), py_seed=18)
     run("env_past_done_c2", base_kwargs(station_list=[16, 0], fcev_permeate=0.0), 1, 200, "random", (3737, 3838), py_seed=19)
+    # every kwarg the reference gives a default left to it (MGR:25-27: a 430 m^3/h electrolyser, a 5000 m^3 tank at SOC 0.5, 100 fuel cells);
+    # seed_rand=False only so that the streams are the recorded seeds'
+    run("env_defaults", {"station_list": [20, 25], "station_type_list": ["fast", "slow"], "seed_rand": False}, 1, 96, "random", (3939, 4040), py_seed=20)
 
 
 if __name__ == "__main__":

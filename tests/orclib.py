@@ -281,7 +281,9 @@ GOLDEN_ENV = ["env_c1_envtest", "env_c3_random", "env_c2_random", "env_c5_random
               "env_slow_slow", "env_fast_fast", "env_no_electrolyser", "env_permeate_cap", "env_one_pile", "env_constant_swapped",
               # round 5: stepping past `done` without a reset (MGR:271-299; the registered horizon is 999 steps, evcssp_env_cpp/__init__.py:6):
               # one episode of 250 steps (C3 hub, fluctuating series, tank loss) and one of 200 (C2 hub)
-              "env_past_done", "env_past_done_c2"]
+              "env_past_done", "env_past_done_c2",
+              # ... and every kwarg the reference gives a default left to it (a 430 m^3/h electrolyser, a 5000 m^3 tank at SOC 0.5, 100 fuel cells)
+              "env_defaults"]
 
 
 class OrcEnv:
