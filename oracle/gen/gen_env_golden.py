@@ -301,6 +301,11 @@ def main():
     # every kwarg the reference gives a default left to it (MGR:25-27: a 430 m^3/h electrolyser, a 5000 m^3 tank at SOC 0.5, 100 fuel cells);
     # seed_rand=False only so that the streams are the recorded seeds'
     run("env_defaults", {"station_list": [20, 25], "station_type_list": ["fast", "slow"], "seed_rand": False}, 1, 96, "random", (3939, 4040), py_seed=20)
+    # the tank at the two ends of the range the constructor accepts (HYD:137: 0.1 <= init_soc <= 1): at its 10 % floor from the first step on
+    # (must_charge binds, the forecourt's demand is not met: HYD:172-176, 108-118) and full to the brim (upper_charge = 0: the electrolyser idles)
+    out = run("env_tank_floor", base_kwargs(init_soc=0.1, fcev_permeate=0.03, hydro_store_vlt=5), 1, 96, "random", (4141, 4242), py_seed=21)
+    assert out["telem"][:, 7].max() > 0, "no unmet demand in this fixture"
+    run("env_tank_brim", base_kwargs(init_soc=1.0, hydro_store_vlt=5, station_list=[6, 9]), 1, 96, "random", (4343, 4444), py_seed=22)
 
 
 if __name__ == "__main__":

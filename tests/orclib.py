@@ -283,7 +283,9 @@ GOLDEN_ENV = ["env_c1_envtest", "env_c3_random", "env_c2_random", "env_c5_random
               # one episode of 250 steps (C3 hub, fluctuating series, tank loss) and one of 200 (C2 hub)
               "env_past_done", "env_past_done_c2",
               # ... and every kwarg the reference gives a default left to it (a 430 m^3/h electrolyser, a 5000 m^3 tank at SOC 0.5, 100 fuel cells)
-              "env_defaults"]
+              "env_defaults",
+              # the tank at its 10 % floor from the first step on (unmet forecourt demand) and full to the brim (the electrolyser idles)
+              "env_tank_floor", "env_tank_brim"]
 
 
 class OrcEnv:

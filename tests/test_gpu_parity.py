@@ -539,7 +539,7 @@ def test_dropin_class_reproduces_env_test():
 PY_SEEDS = {"env_c3_random": 1, "env_c2_random": 2, "env_c5_random": 3, "env_slow_only_fcev": 4, "env_clamp": 5, "env_full_tank": 6,
             "env_constant": 7, "env_fcev_queue": 8, "env_small_fast_neg": 9, "env_fcev_queue_deep": 10, "env_big_100_70": 11,
             "env_slow_slow": 12, "env_fast_fast": 13, "env_no_electrolyser": 14, "env_permeate_cap": 15, "env_one_pile": 16,
-            "env_constant_swapped": 17, "env_past_done": 18, "env_past_done_c2": 19, "env_defaults": 20}
+            "env_constant_swapped": 17, "env_past_done": 18, "env_past_done_c2": 19, "env_defaults": 20, "env_tank_floor": 21, "env_tank_brim": 22}
 
 
 @pytest.mark.parametrize("name", sorted(PY_SEEDS))

@@ -74,7 +74,7 @@ def _pk_word(n, prev_slots, cur_slots, line_before, line_after, flow):
 ALL_FIXTURES = ["env_c1_envtest", "env_c3_random", "env_c2_random", "env_c5_random", "env_slow_only_fcev", "env_clamp", "env_full_tank",
                 "env_fcev_queue", "env_constant", "env_small_fast_neg", "env_fcev_queue_deep", "env_big_100_70",
                 "env_slow_slow", "env_fast_fast", "env_no_electrolyser", "env_permeate_cap", "env_one_pile", "env_constant_swapped",
-                "env_past_done", "env_past_done_c2", "env_defaults"]
+                "env_past_done", "env_past_done_c2", "env_defaults", "env_tank_floor", "env_tank_brim"]
 assert sorted(ALL_FIXTURES) == sorted(orclib.GOLDEN_ENV)
 
 
