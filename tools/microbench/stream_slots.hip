@@ -249,6 +249,75 @@ static void run_adj(const char *name, u32x2 *state, float **acts, uint32_t *pk, 
     hipStreamDestroy(st);
 }
 
+// FOUR ADJACENT 4-byte slots per lane: one 16-byte state load and store per lane instead of four 4-byte ones, the four actions as one
+// (unaligned) 16-byte load as if no env boundary fell between them -- a floor for a slot kernel whose lanes own runs of consecutive
+// slots instead of strided ones, not a layout proposal.  Same scattered reads per slot as k_stream4.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_stream4_adj(u32x4 *__restrict__ state4, const float *__restrict__ act, const uint32_t *__restrict__ pk,
+                                                      u32x4 *__restrict__ rec, int n_envs, int S, int epb, uint32_t magic,
+                                                      const u32x4 *__restrict__ table, const float *__restrict__ ttab, uint32_t salt) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, env_first = blockIdx.x * epb;
+    const int v = 4 * tid, e = (int) (((uint32_t) v * magic) >> 20), env = env_first + e;
+    const bool ok = e < epb && env < n_envs;
+    const uint32_t idx = (uint32_t) env_first * (uint32_t) S + (uint32_t) v;
+    u32x4 s = {0u, 0u, 0u, 0u};
+    f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (ok) {
+        s = *(const u32x4 *) ((const char *) state4 + (size_t) idx * 4u);
+        a = *(const f32x4 *) (act + idx + 2u * (uint32_t) env);
+    }
+    uint32_t sw[4] = {s.x, s.y, s.z, s.w};
+    float aw[4] = {a.x, a.y, a.z, a.w};
+    u32x4 r[4];
+    float tt[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t h = mix((idx + (uint32_t) j) ^ salt ^ sw[j]);
+        r[j] = u32x4{0u, 0u, 0u, 0u};
+        tt[j] = 0.0f;
+        if (ok && h % 100u < 55u) {
+            r[j] = *(const u32x4 *) ((const char *) table + ((h >> 8) % 4096u) * 256u + ((h >> 24) % 27u) * 8u);
+            tt[j] = ttab[(h >> 4) % 1000u];
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) sw[j] += r[j].x + r[j].w + (tt[j] + aw[j] > 0.0f ? 1u : 0u);
+        *(u32x4 *) ((char *) state4 + (size_t) idx * 4u) = u32x4{sw[0], sw[1], sw[2], sw[3]};
+    }
+    if (tid < 2 * epb) {
+        const int env2 = env_first + (tid >> 1);
+        if (env2 < n_envs) {
+            const uint32_t u = (uint32_t) (tid & 1) * (uint32_t) n_envs + (uint32_t) env2;
+            const uint32_t p = pk[u];
+            rec[u] = u32x4{p, p + 1u, p + 2u, p + 3u};
+        }
+    }
+}
+
+template <int BLOCK>
+static void run4_adj(const char *name, uint32_t *state, float **acts, uint32_t *pk, u32x4 *rec, int N, int S, const u32x4 *table, const float *ttab) {
+    const int epb = BLOCK * 4 / S;
+    const uint32_t magic = (1u << 20) / (uint32_t) S + 1u;
+    const int nb = (N + epb - 1) / epb;
+    hipStream_t st;
+    hipStreamCreate(&st);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 50; i++) hipLaunchKernelGGL((k_stream4_adj<BLOCK>), dim3(nb), dim3(BLOCK), 0, st, (u32x4 *) state, acts[i & 7], pk, rec, N, S, epb, magic, table, ttab, (uint32_t) i);
+    const int R = 2000;
+    hipEventRecord(e0, st);
+    for (int i = 0; i < R; i++) hipLaunchKernelGGL((k_stream4_adj<BLOCK>), dim3(nb), dim3(BLOCK), 0, st, (u32x4 *) state, acts[i & 7], pk, rec, N, S, epb, magic, table, ttab, (uint32_t) i * 2654435761u);
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-20s 4-byte state, FOUR ADJACENT slots per lane (16-byte accesses) + gathers %5d workgroups: %.2f us per launch\n", name, nb, ms / R * 1e3);
+    hipStreamDestroy(st);
+}
+
 template <int BLOCK, int T, bool BITS>
 static void run4(const char *name, uint32_t *state, float **acts, uint32_t *pk, u32x4 *rec, int N, int S, const u32x4 *table, const float *ttab) {
     const int epb = BLOCK * T / S;
@@ -338,5 +407,10 @@ int main(int argc, char **argv) {
     run_split<256, 2>("256 lanes x 2 slots", state, acts, pk, rec, N, S, table);
     run4<256, 2, false>("256 lanes x 2 slots", (uint32_t *) state, acts, pk, rec, N, S, table, ttab);
     run4<256, 2, true>("256 lanes x 2 slots", (uint32_t *) state, acts, pk, rec, N, S, table, ttab);
+    run4<256, 4, false>("256 lanes x 4 slots", (uint32_t *) state, acts, pk, rec, N, S, table, ttab);
+    run4<512, 4, false>("512 lanes x 4 slots", (uint32_t *) state, acts, pk, rec, N, S, table, ttab);
+    run4_adj<256>("256 lanes x 4 adj", (uint32_t *) state, acts, pk, rec, N, S, table, ttab);
+    run4_adj<512>("512 lanes x 4 adj", (uint32_t *) state, acts, pk, rec, N, S, table, ttab);
+    run4<256, 2, false>("256 lanes x 2 slots", (uint32_t *) state, acts, pk, rec, N, S, table, ttab);
     return 0;
 }
