@@ -1207,9 +1207,6 @@ __device__ __forceinline__ uint32_t sload_u32(const void *p, int i) { return ((c
 #else
 #define CHUB_ACT_LOAD(p) (*(p))
 #endif
-#ifndef CHUB_ADJ
-#define CHUB_ADJ 1  // 1: a lane owns T CONSECUTIVE slots (one 8- / 16-byte state access per lane: C5 87 -> ?? us); 0: slots strided by the workgroup size (rounds 2-4)
-#endif
 #ifndef CHUB_ACC_COPIES
 #define CHUB_ACC_COPIES 2  // copies of a unit's LDS accumulators (lanes spread over them by lane number: fewer same-address atomics; 1 / 2 / 4: 21.28 / 20.95 / 21.12 us)
 #endif
@@ -1319,24 +1316,17 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
 
     // phase A loads: slot state, action, the unit's queue length and packed draws.  No zero fill for the lanes without a slot:
     // what they hold is never used (their occupancy is forced to 0 below).
-    // ADJ: lane tid owns the T consecutive slots v = T * tid + j (its state words are ONE 8- / 16-byte access, and so are its actions where
-    // no env boundary falls between them); a wave then covers 64 * T consecutive slots.  (Rounds 2-4: v = tid + j * BLOCK, 4-byte accesses.)
-    constexpr bool ADJ = CHUB_ADJ != 0;
-    typedef uint32_t u32xT __attribute__((ext_vector_type(T == 4 ? 4 : 2), aligned(4)));
-    typedef float f32xT __attribute__((ext_vector_type(T == 4 ? 4 : 2), aligned(4)));
-    static_assert(!ADJ || T == 2 || T == 4, "the vector accesses of the adjacent layout");
     int e_[T], k_[T], slot[T];
-    bool valid[T], inr[T];
+    bool valid[T];
     uint32_t sidx[T];
     uint32_t s2[T];
     float act[T];
     u32x2 actw[T];  // BITS: the word of the env's decision bits this slot's bit sits in
     int hs_[T];
     uint32_t pk_in[T];
-    uint32_t served_[T];
 #pragma unroll
     for (int j = 0; j < T; j++) {
-        const int v = ADJ ? tid * T + j : tid + j * BLOCK;
+        const int v = tid + j * BLOCK;
         // v / (S0 + S1) (magic = 2^20 / St + 1, checked on the host); 24-bit multiplies (full rate; v < 2^11, magic <= 2^20 + 1, the
         // product below 2^32): the 32-bit v_mul_lo_u32 is a quarter-rate instruction
         e_[j] = (int) (__umul24((uint32_t) v, pa.magic) >> 20);
@@ -1345,43 +1335,24 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         hs_[j] = hs;
         slot[j] = hs - (k_[j] ? S0 : 0);
         const int env = env_first + e_[j];
-        inr[j] = e_[j] < epb && env < N;
-        valid[j] = inr[j];
-        served_[j] = 1u;  // per-env clocks: is the env served by this launch?  Requested with the state, looked at after it
-        if (MASKED && valid[j]) served_[j] = pa.env_mask[env];
+        valid[j] = e_[j] < epb && env < N;
+        uint32_t served = 1u;  // per-env clocks: is the env served by this launch?  Requested with the state, looked at after it
+        if (MASKED && valid[j]) served = pa.env_mask[env];
         sidx[j] = (uint32_t) (k_[j] ? N : 0) + (uint32_t) env;
         asm volatile("" : "=v"(s2[j]), "=v"(act[j]), "=v"(pk_in[j]), "=v"(actw[j]));
         if (RESET) {
             s2[j] = 0u;
             act[j] = 0.0f;
         }
-    }
-    // a lane whose T slots all lie inside the workgroup's envs reads them as one word; the one lane that straddles the end, slot by slot
-    const bool whole = ADJ && inr[T - 1];
-    if (ADJ && !RESET && whole) {
-        const u32xT sv = CHUB_AT(const u32xT, pa.state, (idx0 + (uint32_t) (tid * T)) << 2);
-#pragma unroll
-        for (int j = 0; j < T; j++) s2[j] = sv[j];
-        if (!BITS && e_[0] == e_[T - 1]) {  // (one env: its action row holds the T values side by side)
-            const f32xT av = CHUB_AT(const f32xT, pa.actions, (idx0 + (uint32_t) (tid * T) + 2u * (uint32_t) (env_first + e_[0])) << 2);
-#pragma unroll
-            for (int j = 0; j < T; j++) act[j] = av[j];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < T; j++) {
-        const int v = ADJ ? tid * T + j : tid + j * BLOCK;
-        const int env = env_first + e_[j];
         if (valid[j]) {
             if (!RESET) {
-                if (!(ADJ && whole)) s2[j] = CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) v) << 2);
-                if (BITS) actw[j] = CHUB_AT(const u32x2, pa.actions, ((uint32_t) env * (((uint32_t) St + 63u) >> 6) + ((uint32_t) hs_[j] >> 6)) << 3);
-                else if (!(ADJ && whole && e_[0] == e_[T - 1]))
-                    act[j] = CHUB_ACT_LOAD((CHUB_G(const float)) ((CHUB_G(const char)) pa.actions + (uint32_t) ((idx0 + (uint32_t) v + 2u * (uint32_t) env) << 2)));  // row stride S0 + S1 + 2
+                s2[j] = CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) v) << 2);
+                if (BITS) actw[j] = CHUB_AT(const u32x2, pa.actions, ((uint32_t) env * (((uint32_t) St + 63u) >> 6) + ((uint32_t) hs >> 6)) << 3);
+                else act[j] = CHUB_ACT_LOAD((CHUB_G(const float)) ((CHUB_G(const char)) pa.actions + (uint32_t) ((idx0 + (uint32_t) v + 2u * (uint32_t) env) << 2)));  // row stride S0 + S1 + 2
             }
             pk_in[j] = CHUB_AT(const uint32_t, pa.pk, sidx[j] << 2);
         }
-        if (MASKED && valid[j]) valid[j] = served_[j] != 0u;
+        if (MASKED && valid[j]) valid[j] = served != 0u;
     }
     if (!TAPE) {  // the new cars' Philox inputs: scalar registers from here on, requested behind the first loads
         pa.tick += sload_u32(pa.tick_base, 0);  // CHUB_TICK
@@ -1424,7 +1395,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     for (int j = 0; j < T; j++) {
         empty[j] = valid[j] && !stays[j];
         be[j] = __ballot(empty[j]);
-        if (lane == 0) s_ball[ADJ ? wave * T + j : wave + j * WAVES] = be[j];  // ADJ: bit l of ballot j = slot 64 T wave + T l + j
+        if (lane == 0) s_ball[wave + j * WAVES] = be[j];
     }
     if (FUSED) hook.park();
     CHUB_STAMP(3);
@@ -1439,29 +1410,6 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
             const int e = u >> 1, k = u & 1;
             const int Sk = k ? S1 : S0;
             const int U0 = e * St + (k ? S0 : 0), U1 = U0 + Sk;  // the unit's virtual lanes [U0, U1) of the workgroup
-            if (ADJ) {
-                // a wave holds 64 T consecutive slots, slot T l + j of it in bit l of its ballot j: the empties among its first X slots
-                auto below = [&](const int pw, const int X) {
-                    int c = 0;
-#pragma unroll
-                    for (int j = 0; j < T; j++) {
-                        const int n = X - j <= 0 ? 0 : (X - j + T - 1) / T;  // lanes l with T l + j < X
-                        c += __popcll(s_ball[pw * T + j] & (n >= 64 ? ~0ull : ((1ull << n) - 1ull)));
-                    }
-                    return c;
-                };
-                const int pw = U0 / (64 * T), A = U0 - pw * 64 * T;
-                const int Bq = U1 - pw * 64 * T, B = Bq < 64 * T ? Bq : 64 * T;
-                uint32_t info = (uint32_t) pw << 24;
-                if (Sk > 0) {
-                    const int start_e = below(pw, A), cnt0 = below(pw, B) - start_e;
-                    const int over = Bq - 64 * T;  // slots of the unit in the next wave
-                    const int cnt1 = over > 0 ? below(pw + 1, over) : 0;
-                    info |= (uint32_t) start_e | ((uint32_t) cnt0 << 8) | ((uint32_t) (cnt0 + cnt1) << 16);
-                }
-                s_uinfo[u] = info;
-                continue;
-            }
             const int wv = U0 >> 6, lo = U0 & 63;
             const int hi0 = (U1 - (wv << 6)) < 64 ? (U1 - (wv << 6)) : 64;
             uint32_t info = (uint32_t) wv << 24;
@@ -1519,51 +1467,15 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     bool adm[T];
     uint64_t ba[T];
     uint32_t n_push = 0;
-    // ADJ: the empties of this wave in front of the lane's first slot (every slot of a lower lane comes before it): T mbcnt pairs, once
-    int m_lane = 0;
-    if (ADJ) {
-#pragma unroll
-        for (int j = 0; j < T; j++) m_lane += prefix_count(be[j]);
-    }
 #pragma unroll
     for (int j = 0; j < T; j++) {
-        const int vw = ADJ ? wave : wave + j * WAVES;
+        const int vw = wave + j * WAVES;
         int empties, rank;
-        int m_adj = m_lane;  // ... + those of the lane's own slots in front of this one
-        if (ADJ) {
-#pragma unroll
-            for (int jj = 0; jj < T; jj++) m_adj += (jj < j && empty[jj]) ? 1 : 0;
-        }
-        if (ADJ && BIG) {
-            // a unit of up to 256 slots: its empties in every wave it touches (each wave: 64 T consecutive slots, T ballots)
-            const int Sk = k_[j] ? S1 : S0;
-            const int ub = e_[j] * St + (k_[j] ? S0 : 0), ue = ub + Sk;  // the unit's slots, workgroup numbering
-            empties = 0;
-            rank = 0;
-#pragma unroll
-            for (int w = 0; w < WAVES; w++) {
-                int lo = ub - w * 64 * T, hi = ue - w * 64 * T;  // relative to wave w's first slot
-                lo = lo < 0 ? 0 : lo;
-                hi = hi > 64 * T ? 64 * T : hi;
-                if (hi > lo) {
-                    int c_lo = 0, c_hi = 0;
-#pragma unroll
-                    for (int jj = 0; jj < T; jj++) {
-                        const uint64_t b = w == wave ? be[jj] : s_ball[w * T + jj];
-                        const int n_lo = lo - jj <= 0 ? 0 : (lo - jj + T - 1) / T, n_hi = hi - jj <= 0 ? 0 : (hi - jj + T - 1) / T;
-                        c_lo += __popcll(b & (n_lo >= 64 ? ~0ull : ((1ull << n_lo) - 1ull)));
-                        c_hi += __popcll(b & (n_hi >= 64 ? ~0ull : ((1ull << n_hi) - 1ull)));
-                    }
-                    empties += c_hi - c_lo;
-                    if (w < wave) rank += c_hi - c_lo;
-                    else if (w == wave) rank += m_adj - c_lo;
-                }
-            }
-        } else if (!BIG) {
+        if (!BIG) {
             // rank = the unit's empties in front of this lane: inside the unit's first wave, empties of the wave below the lane minus
             // those in front of the unit; in its second wave, the unit's empties of the first wave + those below the lane
             const uint32_t info = valid[j] ? s_uinfo[2 * e_[j] + k_[j]] : 0u;  // (lanes past the workgroup's last env hold no unit)
-            const int m = ADJ ? m_adj : prefix_count(be[j]);
+            const int m = prefix_count(be[j]);
             empties = (int) ((info >> 16) & 255u);
             rank = (int) (info >> 24) == vw ? m - (int) (info & 255u) : m + (int) ((info >> 8) & 255u);
         } else {
@@ -1617,22 +1529,13 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
         base = __shfl(base, 0);
 #pragma unroll
         for (int j = 0; j < T; j++) {
-            if (adm[j]) q_new[base + prefix_count(ba[j])] = (uint32_t) (ADJ ? tid * T + j : tid + j * BLOCK);
+            if (adm[j]) q_new[base + prefix_count(ba[j])] = (uint32_t) (tid + j * BLOCK);
             base += (uint32_t) __popcll(ba[j]);
         }
     }
-    bool one_store = ADJ;  // ADJ: the lane's T words leave as one, unless a new car (written by the new-car pass) or an unserved env is among them
-#pragma unroll
-    for (int j = 0; j < T; j++) one_store = one_store && valid[j] && !adm[j];
-    if (one_store) {
-        u32xT sv;
-#pragma unroll
-        for (int j = 0; j < T; j++) sv[j] = w0n[j];
-        CHUB_AT(u32xT, pa.state, (idx0 + (uint32_t) (tid * T)) << 2) = sv;
-    }
 #pragma unroll
     for (int j = 0; j < T; j++) {
-        if (!one_store && valid[j] && !adm[j]) CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) (ADJ ? tid * T + j : tid + j * BLOCK)) << 2) = w0n[j];
+        if (valid[j] && !adm[j]) CHUB_AT(uint32_t, pa.state, (idx0 + (uint32_t) (tid + j * BLOCK)) << 2) = w0n[j];
         if (valid[j] && slot[j] == 0) s_unit[2 * e_[j] + k_[j]] = pkd_make(line[j], flow[j], 0);
     }
     CHUB_STAMP(7);  // admission done, state stores issued
@@ -1720,7 +1623,7 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
 }
 
 template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED, bool BITS = false>
-__global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 6)) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in) {
+__global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_slot_packed(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in) {
     __shared__ uint32_t q_new[BLOCK * T];
     __shared__ uint32_t q_cnt[2];
     __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];                   // [1 + virtual wave]: a unit's neighbouring wave may be "wave -1" or "wave WAVES"
