@@ -347,7 +347,9 @@ class VecChargingHub(object):
     def telemetry_views(self):
         """the handle's telemetry block as live numpy views, no copy and no device read (chub_telemetry_host): telem [T_COUNT, N]
         (one row per _lib.TELEMETRY_NAMES entry), obs64 [N, D], reward64 [N].  Current once the call that produced them has
-        completed: reset() / step() return completed; after a device-pointer call, sync() first."""
+        completed: reset() / step() return completed; after a device-pointer call, sync() first.  Handles of a few envs only (action rows
+        of at most 16 KB in all: the drop-in class's one env): a batch keeps its block in device memory -- libchub returns
+        CHUB_ERR_UNSUPPORTED here (ChubError) and telemetry() / obs_f64() / reward_f64() copy."""
         if getattr(self, "_tel_views", None) is None:
             pt, po, pr = C.c_void_p(), C.c_void_p(), C.c_void_p()
             check(self._lib.chub_telemetry_host(self._h, C.byref(pt), C.byref(po), C.byref(pr)))
