@@ -55,6 +55,8 @@ constexpr int kSlotsPerLane = CHUB_SLOTS_PER_LANE;  // packed slot kernel: slots
 #endif
 constexpr int kBigBlock = CHUB_BIG_BLOCK, kBigSlotsPerLane = CHUB_BIG_SLOTS_PER_LANE;
 constexpr int64_t kBigTileSlots = (int64_t) 10 << 20;  // handles of at least this many charger slots take the second tile (chub_options.tile overrides)
+constexpr int64_t kXcdOrderSlots = (int64_t) 6 << 20;  // handles of at most this many charger slots (their streams live in the caches) run their
+                                                       // step kernels in XCD-aware work order
 constexpr int kClsRow = 32;        // PHILOX: entries (power, t_soc) per arrival-SoC class = car_steps a car can take (stay_time <= 27 here)
 constexpr int kTelemCount = 38;
 constexpr int kCompatSmallBlock = 512;  // k_compat_small: wave 0 walks the envs' streams, ...
@@ -209,6 +211,7 @@ struct HubParams {
     int32_t pblock, pslots;  // packed slot kernel: the handle's tile, (kPackedBlock, kSlotsPerLane) or (kBigBlock, kBigSlotsPerLane)
     int32_t packed;          // PHILOX steps run k_slot_packed (any hub shape of up to 512 piles)
     int32_t compat_split;    // COMPAT resets / steps run empties -> walk (lane = env) -> slots instead of one kernel per station
+    int32_t xcd;             // PHILOX packed kernels: tiles, tail and level workgroups in XCD-aware order (xcd_order in chub_kernels.hip)
 };
 
 // Everything a kernel needs that does not change from step to step, kept in device memory and passed by pointer

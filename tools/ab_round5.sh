@@ -1,6 +1,6 @@
 # A/B inside one GPU call: libchub_a.so (baseline build) against the tree's libchub.so; AB_WHAT selects the sizes
 mkdir -p gpurun_out/$1
-A=$PWD/charginghub-env_amd/libchub_a.so
+A=${AB_LIB:-$PWD/charginghub-env_amd/libchub_a.so}
 for rep in 1 2; do
   for cfg in ${AB_WHAT:-c4 c5}; do
     case $cfg in
