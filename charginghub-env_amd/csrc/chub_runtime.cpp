@@ -386,6 +386,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if (opt.fused_step < 0 || opt.fused_step > 2) return fail(CHUB_ERR_ARG, "chub_options.fused_step must be 0, 1 or 2");
     if (opt.tile < 0 || opt.tile > 2) return fail(CHUB_ERR_ARG, "chub_options.tile must be 0, 1 or 2");
     if (opt.walk_ahead < 0 || opt.walk_ahead > 1) return fail(CHUB_ERR_ARG, "chub_options.walk_ahead must be 0 or 1");
+    if (opt.work_order < 0 || opt.work_order > 1) return fail(CHUB_ERR_ARG, "chub_options.work_order must be 0 or 1");
     *out = nullptr;
     if (n_envs <= 0) return fail(CHUB_ERR_ARG, "n_envs must be positive");
     if (n_envs * (int64_t) (cfg->station_list[0] + cfg->station_list[1] + 2) >= (int64_t) 1 << 31)
@@ -717,7 +718,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         hp.pblock = big_tile ? kBigBlock : kPackedBlock;
         hp.pslots = big_tile ? kBigSlotsPerLane : kSlotsPerLane;
         // ... and the work order: XCD-aware while the streams are cache-resident (measured: 4-6 % of the step; HBM-resident sizes lose 1 %)
-        hp.xcd = (!big_tile && n_envs * (int64_t) St <= kXcdOrderSlots) ? 1 : 0;
+        hp.xcd = (opt.work_order == 0 && !big_tile && n_envs * (int64_t) St <= kXcdOrderSlots) ? 1 : 0;
         const int pb = hp.pblock * hp.pslots;
         hp.epb = pb / St > 0 ? pb / St : 1;
         if (hp.epb > pb / 4) hp.epb = pb / 4;  // the workgroup's per-unit LDS areas hold 2 * pb / 4 units: hubs of 1-3 piles leave lanes idle

@@ -85,7 +85,10 @@ typedef struct chub_options {
                              launch (the walk writes a shadow of the streams that the slot pass of step i + 1 commits: a reset that comes
                              instead never sees it) (default), 1 = never (every step walks its own streams first: the parity cross-check).
                              Results are bit-identical. */
-    int32_t reserved[3];
+    int32_t work_order;   /* PHILOX packed kernels, cache-resident sizes (the small tile, at most 6 M charger slots): 0 = tiles, tail and level workgroups
+                             take their work in contiguous eighths per XCD (the dispatcher hands workgroup b to XCD b % 8) (default),
+                             1 = the dispatcher's order (workgroup b takes tile b: the A/B and the parity cross-check).  Results are bit-identical. */
+    int32_t reserved[2];
 } chub_options;
 
 /* telemetry column indices of chub_get_telemetry (names of the reference attributes, MGR:183-297) */

@@ -140,6 +140,9 @@ PHILOX_CASES = [
                 init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01), 192),
     ("c5", dict(station_list=[32, 32], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
                 init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01, renew_fluctuate=0.3, price_fluctuate=0.3), 128),
+    # a multiple of 2048 envs: tiles, tail AND level workgroups in XCD-aware order (chub_options.work_order, k_env's level branch)
+    ("c3_xcd", dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+                    init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01, renew_fluctuate=0.2), 2048),
     ("ragged", dict(station_list=[3, 7], station_type_list=["slow", "fast"], hydro_prod_rate=430.0,
                     hydro_store_vlt=5000.0, init_soc=0.5, fc_max_power=50.0, fcev_permeate=0.05, hydro_loss=0.001), 77),
     ("one_pile", dict(station_list=[1, 0], station_type_list=["fast", "fast"], hydro_prod_rate=100.0,
@@ -294,6 +297,48 @@ def test_large_tile_is_bit_identical(piles):
         st.destroy()
     for k, (a, b) in enumerate(zip(res["small"], res["large"])):
         assert np.array_equal(a, b), ("large tile vs small tile", piles, k)
+
+
+@pytest.mark.parametrize("n", [4096, 2500, 6144 + 256])
+def test_work_order_is_bit_identical(n):
+    """chub_options.work_order: the XCD-aware order of the packed kernels' workgroups (tiles, tail and level workgroups in contiguous eighths per
+    XCD; the level workgroups only where the launch divides evenly: 4096) against the dispatcher's order on the same handle arguments --
+    resets, steps over a day and beyond, steps as graph replays: packed outputs, slot state, station records, clocks bit for bit"""
+    chub = hub()
+    from charginghub_env_amd import multi_gpu
+    kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+              init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.02, renew_fluctuate=0.2, price_fluctuate=0.1)
+    res = {}
+    for order in ("auto", "dispatch"):
+        v = chub.VecChargingHub(n, seed=9, work_order=order, fused_step="off", **kw)
+        st = multi_gpu.Stream(0)
+        acts = [multi_gpu.DeviceBuffer(n * v.act_dim * 4) for _ in range(4)]
+        for b, a in enumerate(acts):
+            v.random_actions_device(a.ptr, 41, b, st.ptr)
+        packed = [multi_gpu.DeviceBuffer(n * (v.obs_dim + 2) * 4) for _ in range(2)]
+        obs = multi_gpu.DeviceBuffer(n * v.obs_dim * 4)
+        trace = []
+        for i in range(100):
+            if i % 96 == 0:
+                v.reset_device(obs.ptr, stream=st.ptr)
+                trace.append(obs.to_host(np.float32, (n, v.obs_dim), st.ptr))
+            v.step_device_packed(acts[i % 4].ptr, packed[i & 1].ptr, stream=st.ptr)
+            if i % 9 == 0:
+                trace.append(packed[i & 1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr))
+        st.sync()
+        v.graph_begin(st.ptr)
+        for i in range(6):
+            v.step_device_packed(acts[i % 4].ptr, packed[i & 1].ptr, stream=st.ptr)
+        g = v.graph_end(st.ptr)
+        v.graph_launch(g, st.ptr)
+        trace.append(packed[1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr))
+        v.graph_destroy(g)
+        trace += [np.concatenate([x.reshape(n, -1) for x in v.slots()], axis=1), v.station_scalars().reshape(n, -1), v.env_clocks()]
+        res[order] = trace
+        v.close()
+        st.destroy()
+    for k, (a, b) in enumerate(zip(res["auto"], res["dispatch"])):
+        assert np.array_equal(a, b), ("XCD-aware order vs the dispatcher's", n, k)
 
 
 @pytest.mark.parametrize("piles,types", [((4, 5), ("fast", "slow")), ((7, 13), ("slow", "fast")), ((33, 45), ("fast", "slow")),

@@ -8,7 +8,7 @@ import charginghub_env_amd as chub
 from charginghub_env_amd import multi_gpu
 n = int(os.environ.get("AB_ENVS", "65536"))
 kw = dict(station_list=[20,25], station_type_list=["fast","slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
-STEPS, WARM = 1920, 960
+STEPS, WARM = int(os.environ.get("AB_STEPS", "1920")), int(os.environ.get("AB_WARM", "960"))
 if os.environ.get("AB_CONFIG") == "c5":  # 262 144 envs x [32, 32]: the working set beyond the Infinity Cache
     n = int(os.environ.get("AB_ENVS", "262144"))
     kw.update(station_list=[32, 32], renew_fluctuate=0.3, price_fluctuate=0.3)
@@ -16,7 +16,8 @@ if os.environ.get("AB_CONFIG") == "c5":  # 262 144 envs x [32, 32]: the working 
 if os.environ.get("AB_CONFIG") == "c2":  # 4096 envs x [16, 0]: the single-launch step
     n = int(os.environ.get("AB_ENVS", "4096"))
     kw.update(station_list=[16, 0], fcev_permeate=0.0)
-v = chub.VecChargingHub(n, seed=1, tile=os.environ.get("AB_TILE", "auto"), fused_step=os.environ.get("AB_FUSED", "auto"), **kw)
+v = chub.VecChargingHub(n, seed=1, tile=os.environ.get("AB_TILE", "auto"), fused_step=os.environ.get("AB_FUSED", "auto"),
+                        work_order=os.environ.get("AB_ORDER", "auto"), **kw)
 A = v.act_dim
 acts = [multi_gpu.DeviceBuffer(n * A * 4) for _ in range(4)]
 for b, a in enumerate(acts): v.random_actions_device(a.ptr, 123, b, 0)
@@ -51,5 +52,5 @@ st.sync()
 graph_us = (time.perf_counter() - t0) / (reps * 192) * 1e6
 v.graph_destroy(g)
 chk = float(packed.to_host(np.float32, (n, D2)).astype(np.float64).sum())  # same seeds, same result whatever the build
-print(os.environ.get("CHUB_LIB","")[-12:], os.environ.get("AB_TILE", ""), os.environ.get("AB_FUSED", ""), n, kw["station_list"], "slot_us %.2f env_us %.2f step_us %.2f graph_us %.2f  checksum %.6f" % (a/k*1e3, b/k*1e3, dt/STEPS*1e6, graph_us, chk))
+print(os.environ.get("CHUB_LIB","")[-12:], os.environ.get("AB_TILE", ""), os.environ.get("AB_FUSED", ""), os.environ.get("AB_ORDER", ""), n, kw["station_list"], "slot_us %.2f env_us %.2f step_us %.2f graph_us %.2f  checksum %.6f" % (a/k*1e3, b/k*1e3, dt/STEPS*1e6, graph_us, chk))
 v.close()
