@@ -541,6 +541,8 @@ def main():
     ap.add_argument("--no-dropin", action="store_true", help="skip the secondary dropin_single_env block (the reference-shaped class at one env, COMPAT mode as a batch)")
     ap.add_argument("--fused", choices=["auto", "on", "off"], default="auto",
                     help="the step as ONE launch (k_step_fused); auto: the library's choice (small batches)")
+    ap.add_argument("--work-order", choices=["auto", "dispatch"], default="auto",
+                    help="the packed kernels' workgroups: auto = XCD-aware where the library chooses it, dispatch = the dispatcher's order (A/B)")
     ap.add_argument("--dry-run", action="store_true",
                     help="stop every rank before libchub is loaded and print who it is (launch plumbing check, runs without a GPU)")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="(tests) with --dry-run: this rank exits with status 3")
@@ -594,7 +596,8 @@ def main():
     overlap = bool(comm is not None and args.overlap_gather)
     if overlap:
         comm.set_overlap(True)
-    v = chub.VecChargingHub(per, seed=SEED, rng="philox", device=local_rank, env_id0=rank * per, fused_step=args.fused, **hub_kw)
+    v = chub.VecChargingHub(per, seed=SEED, rng="philox", device=local_rank, env_id0=rank * per, fused_step=args.fused, work_order=args.work_order,
+                            **hub_kw)
     D, A, S = v.obs_dim, v.act_dim, v.n_slots
     v_fused = v.uses_fused_step
     stream = multi_gpu.Stream(local_rank)
@@ -809,6 +812,8 @@ def main():
                                       {"c4": "configs[3]", "c5": "configs[4]"}.get(config, config), hub_kw["fcev_permeate"]),
                        "envs_per_gpu": per, "obs_dim": D, "act_dim": A, "launch": launch,
                        "kernels_per_step": "1 (k_step_fused)" if v_fused else "2 (k_slot_packed + k_env)",
+                       "work_order": ("XCD-aware (tiles, tail and level workgroups in contiguous eighths per XCD)" if v.uses_xcd_order else
+                                      "the dispatcher's" + (" (--work-order dispatch)" if args.work_order == "dispatch" else " (the library's choice at this size)")),
                        "window": "timed: slot %d of day %d .. slot %d of day %d; roofline: whole untimed days afterwards" % (s0, d0, s1, d1),
                        "host_issue_ms_per_step": t_issue / steps * 1e3,
                        "graph": ("on" if (span_graph is not None or episode_graph is not None) else

@@ -87,7 +87,7 @@ def load_library():
         "chub_create": (I, [C.POINTER(ChubConfig), C.c_char_p, L, L, I, C.c_uint64, I, C.POINTER(P)]),
         "chub_create_ex": (I, [C.POINTER(ChubConfig), C.c_char_p, L, L, I, C.c_uint64, I, C.POINTER(ChubOptions), C.POINTER(P)]),
         "chub_destroy": (I, [P]),
-        "chub_obs_dim": (I, [P]), "chub_act_dim": (I, [P]), "chub_num_envs": (L, [P]), "chub_clock": (I, [P]), "chub_uses_packed_kernel": (I, [P]), "chub_uses_fused_step": (I, [P]),
+        "chub_obs_dim": (I, [P]), "chub_act_dim": (I, [P]), "chub_num_envs": (L, [P]), "chub_clock": (I, [P]), "chub_uses_packed_kernel": (I, [P]), "chub_uses_fused_step": (I, [P]), "chub_uses_xcd_order": (I, [P]),
         "chub_reset": (I, [P, P, P, P]),
         "chub_step": (I, [P, P, P, P, P, P]), "chub_host_actions": (I, [P, C.POINTER(P)]),
         "chub_step_bits": (I, [P, P, P, P, P, P, P]), "chub_host_bits": (I, [P, C.POINTER(P), C.POINTER(P)]),
@@ -142,7 +142,7 @@ def load_library():
     return lib
 
 
-EXPORTED = ["chub_create", "chub_create_ex", "chub_destroy", "chub_obs_dim", "chub_act_dim", "chub_num_envs", "chub_clock", "chub_uses_packed_kernel", "chub_uses_fused_step", "chub_reset",
+EXPORTED = ["chub_create", "chub_create_ex", "chub_destroy", "chub_obs_dim", "chub_act_dim", "chub_num_envs", "chub_clock", "chub_uses_packed_kernel", "chub_uses_fused_step", "chub_uses_xcd_order", "chub_reset",
             "chub_step", "chub_host_actions", "chub_step_bits", "chub_host_bits", "chub_step_bits_device", "chub_step_bits_device_packed", "chub_reset_device", "chub_step_device", "chub_step_device_packed", "chub_step_load", "chub_step_load_device", "chub_step_load_envs", "chub_step_load_envs_device", "chub_reset_envs", "chub_step_envs", "chub_reset_envs_device", "chub_step_envs_device",
             "chub_env_clocks", "chub_clock_groups", "chub_random_actions_device", "chub_sync", "chub_profile_begin", "chub_profile_end",
             "chub_get_slots", "chub_get_station_scalars", "chub_get_telemetry", "chub_get_obs_f64",

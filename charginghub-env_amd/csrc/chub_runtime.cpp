@@ -893,6 +893,7 @@ int chub_clock(const chub_env *e) {  // lock-step: the clock; per-env clocks: en
     return (int) (c & 127u);
 }
 int chub_uses_packed_kernel(const chub_env *e) { return e ? e->hp.packed : CHUB_ERR_ARG; }
+int chub_uses_xcd_order(const chub_env *e) { return e ? ((e->hp.packed && e->hp.xcd && !e->fused) ? 1 : 0) : CHUB_ERR_ARG; }  // (the single-launch step has one order only)
 int chub_uses_fused_step(const chub_env *e) { return e ? ((e->fused || e->compat_small) ? 1 : 0) : CHUB_ERR_ARG; }
 
 int chub_sync(chub_env *e) {

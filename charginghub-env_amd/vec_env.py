@@ -337,6 +337,10 @@ class VecChargingHub(object):
         return bool(self._lib.chub_uses_fused_step(self._h))
 
     @property
+    def uses_xcd_order(self):
+        return bool(self._lib.chub_uses_xcd_order(self._h))
+
+    @property
     def clock(self):
         return self._lib.chub_clock(self._h)
 

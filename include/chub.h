@@ -124,6 +124,7 @@ int64_t chub_num_envs(const chub_env *env);
 int chub_clock(const chub_env *env);    /* 0..95: the slot of day, shared by all envs while they run in lock-step (env 0's otherwise) */
 int chub_uses_packed_kernel(const chub_env *env); /* 1: PHILOX steps of this handle run k_slot_packed (the production kernel) */
 int chub_uses_fused_step(const chub_env *env);    /* 1: its lock-step steps run as one launch (k_step_fused / k_compat_small, small batches) */
+int chub_uses_xcd_order(const chub_env *env);     /* 1: its packed kernels' workgroups take their work in XCD-aware order (chub_options.work_order) */
 
 /* ---- hot path ------------------------------------------------------------------------------
  * chub_reset replaces EvcsspManagerEnv_v6.reset (MGR:304-316 -> AGG:157-175 evs_reset main.cpp:199,251,

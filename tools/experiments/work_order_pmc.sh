@@ -1,20 +1,20 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/experiments/work_order_pmc.sh <outdir>
 # What the XCD-aware work order (chub_options.work_order) changes in the memory system: counter passes of the same
-# short run (65 536 envs x [20,25], tools/ab_step_times.py) in both orders, one --pmc set per run, mean per dispatch of the two step kernels.
+# short run (65 536 envs x [20,25], bench.py --work-order ...) in both orders, one --pmc set per run, mean per dispatch of the two step kernels.
 OUT=${1:-gpurun_out/work_order_pmc}
 mkdir -p $OUT
-export TMPDIR=/tmp AB_STEPS=192 AB_WARM=96
-rocprofv3 -L > $OUT/counters_available.txt 2>&1 || true
-# (every pass under its own timeout, a pause between passes, and the script stops at the first pass that fails: a second rocprofv3 --pmc run
-# started within half a second of the previous one's exit once hung in its start-up on this pool)
+export TMPDIR=/tmp
+ARGS="--steps 96 --warmup 96 --no-cpu-baseline --no-events --no-c5 --no-bits --no-dropin"
+# (bench.py as the vehicle, as in tools/refresh_profiles.sh: a second consecutive rocprofv3 --pmc run of tools/ab_step_times.py hung in its start-up
+# twice on this pool; every pass under its own timeout, and the script stops at the first pass that fails)
 for order in auto dispatch; do
   i=0
   while read -r set; do
     [ -z "$set" ] && continue
     i=$((i+1))
     sleep 3
-    AB_ORDER=$order timeout -k 10 240 rocprofv3 --pmc $set -d $OUT/${order}_p$i --output-format csv -- python3 tools/ab_step_times.py > /dev/null 2> $OUT/${order}_p$i.err || { echo "pass $order $i failed: $set"; exit 1; }
+    timeout -k 10 300 rocprofv3 --pmc $set -d $OUT/${order}_p$i --output-format csv -- python3 bench.py $ARGS --work-order $order > /dev/null 2> $OUT/${order}_p$i.err || { echo "pass $order $i failed: $set"; exit 1; }
     echo "pass $order $i done: $set"
   done <<'SETS'
 TCC_HIT_sum TCC_MISS_sum
