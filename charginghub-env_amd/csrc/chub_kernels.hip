@@ -221,7 +221,8 @@ constexpr int MODE_COMPAT = 0, MODE_PHILOX = 1;
 
 // XCD-aware work order.  The dispatcher hands workgroup b of a launch to XCD b % 8 (each XCD has its own L2); with this mapping XCD x works
 // on ONE contiguous eighth of the launch's tiles (its b / 8-th) instead of on every eighth tile, so that neighbouring tiles -- which share
-// cache lines at their borders -- and, in both step kernels, the same envs meet in the same L2.  Measured (round 5, A/B inside one call,
+// cache lines at their borders -- share an L2 (slot kernel: L2 misses - 14 %, fabric writes - 11.5 %) and a CU touches one eighth of every
+// array (vector-TLB misses 954 -> 0 per launch); nothing stays in L2 across kernel boundaries (profiles/round5_work_order_pmc.txt).  Measured (round 5, A/B inside one call,
 // bit-identical; tiles, tail workgroups and level workgroups all in this order): cache-resident sizes gain 4-6 % of the step (C4 27.1 ->
 // 25.95 us, 32 768 envs 18.3 -> 17.1, 8192 envs 10.8 -> 10.3, 131 072 envs 44.8 -> 43.8); the HBM-resident C5 LOSES 1 % (contiguous eighths
 // concentrate each XCD's streams on fewer memory channels at a time), so handles of more than kXcdOrderSlots slots keep the dispatcher's
@@ -2626,7 +2627,7 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
 #endif
         // XCD-aware order here too where the launch divides evenly (every XCD's eighth of the envs a whole number of workgroups, the tail
         // workgroups a multiple of 8): level workgroup j runs on XCD j % 8 and takes that XCD's envs -- station 0's units, station 1's,
-        // then the env draws -- so that what it reads (the records) and leaves (the decoded draws) stays with the XCD that owns the envs
+        // then the env draws -- so that its CUs touch the same eighth of every array as the tail workgroups beside them
         const uint32_t jb = blockIdx.x - (uint32_t) nb_env, n32 = (uint32_t) ctx->hp.n_envs, per = n32 >> 3;  // envs per XCD
         bool have;
         if (!MULTI && ta.xcd && (n32 & 2047u) == 0u && ((uint32_t) nb_env & 7u) == 0u) {
