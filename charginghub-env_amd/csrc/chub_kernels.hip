@@ -1201,7 +1201,8 @@ struct PackedArgs {
     uint32_t late[8];                // the first 8 thresholds of mk_late_time's table (late_from_word); beyond them with probability 0.3 %
     CHUB_G(const uint8_t) env_mask;  // per-env clocks: non-zero = the launch serves this env (null: every env)
     uint32_t blk0;                   // ... and the first workgroup of the range of envs it names (the grid covers that range only)
-    uint32_t xcd;                    // 1: tiles in XCD-aware order (xcd_order): handles whose streams are cache-resident (the small tile)
+    uint32_t xcd;                    // non-zero: tiles in XCD-aware order (xcd_order; handles whose streams are cache-resident: the small tile) -- the
+                                     // launch's number of workgroups, here so that it arrives with the first batch of arguments (gridDim.x is a load of its own)
     CHUB_G(float) tail_act;          // [N][2] out: the env's two tail actions, for the tail kernel (StationArrays::tail_act)
     CHUB_G(uint8_t) stay8;           // [N][S0 + S1] out, per admitted car: its stay_time (introspection only)
 };
@@ -1652,7 +1653,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK <= 256 ? 8 : 2048 / BLOCK)) void k_sl
     asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
                       "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
     NoHook hook;
-    (void) slot_body_packed<BLOCK, T, TAPE, RESET, BIG, MASKED, false, NoHook, BITS>(ctx->hp, sa, pa, ctx->tb, xcd_order(blockIdx.x, gridDim.x, MASKED ? 0u : pa.xcd) + (MASKED ? pa.blk0 : 0u), q_cnt, q_new,
+    (void) slot_body_packed<BLOCK, T, TAPE, RESET, BIG, MASKED, false, NoHook, BITS>(ctx->hp, sa, pa, ctx->tb, xcd_order(blockIdx.x, pa.xcd, MASKED ? 0u : pa.xcd) + (MASKED ? pa.blk0 : 0u), q_cnt, q_new,
                                                                                      s_ball + 1, s_acc, s_unit, hook, nullptr, s_uinfo);
 }
 
@@ -3230,7 +3231,7 @@ static PackedArgs make_packed_args(const HubParams &hp, const StepArgs &sa, cons
     for (int j = 0; j < 8; j++) pa.late[j] = pp.late8[j];
     pa.env_mask = (CHUB_G(const uint8_t)) sa.env_mask;
     pa.blk0 = sa.env_mask ? (uint32_t) (sa.env_lo / hp.epb) : 0u;
-    pa.xcd = hp.xcd ? 1u : 0u;
+    pa.xcd = hp.xcd ? (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb) : 0u;  // (the grid of an unmasked launch: launch_slot)
     pa.tail_act = (CHUB_G(float)) pp.st->tail_act;
     pa.stay8 = (CHUB_G(uint8_t)) pp.stay8;
     return pa;
