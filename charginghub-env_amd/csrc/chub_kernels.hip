@@ -2015,7 +2015,8 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     const EnvArrays &ev = ctx->ev;
     const CompatRng &cr = ctx->cr;
     const Tables &tb = ctx->tb;
-    const int64_t N = hp.n_envs;
+    const int64_t N = hp.n_envs;  // (through the context pointer on purpose: round 5 measured the step 0.1 us SLOWER with this and hp.telemetry taken from
+                                  // the kernel arguments -- the first touch of the context then comes later, in the middle of the dependent chain)
     // the clock of this lane's env: the launch's (lock-step), or its group's (per-env clocks: table rows then come straight
     // from global memory instead of the LDS copy of "the" slot of the day)
     constexpr bool multi = MULTI;  // its own instantiation: the lock-step kernel carries none of this
@@ -2068,8 +2069,13 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             if (MODE == MODE_COMPAT && !multi && i < kLevels / 4) st_hv = ((CHUB_G(const uint32_t)) tb.cnt_hv)[sa.t * (kLevels / 4) + i];
         }
     }
-    // (the device-side tick offset of graph replays comes by scalar load: it does not hold up the vector loads behind it)
-    PhiloxCtx px{ta.key[0], ta.key[1], MODE == MODE_PHILOX ? sa.tick + sload_u32(ta.tick_base, 0) : sa.tick, ta.gid0 + (uint32_t) env};
+    // The device-side tick offset of graph replays is a scalar load from DEVICE memory (a miss in the scalar cache of every CU at the start of a
+    // launch), and a wave cannot wait for its scalar loads one by one: issued here it sat in front of the per-env loads below, which wait for
+    // kernel arguments (round 5: the compiler's s_waitcnt lgkmcnt(0) in front of the burst waited for it -- two round trips in a row).  The
+    // steady-state PHILOX step needs the tick only for the forecourt's later arrivals, so it asks for the offset BEHIND the burst.
+    constexpr bool tick_late = MODE == MODE_PHILOX && !RESET && !TAPE;
+    const bool tick_now = MODE == MODE_PHILOX && (!tick_late || sa.fresh != 0);
+    PhiloxCtx px{ta.key[0], ta.key[1], tick_now ? sa.tick + sload_u32(ta.tick_base, 0) : sa.tick, ta.gid0 + (uint32_t) env};
     double cap = 0.0, in_price_noise = 0.0;
     double ou_pv = 0.0, ou_wd = 0.0, ou_price = 0.0, z_pv = 0.0, z_wd = 0.0, z_pr = 0.0;
     float a_el_f = 0.0f, a_fc_f = 0.0f, P0f = 0.0f, P1f = 0.0f, mn0 = 0.0f, mx0 = 0.0f, mn1 = 0.0f, mx1 = 0.0f;
@@ -2144,6 +2150,11 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     }
 
 
+    if (tick_late && !tick_now) {
+        const uint32_t *tbp = ta.tick_base;
+        asm volatile("" : "+s"(tbp) : : "memory");  // (not to be hoisted above the loads issued so far)
+        px.tick += sload_u32(tbp, 0);
+    }
     if (!FUSED) {
         // the table rows requested at the top arrive with the state loads; park them in LDS
         static_assert(EB >= 150, "one table element per lane");
