@@ -753,6 +753,278 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     }
 }
 
+// ---------------------------------------------------------------------------------------- the split step's slot pass, two units' worth per lane
+// slot_body_compat<.., SPLIT> spends its instructions on lanes that sit idle: the f64 curve work of car_step is needed by the third of
+// the lanes whose car charges, add_car's by one lane in fifteen, and the sequential f32 sums by one lane per unit -- but a wave pays
+// for each in full.  Here a lane carries TWO slots (virtual waves 2w and 2w + 1 of the same station), and those three pieces are done
+// ONCE per wave for both: the charging lanes' inputs of both virtual waves are packed into the wave's own LDS area by ballot ranks (42 of
+// 128 on average: one pass), evaluated by lanes 0 .. n - 1 with the same device functions -- the same bits -- and picked up again;
+// likewise the new cars; and lane 2 * unit + v adds up the terms of unit `unit` of virtual wave v, so one loop serves both.  No
+// workgroup barrier anywhere (the gathering across a WORKGROUP's waves lost to its barriers).  Lock-step and
+// masked steps without the scalar-load mode; everything else keeps slot_body_compat.
+template <int TYPE, int BLOCK>
+__device__ __forceinline__ void slot_body_split2(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
+                                                 const CompatRng &cr, const int k, const int64_t block_local, float *lds) {
+    constexpr int WAVES = BLOCK / 64;
+    constexpr int kArea = 3 * 128 + 16;  // per wave: three arrays of 128 terms (aliased by the gathering areas) + the units' words
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int U = hp.U[k], S = hp.S[k];
+    const int upw = 64 / U;
+    const int uiw = lane / U;
+    const int slot = lane - uiw * U;
+    const int N = (int) hp.n_envs;
+    const int env_first = (int) block_local * (WAVES * 2 * upw);
+    const int leader = uiw < upw ? uiw * U : 63;  // the unit's first lane
+    const uint64_t unit_mask = (U == 64) ? ~0ull : (uiw < upw ? (((1ull << U) - 1ull) << leader) : 0ull);
+    const int hub_slot = (k ? hp.S[0] : 0) + slot;
+    const uint32_t St = (uint32_t) (hp.S[0] + hp.S[1]);
+    const bool cp = hp.constant_charging != 0;
+    float *wl = lds + wave * kArea;
+    uint32_t *wu = (uint32_t *) wl;
+
+    int env[2];
+    bool unit_ok[2], valid[2];
+    uint32_t idx[2], sidx[2], line_in[2], fa_w[2];
+    u32x4 hot[2];
+    float a[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        env[j] = env_first + (2 * wave + j) * upw + uiw;
+        unit_ok[j] = uiw < upw && env[j] < N && in_group(sa, env[j]);
+        valid[j] = unit_ok[j] && slot < S;
+        idx[j] = (uint32_t) hp.base[k] + (uint32_t) env[j] * (uint32_t) S + (uint32_t) slot;
+        sidx[j] = (uint32_t) k * (uint32_t) N + (uint32_t) env[j];
+        line_in[j] = 0u;
+        hot[j] = u32x4{0u, 0u, 0u, 0u};
+        a[j] = 0.0f;
+        fa_w[j] = 0u;
+        if (unit_ok[j]) line_in[j] = st.rec[4u * sidx[j] + 3u];
+        if (unit_ok[j] && slot == 0) fa_w[j] = st.fa[sidx[j]];  // what the walk came to: with the first loads
+        if (valid[j]) {
+            hot[j] = ((CHUB_G(u32x4)) sl.hot)[idx[j]];
+            a[j] = sa.actions[(uint32_t) env[j] * (uint32_t) hp.act_dim + (uint32_t) hub_slot];
+        }
+    }
+    // the step's draws are taken (the walk made them one launch ago): the streams' state it left behind them (the shadow) becomes the env's
+    // -- station 0's unit of the env does it, every env has one -- HERE, in the shadow of the first loads, not as a round trip of its own
+    // at the end of the wave (nothing else in this launch looks at the streams)
+    if (sa.commit_rng && k == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (unit_ok[j] && slot == 0) {
+                const u32x4 *src = (const u32x4 *) (cr.g_next + (size_t) env[j] * 32u);
+                u32x4 *dst = (u32x4 *) (cr.g + (size_t) env[j] * 32u);
+                u32x4 q[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) q[i] = src[i];
+                const uint32_t x = cr.minstd_next[env[j]];
+#pragma unroll
+                for (int i = 0; i < 8; i++) dst[i] = q[i];
+                cr.minstd[env[j]] = x;
+            }
+        }
+    }
+    float power[2], t_target[2], t_soc[2];
+    int tl[2], meta[2];
+    bool car[2], leave[2], on[2], charge[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        power[j] = __uint_as_float(hot[j].x);
+        t_target[j] = __uint_as_float(hot[j].y);
+        t_soc[j] = __uint_as_float(hot[j].z);
+        tl[j] = (int) (hot[j].w & 127u);
+        meta[j] = (int) (hot[j].w >> 8);
+        car[j] = tl[j] > 0;
+        leave[j] = false;
+        // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373); action_to_real (MGR:384-393)
+        on[j] = car[j] && (a[j] >= kActOnThreshold || must_charge(t_target[j], t_soc[j], tl[j]));
+    }
+    // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627), ahead of car_step: who leaves depends on the stay alone (remove_car, CHS.hpp:912-923 /
+    // 1077-1088), so the empties, the ranks and who is admitted are known here, and the new cars' variates (the walk's) are requested
+    // BEFORE the curve work instead of behind it
+    bool empty[2], adm[2];
+    int rank[2], line[2], flow[2], assign[2];
+    u32x2 vv[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        empty[j] = valid[j] && !(car[j] && tl[j] > 1);
+        const uint64_t be = __ballot(empty[j]) & unit_mask;
+        rank[j] = prefix_count(be);
+        int2 fa = make_int2(0, 0);
+        int new_line = pkd_line(line_in[j]);
+        if (unit_ok[j] && slot == 0) {
+            const uint32_t w = fa_w[j];
+            fa = make_int2((int) (int16_t) (w & 0xFFFFu), (int) ((w >> 16) & 255u));
+            new_line = (int) (w >> 24);
+        }
+        flow[j] = __shfl(fa.x, leader);
+        assign[j] = __shfl(fa.y, leader);
+        line[j] = __shfl(new_line, leader);
+        adm[j] = empty[j] && rank[j] < assign[j];
+        vv[j] = u32x2{0u, 0u};
+        if (adm[j]) vv[j] = ((CHUB_G(const u32x2)) sl.var)[(uint32_t) env[j] * St + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank[j]];
+    }
+    // ---- car_step (CHS.hpp:900-905 / 1065-1070) of both virtual waves' charging cars, packed
+    {
+        const uint64_t b0 = __ballot(on[0]), b1 = __ballot(on[1]);
+        const int n0 = __popcll(b0), n1 = __popcll(b1);
+        if (n0 + n1 <= 64) {
+            float *g_in = wl, *g_pw = wl + 64, *g_ts = wl + 128;
+            const int p0 = prefix_count(b0), p1 = n0 + prefix_count(b1);
+            if (on[0]) g_in[p0] = __fadd_rn(t_soc[0], 1.0f);
+            if (on[1]) g_in[p1] = __fadd_rn(t_soc[1], 1.0f);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < n0 + n1) {
+                float soc_new, pw;
+                car_step_curves<TYPE>(g_in[lane], cp, hp.cc, soc_new, pw);
+                g_pw[lane] = pw;
+                g_ts[lane] = soc_to_time<TYPE>(soc_new, cp);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (on[0]) { power[0] = g_pw[p0]; t_soc[0] = g_ts[p0]; }
+            if (on[1]) { power[1] = g_pw[p1]; t_soc[1] = g_ts[p1]; }
+            __builtin_amdgcn_wave_barrier();
+        } else {  // (more than half of the slots charge: each virtual wave for itself)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                if (on[j]) {
+                    float soc_new;
+                    car_step_curves<TYPE>(__fadd_rn(t_soc[j], 1.0f), cp, hp.cc, soc_new, power[j]);
+                    t_soc[j] = soc_to_time<TYPE>(soc_new, cp);
+                }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        if (on[j]) meta[j] += 1 << 17;  // one more car_step on this car's account (its SoC is replayed from it on demand)
+        if (car[j]) {  // remove_car (CHS.hpp:912-923 / 1077-1088)
+            tl[j] -= 1;
+            if (tl[j] <= 0) {
+                car[j] = false;
+                leave[j] = true;
+                tl[j] = 0;
+                power[j] = t_target[j] = t_soc[j] = 0.0f;
+                meta[j] = 0;
+            }
+        }
+        charge[j] = on[j] && car[j];
+    }
+    // ---- add_car (CHS.hpp:864-877 / 1029-1042) of both virtual waves' new cars, packed (their variates are the walk's)
+    float nc_soc[2] = {0.0f, 0.0f};
+    {
+        const uint64_t b0 = __ballot(adm[0]), b1 = __ballot(adm[1]);
+        const int n0 = __popcll(b0), n1 = __popcll(b1);
+        if (n0 + n1 <= 64) {
+            float *g_soc = wl, *g_pw = wl + 128, *g_ts = wl + 192, *g_tt = wl + 256;
+            uint32_t *g_ll = wu + 64, *g_st = wu + 320;
+            const int p0 = prefix_count(b0), p1 = n0 + prefix_count(b1);
+            if (adm[0]) { g_soc[p0] = __uint_as_float(vv[0].x); g_ll[p0] = vv[0].y; }
+            if (adm[1]) { g_soc[p1] = __uint_as_float(vv[1].x); g_ll[p1] = vv[1].y; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < n0 + n1) {
+                const uint32_t w = g_ll[lane];
+                const int lev = (int) (w & 0xFFFFu);
+                const float target = uniform_level(lev, 80.0f, 100.0f);
+                const NewCar nc = make_car<TYPE>(g_soc[lane], lev, soc_to_time<TYPE>(target, cp), (int) (w >> 16), cp);
+                g_pw[lane] = nc.power;
+                g_ts[lane] = nc.t_soc;
+                g_tt[lane] = nc.t_target;
+                g_st[lane] = (uint32_t) nc.stay;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int pj = j ? p1 : p0;
+                if (adm[j]) {
+                    const int lev = (int) (vv[j].y & 0xFFFFu);
+                    nc_soc[j] = __uint_as_float(vv[j].x);
+                    t_target[j] = g_tt[pj];
+                    t_soc[j] = g_ts[pj];
+                    tl[j] = (int) g_st[pj];
+                    power[j] = g_pw[pj];
+                    car[j] = tl[j] > 0;
+                    meta[j] = tl[j] | (lev << 7);
+                } else if (leave[j]) {
+                    meta[j] = 0;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                if (adm[j]) {
+                    const int lev = (int) (vv[j].y & 0xFFFFu);
+                    const float target = uniform_level(lev, 80.0f, 100.0f);
+                    const NewCar nc = make_car<TYPE>(__uint_as_float(vv[j].x), lev, soc_to_time<TYPE>(target, cp), (int) (vv[j].y >> 16), cp);
+                    nc_soc[j] = nc.soc;
+                    t_target[j] = nc.t_target;
+                    t_soc[j] = nc.t_soc;
+                    tl[j] = nc.stay;
+                    power[j] = nc.power;
+                    car[j] = tl[j] > 0;
+                    meta[j] = nc.stay | (nc.lev << 7);
+                } else if (leave[j]) {
+                    meta[j] = 0;
+                }
+            }
+        }
+    }
+    // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572): the reference adds slot powers sequentially in f32 (CHS.hpp:1244-1255):
+    // same order, same roundings -- lane 2 * unit + v adds up unit `unit` of virtual wave v
+    float *t_max = wl, *t_min = wl + 128, *t_chg = wl + 256;
+    uint32_t *u_word = wu + 384;  // [v * 8 + unit]: line | flow | cars of the unit (pkd_make)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const bool urgent = car[j] && must_charge(t_target[j], t_soc[j], tl[j]);
+        t_max[j * 64 + lane] = car[j] ? power[j] : 0.0f;
+        t_min[j * 64 + lane] = urgent ? power[j] : 0.0f;
+        t_chg[j * 64 + lane] = charge[j] ? power[j] : 0.0f;
+        const int cars = __popcll(__ballot(car[j]) & unit_mask);
+        if (unit_ok[j] && slot == 0) u_word[j * 8 + uiw] = pkd_make(line[j], flow[j], cars);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 2 * upw) {
+        const int v = lane & 1, un = lane >> 1;
+        const int e = env_first + (2 * wave + v) * upw + un;
+        if (e < N && in_group(sa, e)) {
+            const int base = v * 64 + un * U;
+            float r_min = 0.0f, r_max = 0.0f, r_chg = 0.0f;
+            for (int i = 0; i < S; i++) {
+                r_max = __fadd_rn(r_max, t_max[base + i]);
+                r_min = __fadd_rn(r_min, t_min[base + i]);
+                r_chg = __fadd_rn(r_chg, t_chg[base + i]);
+            }
+            rec_store(st.rec, (uint32_t) k * (uint32_t) N + (uint32_t) e, r_min, r_chg, r_max, u_word[v * 8 + un]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        if (valid[j]) {
+            u32x4 h2;
+            h2.x = __float_as_uint(power[j]);
+            h2.y = __float_as_uint(t_target[j]);
+            h2.z = __float_as_uint(t_soc[j]);
+            h2.w = (uint32_t) tl[j] | (charge[j] ? 128u : 0u) | ((uint32_t) meta[j] << 8);
+            ((CHUB_G(u32x4)) sl.hot)[idx[j]] = h2;
+            if (adm[j]) sl.init_soc[idx[j]] = nc_soc[j];  // the only cold store: the arrival SoC of a new car
+        }
+        // what the next step's walk needs of the slots: a slot is empty after remove_car iff it has at most one slot of stay left
+        const int n_empty = __popcll(__ballot(valid[j] && tl[j] <= 1) & unit_mask);
+        if (unit_ok[j] && slot == 0) st.empt[sidx[j]] = (uint8_t) n_empty;
+    }
+}
+
 // ---------------------------------------------------------------------------------------- k_slot, PHILOX, wave-local units
 // The same phases on the 4-byte PHILOX slot state for what the packed kernel below does not cover: the scalar-load control mode
 // (and every step of a handle created with chub_options.slot_kernel = 1: the parity cross-check).  One unit = H = pow2 >= S_k lanes of one wave: ballot + prefix rank inside the wave,
@@ -1880,6 +2152,20 @@ template <bool RESET>
 __global__ __launch_bounds__(256) void k_compat_walk(const DevCtx *__restrict__ ctx, StepArgs sa) {
     __shared__ uint32_t s_ring[32 * 256];
     compat_walk_block<RESET>(ctx, sa, blockIdx.x, s_ring);
+}
+
+#ifndef CHUB_SPLIT2
+#define CHUB_SPLIT2 1  // the split step's slot pass with two slots per lane (slot_body_split2); 0: slot_body_compat<.., SPLIT> for every step
+#endif
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 7) void k_slot_split2(const DevCtx *__restrict__ ctx, StepArgs sa, int64_t nb0) {
+    const HubParams &hp = ctx->hp;
+    const int64_t bid = blockIdx.x;
+    const int k = (bid >= nb0) ? 1 : 0;
+    const int64_t bl = k ? bid - nb0 : bid;
+    __shared__ float lds[(BLOCK / 64) * (3 * 128 + 16)];
+    if (hp.type[k] == 0) slot_body_split2<0, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, k, bl, lds);
+    else slot_body_split2<1, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, k, bl, lds);
 }
 
 template <bool RESET, int BLOCK>
@@ -3150,7 +3436,11 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
         const bool walk_now = RESET || !sa.walked;  // (otherwise the walk ran beside the previous step's tails, k_env_walk)
         if (walk_now)
             CHUB_LAUNCH((k_compat_walk<RESET>), dim3((unsigned) ((hp.n_envs + 255) / 256)), dim3(256), stream, count_first ? (hipEvent_t) nullptr : ev0, (hipEvent_t) nullptr, ctx, sa);
-        CHUB_LAUNCH((k_slot_split<RESET, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, walk_now ? (hipEvent_t) nullptr : ev0, ev1, ctx, sa, nb0);
+        if (CHUB_SPLIT2 && !RESET && !sa.load_mode && hp.U[0] >= 8 && hp.U[1] >= 8) {  // two slots per lane (stations of 8 to 64 piles: at most 8 units per virtual wave)
+            const int64_t sb0 = blocks_for(hp.n_envs, hp.U[0], 2 * BLOCK), sb1 = blocks_for(hp.n_envs, hp.U[1], 2 * BLOCK);
+            CHUB_LAUNCH((k_slot_split2<BLOCK>), dim3((unsigned) (sb0 + sb1)), dim3(BLOCK), stream, walk_now ? (hipEvent_t) nullptr : ev0, ev1, ctx, sa, sb0);
+        } else
+            CHUB_LAUNCH((k_slot_split<RESET, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, walk_now ? (hipEvent_t) nullptr : ev0, ev1, ctx, sa, nb0);
     } else {
         for (int k = 0; k < 2; k++) {  // the reference streams are consumed station 0 first, then station 1
             StepArgs s2 = sa;
