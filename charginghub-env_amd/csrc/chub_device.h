@@ -99,8 +99,8 @@ struct SlotArrays {          // index = base_k + env*S_k + slot  (station-major)
     // recorded number of car_steps (k_replay_soc), target SoC from its level; slots without a car read as zeros.
     CHUB_G(float) init_soc;  // arrival SoC (COMPAT)
     CHUB_G(uint8_t) stay8;   // PHILOX [N][S0 + S1]: Station::stay_time of the car in the slot (CHS.hpp:245), written when it is admitted
-    CHUB_G(uint32_t) var;    // COMPAT, split step [N][S0 + S1][2], hub-major by admission rank: what the stream walk (k_compat_walk) drew for the
-                             // r-th car a unit admits this step: arrival SoC (f32 bits), target level | extra stay << 16
+    CHUB_G(uint32_t) var[2]; // COMPAT, split step [N][S0 + S1][2], hub-major by admission rank, double-buffered by the parity of the step's tick: what the
+                             // stream walk (k_compat_walk) drew for the r-th car a unit admits in that step: arrival SoC (f32 bits), target level | extra stay << 16
 };
 
 struct StationArrays {       // unit index u = k*N + env
@@ -111,7 +111,12 @@ struct StationArrays {       // unit index u = k*N + env
                                  // instead of one 128-byte line per env of the [N, S+2] action matrix
     CHUB_G(uint8_t) empt;        // COMPAT, split step [2N]: the unit's empty slots once the NEXT step's departures are out: slots with at most one slot
                                  // of stay left (k_slot_split at its end, or k_compat_empties)
-    CHUB_G(uint32_t) fa;         // COMPAT, split step [2N]: what the unit's walk came to: flow_in (16 bits, signed) | cars admitted << 16 | queue << 24
+    CHUB_G(uint32_t) fa[2];      // COMPAT, split step [2N], by the parity of the step's tick: what the unit's walk came to: flow_in (16 bits, signed) |
+                                 // cars admitted << 16 | queue << 24
+    // ... and what lets a walk run TWO steps ahead of the slots it draws for (beside the slot pass of the step in between, k_slot_walk2):
+    CHUB_G(uint8_t) empt2[2];    // [2N], by the parity of the tick of the slot pass that leaves it: the unit's slots with at most TWO slots of stay left
+    CHUB_G(uint8_t) shrt[2];     // [2N], by the parity of the step's tick: how many of the cars the walk admits in that step stay one slot at most
+                                 // (their slots are empty again for the next step's admission; make_car's stay, same arithmetic)
     CHUB_G(uint32_t) pk[2];      // PHILOX, double-buffered by tick parity: what a unit's station-level draws of a step come to,
                                  // decoded one launch ahead against the queue the previous step left (dk_make): bits 0-7 queue after
                                  // the renege pass + arrivals that stay = the cars that want a slot, bits 8-15 flow_in.  For a reset:
@@ -152,8 +157,8 @@ struct CompatRng {           // reference streams, per env
     // the split step: the walk (k_compat_walk, lane = env) leaves the streams' state behind its draws HERE, and the slot pass of the step
     // those draws belong to (k_slot_split) commits it to g / minstd -- so a walk may run ahead of its step (beside the previous step's
     // tail, one launch: k_env_walk) and a reset that comes instead of that step simply never sees it
-    CHUB_G(uint32_t) g_next;     // [N][32]
-    CHUB_G(uint32_t) minstd_next;  // [N]
+    CHUB_G(uint32_t) g_sh[2];    // [N][32], by the parity of the tick of the step the draws belong to
+    CHUB_G(uint32_t) minstd_sh[2];  // [N]
 };
 
 struct Tables {
@@ -283,6 +288,11 @@ struct StepArgs {
     // kernel made this step's draws); hv_tape / hv_w above then also carry the forecourt's draws of that walk to the tail
     int32_t commit_rng;
     int32_t walked;          // ... and this step's walk has run already (beside the previous step's tails, k_env_walk): the slot launch skips it
+    // a walk two steps ahead of the slots (k_slot_walk2: beside the slot pass of the step before its own).  walk_far: it reads the streams
+    // as the previous step's walk left them (that step's shadow, being committed in the same launch), the queue from that walk's word
+    // and the empty slots as empt2 - cars admitted by that walk + those of them that stay one slot at most.  walk_short: the walk leaves
+    // that count (StationArrays::shrt) for the walk behind it
+    int32_t walk_far, walk_short;
 #if CHUB_TRACE
     // measurement builds only (make KFLAGS=-DCHUB_TRACE=1, tools/experiments/phase_stamps.py): s_memtime stamps at the phase boundaries of
     // the packed slot kernel and of the tail kernel (16 words per workgroup each); null: none taken

@@ -100,11 +100,13 @@ struct RingGlobal {
     __device__ __forceinline__ uint32_t get(uint32_t i) const { return g[i]; }
     __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { g[i] = v; }
 };
-struct RingLds {
+template <int NW>
+struct RingLdsT {  // NW: the lanes (envs) whose rings share the area
     uint32_t *s;
-    __device__ __forceinline__ uint32_t get(uint32_t i) const { return s[i * 256u]; }
-    __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { s[i * 256u] = v; }
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return s[i * (uint32_t) NW]; }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { s[i * (uint32_t) NW] = v; }
 };
+typedef RingLdsT<256> RingLds;
 template <typename Ring>
 struct CompatStreamT {
     Ring r;  // 32 words: ring[31] + front index
@@ -622,7 +624,7 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     if (SPLIT) {
         mid();
         if (unit_ok && slot == 0) {
-            const uint32_t w = st.fa[sidx];
+            const uint32_t w = st.fa[sa.tick & 1u][sidx];
             fa = make_int2((int) (int16_t) (w & 0xFFFFu), (int) ((w >> 16) & 255u));
             new_line = (int) (w >> 24);
         }
@@ -673,7 +675,7 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
         int lev, late_;
         float soc_;
         if (SPLIT) {
-            const u32x2 vv = ((CHUB_G(const u32x2)) sl.var)[(uint32_t) env * (uint32_t) (hp.S[0] + hp.S[1]) + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank];
+            const u32x2 vv = ((CHUB_G(const u32x2)) sl.var[sa.tick & 1u])[(uint32_t) env * (uint32_t) (hp.S[0] + hp.S[1]) + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank];
             soc_ = __uint_as_float(vv.x);
             lev = (int) (vv.y & 0xFFFFu);
             late_ = (int) (vv.y >> 16);
@@ -735,17 +737,20 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
         rec_store(st.rec, sidx, r_min, r_chg, r_max, pkd_make(line, flow, cars));
     }
     if (SPLIT) {  // what the next step's walk needs of the slots: a slot is empty after remove_car iff it has at most one slot of stay left
-        const int n_empty = __popcll(__ballot(valid && tl <= 1) & unit_mask);
-        if (unit_ok && slot == 0) st.empt[sidx] = (uint8_t) n_empty;
+        const int n_empty = __popcll(__ballot(valid && tl <= 1) & unit_mask), n_empty2 = __popcll(__ballot(valid && tl <= 2) & unit_mask);
+        if (unit_ok && slot == 0) {
+            st.empt[sidx] = (uint8_t) n_empty;
+            st.empt2[sa.tick & 1u][sidx] = (uint8_t) n_empty2;
+        }
         // ... and the step's draws are now taken: the streams' state the walk left behind them becomes the env's (station 0's unit of the
         // env does it: every env has one, with or without piles)
         if (sa.commit_rng && k == 0 && unit_ok && slot == 0) {
-            const u32x4 *src = (const u32x4 *) (cr.g_next + (size_t) env * 32u);
+            const u32x4 *src = (const u32x4 *) (cr.g_sh[sa.tick & 1u] + (size_t) env * 32u);
             u32x4 *dst = (u32x4 *) (cr.g + (size_t) env * 32u);
             u32x4 q[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) q[j] = src[j];
-            const uint32_t x = cr.minstd_next[env];
+            const uint32_t x = cr.minstd_sh[sa.tick & 1u][env];
 #pragma unroll
             for (int j = 0; j < 8; j++) dst[j] = q[j];
             cr.minstd[env] = x;
@@ -800,7 +805,7 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
         a[j] = 0.0f;
         fa_w[j] = 0u;
         if (unit_ok[j]) line_in[j] = st.rec[4u * sidx[j] + 3u];
-        if (unit_ok[j] && slot == 0) fa_w[j] = st.fa[sidx[j]];  // what the walk came to: with the first loads
+        if (unit_ok[j] && slot == 0) fa_w[j] = st.fa[sa.tick & 1u][sidx[j]];  // what the walk came to: with the first loads
         if (valid[j]) {
             hot[j] = ((CHUB_G(u32x4)) sl.hot)[idx[j]];
             a[j] = sa.actions[(uint32_t) env[j] * (uint32_t) hp.act_dim + (uint32_t) hub_slot];
@@ -813,12 +818,12 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             if (unit_ok[j] && slot == 0) {
-                const u32x4 *src = (const u32x4 *) (cr.g_next + (size_t) env[j] * 32u);
+                const u32x4 *src = (const u32x4 *) (cr.g_sh[sa.tick & 1u] + (size_t) env[j] * 32u);
                 u32x4 *dst = (u32x4 *) (cr.g + (size_t) env[j] * 32u);
                 u32x4 q[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) q[i] = src[i];
-                const uint32_t x = cr.minstd_next[env[j]];
+                const uint32_t x = cr.minstd_sh[sa.tick & 1u][env[j]];
 #pragma unroll
                 for (int i = 0; i < 8; i++) dst[i] = q[i];
                 cr.minstd[env[j]] = x;
@@ -863,7 +868,7 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
         line[j] = __shfl(new_line, leader);
         adm[j] = empty[j] && rank[j] < assign[j];
         vv[j] = u32x2{0u, 0u};
-        if (adm[j]) vv[j] = ((CHUB_G(const u32x2)) sl.var)[(uint32_t) env[j] * St + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank[j]];
+        if (adm[j]) vv[j] = ((CHUB_G(const u32x2)) sl.var[sa.tick & 1u])[(uint32_t) env[j] * St + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank[j]];
     }
     // ---- car_step (CHS.hpp:900-905 / 1065-1070) of both virtual waves' charging cars, packed
     {
@@ -1020,8 +1025,11 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
             if (adm[j]) sl.init_soc[idx[j]] = nc_soc[j];  // the only cold store: the arrival SoC of a new car
         }
         // what the next step's walk needs of the slots: a slot is empty after remove_car iff it has at most one slot of stay left
-        const int n_empty = __popcll(__ballot(valid[j] && tl[j] <= 1) & unit_mask);
-        if (unit_ok[j] && slot == 0) st.empt[sidx[j]] = (uint8_t) n_empty;
+        const int n_empty = __popcll(__ballot(valid[j] && tl[j] <= 1) & unit_mask), n_empty2 = __popcll(__ballot(valid[j] && tl[j] <= 2) & unit_mask);
+        if (unit_ok[j] && slot == 0) {
+            st.empt[sidx[j]] = (uint8_t) n_empty;
+            st.empt2[sa.tick & 1u][sidx[j]] = (uint8_t) n_empty2;
+        }
     }
 }
 
@@ -2040,8 +2048,12 @@ __global__ __launch_bounds__(BLOCK) void k_compat_empties(const DevCtx *__restri
     uint32_t w = 0u;
     if (valid) w = ctx->sl.hot[4 * ((size_t) hp.base[k] + (size_t) env * (size_t) S + (size_t) slot) + 3];  // (slot indices go up to 2^31: 64-bit word index)
     const bool empty = valid && (int) (w & 127u) <= 1;
-    const uint64_t be = __ballot(empty) & unit_mask;
-    if (unit_ok && slot == 0) ctx->st.empt[(uint32_t) k * (uint32_t) hp.n_envs + (uint32_t) env] = (uint8_t) __popcll(be);
+    const uint64_t be = __ballot(empty) & unit_mask, be2 = __ballot(valid && (int) (w & 127u) <= 2) & unit_mask;
+    if (unit_ok && slot == 0) {
+        ctx->st.empt[(uint32_t) k * (uint32_t) hp.n_envs + (uint32_t) env] = (uint8_t) __popcll(be);
+        // ... and what the slot pass of the step before this one would have left for the walk of the step behind this one (empt2)
+        ctx->st.empt2[(sa.tick + 1u) & 1u][(uint32_t) k * (uint32_t) hp.n_envs + (uint32_t) env] = (uint8_t) __popcll(be2);
+    }
 }
 
 // The walk of ONE env: station 0's draws, then station 1's, in the reference's consumption order (receive_car, CHS.hpp:1272-1316 /
@@ -2056,12 +2068,25 @@ __device__ __forceinline__ void compat_walk_env(const DevCtx *__restrict__ ctx, 
     const StationArrays &st = ctx->st;
     const int64_t N = hp.n_envs;
     const uint32_t St = (uint32_t) (hp.S[0] + hp.S[1]);
+    const uint32_t par = sa.tick & 1u;  // the step the draws belong to: its buffers
+    const bool far = !RESET && sa.walk_far != 0;
+    const bool cp = hp.constant_charging != 0;
     for (int k = 0; k < 2; k++) {
         const int S = hp.S[k];
         const bool fast = hp.type[k] == 0;
         const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
-        const int line = RESET ? 0 : pkd_line(st.rec[4u * sidx + 3u]);
-        const int empties = RESET ? S : (int) st.empt[sidx];
+        int line = 0, empties = S;
+        if (far) {
+            // two steps ahead of the slots (StepArgs::walk_far): the queue as the previous step's walk left it, and the slots that will be
+            // empty = those with at most two slots of stay left when the step before that one ended, minus the cars the previous step's
+            // walk admits, plus those of them that stay one slot at most
+            const uint32_t wp = st.fa[par ^ 1u][sidx];
+            line = (int) (wp >> 24);
+            empties = (int) st.empt2[par][sidx] - (int) ((wp >> 16) & 255u) + (int) st.shrt[par ^ 1u][sidx];
+        } else if (!RESET) {
+            line = pkd_line(st.rec[4u * sidx + 3u]);
+            empties = (int) st.empt[sidx];
+        }
         const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
         int n_in;
         if (RESET) {
@@ -2086,15 +2111,25 @@ __device__ __forceinline__ void compat_walk_env(const DevCtx *__restrict__ ctx, 
         const int as = (new_line + fl) < empties ? (new_line + fl) : empties;
         new_line = new_line + fl - as;
         new_line = new_line < kMaxLine ? new_line : kMaxLine;
-        CHUB_G(u32x2) var = (CHUB_G(u32x2)) ctx->sl.var + ((uint32_t) env * St + (uint32_t) (k ? hp.S[0] : 0));
+        CHUB_G(u32x2) var = (CHUB_G(u32x2)) ctx->sl.var[par] + ((uint32_t) env * St + (uint32_t) (k ? hp.S[0] : 0));
+        int n_short = 0;
         for (int rr = 0; rr < as; rr++) {  // ascending slot order == ascending rank
             const float soc = arrive_soc_from(rs.normal_d(7.0, 3.0));
             const uint32_t lev = (uint32_t) rs.level();
             int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
             late = late < 0 ? 0 : late;
             var[rr] = u32x2{__float_as_uint(soc), lev | ((uint32_t) late << 16)};
+            // the stay add_car will give this car (make_car: ceil(soc_to_time(target) - soc_to_time(soc)) + late, the same functions on the
+            // same values): one slot at most only without extra stay, and only at a fast station -- a slow one needs more than a slot from
+            // the highest arrival SoC (70) to the lowest target (80) on either of its curves (1.29 / 1.47 slots)
+            if (sa.walk_short && fast && late == 0) {
+                const float target = uniform_level((int) lev, 80.0f, 100.0f);
+                const float need = __fsub_rn(soc_to_time<0>(target, cp), soc_to_time<0>(soc, cp));
+                n_short += ((int) ceilf(need) <= 1) ? 1 : 0;
+            }
         }
-        st.fa[sidx] = ((uint32_t) fl & 0xFFFFu) | ((uint32_t) (as > 0 ? as : 0) << 16) | ((uint32_t) new_line << 24);
+        st.fa[par][sidx] = ((uint32_t) fl & 0xFFFFu) | ((uint32_t) (as > 0 ? as : 0) << 16) | ((uint32_t) new_line << 24);
+        if (sa.walk_short) st.shrt[par][sidx] = (uint8_t) n_short;
     }
     if (FORECOURT && !RESET) {
         const int t_env = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;
@@ -2105,45 +2140,54 @@ __device__ __forceinline__ void compat_walk_env(const DevCtx *__restrict__ ctx, 
     }
 }
 
-// One workgroup's 256 walks: the rings parked in LDS, walked, and the streams' state behind the draws written to the SHADOW (g_next /
-// minstd_next): the slot pass of the step the draws belong to commits it.
-template <bool RESET>
-__device__ __forceinline__ void compat_walk_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const uint32_t blk, uint32_t *s_ring) {
+// One workgroup's NW walks (256; k_slot_walk2: 64, one wave): the rings parked in LDS, walked, and the streams' state behind the draws
+// written to the SHADOW of the step the draws belong to (g_sh / minstd_sh of its tick's parity): the slot pass of that step commits it.
+// A walk two steps ahead (StepArgs::walk_far) starts from the previous step's shadow instead of the committed streams.
+template <bool RESET, int NW = 256>
+__device__ __forceinline__ void compat_walk_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const uint32_t blk, uint32_t *s_ring,
+                                                  const uint32_t tid = threadIdx.x) {  // tid: the lane's number among the block's NW
     const int64_t N = ctx->hp.n_envs;
-    // the glibc rings of the workgroup's 256 envs (32 KB, one contiguous run of memory) are parked in LDS for the walk: transposed, so that
-    // the lanes of a wave hit different banks when each reads a word of its own ring
-    const uint32_t env0 = blk * 256u;
-    const uint32_t n_here = (uint32_t) N - env0 < 256u ? (uint32_t) N - env0 : 256u;
+    const uint32_t par = sa.tick & 1u;
+    const bool far = !RESET && sa.walk_far != 0;
+    const uint32_t *g_src = far ? (const uint32_t *) ctx->cr.g_sh[par ^ 1u] : (const uint32_t *) ctx->cr.g;
+    const uint32_t *m_src = far ? (const uint32_t *) ctx->cr.minstd_sh[par ^ 1u] : (const uint32_t *) ctx->cr.minstd;
+    // the glibc rings of the workgroup's envs (128 bytes each, one contiguous run of memory) are parked in LDS for the walk: transposed, so
+    // that the lanes of a wave hit different banks when each reads a word of its own ring
+    const uint32_t env0 = blk * (uint32_t) NW;
+    const uint32_t n_here = (uint32_t) N - env0 < (uint32_t) NW ? (uint32_t) N - env0 : (uint32_t) NW;
     {
-        const u32x4 *src = (const u32x4 *) (ctx->cr.g + (size_t) env0 * 32u);
-        for (uint32_t j = threadIdx.x; j < n_here * 8u; j += 256u) {
+        const u32x4 *src = (const u32x4 *) (g_src + (size_t) env0 * 32u);
+        for (uint32_t j = tid; j < n_here * 8u; j += (uint32_t) NW) {
             const u32x4 q = src[j];
             const uint32_t l = j >> 3, w = (j & 7u) << 2;
-            s_ring[(w + 0u) * 256u + l] = q.x;
-            s_ring[(w + 1u) * 256u + l] = q.y;
-            s_ring[(w + 2u) * 256u + l] = q.z;
-            s_ring[(w + 3u) * 256u + l] = q.w;
+            s_ring[(w + 0u) * (uint32_t) NW + l] = q.x;
+            s_ring[(w + 1u) * (uint32_t) NW + l] = q.y;
+            s_ring[(w + 2u) * (uint32_t) NW + l] = q.z;
+            s_ring[(w + 3u) * (uint32_t) NW + l] = q.w;
         }
     }
     __syncthreads();
     // (64 walks per wave: fewer -- 32 or 16 envs per wave, more waves -- measured slower: 115 / 129 vs 110 us per step at 65 536 envs)
-    const int env = (int) (env0 + threadIdx.x);
+    const int env = (int) (env0 + tid);
     if (env < (int) N && in_group(sa, env)) {
-        CompatStreamT<RingLds> rs;
-        rs.r.s = s_ring + threadIdx.x;
+        CompatStreamT<RingLdsT<NW>> rs;
+        rs.r.s = s_ring + tid;
         rs.gf = rs.r.get(31);
         rs.gr = (rs.gf + 28u) % 31u;
-        rs.x = ctx->cr.minstd[env];
-        compat_walk_env<RESET, CompatStreamT<RingLds>, true>(ctx, sa, env, rs);
+        rs.x = m_src[env];
+        compat_walk_env<RESET, CompatStreamT<RingLdsT<NW>>, true>(ctx, sa, env, rs);
         rs.r.set(31, rs.gf);
-        ctx->cr.minstd_next[env] = rs.x;
+        ctx->cr.minstd_sh[par][env] = rs.x;
+    } else if (env < (int) N) {
+        ctx->cr.minstd_sh[par][env] = m_src[env];  // (an env the call does not name: its streams as they are, in the shadow too)
     }
     __syncthreads();
     {
-        u32x4 *dst = (u32x4 *) (ctx->cr.g_next + (size_t) env0 * 32u);
-        for (uint32_t j = threadIdx.x; j < n_here * 8u; j += 256u) {
+        u32x4 *dst = (u32x4 *) (ctx->cr.g_sh[par] + (size_t) env0 * 32u);
+        for (uint32_t j = tid; j < n_here * 8u; j += (uint32_t) NW) {
             const uint32_t l = j >> 3, w = (j & 7u) << 2;
-            dst[j] = u32x4{s_ring[(w + 0u) * 256u + l], s_ring[(w + 1u) * 256u + l], s_ring[(w + 2u) * 256u + l], s_ring[(w + 3u) * 256u + l]};
+            dst[j] = u32x4{s_ring[(w + 0u) * (uint32_t) NW + l], s_ring[(w + 1u) * (uint32_t) NW + l], s_ring[(w + 2u) * (uint32_t) NW + l],
+                           s_ring[(w + 3u) * (uint32_t) NW + l]};
         }
     }
 }
@@ -2164,6 +2208,34 @@ __global__ __launch_bounds__(BLOCK, 7) void k_slot_split2(const DevCtx *__restri
     const int k = (bid >= nb0) ? 1 : 0;
     const int64_t bl = k ? bid - nb0 : bid;
     __shared__ float lds[(BLOCK / 64) * (3 * 128 + 16)];
+    if (hp.type[k] == 0) slot_body_split2<0, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, k, bl, lds);
+    else slot_body_split2<1, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, k, bl, lds);
+}
+
+// The slot pass of step i and the stream walks of step i + 1 in ONE launch: the walk -- one serial chain per env, a wave per SIMD for 20 to
+// 40 us -- no longer stands between two slot passes but runs in the shadow of one.  It cannot look at what the slot pass beside it leaves,
+// and does not need to: who leaves depends on the stays alone, so the slots that will be empty for step i + 1 are those with at most two
+// slots of stay left after step i - 1 (StationArrays::empt2, left by that step's pass) minus the cars step i admits (its walk's word) plus
+// those of them that stay one slot at most (StationArrays::shrt, from that walk: make_car's arithmetic); the queue is in that word too,
+// and the streams continue from step i's shadow, which the slot pass beside it is committing (StepArgs::walk_far).  Workgroups
+// [0, nwalk): 64 walks each, on their first wave (8 KB of rings in LDS: a larger area would cost the slot workgroups their occupancy),
+// at raised priority; the others: slot_body_split2.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 7) void k_slot_walk2(const DevCtx *__restrict__ ctx, StepArgs sa, StepArgs sw, int64_t nb0, int nwalk) {
+    constexpr int kWords = (BLOCK / 64) * (3 * 128 + 16) > 32 * 64 ? (BLOCK / 64) * (3 * 128 + 16) : 32 * 64;
+    __shared__ float lds[kWords];
+    if ((int) blockIdx.x < nwalk) {
+        // one wave of the workgroup walks, the others end at once (ended waves do not count at its barriers) -- the wave whose number is
+        // the workgroup's modulo 4, so that the walks of the workgroups a CU receives do not all sit on the same SIMD
+        if ((threadIdx.x >> 6) != (blockIdx.x & 3u)) return;
+        __builtin_amdgcn_s_setprio(3);
+        compat_walk_block<false, 64>(ctx, sw, blockIdx.x, (uint32_t *) lds, threadIdx.x & 63u);
+        return;
+    }
+    const HubParams &hp = ctx->hp;
+    const int64_t bid = (int64_t) blockIdx.x - nwalk;
+    const int k = (bid >= nb0) ? 1 : 0;
+    const int64_t bl = k ? bid - nb0 : bid;
     if (hp.type[k] == 0) slot_body_split2<0, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, k, bl, lds);
     else slot_body_split2<1, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, k, bl, lds);
 }
@@ -3450,6 +3522,28 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
             else CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), stream, e0, e1, ctx, s2, nb0);
         }
     }
+}
+
+// COMPAT split step, lock-step steps of every env of a handle whose stations take the two-slots-per-lane pass: the slot pass of step i
+// (sa) beside the stream walks of step i + 1 (sw: walk_far), k_slot_walk2.  Step i's own walk first where it has not run (the first step
+// after a reset or anything else that voided it: near, from the committed streams), the empty-slot counts in front of it where they are
+// not the previous pass's.
+bool slot_walk2_covers(const HubParams &hp) { return CHUB_SPLIT2 && hp.compat_split && hp.S[0] <= 64 && hp.S[1] <= 64 && hp.U[0] >= 8 && hp.U[1] >= 8; }
+void launch_slot_walk2(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, const StepArgs &sw, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    constexpr int BLOCK = 256;
+    const int64_t nb0 = blocks_for(hp.n_envs, hp.U[0], BLOCK), nb1 = blocks_for(hp.n_envs, hp.U[1], BLOCK);
+    const bool count_first = sa.empt_fresh && !sa.walked;
+    if (count_first) {
+        StepArgs all = sa;
+        all.env_mask = nullptr;
+        CHUB_LAUNCH((k_compat_empties<BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, ev0, (hipEvent_t) nullptr, ctx, all, nb0);
+    }
+    const bool walk_now = !sa.walked;
+    if (walk_now)
+        CHUB_LAUNCH((k_compat_walk<false>), dim3((unsigned) ((hp.n_envs + 255) / 256)), dim3(256), stream, count_first ? (hipEvent_t) nullptr : ev0, (hipEvent_t) nullptr, ctx, sa);
+    const int64_t sb0 = blocks_for(hp.n_envs, hp.U[0], 2 * BLOCK), sb1 = blocks_for(hp.n_envs, hp.U[1], 2 * BLOCK);
+    const int nwalk = (int) ((hp.n_envs + 63) / 64);
+    CHUB_LAUNCH((k_slot_walk2<BLOCK>), dim3((unsigned) (nwalk + sb0 + sb1)), dim3(BLOCK), stream, walk_now ? (hipEvent_t) nullptr : ev0, ev1, ctx, sa, sw, sb0, nwalk);
 }
 
 static PackedArgs make_packed_args(const HubParams &hp, const StepArgs &sa, const PackedPtrs &pp);

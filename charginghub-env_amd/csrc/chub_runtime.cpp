@@ -31,6 +31,8 @@ void launch_expand_bits(const HubParams &hp, const uint64_t *d_bits, const float
 void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp, hipEvent_t ev0,
                        hipEvent_t ev1);
 void launch_compat_small(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp);
+bool slot_walk2_covers(const HubParams &hp);
+void launch_slot_walk2(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, const StepArgs &sw, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 void launch_env_walk(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, const StepArgs &sw, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
                      const PackedPtrs &pp);
 }  // namespace chub
@@ -65,6 +67,7 @@ struct chub_env {
     bool fused;         // PHILOX lock-step steps of this handle run as ONE launch (k_step_fused): small batches
     bool no_walk_ahead = false;  // chub_options.walk_ahead = 1: the split COMPAT step never walks ahead (A/B, parity cross-check)
     uint32_t walked_tick = 0;  // COMPAT split step: the tick whose stream walk has run already, beside the previous step's tails (0: none)
+    uint32_t e2_tick = ~0u;    // ... and the tick of the pass after which StationArrays::empt2 holds every unit's count (what a walk two steps ahead needs)
     bool compat_small;  // COMPAT: every env fits one workgroup for both stations: lock-step resets and steps are ONE launch (k_compat_small)
     bool empt_valid;    // COMPAT, split step: StationArrays::empt holds every unit's empty-slot count for the next step (left by the last split pass)
     DevCtx *d_ctx;      // device copy of {hp, sl, st, ev, cr, tb}
@@ -484,8 +487,8 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
 
     {   // arena: generous upper bound of everything allocated below (telemetry buffers come later, separately)
         const size_t S_tot = (size_t) (cfg->station_list[0] + cfg->station_list[1]);
-        const size_t per_env = S_tot * 40 + 1024 + (size_t) qcap * 16 +
-                               (rng_mode == CHUB_RNG_COMPAT ? 102 * 8 + 2 * 33 * 4 + 2 * 4 * (size_t) (1 + hv_max_arrive) + 1024 : 0);
+        const size_t per_env = S_tot * 40 + 1024 + (size_t) qcap * 16 +  // (COMPAT: 16 + 4 + 2 * 8 bytes per slot)
+                               (rng_mode == CHUB_RNG_COMPAT ? 102 * 8 + 3 * 33 * 4 + 2 * 4 * (size_t) (1 + hv_max_arrive) + 1024 + 64 : 0);
         const size_t want = (size_t) n_envs * per_env + ((size_t) 8 << 20) +
                             (rng_mode == CHUB_RNG_PHILOX ? 2 * ((size_t) kSocLevels + 2) * (kClsRow * 8 + 4) : 0);
         void *q = nullptr;
@@ -794,16 +797,18 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
     e->sl.init_soc = nullptr;
     e->sl.stay8 = nullptr;
-    e->sl.var = nullptr;
+    e->sl.var[0] = e->sl.var[1] = nullptr;
     e->st.empt = nullptr;
-    e->st.fa = nullptr;
+    e->st.fa[0] = e->st.fa[1] = nullptr;
+    e->st.empt2[0] = e->st.empt2[1] = e->st.shrt[0] = e->st.shrt[1] = nullptr;
     if (rng_mode == CHUB_RNG_PHILOX) {
         ALLOC(e->sl.hot, NS);  // 4-byte slot state
         ALLOC(e->sl.stay8, NS);
     } else {
         ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.init_soc, NS);
-        ALLOC(e->sl.var, 2 * NS);  // the split step's per-admission variates
-        ALLOC(e->st.empt, 2 * N); ALLOC(e->st.fa, 2 * N);
+        ALLOC(e->sl.var[0], 2 * NS); ALLOC(e->sl.var[1], 2 * NS);  // the split step's per-admission variates
+        ALLOC(e->st.empt, 2 * N); ALLOC(e->st.fa[0], 2 * N); ALLOC(e->st.fa[1], 2 * N);
+        ALLOC(e->st.empt2[0], 2 * N); ALLOC(e->st.empt2[1], 2 * N); ALLOC(e->st.shrt[0], 2 * N); ALLOC(e->st.shrt[1], 2 * N);
     }
     ALLOC(e->st.rec, 8 * N); ALLOC(e->st.pk[0], 2 * N); ALLOC(e->st.pk[1], 2 * N); ALLOC(e->st.tail_act, 2 * N);
     ALLOC(e->ev.cap, N); ALLOC(e->ev.store_soc, N); ALLOC(e->ev.ou, 3 * N); ALLOC(e->ev.price_noise, N);
@@ -813,11 +818,13 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     ALLOC(e->ev.drw[0], 4 * N); ALLOC(e->ev.drw[1], 4 * N); ALLOC(e->ev.drw_cnt[0], N); ALLOC(e->ev.drw_cnt[1], N);
     e->ev.obs64 = nullptr; e->ev.reward64 = nullptr; e->ev.telem = nullptr;
     e->cr.g = nullptr; e->cr.minstd = nullptr;
-    e->cr.g_next = nullptr; e->cr.minstd_next = nullptr;
+    e->cr.g_sh[0] = e->cr.g_sh[1] = nullptr; e->cr.minstd_sh[0] = e->cr.minstd_sh[1] = nullptr;
     e->ev.hv_pre[0] = e->ev.hv_pre[1] = nullptr;
     if (rng_mode == CHUB_RNG_COMPAT) {
         ALLOC(e->cr.g, N * 32); ALLOC(e->cr.minstd, N); ALLOC(e->ev.hy_env, N * 102);
-        ALLOC(e->cr.g_next, N * 32); ALLOC(e->cr.minstd_next, N);  // the walk's shadow of the streams (committed by the slot pass)
+        for (int p = 0; p < 2; p++) {  // the walks' shadows of the streams (committed by the slot pass of the step the draws belong to), by tick parity
+            ALLOC(e->cr.g_sh[p], N * 32); ALLOC(e->cr.minstd_sh[p], N);
+        }
         ALLOC(e->ev.hv_pre[0], N * (size_t) hp.hv_w); ALLOC(e->ev.hv_pre[1], N * (size_t) hp.hv_w);
         std::vector<double> rep(N * 102);  // until chub_compat_replay_constructor: every env the zero-demand table
         for (size_t i = 0; i < N; i++) memcpy(&rep[i * 102], e->hy_table, sizeof e->hy_table);
@@ -994,6 +1001,11 @@ static int note_served(chub_env *e, const uint8_t *mask, int served, hipStream_t
 }
 
 // ONE launched reset: of every env (served = 2) or of the envs of the uploaded mask (served = 1)
+// COMPAT: the handle's lock-step steps of every env run the slot pass beside the NEXT step's stream walks (k_slot_walk2)
+static bool walks_two_ahead(const chub_env *e) {
+    return e->hp.rng_mode == CHUB_RNG_COMPAT && !e->compat_small && !e->no_walk_ahead && slot_walk2_covers(e->hp);
+}
+
 static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const double *d_exo_z, float *d_obs, hipStream_t s) {
     e->tick += 1;
     StepArgs sa;
@@ -1011,6 +1023,7 @@ static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const d
     sa.tail_tape = e->tape_tail ? 1 : 0;  // chub_reset_tape_env: the tail's days and normals from the caller as well
     // COMPAT split reset: the walk's draws are committed by the slot pass (k_compat_small walks the streams in place: nothing to commit)
     sa.commit_rng = (e->hp.compat_split != 0 && !(e->compat_small && !e->per_env)) ? 1 : 0;
+    sa.walk_short = walks_two_ahead(e) ? 1 : 0;  // (the reset's walk leaves its short stays for a walk two steps ahead, as every walk of such a handle)
     e->walked_tick = 0;                   // (a walk that ran ahead for a step that now does not come: its shadow is simply overwritten)
     sa.env_lo = 0;
     sa.env_hi = (int32_t) (e->hp.n_envs - 1);
@@ -1032,6 +1045,7 @@ static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const d
         launch_env(true, e->hp, e->d_ctx, sa, s, nullptr, nullptr, packed_ptrs(e));
         // (a split reset leaves the counts of the units it served; those of the others are as good as they were)
         e->empt_valid = e->hp.compat_split != 0 && (served == 2 || e->empt_valid) && !e->capturing;
+        if (e->hp.compat_split != 0 && served == 2 && !e->capturing) e->e2_tick = e->tick;  // (... and every unit's empt2, at this tick's parity)
     }
     HIP_TRY(hipGetLastError());
     e->predrawn = served == 2;  // the launch's level blocks left the next step's draws of every env it served
@@ -1181,6 +1195,7 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
         sa.hv_tape = (const uint32_t *) e->ev.hv_pre[sa.tick & 1u];
         sa.hv_w = e->hp.hv_w;
         sa.walked = (e->walked_tick == e->tick && served == 2 && !e->per_env) ? 1 : 0;
+        sa.walk_short = walks_two_ahead(e) ? 1 : 0;
     }
     e->walked_tick = 0;
     sa.env_lo = 0;
@@ -1221,8 +1236,23 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
             HIP_TRY(hipEventRecord(pe[2], s));
             HIP_TRY(hipEventRecord(pe[3], s));
         }
+    } else if (split_step && served == 2 && !e->per_env && !load_mode && !e->capturing && walks_two_ahead(e)) {
+        // lock-step COMPAT steps of every env, stations of 8 to 64 piles: the slot pass of this step beside the stream walks of the NEXT one
+        // (k_slot_walk2: the walk two steps ahead of the slots it draws for), then the tails alone -- if the next call is that step, its walk
+        // has run; if it is anything else, the walk's shadow is never committed
+        if (e->e2_tick != e->tick - 1u) sa.empt_fresh = 1;  // (empt2 is not the previous pass's for every unit: counted in front)
+        StepArgs sw = sa;
+        sw.t = (e->t + 1) % 96;
+        sw.tick = sa.tick + 1u;
+        sw.walk_far = 1;
+        launch_slot_walk2(e->hp, e->d_ctx, sa, sw, s, prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
+        launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
+        e->walked_tick = e->tick + 1u;
+        e->empt_valid = true;
+        e->e2_tick = e->tick;
     } else {
         launch_slot(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e), prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
+        if (split_step && served == 2 && !e->per_env && !e->capturing) e->e2_tick = e->tick;  // (every unit's empt2, whichever pass it was)
         if (split_step && served == 2 && !e->per_env && !e->no_walk_ahead) {
             // lock-step COMPAT steps of every env: the tails of this step and the stream walks of the NEXT one in one launch (k_env_walk) --
             // if the next call is that step, its walk has run; if it is anything else, the walk's shadow is never committed
