@@ -491,8 +491,8 @@ def dropin_block(chub, multi_gpu, lib, device):
         assert np.isfinite(o).all()
         rates[str(n)] = {"value": n * 192 / dt, "unit": "env-steps/s", "ms_per_step": dt / 192 * 1e3}
         if n == 65536:
-            # the reference-exact mode against the same roofline: SURVEY 8(d) bytes over the day averages of its two launches (k_slot_split;
-            # k_env_walk = the tails of the step beside the stream walks of the next one), every 5th step of 5 days: each slot of the day once
+            # the reference-exact mode against the same roofline: SURVEY 8(d) bytes over the day averages of its two launches (k_slot_walk2 = the
+            # slot pass of the step beside the stream walks of the NEXT one; k_env = the step's tails), every 5th step of 5 days: each slot of the day once
             v.profile_begin(96, every=PROFILE_DAYS)
             for _ in range(PROFILE_DAYS):
                 day()
@@ -504,11 +504,12 @@ def dropin_block(chub, multi_gpu, lib, device):
             out["roofline_compat"] = {
                 "what": "the reference-exact COMPAT step (the reference's own glibc rand() / minstd_rand0 streams walked per env, the charge curves "
                         "evaluated in f64 in the reference's order) at the headline size, priced like `roofline_step`",
-                "bound": "hbm", "limited_by": "instruction issue: the slot pass (532 VALU + 281 SALU per wave, half of the VALU in f64 curves) and the serial stream walks (one per lane)",
-                "kernels": "k_slot_split (the slot pass of both stations; + k_compat_walk in front of it on a day's first step) + k_env_walk (the "
-                           "step's tails beside the stream walks of the NEXT step, one launch)",
+                "bound": "hbm", "limited_by": "instruction issue: the slot pass (two slots per lane, the f64 curve work of both packed into one pass per wave) and, "
+                                              "in the same launch, the serial stream walks of the next step (one per lane); the tails are a latency chain",
+                "kernels": "k_slot_walk2 (the slot pass of both stations beside the NEXT step's stream walks, which run two steps ahead of the slots they "
+                           "draw for; + k_compat_walk in front of it on a day's first step) + k_env (the step's tails)",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_step": (slot_b + env_b) * n, "slot_pass_us": slot_us, "tails_and_next_walks_us": env_us,
+                "algorithmic_bytes_per_step": (slot_b + env_b) * n, "slot_pass_and_next_walks_us": slot_us, "tails_us": env_us,
                 "launches_sampled": k, "frac_call_by_call": (slot_b + env_b) * n / (dt / 192) / 1e9 / HBM_PEAK_GBS,
                 "workload": "%d envs x hub [20 fast, 25 slow], COMPAT streams, device-resident actions and normals, call by call" % n}
         v.close()

@@ -81,9 +81,11 @@ typedef struct chub_options {
                              launch too -- station 0, station 1, tail back to back -- unless this is 1. */
     int32_t tile;         /* workgroup tile of the packed slot kernel: 0 = by working-set size (default), 1 = 256 lanes x 2 slots (state
                              and action rows live in the caches), 2 = 512 lanes x 4 slots (they stream from HBM).  Results are bit-identical. */
-    int32_t walk_ahead;   /* COMPAT split step: 0 = lock-step steps of every env run the tails of step i and the stream walks of step i + 1 in ONE
-                             launch (the walk writes a shadow of the streams that the slot pass of step i + 1 commits: a reset that comes
-                             instead never sees it) (default), 1 = never (every step walks its own streams first: the parity cross-check).
+    int32_t walk_ahead;   /* COMPAT split step: 0 = lock-step steps of every env walk the streams ahead of their step (default): stations of 8 to 64
+                             piles run the slot pass of step i and the stream walks of step i + 1 in ONE launch (the walk two steps ahead of the
+                             slots it draws for: it takes the slots that will be empty from the stays alone), other shapes the tails of step i
+                             and those walks; the walk writes a shadow of the streams that the slot pass of step i + 1 commits, so a reset that
+                             comes instead never sees it.  1 = never (every step walks its own streams first: the parity cross-check).
                              Results are bit-identical. */
     int32_t work_order;   /* PHILOX packed kernels, cache-resident sizes (the small tile, at most 6 M charger slots): 0 = tiles, tail and level workgroups
                              take their work in contiguous eighths per XCD (the dispatcher hands workgroup b to XCD b % 8) (default),

@@ -76,7 +76,7 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(r["frac_of_layout"] - r["layout_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 8e12) < 1e-12
     assert d["roofline_c5"]["limited_by"] == "hbm" and d["roofline_c5"]["layout_bytes_per_launch"] == 262144 * (12 * 64 + 48)
     rc = d["roofline_compat"]
-    assert rc["bound"] == "hbm" and abs(rc["frac"] - 1941 * 65536 / ((rc["slot_pass_us"] + rc["tails_and_next_walks_us"]) * 1e-6) / 8e12) < 1e-9
+    assert rc["bound"] == "hbm" and abs(rc["frac"] - 1941 * 65536 / ((rc["slot_pass_and_next_walks_us"] + rc["tails_us"]) * 1e-6) / 8e12) < 1e-9
     assert d["cpu_baseline"]["host_cores"] >= d["cpu_baseline"]["cores"]
     # ... and the rocprofv3 summaries the three fractions can be recomputed from are committed next to the line
     for name in ("_kernel_stats.csv", "_kernel_stats_c5.csv", "_kernel_stats_compat.csv", "_pmc_compat.json", "_pmc_traffic_c5.json"):

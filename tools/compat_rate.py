@@ -48,6 +48,6 @@ dt = time.perf_counter() - t0
 a, b, k = v.profile_end()
 o = obs.to_host(np.float32, (n, D), st.ptr).astype(np.float64)
 sl = np.concatenate([x.reshape(n, -1) for x in v.slots()], axis=1).astype(np.float64)
-print(os.environ.get("CHUB_LIB", "")[-12:], os.environ.get("AB_SLOT", "auto"), n, piles, "step_us %.1f  station kernels %.1f  tail %.1f   (%.0f M env-steps/s)   checksum %.9f %.6f" % (
+print(os.environ.get("CHUB_LIB", "")[-12:], os.environ.get("AB_SLOT", "auto"), n, piles, "step_us %.1f  slot pass (+ walks) %.1f  tails (+ walks) %.1f   (%.0f M env-steps/s)   checksum %.9f %.6f" % (
     dt / 96 * 1e6, a / k * 1e3, b / k * 1e3, n * 96 / dt / 1e6, o.sum(), np.nansum(sl)))
 v.close()

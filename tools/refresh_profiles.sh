@@ -88,7 +88,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/kt5 --output-format csv -- python3 benc
 cp $(find $OUT/kt5 -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats_c5.csv
 echo "c5 kernel trace done"
 # (2) the reference-exact COMPAT mode at the headline size (tools/compat_rate.py: 65 536 envs x [20, 25], 2 days call by call): kernel-trace
-# stats + one counter set per pass for k_slot_split / k_env_walk (tails + the next step's stream walks), to check roofline_compat against
+# stats + one counter set per pass for k_slot_walk2 (the slot pass beside the next step's stream walks) / k_env (the tails), to check roofline_compat against
 rocprofv3 --kernel-trace --stats -d $OUT/ktc --output-format csv -- python3 tools/compat_rate.py > $OUT/compat_rate_under_rocprof.txt 2> $OUT/ktc.err
 cp $(find $OUT/ktc -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats_compat.csv
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_compat --output-format csv -- python3 tools/compat_rate.py > /dev/null 2> $OUT/pmc_fetch_compat.err
@@ -118,8 +118,8 @@ res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes)
                "doubled as MI355X_MICROARCH.md prescribes for gfx950",
        "build_id": chub.load_library().chub_build_id().decode(), "envs": 65536, "hub": [20, 25], "mode": "compat",
        "calibration": {"fetch_factor": 2.0, "write_factor": 1.0}}
-# (since the split step walks ahead: k_slot_split + k_env_walk per step; k_compat_walk<false> only in front of a day's first step)
-for label, key in (("k_slot_split", "k_slot_split<false"), ("k_env_walk", "k_env_walk"), ("k_compat_walk", "k_compat_walk<false>")):
+# (the split step walks two steps ahead: k_slot_walk2 + k_env<.., COMPAT> per step; k_compat_walk<false> only in front of a day's first step)
+for label, key in (("k_slot_walk2", "k_slot_walk2"), ("k_env_compat", "k_env<false, 0"), ("k_compat_walk", "k_compat_walk<false>")):
     f, w = pick(fe, key).get("FETCH_SIZE", 0.0), pick(wr, key).get("WRITE_SIZE", 0.0)
     res[label] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes_per_launch": (f * 2.0 + w) * 1024.0}
     res[label + "_sq_counters_per_dispatch"] = pick(sq, key)
