@@ -2439,7 +2439,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     float a_el_f = 0.0f, a_fc_f = 0.0f, P0f = 0.0f, P1f = 0.0f, mn0 = 0.0f, mx0 = 0.0f, mn1 = 0.0f, mx1 = 0.0f;
     int pv_day = 0, wd_day = 0, q_len = 0, hv_line = 0, F0i = 0, F1i = 0, ln0 = 0, ln1 = 0, hv_lev = 0, hv_arrive = 0;
     u32x4 drw_raw = {0u, 0u, 0u, 0u};
-    uint32_t drw_n = 0u;
+    uint32_t drw_n = 0u, hvw0 = 0u, hvw1 = 0u;
     const bool have_pre = FUSED && use_pre;  // the env's own state came in ahead of time (tail_prefetch)
     if (live) {
         if (have_pre) {
@@ -2474,6 +2474,10 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             wd_day = ta.wd_day[e32];
             q_len = ta.q_len[e32];
             hv_line = ta.hv_line[e32];
+        }
+        if (MODE == MODE_COMPAT && !RESET && sa.hv_tape) {  // the split step: the forecourt's draws wait where the walk left them -- the count and
+            hvw0 = sa.hv_tape[e32 * (uint32_t) sa.hv_w];    // the first arrival's SoC with the burst, not as two round trips of their own behind it
+            if (sa.hv_w > 1) hvw1 = sa.hv_tape[e32 * (uint32_t) sa.hv_w + 1u];
         }
         if (TAPE) {
             z_pv = sa.exo_z[e32 * 3u + 0u];
@@ -2571,6 +2575,14 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     // what the first half hands to the second
     const double *hy_env = MODE == MODE_COMPAT ? (const double *) ev.hy_env + (size_t) e32 * 102u : nullptr;
     (void) hy_env;
+    // COMPAT: the env's own hy_power_speed_list entry the electrolyser clamp looks at first (MGR:160-180; its index follows from the action
+    // alone) is requested HERE, in front of the first half, instead of as a round trip of its own in the second
+    double hy_req_pre = 0.0;
+    if (MODE == MODE_COMPAT && !RESET && live) {
+        int rq = (int) ceil((((double) a_el_f + 1) / 2) * 100);
+        rq = rq < 0 ? 0 : (rq > 101 ? 101 : rq);
+        hy_req_pre = hy_env[rq];
+    }
     const double cap_mass = hp.cap_mass;
     double store_soc = 0.0, reward = 0.0, in_re_pv = 0.0, in_re_wd = 0.0, in_price_next = 0.0, total_mass_need = 0.0;
     double re_pv = 0.0, re_wd = 0.0, price_next = 0.0;
@@ -2625,7 +2637,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         const int qcap = hp.qcap;
         double *qt = (double *) ev.q_time + (size_t) e32 * (size_t) qcap, *qm = (double *) ev.q_mass + (size_t) e32 * (size_t) qcap;
         if (MODE == MODE_COMPAT && !hv_walked) hv_lev = rs.level();
-        arrive = MODE == MODE_COMPAT ? (hv_walked ? (int) sa.hv_tape[e32 * (uint32_t) sa.hv_w] : (int) TAB_HV(hv_lev)) : hv_arrive;
+        arrive = MODE == MODE_COMPAT ? (hv_walked ? (int) hvw0 : (int) TAB_HV(hv_lev)) : hv_arrive;
         double total_mass = 0.0;
         const bool fcev_pre = !TAPE && MODE == MODE_PHILOX && !RESET && !sa.fresh;
         // the first arrival's SoC was drawn one launch ahead with the other env draws (level_block: same Philox counter); its
@@ -2660,7 +2672,8 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
                     mn = pre_mn;
                 } else {
                     float socf;
-                    if (TAPE || hv_walked) socf = __uint_as_float(sa.hv_tape[e32 * (uint32_t) sa.hv_w + 1u + (uint32_t) j]);
+                    if (hv_walked && j == 0) socf = __uint_as_float(hvw1);
+                    else if (TAPE || hv_walked) socf = __uint_as_float(sa.hv_tape[e32 * (uint32_t) sa.hv_w + 1u + (uint32_t) j]);
                     else if (MODE == MODE_COMPAT) socf = arrive_soc_from(rs.normal_d(7.0, 3.0));
                     else socf = soc_from_word(tb.soc_d_icdf, px.block(SITE_HVSOC, (uint32_t) j, 0).v[0]);
                     fcev_time_mass(socf, tn, mn);
@@ -2770,7 +2783,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         double act_el = a_el;
         int req = (int) ceil(a_el * 100);
         req = req < 0 ? 0 : (req > 101 ? 101 : req);  // actions outside [-1,1] would index out of the table
-        if (TAB_HY(req) > hy_power_limit) {
+        if ((MODE == MODE_COMPAT ? hy_req_pre : TAB_HY(req)) > hy_power_limit) {
             int ind = 0;
             while (ind < 102 && !(TAB_HY(ind) >= hy_power_limit)) ind++;
             // hy_power_speed_list_input[ind - 1]; python index -1 wraps to the last entry (1.0)
