@@ -814,19 +814,30 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
     // the step's draws are taken (the walk made them one launch ago): the streams' state it left behind them (the shadow) becomes the env's
     // -- station 0's unit of the env does it, every env has one -- HERE, in the shadow of the first loads, not as a round trip of its own
     // at the end of the wave (nothing else in this launch looks at the streams)
-    if (sa.commit_rng && k == 0) {
+    if (sa.commit_rng && k == 0) {  // (lane 8 * (2 * unit + v) + quad copies one 16-byte quad of the ring of unit `unit` of virtual wave v; upw <= 4 here)
+        const int cu = lane >> 3, cq = lane & 7, cv = cu & 1, cun = cu >> 1;
+        const int ce = env_first + (2 * wave + cv) * upw + cun;
+        if (cun < upw && upw <= 4 && ce < N && in_group(sa, ce)) {
+            const u32x4 q = ((const u32x4 *) (cr.g_sh[sa.tick & 1u] + (size_t) ce * 32u))[cq];
+            uint32_t x = 0u;
+            if (cq == 0) x = cr.minstd_sh[sa.tick & 1u][ce];
+            ((u32x4 *) (cr.g + (size_t) ce * 32u))[cq] = q;
+            if (cq == 0) cr.minstd[ce] = x;
+        }
+        if (upw > 4) {  // (units of 8 to 15 piles: more than 8 per lane pair -- the unit's first lane copies its env's ring)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            if (unit_ok[j] && slot == 0) {
-                const u32x4 *src = (const u32x4 *) (cr.g_sh[sa.tick & 1u] + (size_t) env[j] * 32u);
-                u32x4 *dst = (u32x4 *) (cr.g + (size_t) env[j] * 32u);
-                u32x4 q[8];
+            for (int j = 0; j < 2; j++) {
+                if (unit_ok[j] && slot == 0) {
+                    const u32x4 *src = (const u32x4 *) (cr.g_sh[sa.tick & 1u] + (size_t) env[j] * 32u);
+                    u32x4 *dst = (u32x4 *) (cr.g + (size_t) env[j] * 32u);
+                    u32x4 q[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) q[i] = src[i];
-                const uint32_t x = cr.minstd_sh[sa.tick & 1u][env[j]];
+                    for (int i = 0; i < 8; i++) q[i] = src[i];
+                    const uint32_t x = cr.minstd_sh[sa.tick & 1u][env[j]];
 #pragma unroll
-                for (int i = 0; i < 8; i++) dst[i] = q[i];
-                cr.minstd[env[j]] = x;
+                    for (int i = 0; i < 8; i++) dst[i] = q[i];
+                    cr.minstd[env[j]] = x;
+                }
             }
         }
     }
@@ -999,18 +1010,18 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < 2 * upw) {
-        const int v = lane & 1, un = lane >> 1;
+    // (one lane per unit, virtual wave AND term: lane 16 * term + 2 * unit + v -- a loop of S additions instead of 3 S; each lane stores its
+    // own word of the unit's record: min, charge, max power in that order, the first of them the packed word behind)
+    if (lane < 48 && (lane & 15) < 2 * upw) {
+        const int term = lane >> 4, v = lane & 1, un = (lane & 15) >> 1;
         const int e = env_first + (2 * wave + v) * upw + un;
         if (e < N && in_group(sa, e)) {
-            const int base = v * 64 + un * U;
-            float r_min = 0.0f, r_max = 0.0f, r_chg = 0.0f;
-            for (int i = 0; i < S; i++) {
-                r_max = __fadd_rn(r_max, t_max[base + i]);
-                r_min = __fadd_rn(r_min, t_min[base + i]);
-                r_chg = __fadd_rn(r_chg, t_chg[base + i]);
-            }
-            rec_store(st.rec, (uint32_t) k * (uint32_t) N + (uint32_t) e, r_min, r_chg, r_max, u_word[v * 8 + un]);
+            const float *t = (term == 0 ? t_min : (term == 1 ? t_chg : t_max)) + v * 64 + un * U;
+            float r = 0.0f;
+            for (int i = 0; i < S; i++) r = __fadd_rn(r, t[i]);
+            const uint32_t u = (uint32_t) k * (uint32_t) N + (uint32_t) e;
+            st.rec[4u * u + (uint32_t) term] = __float_as_uint(r);
+            if (term == 0) st.rec[4u * u + 3u] = u_word[v * 8 + un];
         }
     }
 #pragma unroll
@@ -1995,7 +2006,7 @@ inline TailArgs make_tail_args(const EnvArrays &ev, const StationArrays &st, con
     ta.n_envs = (uint32_t) hp.n_envs;
     ta.act_dim = (uint32_t) hp.act_dim;
     ta.s_tot = (uint32_t) (hp.S[0] + hp.S[1]);
-    ta.xcd = (hp.rng_mode == MODE_PHILOX && hp.packed && hp.xcd) ? 1u : 0u;
+    ta.xcd = (hp.rng_mode == MODE_PHILOX && hp.packed && hp.xcd) ? 1u : 0u;  // (COMPAT tails in this order: measured, no gain)
     return ta;
 }
 
