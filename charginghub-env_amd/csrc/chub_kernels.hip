@@ -2435,7 +2435,9 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         }
         if (!RESET) {
             if (i < 102) st_hy = ta.hy_table[i];
-            if (MODE == MODE_COMPAT && !multi && i < kLevels / 4) st_hv = ((CHUB_G(const uint32_t)) tb.cnt_hv)[sa.t * (kLevels / 4) + i];
+            // (the split step's tail does not look the forecourt's arrivals up -- the walk did: no table row, and no hop through the context
+            // pointer for its address in front of the per-env loads)
+            if (MODE == MODE_COMPAT && !multi && !sa.hv_tape && i < kLevels / 4) st_hv = ((CHUB_G(const uint32_t)) tb.cnt_hv)[sa.t * (kLevels / 4) + i];
         }
     }
     // The device-side tick offset of graph replays is a scalar load from DEVICE memory (a miss in the scalar cache of every CU at the start of a
