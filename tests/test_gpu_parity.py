@@ -1343,9 +1343,10 @@ def test_compat_split_step_is_bit_identical_through_restores_and_masked_calls():
               init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.02)
     n = 300
     out = {}
-    for form in ("wave", "packed"):
+    for form in ("wave", "packed", "packed_own_walks"):  # (packed: the walk two steps ahead, k_slot_walk2; packed_own_walks: chub_options.walk_ahead = 1)
         rs = np.random.RandomState(12)
-        v = chub.VecChargingHub(n, rng="compat", slot_kernel=form, **kw)
+        fkw = dict(slot_kernel="packed", walk_ahead="off") if form == "packed_own_walks" else dict(slot_kernel=form)
+        v = chub.VecChargingHub(n, rng="compat", **fkw, **kw)
         v.set_compat_seeds(np.stack([rs.randint(1, 2**31 - 1, n), rs.randint(1, 2**31 - 1, n)], axis=1).astype(np.uint32))
         v.compat_replay_constructor()
         trace = []
@@ -1363,7 +1364,7 @@ def test_compat_split_step_is_bit_identical_through_restores_and_masked_calls():
             note(o, r)
         snap = v.get_state()
         v.close()
-        v = chub.VecChargingHub(n, rng="compat", slot_kernel=form, **kw)
+        v = chub.VecChargingHub(n, rng="compat", **fkw, **kw)
         v.set_state(snap)
         for t in range(10):
             o, r, d, _ = v.step(act(), rs.normal(size=(n, 3)))
@@ -1389,6 +1390,7 @@ def test_compat_split_step_is_bit_identical_through_restores_and_masked_calls():
         trace += [np.concatenate([x.reshape(n, -1) for x in v.slots()], axis=1), v.station_scalars().reshape(n, -1), v.compat_state()]
         out[form] = trace
         v.close()
-    assert len(out["wave"]) == len(out["packed"])
-    for k, (a, b) in enumerate(zip(out["wave"], out["packed"])):
+    assert len(out["wave"]) == len(out["packed"]) == len(out["packed_own_walks"])
+    for k, (a, b, c) in enumerate(zip(out["wave"], out["packed"], out["packed_own_walks"])):
         assert np.array_equal(a, b, equal_nan=True), k
+        assert np.array_equal(a, c, equal_nan=True), ("own walks", k)
