@@ -64,6 +64,7 @@ ACTION_KEY = 0xC0FFEE
 N_ACTION_BATCHES = 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 GRAPH_EPISODES = 2     # episodes per captured graph: 2 resets + 192 steps = an even number of launches (double-buffered draws)
+DAY_AVG_DAYS = 10      # whole days behind `value_day_avg` (the same launch form as the timed region, after it)
 SPAN_GRAPH_MAX = 1920  # a timed region of up to this many steps is captured as ONE graph of exactly those steps
 
 
@@ -94,8 +95,10 @@ def measured_traffic(build_id, envs_per_gpu, total_envs, hub):
 
 
 def cpu_baseline(hub_kw, total_envs, target_seconds=12.0):
-    """The oracle's scalar restatement (kind "port"), PHILOX streams, all host cores of this box, on a bounded
-    sample of the same workload: n_envs chosen so the run takes ~target_seconds; reports env-steps/s."""
+    """The oracle's scalar restatement (kind "port") on the reference's own streams (COMPAT: per env the glibc rand() ring and minstd_rand0 with
+    libstdc++'s polar normals -- SURVEY.md 8(d): "compat-RNG mode"; the exogenous normals / days numpy would draw come from a seeded
+    RandomState, as the reference's host does), pthreads over the host cores this box's share allows, on a bounded sample of the same
+    workload: n_envs chosen so the run takes ~target_seconds; reports env-steps/s."""
     import ctypes as C
 
     import numpy as np
@@ -112,18 +115,20 @@ def cpu_baseline(hub_kw, total_envs, target_seconds=12.0):
     A = sum(hub_kw["station_list"]) + 2
 
     def run(n, steps):
-        h = orc.orc_vec_create(C.byref(cfg), orclib.tables(), n, 0, orclib.PHILOX, SEED)
+        h = orc.orc_vec_create(C.byref(cfg), orclib.tables(), n, 0, orclib.COMPAT, SEED)
         obs = np.zeros((n, D))
         rew = np.zeros(n)
         done = np.zeros(n, dtype=np.uint8)
         rs = np.random.RandomState(0)
         acts = [rs.uniform(-1, 1, size=(n, A)).astype(np.float32) for _ in range(4)]
-        orc.orc_vec_reset(h, None, None, ptr(obs))
+        zs = [np.ascontiguousarray(rs.normal(size=(n, 3))) for _ in range(4)]
+        days = np.ascontiguousarray(np.stack([rs.randint(0, 100, n), rs.randint(0, 150, n)], axis=1).astype(np.int32))
+        orc.orc_vec_reset(h, ptr(days), ptr(zs[0]), ptr(obs))
         t0 = time.perf_counter()
         for t in range(steps):
             if t and t % 96 == 0:
-                orc.orc_vec_reset(h, None, None, ptr(obs))
-            orc.orc_vec_step(h, ptr(acts[t % 4]), None, ptr(obs), ptr(rew), ptr(done), cores)
+                orc.orc_vec_reset(h, ptr(days), ptr(zs[0]), ptr(obs))
+            orc.orc_vec_step(h, ptr(acts[t % 4]), ptr(zs[(t + 1) % 4]), ptr(obs), ptr(rew), ptr(done), cores)
         dt = time.perf_counter() - t0
         orc.orc_vec_destroy(h)
         return n * steps / dt
@@ -137,8 +142,9 @@ def cpu_baseline(hub_kw, total_envs, target_seconds=12.0):
         steps = 96 * max(1, min(4, int(round(rate * target_seconds / (n * 96.0)))))
     rate = run(n, steps)
     out = {"value": rate, "unit": "env-steps/s", "cores": cores, "host_cores": host_cores, "kind": "port",
-           "sample": "%d envs x %d steps of the same hub (oracle/chub_oracle.c, Philox streams, %d pthreads = min(the %d cores this "
-                     "process may run on, the 16 of a one-GPU box's CPU share))" % (n, steps, cores, host_cores)}
+           "sample": "%d envs x %d steps of the same hub (oracle/chub_oracle.c on the reference's own streams -- COMPAT: glibc rand() + minstd_rand0 "
+                     "per env, SURVEY 8(d); %d pthreads = min(the %d cores this process may run on, the 16 of a one-GPU box's CPU share: the "
+                     "pool's process guard sizes worker pools to it))" % (n, steps, cores, host_cores)}
     ref = reference_stations_rate(hub_kw)
     if ref:
         out["reference_stations"] = ref
@@ -311,6 +317,8 @@ def roofline_block(slot_us, env_us, slot_b, env_b, per, traffic, traffic_src, n_
             # the bytes the counters saw move per launch over the same duration (L2's memory side; Infinity-Cache hits included):
             # what the kernel really streams, next to the algorithmic figure the fraction is made of
             "traffic_GBps": (traffic / (slot_us * 1e-6) / 1e9) if traffic else None,
+            # ... and the three readings side by side: `frac` (SURVEY 8(d)'s bytes), `frac_of_traffic` (the bytes the counters saw), `frac_of_layout`
+            "frac_of_traffic": (traffic / (slot_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "algorithmic_bytes_per_launch": slot_b * per, "avg_launch_us": slot_us, "launches_sampled": n_prof,
             "window": window, "env_kernel_avg_launch_us": env_us, "env_kernel_algorithmic_bytes_per_launch": env_b * per,
             "env_kernel_frac": env_b * per / (env_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
@@ -428,6 +436,76 @@ def packed_actions_block(chub, multi_gpu, lib, device):
     return out
 
 
+class CompatBatch(object):
+    """The reference-exact COMPAT mode as a batch, as `roofline_compat` / `compat_mode` run it: n envs of the headline hub, the library's default
+    per-env seeds (env i: srand(SEED + 2 i + 1), minstd_rand0(SEED + 2 i + 2)), the reference constructor replayed, device-resident actions
+    and exogenous normals (two batches, alternating), whole days = one reset + 96 steps.  `**form`: chub_options of the handle (slot_kernel,
+    walk_ahead) -- the bench runs the default; tests/test_gpu_bench.py runs the same days on slot_kernel="wave" for the digest."""
+
+    def __init__(self, chub, multi_gpu, n, device=0, **form):
+        import numpy as np
+
+        kw = {k: v for k, v in HUB.items()}
+        self.n, self.n_days = n, 0
+        self.v = v = chub.VecChargingHub(n, seed=SEED, rng="compat", device=device, **form, **kw)
+        v.compat_replay_constructor()
+        D, A = v.obs_dim, v.act_dim
+        self.st = st = multi_gpu.Stream(device)
+        rs = np.random.RandomState(1)
+        self.acts, self.zs = [], []
+        for b in range(2):
+            a = multi_gpu.DeviceBuffer(n * A * 4, device)
+            v.random_actions_device(a.ptr, ACTION_KEY, b, st.ptr)
+            z = multi_gpu.DeviceBuffer(n * 3 * 8, device)
+            z.from_host(rs.normal(size=(n, 3)), st.ptr)
+            self.acts.append(a)
+            self.zs.append(z)
+        self.day_buf = multi_gpu.DeviceBuffer(n * 2 * 4, device)
+        self.day_buf.from_host(np.stack([rs.randint(0, 100, n), rs.randint(0, 150, n)], axis=1).astype(np.int32), st.ptr)
+        self.obs, self.rew, self.done = multi_gpu.DeviceBuffer(n * D * 4, device), multi_gpu.DeviceBuffer(n * 4, device), multi_gpu.DeviceBuffer(n, device)
+
+    def days(self, count):
+        v, st = self.v, self.st
+        for _ in range(count):
+            v.reset_device(self.obs.ptr, self.day_buf.ptr, self.zs[0].ptr, stream=st.ptr)
+            for t in range(96):
+                v.step_device(self.acts[t & 1].ptr, self.obs.ptr, self.rew.ptr, self.done.ptr, d_exo_z=self.zs[t & 1].ptr, stream=st.ptr)
+            st.sync()
+        self.n_days += count
+
+    def end_state_digest(self):
+        import hashlib
+
+        import numpy as np
+
+        v, n = self.v, self.n
+        h = hashlib.blake2b(digest_size=16)
+        for a in ([self.obs.to_host(np.float32, (n, v.obs_dim), self.st.ptr), self.rew.to_host(np.float32, (n,), self.st.ptr)] + list(v.slots()) +
+                  [v.station_scalars(), v.compat_state()]):
+            h.update(np.ascontiguousarray(a).tobytes())
+        return h.hexdigest()
+
+    def close(self):
+        self.v.close()
+        for b in self.acts + self.zs + [self.day_buf, self.obs, self.rew, self.done]:
+            b.free()
+        self.st.destroy()
+
+
+def compat_traffic(build_id, n_envs):
+    """HBM-side bytes per COMPAT step (both launches) from profiles/round*_pmc_compat.json, when measured on THIS build at this size"""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_compat.json")), reverse=True):
+        try:
+            rec = json.load(open(f))
+        except Exception:
+            continue
+        if rec.get("build_id") == build_id and rec.get("envs") == n_envs and rec.get("traffic_bytes_per_step"):
+            return float(rec["traffic_bytes_per_step"]), os.path.basename(f)
+    return None, None
+
+
 def dropin_block(chub, multi_gpu, lib, device):
     """Secondary: the two paths a user of the reference's own class hits.  (i) EvcsspManagerEnv_v6.step() for ONE env (BASELINE.json
     configs[0]: test/env_test.py's loop; the reference's CPU step takes about 220 us) in the reference-exact
@@ -459,63 +537,45 @@ def dropin_block(chub, multi_gpu, lib, device):
         env.close()
     rates = {}
     for n in (4096, 65536):
-        v = chub.VecChargingHub(n, seed=SEED, rng="compat", device=device, **kw)
-        v.compat_replay_constructor()
-        D, A = v.obs_dim, v.act_dim
-        st = multi_gpu.Stream(device)
-        rs = np.random.RandomState(1)
-        acts, zs = [], []
-        for b in range(2):
-            a = multi_gpu.DeviceBuffer(n * A * 4, device)
-            v.random_actions_device(a.ptr, ACTION_KEY, b, st.ptr)
-            z = multi_gpu.DeviceBuffer(n * 3 * 8, device)
-            z.from_host(rs.normal(size=(n, 3)), st.ptr)
-            acts.append(a)
-            zs.append(z)
-        days = multi_gpu.DeviceBuffer(n * 2 * 4, device)
-        days.from_host(np.stack([rs.randint(0, 100, n), rs.randint(0, 150, n)], axis=1).astype(np.int32), st.ptr)
-        obs, rew, done = multi_gpu.DeviceBuffer(n * D * 4, device), multi_gpu.DeviceBuffer(n * 4, device), multi_gpu.DeviceBuffer(n, device)
-
-        def day():
-            v.reset_device(obs.ptr, days.ptr, zs[0].ptr, stream=st.ptr)
-            for t in range(96):
-                v.step_device(acts[t & 1].ptr, obs.ptr, rew.ptr, done.ptr, d_exo_z=zs[t & 1].ptr, stream=st.ptr)
-            st.sync()
-
-        day()
+        run = CompatBatch(chub, multi_gpu, n, device)
+        v, st = run.v, run.st
+        run.days(1)
         t0 = time.perf_counter()
-        for _ in range(2):
-            day()
+        run.days(2)
         dt = time.perf_counter() - t0
-        o = obs.to_host(np.float32, (n, D), st.ptr)
+        o = run.obs.to_host(np.float32, (n, v.obs_dim), st.ptr)
         assert np.isfinite(o).all()
         rates[str(n)] = {"value": n * 192 / dt, "unit": "env-steps/s", "ms_per_step": dt / 192 * 1e3}
         if n == 65536:
             # the reference-exact mode against the same roofline: SURVEY 8(d) bytes over the day averages of its two launches (k_slot_walk2 = the
             # slot pass of the step beside the stream walks of the NEXT one; k_env = the step's tails), every 5th step of 5 days: each slot of the day once
             v.profile_begin(96, every=PROFILE_DAYS)
-            for _ in range(PROFILE_DAYS):
-                day()
+            run.days(PROFILE_DAYS)
             slot_ms, env_ms, k = v.profile_end()
             assert k == 96
+            D = v.obs_dim
             slot_b, env_b = algorithmic_bytes(v.n_slots, D)
             slot_us, env_us = slot_ms / k * 1e3, env_ms / k * 1e3
             ach = (slot_b + env_b) * n / ((slot_us + env_us) * 1e-6) / 1e9
+            traffic, traffic_src = compat_traffic(lib.chub_build_id().decode(), n)
             out["roofline_compat"] = {
                 "what": "the reference-exact COMPAT step (the reference's own glibc rand() / minstd_rand0 streams walked per env, the charge curves "
                         "evaluated in f64 in the reference's order) at the headline size, priced like `roofline_step`",
                 "bound": "hbm", "limited_by": "instruction issue: the slot pass (two slots per lane, the f64 curve work of both packed into one pass per wave) and, "
-                                              "in the same launch, the serial stream walks of the next step (one per lane); the tails are a latency chain",
+                                              "in the same launch, the serial stream walks of the next step (one per lane; they make the new cars too); the tails are a latency chain",
                 "kernels": "k_slot_walk2 (the slot pass of both stations beside the NEXT step's stream walks, which run two steps ahead of the slots they "
                            "draw for; + k_compat_walk in front of it on a day's first step) + k_env (the step's tails)",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_step": (slot_b + env_b) * n, "slot_pass_and_next_walks_us": slot_us, "tails_us": env_us,
+                # HBM-side bytes per step from the counters (both launches; profiles/*_pmc_compat.json of THIS build, else null) next to the algorithmic figure
+                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_over_algorithmic": (traffic / ((slot_b + env_b) * n)) if traffic else None,
                 "launches_sampled": k, "frac_call_by_call": (slot_b + env_b) * n / (dt / 192) / 1e9 / HBM_PEAK_GBS,
-                "workload": "%d envs x hub [20 fast, 25 slow], COMPAT streams, device-resident actions and normals, call by call" % n}
-        v.close()
-        for b in acts + zs + [days, obs, rew, done]:
-            b.free()
-        st.destroy()
+                "workload": "%d envs x hub [20 fast, 25 slow], COMPAT streams, device-resident actions and normals, call by call" % n,
+                # what the %d days this block has stepped (1 + 2 + %d) left behind: tests/test_gpu_bench.py runs the same days on the one-kernel-per-
+                # station form (the unit's first lane walking the env's streams in the reference's order) and holds this digest to that one
+                "end_state_digest": run.end_state_digest(), "days_stepped": run.n_days}
+        run.close()
     out["compat_mode"] = rates
     return out
 
@@ -537,6 +597,7 @@ def main():
     ap.add_argument("--force-comm", action="store_true", help="N = 1: still make the communicator and gather (to rank 0 itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the untimed profiled day (no `roofline` block)")
+    ap.add_argument("--no-day-avg", action="store_true", help="skip the untimed ten days behind value_day_avg / ms_per_step_day_avg")
     ap.add_argument("--no-c5", action="store_true", help="skip the secondary roofline_c5 block")
     ap.add_argument("--no-bits", action="store_true", help="skip the secondary packed_actions block (one bit per pile as the action input)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the secondary dropin_single_env block (the reference-shaped class at one env, COMPAT mode as a batch)")
@@ -751,6 +812,38 @@ def main():
         slot_us, env_us, n_prof, _ = profiled_days(v, span, i)
         i += 96 * PROFILE_DAYS
     fence()
+    # ---- untimed by the contract, reported BESIDE `value`: DAY_AVG_DAYS whole days (resets included) in the launch form of the timed region --
+    # the driver's short form (--steps 20 --warmup 5) times slots 5..24 of a day, a night-time window in which few cars arrive and the
+    # slot kernel runs 3 % under its day average; this figure does not depend on where a window falls
+    day_avg = None
+    if not args.no_day_avg:
+        span(i, (-i) % 96)
+        i += (-i) % 96
+        g_days = episode_graph
+        if use_graph and g_days is None:
+            stream.sync()
+            v.graph_begin(stream.ptr)
+            for j in range(per_graph):
+                one_step(i + j)
+            g_days = v.graph_end(stream.ptr)
+        if g_days is not None:
+            v.graph_launch(g_days, stream.ptr)  # (untimed: the first replay of a fresh graph uploads it)
+            i += per_graph
+        fence()
+        t1 = time.perf_counter()
+        if g_days is not None:
+            for _ in range(DAY_AVG_DAYS // GRAPH_EPISODES):
+                v.graph_launch(g_days, stream.ptr)
+        else:
+            span(i, 96 * DAY_AVG_DAYS)
+        fence()
+        dt_days = time.perf_counter() - t1
+        i += 96 * DAY_AVG_DAYS
+        if comm is not None:
+            dt_days = comm.max(dt_days, stream.ptr)
+        day_avg = (dt_days / (96 * DAY_AVG_DAYS), "hipGraph replays of %d episodes" % GRAPH_EPISODES if g_days is not None else "every step a call (issued from C)")
+        if g_days is not None and g_days is not episode_graph:
+            v.graph_destroy(g_days)
     # ---- with a communicator: the step taken apart per rank, so that a measured point explains itself -- this rank's kernels (the
     # day averages above), the gather alone (HIP events around 100 of them back to back), the host's issue time per step in the
     # timed region, the rank's own wall clock per step -- gathered to rank 0 through the communicator
@@ -830,6 +923,13 @@ def main():
                               "algorithmic_bytes_per_env_step": slot_b + env_b},
             "build_id": build_id,
         }
+        if day_avg is not None:
+            out["value_day_avg"] = total / day_avg[0]
+            out["ms_per_step_day_avg"] = day_avg[0] * 1e3
+            out["day_avg"] = {"what": "the same job over %d whole days (%d steps + their resets) after the timed region, untimed by the contract: env-steps/s that do "
+                                      "not depend on which slots of the day a short timed window covers" % (DAY_AVG_DAYS, 96 * DAY_AVG_DAYS),
+                              "days": DAY_AVG_DAYS, "launch": day_avg[1],
+                              "roofline_step_frac": (slot_b + env_b) * per / day_avg[0] / 1e9 / HBM_PEAK_GBS}
         if phases is not None:
             # what the builder expects of this configuration, from its own parts: a step cannot be shorter than the slowest rank's
             # kernels + one gather (GPU side) nor than the slowest rank's host issue time (call by call, the host issues two kernel

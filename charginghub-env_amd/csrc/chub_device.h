@@ -99,8 +99,10 @@ struct SlotArrays {          // index = base_k + env*S_k + slot  (station-major)
     // recorded number of car_steps (k_replay_soc), target SoC from its level; slots without a car read as zeros.
     CHUB_G(float) init_soc;  // arrival SoC (COMPAT)
     CHUB_G(uint8_t) stay8;   // PHILOX [N][S0 + S1]: Station::stay_time of the car in the slot (CHS.hpp:245), written when it is admitted
-    CHUB_G(uint32_t) var[2]; // COMPAT, split step [N][S0 + S1][2], hub-major by admission rank, double-buffered by the parity of the step's tick: what the
-                             // stream walk (k_compat_walk) drew for the r-th car a unit admits in that step: arrival SoC (f32 bits), target level | extra stay << 16
+    CHUB_G(uint32_t) var[2]; // COMPAT, split step [N][S0 + S1][4], hub-major by admission rank, double-buffered by the parity of the step's tick: the r-th car
+                             // a unit admits in that step AS add_car MAKES IT (CHS.hpp:864-877), evaluated by the stream walk where its variates are drawn
+                             // (compat_walk_env): power, t_target, t_soc (f32 bits), stay | target level << 7 -- the hot record's own words
+    CHUB_G(float) var_soc[2];// ... and its arrival SoC (what the slot pass leaves in init_soc)
 };
 
 struct StationArrays {       // unit index u = k*N + env
@@ -151,14 +153,16 @@ struct EnvArrays {           // index = env (or field*N + env)
     CHUB_G(double) telem;        // [kTelemCount][N] (telemetry only)
 };
 
-struct CompatRng {           // reference streams, per env
-    CHUB_G(uint32_t) g;          // [N][32]: 31-word glibc TYPE_3 ring + front index in word 31
-    CHUB_G(uint32_t) minstd;     // [N]
-    // the split step: the walk (k_compat_walk, lane = env) leaves the streams' state behind its draws HERE, and the slot pass of the step
-    // those draws belong to (k_slot_split) commits it to g / minstd -- so a walk may run ahead of its step (beside the previous step's
-    // tail, one launch: k_env_walk) and a reset that comes instead of that step simply never sees it
-    CHUB_G(uint32_t) g_sh[2];    // [N][32], by the parity of the tick of the step the draws belong to
-    CHUB_G(uint32_t) minstd_sh[2];  // [N]
+struct CompatRng {           // reference streams, per env: THREE buffers in rotation
+    // StepArgs::rng_cur names the buffer that holds the COMMITTED streams (what chub_get_rng_compat_state and snapshots see, what the kernels
+    // that walk the streams in place -- one kernel per station, k_compat_small, the constructor sweep -- read and write).  The split step's walk
+    // (k_compat_walk, lane = env) reads buffer rng_cur and leaves the streams' state behind its draws in buffer rng_cur + 1 (mod 3), the shadow;
+    // once the slot pass of the step those draws belong to has been launched the host moves rng_cur on by one: that IS the commit, nothing
+    // is copied (until round 6 station 0's unit of every env copied 33 words).  So a walk may run ahead of its step and a reset that comes
+    // instead of that step simply never sees it.  A walk TWO steps ahead (k_slot_walk2, beside the slot pass of the step in between) reads
+    // rng_cur + 1 and writes rng_cur + 2.
+    CHUB_G(uint32_t) g3[3];      // [N][32]: 31-word glibc TYPE_3 ring + front index in word 31
+    CHUB_G(uint32_t) minstd3[3]; // [N]
 };
 
 struct Tables {
@@ -284,9 +288,11 @@ struct StepArgs {
     // knows every slot's remaining stay when it ends); empt_fresh: this launch counts them itself first (k_compat_empties) -- after
     // create, chub_set_state and a pass in another launch form (k_compat_small)
     int32_t empt_fresh;
-    // COMPAT, split step: commit_rng: this slot pass commits the streams' state the walk left in CompatRng::g_next (always, when a walk
-    // kernel made this step's draws); hv_tape / hv_w above then also carry the forecourt's draws of that walk to the tail
+    // COMPAT, split step: commit_rng: with this slot pass the streams' state the walk left in the shadow buffer becomes the committed one (always, when
+    // a walk kernel made this step's draws: the host moves rng_cur on behind the launch); hv_tape / hv_w above then also carry the forecourt's
+    // draws of that walk to the tail
     int32_t commit_rng;
+    int32_t rng_cur;         // COMPAT: which of CompatRng's three buffers holds the committed streams when this launch starts
     int32_t walked;          // ... and this step's walk has run already (beside the previous step's tails, k_env_walk): the slot launch skips it
     // a walk two steps ahead of the slots (k_slot_walk2: beside the slot pass of the step before its own).  walk_far: it reads the streams
     // as the previous step's walk left them (that step's shadow, being committed in the same launch), the queue from that walk's word

@@ -111,15 +111,16 @@ template <typename Ring>
 struct CompatStreamT {
     Ring r;  // 32 words: ring[31] + front index
     uint32_t gf, gr, x;
-    __device__ void load(const CompatRng &cr, int64_t env) {  // (RingGlobal)
-        r.g = cr.g + env * 32;
+    // (cur: which of the handle's three stream buffers holds the committed streams, StepArgs::rng_cur)
+    __device__ void load(const CompatRng &cr, int cur, int64_t env) {  // (RingGlobal)
+        r.g = cr.g3[cur] + env * 32;
         gf = r.get(31);
         gr = (gf + 28u) % 31u;
-        x = cr.minstd[env];
+        x = cr.minstd3[cur][env];
     }
-    __device__ void store(const CompatRng &cr, int64_t env) {
+    __device__ void store(const CompatRng &cr, int cur, int64_t env) {
         r.set(31, gf);
-        cr.minstd[env] = x;
+        cr.minstd3[cur][env] = x;
     }
     // glibc random_r TYPE_3: *f += *r; result = *f >> 1  (rand(), CHS.hpp:41)
     __device__ uint32_t rand31() {
@@ -138,18 +139,21 @@ struct CompatStreamT {
         x = v >= 2147483647u ? v - 2147483647u : v;
         return x;
     }
-    // libstdc++ generate_canonical<double,53>: two draws
+    // libstdc++ generate_canonical<double,53>: two draws.  The division by the constant R * R is q = sum * RN(1 / (R * R)), one exact
+    // residual, one correction (chub_curves.h, CHUB_DIV_K64): with the correctly rounded reciprocal and q within an ulp of the quotient that is the
+    // correctly rounded quotient (Markstein 1990) -- 3 instructions instead of the ~35 of the f64 division sequence, twice per polar trial
+    // on the walk's serial chain (tests/test_host_cpu.py checks the identity on 4e8 dividends of this shape on the CPU)
     __device__ double canon_d() {
         const double R = 2147483646.0;
         double sum = (double) (minstd() - 1u);
         sum += (double) (minstd() - 1u) * R;
-        double ret = sum / (R * R);
+        double ret = CHUB_DIV_K64(sum, R * R);
         if (ret >= 1.0) ret = 0.99999999999999988898;
         return ret;
     }
-    // generate_canonical<float,24>: one draw
+    // generate_canonical<float,24>: one draw (the division by 2^31 is the multiplication by 2^-31: exact scaling, nothing underflows)
     __device__ float canon_f() {
-        float ret = __fdiv_rn((float) (minstd() - 1u), 2147483648.0f);
+        float ret = __fmul_rn((float) (minstd() - 1u), 4.656612873077392578125e-10f);
         if (ret >= 1.0f) ret = 0.99999994f;
         return ret;
     }
@@ -630,7 +634,7 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
         }
     } else if (unit_ok && slot == 0) {
         CompatStream rs;
-        rs.load(cr, env);
+        rs.load(cr, sa.rng_cur, env);
         int n_in;
         if (RESET) {
             const float cn = rs.normal_f((float) mu, 1.0f);
@@ -660,7 +664,7 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
             int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
             lds_late[lbase + rr] = (uint32_t) (late < 0 ? 0 : late);
         }
-        rs.store(cr, env);
+        rs.store(cr, sa.rng_cur, env);
         fa = make_int2(fl, as);
     }
     const int flow = __shfl(fa.x, leader);
@@ -671,21 +675,20 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const bool adm = empty && rank < assign;
     float nc_soc = 0.0f;
-    if (adm) {
-        int lev, late_;
-        float soc_;
-        if (SPLIT) {
-            const u32x2 vv = ((CHUB_G(const u32x2)) sl.var[sa.tick & 1u])[(uint32_t) env * (uint32_t) (hp.S[0] + hp.S[1]) + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank];
-            soc_ = __uint_as_float(vv.x);
-            lev = (int) (vv.y & 0xFFFFu);
-            late_ = (int) (vv.y >> 16);
-        } else {
-            lev = (int) lds_lev[lbase + rank];
-            soc_ = lds_soc[lbase + rank];
-            late_ = (int) lds_late[lbase + rank];
-        }
+    if (adm && SPLIT) {  // the car as the walk made it (compat_walk_env: add_car there, one record per admission rank)
+        const uint32_t vi = (uint32_t) env * (uint32_t) (hp.S[0] + hp.S[1]) + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank;
+        const u32x4 vv = ((CHUB_G(const u32x4)) sl.var[sa.tick & 1u])[vi];
+        nc_soc = sl.var_soc[sa.tick & 1u][vi];
+        power = __uint_as_float(vv.x);
+        t_target = __uint_as_float(vv.y);
+        t_soc = __uint_as_float(vv.z);
+        tl = (int) (vv.w & 127u);
+        car = tl > 0;
+        meta = (int) vv.w;
+    } else if (adm) {
+        const int lev = (int) lds_lev[lbase + rank];
         const float target = uniform_level(lev, 80.0f, 100.0f);
-        const NewCar nc = make_car<TYPE>(soc_, lev, soc_to_time<TYPE>(target, cp), late_, cp);
+        const NewCar nc = make_car<TYPE>(lds_soc[lbase + rank], lev, soc_to_time<TYPE>(target, cp), (int) lds_late[lbase + rank], cp);
         nc_soc = nc.soc;
         t_target = nc.t_target;
         t_soc = nc.t_soc;
@@ -742,19 +745,8 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
             st.empt[sidx] = (uint8_t) n_empty;
             st.empt2[sa.tick & 1u][sidx] = (uint8_t) n_empty2;
         }
-        // ... and the step's draws are now taken: the streams' state the walk left behind them becomes the env's (station 0's unit of the
-        // env does it: every env has one, with or without piles)
-        if (sa.commit_rng && k == 0 && unit_ok && slot == 0) {
-            const u32x4 *src = (const u32x4 *) (cr.g_sh[sa.tick & 1u] + (size_t) env * 32u);
-            u32x4 *dst = (u32x4 *) (cr.g + (size_t) env * 32u);
-            u32x4 q[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) q[j] = src[j];
-            const uint32_t x = cr.minstd_sh[sa.tick & 1u][env];
-#pragma unroll
-            for (int j = 0; j < 8; j++) dst[j] = q[j];
-            cr.minstd[env] = x;
-        }
+        // (the step's draws are now taken: the buffer the walk left the streams' state in becomes the committed one -- on the host, by
+        // moving StepArgs::rng_cur on: no copy)
     }
 }
 
@@ -811,36 +803,6 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
             a[j] = sa.actions[(uint32_t) env[j] * (uint32_t) hp.act_dim + (uint32_t) hub_slot];
         }
     }
-    // the step's draws are taken (the walk made them one launch ago): the streams' state it left behind them (the shadow) becomes the env's
-    // -- station 0's unit of the env does it, every env has one -- HERE, in the shadow of the first loads, not as a round trip of its own
-    // at the end of the wave (nothing else in this launch looks at the streams)
-    if (sa.commit_rng && k == 0) {  // (lane 8 * (2 * unit + v) + quad copies one 16-byte quad of the ring of unit `unit` of virtual wave v; upw <= 4 here)
-        const int cu = lane >> 3, cq = lane & 7, cv = cu & 1, cun = cu >> 1;
-        const int ce = env_first + (2 * wave + cv) * upw + cun;
-        if (cun < upw && upw <= 4 && ce < N && in_group(sa, ce)) {
-            const u32x4 q = ((const u32x4 *) (cr.g_sh[sa.tick & 1u] + (size_t) ce * 32u))[cq];
-            uint32_t x = 0u;
-            if (cq == 0) x = cr.minstd_sh[sa.tick & 1u][ce];
-            ((u32x4 *) (cr.g + (size_t) ce * 32u))[cq] = q;
-            if (cq == 0) cr.minstd[ce] = x;
-        }
-        if (upw > 4) {  // (units of 8 to 15 piles: more than 8 per lane pair -- the unit's first lane copies its env's ring)
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                if (unit_ok[j] && slot == 0) {
-                    const u32x4 *src = (const u32x4 *) (cr.g_sh[sa.tick & 1u] + (size_t) env[j] * 32u);
-                    u32x4 *dst = (u32x4 *) (cr.g + (size_t) env[j] * 32u);
-                    u32x4 q[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) q[i] = src[i];
-                    const uint32_t x = cr.minstd_sh[sa.tick & 1u][env[j]];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) dst[i] = q[i];
-                    cr.minstd[env[j]] = x;
-                }
-            }
-        }
-    }
     float power[2], t_target[2], t_soc[2];
     int tl[2], meta[2];
     bool car[2], leave[2], on[2], charge[2];
@@ -861,7 +823,8 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
     // BEFORE the curve work instead of behind it
     bool empty[2], adm[2];
     int rank[2], line[2], flow[2], assign[2];
-    u32x2 vv[2];
+    u32x4 vv[2];
+    float nc_soc[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         empty[j] = valid[j] && !(car[j] && tl[j] > 1);
@@ -878,8 +841,13 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
         assign[j] = __shfl(fa.y, leader);
         line[j] = __shfl(new_line, leader);
         adm[j] = empty[j] && rank[j] < assign[j];
-        vv[j] = u32x2{0u, 0u};
-        if (adm[j]) vv[j] = ((CHUB_G(const u32x2)) sl.var[sa.tick & 1u])[(uint32_t) env[j] * St + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank[j]];
+        vv[j] = u32x4{0u, 0u, 0u, 0u};
+        nc_soc[j] = 0.0f;
+        if (adm[j]) {  // the new car as the walk made it (add_car in compat_walk_env): requested here, picked up behind the curve work
+            const uint32_t vi = (uint32_t) env[j] * St + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank[j];
+            vv[j] = ((CHUB_G(const u32x4)) sl.var[sa.tick & 1u])[vi];
+            nc_soc[j] = sl.var_soc[sa.tick & 1u][vi];
+        }
     }
     // ---- car_step (CHS.hpp:900-905 / 1065-1070) of both virtual waves' charging cars, packed
     {
@@ -930,68 +898,18 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
         }
         charge[j] = on[j] && car[j];
     }
-    // ---- add_car (CHS.hpp:864-877 / 1029-1042) of both virtual waves' new cars, packed (their variates are the walk's)
-    float nc_soc[2] = {0.0f, 0.0f};
-    {
-        const uint64_t b0 = __ballot(adm[0]), b1 = __ballot(adm[1]);
-        const int n0 = __popcll(b0), n1 = __popcll(b1);
-        if (n0 + n1 <= 64) {
-            float *g_soc = wl, *g_pw = wl + 128, *g_ts = wl + 192, *g_tt = wl + 256;
-            uint32_t *g_ll = wu + 64, *g_st = wu + 320;
-            const int p0 = prefix_count(b0), p1 = n0 + prefix_count(b1);
-            if (adm[0]) { g_soc[p0] = __uint_as_float(vv[0].x); g_ll[p0] = vv[0].y; }
-            if (adm[1]) { g_soc[p1] = __uint_as_float(vv[1].x); g_ll[p1] = vv[1].y; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < n0 + n1) {
-                const uint32_t w = g_ll[lane];
-                const int lev = (int) (w & 0xFFFFu);
-                const float target = uniform_level(lev, 80.0f, 100.0f);
-                const NewCar nc = make_car<TYPE>(g_soc[lane], lev, soc_to_time<TYPE>(target, cp), (int) (w >> 16), cp);
-                g_pw[lane] = nc.power;
-                g_ts[lane] = nc.t_soc;
-                g_tt[lane] = nc.t_target;
-                g_st[lane] = (uint32_t) nc.stay;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- add_car (CHS.hpp:864-877 / 1029-1042): the walk evaluated it (one record per admission rank); the admitted lanes take theirs
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int pj = j ? p1 : p0;
-                if (adm[j]) {
-                    const int lev = (int) (vv[j].y & 0xFFFFu);
-                    nc_soc[j] = __uint_as_float(vv[j].x);
-                    t_target[j] = g_tt[pj];
-                    t_soc[j] = g_ts[pj];
-                    tl[j] = (int) g_st[pj];
-                    power[j] = g_pw[pj];
-                    car[j] = tl[j] > 0;
-                    meta[j] = tl[j] | (lev << 7);
-                } else if (leave[j]) {
-                    meta[j] = 0;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                if (adm[j]) {
-                    const int lev = (int) (vv[j].y & 0xFFFFu);
-                    const float target = uniform_level(lev, 80.0f, 100.0f);
-                    const NewCar nc = make_car<TYPE>(__uint_as_float(vv[j].x), lev, soc_to_time<TYPE>(target, cp), (int) (vv[j].y >> 16), cp);
-                    nc_soc[j] = nc.soc;
-                    t_target[j] = nc.t_target;
-                    t_soc[j] = nc.t_soc;
-                    tl[j] = nc.stay;
-                    power[j] = nc.power;
-                    car[j] = tl[j] > 0;
-                    meta[j] = nc.stay | (nc.lev << 7);
-                } else if (leave[j]) {
-                    meta[j] = 0;
-                }
-            }
+    for (int j = 0; j < 2; j++) {
+        if (adm[j]) {
+            power[j] = __uint_as_float(vv[j].x);
+            t_target[j] = __uint_as_float(vv[j].y);
+            t_soc[j] = __uint_as_float(vv[j].z);
+            tl[j] = (int) (vv[j].w & 127u);
+            car[j] = tl[j] > 0;
+            meta[j] = (int) vv[j].w;
+        } else if (leave[j]) {
+            meta[j] = 0;
         }
     }
     // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572): the reference adds slot powers sequentially in f32 (CHS.hpp:1244-1255):
@@ -1333,7 +1251,7 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
         if (MODE == MODE_COMPAT) {
             const CompatRng &cr = ctx->cr;
             CompatStream rs;
-            rs.load(cr, env);
+            rs.load(cr, sa.rng_cur, env);
             const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
             int n_in;
             if (RESET) {
@@ -1362,7 +1280,7 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
                 const int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
                 s_w[rr] = (uint32_t) (late < 0 ? 0 : late);
             }
-            rs.store(cr, env);
+            rs.store(cr, sa.rng_cur, env);
         } else {
             const uint32_t pk = st.pk[sa.tick & 1u][sidx];
             int want;
@@ -2122,22 +2040,25 @@ __device__ __forceinline__ void compat_walk_env(const DevCtx *__restrict__ ctx, 
         const int as = (new_line + fl) < empties ? (new_line + fl) : empties;
         new_line = new_line + fl - as;
         new_line = new_line < kMaxLine ? new_line : kMaxLine;
-        CHUB_G(u32x2) var = (CHUB_G(u32x2)) ctx->sl.var[par] + ((uint32_t) env * St + (uint32_t) (k ? hp.S[0] : 0));
+        CHUB_G(u32x4) var = (CHUB_G(u32x4)) ctx->sl.var[par] + ((uint32_t) env * St + (uint32_t) (k ? hp.S[0] : 0));
+        CHUB_G(float) var_soc = ctx->sl.var_soc[par] + ((uint32_t) env * St + (uint32_t) (k ? hp.S[0] : 0));
         int n_short = 0;
         for (int rr = 0; rr < as; rr++) {  // ascending slot order == ascending rank
             const float soc = arrive_soc_from(rs.normal_d(7.0, 3.0));
-            const uint32_t lev = (uint32_t) rs.level();
+            const int lev = rs.level();
             int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
             late = late < 0 ? 0 : late;
-            var[rr] = u32x2{__float_as_uint(soc), lev | ((uint32_t) late << 16)};
-            // the stay add_car will give this car (make_car: ceil(soc_to_time(target) - soc_to_time(soc)) + late, the same functions on the
-            // same values): one slot at most only without extra stay, and only at a fast station -- a slow one needs more than a slot from
-            // the highest arrival SoC (70) to the lowest target (80) on either of its curves (1.29 / 1.47 slots)
-            if (sa.walk_short && fast && late == 0) {
-                const float target = uniform_level((int) lev, 80.0f, 100.0f);
-                const float need = __fsub_rn(soc_to_time<0>(target, cp), soc_to_time<0>(soc, cp));
-                n_short += ((int) ceilf(need) <= 1) ? 1 : 0;
-            }
+            // add_car (CHS.hpp:864-877 / 1029-1042) HERE, where the car's variates are in registers: every lane of the walk that still has a car
+            // to draw evaluates it, while in the slot pass the one lane in fifteen that admits a car made its whole wave pay for the f64 curve
+            // work (round 6: 250 of a slot wave's 813 vector instructions).  Same functions on the same values: the same bits.
+            const float target = uniform_level(lev, 80.0f, 100.0f);
+            NewCar nc;
+            if (fast) nc = make_car<0>(soc, lev, soc_to_time<0>(target, cp), late, cp);
+            else nc = make_car<1>(soc, lev, soc_to_time<1>(target, cp), late, cp);
+            var[rr] = u32x4{__float_as_uint(nc.power), __float_as_uint(nc.t_target), __float_as_uint(nc.t_soc), (uint32_t) nc.stay | ((uint32_t) lev << 7)};
+            var_soc[rr] = soc;
+            // (what a walk two steps ahead needs of this step's admissions: how many of them stay one slot at most)
+            n_short += (nc.stay <= 1) ? 1 : 0;
         }
         st.fa[par][sidx] = ((uint32_t) fl & 0xFFFFu) | ((uint32_t) (as > 0 ? as : 0) << 16) | ((uint32_t) new_line << 24);
         if (sa.walk_short) st.shrt[par][sidx] = (uint8_t) n_short;
@@ -2152,16 +2073,19 @@ __device__ __forceinline__ void compat_walk_env(const DevCtx *__restrict__ ctx, 
 }
 
 // One workgroup's NW walks (256; k_slot_walk2: 64, one wave): the rings parked in LDS, walked, and the streams' state behind the draws
-// written to the SHADOW of the step the draws belong to (g_sh / minstd_sh of its tick's parity): the slot pass of that step commits it.
-// A walk two steps ahead (StepArgs::walk_far) starts from the previous step's shadow instead of the committed streams.
+// written to the SHADOW of the step the draws belong to -- the stream buffer behind the committed one (CompatRng::g3 / minstd3: three buffers in
+// rotation, StepArgs::rng_cur names the committed one): when the slot pass of that step has been launched the host moves rng_cur on, which IS
+// the commit -- nothing is copied.  A walk two steps ahead (StepArgs::walk_far) starts from the previous step's shadow, rng_cur + 1, instead of the
+// committed streams and writes rng_cur + 2.
 template <bool RESET, int NW = 256>
 __device__ __forceinline__ void compat_walk_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const uint32_t blk, uint32_t *s_ring,
                                                   const uint32_t tid = threadIdx.x) {  // tid: the lane's number among the block's NW
     const int64_t N = ctx->hp.n_envs;
-    const uint32_t par = sa.tick & 1u;
     const bool far = !RESET && sa.walk_far != 0;
-    const uint32_t *g_src = far ? (const uint32_t *) ctx->cr.g_sh[par ^ 1u] : (const uint32_t *) ctx->cr.g;
-    const uint32_t *m_src = far ? (const uint32_t *) ctx->cr.minstd_sh[par ^ 1u] : (const uint32_t *) ctx->cr.minstd;
+    const uint32_t b_src = ((uint32_t) sa.rng_cur + (far ? 1u : 0u)) % 3u, b_dst = (b_src + 1u) % 3u;
+    const uint32_t *g_src = (const uint32_t *) ctx->cr.g3[b_src];
+    const uint32_t *m_src = (const uint32_t *) ctx->cr.minstd3[b_src];
+    uint32_t *m_dst = (uint32_t *) ctx->cr.minstd3[b_dst];
     // the glibc rings of the workgroup's envs (128 bytes each, one contiguous run of memory) are parked in LDS for the walk: transposed, so
     // that the lanes of a wave hit different banks when each reads a word of its own ring
     const uint32_t env0 = blk * (uint32_t) NW;
@@ -2188,13 +2112,13 @@ __device__ __forceinline__ void compat_walk_block(const DevCtx *__restrict__ ctx
         rs.x = m_src[env];
         compat_walk_env<RESET, CompatStreamT<RingLdsT<NW>>, true>(ctx, sa, env, rs);
         rs.r.set(31, rs.gf);
-        ctx->cr.minstd_sh[par][env] = rs.x;
+        m_dst[env] = rs.x;
     } else if (env < (int) N) {
-        ctx->cr.minstd_sh[par][env] = m_src[env];  // (an env the call does not name: its streams as they are, in the shadow too)
+        m_dst[env] = m_src[env];  // (an env the call does not name: its streams as they are, in the shadow too)
     }
     __syncthreads();
     {
-        u32x4 *dst = (u32x4 *) (ctx->cr.g_sh[par] + (size_t) env0 * 32u);
+        u32x4 *dst = (u32x4 *) (ctx->cr.g3[b_dst] + (size_t) env0 * 32u);
         for (uint32_t j = tid; j < n_here * 8u; j += (uint32_t) NW) {
             const uint32_t l = j >> 3, w = (j & 7u) << 2;
             dst[j] = u32x4{s_ring[(w + 0u) * (uint32_t) NW + l], s_ring[(w + 1u) * (uint32_t) NW + l], s_ring[(w + 2u) * (uint32_t) NW + l],
@@ -2610,7 +2534,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     // were made by the walk behind the stations' and wait in sa.hv_tape (the tail then does not touch the streams)
     const bool hv_walked = MODE == MODE_COMPAT && sa.hv_tape != nullptr;
     CompatStream rs;
-    if (MODE == MODE_COMPAT && !RESET && !hv_walked) rs.load(cr, env);
+    if (MODE == MODE_COMPAT && !RESET && !hv_walked) rs.load(cr, sa.rng_cur, env);
 
     if (RESET) {
         // renew_reset (REN:51-53) + hy_reset (HYD:197-208)
@@ -2769,7 +2693,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             price_next = price_last + in_price_noise;
         }
     }
-    if (MODE == MODE_COMPAT && !RESET && !hv_walked) rs.store(cr, env);
+    if (MODE == MODE_COMPAT && !RESET && !hv_walked) rs.store(cr, sa.rng_cur, env);
     } while (0);
 
     CHUB_STAMP(4);  // first half (exogenous values, forecourt, next slot's exogenous update) done
@@ -3129,9 +3053,9 @@ __global__ __launch_bounds__(kCompatSmallBlock) void k_compat_small(const DevCtx
         const int env = (int) threadIdx.x;
         if (env < (int) hp.n_envs) {
             CompatStream rs;
-            rs.load(ctx->cr, env);
+            rs.load(ctx->cr, sa.rng_cur, env);
             compat_walk_env<RESET>(ctx, sa, env, rs);
-            rs.store(ctx->cr, env);
+            rs.store(ctx->cr, sa.rng_cur, env);
         }
         mid();  // (the barrier the slot waves reach inside their bodies)
     } else if (hp.type[k] == 0) {
@@ -3273,14 +3197,14 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
 // power at request 0.01 * i.  Then hy_reset().  One lane per env replays exactly that: the streams advance by what the
 // reference's constructor consumes and the table comes out as the reference's (it depends on the draws whenever a tank
 // clamp binds).  Same operations as the step's tail (env_tail), plain f64 divisions.
-__global__ void k_compat_ctor_sweep(const DevCtx *__restrict__ ctx) {
+__global__ void k_compat_ctor_sweep(const DevCtx *__restrict__ ctx, int rng_cur) {
     const HubParams &hp = ctx->hp;
     const EnvArrays &ev = ctx->ev;
     const Tables &tb = ctx->tb;
     const int64_t env = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= hp.n_envs) return;
     CompatStream rs;
-    rs.load(ctx->cr, env);
+    rs.load(ctx->cr, rng_cur, env);
     const int qcap = hp.qcap;
     double *qt = (double *) ev.q_time + (size_t) env * (size_t) qcap, *qm = (double *) ev.q_mass + (size_t) env * (size_t) qcap;
     double *table = (double *) ev.hy_env + (size_t) env * 102u;
@@ -3371,12 +3295,12 @@ __global__ void k_compat_ctor_sweep(const DevCtx *__restrict__ ctx) {
         table[i] = ele_power + cpr_power;
     }
     table[101] = table[100];
-    rs.store(ctx->cr, env);
+    rs.store(ctx->cr, rng_cur, env);
     // hy_reset (HYD:197-208): the step state is re-initialised by chub_reset; the FIFO arrays were scratch here
 }
 
-void launch_compat_ctor_sweep(const HubParams &hp, const DevCtx *ctx, hipStream_t stream) {
-    hipLaunchKernelGGL(k_compat_ctor_sweep, dim3((unsigned) ((hp.n_envs + 63) / 64)), dim3(64), 0, stream, ctx);
+void launch_compat_ctor_sweep(const HubParams &hp, const DevCtx *ctx, int rng_cur, hipStream_t stream) {
+    hipLaunchKernelGGL(k_compat_ctor_sweep, dim3((unsigned) ((hp.n_envs + 63) / 64)), dim3(64), 0, stream, ctx, rng_cur);
 }
 
 // -------------------------------------------------------------------- random policy (bench / tests)

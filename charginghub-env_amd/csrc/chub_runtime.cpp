@@ -23,7 +23,7 @@ void launch_replay_soc(const HubParams &hp, const DevCtx *ctx, float *d_out, hip
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
                 hipEvent_t ev1, const PackedPtrs &pp);
 void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream);
-void launch_compat_ctor_sweep(const HubParams &hp, const DevCtx *ctx, hipStream_t stream);
+void launch_compat_ctor_sweep(const HubParams &hp, const DevCtx *ctx, int rng_cur, hipStream_t stream);
 void launch_tick_advance(uint32_t *tick_base, uint32_t by, hipStream_t stream);
 void launch_fill_clocks(uint16_t *dst, int64_t n, uint16_t value, hipStream_t stream);
 void launch_keep_clocks(uint16_t *dst, const uint16_t *src, int64_t n, hipStream_t stream);
@@ -66,6 +66,7 @@ struct chub_env {
     int device;
     bool fused;         // PHILOX lock-step steps of this handle run as ONE launch (k_step_fused): small batches
     bool no_walk_ahead = false;  // chub_options.walk_ahead = 1: the split COMPAT step never walks ahead (A/B, parity cross-check)
+    int rng_cur = 0;           // COMPAT: which of CompatRng's three buffers holds the committed streams (moved on by every commit: chub_device.h)
     uint32_t walked_tick = 0;  // COMPAT split step: the tick whose stream walk has run already, beside the previous step's tails (0: none)
     uint32_t e2_tick = ~0u;    // ... and the tick of the pass after which StationArrays::empt2 holds every unit's count (what a walk two steps ahead needs)
     bool compat_small;  // COMPAT: every env fits one workgroup for both stations: lock-step resets and steps are ONE launch (k_compat_small)
@@ -487,7 +488,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
 
     {   // arena: generous upper bound of everything allocated below (telemetry buffers come later, separately)
         const size_t S_tot = (size_t) (cfg->station_list[0] + cfg->station_list[1]);
-        const size_t per_env = S_tot * 40 + 1024 + (size_t) qcap * 16 +  // (COMPAT: 16 + 4 + 2 * 8 bytes per slot)
+        const size_t per_env = S_tot * (rng_mode == CHUB_RNG_COMPAT ? 64 : 40) + 1024 + (size_t) qcap * 16 +  // (COMPAT: 16 + 4 + 2 * (16 + 4) bytes per slot)
                                (rng_mode == CHUB_RNG_COMPAT ? 102 * 8 + 3 * 33 * 4 + 2 * 4 * (size_t) (1 + hv_max_arrive) + 1024 + 64 : 0);
         const size_t want = (size_t) n_envs * per_env + ((size_t) 8 << 20) +
                             (rng_mode == CHUB_RNG_PHILOX ? 2 * ((size_t) kSocLevels + 2) * (kClsRow * 8 + 4) : 0);
@@ -798,6 +799,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->sl.init_soc = nullptr;
     e->sl.stay8 = nullptr;
     e->sl.var[0] = e->sl.var[1] = nullptr;
+    e->sl.var_soc[0] = e->sl.var_soc[1] = nullptr;
     e->st.empt = nullptr;
     e->st.fa[0] = e->st.fa[1] = nullptr;
     e->st.empt2[0] = e->st.empt2[1] = e->st.shrt[0] = e->st.shrt[1] = nullptr;
@@ -806,7 +808,8 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         ALLOC(e->sl.stay8, NS);
     } else {
         ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.init_soc, NS);
-        ALLOC(e->sl.var[0], 2 * NS); ALLOC(e->sl.var[1], 2 * NS);  // the split step's per-admission variates
+        ALLOC(e->sl.var[0], 4 * NS); ALLOC(e->sl.var[1], 4 * NS);  // the split step's new cars as the walk made them, by admission rank
+        ALLOC(e->sl.var_soc[0], NS); ALLOC(e->sl.var_soc[1], NS);
         ALLOC(e->st.empt, 2 * N); ALLOC(e->st.fa[0], 2 * N); ALLOC(e->st.fa[1], 2 * N);
         ALLOC(e->st.empt2[0], 2 * N); ALLOC(e->st.empt2[1], 2 * N); ALLOC(e->st.shrt[0], 2 * N); ALLOC(e->st.shrt[1], 2 * N);
     }
@@ -817,13 +820,13 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->ev.hy_env = nullptr;
     ALLOC(e->ev.drw[0], 4 * N); ALLOC(e->ev.drw[1], 4 * N); ALLOC(e->ev.drw_cnt[0], N); ALLOC(e->ev.drw_cnt[1], N);
     e->ev.obs64 = nullptr; e->ev.reward64 = nullptr; e->ev.telem = nullptr;
-    e->cr.g = nullptr; e->cr.minstd = nullptr;
-    e->cr.g_sh[0] = e->cr.g_sh[1] = nullptr; e->cr.minstd_sh[0] = e->cr.minstd_sh[1] = nullptr;
+    for (int p = 0; p < 3; p++) e->cr.g3[p] = e->cr.minstd3[p] = nullptr;
+    e->rng_cur = 0;
     e->ev.hv_pre[0] = e->ev.hv_pre[1] = nullptr;
     if (rng_mode == CHUB_RNG_COMPAT) {
-        ALLOC(e->cr.g, N * 32); ALLOC(e->cr.minstd, N); ALLOC(e->ev.hy_env, N * 102);
-        for (int p = 0; p < 2; p++) {  // the walks' shadows of the streams (committed by the slot pass of the step the draws belong to), by tick parity
-            ALLOC(e->cr.g_sh[p], N * 32); ALLOC(e->cr.minstd_sh[p], N);
+        ALLOC(e->ev.hy_env, N * 102);
+        for (int p = 0; p < 3; p++) {  // the streams' three buffers in rotation: committed (rng_cur), the walk's shadow, the far walk's (CompatRng)
+            ALLOC(e->cr.g3[p], N * 32); ALLOC(e->cr.minstd3[p], N);
         }
         ALLOC(e->ev.hv_pre[0], N * (size_t) hp.hv_w); ALLOC(e->ev.hv_pre[1], N * (size_t) hp.hv_w);
         std::vector<double> rep(N * 102);  // until chub_compat_replay_constructor: every env the zero-demand table
@@ -1024,6 +1027,7 @@ static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const d
     // COMPAT split reset: the walk's draws are committed by the slot pass (k_compat_small walks the streams in place: nothing to commit)
     sa.commit_rng = (e->hp.compat_split != 0 && !(e->compat_small && !e->per_env)) ? 1 : 0;
     sa.walk_short = walks_two_ahead(e) ? 1 : 0;  // (the reset's walk leaves its short stays for a walk two steps ahead, as every walk of such a handle)
+    sa.rng_cur = e->rng_cur;
     e->walked_tick = 0;                   // (a walk that ran ahead for a step that now does not come: its shadow is simply overwritten)
     sa.env_lo = 0;
     sa.env_hi = (int32_t) (e->hp.n_envs - 1);
@@ -1042,6 +1046,7 @@ static int run_reset(chub_env *e, int served, const int32_t *d_exo_days, const d
         e->empt_valid = true;  // (k_compat_small is the split step in one launch: its slot waves leave the counts)
     } else {
         launch_slot(true, e->hp, e->d_ctx, sa, s, packed_ptrs(e), nullptr, nullptr);
+        if (sa.commit_rng) sa.rng_cur = e->rng_cur = (e->rng_cur + 1) % 3;  // the commit: the walk's shadow is the streams' buffer from here on
         launch_env(true, e->hp, e->d_ctx, sa, s, nullptr, nullptr, packed_ptrs(e));
         // (a split reset leaves the counts of the units it served; those of the others are as good as they were)
         e->empt_valid = e->hp.compat_split != 0 && (served == 2 || e->empt_valid) && !e->capturing;
@@ -1190,6 +1195,7 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
     sa.hv_w = e->tape_hv_w;
     sa.tail_tape = e->tape_tail ? 1 : 0;
     const bool split_step = e->hp.compat_split != 0 && !(e->compat_small && !load_mode && !e->per_env);
+    sa.rng_cur = e->rng_cur;
     if (split_step) {  // COMPAT split step: the slot pass commits the walk's draws, the tail reads the forecourt's from where the walk left them
         sa.commit_rng = 1;
         sa.hv_tape = (const uint32_t *) e->ev.hv_pre[sa.tick & 1u];
@@ -1244,19 +1250,21 @@ static int run_step(chub_env *e, int served, const float *d_actions, const doubl
         StepArgs sw = sa;
         sw.t = (e->t + 1) % 96;
         sw.tick = sa.tick + 1u;
-        sw.walk_far = 1;
+        sw.walk_far = 1;  // (reads the buffer behind the committed one -- this step's shadow -- and writes the one behind that)
         launch_slot_walk2(e->hp, e->d_ctx, sa, sw, s, prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
+        sa.rng_cur = e->rng_cur = (e->rng_cur + 1) % 3;  // the commit of this step's draws: its walk's shadow is the streams' buffer now
         launch_env(false, e->hp, e->d_ctx, sa, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
         e->walked_tick = e->tick + 1u;
         e->empt_valid = true;
         e->e2_tick = e->tick;
     } else {
         launch_slot(false, e->hp, e->d_ctx, sa, s, packed_ptrs(e), prof ? pe[0] : nullptr, prof ? pe[1] : nullptr);
+        if (sa.commit_rng) sa.rng_cur = e->rng_cur = (e->rng_cur + 1) % 3;  // the commit (as above)
         if (split_step && served == 2 && !e->per_env && !e->capturing) e->e2_tick = e->tick;  // (every unit's empt2, whichever pass it was)
         if (split_step && served == 2 && !e->per_env && !e->no_walk_ahead) {
             // lock-step COMPAT steps of every env: the tails of this step and the stream walks of the NEXT one in one launch (k_env_walk) --
             // if the next call is that step, its walk has run; if it is anything else, the walk's shadow is never committed
-            StepArgs sw = sa;
+            StepArgs sw = sa;  // (rng_cur: the buffer this step's slot pass has just made the committed one)
             sw.t = (e->t + 1) % 96;
             sw.tick = sa.tick + 1u;
             launch_env_walk(e->hp, e->d_ctx, sa, sw, s, prof ? pe[2] : nullptr, prof ? pe[3] : nullptr, packed_ptrs(e));
@@ -2285,8 +2293,8 @@ int chub_set_rng_compat_seeds(chub_env *e, const uint32_t *seeds) {
         uint32_t x = seeds[2 * i + 1] % 2147483647u;  // minstd_rand0::seed
         m[i] = x ? x : 1u;
     }
-    HIP_TRY(hipMemcpy(e->cr.g, g.data(), g.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->cr.minstd, m.data(), m.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->cr.g3[e->rng_cur], g.data(), g.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->cr.minstd3[e->rng_cur], m.data(), m.size() * 4, hipMemcpyHostToDevice));
     return CHUB_OK;
 }
 
@@ -2303,8 +2311,8 @@ int chub_set_rng_compat_state(chub_env *e, const uint32_t *state) {
         memcpy(&g[i * 32], &state[i * 33], 32 * 4);
         m[i] = state[i * 33 + 32];
     }
-    HIP_TRY(hipMemcpy(e->cr.g, g.data(), g.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->cr.minstd, m.data(), m.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->cr.g3[e->rng_cur], g.data(), g.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->cr.minstd3[e->rng_cur], m.data(), m.size() * 4, hipMemcpyHostToDevice));
     return CHUB_OK;
 }
 
@@ -2316,7 +2324,7 @@ int chub_get_rng_compat_state(chub_env *e, uint32_t *state) {
     const size_t N = (size_t) e->hp.n_envs;
     std::vector<uint32_t> g, m;
     int rc;
-    if ((rc = fetch(g, (const uint32_t *) e->cr.g, N * 32)) || (rc = fetch(m, (const uint32_t *) e->cr.minstd, N))) return rc;
+    if ((rc = fetch(g, (const uint32_t *) e->cr.g3[e->rng_cur], N * 32)) || (rc = fetch(m, (const uint32_t *) e->cr.minstd3[e->rng_cur], N))) return rc;
     for (size_t i = 0; i < N; i++) {
         memcpy(&state[i * 33], &g[i * 32], 32 * 4);
         state[i * 33 + 32] = m[i];
@@ -2371,12 +2379,15 @@ int chub_compat_replay_constructor(chub_env *e) {
     memset(&sa, 0, sizeof sa);
     sa.station_filter = -1;
     sa.env_hi = (int32_t) (e->hp.n_envs - 1);
-    sa.commit_rng = e->hp.compat_split;  // (the split form's walk leaves the streams' state in the shadow: the slot pass commits it)
+    sa.commit_rng = e->hp.compat_split;  // (the split form's walk leaves the streams' state in the shadow buffer: the commit moves rng_cur on)
+    sa.rng_cur = e->rng_cur;
     launch_slot(true, e->hp, e->d_ctx, sa, nullptr, packed_ptrs(e), nullptr, nullptr);
+    if (sa.commit_rng) e->rng_cur = (e->rng_cur + 1) % 3;
     e->empt_valid = e->hp.compat_split != 0;
+    e->e2_tick = ~0u;  // (no pass has left empt2 for a walk two steps ahead: the first step counts for itself)
     // (2) HySystem.__init__: 101 hy_step()s with live FCEV arrivals (HYD:154-157,168,250-259) -> the streams advance and
     //     every env gets the hy_power_speed_list the reference would have built from its draws
-    launch_compat_ctor_sweep(e->hp, e->d_ctx, nullptr);
+    launch_compat_ctor_sweep(e->hp, e->d_ctx, e->rng_cur, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     return CHUB_OK;
@@ -2394,6 +2405,7 @@ struct SnapshotHeader {
     double hy_table[102];
     // per-env clocks (the clocks themselves are in the arena); the blob ends with every env's last tick
     int32_t predrawn, per_env;
+    int32_t rng_cur, pad_;  // COMPAT: which of the arena's three stream buffers holds the committed streams
 };
 static const uint64_t kSnapMagic = 0x43485542534e4150ull;  // "CHUBSNAP"
 
@@ -2425,6 +2437,7 @@ int chub_get_state(chub_env *e, void *buf, int64_t size) {
     memcpy(h.hy_table, e->hy_table, sizeof h.hy_table);
     h.predrawn = e->predrawn ? 1 : 0;
     h.per_env = e->per_env ? 1 : 0;
+    h.rng_cur = e->rng_cur;
     memcpy(buf, &h, sizeof h);
     HIP_TRY(hipMemcpy((char *) buf + sizeof h, e->arena, e->arena_used, hipMemcpyDeviceToHost));
     {
@@ -2456,6 +2469,9 @@ int chub_set_state(chub_env *e, const void *buf, int64_t size) {
     // checks above guarantee is the same; the DevCtx block (pointers, flags) is rewritten from the host copy
     HIP_TRY(hipMemcpy(e->arena, (const char *) buf + sizeof h, e->arena_used, hipMemcpyHostToDevice));
     e->empt_valid = false;  // (the restored slot state has not been counted)
+    e->e2_tick = ~0u;       // (... nor has any pass left empt2 for a walk two steps ahead)
+    if (h.rng_cur < 0 || h.rng_cur > 2) return fail(CHUB_ERR_ARG, "snapshot header is corrupt");
+    e->rng_cur = h.rng_cur;
     e->t = h.t;
     e->price_count = h.price_count;
     e->tick = h.tick;

@@ -211,10 +211,22 @@ class VecChargingHub(object):
         if exo_days is None and exo_z is None:
             check(self._lib.chub_reset_tape(self._h, _ptr(oc), _ptr(ct), _ptr(self._obs)))
         else:
+            if exo_days is None or exo_z is None:  # (the C API's own refusal, before numpy sees a None)
+                raise ChubError("chub_reset_tape_env needs exo_days AND exo_z (the tail's side of the tape), or neither")
             d = np.ascontiguousarray(exo_days, dtype=np.int32).reshape(self.n_envs, 2)
-            z = np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)).reshape(self.n_envs, 3)
+            z = self._tape_normals(exo_z)
             check(self._lib.chub_reset_tape_env(self._h, _ptr(oc), _ptr(ct), _ptr(d), _ptr(z), _ptr(self._obs)))
         return self._obs.copy() if self._copy_outputs else self._obs
+
+    def _tape_normals(self, exo_z):
+        """[N, 3] f64 normals of a tape.  The wind process samples on every call (REN:66-69): its column must be finite.  The PV process samples only
+        while the panel's table value is non-zero (REN:56-63: nothing is drawn at night) and the price noise on every fourth step (MGR:354):
+        where the reference drew nothing its fixtures hold NaN, which becomes 0 here -- the tail does not look at a normal its process does not
+        draw"""
+        z = np.ascontiguousarray(exo_z, dtype=np.float64).reshape(self.n_envs, 3)
+        if not np.isfinite(z[:, 1]).all():
+            raise ChubError("tape normals: the wind column is drawn on every call and must be finite")
+        return np.nan_to_num(z)
 
     def step_tape(self, actions, pk_tape, car_tape, exo_z=None, hv_tape=None):
         """one step from the tape (chub_step_tape); with exo_z [N, 3] f64 and hv_tape [N, W] u32 (word 0 = FCEV arrivals, word 1 + j =
@@ -225,7 +237,9 @@ class VecChargingHub(object):
         if exo_z is None and hv_tape is None:
             check(self._lib.chub_step_tape(self._h, _ptr(a), _ptr(pk), _ptr(ct), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
         else:
-            z = np.nan_to_num(np.ascontiguousarray(exo_z, dtype=np.float64)).reshape(self.n_envs, 3)
+            if exo_z is None or hv_tape is None:
+                raise ChubError("chub_step_tape_env needs exo_z AND hv_tape (the tail's side of the tape), or neither")
+            z = self._tape_normals(exo_z)
             hv = np.ascontiguousarray(hv_tape, dtype=np.uint32)
             hv = hv.reshape(self.n_envs, hv.size // self.n_envs)
             check(self._lib.chub_step_tape_env(self._h, _ptr(a), _ptr(pk), _ptr(ct), _ptr(z), _ptr(hv), int(hv.shape[1]), _ptr(self._obs),

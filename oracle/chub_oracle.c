@@ -251,6 +251,32 @@ static double normal_double_compat(orc_rng *r, double mean, double sd) {
     double ret = y * mult;
     return ret * sd + mean;
 }
+/* tests/test_host_cpu.py: the device's stream walk divides generate_canonical<double>'s sum by the constant R * R as q = sum * RN(1 / (R * R)),
+ * one exact residual, one correction (two fmas: Markstein 1990 -- with the correctly rounded reciprocal and q within an ulp that IS the
+ * correctly rounded quotient).  Here the identity is checked against the division itself on n dividends of the shape the walk produces
+ * (a + b * R, a and b draws of minstd_rand0 minus one; the first n / 16 with b near 0, the next n / 16 with b near its maximum).
+ * -> the number of dividends on which the two differ (must be 0). */
+long orc_check_canon_division(long n, unsigned long long seed) {
+    const double R = 2147483646.0, C = R * R, rc = 1.0 / C;
+    unsigned long long s = seed ? seed : 88172645463325252ull;
+    long bad = 0;
+    for (long i = 0; i < n; i++) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        uint32_t a = (uint32_t) (s % 2147483646u);
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        uint32_t b = (uint32_t) (s % 2147483646u);
+        if (i < n / 16) b = (uint32_t) (i & 1023);
+        else if (i < n / 8) b = 2147483645u - (uint32_t) (i & 1023);
+        double sum = (double) a;
+        sum += (double) b * R;
+        const double want = sum / C;
+        const double q = sum * rc;
+        const double got = fma(fma(-q, C, sum), rc, q);
+        bad += want != got;
+    }
+    return bad;
+}
+
 static float normal_float_compat(orc_rng *r, float mean, float sd) {
     float x, y, r2;
     do {

@@ -194,6 +194,7 @@ void orc_vec_step(orc_vec *v, const float *actions, const double *exo_z, double 
 void orc_vec_step_load(orc_vec *v, const float *actions, const double *exo_z, double *obs, double *reward,
                        unsigned char *done, int n_threads);
 long orc_sizeof_env(void);
+long orc_check_canon_division(long n, unsigned long long seed); /* see chub_oracle.c */
 
 /* ---- accessors for the ctypes tests ---- */
 orc_tables *orc_tables_load(const char *data_dir);

@@ -122,6 +122,7 @@ def _load_oracle():
         "orc_vec_step": (None, [P, P, P, P, P, P, I]),
         "orc_vec_step_load": (None, [P, P, P, P, P, P, I]),
         "orc_env_step_load": (None, [P, P, P, P, P, P]),
+        "orc_check_canon_division": (C.c_long, [C.c_long, C.c_uint64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

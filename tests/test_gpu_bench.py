@@ -39,6 +39,34 @@ def test_bench_short_form_prints_the_contract_line():
     # the day average does not depend on where the 20 timed steps fell: the same number the long default run reports (+- box noise)
     assert 15.0 < r["avg_launch_us"] < 30.0
     assert d["build_id"] and d["config"]["kernels_per_step"].startswith("2")
+    # the three readings of the dominant kernel side by side (traffic: null unless profiles/ holds counters of this very build)
+    assert "frac_of_traffic" in r and (r["frac_of_traffic"] is None) == (r["traffic"] is None)
+    if r["traffic"] is not None:
+        assert abs(r["frac_of_traffic"] - r["traffic"] / (r["avg_launch_us"] * 1e-6) / 8e12) < 1e-12 and r["frac_of_traffic"] < r["frac"]
+    # ... and the rate over ten whole days next to the night-window `value` of the 20 timed steps
+    assert d["day_avg"]["days"] == 10 and d["day_avg"]["launch"].startswith("hipGraph replays")
+    assert abs(d["value_day_avg"] - 65536 / (d["ms_per_step_day_avg"] * 1e-3)) < 1e-6 * d["value_day_avg"]
+    assert 0.8 * d["value"] < d["value_day_avg"] < 1.1 * d["value"] and d["value_day_avg"] > 5e8
+
+
+def test_bench_compat_block_carries_the_end_state_of_the_reference_exact_run():
+    """`roofline_compat` (the reference-exact COMPAT mode at 65 536 envs: k_slot_walk2 + k_env) carries a digest of what its days left behind --
+    observations, rewards, slot state, station records, the streams; the same days on the one-kernel-per-station form (the unit's first lane
+    walks the env's two streams in the reference's consumption order, CHS.hpp:1272-1316 / 1583-1627; pinned to the reference's fixtures by
+    test_compat_matches_reference_golden[*-4_per_station]) must leave the same digest: the rate the line prints is the rate of a correct run."""
+    d = _bench("--no-cpu-baseline", "--no-bits")
+    rc = d["roofline_compat"]
+    assert rc["days_stepped"] == 8 and len(rc["end_state_digest"]) == 32 and 0.1 < rc["frac"] < 1.0
+    assert "traffic" in rc and (rc["traffic"] is None or rc["traffic_over_algorithmic"] > 0.3)
+    sys.path.insert(0, ROOT)
+    import bench
+    import charginghub_env_amd as chub
+    from charginghub_env_amd import multi_gpu
+    ref = bench.CompatBatch(chub, multi_gpu, 65536, 0, slot_kernel="wave")
+    ref.days(rc["days_stepped"])
+    want = ref.end_state_digest()
+    ref.close()
+    assert rc["end_state_digest"] == want
 
 
 def test_bench_multi_rank_path_on_a_world_of_one():

@@ -79,28 +79,71 @@ assert sorted(ALL_FIXTURES) == sorted(orclib.GOLDEN_ENV)
 
 
 TIGHT = 1e-9
-# (CHUB_TAPE_TOL scales the bar of the columns downstream of the station power sums: how DESIGN.md's "observed" figures were found)
+RTOL = 1e-5  # north_star: "within 1e-5 relative for battery SoC, power and reward floats"
+# (CHUB_TAPE_TOL scales the bars of the columns downstream of the station power sums: how DESIGN.md's "observed" figures were found)
 TOL = float(__import__("os").environ.get("CHUB_TAPE_TOL", "1"))
 # telemetry columns (charginghub-env_amd/_lib.py: TELEMETRY_NAMES) that no station power sum reaches: the exogenous series, the price, the
 # forecourt's demand.  (The hydrogen system is not among them: the electrolyser clamp MGR:160-180 and the fuel cell's draw on the tank,
 # capped by the EV load HYD:409-430, both look at the station sums.)
 TEL_EXO = [5, 16, 17, 18]               # total_mass_need, re_pv_power, re_wd_power, price_next
+# ---- the absolute part of the bars: not a blanket floor, but what the arithmetic needs.  The one place where the production
+# path may differ from the reference's arithmetic at all is a station's three power sums: the reference adds its S slot powers one by one in
+# f32 (CHS.hpp:1244-1255), so ITS sum is off the exact one by up to (S - 1) * 2^-24 * sum|p| (<= max_power); the production sum is exact on a
+# 2^-19 kW grid, off by up to S * 2^-20 kW.  `slack` below is that distance per station, in kW, from the reference's own record of the
+# step; every column downstream gets slack times the factor by which the reference's formulas pass a kW of station power on
+# (MGR:233-269, HYD:409-430: 1500 / 119.6 g of hydrogen per kW of fuel cell; incomes at 0.42 / 4 + price / 4 $ per kW; reward = income / 50;
+# MGR:399-402: a station column of the observation is (P - half) / half).  Next to it the relative 1e-5 of the north star.
+G_PER_KW = 1500 / 119.6
+TEL_KW = [8, 10, 11, 12, 13]            # fc_power, re_used_renew, re_ev_power_0 / _1, re_hydrogen_power
+TEL_GRAM = [4, 6, 7, 9]                 # capacity, hy_use, not_meet, hy_to_use
+TEL_CLAMP = [0, 1, 2]                   # hy_act, hy_flow_speed, all_power_second: functions of the clamp's table index alone -- exact unless it flips
+OBSERVED = {}                           # (kind, column) -> largest |got - want| / bar seen over the whole session (reported by the last test)
 
 
-def _check_tail(v, g, i, name, n_envs, what):
+def _slack(st_row, piles):
+    """per station, kW: how far the reference's sequential f32 sums of this step and the production's integer sums may lie apart"""
+    return [max(piles[k] - 1, 0) * 2.0 ** -24 * float(st_row[6 * k + 2]) + piles[k] * 2.0 ** -20 for k in (0, 1)]
+
+
+def _hold(kind, cols, got, want, atol, ctx):
+    got, want, atol = np.atleast_1d(got).astype(np.float64), np.atleast_1d(want).astype(np.float64), np.broadcast_to(np.atleast_1d(atol), np.atleast_1d(want).shape)
+    bar = RTOL * TOL * np.abs(want) + atol * TOL
+    err = np.abs(got - want)
+    for c, e_, b_ in zip(cols, err, bar):
+        OBSERVED[(kind, int(c))] = max(OBSERVED.get((kind, int(c)), 0.0), float(e_ / b_) if b_ > 0 else (0.0 if e_ == 0 else np.inf))
+    assert (err <= bar).all(), ctx + (kind, list(cols), got, want, bar)
+
+
+def _check_tail(v, g, i, name, n_envs, what, piles):
     """observation / reward / done / telemetry of the production tail against the reference's record of step i"""
     o64, r64, tel = v.obs_f64(), v.reward_f64(), v.telemetry()
+    sc = v.station_scalars()
     D = o64.shape[1]
     want_o, want_t = g["obs"][i], g["telem"][i]
+    slack = _slack(g["stations"][i], piles)
+    dP = slack[0] + slack[1]
+    price = max(float(np.abs(g["real_state"][:, 1]).max()), float(np.abs(g["reset_real_state"][:, 1]).max()))  # (the tariff + its noise: the fixture's largest)
+    k_money = 0.42 / 4 + price / 4 + 6 / 1000 * G_PER_KW   # $ per kW: charging income, the grid's price, the fuel cell's hydrogen
+    cap_mass = float(want_t[4]) / float(want_t[3]) if want_t[3] > 0 else np.inf
     # observation layout (MGR:364-373): [sin t, price, {min, charge, max, line / 5} per station with piles, H2 SOC, pv, wd]
     exact_cols = [0, 1, D - 2, D - 1] + [c for c in range(2, D - 3) if (c - 2) % 4 == 3]
+    with_piles = [k for k in (0, 1) if piles[k] > 0]
     for e in range(n_envs):
-        assert np.allclose(o64[e, exact_cols], want_o[exact_cols], rtol=TIGHT, atol=TIGHT), (name, what, "obs (exogenous, price, queues)", o64[e], want_o)
-        assert np.allclose(o64[e], want_o, rtol=1e-5 * TOL, atol=2e-6 * TOL), (name, what, "obs", o64[e], want_o)
-        assert np.allclose(r64[e], g["reward"][i], rtol=1e-5 * TOL, atol=2e-6 * TOL), (name, what, "reward", r64[e], g["reward"][i])
-        assert np.array_equal(tel[e, 19:22], want_t[19:22]), (name, what, "fcev ints", tel[e, 19:22], want_t[19:22])
-        assert np.allclose(tel[e, TEL_EXO], want_t[TEL_EXO], rtol=TIGHT, atol=TIGHT), (name, what, "telemetry (exogenous)", tel[e], want_t)
-        assert np.allclose(tel[e, :19], want_t[:19], rtol=1e-5 * TOL, atol=2e-5 * TOL), (name, what, "telemetry", tel[e, :19], want_t[:19])
+        ctx = (name, what, e)
+        assert np.allclose(o64[e, exact_cols], want_o[exact_cols], rtol=TIGHT, atol=TIGHT), ctx + ("obs (exogenous, price, queues)", o64[e], want_o)
+        for j, k in enumerate(with_piles):   # (P - half) / half with half = transformer_limit / 2 (MGR:399-402)
+            cols = [2 + 4 * j, 3 + 4 * j, 4 + 4 * j]
+            _hold("obs_station", cols, o64[e, cols], want_o[cols], slack[k] / (float(sc[e, k, 7]) / 2), ctx)
+        _hold("obs_soc", [D - 3], o64[e, D - 3], want_o[D - 3], G_PER_KW * dP / cap_mass, ctx)
+        _hold("reward", [0], r64[e], g["reward"][i], k_money * dP / 50, ctx)
+        assert np.array_equal(tel[e, 19:22], want_t[19:22]), ctx + ("fcev ints", tel[e, 19:22], want_t[19:22])
+        assert np.allclose(tel[e, TEL_EXO], want_t[TEL_EXO], rtol=TIGHT, atol=TIGHT), ctx + ("telemetry (exogenous)", tel[e], want_t)
+        _hold("tel_clamp", TEL_CLAMP, tel[e, TEL_CLAMP], want_t[TEL_CLAMP], 0.0, ctx)
+        _hold("tel_kw", TEL_KW, tel[e, TEL_KW], want_t[TEL_KW], dP, ctx)
+        _hold("tel_gram", TEL_GRAM, tel[e, TEL_GRAM], want_t[TEL_GRAM], G_PER_KW * dP, ctx)
+        _hold("tel_soc", [3], tel[e, 3], want_t[3], G_PER_KW * dP / cap_mass, ctx)
+        _hold("tel_money", [14], tel[e, 14], want_t[14], k_money * dP, ctx)
+        _hold("tel_reward", [15], tel[e, 15], want_t[15], k_money * dP / 50, ctx)
 
 
 @pytest.mark.parametrize("name", ["env_c5_random", "env_big_100_70", "env_small_fast_neg"])
@@ -169,8 +212,8 @@ def test_packed_kernel_replays_reference_fixture(name, tile="small", fused="off"
                 ref = st[6 * k:6 * k + 6]
                 assert np.array_equal(sc[e, k, 3:6], ref[3:6]), (name, what, k, sc[e, k], ref)          # car_number, line, flow_in
                 # the production sums: every car's power to the nearest 2^-19 kW, added as integers -- within the north star's 1e-5
-                # relative of the reference's sequential f32 sums
-                assert np.allclose(sc[e, k, :3], ref[:3], rtol=1e-5, atol=1e-6), (name, what, k, sc[e, k], ref)
+                # relative of the reference's sequential f32 sums, + the distance the two kinds of sum may lie apart (_slack)
+                _hold("station_sums", [3 * k, 3 * k + 1, 3 * k + 2], sc[e, k, :3], ref[:3], _slack(st, piles)[k], (name, what, e))
 
     i = 0
     n_new = 0
@@ -218,7 +261,12 @@ def test_packed_kernel_replays_reference_fixture(name, tile="small", fused="off"
             cols = [0, 1, D_ - 3, D_ - 2, D_ - 1]
         for e in range(n_envs):
             assert np.allclose(o64[e, cols], g["reset_obs"][ep][cols], rtol=TIGHT, atol=TIGHT), (name, "reset obs", ep, o64[e], g["reset_obs"][ep])
-            assert via_set_slots or np.allclose(o64[e], g["reset_obs"][ep], rtol=1e-5, atol=2e-6), (name, "reset obs", ep, o64[e], g["reset_obs"][ep])
+            if not via_set_slots:  # (the station columns: the reset's own sums, held as a step's are)
+                sl_ = _slack(rst, piles)
+                sc_ = v.station_scalars()
+                for j, k in enumerate([k for k in (0, 1) if piles[k] > 0]):
+                    cs = [2 + 4 * j, 3 + 4 * j, 4 + 4 * j]
+                    _hold("reset_obs_station", cs, o64[e, cs], g["reset_obs"][ep][cs], sl_[k] / (float(sc_[e, k, 7]) / 2), (name, "reset obs", ep))
         line = [int(rst[4]), int(rst[10])]
         for t in range(steps):
             cur = [g["slots0"][i], g["slots1"][i]]
@@ -240,7 +288,7 @@ def test_packed_kernel_replays_reference_fixture(name, tile="small", fused="off"
             _, _, done = v.step_tape(rep(g["action"][i]), pk, rep(car), rep(g["exo_z"][i]), rep(hv))[:3]
             compare(cur, st, (ep, t))
             assert all(bool(d) == bool(g["done"][i]) for d in done)
-            _check_tail(v, g, i, name, n_envs, (ep, t))
+            _check_tail(v, g, i, name, n_envs, (ep, t), piles)
             prev = cur
             i += 1
     assert n_new > 40                                            # the tape really admitted cars
@@ -277,3 +325,22 @@ def test_tape_handles_refuse_what_would_mix_the_two_sets_of_classes():
     v.reset_tape(occ, car)
     v.step_tape(np.zeros((n, v.act_dim), dtype=np.float32), pk, car)
     v.close()
+
+
+def test_zz_report_the_observed_distances():
+    """(runs last in this file) what the replays above observed, per kind of column: the largest |got - want| as a fraction of its bar
+    (rtol 1e-5 + the slack of the reference's own f32 sums passed through the reference's formulas) -- printed with -s and left in
+    gpurun_out/tape_observed.json for DESIGN.md section 2"""
+    import json
+    import os
+    if not OBSERVED:
+        pytest.skip("no replay ran in this session")
+    worst = {}
+    for (kind, c), r in OBSERVED.items():
+        worst[kind] = max(worst.get(kind, 0.0), r)
+    print("\nlargest error / bar per kind of column:", json.dumps(worst, indent=1, sort_keys=True))
+    assert max(worst.values()) <= 1.0
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({"tol_scale": TOL, "rtol": RTOL, "worst_error_over_bar": worst,
+                   "per_column": {"%s[%d]" % k: v for k, v in sorted(OBSERVED.items())}}, open(os.path.join(out, "tape_observed.json"), "w"), indent=1)

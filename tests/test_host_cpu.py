@@ -205,3 +205,11 @@ def test_philox_mode_is_statistically_the_reference_process():
     for key, tol in (("cars", 0.35), ("line", 0.25), ("flow", 0.15)):
         assert abs(a[key].mean() - b[key].mean()) < tol, (key, a[key].mean(), b[key].mean())
     assert abs(a["cars"].std() - b["cars"].std()) < 0.4
+
+
+def test_canonical_division_by_the_constant_is_the_division_itself():
+    """libstdc++'s generate_canonical<double> divides its two-draw sum by R * R (R = 2^31 - 2); the device's stream walk (CompatStreamT::canon_d,
+    csrc/chub_kernels.hip) multiplies by the rounded reciprocal and corrects with two fmas.  The identity is a theorem (Markstein); here it is
+    also exercised on 4e8 dividends of the walk's own shape, incl. the smallest and largest second draws."""
+    import orclib
+    assert orclib.orc.orc_check_canon_division(400_000_000, 20260105) == 0

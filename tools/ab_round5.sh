@@ -4,9 +4,9 @@ A=${AB_LIB:-$PWD/charginghub-env_amd/libchub_a.so}
 for rep in 1 2; do
   for cfg in ${AB_WHAT:-c4 c5}; do
     case $cfg in
-      c4) E="";; c5) E="AB_CONFIG=c5";; c2) E="AB_CONFIG=c2";; *) E="AB_ENVS=$cfg";;
+      c4) E="--config c4";; c5) E="--config c5";; c2) E="--config c2";; *) E="--envs $cfg";;
     esac
-    env $E CHUB_LIB=$A python tools/ab_step_times.py; env $E python tools/ab_step_times.py
+    python3 tools/ab_step_times.py $E --lib $A; python3 tools/ab_step_times.py $E
   done
 done > gpurun_out/$1/ab.log 2>&1
 cat gpurun_out/$1/ab.log

@@ -5,7 +5,7 @@
 # Copy the files into profiles/ (tracked) afterwards.
 set -e
 TAG=${1:-vX}
-ROUND=${ROUND:-round5}
+ROUND=${ROUND:-round6}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -74,19 +74,6 @@ for label, key in KEYS5:
 json.dump(res5, open("%s/%s_%s_pmc_traffic_c5.json" % (out, rnd, tag), "w"), indent=1)
 print(json.dumps(res5["k_slot"]))
 PY
-# the traffic summaries go where bench.py looks for them (profiles/, matched by build id), so that the bench lines written next
-# carry `roofline.traffic` of this very build
-cp $OUT/${ROUND}_${TAG}_pmc_traffic.json $OUT/${ROUND}_${TAG}_pmc_traffic_c5.json profiles/
-python3 bench.py > $OUT/${ROUND}_${TAG}_bench.json 2> $OUT/bench.err
-echo "bench done"; tail -c 400 $OUT/${ROUND}_${TAG}_bench.json; echo
-rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 > $OUT/${ROUND}_${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
-cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats.csv
-echo "kernel trace done"
-# ---- round 5: the two workloads whose fractions the bench line quotes without a rocprof summary so far
-# (1) C5 as the bench's own workload (262 144 envs x [32, 32]): kernel-trace stats, to check roofline_c5.avg_launch_us against
-rocprofv3 --kernel-trace --stats -d $OUT/kt5 --output-format csv -- python3 bench.py --config c5 --no-cpu-baseline > $OUT/${ROUND}_${TAG}_bench_c5_under_rocprof.json 2> $OUT/kt5.err
-cp $(find $OUT/kt5 -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats_c5.csv
-echo "c5 kernel trace done"
 # (2) the reference-exact COMPAT mode at the headline size (tools/compat_rate.py: 65 536 envs x [20, 25], 2 days call by call): kernel-trace
 # stats + one counter set per pass for k_slot_walk2 (the slot pass beside the next step's stream walks) / k_env (the tails), to check roofline_compat against
 rocprofv3 --kernel-trace --stats -d $OUT/ktc --output-format csv -- python3 tools/compat_rate.py > $OUT/compat_rate_under_rocprof.txt 2> $OUT/ktc.err
@@ -123,8 +110,23 @@ for label, key in (("k_slot_walk2", "k_slot_walk2"), ("k_env_compat", "k_env<fal
     f, w = pick(fe, key).get("FETCH_SIZE", 0.0), pick(wr, key).get("WRITE_SIZE", 0.0)
     res[label] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes_per_launch": (f * 2.0 + w) * 1024.0}
     res[label + "_sq_counters_per_dispatch"] = pick(sq, key)
+# the whole COMPAT step as bench.py's roofline_compat prices it: both launches of a lock-step step
+res["traffic_bytes_per_step"] = res["k_slot_walk2"]["traffic_bytes_per_launch"] + res["k_env_compat"]["traffic_bytes_per_launch"]
 json.dump(res, open("%s/%s_%s_pmc_compat.json" % (out, rnd, tag), "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k.startswith("k_") and not k.endswith("dispatch")}))
 PY
+# the traffic summaries go where bench.py looks for them (profiles/, matched by build id), so that the bench lines written next
+# carry `roofline.traffic` of this very build
+cp $OUT/${ROUND}_${TAG}_pmc_traffic.json $OUT/${ROUND}_${TAG}_pmc_traffic_c5.json $OUT/${ROUND}_${TAG}_pmc_compat.json profiles/
+python3 bench.py > $OUT/${ROUND}_${TAG}_bench.json 2> $OUT/bench.err
+echo "bench done"; tail -c 400 $OUT/${ROUND}_${TAG}_bench.json; echo
+rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 > $OUT/${ROUND}_${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
+cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats.csv
+echo "kernel trace done"
+# ---- round 5: the two workloads whose fractions the bench line quotes without a rocprof summary so far
+# (1) C5 as the bench's own workload (262 144 envs x [32, 32]): kernel-trace stats, to check roofline_c5.avg_launch_us against
+rocprofv3 --kernel-trace --stats -d $OUT/kt5 --output-format csv -- python3 bench.py --config c5 --no-cpu-baseline > $OUT/${ROUND}_${TAG}_bench_c5_under_rocprof.json 2> $OUT/kt5.err
+cp $(find $OUT/kt5 -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats_c5.csv
+echo "c5 kernel trace done"
 rm -rf $OUT/kt $OUT/kt5 $OUT/ktc $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_tcc $OUT/pmc_tcp $OUT/pmc_fetch_c5 $OUT/pmc_write_c5 $OUT/pmc_fetch_compat $OUT/pmc_write_compat $OUT/pmc_sq_compat
 ls $OUT
