@@ -157,28 +157,45 @@ struct CompatStreamT {
         if (ret >= 1.0f) ret = 0.99999994f;
         return ret;
     }
-    // std::normal_distribution<double>, fresh per call: polar, y*mult (CHS.hpp:805)
-    __device__ double normal_d(double mean, double sd) {
-        double x_, y_, r2;
+    // std::normal_distribution<double>, fresh per call: polar, y*mult (CHS.hpp:805).  In two halves: polar_d is all that touches the stream
+    // (the rejection loop: cheap, serial per env); normal_of_polar_d is the transform (f64 log, division, sqrt: a hundred-odd instructions that
+    // depend on nothing but the accepted point) -- the dense stream walk (compat_walk_wave) runs the first half one env per lane and the
+    // second one CAR per lane.  normal_d = both, back to back: the same operations in the same order, the same bits.
+    __device__ void polar_d(double &y_, double &r2) {
+        double x_;
         do {
             x_ = 2.0 * canon_d() - 1.0;
             y_ = 2.0 * canon_d() - 1.0;
             r2 = x_ * x_ + y_ * y_;
         } while (r2 > 1.0 || r2 == 0.0);
+    }
+    static __device__ __forceinline__ double normal_of_polar_d(double y_, double r2, double mean, double sd) {
         double mult = __dsqrt_rn(-2.0 * log(r2) / r2);
         return (y_ * mult) * sd + mean;
     }
+    __device__ double normal_d(double mean, double sd) {
+        double y_, r2;
+        polar_d(y_, r2);
+        return normal_of_polar_d(y_, r2, mean, sd);
+    }
     // std::normal_distribution<float> (CHS.hpp:819,833).  logf is evaluated as the f32 rounding of the f64 log.
-    __device__ float normal_f(float mean, float sd) {
-        float x_, y_, r2;
+    __device__ void polar_f(float &y_, float &r2) {
+        float x_;
         do {
             x_ = __fsub_rn(__fmul_rn(2.0f, canon_f()), 1.0f);
             y_ = __fsub_rn(__fmul_rn(2.0f, canon_f()), 1.0f);
             r2 = __fadd_rn(__fmul_rn(x_, x_), __fmul_rn(y_, y_));
         } while (r2 > 1.0f || r2 == 0.0f);
+    }
+    static __device__ __forceinline__ float normal_of_polar_f(float y_, float r2, float mean, float sd) {
         float lg = (float) log((double) r2);
         float mult = __fsqrt_rn(__fdiv_rn(__fmul_rn(-2.0f, lg), r2));
         return __fadd_rn(__fmul_rn(__fmul_rn(y_, mult), sd), mean);
+    }
+    __device__ float normal_f(float mean, float sd) {
+        float y_, r2;
+        polar_f(y_, r2);
+        return normal_of_polar_f(y_, r2, mean, sd);
     }
 };
 typedef CompatStreamT<RingGlobal> CompatStream;
@@ -2072,14 +2089,190 @@ __device__ __forceinline__ void compat_walk_env(const DevCtx *__restrict__ ctx, 
     }
 }
 
+// ---- the dense walk (round 6): the walk of 64 envs by ONE WAVE, in two kinds of phase.
+// What is serial in a walk is the streams, and the streams are touched by cheap integer work only: the level draws, and the rejection loops of
+// the polar normals (CompatStreamT::polar_d / polar_f).  What is expensive -- per new car two f64 logs, two divisions, two square roots and
+// add_car's curve work, some 400 vector instructions -- depends on nothing but the accepted points.  With one env per lane all the way
+// (compat_walk_env) a wave pays those 400 instructions once per car of its BUSIEST env (8 + 5 passes on an average step of the bench hub for
+// 3 + 1.5 cars per env) on a chain that is the split step's long pole.  Here: phase A, lane = env, draws the raw points of up to kWalkCap cars
+// into the wave's staging area in LDS (compacted: car j of the lanes that still have one, lane order); phase B, lane = CAR, evaluates them
+// densely packed (3 + 2 passes) and writes the new cars where the slot pass looks for them.  Rounds repeat while any env has cars left.
+// Same streams, same order of draws per env, the same functions on the same values: the same bits as compat_walk_env, which k_compat_small
+// (a handful of envs on one wave's lanes) keeps.
+constexpr int kWalkCap = 256;
+constexpr int kWalkStageWords = kWalkCap * 7 + 64;  // per staged car: y, r2 of the SoC normal (f64), y, r2 of the extra-stay normal (f32), a word; + one counter per lane
+struct WalkStage {
+    double *yd, *r2d;
+    float *yf, *r2f;
+    uint32_t *meta;  // target level (10 bits) | owner lane << 10 | the car's admission rank << 16
+    uint32_t *cnt;   // [64] per owner lane: cars of the round's station that stay one slot at most
+};
+__device__ __forceinline__ WalkStage walk_stage(uint32_t *base) {  // base: 8-byte aligned, kWalkStageWords words
+    WalkStage g;
+    g.yd = (double *) base;
+    g.r2d = g.yd + kWalkCap;
+    g.yf = (float *) (g.r2d + kWalkCap);
+    g.r2f = g.yf + kWalkCap;
+    g.meta = (uint32_t *) (g.r2f + kWalkCap);
+    g.cnt = g.meta + kWalkCap;
+    return g;
+}
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// KIND 0: a station's new cars (variates + add_car, written to SlotArrays::var / var_soc of env0 + owner lane); KIND 1: the forecourt's
+// arrivals (one SoC normal each, written to EnvArrays::hv_pre).  `want`: how many the lane's env has to draw (0: none / no env).  All 64 lanes call.
+template <int KIND, typename Stream>
+__device__ __forceinline__ void walk_rounds(const DevCtx *__restrict__ ctx, const StepArgs &sa, Stream &rs, const WalkStage &sg, const int lane, const uint32_t env0,
+                                            const int want, const int k, const bool fast) {
+    const HubParams &hp = ctx->hp;
+    const uint32_t St = (uint32_t) (hp.S[0] + hp.S[1]);
+    const uint32_t par = sa.tick & 1u;
+    const bool cp = hp.constant_charging != 0;
+    int rr = 0;
+    while (__any(want - rr > 0)) {
+        const int rem = want - rr;
+        // ---- phase A, lane = env: raw points of car rr + j of every env that has one, for j = 0, 1, .. while the staging area holds them
+        int base = 0, mine = 0;
+        for (int j = 0;; j++) {
+            const uint64_t m = __ballot(rem > j);
+            const int c = __popcll(m);
+            if (c == 0 || base + c > kWalkCap) break;  // (j = 0 always fits: c <= 64)
+            if (rem > j) {
+                const int i = base + prefix_count(m);
+                double yd, r2d;
+                rs.polar_d(yd, r2d);  // the SoC normal's accepted point (mk_soc, CHS.hpp:804-814 / HYD:259)
+                sg.yd[i] = yd;
+                sg.r2d[i] = r2d;
+                uint32_t lev = 0u;
+                if (KIND == 0) {
+                    lev = (uint32_t) rs.level();  // target level (CHS.hpp:35-44)
+                    float yf, r2f;
+                    rs.polar_f(yf, r2f);          // mk_late_time's accepted point (CHS.hpp:816-830)
+                    sg.yf[i] = yf;
+                    sg.r2f[i] = r2f;
+                }
+                sg.meta[i] = lev | ((uint32_t) lane << 10) | ((uint32_t) (rr + j) << 16);
+                mine = j + 1;
+            }
+            base += c;
+        }
+        wave_sync_lds();
+        // ---- phase B, lane = car
+        for (int i = lane; i < base; i += 64) {
+            const uint32_t w = sg.meta[i];
+            const uint32_t owner = (w >> 10) & 63u, rank = w >> 16;
+            const float soc = arrive_soc_from(Stream::normal_of_polar_d(sg.yd[i], sg.r2d[i], 7.0, 3.0));
+            if (KIND == 0) {
+                const int lev = (int) (w & 1023u);
+                int late = (int) roundf(Stream::normal_of_polar_f(sg.yf[i], sg.r2f[i], 2.0f, 2.0f));  // mk_late_time("slow")
+                late = late < 0 ? 0 : late;
+                // add_car (CHS.hpp:864-877 / 1029-1042)
+                const float target = uniform_level(lev, 80.0f, 100.0f);
+                NewCar nc;
+                if (fast) nc = make_car<0>(soc, lev, soc_to_time<0>(target, cp), late, cp);
+                else nc = make_car<1>(soc, lev, soc_to_time<1>(target, cp), late, cp);
+                const uint32_t vi = (env0 + owner) * St + (uint32_t) (k ? hp.S[0] : 0) + rank;
+                ((CHUB_G(u32x4)) ctx->sl.var[par])[vi] =
+                    u32x4{__float_as_uint(nc.power), __float_as_uint(nc.t_target), __float_as_uint(nc.t_soc), (uint32_t) nc.stay | ((uint32_t) lev << 7)};
+                ctx->sl.var_soc[par][vi] = soc;
+                // (what a walk two steps ahead needs of this step's admissions: how many of them stay one slot at most)
+                if (nc.stay <= 1) atomicAdd(&sg.cnt[owner], 1u);
+            } else {
+                ctx->ev.hv_pre[par][(env0 + owner) * (uint32_t) hp.hv_w + 1u + rank] = __float_as_uint(soc);  // (rank < arrivals < hv_w: chub_create)
+            }
+        }
+        wave_sync_lds();
+        rr += mine;
+    }
+}
+
+// The walk of 64 envs by one wave (lane = env in the serial phases): station 0's draws, then station 1's, then the forecourt's, in the
+// reference's consumption order -- what compat_walk_env<.., FORECOURT = true> does for one env, with the new cars evaluated densely (above).
+// live: the lane has an env to walk (inside the batch and named by the call).  All 64 lanes call.
+template <bool RESET, typename Stream>
+__device__ __forceinline__ void compat_walk_wave(const DevCtx *__restrict__ ctx, const StepArgs &sa, const uint32_t env0, const int lane, const bool live,
+                                                 Stream &rs, uint32_t *stage_words) {
+    const HubParams &hp = ctx->hp;
+    const Tables &tb = ctx->tb;
+    const StationArrays &st = ctx->st;
+    const int64_t N = hp.n_envs;
+    const uint32_t par = sa.tick & 1u;  // the step the draws belong to: its buffers
+    const bool far = !RESET && sa.walk_far != 0;
+    const int env = (int) env0 + lane;
+    const WalkStage sg = walk_stage(stage_words);
+    sg.cnt[lane] = 0u;
+    wave_sync_lds();
+    for (int k = 0; k < 2; k++) {
+        const int S = hp.S[k];
+        const bool fast = hp.type[k] == 0;
+        const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
+        int as = 0, fl = 0, new_line = 0;
+        if (live) {
+            int line = 0, empties = S;
+            if (far) {  // (two steps ahead of the slots: see compat_walk_env)
+                const uint32_t wp = st.fa[par ^ 1u][sidx];
+                line = (int) (wp >> 24);
+                empties = (int) st.empt2[par][sidx] - (int) ((wp >> 16) & 255u) + (int) st.shrt[par ^ 1u][sidx];
+            } else if (!RESET) {
+                line = pkd_line(st.rec[4u * sidx + 3u]);
+                empties = (int) st.empt[sidx];
+            }
+            const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
+            int n_in;
+            if (RESET) {
+                const float cn = rs.normal_f((float) mu, 1.0f);
+                int temp = (int) roundf(cn);
+                temp = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
+                n_in = temp;
+            } else {
+                const int t_env = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;  // per-env clocks: the env's own slot of day
+                n_in = (int) tb.cnt[k][t_env * kLevels + rs.level()];
+            }
+            int tline = 0;
+            for (int w = 0; w < line; w++) tline += (rs.level() >= (int) tb.thr_renege[w]) ? 1 : 0;
+            new_line = tline;
+            int true_in = 0;
+            for (int j = 0; j < n_in; j++) {
+                const int m = new_line + j;
+                const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
+                true_in += (rs.level() <= thr && j <= S) ? 1 : 0;
+            }
+            fl = fast ? n_in : true_in;
+            as = (new_line + fl) < empties ? (new_line + fl) : empties;
+            new_line = new_line + fl - as;
+            new_line = new_line < kMaxLine ? new_line : kMaxLine;
+            as = as > 0 ? as : 0;
+        }
+        walk_rounds<0>(ctx, sa, rs, sg, lane, env0, as, k, fast);
+        if (live) {
+            st.fa[par][sidx] = ((uint32_t) fl & 0xFFFFu) | ((uint32_t) as << 16) | ((uint32_t) new_line << 24);
+            if (sa.walk_short) st.shrt[par][sidx] = (uint8_t) sg.cnt[lane];
+        }
+        sg.cnt[lane] = 0u;  // (read and cleared by its own lane; the next station's phase B comes behind a wave barrier)
+    }
+    if (!RESET) {
+        int arrive = 0;
+        if (live) {
+            const int t_env = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;
+            arrive = (int) tb.cnt_hv[(uint32_t) t_env * (uint32_t) kLevels + (uint32_t) rs.level()];
+            ctx->ev.hv_pre[par][(uint32_t) env * (uint32_t) hp.hv_w] = (uint32_t) arrive;
+        }
+        walk_rounds<1>(ctx, sa, rs, sg, lane, env0, arrive, 0, false);
+    }
+}
+
 // One workgroup's NW walks (256; k_slot_walk2: 64, one wave): the rings parked in LDS, walked, and the streams' state behind the draws
 // written to the SHADOW of the step the draws belong to -- the stream buffer behind the committed one (CompatRng::g3 / minstd3: three buffers in
 // rotation, StepArgs::rng_cur names the committed one): when the slot pass of that step has been launched the host moves rng_cur on, which IS
 // the commit -- nothing is copied.  A walk two steps ahead (StepArgs::walk_far) starts from the previous step's shadow, rng_cur + 1, instead of the
 // committed streams and writes rng_cur + 2.
 template <bool RESET, int NW = 256>
-__device__ __forceinline__ void compat_walk_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const uint32_t blk, uint32_t *s_ring,
-                                                  const uint32_t tid = threadIdx.x) {  // tid: the lane's number among the block's NW
+__device__ __forceinline__ void compat_walk_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const uint32_t blk, uint32_t *s_ring, uint32_t *s_stage,
+                                                  const uint32_t tid = threadIdx.x) {  // tid: the lane's number among the block's NW; s_stage: NW / 64 staging areas of kWalkStageWords
     const int64_t N = ctx->hp.n_envs;
     const bool far = !RESET && sa.walk_far != 0;
     const uint32_t b_src = ((uint32_t) sa.rng_cur + (far ? 1u : 0u)) % 3u, b_dst = (b_src + 1u) % 3u;
@@ -2104,17 +2297,22 @@ __device__ __forceinline__ void compat_walk_block(const DevCtx *__restrict__ ctx
     __syncthreads();
     // (64 walks per wave: fewer -- 32 or 16 envs per wave, more waves -- measured slower: 115 / 129 vs 110 us per step at 65 536 envs)
     const int env = (int) (env0 + tid);
-    if (env < (int) N && in_group(sa, env)) {
+    const bool live = env < (int) N && in_group(sa, env);
+    {
         CompatStreamT<RingLdsT<NW>> rs;
         rs.r.s = s_ring + tid;
-        rs.gf = rs.r.get(31);
-        rs.gr = (rs.gf + 28u) % 31u;
-        rs.x = m_src[env];
-        compat_walk_env<RESET, CompatStreamT<RingLdsT<NW>>, true>(ctx, sa, env, rs);
-        rs.r.set(31, rs.gf);
-        m_dst[env] = rs.x;
-    } else if (env < (int) N) {
-        m_dst[env] = m_src[env];  // (an env the call does not name: its streams as they are, in the shadow too)
+        rs.gf = rs.gr = 0u;
+        rs.x = 1u;
+        if (env < (int) N) {
+            rs.gf = rs.r.get(31);
+            rs.gr = (rs.gf + 28u) % 31u;
+            rs.x = m_src[env];  // (an env the call does not name: its streams as they are, in the shadow too)
+        }
+        compat_walk_wave<RESET>(ctx, sa, env0 + (tid & ~63u), (int) (tid & 63u), live, rs, s_stage + (tid >> 6) * (uint32_t) kWalkStageWords);
+        if (env < (int) N) {
+            rs.r.set(31, rs.gf);
+            m_dst[env] = rs.x;
+        }
     }
     __syncthreads();
     {
@@ -2129,8 +2327,9 @@ __device__ __forceinline__ void compat_walk_block(const DevCtx *__restrict__ ctx
 
 template <bool RESET>
 __global__ __launch_bounds__(256) void k_compat_walk(const DevCtx *__restrict__ ctx, StepArgs sa) {
-    __shared__ uint32_t s_ring[32 * 256];
-    compat_walk_block<RESET>(ctx, sa, blockIdx.x, s_ring);
+    __shared__ __attribute__((aligned(16))) uint32_t s_ring[32 * 256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[4 * kWalkStageWords];
+    compat_walk_block<RESET>(ctx, sa, blockIdx.x, s_ring, s_stage);
 }
 
 #ifndef CHUB_SPLIT2
@@ -2155,16 +2354,19 @@ __global__ __launch_bounds__(BLOCK, 7) void k_slot_split2(const DevCtx *__restri
 // and the streams continue from step i's shadow, which the slot pass beside it is committing (StepArgs::walk_far).  Workgroups
 // [0, nwalk): 64 walks each, on their first wave (8 KB of rings in LDS: a larger area would cost the slot workgroups their occupancy),
 // at raised priority; the others: slot_body_split2.
+#ifndef CHUB_WALK2_OCC
+#define CHUB_WALK2_OCC 7  // workgroups per CU of k_slot_walk2 (sets its register budget: 72 VGPRs at 7, 80 at 6, 96 at 5)
+#endif
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 7) void k_slot_walk2(const DevCtx *__restrict__ ctx, StepArgs sa, StepArgs sw, int64_t nb0, int nwalk) {
-    constexpr int kWords = (BLOCK / 64) * (3 * 128 + 16) > 32 * 64 ? (BLOCK / 64) * (3 * 128 + 16) : 32 * 64;
-    __shared__ float lds[kWords];
+__global__ __launch_bounds__(BLOCK, CHUB_WALK2_OCC) void k_slot_walk2(const DevCtx *__restrict__ ctx, StepArgs sa, StepArgs sw, int64_t nb0, int nwalk) {
+    constexpr int kWords = (BLOCK / 64) * (3 * 128 + 16) > 32 * 64 + kWalkStageWords ? (BLOCK / 64) * (3 * 128 + 16) : 32 * 64 + kWalkStageWords;
+    __shared__ __attribute__((aligned(16))) float lds[kWords];  // a walk workgroup: 8 KB of rings + the walking wave's staging area
     if ((int) blockIdx.x < nwalk) {
         // one wave of the workgroup walks, the others end at once (ended waves do not count at its barriers) -- the wave whose number is
         // the workgroup's modulo 4, so that the walks of the workgroups a CU receives do not all sit on the same SIMD
         if ((threadIdx.x >> 6) != (blockIdx.x & 3u)) return;
         __builtin_amdgcn_s_setprio(3);
-        compat_walk_block<false, 64>(ctx, sw, blockIdx.x, (uint32_t *) lds, threadIdx.x & 63u);
+        compat_walk_block<false, 64>(ctx, sw, blockIdx.x, (uint32_t *) lds, (uint32_t *) lds + 32 * 64, threadIdx.x & 63u);
         return;
     }
     const HubParams &hp = ctx->hp;
@@ -2984,10 +3186,10 @@ __global__ __launch_bounds__(kEnvBlock) void k_env(const DevCtx *__restrict__ ct
 // committed them (the tail does not touch them: its forecourt draws were made by step i's walk); it writes the streams' state behind its
 // draws to the shadow, so if a reset comes instead of step i + 1 nothing has happened.  Workgroups [0, nb_env): env_tail; the others: walks.
 __global__ __launch_bounds__(256) void k_env_walk(const DevCtx *__restrict__ ctx, StepArgs sa, TailArgs ta, StepArgs sw, int nb_env) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[32 * 256];  // the walk's rings (32 KB) / the tail's table rows and output rows (22 KB)
+    __shared__ __attribute__((aligned(16))) uint32_t lds[32 * 256 + 4 * kWalkStageWords];  // the walk's rings (32 KB) + its waves' staging areas / the tail's table rows and output rows (22 KB)
     if ((int) blockIdx.x >= nb_env) {
         __builtin_amdgcn_s_setprio(3);  // the walks are the launch's long pole: the tail wave on the same SIMD takes the issue slots they leave
-        compat_walk_block<false>(ctx, sw, blockIdx.x - (uint32_t) nb_env, lds);
+        compat_walk_block<false>(ctx, sw, blockIdx.x - (uint32_t) nb_env, lds, lds + 32 * 256);
         return;
     }
     double *s_pv = (double *) lds, *s_wd = s_pv + 100, *s_pv_now = s_wd + 150, *s_wd_now = s_pv_now + 100, *s_hy = s_wd_now + 150;  // 602 doubles

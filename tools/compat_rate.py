@@ -15,7 +15,8 @@ from charginghub_env_amd import multi_gpu
 n = int(os.environ.get("AB_ENVS", "65536"))
 piles = [int(x) for x in os.environ.get("AB_PILES", "20,25").split(",")]
 kw = dict(station_list=piles, station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
-v = chub.VecChargingHub(n, seed=1, rng="compat", slot_kernel=os.environ.get("AB_SLOT", "auto"), **kw)  # AB_SLOT=wave: one kernel per station
+# AB_SLOT=wave: one kernel per station; AB_WALK=off: every step walks for itself in front of its slot pass (k_compat_walk + k_slot_split2 + k_env)
+v = chub.VecChargingHub(n, seed=1, rng="compat", slot_kernel=os.environ.get("AB_SLOT", "auto"), walk_ahead=os.environ.get("AB_WALK", "auto"), **kw)
 v.compat_replay_constructor()
 D, A = v.obs_dim, v.act_dim
 st = multi_gpu.Stream(0)
