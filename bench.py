@@ -792,12 +792,14 @@ def main():
         dt = comm.max(dt, stream.ptr)
     # sanity on the last outputs (rank-local): finite, done flag consistent with the clock
     last_i = warmup + steps - 1
-    last = packed[last_i & 1].to_host(np.float32, (per, D + 2), stream.ptr)
+    if use_comm and rank == 0:  # the root's kernels write its block straight into the gathered buffer (chub_step_gather: in place, no self-send)
+        g = gathered[last_i & 1].to_host(np.float32, (total, D + 2), stream.ptr)
+        last = g[:per]
+    else:
+        last = packed[last_i & 1].to_host(np.float32, (per, D + 2), stream.ptr)
     assert np.isfinite(last).all(), "non-finite step output"
     assert (last[:, D + 1] > 0.5).all() == (((warmup + steps) % 96) == 0), "done flag out of step with the clock"
-    if use_comm and rank == 0:  # the gathered block's own shard is the local block; every other shard has arrived too
-        g = gathered[last_i & 1].to_host(np.float32, (total, D + 2), stream.ptr)
-        assert np.array_equal(g[:per], last), "gathered block differs from the local one"
+    if use_comm and rank == 0:  # every other shard has arrived too
         assert np.isfinite(g).all()
         assert ((g[:, D + 1] > 0.5) == (((warmup + steps) % 96) == 0)).all(), "a shard's done flags are out of step"
         assert (np.abs(g[:, :D]).sum(axis=1) > 0).all(), "a shard's rows never arrived"
@@ -852,7 +854,8 @@ def main():
         # (a rank that fails in here leaves the others inside a collective that never completes: it says so and exits non-zero at once,
         # and the launcher -- this file's, or torch.distributed.run -- stops the rest instead of waiting for its timeout)
         try:
-            g_us = comm.gather_us(packed[0].ptr, gathered[0].ptr if rank == 0 else 0, per * row, stream.ptr, reps=100)
+            # (the gather as chub_step_gather issues it: in place on the root -- its own block is in the gathered buffer already)
+            g_us = comm.gather_us(gathered[0].ptr if rank == 0 else packed[0].ptr, gathered[0].ptr if rank == 0 else 0, per * row, stream.ptr, reps=100)
             mine = np.array([rank, slot_us, env_us, g_us, t_issue / steps * 1e6, dt_local / steps * 1e6], dtype=np.float64)
             d_mine = multi_gpu.DeviceBuffer(mine.nbytes, local_rank)
             d_everyone = multi_gpu.DeviceBuffer(mine.nbytes * world, local_rank) if rank == 0 else None
@@ -914,7 +917,7 @@ def main():
                                  "off (--graph on captures the RCCL gather with the step kernels; verified on a world of one only, so N > 1 "
                                  "issues every step as a call by default)" if use_comm else "off"),
                        "collective": "none" if not use_comm else
-                       "one grouped ncclSend/ncclRecv (RCCL) of [envs_per_gpu, %d] f32 per step to rank 0, %s" % (
+                       "one grouped ncclSend/ncclRecv (RCCL) of [envs_per_gpu, %d] f32 per step to rank 0 (whose own block is written in place by its step kernels), %s" % (
                            D + 2, "on the communicator's own stream beside the next step's kernels (--overlap-gather)" if overlap else "on the step's stream")},
             "n_ranks_seen": n_ranks_seen, "rccl_comm_count": comm_count, "ranks": rank_devices,
             "roofline": roofline,

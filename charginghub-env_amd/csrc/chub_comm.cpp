@@ -92,7 +92,9 @@ struct chub_comm {
         const void *buf = nullptr;
         hipEvent_t ready = nullptr, done = nullptr;  // the block is written (caller's stream) / has left (the communicator's)
         bool busy = false;
+        uint64_t seq = 0;  // when its gather went out (the older of two busy slots is the one a third buffer waits for)
     } slot[2];
+    uint64_t gather_seq = 0;
 };
 
 // chub_runtime.cpp owns the thread-local error string behind chub_last_error()
@@ -177,10 +179,16 @@ int chub_comm_world(const chub_comm *c) {
 int chub_comm_rank(const chub_comm *c) { return c ? c->rank : CHUB_ERR_ARG; }
 
 static int gather_on(chub_comm *c, const void *d_send, void *d_recv, int64_t bytes, hipStream_t s) {
+    // IN PLACE on the root: when rank 0's block already lies where it belongs -- d_send == d_recv, the first `bytes` of the gathered buffer:
+    // chub_step_gather has the root's step kernels write it there -- the root neither sends to itself nor receives from itself (until round 6
+    // every rank incl. the root sent: one copy kernel more inside every group, + 8 us per step on a world of one at 65 536 envs)
+    const bool in_place = c->rank == 0 && d_send == d_recv;
+    if (in_place && c->world == 1) return CHUB_OK;  // nothing to move
     NCCL_TRY(g_rccl.GroupStart());
-    ncclResult_t r = g_rccl.Send(d_send, (size_t) bytes, ncclUint8, 0, c->comm, s);
+    ncclResult_t r = (ncclResult_t) kNcclSuccess;
+    if (!in_place) r = g_rccl.Send(d_send, (size_t) bytes, ncclUint8, 0, c->comm, s);
     if (r == kNcclSuccess && c->rank == 0)
-        for (int p = 0; p < c->world && r == kNcclSuccess; p++)
+        for (int p = in_place ? 1 : 0; p < c->world && r == kNcclSuccess; p++)
             r = g_rccl.Recv((char *) d_recv + (size_t) p * (size_t) bytes, (size_t) bytes, ncclUint8, p, c->comm, s);
     ncclResult_t r2 = g_rccl.GroupEnd();
     if (r != kNcclSuccess) return comm_fail(CHUB_ERR_COMM, std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(r));
@@ -188,16 +196,22 @@ static int gather_on(chub_comm *c, const void *d_send, void *d_recv, int64_t byt
     return CHUB_OK;
 }
 
+// A slot is bound to a send buffer's address while a gather of it may still be out; once that gather has been joined (busy == false) the
+// slot may be taken over by another buffer -- a caller that frees and re-allocates its blocks, or uses a third one, neither runs out of
+// slots nor aliases a stale binding.
 static chub_comm::Slot *slot_of(chub_comm *c, const void *buf, bool claim) {
     for (chub_comm::Slot &sl : c->slot)
         if (sl.buf == buf) return &sl;
     if (!claim) return nullptr;
     for (chub_comm::Slot &sl : c->slot)
-        if (!sl.buf) {
+        if (!sl.buf || !sl.busy) {
             sl.buf = buf;
+            sl.busy = false;
             return &sl;
         }
-    return nullptr;
+    // both slots have a gather out: the older one's (the caller waits for it on its stream before the buffer is written: chub_comm_gather_begin)
+    chub_comm::Slot *old = c->slot[0].seq <= c->slot[1].seq ? &c->slot[0] : &c->slot[1];
+    return old;
 }
 
 // Overlapped gathers (off by default): chub_comm_gather then runs on the communicator's own stream behind an event of the caller's, and
@@ -209,11 +223,21 @@ int chub_comm_set_overlap(chub_comm *c, int enabled) {
     HIPC_TRY(hipSetDevice(c->device));
     for (const chub_comm::Slot &sl : c->slot)
         if (sl.busy) return comm_fail(CHUB_ERR_ARG, "gathers are outstanding: chub_comm_join first");
-    if (enabled && !c->stream) {
-        HIPC_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        for (chub_comm::Slot &sl : c->slot) {
-            HIPC_TRY(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
-            HIPC_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (enabled && !c->stream) {  // the stream and all four events, or nothing: created into locals and handed over only when all of them exist
+        hipStream_t st = nullptr;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        hipError_t he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (int i = 0; i < 4 && he == hipSuccess; i++) he = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+        if (he != hipSuccess) {
+            for (hipEvent_t e_ : ev)
+                if (e_) (void) hipEventDestroy(e_);
+            if (st) (void) hipStreamDestroy(st);
+            return comm_fail(CHUB_ERR_HIP, std::string("chub_comm_set_overlap: ") + hipGetErrorString(he));
+        }
+        c->stream = st;
+        for (int i = 0; i < 2; i++) {
+            c->slot[i].ready = ev[2 * i];
+            c->slot[i].done = ev[2 * i + 1];
         }
     }
     c->overlap = enabled != 0;
@@ -225,11 +249,11 @@ int chub_comm_gather_begin(chub_comm *c, const void *d_send, void *stream) {
     if (!c || !d_send) return comm_fail(CHUB_ERR_ARG, "null argument");
     if (!c->overlap) return CHUB_OK;
     chub_comm::Slot *sl = slot_of(c, d_send, true);  // (announcing a buffer is what makes its gathers overlapped ones)
-    if (!sl) return comm_fail(CHUB_ERR_ARG, "overlapped gathers take at most two send buffers (the double-buffered packed step output)");
-    if (sl->busy) {  // the gather that last read this buffer must have left before the buffer is written again
+    if (sl->busy) {  // the gather that last read this buffer -- or, for a third buffer, the older of the two still out -- must have left first
         HIPC_TRY(hipStreamWaitEvent((hipStream_t) stream, sl->done, 0));
         sl->busy = false;
     }
+    sl->buf = d_send;
     return CHUB_OK;
 }
 
@@ -265,6 +289,7 @@ int chub_comm_gather(chub_comm *c, const void *d_send, void *d_recv, int64_t byt
     if (rc) return rc;
     HIPC_TRY(hipEventRecord(sl->done, c->stream));
     sl->busy = true;
+    sl->seq = ++c->gather_seq;
     return CHUB_OK;
 }
 

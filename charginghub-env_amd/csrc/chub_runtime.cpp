@@ -1109,15 +1109,21 @@ int chub_step_device_packed(chub_env *e, const float *d_actions, const double *d
 }
 
 int chub_step_gather(chub_env *e, chub_comm *comm, const float *d_actions, float *d_packed, float *d_gathered, void *stream) {
-    if (!e || !comm || !d_actions || !d_packed) return fail(CHUB_ERR_ARG, "null argument");
+    if (!e || !comm || !d_actions) return fail(CHUB_ERR_ARG, "null argument");
     // (overlapped gathers, chub_comm_set_overlap: the gather that last sent this block must have left before the kernels overwrite it;
     // a capture remembers the communicator so that chub_graph_end can join its stream)
-    int rc = chub_comm_gather_begin(comm, d_packed, stream);
+    // the ROOT's kernels write its packed block straight into the gathered buffer (its first n_envs rows): no copy of the root's own block, neither
+    // by a send to itself nor otherwise; d_packed is not touched there (may be null).  Every other rank steps into d_packed and sends it.
+    const bool root = chub_comm_rank(comm) == 0;
+    if (root && !d_gathered) return fail(CHUB_ERR_ARG, "rank 0 needs the gathered buffer");
+    if (!root && !d_packed) return fail(CHUB_ERR_ARG, "null argument");
+    float *out = root ? d_gathered : d_packed;
+    int rc = chub_comm_gather_begin(comm, out, stream);
     if (rc) return rc;
     if (e->capturing) e->cap_comm = comm;
-    rc = chub_step_device_packed(e, d_actions, nullptr, d_packed, stream);
+    rc = chub_step_device_packed(e, d_actions, nullptr, out, stream);
     if (rc) return rc;
-    return chub_comm_gather(comm, d_packed, d_gathered, e->hp.n_envs * (int64_t) (e->hp.obs_dim + 2) * (int64_t) sizeof(float), stream);
+    return chub_comm_gather(comm, out, d_gathered, e->hp.n_envs * (int64_t) (e->hp.obs_dim + 2) * (int64_t) sizeof(float), stream);
 }
 
 // A run of steps issued from C: what a host loop of chub_reset_device / chub_step_device_packed / chub_step_gather calls does, without

@@ -219,8 +219,13 @@ int chub_sync(chub_env *env);
  * capturable in a hipGraph.  RCCL is loaded on first use (dlopen); a process that never makes a communicator never maps it.
  *   chub_comm_unique_id: rank 0 makes the 128-byte RCCL id; the host passes it to the other ranks (file, pipe, socket).
  *   chub_comm_create:    every rank, same id (ncclCommInitRank on `device`).
- *   chub_comm_gather:    every rank: `bytes` from d_send to rank 0's d_recv + rank * bytes (d_recv ignored elsewhere).
- *   chub_step_gather:    chub_step_device_packed + chub_comm_gather of the packed block on one stream -- the multi-GPU step.
+ *   chub_comm_gather:    every rank: `bytes` from d_send to rank 0's d_recv + rank * bytes (d_recv ignored elsewhere).  IN PLACE on rank 0:
+ *                        with d_send == d_recv its own block already lies where it belongs and rank 0 neither sends to nor receives from
+ *                        itself (on a world of one nothing is enqueued at all).
+ *   chub_step_gather:    the multi-GPU step: chub_step_device_packed + chub_comm_gather of the packed block on one stream.  Rank 0's step
+ *                        kernels write its block STRAIGHT INTO d_gathered (rows 0 .. n_local - 1: the in-place form above -- no copy of
+ *                        the root's own block); d_packed is not touched on rank 0 and may be NULL there.  Every other rank steps into
+ *                        d_packed and sends it; d_gathered is ignored there.
  *   chub_comm_max_f64 / chub_comm_barrier: max over ranks of one host double / rendezvous (both synchronise `stream`);
  *                        what bench.py brackets its timed region with.
  *   chub_comm_gather_timed: the same gather `reps` times back to back between two HIP events on `stream`: microseconds per gather
@@ -245,9 +250,13 @@ int chub_comm_ranks_seen(chub_comm *comm, int *out, void *stream);
  * k runs beside the kernels of step k + 1.  Inside a hipGraph capture (chub_graph_begin .. chub_graph_end) the events are graph edges --
  * no host cost per replay; call by call they cost the host two event calls per step (measured slower than the serial form).
  *   chub_comm_gather_begin: before enqueueing work that overwrites a send buffer: `stream` waits for the gather that last read it.
- *                           Announcing a buffer here is what makes its gathers overlapped ones (at most two buffers per communicator:
- *                           the double-buffered packed step output; chub_step_gather announces its block); chub_comm_gather of any
- *                           other buffer goes out on the caller's stream behind every gather still out
+ *                           Announcing a buffer here is what makes its gathers overlapped ones (two gathers may be out at a time: the packed
+ *                           step output is double-buffered; chub_step_gather announces its block -- a third buffer waits, on `stream`, for
+ *                           the older of the two; a buffer whose gather has been joined gives its slot up); chub_comm_gather of a buffer
+ *                           nobody announced goes out on the caller's stream behind every gather still out
+ *                           Join (chub_comm_join) BEFORE chub_graph_begin: a capture must not wait on an event recorded outside it.  The
+ *                           overlapped form has run on a world of one only; it stays off by default (bench.py --overlap-gather) until a
+ *                           run with more than one rank has verified it
  *   chub_comm_join:         `stream` waits for every gather still out: before the gathered blocks are consumed, before a host
  *                           synchronisation that is meant to cover them (chub_graph_end, chub_comm_max_f64 / barrier / ranks_seen /
  *                           gather_timed call it themselves) */

@@ -76,14 +76,14 @@ def test_bench_multi_rank_path_on_a_world_of_one():
     assert d["roofline"] is None                  # --no-events: no per-kernel block, never a made-up one
     assert d["config"]["graph"].startswith("off (")
     ph = d["phases"]                              # the step taken apart per rank + what the builder expects of it
-    assert len(ph["per_rank"]) == 1 and ph["per_rank"][0]["rank"] == 0 and ph["per_rank"][0]["gather_us"] > 0
+    assert len(ph["per_rank"]) == 1 and ph["per_rank"][0]["rank"] == 0 and 0 <= ph["per_rank"][0]["gather_us"] < 50  # (a world of one: the root's block is in place, nothing moves)
     assert ph["per_rank"][0]["host_issue_us"] > 0 and ph["expected_ms_per_step"] > 0 and ph["measured_ms_per_step"] == d["ms_per_step"]
 
 
 def test_bench_multi_rank_path_reports_its_phases_with_kernel_times():
     d = _bench("--force-comm", "--graph", "off", "--no-c5", "--no-cpu-baseline", "--envs", "8192")
     r0 = d["phases"]["per_rank"][0]               # an 8-GPU shard's worth of envs: the single-launch step, priced as one kernel
-    assert 3.0 < r0["slot_kernel_us"] + r0["env_kernel_us"] < 40.0 and 1.0 < r0["gather_us"] < 200.0
+    assert 3.0 < r0["slot_kernel_us"] + r0["env_kernel_us"] < 40.0 and 0.0 <= r0["gather_us"] < 200.0
     assert d["phases"]["expected_bound"] in ("gpu (kernels + gather)", "host issue (call by call)")
     # the expectation is built from the parts and the measurement must not be far under it (nothing runs faster than its parts)
     assert d["phases"]["measured_ms_per_step"] > 0.5 * d["phases"]["expected_ms_per_step"]
