@@ -3318,8 +3318,8 @@ struct TailPrefetch {
     }
 };
 
-template <int BLOCK, int T, bool BITS = false, bool TAPE = false>
-__global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in, TailArgs ta) {
+template <int BLOCK, int T, bool BITS, bool TAPE>
+__device__ __forceinline__ void step_fused_body(const DevCtx *__restrict__ ctx, const StepArgs &sa, const PackedArgs &pa_in, const TailArgs &ta) {
     static_assert(BLOCK >= 150 && BLOCK / 64 >= 3, "one table element per lane; three waves with work of their own");
     __shared__ uint32_t q_new[BLOCK * T];
     __shared__ uint32_t q_cnt[2];
@@ -3390,6 +3390,75 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
             env_tail<false, MODE_PHILOX, false, true, RecordsMid, kEnvBlock, TAPE>(ctx, sa, env, live, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, nullptr, s_out, 0, ta,
                                                                                    s_rec, live ? le : 0, env_first + c, rows > 0 ? rows : 0, hook.tin, c == 0, mid);
         }
+    }
+}
+
+template <int BLOCK, int T, bool BITS = false, bool TAPE = false>
+__global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in, TailArgs ta) {
+    step_fused_body<BLOCK, T, BITS, TAPE>(ctx, sa, pa_in, ta);
+}
+
+// ---- A SPAN of lock-step steps in ONE launch ("multi-step persistent kernel for the random-policy bench").
+// k_step_fused gives every workgroup whole envs -- their slots, their station records, their tails, the next step's draws -- and nothing
+// crosses workgroups (MGR:136-302: the reference's envs are separate objects), so a workgroup can go from one step to the next BY ITSELF:
+// no grid-wide synchronisation, one workgroup barrier between steps (every store of a step is then out and visible to the workgroup's own
+// waves, which share the CU's vector cache).  What a step needs beyond the previous step's state arrives as today: the step's action rows
+// (chub_run_steps's batches, step i reads batch i % n_batches) and its packed output block (step i writes block i & 1) -- so the policy is
+// open loop over the span (the random-policy bench, replayed action tapes), and of the span's outputs the last two blocks remain.  Every
+// per-step kernel argument is a function of the step number (clock, Philox tick, tariff, table rows, buffer parities): same functions,
+// same Philox counters, bit-identical to the steps issued one by one.  What it saves is the kernel boundary between two steps of a
+// launch-bound batch (the one-launch step is boundary + five dependent round trips + an f64 chain).
+struct SpanArgs {
+    int32_t n_steps, pc0;         // steps in the span (it ends at a day boundary at the latest); price_count before its first step (MGR:354)
+    uint32_t first;               // index of its first step
+    int32_t n_batches, D;
+    const float *actions[8];      // chub_run_steps's action batches (n_batches <= 8)
+    float *packed[2];             // ... and its two packed output blocks
+    CHUB_G(const uint32_t) pk[2];     // StationArrays::pk, EnvArrays::drw / drw_cnt by tick parity
+    CHUB_G(const uint32_t) drw[2];
+    CHUB_G(const uint8_t) drw_cnt[2];
+    CHUB_G(const double) price;   // Tables::price, pvT, wdT, sin96
+    CHUB_G(const double) pvT;
+    CHUB_G(const double) wdT;
+    CHUB_G(const double) sin96;
+};
+template <int BLOCK, int T>
+__global__ __launch_bounds__(BLOCK, 2) void k_steps_fused(const DevCtx *__restrict__ ctx, StepArgs sa0, PackedArgs pa0, TailArgs ta0, SpanArgs sp) {
+    for (int s = 0; s < sp.n_steps; s++) {
+        if (s) __syncthreads();
+        StepArgs sa = sa0;
+        PackedArgs pa = pa0;
+        TailArgs ta = ta0;
+        const uint32_t i = sp.first + (uint32_t) s;
+        const int t = sa0.t + s, t_next = (t + 1) % 96;
+        sa.t = t;
+        sa.tick = sa0.tick + (uint32_t) s;
+        sa.draw_price = ((sp.pc0 + s) % 4 == 0) ? 1 : 0;
+        sa.price_last = sp.price[t];               // AGG:147
+        sa.price_prev = sp.price[(t + 95) % 96];
+        const uint32_t b = i % (uint32_t) sp.n_batches;
+        const float *act = sp.actions[0];
+#pragma unroll
+        for (int j = 1; j < 8; j++) act = b == (uint32_t) j ? sp.actions[j] : act;
+        float *out = (i & 1u) ? sp.packed[1] : sp.packed[0];
+        sa.actions = act;
+        sa.obs = out;
+        sa.reward = out + sp.D;
+        sa.done_f32 = out + sp.D + 1;
+        if (s) sa.fresh = 0;  // (the previous step of this launch left this step's draws)
+        const bool odd = (sa.tick & 1u) != 0u;
+        pa.pk = odd ? sp.pk[1] : sp.pk[0];
+        pa.actions = (CHUB_G(const float)) act;
+        pa.tick = sa.tick;
+        ta.drw = odd ? sp.drw[1] : sp.drw[0];
+        ta.drw_cnt = odd ? sp.drw_cnt[1] : sp.drw_cnt[0];
+        ta.actions = (CHUB_G(const float)) act;
+        ta.pv_row = sp.pvT + t_next * 100;
+        ta.wd_row = sp.wdT + t_next * 150;
+        ta.pv_row_now = sp.pvT + t * 100;
+        ta.wd_row_now = sp.wdT + t * 150;
+        ta.sin_t = sp.sin96[t_next];
+        step_fused_body<BLOCK, T, false, false>(ctx, sa, pa, ta);
     }
 }
 
@@ -3806,6 +3875,35 @@ void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &s
 }
 
 // COMPAT lock-step reset / step of a handle whose envs all fit one workgroup (the caller has checked): one launch
+// a span of n_steps lock-step steps from `sa` (the span's first step) in one launch: chub_run_steps, PHILOX handles on the one-launch step
+void launch_steps_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp, int n_steps, int pc0,
+                        int64_t first, const float *const *batches, int n_batches, float *const *packed2) {
+    if (sa.fresh) hipLaunchKernelGGL(k_draw_levels, dim3((unsigned) ((2 * ((int64_t) sa.env_hi - sa.env_lo + 1) + 255) / 256)), dim3(256), 0, stream, ctx, sa);
+    const PackedArgs pa = make_packed_args(hp, sa, pp);
+    TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa, pp, false);
+    ta.tail_act = nullptr;  // (the tails read their two actions from the action rows, as in k_step_fused)
+    SpanArgs sp = {};
+    sp.n_steps = n_steps;
+    sp.pc0 = pc0;
+    sp.first = (uint32_t) (first % (2 * n_batches));  // (only first mod n_batches and first mod 2 matter: 2 * n_batches is a multiple of both)
+    sp.n_batches = n_batches;
+    sp.D = hp.obs_dim;
+    for (int j = 0; j < 8; j++) sp.actions[j] = batches[j < n_batches ? j : 0];
+    sp.packed[0] = packed2[0];
+    sp.packed[1] = packed2[1];
+    for (int q = 0; q < 2; q++) {
+        sp.pk[q] = (CHUB_G(const uint32_t)) pp.pk[q];
+        sp.drw[q] = (CHUB_G(const uint32_t)) pp.ev->drw[q];
+        sp.drw_cnt[q] = (CHUB_G(const uint8_t)) pp.ev->drw_cnt[q];
+    }
+    sp.price = (CHUB_G(const double)) pp.tb->price;
+    sp.pvT = (CHUB_G(const double)) pp.tb->pvT;
+    sp.wdT = (CHUB_G(const double)) pp.tb->wdT;
+    sp.sin96 = (CHUB_G(const double)) pp.tb->sin96;
+    const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
+    hipLaunchKernelGGL((k_steps_fused<kPackedBlock, kSlotsPerLane>), dim3(nb), dim3(kPackedBlock), 0, stream, ctx, sa, pa, ta, sp);
+}
+
 void launch_compat_small(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp) {
     const TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa, pp, reset);
     if (reset) hipLaunchKernelGGL(k_compat_small<true>, dim3(1), dim3(kCompatSmallBlock), 0, stream, ctx, sa, ta);

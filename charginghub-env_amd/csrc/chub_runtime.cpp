@@ -31,6 +31,8 @@ void launch_expand_bits(const HubParams &hp, const uint64_t *d_bits, const float
 void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp, hipEvent_t ev0,
                        hipEvent_t ev1);
 void launch_compat_small(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp);
+void launch_steps_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp, int n_steps, int pc0,
+                        int64_t first, const float *const *batches, int n_batches, float *const *packed2);
 bool slot_walk2_covers(const HubParams &hp);
 void launch_slot_walk2(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, const StepArgs &sw, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 void launch_env_walk(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, const StepArgs &sw, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
@@ -65,6 +67,7 @@ struct chub_env {
     Tables tb;
     int device;
     bool fused;         // PHILOX lock-step steps of this handle run as ONE launch (k_step_fused): small batches
+    int span_steps = 0;          // chub_options.span_steps: chub_run_steps's spans of steps in one launch (0: up to a day's rest; 1: never; n: at most n)
     bool no_walk_ahead = false;  // chub_options.walk_ahead = 1: the split COMPAT step never walks ahead (A/B, parity cross-check)
     int rng_cur = 0;           // COMPAT: which of CompatRng's three buffers holds the committed streams (moved on by every commit: chub_device.h)
     uint32_t walked_tick = 0;  // COMPAT split step: the tick whose stream walk has run already, beside the previous step's tails (0: none)
@@ -391,6 +394,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if (opt.tile < 0 || opt.tile > 2) return fail(CHUB_ERR_ARG, "chub_options.tile must be 0, 1 or 2");
     if (opt.walk_ahead < 0 || opt.walk_ahead > 1) return fail(CHUB_ERR_ARG, "chub_options.walk_ahead must be 0 or 1");
     if (opt.work_order < 0 || opt.work_order > 1) return fail(CHUB_ERR_ARG, "chub_options.work_order must be 0 or 1");
+    if (opt.span_steps < 0 || opt.span_steps > 96) return fail(CHUB_ERR_ARG, "chub_options.span_steps must be 0 .. 96");
     *out = nullptr;
     if (n_envs <= 0) return fail(CHUB_ERR_ARG, "n_envs must be positive");
     if (n_envs * (int64_t) (cfg->station_list[0] + cfg->station_list[1] + 2) >= (int64_t) 1 << 31)
@@ -744,6 +748,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     {   // the reference-exact mode at a handful of envs (the drop-in class: one): both station passes and the tail in one launch
         const int64_t fit = std::min<int64_t>(64, std::min<int64_t>(kCompatSmallWaves0 * (64 / hp.U[0]), kCompatSmallWaves1 * (64 / hp.U[1])));
         e->no_walk_ahead = opt.walk_ahead == 1;
+        e->span_steps = opt.span_steps;
         e->compat_small = rng_mode == CHUB_RNG_COMPAT && opt.fused_step != 1 && hp.S[0] <= 64 && hp.S[1] <= 64 && n_envs <= fit;
         // ... and everything else as the split step (stream walks, one env per lane -> slots of both stations in one launch) unless
         // slot_kernel = 1 asks for one kernel per station with the unit's first lane walking (the parity cross-check).  Measured, us per
@@ -1126,6 +1131,54 @@ int chub_step_gather(chub_env *e, chub_comm *comm, const float *d_actions, float
     return chub_comm_gather(comm, out, d_gathered, e->hp.n_envs * (int64_t) (e->hp.obs_dim + 2) * (int64_t) sizeof(float), stream);
 }
 
+// chub_run_steps on a PHILOX handle that runs the one-launch step (k_step_fused): a span of lock-step steps goes out as ONE launch
+// (k_steps_fused: the workgroup that owns an env's slots, records and tail goes from step to step by itself).  Not while a tape is loaded,
+// on per-env clocks, with one bit per pile, under the per-kernel profiler or with chub_options.span_steps = 1.
+static bool span_ok(const chub_env *e, int n_batches) {
+    return e->fused && e->span_steps != 1 && e->hp.rng_mode == CHUB_RNG_PHILOX && !e->per_env && !e->prof_on && !e->tape_pk && !e->tape_car &&
+           !e->tape_tail && !e->tape_only && !e->cur_bits && n_batches <= 8 && e->tick != 0 && !e->hp.telemetry;
+}
+
+static int run_span(chub_env *e, const float *const *batches, int n_batches, float *const *packed2, int64_t first, int k, hipStream_t s) {
+    HIP_TRY(hipSetDevice(e->device));
+    (void) hipGetLastError();
+    if (e->t + k > 96) return fail(CHUB_ERR_ARG, "a span of steps ends at the day's end at the latest");
+    const int D = e->hp.obs_dim;
+    StepArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.t = e->t;
+    sa.tick = e->tick + 1u - e->graph_base;
+    sa.draw_price = (e->price_count % 4 == 0) ? 1 : 0;
+    sa.station_filter = -1;
+    sa.price_last = e->price[e->t];
+    sa.price_prev = e->price[(e->t + 95) % 96];
+    sa.actions = batches[first % n_batches];
+    float *out = packed2[first & 1];
+    sa.obs = out;
+    sa.obs_stride = D + 2;
+    sa.reward = out + D;
+    sa.reward_stride = D + 2;
+    sa.done_f32 = out + D + 1;
+    sa.env_lo = 0;
+    sa.env_hi = (int32_t) (e->hp.n_envs - 1);
+    sa.fresh = (!e->predrawn || (e->capturing && e->tick == e->graph_tick0)) ? 1 : 0;  // (as run_step: a graph's first step makes its own draws)
+#if CHUB_TRACE
+    sa.stamps_slot = nullptr;
+    sa.stamps_env = nullptr;
+#endif
+    int rc = sync_ctx(e, s);
+    if (rc) return rc;
+    launch_steps_fused(e->hp, e->d_ctx, sa, s, packed_ptrs(e), k, e->price_count, first, batches, n_batches, packed2);
+    HIP_TRY(hipGetLastError());
+    e->tick += (uint32_t) k;
+    if (e->capturing) e->cap_full_rel = e->tick - e->graph_tick0;  // (note_served: which launch of the capture served every env last)
+    else e->full_tick = e->tick;
+    e->predrawn = true;
+    e->price_count += k;
+    e->t = (e->t + k) % 96;
+    return CHUB_OK;
+}
+
 // A run of steps issued from C: what a host loop of chub_reset_device / chub_step_device_packed / chub_step_gather calls does, without
 // a trip through the host language per step (multi-GPU shards of a few thousand envs are otherwise bound by the host's issue rate)
 int chub_run_steps(chub_env *e, chub_comm *comm, const float *const *d_action_batches, int n_batches, float *const *d_packed2,
@@ -1136,6 +1189,17 @@ int chub_run_steps(chub_env *e, chub_comm *comm, const float *const *d_action_ba
     for (int64_t i = first_step; i < first_step + n_steps; i++) {
         int rc;
         if (i % 96 == 0 && (rc = chub_reset_device(e, nullptr, nullptr, d_reset_obs, stream))) return rc;
+        // a SPAN of steps in ONE launch (k_steps_fused) where the handle runs the one-launch step anyway: up to the day's end or the call's
+        if (!comm) {
+            int64_t k = first_step + n_steps - i;
+            k = k < 96 - i % 96 ? k : 96 - i % 96;
+            if (e->span_steps > 1 && k > e->span_steps) k = e->span_steps;
+            if (k >= 2 && span_ok(e, n_batches)) {
+                if ((rc = run_span(e, d_action_batches, n_batches, d_packed2, i, (int) k, (hipStream_t) stream))) return rc;
+                i += k - 1;
+                continue;
+            }
+        }
         const float *act = d_action_batches[i % n_batches];
         float *packed = d_packed2[i & 1];
         if (comm) rc = chub_step_gather(e, comm, act, packed, d_gathered2 ? d_gathered2[i & 1] : nullptr, stream);

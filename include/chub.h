@@ -90,7 +90,12 @@ typedef struct chub_options {
     int32_t work_order;   /* PHILOX packed kernels, cache-resident sizes (the small tile, at most 6 M charger slots): 0 = tiles, tail and level workgroups
                              take their work in contiguous eighths per XCD (the dispatcher hands workgroup b to XCD b % 8) (default),
                              1 = the dispatcher's order (workgroup b takes tile b: the A/B and the parity cross-check).  Results are bit-identical. */
-    int32_t reserved[2];
+    int32_t span_steps;   /* chub_run_steps on a PHILOX handle that runs the one-launch step (fused_step): spans of lock-step steps as ONE launch
+                             (k_steps_fused: each workgroup goes from step to step by itself, one workgroup barrier between steps; a span ends
+                             at the day's end at the latest): 0 = as many steps as the call and the day allow (default), 1 = never (every step
+                             a launch: the parity cross-check), n = at most n steps per launch.  Results are bit-identical.  Of a span's packed
+                             outputs the last two blocks remain (the policy is open loop over the span: the call's own action batches). */
+    int32_t reserved[1];
 } chub_options;
 
 /* telemetry column indices of chub_get_telemetry (names of the reference attributes, MGR:183-297) */

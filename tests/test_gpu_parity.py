@@ -1394,3 +1394,80 @@ def test_compat_split_step_is_bit_identical_through_restores_and_masked_calls():
     for k, (a, b, c) in enumerate(zip(out["wave"], out["packed"], out["packed_own_walks"])):
         assert np.array_equal(a, b, equal_nan=True), k
         assert np.array_equal(a, c, equal_nan=True), ("own walks", k)
+
+
+@pytest.mark.parametrize("label", ["c2", "c3_small", "ragged"])
+def test_spans_of_steps_in_one_launch_are_bit_identical(label):
+    """chub_run_steps on a handle that runs the one-launch step issues spans of lock-step steps as ONE launch (k_steps_fused: each workgroup goes
+    from step to step by itself; chub_options.span_steps).  The same program of calls with spans of any length, of at most 7 steps, and with
+    every step a launch of its own (span_steps = 1: the form every other test pins to the oracle / the reference): both packed blocks after
+    every call, slot state, station records, clocks bit for bit -- across day boundaries, from odd first steps, with 3 action batches (i % 3
+    against i & 1), mixed with single steps, a call on a subset of the envs (per-env clocks: no spans from there until everybody is reset) and
+    inside a hipGraph."""
+    chub = hub()
+    from charginghub_env_amd import multi_gpu
+    from charginghub_env_amd._lib import check
+    kw = {"c2": dict(station_list=[16, 0], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2,
+                     fc_max_power=100.0, fcev_permeate=0.0),
+          "c3_small": dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2,
+                           fc_max_power=100.0, fcev_permeate=0.02, renew_fluctuate=0.2, price_fluctuate=0.1),
+          "ragged": dict(station_list=[7, 13], station_type_list=["slow", "fast"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.3,
+                         fc_max_power=100.0, fcev_permeate=0.05, renew_fluctuate=0.3, price_fluctuate=0.3, hydro_loss=0.001)}[label]
+    n = {"c2": 4096, "c3_small": 1500, "ragged": 777}[label]
+    res = {}
+    for form in ("off", "auto", 7, "graph"):
+        v = chub.VecChargingHub(n, seed=21, span_steps="auto" if form == "graph" else form, **kw)
+        assert v.uses_fused_step
+        D, A = v.obs_dim, v.act_dim
+        st = multi_gpu.Stream(0)
+        acts = [multi_gpu.DeviceBuffer(n * A * 4) for _ in range(3)]
+        for b, a in enumerate(acts):
+            v.random_actions_device(a.ptr, 9, b, st.ptr)
+        packed = [multi_gpu.DeviceBuffer(n * (D + 2) * 4) for _ in range(2)]
+        obs0, rew, done = multi_gpu.DeviceBuffer(n * D * 4), multi_gpu.DeviceBuffer(n * 4), multi_gpu.DeviceBuffer(n)
+        c_acts = (C.c_void_p * 3)(*[a.ptr for a in acts])
+        c_packed = (C.c_void_p * 2)(packed[0].ptr, packed[1].ptr)
+        trace = []
+
+        def run(first, count):
+            check(v._lib.chub_run_steps(v._h, None, c_acts, 3, c_packed, None, obs0.ptr, first, count, st.ptr))
+
+        def note():
+            trace.extend([packed[0].to_host(np.float32, (n, D + 2), st.ptr), packed[1].to_host(np.float32, (n, D + 2), st.ptr)])
+
+        run(0, 5)       # reset + a short span
+        note()
+        run(5, 1)       # a single step through the same entry point
+        note()
+        v.step_device_packed(acts[0].ptr, packed[0].ptr, stream=st.ptr)  # step 6, from the host
+        run(7, 96 - 7 + 30)  # an odd first step, to the day's end, a reset inside, 30 steps into the next day
+        note()
+        if form == "graph":
+            st.sync()
+            v.graph_begin(st.ptr)
+            run(126, 66 + 96)  # to the end of day 2 and through day 3: 162 steps + 1 reset = 163 launches' worth of ticks
+            run(288, 2)        # + 1 reset + 2 steps: an even count of ticks in the graph (the draws are double-buffered by tick parity)
+            g = v.graph_end(st.ptr)
+            v.graph_launch(g, st.ptr)
+            st.sync()
+            v.graph_destroy(g)
+        else:
+            run(126, 66 + 96)
+            run(288, 2)
+        note()
+        m = np.ascontiguousarray(np.arange(n) % 3 == 0, dtype=np.uint8)  # per-env clocks from here: run_steps goes step by step
+        check(v._lib.chub_step_envs_device(v._h, m.ctypes.data, acts[1].ptr, None, obs0.ptr, rew.ptr, done.ptr, st.ptr))
+        trace.append(obs0.to_host(np.float32, (n, D), st.ptr))
+        run(290, 3)
+        note()
+        run(288 + 96, 40)  # (a multiple of 96: everybody is reset, one clock again, spans again)
+        note()
+        trace += [np.concatenate([x.reshape(n, -1) for x in v.slots()], axis=1), v.station_scalars().reshape(n, -1), v.env_clocks(ticks=True)[0],
+                  v.env_clocks(ticks=True)[1]]
+        res[form] = trace
+        v.close()
+        st.destroy()
+    for form in ("auto", 7, "graph"):
+        assert len(res[form]) == len(res["off"])
+        for k, (a, b) in enumerate(zip(res["off"], res[form])):
+            assert np.array_equal(a, b), (label, "spans", form, "vs every step a launch: array", k)

@@ -15,6 +15,7 @@ ap.add_argument("--tile", default=os.environ.get("AB_TILE", "auto"))
 ap.add_argument("--fused", default=os.environ.get("AB_FUSED", "auto"))
 ap.add_argument("--order", default=os.environ.get("AB_ORDER", "auto"))
 ap.add_argument("--lib", default=None, help="another build of libchub.so (the same as CHUB_LIB=...)")
+ap.add_argument("--no-events", action="store_true", help="no per-kernel dispatch timestamps (chub_profile_*: hipExtLaunchKernelGGL with start / stop events)")
 ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replays at the end (counter passes: the eager steps are what is counted)")
 args = ap.parse_args()
 if args.lib:
@@ -41,13 +42,14 @@ for i in range(WARM):
     if i % 96 == 0: v.reset_device(obs0.ptr)
     v.step_device_packed(acts[i%4].ptr, packed.ptr)
 v.sync()
-v.profile_begin(STEPS, every=2)
+if not args.no_events: v.profile_begin(STEPS, every=2)
 import time
 t0 = time.perf_counter()
 for i in range(STEPS):
     if i % 96 == 0: v.reset_device(obs0.ptr)
     v.step_device_packed(acts[i%4].ptr, packed.ptr)
-a, b, k = v.profile_end()
+a, b, k = v.profile_end() if not args.no_events else (0.0, 0.0, 1)
+v.sync()
 dt = time.perf_counter() - t0
 import numpy as np
 # the same steps as hipGraph replays of two episodes (what bench.py times at N = 1): microseconds per step without the host
