@@ -696,17 +696,8 @@ def main():
         if len({d["pci"] for d in rank_devices}) != world and not args.force_comm:
             raise SystemExit("ranks share a GPU: %s" % rank_devices)
 
-    def one_step(i):
-        b = i & 1
-        if i % 96 == 0:
-            v.reset_device(reset_obs.ptr, stream=stream.ptr)
-        if use_comm:  # step kernels + ONE grouped ncclSend / ncclRecv on the same stream (chub_step_gather)
-            chub._lib.check(lib.chub_step_gather(v._h, comm._h, actions[i % N_ACTION_BATCHES].ptr, packed[b].ptr,
-                                                 gathered[b].ptr if rank == 0 else None, stream.ptr))
-        else:
-            v.step_device_packed(actions[i % N_ACTION_BATCHES].ptr, packed[b].ptr, stream=stream.ptr)
-
-    # the same calls issued from C for a whole span of steps (chub_run_steps): no trip through Python per step
+    # every step goes out through chub_run_steps: a whole span of steps issued from C (a reset at every day boundary; per step chub_step_device_packed,
+    # or -- with a communicator -- chub_step_gather: the step kernels + ONE grouped ncclSend / ncclRecv on the same stream): no trip through Python per step
     import ctypes as C
     PtrArr = C.c_void_p * N_ACTION_BATCHES
     c_actions = PtrArr(*[a.ptr for a in actions])
@@ -735,8 +726,7 @@ def main():
     if use_graph and steps > SPAN_GRAPH_MAX:
         stream.sync()
         v.graph_begin(stream.ptr)
-        for i in range(per_graph):
-            one_step(i)
+        span(0, per_graph)  # (chub_run_steps: the same resets and steps issued from C; a handle on the one-launch step sends whole spans of steps as ONE launch)
         episode_graph = v.graph_end(stream.ptr)
 
     replayed = [0]
@@ -772,8 +762,7 @@ def main():
             n -= 1
         if n > 0:
             v.graph_begin(stream.ptr)
-            for i in range(warmup, warmup + n):
-                one_step(i)
+            span(warmup, n)
             span_graph = v.graph_end(stream.ptr)
             span_graph_steps = n
             fence()
@@ -825,8 +814,7 @@ def main():
         if use_graph and g_days is None:
             stream.sync()
             v.graph_begin(stream.ptr)
-            for j in range(per_graph):
-                one_step(i + j)
+            span(i, per_graph)
             g_days = v.graph_end(stream.ptr)
         if g_days is not None:
             v.graph_launch(g_days, stream.ptr)  # (untimed: the first replay of a fresh graph uploads it)
@@ -879,6 +867,8 @@ def main():
         roofline = None
         if n_prof and v_fused:  # ONE kernel does the whole step: it is priced with the whole step's bytes
             achieved = (slot_b + env_b) * per / (slot_us * 1e-6) / 1e9
+            # (the dispatch timestamps are per launch: the profiled days run every step as a launch of its own, k_step_fused; the timed region and
+            # value_day_avg run whole spans of steps per launch where there is no communicator -- `roofline_step` / `day_avg.roofline_step_frac` price those)
             roofline = {"bound": "hbm", "limited_by": "launch + latency", "kernel": "k_step_fused", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                         "algorithmic_bytes_per_launch": (slot_b + env_b) * per, "avg_launch_us": slot_us, "launches_sampled": n_prof,
@@ -908,7 +898,8 @@ def main():
                                    % (total, hub_kw["station_list"][0], hub_kw["station_list"][1],
                                       {"c4": "configs[3]", "c5": "configs[4]"}.get(config, config), hub_kw["fcev_permeate"]),
                        "envs_per_gpu": per, "obs_dim": D, "act_dim": A, "launch": launch,
-                       "kernels_per_step": "1 (k_step_fused)" if v_fused else "2 (k_slot_packed + k_env)",
+                       "kernels_per_step": ("1 per SPAN of up to 96 steps (k_steps_fused: every workgroup goes from step to step by itself; chub_run_steps)"
+                                            if (v_fused and not use_comm) else "1 (k_step_fused)") if v_fused else "2 (k_slot_packed + k_env)",
                        "work_order": ("XCD-aware (tiles, tail and level workgroups in contiguous eighths per XCD)" if v.uses_xcd_order else
                                       "the dispatcher's" + (" (--work-order dispatch)" if args.work_order == "dispatch" else " (the library's choice at this size)")),
                        "window": "timed: slot %d of day %d .. slot %d of day %d; roofline: whole untimed days afterwards" % (s0, d0, s1, d1),

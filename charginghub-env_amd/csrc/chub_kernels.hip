@@ -2270,9 +2270,10 @@ __device__ __forceinline__ void compat_walk_wave(const DevCtx *__restrict__ ctx,
 // rotation, StepArgs::rng_cur names the committed one): when the slot pass of that step has been launched the host moves rng_cur on, which IS
 // the commit -- nothing is copied.  A walk two steps ahead (StepArgs::walk_far) starts from the previous step's shadow, rng_cur + 1, instead of the
 // committed streams and writes rng_cur + 2.
-template <bool RESET, int NW = 256>
+template <bool RESET, int NW = 256, int LANES = NW>  // NW envs walked by LANES threads (LANES = 64 > NW = 32: half a wave's lanes walk, all of them evaluate the new cars)
 __device__ __forceinline__ void compat_walk_block(const DevCtx *__restrict__ ctx, const StepArgs &sa, const uint32_t blk, uint32_t *s_ring, uint32_t *s_stage,
-                                                  const uint32_t tid = threadIdx.x) {  // tid: the lane's number among the block's NW; s_stage: NW / 64 staging areas of kWalkStageWords
+                                                  const uint32_t tid = threadIdx.x) {  // tid: the thread's number among the block's LANES; s_stage: LANES / 64 staging areas of kWalkStageWords
+    static_assert(LANES >= NW && LANES % 64 == 0 && (NW % 64 == 0 || LANES == 64), "whole waves; a block of fewer than 64 envs is one wave");
     const int64_t N = ctx->hp.n_envs;
     const bool far = !RESET && sa.walk_far != 0;
     const uint32_t b_src = ((uint32_t) sa.rng_cur + (far ? 1u : 0u)) % 3u, b_dst = (b_src + 1u) % 3u;
@@ -2285,7 +2286,7 @@ __device__ __forceinline__ void compat_walk_block(const DevCtx *__restrict__ ctx
     const uint32_t n_here = (uint32_t) N - env0 < (uint32_t) NW ? (uint32_t) N - env0 : (uint32_t) NW;
     {
         const u32x4 *src = (const u32x4 *) (g_src + (size_t) env0 * 32u);
-        for (uint32_t j = tid; j < n_here * 8u; j += (uint32_t) NW) {
+        for (uint32_t j = tid; j < n_here * 8u; j += (uint32_t) LANES) {
             const u32x4 q = src[j];
             const uint32_t l = j >> 3, w = (j & 7u) << 2;
             s_ring[(w + 0u) * (uint32_t) NW + l] = q.x;
@@ -2297,19 +2298,20 @@ __device__ __forceinline__ void compat_walk_block(const DevCtx *__restrict__ ctx
     __syncthreads();
     // (64 walks per wave: fewer -- 32 or 16 envs per wave, more waves -- measured slower: 115 / 129 vs 110 us per step at 65 536 envs)
     const int env = (int) (env0 + tid);
-    const bool live = env < (int) N && in_group(sa, env);
+    const bool has_env = tid < (uint32_t) NW && env < (int) N;
+    const bool live = has_env && in_group(sa, env);
     {
         CompatStreamT<RingLdsT<NW>> rs;
-        rs.r.s = s_ring + tid;
+        rs.r.s = s_ring + (tid < (uint32_t) NW ? tid : 0u);
         rs.gf = rs.gr = 0u;
         rs.x = 1u;
-        if (env < (int) N) {
+        if (has_env) {
             rs.gf = rs.r.get(31);
             rs.gr = (rs.gf + 28u) % 31u;
             rs.x = m_src[env];  // (an env the call does not name: its streams as they are, in the shadow too)
         }
         compat_walk_wave<RESET>(ctx, sa, env0 + (tid & ~63u), (int) (tid & 63u), live, rs, s_stage + (tid >> 6) * (uint32_t) kWalkStageWords);
-        if (env < (int) N) {
+        if (has_env) {
             rs.r.set(31, rs.gf);
             m_dst[env] = rs.x;
         }
@@ -2317,7 +2319,7 @@ __device__ __forceinline__ void compat_walk_block(const DevCtx *__restrict__ ctx
     __syncthreads();
     {
         u32x4 *dst = (u32x4 *) (ctx->cr.g3[b_dst] + (size_t) env0 * 32u);
-        for (uint32_t j = tid; j < n_here * 8u; j += (uint32_t) NW) {
+        for (uint32_t j = tid; j < n_here * 8u; j += (uint32_t) LANES) {
             const uint32_t l = j >> 3, w = (j & 7u) << 2;
             dst[j] = u32x4{s_ring[(w + 0u) * (uint32_t) NW + l], s_ring[(w + 1u) * (uint32_t) NW + l], s_ring[(w + 2u) * (uint32_t) NW + l],
                            s_ring[(w + 3u) * (uint32_t) NW + l]};
@@ -2352,21 +2354,26 @@ __global__ __launch_bounds__(BLOCK, 7) void k_slot_split2(const DevCtx *__restri
 // slots of stay left after step i - 1 (StationArrays::empt2, left by that step's pass) minus the cars step i admits (its walk's word) plus
 // those of them that stay one slot at most (StationArrays::shrt, from that walk: make_car's arithmetic); the queue is in that word too,
 // and the streams continue from step i's shadow, which the slot pass beside it is committing (StepArgs::walk_far).  Workgroups
-// [0, nwalk): 64 walks each, on their first wave (8 KB of rings in LDS: a larger area would cost the slot workgroups their occupancy),
+// [0, nwalk): 64 (or 32) walks each, on one wave (8 KB of rings + 7 KB of staging in LDS: a larger area would cost the slot workgroups their occupancy),
 // at raised priority; the others: slot_body_split2.
+// Envs per walk workgroup of k_slot_walk2 (one wave walks them): 64, or -- batches of at most kWalk2HalfMaxEnvs envs -- 32: twice the walking
+// waves, each with half the cars to evaluate (all 64 lanes still evaluate).  A small batch's launch lasts as long as its longest walk
+// (4096 envs: 27.0 -> 22.3 us, 16 384: 31.1 -> 26.8); a large one is bound by instruction issue, where the second set of serial phases costs
+// more than the shorter chain gives (65 536 envs: 54.6 -> 59.1 us).
+constexpr int64_t kWalk2HalfMaxEnvs = 24576;
 #ifndef CHUB_WALK2_OCC
 #define CHUB_WALK2_OCC 7  // workgroups per CU of k_slot_walk2 (sets its register budget: 72 VGPRs at 7, 80 at 6, 96 at 5)
 #endif
-template <int BLOCK>
+template <int BLOCK, int kWalk2Envs>
 __global__ __launch_bounds__(BLOCK, CHUB_WALK2_OCC) void k_slot_walk2(const DevCtx *__restrict__ ctx, StepArgs sa, StepArgs sw, int64_t nb0, int nwalk) {
-    constexpr int kWords = (BLOCK / 64) * (3 * 128 + 16) > 32 * 64 + kWalkStageWords ? (BLOCK / 64) * (3 * 128 + 16) : 32 * 64 + kWalkStageWords;
+    constexpr int kWords = (BLOCK / 64) * (3 * 128 + 16) > 32 * kWalk2Envs + kWalkStageWords ? (BLOCK / 64) * (3 * 128 + 16) : 32 * kWalk2Envs + kWalkStageWords;
     __shared__ __attribute__((aligned(16))) float lds[kWords];  // a walk workgroup: 8 KB of rings + the walking wave's staging area
     if ((int) blockIdx.x < nwalk) {
         // one wave of the workgroup walks, the others end at once (ended waves do not count at its barriers) -- the wave whose number is
         // the workgroup's modulo 4, so that the walks of the workgroups a CU receives do not all sit on the same SIMD
         if ((threadIdx.x >> 6) != (blockIdx.x & 3u)) return;
         __builtin_amdgcn_s_setprio(3);
-        compat_walk_block<false, 64>(ctx, sw, blockIdx.x, (uint32_t *) lds, (uint32_t *) lds + 32 * 64, threadIdx.x & 63u);
+        compat_walk_block<false, kWalk2Envs, 64>(ctx, sw, blockIdx.x, (uint32_t *) lds, (uint32_t *) lds + 32 * kWalk2Envs, threadIdx.x & 63u);
         return;
     }
     const HubParams &hp = ctx->hp;
@@ -3763,8 +3770,13 @@ void launch_slot_walk2(const HubParams &hp, const DevCtx *ctx, const StepArgs &s
     if (walk_now)
         CHUB_LAUNCH((k_compat_walk<false>), dim3((unsigned) ((hp.n_envs + 255) / 256)), dim3(256), stream, count_first ? (hipEvent_t) nullptr : ev0, (hipEvent_t) nullptr, ctx, sa);
     const int64_t sb0 = blocks_for(hp.n_envs, hp.U[0], 2 * BLOCK), sb1 = blocks_for(hp.n_envs, hp.U[1], 2 * BLOCK);
-    const int nwalk = (int) ((hp.n_envs + 63) / 64);
-    CHUB_LAUNCH((k_slot_walk2<BLOCK>), dim3((unsigned) (nwalk + sb0 + sb1)), dim3(BLOCK), stream, walk_now ? (hipEvent_t) nullptr : ev0, ev1, ctx, sa, sw, sb0, nwalk);
+    if (hp.n_envs <= kWalk2HalfMaxEnvs) {
+        const int nwalk = (int) ((hp.n_envs + 31) / 32);
+        CHUB_LAUNCH((k_slot_walk2<BLOCK, 32>), dim3((unsigned) (nwalk + sb0 + sb1)), dim3(BLOCK), stream, walk_now ? (hipEvent_t) nullptr : ev0, ev1, ctx, sa, sw, sb0, nwalk);
+    } else {
+        const int nwalk = (int) ((hp.n_envs + 63) / 64);
+        CHUB_LAUNCH((k_slot_walk2<BLOCK, 64>), dim3((unsigned) (nwalk + sb0 + sb1)), dim3(BLOCK), stream, walk_now ? (hipEvent_t) nullptr : ev0, ev1, ctx, sa, sw, sb0, nwalk);
+    }
 }
 
 static PackedArgs make_packed_args(const HubParams &hp, const StepArgs &sa, const PackedPtrs &pp);

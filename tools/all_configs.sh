@@ -1,8 +1,8 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/all_configs.sh <tag> -- bench.py on every BASELINE.json config that fits one GPU,
-# one JSON line each, into gpurun_out/round5_<tag>_all_configs_1gpu.json (copy into profiles/ afterwards)
+# one JSON line each, into gpurun_out/round6_<tag>_all_configs_1gpu.json (copy into profiles/ afterwards)
 TAG=${1:-vX}
-OUT=gpurun_out/round5_${TAG}_all_configs_1gpu.json
+OUT=gpurun_out/round6_${TAG}_all_configs_1gpu.json
 : > $OUT
 for c in c2 c3 c4 c5; do
   python3 bench.py --config $c --steps 1920 --warmup 384 --no-cpu-baseline --no-c5 2>/dev/null | tail -1 >> $OUT
@@ -21,5 +21,5 @@ for line in open(sys.argv[1]):
              d["roofline_step"]["frac"], d["config"]["collective"][:30]))
 PY
 # the same workloads with one bit per pile as the action input (chub_step_bits_device), next to the float rows
-for c in c2 c3 c4 c5; do python3 tools/bits_device_rate.py $c; done > gpurun_out/round5_${TAG}_packed_actions.txt 2>&1
-cat gpurun_out/round5_${TAG}_packed_actions.txt
+for c in c2 c3 c4 c5; do python3 tools/bits_device_rate.py $c; done > gpurun_out/round6_${TAG}_packed_actions.txt 2>&1
+cat gpurun_out/round6_${TAG}_packed_actions.txt

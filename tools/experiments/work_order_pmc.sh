@@ -6,8 +6,13 @@ OUT=${1:-gpurun_out/work_order_pmc}
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 96 --warmup 96 --no-cpu-baseline --no-events --no-c5 --no-bits --no-dropin"
-# (bench.py as the vehicle, as in tools/refresh_profiles.sh: a second consecutive rocprofv3 --pmc run of tools/ab_step_times.py hung in its start-up
-# twice on this pool; every pass under its own timeout, and the script stops at the first pass that fails)
+# (bench.py --no-events as the vehicle, as in tools/refresh_profiles.sh.  Round 5 had tools/ab_step_times.py here and lost two counter passes to a
+# run that never finished.  Round 6 looked for the cause (gpurun_out/r6e, r6f; tools/experiments/README.md): NOT an `env` hop in front of python --
+# the records show the profiled command was `python3 tools/ab_step_times.py` itself, variables exported by the shell, and the same command with
+# flags instead of variables timed out again on its FIRST pass.  Under --pmc the script completes with its dispatch timestamps alone
+# (chub_profile_*: hipExtLaunchKernelGGL with start / stop events; --no-graph) and with its captured graph alone (--no-events); with BOTH in one
+# process it did not come back in 3 of 5 tries (rounds 5 and 6).  Counter passes therefore take --no-events (what is counted are the eager / graph-launched kernels
+# themselves); every pass under its own timeout, and the script stops at the first pass that fails)
 for order in auto dispatch; do
   i=0
   while read -r set; do
