@@ -783,41 +783,56 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
     constexpr int kArea = 3 * 128 + 16;  // per wave: three arrays of 128 terms (aliased by the gathering areas) + the units' words
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    // Units are laid end to end over the wave's 128 VIRTUAL lanes v = 64 j + lane (j = the lane's first / second slot): floor(128 / U) units per
+    // wave -- 5 stations of 25 piles instead of the 2 x 2 that fit when a unit had to stay inside one virtual wave (round 6: a fifth of the
+    // slow station's waves gone), 6 of 20 as before.  At most one unit straddles the two virtual waves; its ranks and counts take both ballots.
     const int U = hp.U[k], S = hp.S[k];
-    const int upw = 64 / U;
-    const int uiw = lane / U;
-    const int slot = lane - uiw * U;
+    const int upp = 128 / U;  // units per wave (U >= 8 here: at most 16)
+    const uint32_t umagic = 65536u / (uint32_t) U + 1u;  // v / U = (v * umagic) >> 16, exact for v < 128 (the error term v / 65536 < 1 / U)
     const int N = (int) hp.n_envs;
-    const int env_first = (int) block_local * (WAVES * 2 * upw);
-    const int leader = uiw < upw ? uiw * U : 63;  // the unit's first lane
-    const uint64_t unit_mask = (U == 64) ? ~0ull : (uiw < upw ? (((1ull << U) - 1ull) << leader) : 0ull);
-    const int hub_slot = (k ? hp.S[0] : 0) + slot;
+    const int env_first = (int) block_local * (WAVES * upp);
     const uint32_t St = (uint32_t) (hp.S[0] + hp.S[1]);
     const bool cp = hp.constant_charging != 0;
     float *wl = lds + wave * kArea;
     uint32_t *wu = (uint32_t *) wl;
 
-    int env[2];
+    int env[2], uiw[2], slot[2];
     bool unit_ok[2], valid[2];
-    uint32_t idx[2], sidx[2], line_in[2], fa_w[2];
+    uint32_t idx[2], sidx[2], fa_w[2];
+    uint64_t m_same[2], m_other[2];  // the unit's lanes in the lane's own virtual wave / in the other one
+    int lead_lane[2], lead_j[2];     // where the unit's first virtual lane sits
     u32x4 hot[2];
     float a[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        env[j] = env_first + (2 * wave + j) * upw + uiw;
-        unit_ok[j] = uiw < upw && env[j] < N && in_group(sa, env[j]);
-        valid[j] = unit_ok[j] && slot < S;
-        idx[j] = (uint32_t) hp.base[k] + (uint32_t) env[j] * (uint32_t) S + (uint32_t) slot;
+        const int v = 64 * j + lane;
+        uiw[j] = (int) (((uint32_t) v * umagic) >> 16);
+        slot[j] = v - uiw[j] * U;
+        const int ua = uiw[j] * U, ub = ua + U;  // the unit's virtual lanes [ua, ub)
+        const bool has = uiw[j] < upp;
+        lead_lane[j] = has ? (ua & 63) : 63;
+        lead_j[j] = ua >> 6;
+        if (j == 0) {  // (ua < 64)
+            const int hi = ub < 64 ? ub : 64;
+            m_same[j] = has ? ((hi == 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << ua) - 1ull)) : 0ull;
+            m_other[j] = (has && ub > 64) ? ((1ull << (ub - 64)) - 1ull) : 0ull;
+        } else {       // (ub > 64)
+            const int lo = ua > 64 ? ua - 64 : 0, hi = ub - 64 < 64 ? ub - 64 : 64;
+            m_same[j] = has ? ((hi == 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull)) : 0ull;
+            m_other[j] = (has && ua < 64) ? (~0ull << ua) : 0ull;
+        }
+        env[j] = env_first + wave * upp + uiw[j];
+        unit_ok[j] = has && env[j] < N && in_group(sa, env[j]);
+        valid[j] = unit_ok[j] && slot[j] < S;
+        idx[j] = (uint32_t) hp.base[k] + (uint32_t) env[j] * (uint32_t) S + (uint32_t) slot[j];
         sidx[j] = (uint32_t) k * (uint32_t) N + (uint32_t) env[j];
-        line_in[j] = 0u;
         hot[j] = u32x4{0u, 0u, 0u, 0u};
         a[j] = 0.0f;
         fa_w[j] = 0u;
-        if (unit_ok[j]) line_in[j] = st.rec[4u * sidx[j] + 3u];
-        if (unit_ok[j] && slot == 0) fa_w[j] = st.fa[sa.tick & 1u][sidx[j]];  // what the walk came to: with the first loads
+        if (unit_ok[j] && slot[j] == 0) fa_w[j] = st.fa[sa.tick & 1u][sidx[j]];  // what the walk came to (flow_in, cars admitted, queue): with the first loads
         if (valid[j]) {
             hot[j] = ((CHUB_G(u32x4)) sl.hot)[idx[j]];
-            a[j] = sa.actions[(uint32_t) env[j] * (uint32_t) hp.act_dim + (uint32_t) hub_slot];
+            a[j] = sa.actions[(uint32_t) env[j] * (uint32_t) hp.act_dim + (uint32_t) ((k ? hp.S[0] : 0) + slot[j])];
         }
     }
     float power[2], t_target[2], t_soc[2];
@@ -842,21 +857,28 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
     int rank[2], line[2], flow[2], assign[2];
     u32x4 vv[2];
     float nc_soc[2];
+    uint64_t be[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         empty[j] = valid[j] && !(car[j] && tl[j] > 1);
-        const uint64_t be = __ballot(empty[j]) & unit_mask;
-        rank[j] = prefix_count(be);
-        int2 fa = make_int2(0, 0);
-        int new_line = pkd_line(line_in[j]);
-        if (unit_ok[j] && slot == 0) {
-            const uint32_t w = fa_w[j];
-            fa = make_int2((int) (int16_t) (w & 0xFFFFu), (int) ((w >> 16) & 255u));
-            new_line = (int) (w >> 24);
+        be[j] = __ballot(empty[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        // rank = the unit's empties in front of this lane: those of its own virtual wave below it, + (second virtual wave of a straddling
+        // unit) all of the unit's empties in the first
+        rank[j] = prefix_count(be[j] & m_same[j]) + (j == 1 ? __popcll(be[0] & m_other[1]) : 0);
+        // the walk's word of the unit (flow_in, cars admitted, queue), from the unit's first virtual lane -- which for a lane's first slot is
+        // in the first virtual wave, for its second slot in either
+        const uint32_t w0 = (uint32_t) __shfl((int) fa_w[0], lead_lane[j]);
+        uint32_t w = w0;
+        if (j == 1) {
+            const uint32_t w1 = (uint32_t) __shfl((int) fa_w[1], lead_lane[j]);
+            w = lead_j[j] ? w1 : w0;
         }
-        flow[j] = __shfl(fa.x, leader);
-        assign[j] = __shfl(fa.y, leader);
-        line[j] = __shfl(new_line, leader);
+        flow[j] = (int) (int16_t) (w & 0xFFFFu);
+        assign[j] = (int) ((w >> 16) & 255u);
+        line[j] = (int) (w >> 24);
         adm[j] = empty[j] && rank[j] < assign[j];
         vv[j] = u32x4{0u, 0u, 0u, 0u};
         nc_soc[j] = 0.0f;
@@ -930,33 +952,36 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
         }
     }
     // ---- calculate_output (CHS.hpp:1233-1261 / 1544-1572): the reference adds slot powers sequentially in f32 (CHS.hpp:1244-1255):
-    // same order, same roundings -- lane 2 * unit + v adds up unit `unit` of virtual wave v
+    // same order, same roundings -- one lane per unit and term adds up the unit's S terms, which lie side by side in the 128 virtual lanes
     float *t_max = wl, *t_min = wl + 128, *t_chg = wl + 256;
-    uint32_t *u_word = wu + 384;  // [v * 8 + unit]: line | flow | cars of the unit (pkd_make)
+    uint32_t *u_word = wu + 384;  // [unit]: line | flow | cars of the unit (pkd_make)
+    {
+        const uint64_t bc0 = __ballot(car[0]), bc1 = __ballot(car[1]);
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const bool urgent = car[j] && must_charge(t_target[j], t_soc[j], tl[j]);
-        t_max[j * 64 + lane] = car[j] ? power[j] : 0.0f;
-        t_min[j * 64 + lane] = urgent ? power[j] : 0.0f;
-        t_chg[j * 64 + lane] = charge[j] ? power[j] : 0.0f;
-        const int cars = __popcll(__ballot(car[j]) & unit_mask);
-        if (unit_ok[j] && slot == 0) u_word[j * 8 + uiw] = pkd_make(line[j], flow[j], cars);
+        for (int j = 0; j < 2; j++) {
+            const bool urgent = car[j] && must_charge(t_target[j], t_soc[j], tl[j]);
+            t_max[j * 64 + lane] = car[j] ? power[j] : 0.0f;
+            t_min[j * 64 + lane] = urgent ? power[j] : 0.0f;
+            t_chg[j * 64 + lane] = charge[j] ? power[j] : 0.0f;
+            const int cars = __popcll((j ? bc1 : bc0) & m_same[j]) + __popcll((j ? bc0 : bc1) & m_other[j]);
+            if (unit_ok[j] && slot[j] == 0) u_word[uiw[j]] = pkd_make(line[j], flow[j], cars);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // (one lane per unit, virtual wave AND term: lane 16 * term + 2 * unit + v -- a loop of S additions instead of 3 S; each lane stores its
-    // own word of the unit's record: min, charge, max power in that order, the first of them the packed word behind)
-    if (lane < 48 && (lane & 15) < 2 * upw) {
-        const int term = lane >> 4, v = lane & 1, un = (lane & 15) >> 1;
-        const int e = env_first + (2 * wave + v) * upw + un;
+    // (one lane per unit AND term: lane 16 * term + unit -- a loop of S additions instead of 3 S; each lane stores its own word of the unit's
+    // record: min, charge, max power in that order, the first of them the packed word behind)
+    if (lane < 48 && (lane & 15) < upp) {
+        const int term = lane >> 4, un = lane & 15;
+        const int e = env_first + wave * upp + un;
         if (e < N && in_group(sa, e)) {
-            const float *t = (term == 0 ? t_min : (term == 1 ? t_chg : t_max)) + v * 64 + un * U;
+            const float *t = (term == 0 ? t_min : (term == 1 ? t_chg : t_max)) + un * U;
             float r = 0.0f;
             for (int i = 0; i < S; i++) r = __fadd_rn(r, t[i]);
             const uint32_t u = (uint32_t) k * (uint32_t) N + (uint32_t) e;
             st.rec[4u * u + (uint32_t) term] = __float_as_uint(r);
-            if (term == 0) st.rec[4u * u + 3u] = u_word[v * 8 + un];
+            if (term == 0) st.rec[4u * u + 3u] = u_word[un];
         }
     }
 #pragma unroll
@@ -970,11 +995,16 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
             ((CHUB_G(u32x4)) sl.hot)[idx[j]] = h2;
             if (adm[j]) sl.init_soc[idx[j]] = nc_soc[j];  // the only cold store: the arrival SoC of a new car
         }
-        // what the next step's walk needs of the slots: a slot is empty after remove_car iff it has at most one slot of stay left
-        const int n_empty = __popcll(__ballot(valid[j] && tl[j] <= 1) & unit_mask), n_empty2 = __popcll(__ballot(valid[j] && tl[j] <= 2) & unit_mask);
-        if (unit_ok[j] && slot == 0) {
-            st.empt[sidx[j]] = (uint8_t) n_empty;
-            st.empt2[sa.tick & 1u][sidx[j]] = (uint8_t) n_empty2;
+    }
+    {   // what the next step's walk needs of the slots: a slot is empty after remove_car iff it has at most one slot of stay left
+        const uint64_t e1[2] = {__ballot(valid[0] && tl[0] <= 1), __ballot(valid[1] && tl[1] <= 1)};
+        const uint64_t e2[2] = {__ballot(valid[0] && tl[0] <= 2), __ballot(valid[1] && tl[1] <= 2)};
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (unit_ok[j] && slot[j] == 0) {  // (the unit's first virtual lane: its own virtual wave's part + the other's)
+                st.empt[sidx[j]] = (uint8_t) (__popcll(e1[j] & m_same[j]) + __popcll(e1[1 - j] & m_other[j]));
+                st.empt2[sa.tick & 1u][sidx[j]] = (uint8_t) (__popcll(e2[j] & m_same[j]) + __popcll(e2[1 - j] & m_other[j]));
+            }
         }
     }
 }
@@ -3712,6 +3742,11 @@ static inline int64_t blocks_for(int64_t n_envs, int H, int block) {
     const int64_t upb = (int64_t) (block / 64) * (64 / H);
     return (n_envs + upb - 1) / upb;
 }
+// slot_body_split2: a wave's units lie end to end over its 128 virtual lanes
+static inline int64_t blocks_for_split2(int64_t n_envs, int U, int block) {
+    const int64_t upb = (int64_t) (block / 64) * (128 / U);
+    return (n_envs + upb - 1) / upb;
+}
 
 // ev0 / ev1 (may be null): kernel start / stop timestamps of the dispatch itself (hipExtLaunchKernelGGL), what
 // chub_profile_* reports -- plain hipEventRecord pairs around a launch also count the gap in front of it
@@ -3737,7 +3772,7 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
         if (walk_now)
             CHUB_LAUNCH((k_compat_walk<RESET>), dim3((unsigned) ((hp.n_envs + 255) / 256)), dim3(256), stream, count_first ? (hipEvent_t) nullptr : ev0, (hipEvent_t) nullptr, ctx, sa);
         if (CHUB_SPLIT2 && !RESET && !sa.load_mode && hp.U[0] >= 8 && hp.U[1] >= 8) {  // two slots per lane (stations of 8 to 64 piles: at most 8 units per virtual wave)
-            const int64_t sb0 = blocks_for(hp.n_envs, hp.U[0], 2 * BLOCK), sb1 = blocks_for(hp.n_envs, hp.U[1], 2 * BLOCK);
+            const int64_t sb0 = blocks_for_split2(hp.n_envs, hp.U[0], BLOCK), sb1 = blocks_for_split2(hp.n_envs, hp.U[1], BLOCK);
             CHUB_LAUNCH((k_slot_split2<BLOCK>), dim3((unsigned) (sb0 + sb1)), dim3(BLOCK), stream, walk_now ? (hipEvent_t) nullptr : ev0, ev1, ctx, sa, sb0);
         } else
             CHUB_LAUNCH((k_slot_split<RESET, BLOCK>), dim3((unsigned) (nb0 + nb1)), dim3(BLOCK), stream, walk_now ? (hipEvent_t) nullptr : ev0, ev1, ctx, sa, nb0);
@@ -3769,7 +3804,7 @@ void launch_slot_walk2(const HubParams &hp, const DevCtx *ctx, const StepArgs &s
     const bool walk_now = !sa.walked;
     if (walk_now)
         CHUB_LAUNCH((k_compat_walk<false>), dim3((unsigned) ((hp.n_envs + 255) / 256)), dim3(256), stream, count_first ? (hipEvent_t) nullptr : ev0, (hipEvent_t) nullptr, ctx, sa);
-    const int64_t sb0 = blocks_for(hp.n_envs, hp.U[0], 2 * BLOCK), sb1 = blocks_for(hp.n_envs, hp.U[1], 2 * BLOCK);
+    const int64_t sb0 = blocks_for_split2(hp.n_envs, hp.U[0], BLOCK), sb1 = blocks_for_split2(hp.n_envs, hp.U[1], BLOCK);
     if (hp.n_envs <= kWalk2HalfMaxEnvs) {
         const int nwalk = (int) ((hp.n_envs + 31) / 32);
         CHUB_LAUNCH((k_slot_walk2<BLOCK, 32>), dim3((unsigned) (nwalk + sb0 + sb1)), dim3(BLOCK), stream, walk_now ? (hipEvent_t) nullptr : ev0, ev1, ctx, sa, sw, sb0, nwalk);

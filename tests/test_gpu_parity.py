@@ -1369,6 +1369,19 @@ def test_compat_split_step_is_bit_identical_through_restores_and_masked_calls():
         for t in range(10):
             o, r, d, _ = v.step(act(), rs.normal(size=(n, 3)))
             note(o, r)
+        # ... and a restore IN PLACE, into a handle that has stepped on: its walks ran ahead of steps that now never come, its
+        # empty-slot counts (empt / empt2) and stream buffers are those of another moment -- the same continuation must come out again
+        snap2 = v.get_state()
+        st_rs = rs.get_state()
+        cont = []
+        for t in range(4):
+            cont.append(v.step(act(), rs.normal(size=(n, 3)))[:2])
+        v.set_state(snap2)
+        rs.set_state(st_rs)
+        for t in range(4):
+            o, r = v.step(act(), rs.normal(size=(n, 3)))[:2]
+            assert np.array_equal(o, cont[t][0], equal_nan=True) and np.array_equal(r, cont[t][1], equal_nan=True), (form, "in-place restore", t)
+            note(o, r)
         mask = (rs.uniform(size=n) < 0.4).astype(np.uint8)
         for t in range(5):
             o, r, d = v.step_envs(mask, act(), rs.normal(size=(n, 3)))[:3]
