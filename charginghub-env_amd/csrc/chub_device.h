@@ -99,10 +99,10 @@ struct SlotArrays {          // index = base_k + env*S_k + slot  (station-major)
     // recorded number of car_steps (k_replay_soc), target SoC from its level; slots without a car read as zeros.
     CHUB_G(float) init_soc;  // arrival SoC (COMPAT)
     CHUB_G(uint8_t) stay8;   // PHILOX [N][S0 + S1]: Station::stay_time of the car in the slot (CHS.hpp:245), written when it is admitted
-    CHUB_G(uint32_t) var[2]; // COMPAT, split step [N][S0 + S1][4], hub-major by admission rank, double-buffered by the parity of the step's tick: the r-th car
+    CHUB_G(uint32_t) var[2]; // COMPAT, split step [N][S0 + S1][8], hub-major by admission rank, double-buffered by the parity of the step's tick: the r-th car
                              // a unit admits in that step AS add_car MAKES IT (CHS.hpp:864-877), evaluated by the stream walk where its variates are drawn
-                             // (compat_walk_env): power, t_target, t_soc (f32 bits), stay | target level << 7 -- the hot record's own words
-    CHUB_G(float) var_soc[2];// ... and its arrival SoC (what the slot pass leaves in init_soc)
+                             // (walk_rounds / compat_walk_env): ONE 32-byte record -- power, t_target, t_soc (f32 bits), stay | target level << 7 (the hot
+                             // record's own words), the arrival SoC (what the slot pass leaves in init_soc), three words of padding
 };
 
 struct StationArrays {       // unit index u = k*N + env

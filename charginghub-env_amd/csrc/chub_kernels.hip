@@ -694,8 +694,8 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     float nc_soc = 0.0f;
     if (adm && SPLIT) {  // the car as the walk made it (compat_walk_env: add_car there, one record per admission rank)
         const uint32_t vi = (uint32_t) env * (uint32_t) (hp.S[0] + hp.S[1]) + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank;
-        const u32x4 vv = ((CHUB_G(const u32x4)) sl.var[sa.tick & 1u])[vi];
-        nc_soc = sl.var_soc[sa.tick & 1u][vi];
+        const u32x4 vv = ((CHUB_G(const u32x4)) sl.var[sa.tick & 1u])[2u * vi];
+        nc_soc = __uint_as_float(sl.var[sa.tick & 1u][8u * vi + 4u]);
         power = __uint_as_float(vv.x);
         t_target = __uint_as_float(vv.y);
         t_soc = __uint_as_float(vv.z);
@@ -884,8 +884,8 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
         nc_soc[j] = 0.0f;
         if (adm[j]) {  // the new car as the walk made it (add_car in compat_walk_env): requested here, picked up behind the curve work
             const uint32_t vi = (uint32_t) env[j] * St + (uint32_t) (k ? hp.S[0] : 0) + (uint32_t) rank[j];
-            vv[j] = ((CHUB_G(const u32x4)) sl.var[sa.tick & 1u])[vi];
-            nc_soc[j] = sl.var_soc[sa.tick & 1u][vi];
+            vv[j] = ((CHUB_G(const u32x4)) sl.var[sa.tick & 1u])[2u * vi];  // (the record's two 16-byte halves share a 32-byte sector)
+            nc_soc[j] = __uint_as_float(sl.var[sa.tick & 1u][8u * vi + 4u]);
         }
     }
     // ---- car_step (CHS.hpp:900-905 / 1065-1070) of both virtual waves' charging cars, packed
@@ -2087,8 +2087,7 @@ __device__ __forceinline__ void compat_walk_env(const DevCtx *__restrict__ ctx, 
         const int as = (new_line + fl) < empties ? (new_line + fl) : empties;
         new_line = new_line + fl - as;
         new_line = new_line < kMaxLine ? new_line : kMaxLine;
-        CHUB_G(u32x4) var = (CHUB_G(u32x4)) ctx->sl.var[par] + ((uint32_t) env * St + (uint32_t) (k ? hp.S[0] : 0));
-        CHUB_G(float) var_soc = ctx->sl.var_soc[par] + ((uint32_t) env * St + (uint32_t) (k ? hp.S[0] : 0));
+        CHUB_G(u32x4) var = (CHUB_G(u32x4)) ctx->sl.var[par] + 2u * ((uint32_t) env * St + (uint32_t) (k ? hp.S[0] : 0));
         int n_short = 0;
         for (int rr = 0; rr < as; rr++) {  // ascending slot order == ascending rank
             const float soc = arrive_soc_from(rs.normal_d(7.0, 3.0));
@@ -2102,8 +2101,8 @@ __device__ __forceinline__ void compat_walk_env(const DevCtx *__restrict__ ctx, 
             NewCar nc;
             if (fast) nc = make_car<0>(soc, lev, soc_to_time<0>(target, cp), late, cp);
             else nc = make_car<1>(soc, lev, soc_to_time<1>(target, cp), late, cp);
-            var[rr] = u32x4{__float_as_uint(nc.power), __float_as_uint(nc.t_target), __float_as_uint(nc.t_soc), (uint32_t) nc.stay | ((uint32_t) lev << 7)};
-            var_soc[rr] = soc;
+            var[2 * rr] = u32x4{__float_as_uint(nc.power), __float_as_uint(nc.t_target), __float_as_uint(nc.t_soc), (uint32_t) nc.stay | ((uint32_t) lev << 7)};
+            var[2 * rr + 1] = u32x4{__float_as_uint(soc), 0u, 0u, 0u};
             // (what a walk two steps ahead needs of this step's admissions: how many of them stay one slot at most)
             n_short += (nc.stay <= 1) ? 1 : 0;
         }
@@ -2165,14 +2164,31 @@ __device__ __forceinline__ void walk_rounds(const DevCtx *__restrict__ ctx, cons
     int rr = 0;
     while (__any(want - rr > 0)) {
         const int rem = want - rr;
-        // ---- phase A, lane = env: raw points of car rr + j of every env that has one, for j = 0, 1, .. while the staging area holds them
-        int base = 0, mine = 0;
-        for (int j = 0;; j++) {
-            const uint64_t m = __ballot(rem > j);
-            const int c = __popcll(m);
-            if (c == 0 || base + c > kWalkCap) break;  // (j = 0 always fits: c <= 64)
-            if (rem > j) {
-                const int i = base + prefix_count(m);
+        // ---- phase A, lane = env: the raw points of the env's next cars -- as many per env as the staging area holds for all (the largest
+        // quota Q with sum over envs of min(cars left, Q) <= kWalkCap), filed ENV BY ENV: lane l's cars at base_l .. base_l + q_l - 1, so
+        // that phase B's neighbouring lanes hold one env's consecutive admission ranks and their records leave as one run of memory
+        int Q = 0;
+        {
+            int total = 0;
+            for (int j = 0;; j++) {
+                const int c = __popcll(__ballot(rem > j));
+                if (c == 0 || total + c > kWalkCap) break;  // (j = 0 always fits: c <= 64)
+                total += c;
+                Q = j + 1;
+            }
+        }
+        const int mine = rem < Q ? (rem > 0 ? rem : 0) : Q;
+        int base_l = mine;  // exclusive prefix sum of `mine` over the lanes (Hillis-Steele over the wave)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(base_l, d);
+            if (lane >= d) base_l += up;
+        }
+        const int base = __shfl(base_l, 63);  // cars staged this round
+        base_l -= mine;
+        for (int j = 0; j < Q; j++) {
+            if (j < mine) {
+                const int i = base_l + j;
                 double yd, r2d;
                 rs.polar_d(yd, r2d);  // the SoC normal's accepted point (mk_soc, CHS.hpp:804-814 / HYD:259)
                 sg.yd[i] = yd;
@@ -2186,9 +2202,7 @@ __device__ __forceinline__ void walk_rounds(const DevCtx *__restrict__ ctx, cons
                     sg.r2f[i] = r2f;
                 }
                 sg.meta[i] = lev | ((uint32_t) lane << 10) | ((uint32_t) (rr + j) << 16);
-                mine = j + 1;
             }
-            base += c;
         }
         wave_sync_lds();
         // ---- phase B, lane = car
@@ -2206,9 +2220,11 @@ __device__ __forceinline__ void walk_rounds(const DevCtx *__restrict__ ctx, cons
                 if (fast) nc = make_car<0>(soc, lev, soc_to_time<0>(target, cp), late, cp);
                 else nc = make_car<1>(soc, lev, soc_to_time<1>(target, cp), late, cp);
                 const uint32_t vi = (env0 + owner) * St + (uint32_t) (k ? hp.S[0] : 0) + rank;
-                ((CHUB_G(u32x4)) ctx->sl.var[par])[vi] =
+                // ONE 32-byte record per new car (the hot record's four words + the arrival SoC): a sector written whole; neighbouring lanes hold
+                // the same env's next admission ranks (the staging area is filled env by env), so a unit's records leave as one run
+                ((CHUB_G(u32x4)) ctx->sl.var[par])[2u * vi] =
                     u32x4{__float_as_uint(nc.power), __float_as_uint(nc.t_target), __float_as_uint(nc.t_soc), (uint32_t) nc.stay | ((uint32_t) lev << 7)};
-                ctx->sl.var_soc[par][vi] = soc;
+                ((CHUB_G(u32x4)) ctx->sl.var[par])[2u * vi + 1u] = u32x4{__float_as_uint(soc), 0u, 0u, 0u};
                 // (what a walk two steps ahead needs of this step's admissions: how many of them stay one slot at most)
                 if (nc.stay <= 1) atomicAdd(&sg.cnt[owner], 1u);
             } else {

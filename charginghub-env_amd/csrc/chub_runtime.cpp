@@ -492,7 +492,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
 
     {   // arena: generous upper bound of everything allocated below (telemetry buffers come later, separately)
         const size_t S_tot = (size_t) (cfg->station_list[0] + cfg->station_list[1]);
-        const size_t per_env = S_tot * (rng_mode == CHUB_RNG_COMPAT ? 64 : 40) + 1024 + (size_t) qcap * 16 +  // (COMPAT: 16 + 4 + 2 * (16 + 4) bytes per slot)
+        const size_t per_env = S_tot * (rng_mode == CHUB_RNG_COMPAT ? 88 : 40) + 1024 + (size_t) qcap * 16 +  // (COMPAT: 16 + 4 + 2 * 32 bytes per slot)
                                (rng_mode == CHUB_RNG_COMPAT ? 102 * 8 + 3 * 33 * 4 + 2 * 4 * (size_t) (1 + hv_max_arrive) + 1024 + 64 : 0);
         const size_t want = (size_t) n_envs * per_env + ((size_t) 8 << 20) +
                             (rng_mode == CHUB_RNG_PHILOX ? 2 * ((size_t) kSocLevels + 2) * (kClsRow * 8 + 4) : 0);
@@ -804,7 +804,6 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     e->sl.init_soc = nullptr;
     e->sl.stay8 = nullptr;
     e->sl.var[0] = e->sl.var[1] = nullptr;
-    e->sl.var_soc[0] = e->sl.var_soc[1] = nullptr;
     e->st.empt = nullptr;
     e->st.fa[0] = e->st.fa[1] = nullptr;
     e->st.empt2[0] = e->st.empt2[1] = e->st.shrt[0] = e->st.shrt[1] = nullptr;
@@ -813,8 +812,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         ALLOC(e->sl.stay8, NS);
     } else {
         ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.init_soc, NS);
-        ALLOC(e->sl.var[0], 4 * NS); ALLOC(e->sl.var[1], 4 * NS);  // the split step's new cars as the walk made them, by admission rank
-        ALLOC(e->sl.var_soc[0], NS); ALLOC(e->sl.var_soc[1], NS);
+        ALLOC(e->sl.var[0], 8 * NS); ALLOC(e->sl.var[1], 8 * NS);  // the split step's new cars as the walk made them: 32 bytes per admission rank
         ALLOC(e->st.empt, 2 * N); ALLOC(e->st.fa[0], 2 * N); ALLOC(e->st.fa[1], 2 * N);
         ALLOC(e->st.empt2[0], 2 * N); ALLOC(e->st.empt2[1], 2 * N); ALLOC(e->st.shrt[0], 2 * N); ALLOC(e->st.shrt[1], 2 * N);
     }
