@@ -30,7 +30,7 @@ def test_traffic_profiles_are_matched_by_build_and_workload():
     """a PMC profile counts as this build's traffic only with the same build id (sources + kernel knobs) and workload"""
     b = _bench()
     profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")))  # the last one: the latest round's final set
-    assert profs and os.path.basename(profs[-1]).startswith("round5_"), "no round-5 traffic profile committed"
+    assert profs and os.path.basename(profs[-1]).startswith("round6_"), "no round-6 traffic profile committed"
     rec = json.load(open(profs[-1]))
     got, src = b.measured_traffic(rec["build_id"], 65536, 65536, [20, 25])
     assert src == os.path.basename(profs[-1]) and abs(got - rec["k_slot"]["traffic_bytes_per_launch"]) < 1.0
@@ -54,7 +54,7 @@ def test_traffic_profiles_are_matched_by_build_and_workload():
 
 def test_committed_bench_line_has_the_contract_fields():
     lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_bench.json")))
-    assert lines and os.path.basename(lines[-1]).startswith("round5_")
+    assert lines and os.path.basename(lines[-1]).startswith("round6_")
     d = json.load(open(lines[-1]))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline", "n_ranks_seen"):
@@ -77,6 +77,13 @@ def test_committed_bench_line_has_the_contract_fields():
     assert d["roofline_c5"]["limited_by"] == "hbm" and d["roofline_c5"]["layout_bytes_per_launch"] == 262144 * (12 * 64 + 48)
     rc = d["roofline_compat"]
     assert rc["bound"] == "hbm" and abs(rc["frac"] - 1941 * 65536 / ((rc["slot_pass_and_next_walks_us"] + rc["tails_us"]) * 1e-6) / 8e12) < 1e-9
+    # round 6: the three readings of the dominant kernel side by side, the rate over ten whole days, COMPAT's counter traffic and end-state digest
+    assert abs(r["frac_of_traffic"] - r["traffic"] / (r["avg_launch_us"] * 1e-6) / 8e12) < 1e-12 and r["frac_of_layout"] < r["frac_of_traffic"] < r["frac"]
+    assert d["day_avg"]["days"] == 10 and abs(d["value_day_avg"] - 65536 / (d["ms_per_step_day_avg"] * 1e-3)) < 1e-6 * d["value_day_avg"]
+    assert abs(d["value_day_avg"] / d["value"] - 1) < 0.05
+    assert rc["traffic_source"] == os.path.basename(lines[-1]).replace("_bench.json", "_pmc_compat.json") and 1.0 < rc["traffic_over_algorithmic"] < 2.5
+    assert len(rc["end_state_digest"]) == 32 and rc["days_stepped"] == 8
+    assert "COMPAT" in d["cpu_baseline"]["sample"]
     assert d["cpu_baseline"]["host_cores"] >= d["cpu_baseline"]["cores"]
     # ... and the rocprofv3 summaries the three fractions can be recomputed from are committed next to the line
     for name in ("_kernel_stats.csv", "_kernel_stats_c5.csv", "_kernel_stats_compat.csv", "_pmc_compat.json", "_pmc_traffic_c5.json"):
