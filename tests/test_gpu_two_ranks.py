@@ -2,8 +2,8 @@
 multi_gpu.NativeShardedHub (libchub's own RCCL leg: the step kernels + ONE grouped ncclSend / ncclRecv of the packed [n_local, D + 2] rows to
 rank 0 per step, chub_step_gather) over a day and a bit; what rank 0 gathers must equal, bit for bit, what ONE process steps over all the envs
 (shards are contiguous ranges of the global env index, the Philox counters carry the global env id: results do not depend on the sharding).
-Also the span issued from C (chub_run_steps) and the overlapped form.  On a one-GPU box RCCL refuses two ranks on one device ("Duplicate
-GPU"), so there the test skips -- the driver's round-end GPU tier and this pool's boxes have one GPU; an 8-GPU node runs it by itself."""
+On a one-GPU box RCCL refuses two ranks on one device ("Duplicate GPU"), so there the two-rank test skips and the SAME rank program runs on a
+world of one -- the driver's round-end GPU tier and this pool's boxes have one GPU; an 8-GPU node runs both by itself."""
 import json
 import os
 import subprocess
@@ -30,7 +30,7 @@ spec = json.loads(os.environ["CHUB_TWO_RANK_SPEC"])
 kw, total, seed, steps, key, out = spec["kw"], spec["total"], spec["seed"], spec["steps"], spec["key"], spec["out"]
 hub = multi_gpu.NativeShardedHub(total, kw, seed=seed)          # Comm() from RANK / WORLD_SIZE / LOCAL_RANK; this rank's shard on its GPU
 sh = hub.shard
-assert hub.world == 2 and hub.comm.world_seen() == 2 and hub.comm.ranks_seen(sh.stream.ptr) == 2
+assert hub.world == spec["world"] and hub.comm.world_seen() == spec["world"] and hub.comm.ranks_seen(sh.stream.ptr) == spec["world"]
 acts = [multi_gpu.DeviceBuffer(hub.n_local * hub.act_dim * 4, sh.device) for _ in range(4)]
 for b, a in enumerate(acts):
     sh.vec.random_actions_device(a.ptr, key, b, sh.stream.ptr)  # keyed by the GLOBAL env index (env_id0 of the shard)
@@ -53,19 +53,16 @@ print("TWO_RANKS_OK", hub.rank)
 '''
 
 
-def test_two_ranks_over_rccl_gather_what_one_process_steps():
+def _ranks_against_one_process(world):
     import charginghub_env_amd as chub
     from charginghub_env_amd import multi_gpu
-    lib = chub.load_library()
-    if lib.chub_device_count() < 2:
-        pytest.skip("one GPU visible: RCCL refuses two ranks on one device; the 2-rank path on CPU: test_sharded_gloo.py, test_launcher_cpu.py")
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "gathered.npy")
-        spec = json.dumps(dict(kw=KW, total=TOTAL, seed=SEED, steps=STEPS, key=KEY, out=out))
+        spec = json.dumps(dict(kw=KW, total=TOTAL, seed=SEED, steps=STEPS, key=KEY, out=out, world=world))
         procs = []
-        for rank in range(2):
-            env = dict(os.environ, CHUB_ROOT=ROOT, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT="29741",
-                       CHUB_RENDEZVOUS_DIR=tmp, CHUB_TWO_RANK_SPEC=spec, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for rank in range(world):
+            env = dict(os.environ, CHUB_ROOT=ROOT, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT="29741", CHUB_RENDEZVOUS_DIR=tmp, CHUB_TWO_RANK_SPEC=spec, HSA_ENABLE_IPC_MODE_LEGACY="0")
             procs.append(subprocess.Popen([sys.executable, "-c", CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
         outs = []
         for p in procs:
@@ -96,3 +93,16 @@ def test_two_ranks_over_rccl_gather_what_one_process_steps():
         assert np.array_equal(got[i], want), ("gathered block of step", i, "differs from the single-process run")
     v.close()
     st.destroy()
+
+
+def test_the_rank_program_on_a_world_of_one():
+    """the same child program with WORLD_SIZE = 1 (what a one-GPU box can run): the rendezvous, the communicator, NativeShardedHub's shard and
+    double-buffered blocks, the in-place gather on the root -- so that the two-rank test below differs from a tested program by its world only"""
+    _ranks_against_one_process(1)
+
+
+def test_two_ranks_over_rccl_gather_what_one_process_steps():
+    import charginghub_env_amd as chub
+    if chub.load_library().chub_device_count() < 2:
+        pytest.skip("one GPU visible: RCCL refuses two ranks on one device; the 2-rank path on CPU: test_sharded_gloo.py, test_launcher_cpu.py")
+    _ranks_against_one_process(2)
