@@ -87,22 +87,20 @@ CHUB_HD int pkd_flow(uint32_t w) { return ((int) (w << 16)) >> 20; }
 CHUB_HD int pkd_cars(uint32_t w) { return (int) (w >> 16); }
 
 struct SlotArrays {          // index = base_k + env*S_k + slot  (station-major)
-    // the hot record, one 16-byte load and one 16-byte store per slot and step:
-    //   .x power     kW at the car's current point of the curve (Station::situation["power"])
-    //   .y t_target  soc_to_time(target)   -- cached, constant over a stay
-    //   .z t_soc     soc_to_time(soc)      -- cached, what car_step and calculate_needed both need
+    // the COMPAT hot record, one 16-byte load and one 16-byte store per slot and step:
+    //   .x power      kW at the car's current point of the curve (Station::situation["power"])
+    //   .y arrive_soc the car's arrival SoC (Station::situation["init_soc"]): its current SoC = this advanced by the recorded number of car_steps
+    //                 (k_replay_soc, on demand).  soc_to_time(target) is NOT kept: it is Tables::ttab[k][level] (checked at create: k_check_ttab)
+    //   .z t_soc      soc_to_time(soc)      -- cached, what car_step and calculate_needed both need
     //   .w bits 0-6 stay_time - already_stay_time (0 = empty), bit 7 charging this step, bits 8-14 stay_time,
     //      bits 15-24 target-SoC level l (target = 80 + 20 * l / 999, CHS.hpp:35-44), bits 25-31 car_steps taken since arrival
     CHUB_G(uint32_t) hot;    // COMPAT [NS][4], station-major; PHILOX [N][S0 + S1]: the 4-byte slot state described in
                              // chub_kernels.hip, hub-major (station 0's piles, then station 1's, like an action row)
-    // cold: written once per arriving car, read only by introspection.  Current SoC = arrival SoC advanced by the
-    // recorded number of car_steps (k_replay_soc), target SoC from its level; slots without a car read as zeros.
-    CHUB_G(float) init_soc;  // arrival SoC (COMPAT)
     CHUB_G(uint8_t) stay8;   // PHILOX [N][S0 + S1]: Station::stay_time of the car in the slot (CHS.hpp:245), written when it is admitted
     CHUB_G(uint32_t) var[2]; // COMPAT, split step [N][S0 + S1][8], hub-major by admission rank, double-buffered by the parity of the step's tick: the r-th car
                              // a unit admits in that step AS add_car MAKES IT (CHS.hpp:864-877), evaluated by the stream walk where its variates are drawn
                              // (walk_rounds / compat_walk_env): ONE 32-byte record -- power, t_target, t_soc (f32 bits), stay | target level << 7 (the hot
-                             // record's own words), the arrival SoC (what the slot pass leaves in init_soc), three words of padding
+                             // record's words x, t_target, z, w), the arrival SoC (what the slot pass puts into the hot record's word y), three words of padding
 };
 
 struct StationArrays {       // unit index u = k*N + env

@@ -476,6 +476,12 @@ __device__ __forceinline__ void car_step_curves(float tt, bool cp, const CurveCo
     }
 }
 
+// COMPAT hot record, word y: the car's ARRIVAL SoC (round 6; until then soc_to_time(target), with the arrival SoC in a cold array of its own whose
+// 4-byte store per new car was a read-modify-write of a whole sector).  soc_to_time(target) is one of 1000 values per station -- the target is
+// level l of uniform_rand(80, 100) -- read from Tables::ttab[k] by the level kept in the record's word; chub_create checks once, on the device, that
+// the table's entries are the bits the device's own soc_to_time gives (k_check_ttab): the table may then stand in for the function.
+__device__ __forceinline__ int hot_level(uint32_t w) { return (int) ((w >> 15) & 1023u); }
+
 // What add_car (CHS.hpp:864-877 / 1029-1042) produces for one admitted slot.
 struct NewCar {
     float soc, t_target, t_soc, power;
@@ -600,10 +606,11 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
         hot = ((CHUB_G(u32x4)) sl.hot)[idx];
         a = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot];
     }
-    float power = __uint_as_float(hot.x), t_target = __uint_as_float(hot.y), t_soc = __uint_as_float(hot.z);
+    float power = __uint_as_float(hot.x), arr_soc = __uint_as_float(hot.y), t_soc = __uint_as_float(hot.z);
     int tl = (int) (hot.w & 127u);
     int meta = (int) (hot.w >> 8);  // all of the meta bits above the flag: stay_time | target level << 7 | car_steps << 17
     bool car = tl > 0, leave = false;
+    float t_target = car ? tb.ttab[k][hot_level(hot.w)] : 0.0f;  // soc_to_time(target) of the car's level (hot_level above)
     int on_override = -1;
     if (!RESET && sa.load_mode)
         on_override = load_mode_on<BLOCK>(hp, sa, st, k, env, unit_ok, valid, slot, car, power,
@@ -622,7 +629,7 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
             car = false;
             leave = true;
             tl = 0;
-            power = t_target = t_soc = 0.0f;
+            power = t_target = t_soc = arr_soc = 0.0f;
             meta = 0;
         }
     }
@@ -746,12 +753,10 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
     if (valid) {
         u32x4 h2;
         h2.x = __float_as_uint(power);
-        h2.y = __float_as_uint(t_target);
+        h2.y = __float_as_uint(adm ? nc_soc : arr_soc);  // the arrival SoC (current SoC and target SoC are derived from it and the word on demand)
         h2.z = __float_as_uint(t_soc);
         h2.w = (uint32_t) tl | (charge ? 128u : 0u) | ((uint32_t) meta << 8);
         ((CHUB_G(u32x4)) sl.hot)[idx] = h2;
-        // the only cold store: the arrival SoC of a new car (current SoC and target SoC are derived on demand)
-        if (adm) sl.init_soc[idx] = nc_soc;
     }
     if (unit_ok && slot == 0) {
         rec_store(st.rec, sidx, r_min, r_chg, r_max, pkd_make(line, flow, cars));
@@ -778,7 +783,7 @@ __device__ __forceinline__ void slot_body_compat(const HubParams &hp, const Step
 // masked steps without the scalar-load mode; everything else keeps slot_body_compat.
 template <int TYPE, int BLOCK>
 __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const StepArgs &sa, const SlotArrays &sl, const StationArrays &st,
-                                                 const CompatRng &cr, const int k, const int64_t block_local, float *lds) {
+                                                 const CompatRng &cr, const Tables &tb, const int k, const int64_t block_local, float *lds) {
     constexpr int WAVES = BLOCK / 64;
     constexpr int kArea = 3 * 128 + 16;  // per wave: three arrays of 128 terms (aliased by the gathering areas) + the units' words
     const int tid = threadIdx.x;
@@ -835,17 +840,19 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
             a[j] = sa.actions[(uint32_t) env[j] * (uint32_t) hp.act_dim + (uint32_t) ((k ? hp.S[0] : 0) + slot[j])];
         }
     }
-    float power[2], t_target[2], t_soc[2];
+    float power[2], t_target[2], t_soc[2], arr_soc[2];
     int tl[2], meta[2];
     bool car[2], leave[2], on[2], charge[2];
+    CHUB_G(const float) ttab_k = tb.ttab[k];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         power[j] = __uint_as_float(hot[j].x);
-        t_target[j] = __uint_as_float(hot[j].y);
+        arr_soc[j] = __uint_as_float(hot[j].y);
         t_soc[j] = __uint_as_float(hot[j].z);
         tl[j] = (int) (hot[j].w & 127u);
         meta[j] = (int) (hot[j].w >> 8);
         car[j] = tl[j] > 0;
+        t_target[j] = car[j] ? ttab_k[hot_level(hot[j].w)] : 0.0f;  // soc_to_time(target) of the car's level (hot_level)
         leave[j] = false;
         // judge_feasibility + assign_on_off_piece (CHS.hpp:1404-1413, 1364-1373); action_to_real (MGR:384-393)
         on[j] = car[j] && (a[j] >= kActOnThreshold || must_charge(t_target[j], t_soc[j], tl[j]));
@@ -931,7 +938,7 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
                 car[j] = false;
                 leave[j] = true;
                 tl[j] = 0;
-                power[j] = t_target[j] = t_soc[j] = 0.0f;
+                power[j] = t_target[j] = t_soc[j] = arr_soc[j] = 0.0f;
                 meta[j] = 0;
             }
         }
@@ -989,11 +996,13 @@ __device__ __forceinline__ void slot_body_split2(const HubParams &hp, const Step
         if (valid[j]) {
             u32x4 h2;
             h2.x = __float_as_uint(power[j]);
-            h2.y = __float_as_uint(t_target[j]);
+            h2.y = __float_as_uint(adm[j] ? nc_soc[j] : arr_soc[j]);  // the arrival SoC
             h2.z = __float_as_uint(t_soc[j]);
             h2.w = (uint32_t) tl[j] | (charge[j] ? 128u : 0u) | ((uint32_t) meta[j] << 8);
+            // (the record goes back whole: storing only the words that changed -- 4 bytes for a car that neither charged, left nor arrived, nothing for
+            // an empty slot -- was measured in round 6: the launch 49.6 -> 59 us, WRITE_SIZE 80 -> 100 MiB, FETCH_SIZE 54 -> 69 MiB: a partly
+            // written sector costs a read-modify-write)
             ((CHUB_G(u32x4)) sl.hot)[idx[j]] = h2;
-            if (adm[j]) sl.init_soc[idx[j]] = nc_soc[j];  // the only cold store: the arrival SoC of a new car
         }
     }
     {   // what the next step's walk needs of the slots: a slot is empty after remove_car iff it has at most one slot of stay left
@@ -1174,16 +1183,17 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
     CHUB_G(const float) cls = tb.cls[k];
 
     // ---- the slot as the previous step left it
-    float power = 0.0f, t_target = 0.0f, t_soc = 0.0f, a = 0.0f, next_power = 0.0f, next_t_soc = 0.0f;
+    float power = 0.0f, t_target = 0.0f, t_soc = 0.0f, arr_soc = 0.0f, a = 0.0f, next_power = 0.0f, next_t_soc = 0.0f;
     int tl = 0, meta = 0;
     uint32_t w0 = 0u;
     if (!RESET && valid) {
         a = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub_slot];
         if (MODE == MODE_COMPAT) {
             const u32x4 hot = ((CHUB_G(u32x4)) sl.hot)[idx];
-            power = __uint_as_float(hot.x); t_target = __uint_as_float(hot.y); t_soc = __uint_as_float(hot.z);
+            power = __uint_as_float(hot.x); arr_soc = __uint_as_float(hot.y); t_soc = __uint_as_float(hot.z);
             tl = (int) (hot.w & 127u);
             meta = (int) (hot.w >> 8);
+            if (tl > 0) t_target = tb.ttab[k][hot_level(hot.w)];  // (hot_level: the record keeps the arrival SoC, the target's time is a table entry)
         } else {
             w0 = sl.hot[idx];
             tl = ps_tl(w0);
@@ -1256,7 +1266,7 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
             tl -= 1;
             if (tl <= 0) {
                 car = false; leave = true; tl = 0;
-                power = t_target = t_soc = 0.0f;
+                power = t_target = t_soc = arr_soc = 0.0f;
                 meta = 0;
             }
         }
@@ -1393,10 +1403,9 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
     if (valid) {
         if (MODE == MODE_COMPAT) {
             u32x4 h2;
-            h2.x = __float_as_uint(power); h2.y = __float_as_uint(t_target); h2.z = __float_as_uint(t_soc);
+            h2.x = __float_as_uint(power); h2.y = __float_as_uint(adm ? nc_soc : arr_soc); h2.z = __float_as_uint(t_soc);
             h2.w = (uint32_t) tl | (charge ? 128u : 0u) | ((uint32_t) meta << 8);
             ((CHUB_G(u32x4)) sl.hot)[idx] = h2;
-            if (adm) sl.init_soc[idx] = nc_soc;
         } else {
             sl.hot[idx] = w0;
         }
@@ -2390,8 +2399,8 @@ __global__ __launch_bounds__(BLOCK, 7) void k_slot_split2(const DevCtx *__restri
     const int k = (bid >= nb0) ? 1 : 0;
     const int64_t bl = k ? bid - nb0 : bid;
     __shared__ float lds[(BLOCK / 64) * (3 * 128 + 16)];
-    if (hp.type[k] == 0) slot_body_split2<0, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, k, bl, lds);
-    else slot_body_split2<1, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, k, bl, lds);
+    if (hp.type[k] == 0) slot_body_split2<0, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds);
+    else slot_body_split2<1, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds);
 }
 
 // The slot pass of step i and the stream walks of step i + 1 in ONE launch: the walk -- one serial chain per env, a wave per SIMD for 20 to
@@ -2426,8 +2435,8 @@ __global__ __launch_bounds__(BLOCK, CHUB_WALK2_OCC) void k_slot_walk2(const DevC
     const int64_t bid = (int64_t) blockIdx.x - nwalk;
     const int k = (bid >= nb0) ? 1 : 0;
     const int64_t bl = k ? bid - nb0 : bid;
-    if (hp.type[k] == 0) slot_body_split2<0, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, k, bl, lds);
-    else slot_body_split2<1, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, k, bl, lds);
+    if (hp.type[k] == 0) slot_body_split2<0, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds);
+    else slot_body_split2<1, BLOCK>(hp, sa, ctx->sl, ctx->st, ctx->cr, ctx->tb, k, bl, lds);
 }
 
 template <bool RESET, int BLOCK>
@@ -3645,7 +3654,7 @@ __global__ void k_random_actions(int64_t n_envs, int64_t env_id0, int act_dim, u
 }
 
 // -------------------------------------------------------------------- introspection: current SoC on demand
-// The step kernels keep, per occupied slot, the arrival SoC (SlotArrays::init_soc) and the number of car_steps taken since
+// The step kernels keep, per occupied slot, the arrival SoC (COMPAT: the hot record's second word; PHILOX: the class) and the number of car_steps taken since
 // (hot.w bits 25-31) instead of storing the SoC every step: the SoC after n steps is the same deterministic chain
 // soc -> soc_to_time -> +1 slot -> time_to_soc the step evaluated (CHS.hpp:900-905 / 1065-1070), replayed here with the
 // same device functions, so the value is bit for bit the one the step produced.
@@ -3671,7 +3680,7 @@ __global__ void k_replay_soc(const DevCtx *__restrict__ ctx, float *out) {
         const uint32_t w = ctx->sl.hot[4 * idx + 3];
         car = (w & 127u) != 0u;
         if (car) {
-            soc = ctx->sl.init_soc[idx];
+            soc = __uint_as_float(ctx->sl.hot[4 * idx + 1]);  // the record's second word: the arrival SoC
             n = (int) (w >> 25);
         }
     }
@@ -4054,6 +4063,21 @@ void launch_keep_clocks(uint16_t *dst, const uint16_t *src, int64_t n, hipStream
 }
 void launch_tick_advance(uint32_t *tick_base, uint32_t by, hipStream_t stream) {
     hipLaunchKernelGGL(k_tick_advance, dim3(1), dim3(1), 0, stream, tick_base, by);
+}
+
+// chub_create, COMPAT handles: every entry of Tables::ttab against the device's own soc_to_time(uniform_level(l, 80, 100)) -- the expression
+// add_car evaluates (make_car's callers) -- bit for bit; *mismatch counts the entries that differ
+__global__ void k_check_ttab(const DevCtx *__restrict__ ctx, uint32_t *mismatch) {
+    const int i = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= 2 * kLevels) return;
+    const int k = i / kLevels, lev = i - k * kLevels;
+    const bool cp = ctx->hp.constant_charging != 0;
+    const float target = uniform_level(lev, 80.0f, 100.0f);
+    const float t = ctx->hp.type[k] == 0 ? soc_to_time<0>(target, cp) : soc_to_time<1>(target, cp);
+    if (__float_as_uint(t) != __float_as_uint(ctx->tb.ttab[k][lev])) atomicAdd(mismatch, 1u);
+}
+void launch_check_ttab(const DevCtx *ctx, uint32_t *d_mismatch, hipStream_t stream) {
+    hipLaunchKernelGGL(k_check_ttab, dim3((2 * kLevels + 255) / 256), dim3(256), 0, stream, ctx, d_mismatch);
 }
 
 void launch_replay_soc(const HubParams &hp, const DevCtx *ctx, float *d_out, hipStream_t stream) {

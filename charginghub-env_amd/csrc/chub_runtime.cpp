@@ -20,6 +20,7 @@ namespace chub {
 void launch_slot(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream,
                  const PackedPtrs &pp, hipEvent_t ev0, hipEvent_t ev1);
 void launch_replay_soc(const HubParams &hp, const DevCtx *ctx, float *d_out, hipStream_t stream);
+void launch_check_ttab(const DevCtx *ctx, uint32_t *d_mismatch, hipStream_t stream);
 void launch_env(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, hipEvent_t ev0,
                 hipEvent_t ev1, const PackedPtrs &pp);
 void launch_random_actions(const HubParams &hp, uint64_t key, uint32_t batch, float *d_actions, hipStream_t stream);
@@ -793,15 +794,14 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
             if ((rc = dev_upload(e, &e->tb.cls_soc0[s], cls_soc0[s]))) return bail(rc);
             e->h_cls[s] = cls[s];
             e->h_soc0[s] = cls_soc0[s];
-            e->h_ttab[s] = ttab[s];
         }
     }
+    for (int s = 0; s < 2; s++) e->h_ttab[s] = ttab[s];  // (both modes: introspection reads a car's target time from its level)
 
     // ---- state in HBM
     const size_t N = (size_t) n_envs, NS = N * (size_t) (hp.S[0] + hp.S[1]);
 #define ALLOC(ptr, count)                                        \
     if ((rc = dev_alloc(e, &(ptr), (count)))) return bail(rc)
-    e->sl.init_soc = nullptr;
     e->sl.stay8 = nullptr;
     e->sl.var[0] = e->sl.var[1] = nullptr;
     e->st.empt = nullptr;
@@ -811,7 +811,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         ALLOC(e->sl.hot, NS);  // 4-byte slot state
         ALLOC(e->sl.stay8, NS);
     } else {
-        ALLOC(e->sl.hot, 4 * NS); ALLOC(e->sl.init_soc, NS);
+        ALLOC(e->sl.hot, 4 * NS);  // the 16-byte hot record: power, arrival SoC, t_soc, word
         ALLOC(e->sl.var[0], 8 * NS); ALLOC(e->sl.var[1], 8 * NS);  // the split step's new cars as the walk made them: 32 bytes per admission rank
         ALLOC(e->st.empt, 2 * N); ALLOC(e->st.fa[0], 2 * N); ALLOC(e->st.fa[1], 2 * N);
         ALLOC(e->st.empt2[0], 2 * N); ALLOC(e->st.empt2[1], 2 * N); ALLOC(e->st.shrt[0], 2 * N); ALLOC(e->st.shrt[1], 2 * N);
@@ -862,6 +862,27 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         if (rc) {
             *out = nullptr;
             return bail(rc);
+        }
+        // the COMPAT hot record keeps a car's target as its LEVEL and reads soc_to_time(target) from Tables::ttab: once per handle the device
+        // evaluates all 2 x 1000 entries itself (the functions the stream walk's add_car uses) and the table must hold exactly those bits
+        uint32_t *d_bad = nullptr, bad = 0u;
+        if ((rc = sync_ctx(e, nullptr))) {
+            *out = nullptr;
+            return bail(rc);
+        }
+        if (hipMalloc((void **) &d_bad, sizeof(uint32_t)) != hipSuccess || hipMemset(d_bad, 0, sizeof(uint32_t)) != hipSuccess) {
+            if (d_bad) (void) hipFree(d_bad);
+            *out = nullptr;
+            return bail(fail(CHUB_ERR_HIP, "hipMalloc failed"));
+        }
+        launch_check_ttab(e->d_ctx, d_bad, nullptr);
+        const hipError_t he = hipMemcpy(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost);
+        (void) hipFree(d_bad);
+        if (he != hipSuccess || bad != 0u) {
+            *out = nullptr;
+            return bail(fail(he != hipSuccess ? CHUB_ERR_HIP : CHUB_ERR_UNSUPPORTED,
+                             he != hipSuccess ? "the target-time table could not be checked on the device"
+                                              : "the device's soc_to_time differs from the host-built table of target times"));
         }
     }
     *out = e;
@@ -1191,6 +1212,7 @@ int chub_run_steps(chub_env *e, chub_comm *comm, const float *const *d_action_ba
         if (!comm) {
             int64_t k = first_step + n_steps - i;
             k = k < 96 - i % 96 ? k : 96 - i % 96;
+            k = k < 96 - e->t ? k : 96 - e->t;  // (the handle's own clock need not be i % 96: a caller may step on past `done` -- the span ends where the clock wraps)
             if (e->span_steps > 1 && k > e->span_steps) k = e->span_steps;
             if (k >= 2 && span_ok(e, n_batches)) {
                 if ((rc = run_span(e, d_action_batches, n_batches, d_packed2, i, (int) k, (hipStream_t) stream))) return rc;
@@ -2148,7 +2170,7 @@ int chub_get_slots(chub_env *e, float *out) {
     const HubParams &hp = e->hp;
     const size_t N = (size_t) hp.n_envs, S = (size_t) (hp.S[0] + hp.S[1]), NS = N * S;
     const bool philox = hp.rng_mode == CHUB_RNG_PHILOX;
-    std::vector<float> soc, init_soc;
+    std::vector<float> soc;
     const std::vector<float> *cls = e->h_cls, *soc0 = e->h_soc0, *ttab = e->h_ttab;
     std::vector<uint32_t> hot;
     int rc;
@@ -2163,7 +2185,6 @@ int chub_get_slots(chub_env *e, float *out) {
     }
     std::vector<uint8_t> stay8;
     if ((rc = fetch(hot, (const uint32_t *) e->sl.hot, (philox ? 1 : 4) * NS))) return rc;
-    if (!philox && (rc = fetch(init_soc, (const float *) e->sl.init_soc, NS))) return rc;
     if (philox && (rc = fetch(stay8, (const uint8_t *) e->sl.stay8, NS))) return rc;
     for (size_t env = 0; env < N; env++) {
         float *o = out + env * 9 * S;
@@ -2184,11 +2205,11 @@ int chub_get_slots(chub_env *e, float *out) {
                     }
                 } else {
                     memcpy(&power, &hot[4 * idx + 0], 4);
-                    memcpy(&t_target, &hot[4 * idx + 1], 4);
+                    memcpy(&arrive, &hot[4 * idx + 1], 4);  // (the record keeps the arrival SoC; the target's time is the level's table entry)
                     memcpy(&t_soc, &hot[4 * idx + 2], 4);
                     const uint32_t w = hot[4 * idx + 3];
                     left = (int) (w & 127u); chg = (w & 128u) != 0; stay = (int) ((w >> 8) & 127u); lev = (int) ((w >> 15) & 1023u);
-                    arrive = init_soc[idx];
+                    if (left > 0) t_target = ttab[k][(size_t) lev];
                 }
                 const bool car = left > 0;
                 const float tr = (float) lev / 999.0f;

@@ -274,7 +274,11 @@ int chub_step_gather(chub_env *env, chub_comm *comm, const float *d_actions, flo
 /* A run of n_steps steps issued from C, starting at step index first_step: before every step whose index is a multiple of 96 a
  * chub_reset_device (into d_reset_obs), then chub_step_gather (comm != NULL; d_gathered2 may be NULL off rank 0) or
  * chub_step_device_packed, with actions d_action_batches[i % n_batches] and outputs d_packed2[i & 1] / d_gathered2[i & 1].  Exactly
- * the calls a host loop would make (PHILOX handles); returns after enqueueing. */
+ * the RESULTS of the calls a host loop would make (PHILOX handles); returns after enqueueing.  Without a communicator, on a handle that
+ * runs the one-launch step (chub_uses_fused_step: small batches) and with at most 8 action batches, consecutive lock-step steps go out as
+ * ONE launch per span (k_steps_fused; chub_options.span_steps) -- a span ends where the call does, at a reset and where the handle's clock
+ * wraps; only the span's last two packed blocks exist afterwards, as after the same steps issued one by one.  Not under the per-kernel
+ * profiler, with telemetry on, with a tape loaded or on per-env clocks: every step is then a launch of its own. */
 int chub_run_steps(chub_env *env, chub_comm *comm, const float *const *d_action_batches, int n_batches, float *const *d_packed2,
                    float *const *d_gathered2, float *d_reset_obs, int64_t first_step, int64_t n_steps, void *stream);
 

@@ -1475,6 +1475,8 @@ def test_spans_of_steps_in_one_launch_are_bit_identical(label):
         note()
         run(288 + 96, 40)  # (a multiple of 96: everybody is reset, one clock again, spans again)
         note()
+        run(5, 80)  # first_step need not be the handle's clock (the caller may step on past `done`, MGR:271-299): the handle stands at slot 40, the
+        note()      # span ends where ITS clock wraps (after 56 steps), the remaining 24 steps follow in the next day without a reset
         trace += [np.concatenate([x.reshape(n, -1) for x in v.slots()], axis=1), v.station_scalars().reshape(n, -1), v.env_clocks(ticks=True)[0],
                   v.env_clocks(ticks=True)[1]]
         res[form] = trace
