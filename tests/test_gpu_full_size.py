@@ -107,6 +107,22 @@ def test_compat_launch_forms_are_bit_identical_at_bench_size(n):
             assert np.array_equal(a, b, equal_nan=True), (form, "end state array", k)
 
 
+@pytest.mark.parametrize("piles,types", [((24, 9), ("fast", "slow")), ((13, 8), ("slow", "fast")), ((64, 64), ("fast", "slow")), ((32, 32), ("slow", "slow")),
+                                         ((8, 25), ("fast", "fast")), ((63, 10), ("slow", "fast")), ((25, 20), ("fast", "slow"))])
+def test_compat_launch_forms_are_bit_identical_on_awkward_station_sizes(piles, types):
+    """the two-slots-per-lane pass lays a wave's units end to end over its 128 virtual lanes (floor(128 / S) units per wave, one of them may
+    straddle the two virtual waves) and the walk files its cars env by env: where the boundaries fall depends on the pile count.  The same
+    program as above at 777 envs (the last wave of each station partly filled) on station sizes of 8 .. 64 piles, both kinds in both places."""
+    kw = dict(HUB_KW, station_list=list(piles), station_type_list=list(types), fcev_permeate=0.03)
+    ref_calls, ref_end = compat_program(777, "wave", seed=77, kw=kw)
+    for form in ("packed", "packed_own_walks"):
+        calls, end = compat_program(777, form, seed=77, kw=kw)
+        first = [k for k, (a, b) in enumerate(zip(ref_calls, calls)) if a != b]
+        assert len(calls) == len(ref_calls) and not first, (piles, form, "first differing call", first[0])
+        for k, (a, b) in enumerate(zip(ref_end, end)):
+            assert np.array_equal(a, b, equal_nan=True), (piles, form, "end state array", k)
+
+
 def philox_program(n, kw, seed, **opts):
     """a day and a bit on the device-pointer path (resets at the episode boundaries), six steps as a graph replay, a masked reset and
     masked steps -> (per-sample digests, end state arrays)"""
