@@ -2413,9 +2413,9 @@ __global__ __launch_bounds__(BLOCK, 7) void k_slot_split2(const DevCtx *__restri
 // at raised priority; the others: slot_body_split2.
 // Envs per walk workgroup of k_slot_walk2 (one wave walks them): 64, or -- batches of at most kWalk2HalfMaxEnvs envs -- 32: twice the walking
 // waves, each with half the cars to evaluate (all 64 lanes still evaluate).  A small batch's launch lasts as long as its longest walk
-// (4096 envs: 27.0 -> 22.3 us, 16 384: 31.1 -> 26.8); a large one is bound by instruction issue, where the second set of serial phases costs
-// more than the shorter chain gives (65 536 envs: 54.6 -> 59.1 us).
-constexpr int64_t kWalk2HalfMaxEnvs = 24576;
+// (4096 envs: 27.0 -> 22.3 us, 16 384: 31.1 -> 26.8, 32 768: 37.7 -> 33.2, 40 000: 40.4 -> 39.7); a large one is bound by instruction issue,
+// where the second set of serial phases costs more than the shorter chain gives (65 536 envs: 54.6 -> 59.1 us).
+constexpr int64_t kWalk2HalfMaxEnvs = 40000;
 #ifndef CHUB_WALK2_OCC
 #define CHUB_WALK2_OCC 7  // workgroups per CU of k_slot_walk2 (sets its register budget: 72 VGPRs at 7, 80 at 6, 96 at 5)
 #endif
