@@ -24,7 +24,7 @@ T = {name: i for i, name in enumerate(TELEMETRY_NAMES)}
 
 class ChubOptions(C.Structure):
     """chub_options of include/chub.h (all zero = defaults; the library reads no environment variables)"""
-    _fields_ = [("slot_kernel", C.c_int32), ("no_arena", C.c_int32), ("fused_step", C.c_int32), ("tile", C.c_int32), ("walk_ahead", C.c_int32), ("work_order", C.c_int32), ("span_steps", C.c_int32), ("reserved", C.c_int32 * 1)]
+    _fields_ = [("slot_kernel", C.c_int32), ("no_arena", C.c_int32), ("fused_step", C.c_int32), ("tile", C.c_int32), ("walk_ahead", C.c_int32), ("work_order", C.c_int32), ("span_steps", C.c_int32), ("span_tails", C.c_int32)]
 
 
 SLOT_KERNELS = {"auto": 0, "wave": 1, "packed": 2}

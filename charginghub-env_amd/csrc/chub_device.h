@@ -61,6 +61,10 @@ constexpr int kClsRow = 32;        // PHILOX: entries (power, t_soc) per arrival
 constexpr int kTelemCount = 38;
 constexpr int kCompatSmallBlock = 512;  // k_compat_small: wave 0 walks the envs' streams, ...
 constexpr int kCompatSmallWaves0 = 3, kCompatSmallWaves1 = 4;  // ... these many waves hold station 0's / station 1's units
+constexpr int kPipedMaxBlocks = 256;   // chub_run_steps's spans with the tails on a wave of their own, a step behind (k_steps_piped), up to this many workgroups --
+                                       // one per CU: the slot waves then have nobody else's tails to overlap with.  us per step, tails on their own wave vs on
+                                       // the last slot wave: 128 workgroups 4.93 vs 6.13; 192: 4.99 vs 6.12; 256: 5.00 vs 6.18 / 4.85 vs 6.40; 373: 9.40 vs 7.47;
+                                       // 384: 9.73 vs 7.25 (two workgroups per CU already run one's tails beside the other's slot phases)
 constexpr int kFusedMaxBlocks = 384;   // PHILOX lock-step steps of at most this many slot workgroups run as ONE launch (k_step_fused).  Measured, us per step
                                        // as graph replays, one launch vs two: 8.08 vs 8.82 at 128 workgroups (C2), 8.50 vs 9.30 at 256, 9.42 vs 9.79 at 373,
                                        // 10.79 vs 10.61 at 745, 11.71 vs 11.38 at 1024, 17.9 vs 13.1 at 1490

@@ -2557,6 +2557,8 @@ __device__ __forceinline__ void tail_prefetch(TailIn &in, const TailArgs &ta, co
 // first half runs while the workgroup's first wave is still busy with the new cars.
 struct NoMid {
     __device__ __forceinline__ void operator()() {}
+    __device__ __forceinline__ void at1() {}  // (two more places every lane with an env passes: k_steps_piped's tail wave meets the slot waves there)
+    __device__ __forceinline__ void at2() {}
 };
 // EB: lanes of the workgroup that calls it (k_env: kEnvBlock; k_compat_small: its 512)
 // TAPE (the parity instrument of include/chub.h, PHILOX handles): the tail's variates come from the caller -- the exogenous normals
@@ -2750,7 +2752,14 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float *dst = sa.obs + (size_t) env0_fused * (size_t) row_w;
             const int total = rows_fused * row_w;
-            for (int i = (int) (threadIdx.x & 63u); i < total; i += 64) dst[i] = s_out[i];
+            if ((((uintptr_t) dst) & 15u) == 0) {  // 16 bytes per lane and store: the wave's last dependent LDS round trips, a quarter as many
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const int quads = total >> 2;
+                for (int i = (int) (threadIdx.x & 63u); i < quads; i += 64) ((f32x4 *) dst)[i] = ((const f32x4 *) s_out)[i];
+                for (int i = (quads << 2) + (int) (threadIdx.x & 63u); i < total; i += 64) dst[i] = s_out[i];
+            } else {
+                for (int i = (int) (threadIdx.x & 63u); i < total; i += 64) dst[i] = s_out[i];
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // s_out is reused by the wave's next group of envs
             return;
@@ -2934,6 +2943,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         }
         total_mass_need = total_mass;
     }
+    mid.at1();
 
     // ---- make_state (MGR:344-361), the exogenous update for the NEXT slot: it looks at neither records nor actions, so it sits in
     // the first half (same operations in the same order as when it followed the reward: every chain is its own)
@@ -3023,6 +3033,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
         store_soc = div_c(cap, cap_mass, hp.rc_cap_mass);
         const double all_power_second = ele_power + cpr_power;
         const bool gen_hy = flow > 0.5;  // MGR:161,173-179
+        mid.at2();
         // ---- renewable netting (MGR:183-213)
         double hydrogen_power = all_power_second;
         double ev_power_sum = charging_power;
@@ -3415,6 +3426,8 @@ __device__ __forceinline__ void step_fused_body(const DevCtx *__restrict__ ctx, 
         const uint32_t *s_unit;
         u32x4 *s_rec;
         bool first;  // the first group of envs: the barrier and the records are still ahead
+        __device__ __forceinline__ void at1() {}
+        __device__ __forceinline__ void at2() {}
         __device__ __forceinline__ void operator()() {
             if (!first) return;
             __syncthreads();
@@ -3521,6 +3534,179 @@ __global__ __launch_bounds__(BLOCK, 2) void k_steps_fused(const DevCtx *__restri
         ta.wd_row_now = sp.wdT + t * 150;
         ta.sin_t = sp.sin96[t_next];
         step_fused_body<BLOCK, T, false, false>(ctx, sa, pa, ta);
+    }
+}
+
+// ---- The same span with the TAILS A STEP BEHIND, on a wave of their own (k_steps_piped; stations of 4 piles and more: at most 64 envs per
+// workgroup).  In k_steps_fused a step is two chains end to end -- the slot phases (three dependent round trips, four barriers: ~3.5 us) and then,
+// on the last wave alone, the tails (~600 dependent f64 operations, a wave64 f64 operation every 8 cycles: ~3 us) -- and neither waits for the
+// other's RESULT: the slot phases of step s + 1 read slot words, decoded draws and action rows, none of which the tails of step s write
+// (level_block takes the queue length from the record pass, not from the tail).  So the workgroup gets a fifth wave that runs the tails of step
+// s - 1 while the four slot waves run step s: the last slot wave writes the station records (two LDS buffers, by step parity) behind the
+// step's fourth barrier, the tail wave reads them a step later, keeps the table rows and the output rows in LDS areas nobody else touches,
+// and after the slot waves' last step runs the last tails alone.  gfx950 has one barrier per workgroup, so the tail wave takes part in the
+// slot waves' five barriers per step: at its start, in the middle of the forecourt half, between the halves, behind the hydrogen step and at its
+// end (Mid::at) -- five pieces of the tail against the five phases of the slot step, each side waiting where the other is slower.
+// Same functions, same Philox counters, same operations per env: bit-identical to steps issued one by one (tests).
+struct PipedMid {
+    __device__ __forceinline__ void at1() { __syncthreads(); }
+    __device__ __forceinline__ void at2() { __syncthreads(); }
+    __device__ __forceinline__ void operator()() { __syncthreads(); }
+};
+__device__ __forceinline__ void span_args(const StepArgs &sa0, const PackedArgs &pa0, const TailArgs &ta0, const SpanArgs &sp, const int s,
+                                          StepArgs &sa, PackedArgs &pa, TailArgs &ta) {
+    sa = sa0;
+    pa = pa0;
+    ta = ta0;
+    const uint32_t i = sp.first + (uint32_t) s;
+    const int t = sa0.t + s, t_next = (t + 1) % 96;
+    sa.t = t;
+    sa.tick = sa0.tick + (uint32_t) s;
+    sa.draw_price = ((sp.pc0 + s) % 4 == 0) ? 1 : 0;
+    sa.price_last = sp.price[t];               // AGG:147
+    sa.price_prev = sp.price[(t + 95) % 96];
+    const uint32_t b = i % (uint32_t) sp.n_batches;
+    const float *act = sp.actions[0];
+#pragma unroll
+    for (int j = 1; j < 8; j++) act = b == (uint32_t) j ? sp.actions[j] : act;
+    float *out = (i & 1u) ? sp.packed[1] : sp.packed[0];
+    sa.actions = act;
+    sa.obs = out;
+    sa.reward = out + sp.D;
+    sa.done_f32 = out + sp.D + 1;
+    if (s) sa.fresh = 0;  // (the previous step of this launch left this step's draws)
+    const bool odd = (sa.tick & 1u) != 0u;
+    pa.pk = odd ? sp.pk[1] : sp.pk[0];
+    pa.actions = (CHUB_G(const float)) act;
+    pa.tick = sa.tick;
+    ta.drw = odd ? sp.drw[1] : sp.drw[0];
+    ta.drw_cnt = odd ? sp.drw_cnt[1] : sp.drw_cnt[0];
+    ta.actions = (CHUB_G(const float)) act;
+    ta.pv_row = sp.pvT + t_next * 100;
+    ta.wd_row = sp.wdT + t_next * 150;
+    ta.pv_row_now = sp.pvT + t * 100;
+    ta.wd_row_now = sp.wdT + t * 150;
+    ta.sin_t = sp.sin96[t_next];
+}
+template <int BLOCK, int T>
+__global__ __launch_bounds__(BLOCK + 64, 2) void k_steps_piped(const DevCtx *__restrict__ ctx, StepArgs sa0, PackedArgs pa0, TailArgs ta0, SpanArgs sp) {
+    constexpr int WAVES = BLOCK / 64;
+    __shared__ uint32_t q_new[BLOCK * T];
+    __shared__ uint32_t q_cnt[2];
+    __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];
+    __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T * kAccCopies];
+    __shared__ uint32_t s_unit[BLOCK * T / 2];
+    __shared__ uint32_t s_uinfo[BLOCK * T / 2];
+    __shared__ __attribute__((aligned(16))) u32x4 s_rec2[2][BLOCK * T / 2];  // the station records of a step, by step parity: written in step s, read by the tails in step s + 1
+    __shared__ double s_pv[100], s_wd[150], s_pv_now[100], s_wd_now[150], s_hy[102];  // the tail wave's
+    __shared__ __attribute__((aligned(16))) float s_out[64 * 16];                      // ... and its output rows
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int n = sp.n_steps;
+    if (wave < WAVES) {
+        // ---- the slot waves: step s = the packed slot body up to its third barrier (#1 #2 #3), the fourth (#4), then next step's draws (waves 0, 1)
+        // and this step's station records (the last slot wave); the fifth barrier (#5) in front of the next step
+        for (int s = 0; s < n; s++) {
+            if (s) __syncthreads();
+            StepArgs sa;
+            PackedArgs pa;
+            TailArgs ta;
+            span_args(sa0, pa0, ta0, sp, s, sa, pa, ta);
+            asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
+                              "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
+            NoHook hook;
+            const int role = slot_body_packed<BLOCK, T, false, false, false, false, true, NoHook, false>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
+                                                                                                          s_ball + 1, s_acc, s_unit, hook, nullptr, s_uinfo);
+            __syncthreads();
+            const int lane = threadIdx.x & 63;
+            const int epb = (int) pa.epb, N = (int) pa.n_envs, env_first = (int) blockIdx.x * epb;
+            if (role == 1) {
+                for (int i = lane; i < 2 * epb; i += 64) {
+                    const int e = i >> 1, k = i & 1, env = env_first + e;
+                    if (env >= N) continue;
+                    int line;
+                    if ((k ? pa.S[1] : pa.S[0]) == 0u) {  // a station without piles: its queue moves on as in the record pass
+                        const int want = dk_want(pa.pk[(uint32_t) (k ? N : 0) + (uint32_t) env]);
+                        line = want < kMaxLine ? want : kMaxLine;
+                    } else {
+                        line = pkd_line(s_unit[i]);
+                    }
+                    level_block<false, false>(ctx, sa, (int64_t) k * N + env, line);
+                }
+            } else if (role == 2) {
+                for (int i = lane; i < epb; i += 64)
+                    if (env_first + i < N) level_block<false, false>(ctx, sa, 2 * (int64_t) N + env_first + i);
+            } else if (role == WAVES) {
+                packed_records<BLOCK, T, false, false, false, true, false>(pa, blockIdx.x, s_acc, s_unit, s_rec2[s & 1]);
+            }
+        }
+        return;  // (a wave that has ended no longer counts at the workgroup's barrier: the tail wave runs the last step's tails by itself)
+    }
+    // ---- the tail wave: during step s the tails of step s - 1
+    for (int s = 0; s <= n; s++) {
+        if (s == 0) {  // nothing to do during the first step: its four barriers
+            __syncthreads();
+            __syncthreads();
+            __syncthreads();
+            __syncthreads();
+        } else {
+            StepArgs sa;
+            PackedArgs pa;
+            TailArgs ta;
+            span_args(sa0, pa0, ta0, sp, s - 1, sa, pa, ta);
+            const int lane = threadIdx.x & 63;
+            const int epb = (int) pa.epb, N = (int) pa.n_envs, env_first = (int) blockIdx.x * epb;
+            const int env = env_first + lane;
+            const bool live = lane < epb && env < N;
+            TailIn tin = TailIn();
+            if (live) tail_prefetch(tin, ta, (uint32_t) env, sa.fresh == 0);
+            double r_pv[2], r_pvn[2], r_wd[3], r_wdn[3], r_hy[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int i = lane + 64 * q;
+                r_pv[q] = r_pvn[q] = r_hy[q] = 0.0;
+                if (i < 100) {
+                    r_pv[q] = ta.pv_row[i];
+                    r_pvn[q] = ta.pv_row_now[i];
+                }
+                if (i < 102 && s == 1) r_hy[q] = ta.hy_table[i];  // (the hydrogen table does not change: parked once)
+            }
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int i = lane + 64 * q;
+                r_wd[q] = r_wdn[q] = 0.0;
+                if (i < 150) {
+                    r_wd[q] = ta.wd_row[i];
+                    r_wdn[q] = ta.wd_row_now[i];
+                }
+            }
+            __syncthreads();  // #1
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int i = lane + 64 * q;
+                if (i < 100) {
+                    s_pv[i] = r_pv[q];
+                    s_pv_now[i] = r_pvn[q];
+                }
+                if (i < 102 && s == 1) s_hy[i] = r_hy[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int i = lane + 64 * q;
+                if (i < 150) {
+                    s_wd[i] = r_wd[q];
+                    s_wd_now[i] = r_wdn[q];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the wave's own LDS rows, read back by other lanes of it)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int rows = epb < 64 ? epb : 64;
+            rows = N - env_first < rows ? N - env_first : rows;
+            PipedMid mid;  // #2 (at<1>), #3 (between the halves), #4 (at<2>)
+            env_tail<false, MODE_PHILOX, false, true, PipedMid, kEnvBlock, false>(ctx, sa, env, live, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, nullptr, s_out, 0, ta,
+                                                                                  s_rec2[(s - 1) & 1], live ? lane : 0, env_first, rows > 0 ? rows : 0, tin, true, mid);
+        }
+        __syncthreads();  // #5 (behind the slot waves' last step: alone)
     }
 }
 
@@ -3949,7 +4135,7 @@ void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &s
 // COMPAT lock-step reset / step of a handle whose envs all fit one workgroup (the caller has checked): one launch
 // a span of n_steps lock-step steps from `sa` (the span's first step) in one launch: chub_run_steps, PHILOX handles on the one-launch step
 void launch_steps_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp, int n_steps, int pc0,
-                        int64_t first, const float *const *batches, int n_batches, float *const *packed2) {
+                        int64_t first, const float *const *batches, int n_batches, float *const *packed2, bool piped) {
     if (sa.fresh) hipLaunchKernelGGL(k_draw_levels, dim3((unsigned) ((2 * ((int64_t) sa.env_hi - sa.env_lo + 1) + 255) / 256)), dim3(256), 0, stream, ctx, sa);
     const PackedArgs pa = make_packed_args(hp, sa, pp);
     TailArgs ta = make_tail_args(*pp.ev, *pp.st, hp, sa, pp, false);
@@ -3973,7 +4159,10 @@ void launch_steps_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &
     sp.wdT = (CHUB_G(const double)) pp.tb->wdT;
     sp.sin96 = (CHUB_G(const double)) pp.tb->sin96;
     const uint32_t nb = (uint32_t) ((hp.n_envs + hp.epb - 1) / hp.epb);
-    hipLaunchKernelGGL((k_steps_fused<kPackedBlock, kSlotsPerLane>), dim3(nb), dim3(kPackedBlock), 0, stream, ctx, sa, pa, ta, sp);
+    if (piped)  // (the caller has checked: at most 64 envs per workgroup -- the tail wave's lanes are the workgroup's envs)
+        hipLaunchKernelGGL((k_steps_piped<kPackedBlock, kSlotsPerLane>), dim3(nb), dim3(kPackedBlock + 64), 0, stream, ctx, sa, pa, ta, sp);
+    else
+        hipLaunchKernelGGL((k_steps_fused<kPackedBlock, kSlotsPerLane>), dim3(nb), dim3(kPackedBlock), 0, stream, ctx, sa, pa, ta, sp);
 }
 
 void launch_compat_small(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp) {

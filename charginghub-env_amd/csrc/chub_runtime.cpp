@@ -33,7 +33,7 @@ void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &s
                        hipEvent_t ev1);
 void launch_compat_small(bool reset, const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp);
 void launch_steps_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, hipStream_t stream, const PackedPtrs &pp, int n_steps, int pc0,
-                        int64_t first, const float *const *batches, int n_batches, float *const *packed2);
+                        int64_t first, const float *const *batches, int n_batches, float *const *packed2, bool piped);
 bool slot_walk2_covers(const HubParams &hp);
 void launch_slot_walk2(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, const StepArgs &sw, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 void launch_env_walk(const HubParams &hp, const DevCtx *ctx, const StepArgs &sa, const StepArgs &sw, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
@@ -68,6 +68,7 @@ struct chub_env {
     Tables tb;
     int device;
     bool fused;         // PHILOX lock-step steps of this handle run as ONE launch (k_step_fused): small batches
+    bool span_piped = false;     // ... with the tails on a wave of their own, a step behind (k_steps_piped; chub_options.span_tails)
     int span_steps = 0;          // chub_options.span_steps: chub_run_steps's spans of steps in one launch (0: up to a day's rest; 1: never; n: at most n)
     bool no_walk_ahead = false;  // chub_options.walk_ahead = 1: the split COMPAT step never walks ahead (A/B, parity cross-check)
     int rng_cur = 0;           // COMPAT: which of CompatRng's three buffers holds the committed streams (moved on by every commit: chub_device.h)
@@ -396,6 +397,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if (opt.walk_ahead < 0 || opt.walk_ahead > 1) return fail(CHUB_ERR_ARG, "chub_options.walk_ahead must be 0 or 1");
     if (opt.work_order < 0 || opt.work_order > 1) return fail(CHUB_ERR_ARG, "chub_options.work_order must be 0 or 1");
     if (opt.span_steps < 0 || opt.span_steps > 96) return fail(CHUB_ERR_ARG, "chub_options.span_steps must be 0 .. 96");
+    if (opt.span_tails < 0 || opt.span_tails > 2) return fail(CHUB_ERR_ARG, "chub_options.span_tails must be 0 (by size), 1 (on the last slot wave) or 2 (on a wave of their own)");
     *out = nullptr;
     if (n_envs <= 0) return fail(CHUB_ERR_ARG, "n_envs must be positive");
     if (n_envs * (int64_t) (cfg->station_list[0] + cfg->station_list[1] + 2) >= (int64_t) 1 << 31)
@@ -745,6 +747,12 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         if (opt.fused_step == 2 && !can)
             return bail(fail(CHUB_ERR_UNSUPPORTED, "fused_step = 2: the single-launch step covers PHILOX handles on the packed slot kernel with "
                                                    "stations of at most 64 piles"));
+        // chub_run_steps's spans: the tails on a wave of their own, a step behind the slot waves (k_steps_piped) -- its 64 lanes are the workgroup's envs
+        const bool can_pipe = e->fused && hp.epb <= 64;
+        e->span_piped = can_pipe && (opt.span_tails == 2 || (opt.span_tails == 0 && nb <= kPipedMaxBlocks));
+        if (opt.span_tails == 2 && !can_pipe)
+            return bail(fail(CHUB_ERR_UNSUPPORTED, "span_tails = 2: the tail wave of a span covers handles on the one-launch step (fused_step) with at most 64 envs "
+                                                   "per workgroup (hubs of 8 piles and more)"));
     }
     {   // the reference-exact mode at a handful of envs (the drop-in class: one): both station passes and the tail in one launch
         const int64_t fit = std::min<int64_t>(64, std::min<int64_t>(kCompatSmallWaves0 * (64 / hp.U[0]), kCompatSmallWaves1 * (64 / hp.U[1])));
@@ -1187,7 +1195,7 @@ static int run_span(chub_env *e, const float *const *batches, int n_batches, flo
 #endif
     int rc = sync_ctx(e, s);
     if (rc) return rc;
-    launch_steps_fused(e->hp, e->d_ctx, sa, s, packed_ptrs(e), k, e->price_count, first, batches, n_batches, packed2);
+    launch_steps_fused(e->hp, e->d_ctx, sa, s, packed_ptrs(e), k, e->price_count, first, batches, n_batches, packed2, e->span_piped);
     HIP_TRY(hipGetLastError());
     e->tick += (uint32_t) k;
     if (e->capturing) e->cap_full_rel = e->tick - e->graph_tick0;  // (note_served: which launch of the capture served every env last)

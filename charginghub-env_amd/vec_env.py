@@ -47,7 +47,7 @@ def _ptr(a):
 class VecChargingHub(object):
     def __init__(self, n_envs, station_list, station_type_list, seed=0, rng="philox", device=0, env_id0=0,
                  data_dir=None, slot_kernel="auto", no_arena=False, copy_outputs=True, fused_step="auto", tile="auto", walk_ahead="auto",
-                 work_order="auto", span_steps="auto", **kwargs):
+                 work_order="auto", span_steps="auto", span_tails="auto", **kwargs):
         """slot_kernel: PHILOX handles: "auto" (the packed slot kernel wherever the hub shape allows), "wave" (the wave-local one for
         every step) or "packed"; COMPAT handles: "auto" / "packed" the split step (stream walks one env per lane, one slot pass over both
         stations), "wave" one kernel per station (bit-identical); no_arena: one device allocation per array (no snapshots) -- chub_options.
@@ -69,6 +69,7 @@ class VecChargingHub(object):
         opt.tile = _lib.TILES[tile]  # packed slot kernel: "auto" (by working-set size), "small" (256 x 2) or "large" (512 x 4)
         opt.walk_ahead = _lib.WALK_AHEAD[walk_ahead]  # COMPAT batches: "auto" (step i + 1's stream walks beside step i's tails) or "off"
         opt.span_steps = 0 if span_steps == "auto" else (1 if span_steps == "off" else int(span_steps))  # chub_run_steps: steps per launch (one-launch handles)
+        opt.span_tails = {"auto": 0, "same_wave": 1, "own_wave": 2}[span_tails]  # ... and the wave a span's tails run on (own_wave: a step behind the slots)
         opt.work_order = _lib.WORK_ORDER[work_order]  # PHILOX packed kernels: "auto" (XCD-aware while the streams are cache-resident) or "dispatch"
         self._copy_outputs = bool(copy_outputs)
         check(self._lib.chub_create_ex(C.byref(self.cfg), (data_dir or _lib.DATA_DIR).encode(), self.n_envs, int(env_id0),

@@ -95,7 +95,10 @@ typedef struct chub_options {
                              at the day's end at the latest): 0 = as many steps as the call and the day allow (default), 1 = never (every step
                              a launch: the parity cross-check), n = at most n steps per launch.  Results are bit-identical.  Of a span's packed
                              outputs the last two blocks remain (the policy is open loop over the span: the call's own action batches). */
-    int32_t reserved[1];
+    int32_t span_tails;   /* ... and where a span's per-env tails run: 0 = by size (default: up to 256 workgroups -- one per CU -- as 2, beyond as 1), 1 = on the
+                             workgroup's last slot wave, behind its slot phases (k_steps_fused), 2 = on a fifth wave of the workgroup, ONE STEP BEHIND
+                             the slot waves (k_steps_piped: the slot phases of step s + 1 read nothing the tails of step s write, so the two chains of a
+                             step run side by side; hubs of 8 piles and more).  Results are bit-identical. */
 } chub_options;
 
 /* telemetry column indices of chub_get_telemetry (names of the reference attributes, MGR:183-297) */

@@ -1409,14 +1409,17 @@ def test_compat_split_step_is_bit_identical_through_restores_and_masked_calls():
         assert np.array_equal(a, c, equal_nan=True), ("own walks", k)
 
 
-@pytest.mark.parametrize("label", ["c2", "c3_small", "ragged"])
+@pytest.mark.parametrize("label", ["c2", "c3_small", "ragged", "many_workgroups"])
 def test_spans_of_steps_in_one_launch_are_bit_identical(label):
-    """chub_run_steps on a handle that runs the one-launch step issues spans of lock-step steps as ONE launch (k_steps_fused: each workgroup goes
-    from step to step by itself; chub_options.span_steps).  The same program of calls with spans of any length, of at most 7 steps, and with
-    every step a launch of its own (span_steps = 1: the form every other test pins to the oracle / the reference): both packed blocks after
-    every call, slot state, station records, clocks bit for bit -- across day boundaries, from odd first steps, with 3 action batches (i % 3
-    against i & 1), mixed with single steps, a call on a subset of the envs (per-env clocks: no spans from there until everybody is reset) and
-    inside a hipGraph."""
+    """chub_run_steps on a handle that runs the one-launch step issues spans of lock-step steps as ONE launch (chub_options.span_steps), the per-env
+    tails either on the workgroup's last slot wave behind its slot phases (k_steps_fused: span_tails = 1) or on a fifth wave ONE STEP BEHIND the
+    slot waves (k_steps_piped: span_tails = 2 -- the tails of step s run beside the slot phases of step s + 1, the station records travel through
+    two LDS buffers, the last step's tails run after the slot waves have ended).  The same program of calls with spans of any length, of at most
+    7 steps (so that spans end and begin everywhere), in both forms, and with every step a launch of its own (span_steps = 1: the form every
+    other test pins to the oracle / the reference): both packed blocks after every call, slot state, station records, clocks bit for bit --
+    across day boundaries, from odd first steps, with 3 action batches (i % 3 against i & 1), mixed with single steps, a call on a subset of the
+    envs (per-env clocks: no spans from there until everybody is reset) and inside a hipGraph.  "many_workgroups": 300 workgroups, where the
+    default is the last slot wave and the tail wave is forced."""
     chub = hub()
     from charginghub_env_amd import multi_gpu
     from charginghub_env_amd._lib import check
@@ -1425,11 +1428,15 @@ def test_spans_of_steps_in_one_launch_are_bit_identical(label):
           "c3_small": dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2,
                            fc_max_power=100.0, fcev_permeate=0.02, renew_fluctuate=0.2, price_fluctuate=0.1),
           "ragged": dict(station_list=[7, 13], station_type_list=["slow", "fast"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.3,
-                         fc_max_power=100.0, fcev_permeate=0.05, renew_fluctuate=0.3, price_fluctuate=0.3, hydro_loss=0.001)}[label]
-    n = {"c2": 4096, "c3_small": 1500, "ragged": 777}[label]
+                         fc_max_power=100.0, fcev_permeate=0.05, renew_fluctuate=0.3, price_fluctuate=0.3, hydro_loss=0.001),
+          "many_workgroups": dict(station_list=[24, 9], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2,
+                                  fc_max_power=100.0, fcev_permeate=0.02, renew_fluctuate=0.1, price_fluctuate=0.2)}[label]
+    n = {"c2": 4096, "c3_small": 1500, "ragged": 777, "many_workgroups": 4500}[label]
     res = {}
-    for form in ("off", "auto", 7, "graph"):
-        v = chub.VecChargingHub(n, seed=21, span_steps="auto" if form == "graph" else form, **kw)
+    FORMS = [("off", "auto"), ("auto", "auto"), ("auto", "same_wave"), ("auto", "own_wave"), (7, "same_wave"), (7, "own_wave"), ("graph", "same_wave"),
+             ("graph", "own_wave")]
+    for form in FORMS:
+        v = chub.VecChargingHub(n, seed=21, span_steps="auto" if form[0] == "graph" else form[0], span_tails=form[1], **kw)
         assert v.uses_fused_step
         D, A = v.obs_dim, v.act_dim
         st = multi_gpu.Stream(0)
@@ -1455,7 +1462,7 @@ def test_spans_of_steps_in_one_launch_are_bit_identical(label):
         v.step_device_packed(acts[0].ptr, packed[0].ptr, stream=st.ptr)  # step 6, from the host
         run(7, 96 - 7 + 30)  # an odd first step, to the day's end, a reset inside, 30 steps into the next day
         note()
-        if form == "graph":
+        if form[0] == "graph":
             st.sync()
             v.graph_begin(st.ptr)
             run(126, 66 + 96)  # to the end of day 2 and through day 3: 162 steps + 1 reset = 163 launches' worth of ticks
@@ -1482,7 +1489,7 @@ def test_spans_of_steps_in_one_launch_are_bit_identical(label):
         res[form] = trace
         v.close()
         st.destroy()
-    for form in ("auto", 7, "graph"):
-        assert len(res[form]) == len(res["off"])
-        for k, (a, b) in enumerate(zip(res["off"], res[form])):
+    for form in FORMS[1:]:
+        assert len(res[form]) == len(res[FORMS[0]])
+        for k, (a, b) in enumerate(zip(res[FORMS[0]], res[form])):
             assert np.array_equal(a, b), (label, "spans", form, "vs every step a launch: array", k)

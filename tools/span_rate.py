@@ -7,13 +7,15 @@ sys.path.insert(0, ".")
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", choices=["c2", "c4k", "shard"], default="c2")
 ap.add_argument("--days", type=int, default=20)
+ap.add_argument("--envs", type=int, default=0, help="another batch size than the config's")
+ap.add_argument("--tails", default="auto", help="chub_options.span_tails: auto / same_wave / own_wave")
 args = ap.parse_args()
 import numpy as np
 import charginghub_env_amd as chub
 from charginghub_env_amd import multi_gpu
 from charginghub_env_amd._lib import check
 kw = dict(station_list=[20, 25], station_type_list=["fast", "slow"], hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2, fc_max_power=100.0, fcev_permeate=0.01)
-n = {"c2": 4096, "c4k": 4096, "shard": 8192}[args.config]
+n = args.envs or {"c2": 4096, "c4k": 4096, "shard": 8192}[args.config]
 fused = "auto"
 if args.config == "c2":
     kw.update(station_list=[16, 0], fcev_permeate=0.0)
@@ -21,7 +23,7 @@ if args.config == "shard":
     fused = "on"  # (745 workgroups: beyond the default's 384; the 8-GPU shard of the headline job)
 out = []
 for span in ("off", "auto", 24):
-    v = chub.VecChargingHub(n, seed=1, span_steps=span, fused_step=fused, **kw)
+    v = chub.VecChargingHub(n, seed=1, span_steps=span, span_tails=args.tails, fused_step=fused, **kw)
     D, A = v.obs_dim, v.act_dim
     st = multi_gpu.Stream(0)
     acts = [multi_gpu.DeviceBuffer(n * A * 4) for _ in range(4)]
