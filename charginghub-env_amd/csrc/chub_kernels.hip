@@ -62,8 +62,10 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
                                             uint32_t k1) {
 #pragma unroll
     for (int i = 0; i < 10; i++) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // (one 32 x 32 -> 64 multiply per product -- v_mad_u64_u32 -- instead of a v_mul_hi_u32 / v_mul_lo_u32 pair: all three run at a quarter of the
+        // 32-bit rate, and a block is 20 products)
+        const uint64_t p0 = (uint64_t) 0xD2511F53u * c0, p1 = (uint64_t) 0xCD9E8D57u * c2;
+        const uint32_t h0 = (uint32_t) (p0 >> 32), l0 = (uint32_t) p0, h1 = (uint32_t) (p1 >> 32), l1 = (uint32_t) p1;
         uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u;
@@ -1573,7 +1575,9 @@ struct NoHook {
 };
 // BITS: the pile decisions arrive as one bit per pile ([N][ceil(S / 64)] u64 behind pa.actions) instead of a row of floats:
 // 8 bytes per env and word instead of 4 per pile (chub_step_bits; the tail kernel reads the two tail actions from their own array).
-template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED, bool FUSED, typename Hook, bool BITS = false>
+// PIPED (k_steps_piped): the new cars are the business of the upper half of the workgroup's slot waves -- the lower half returns right behind the
+// third barrier and makes the next step's draws meanwhile.
+template <int BLOCK, int T, bool TAPE, bool RESET, bool BIG, bool MASKED, bool FUSED, typename Hook, bool BITS = false, bool PIPED = false>
 __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepArgs &sa, PackedArgs &pa, const Tables &tb,
                                                 const uint32_t block_local, uint32_t *q_cnt, uint32_t *q_new,
                                                 uint64_t *s_ball, int *s_acc, uint32_t *s_unit, Hook &hook, u32x4 *s_rec, uint32_t *s_uinfo) {
@@ -1828,9 +1832,10 @@ __device__ __forceinline__ int slot_body_packed(const HubParams &hp, const StepA
     // serves its share and the workgroup meets again in front of the records.
     constexpr bool ALL = RESET || CHUB_EPI_ALL || FUSED;  // every wave takes new cars
     if (!ALL && wave != WAVES - 1) return 0;
+    if (PIPED && wave < WAVES / 2) return wave + 1;
     // ---- add_car (CHS.hpp:864-877 / 1029-1042) for the workgroup's new cars, one lane per car
     const uint32_t n_adm = q_cnt[0];
-    for (uint32_t i = (uint32_t) (ALL ? tid : lane); i < n_adm; i += (ALL ? BLOCK : 64)) {
+    for (uint32_t i = (uint32_t) (PIPED ? tid - (WAVES / 2) * 64 : (ALL ? tid : lane)); i < n_adm; i += (PIPED ? BLOCK - (WAVES / 2) * 64 : (ALL ? BLOCK : 64))) {
         const int src = (int) q_new[i];
         const int s_e = (int) (__umul24((uint32_t) src, pa.magic) >> 20);
         const int s_hs = src - (int) __umul24((uint32_t) s_e, (uint32_t) St);
@@ -2557,8 +2562,9 @@ __device__ __forceinline__ void tail_prefetch(TailIn &in, const TailArgs &ta, co
 // first half runs while the workgroup's first wave is still busy with the new cars.
 struct NoMid {
     __device__ __forceinline__ void operator()() {}
-    __device__ __forceinline__ void at1() {}  // (two more places every lane with an env passes: k_steps_piped's tail wave meets the slot waves there)
+    __device__ __forceinline__ void at1() {}  // (more places every lane with an env passes: k_steps_piped's tail wave meets the slot waves at some of them)
     __device__ __forceinline__ void at2() {}
+    __device__ __forceinline__ void at3() {}
 };
 // EB: lanes of the workgroup that calls it (k_env: kEnvBlock; k_compat_small: its 512)
 // TAPE (the parity instrument of include/chub.h, PHILOX handles): the tail's variates come from the caller -- the exogenous normals
@@ -3156,6 +3162,7 @@ __device__ __forceinline__ void env_tail(const DevCtx *__restrict__ ctx, const S
     }
     } while (0);
     CHUB_STAMP(5);  // second half (clamp, hydrogen step, netting, fuel cell, money, observation) done
+    mid.at3();
     flush_rows();
 #if CHUB_TRACE
     CHUB_STAMP(6);  // rows flushed
@@ -3428,6 +3435,7 @@ __device__ __forceinline__ void step_fused_body(const DevCtx *__restrict__ ctx, 
         bool first;  // the first group of envs: the barrier and the records are still ahead
         __device__ __forceinline__ void at1() {}
         __device__ __forceinline__ void at2() {}
+        __device__ __forceinline__ void at3() {}
         __device__ __forceinline__ void operator()() {
             if (!first) return;
             __syncthreads();
@@ -3537,21 +3545,34 @@ __global__ __launch_bounds__(BLOCK, 2) void k_steps_fused(const DevCtx *__restri
     }
 }
 
-// ---- The same span with the TAILS A STEP BEHIND, on a wave of their own (k_steps_piped; stations of 4 piles and more: at most 64 envs per
-// workgroup).  In k_steps_fused a step is two chains end to end -- the slot phases (three dependent round trips, four barriers: ~3.5 us) and then,
-// on the last wave alone, the tails (~600 dependent f64 operations, a wave64 f64 operation every 8 cycles: ~3 us) -- and neither waits for the
-// other's RESULT: the slot phases of step s + 1 read slot words, decoded draws and action rows, none of which the tails of step s write
-// (level_block takes the queue length from the record pass, not from the tail).  So the workgroup gets a fifth wave that runs the tails of step
-// s - 1 while the four slot waves run step s: the last slot wave writes the station records (two LDS buffers, by step parity) behind the
-// step's fourth barrier, the tail wave reads them a step later, keeps the table rows and the output rows in LDS areas nobody else touches,
-// and after the slot waves' last step runs the last tails alone.  gfx950 has one barrier per workgroup, so the tail wave takes part in the
-// slot waves' five barriers per step: at its start, in the middle of the forecourt half, between the halves, behind the hydrogen step and at its
-// end (Mid::at) -- five pieces of the tail against the five phases of the slot step, each side waiting where the other is slower.
+// ---- The same span with the TAILS A STEP BEHIND, on a wave of their own (k_steps_piped; hubs of 8 piles and more: at most 64 envs per
+// workgroup).  In k_steps_fused a step is three chains end to end -- the slot phases up to the new cars (three dependent round trips, three
+// barriers: ~2.4 us), the next step's draws (Philox blocks and dependent table reads on two waves: ~1.7 us) and, on the last wave alone, the
+// station records and the tails (~600 dependent f64 operations, a wave64 f64 operation every 8 cycles: ~3.5 us) -- and none of them waits for
+// the next one's RESULT: the slot phases of step s + 1 read slot words, decoded draws and action rows, none of which the tails of step s write
+// (level_block takes the queue length from the admission pass, not from the tail), and the draws need the queue lengths the admission left,
+// not the new cars.  So:
+//   slot waves 0, 1:  behind the third barrier the next step's draws (units / envs) WHILE
+//   slot waves 2, 3:  serve the new cars;  fourth barrier, next step
+//   a fifth wave:     the station records and the tails of step s - 1 while the slot waves run step s: the LDS sums and queue words of a step
+//                     live in two buffers by step parity, the table rows and output rows in areas nobody else touches; after the slot waves'
+//                     last step it runs the last tails alone (a wave that has ended no longer counts at the barrier).
+// gfx950 has ONE barrier per workgroup, so the tail wave takes part in the slot waves' four barriers per step: behind its load requests, behind
+// the records, behind the forecourt (Mid::at1) and in front of its output flush (Mid::at3) -- four pieces of the tail against the four phases of
+// the slot step, placed by the stamps of tools/experiments/piped_stamps.py so that neither side waits long for the other.
 // Same functions, same Philox counters, same operations per env: bit-identical to steps issued one by one (tests).
+#ifdef CHUB_PIPED_STAMPS  // (measurement build: when the tail wave of workgroup 0 reaches and leaves each of a step's four barriers)
+__device__ unsigned long long g_piped_stamps[16];
+#define PIPED_STAMP(k) do { if (stamp_on) g_piped_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PIPED_STAMP(k) do { } while (0)
+#endif
 struct PipedMid {
-    __device__ __forceinline__ void at1() { __syncthreads(); }
-    __device__ __forceinline__ void at2() { __syncthreads(); }
-    __device__ __forceinline__ void operator()() { __syncthreads(); }
+    bool stamp_on;
+    __device__ __forceinline__ void at1() { PIPED_STAMP(4); __syncthreads(); PIPED_STAMP(5); }
+    __device__ __forceinline__ void at2() {}
+    __device__ __forceinline__ void at3() { PIPED_STAMP(6); __syncthreads(); PIPED_STAMP(7); }
+    __device__ __forceinline__ void operator()() {}
 };
 __device__ __forceinline__ void span_args(const StepArgs &sa0, const PackedArgs &pa0, const TailArgs &ta0, const SpanArgs &sp, const int s,
                                           StepArgs &sa, PackedArgs &pa, TailArgs &ta) {
@@ -3591,22 +3612,22 @@ __device__ __forceinline__ void span_args(const StepArgs &sa0, const PackedArgs 
 template <int BLOCK, int T>
 __global__ __launch_bounds__(BLOCK + 64, 2) void k_steps_piped(const DevCtx *__restrict__ ctx, StepArgs sa0, PackedArgs pa0, TailArgs ta0, SpanArgs sp) {
     constexpr int WAVES = BLOCK / 64;
+    static_assert(WAVES == 4, "two waves draw while two serve the new cars");
     __shared__ uint32_t q_new[BLOCK * T];
     __shared__ uint32_t q_cnt[2];
     __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];
-    __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T * kAccCopies];
-    __shared__ uint32_t s_unit[BLOCK * T / 2];
+    __shared__ __attribute__((aligned(16))) int s_acc2[2][2 * BLOCK * T * kAccCopies];  // a step's LDS sums and queue words, by step parity: the tail wave
+    __shared__ uint32_t s_unit2[2][BLOCK * T / 2];                                      // turns them into station records while the next step is under way
     __shared__ uint32_t s_uinfo[BLOCK * T / 2];
-    __shared__ __attribute__((aligned(16))) u32x4 s_rec2[2][BLOCK * T / 2];  // the station records of a step, by step parity: written in step s, read by the tails in step s + 1
-    __shared__ double s_pv[100], s_wd[150], s_pv_now[100], s_wd_now[150], s_hy[102];  // the tail wave's
-    __shared__ __attribute__((aligned(16))) float s_out[64 * 16];                      // ... and its output rows
+    __shared__ __attribute__((aligned(16))) u32x4 s_rec[BLOCK * T / 2];                 // the tail wave's: the records ...
+    __shared__ double s_pv[100], s_wd[150], s_pv_now[100], s_wd_now[150], s_hy[102];    // ... the table rows
+    __shared__ __attribute__((aligned(16))) float s_out[64 * 16];                       // ... and its output rows
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int n = sp.n_steps;
     if (wave < WAVES) {
-        // ---- the slot waves: step s = the packed slot body up to its third barrier (#1 #2 #3), the fourth (#4), then next step's draws (waves 0, 1)
-        // and this step's station records (the last slot wave); the fifth barrier (#5) in front of the next step
+        // ---- the slot waves: step s = the packed slot body up to its third barrier (#1 #2 #3); then waves 0 / 1 the next step's draws, waves 2 / 3
+        // the new cars; the fourth barrier (#4); the next step
         for (int s = 0; s < n; s++) {
-            if (s) __syncthreads();
             StepArgs sa;
             PackedArgs pa;
             TailArgs ta;
@@ -3614,12 +3635,13 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void k_steps_piped(const DevCtx *__r
             asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
                               "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
             NoHook hook;
-            const int role = slot_body_packed<BLOCK, T, false, false, false, false, true, NoHook, false>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
-                                                                                                          s_ball + 1, s_acc, s_unit, hook, nullptr, s_uinfo);
-            __syncthreads();
+            int *const s_acc = s_acc2[s & 1];
+            uint32_t *const s_unit = s_unit2[s & 1];
+            const int role = slot_body_packed<BLOCK, T, false, false, false, false, true, NoHook, false, true>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
+                                                                                                                s_ball + 1, s_acc, s_unit, hook, nullptr, s_uinfo);
             const int lane = threadIdx.x & 63;
             const int epb = (int) pa.epb, N = (int) pa.n_envs, env_first = (int) blockIdx.x * epb;
-            if (role == 1) {
+            if (role == 1) {  // (the queue lengths are the admission's: in s_unit since the third barrier)
                 for (int i = lane; i < 2 * epb; i += 64) {
                     const int e = i >> 1, k = i & 1, env = env_first + e;
                     if (env >= N) continue;
@@ -3635,80 +3657,93 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void k_steps_piped(const DevCtx *__r
             } else if (role == 2) {
                 for (int i = lane; i < epb; i += 64)
                     if (env_first + i < N) level_block<false, false>(ctx, sa, 2 * (int64_t) N + env_first + i);
-            } else if (role == WAVES) {
-                packed_records<BLOCK, T, false, false, false, true, false>(pa, blockIdx.x, s_acc, s_unit, s_rec2[s & 1]);
             }
+            __syncthreads();  // #4
         }
-        return;  // (a wave that has ended no longer counts at the workgroup's barrier: the tail wave runs the last step's tails by itself)
+        return;  // (a wave that has ended no longer counts at the workgroup's barrier: the tail wave runs the last step's records and tails by itself)
     }
-    // ---- the tail wave: during step s the tails of step s - 1
+    // ---- the tail wave: during step s the station records and the tails of step s - 1
     for (int s = 0; s <= n; s++) {
         if (s == 0) {  // nothing to do during the first step: its four barriers
             __syncthreads();
             __syncthreads();
             __syncthreads();
             __syncthreads();
-        } else {
-            StepArgs sa;
-            PackedArgs pa;
-            TailArgs ta;
-            span_args(sa0, pa0, ta0, sp, s - 1, sa, pa, ta);
-            const int lane = threadIdx.x & 63;
-            const int epb = (int) pa.epb, N = (int) pa.n_envs, env_first = (int) blockIdx.x * epb;
-            const int env = env_first + lane;
-            const bool live = lane < epb && env < N;
-            TailIn tin = TailIn();
-            if (live) tail_prefetch(tin, ta, (uint32_t) env, sa.fresh == 0);
-            double r_pv[2], r_pvn[2], r_wd[3], r_wdn[3], r_hy[2];
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int i = lane + 64 * q;
-                r_pv[q] = r_pvn[q] = r_hy[q] = 0.0;
-                if (i < 100) {
-                    r_pv[q] = ta.pv_row[i];
-                    r_pvn[q] = ta.pv_row_now[i];
-                }
-                if (i < 102 && s == 1) r_hy[q] = ta.hy_table[i];  // (the hydrogen table does not change: parked once)
-            }
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const int i = lane + 64 * q;
-                r_wd[q] = r_wdn[q] = 0.0;
-                if (i < 150) {
-                    r_wd[q] = ta.wd_row[i];
-                    r_wdn[q] = ta.wd_row_now[i];
-                }
-            }
-            __syncthreads();  // #1
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int i = lane + 64 * q;
-                if (i < 100) {
-                    s_pv[i] = r_pv[q];
-                    s_pv_now[i] = r_pvn[q];
-                }
-                if (i < 102 && s == 1) s_hy[i] = r_hy[q];
-            }
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const int i = lane + 64 * q;
-                if (i < 150) {
-                    s_wd[i] = r_wd[q];
-                    s_wd_now[i] = r_wdn[q];
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the wave's own LDS rows, read back by other lanes of it)
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            int rows = epb < 64 ? epb : 64;
-            rows = N - env_first < rows ? N - env_first : rows;
-            PipedMid mid;  // #2 (at<1>), #3 (between the halves), #4 (at<2>)
-            env_tail<false, MODE_PHILOX, false, true, PipedMid, kEnvBlock, false>(ctx, sa, env, live, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, nullptr, s_out, 0, ta,
-                                                                                  s_rec2[(s - 1) & 1], live ? lane : 0, env_first, rows > 0 ? rows : 0, tin, true, mid);
+            continue;
         }
-        __syncthreads();  // #5 (behind the slot waves' last step: alone)
+        StepArgs sa;
+        PackedArgs pa;
+        TailArgs ta;
+        span_args(sa0, pa0, ta0, sp, s - 1, sa, pa, ta);
+        const int lane = threadIdx.x & 63;
+        const int epb = (int) pa.epb, N = (int) pa.n_envs, env_first = (int) blockIdx.x * epb;
+        const int env = env_first + lane;
+        const bool live = lane < epb && env < N;
+        TailIn tin = TailIn();
+        if (live) tail_prefetch(tin, ta, (uint32_t) env, sa.fresh == 0);
+        double r_pv[2], r_pvn[2], r_wd[3], r_wdn[3], r_hy[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int i = lane + 64 * q;
+            r_pv[q] = r_pvn[q] = r_hy[q] = 0.0;
+            if (i < 100) {
+                r_pv[q] = ta.pv_row[i];
+                r_pvn[q] = ta.pv_row_now[i];
+            }
+            if (i < 102 && s == 1) r_hy[q] = ta.hy_table[i];  // (the hydrogen table does not change: parked once)
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int i = lane + 64 * q;
+            r_wd[q] = r_wdn[q] = 0.0;
+            if (i < 150) {
+                r_wd[q] = ta.wd_row[i];
+                r_wdn[q] = ta.wd_row_now[i];
+            }
+        }
+        const bool stamp_on = blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s == n - 2;
+        (void) stamp_on;
+        PIPED_STAMP(0);
+        __syncthreads();  // #1
+        PIPED_STAMP(1);
+        // the station records of step s - 1 (every car's sums are in since that step's fourth barrier), into the record array and into s_rec
+        packed_records<BLOCK, T, false, false, false, true, false>(pa, blockIdx.x, s_acc2[(s - 1) & 1], s_unit2[(s - 1) & 1], s_rec);
+        PIPED_STAMP(2);
+        __syncthreads();  // #2
+        PIPED_STAMP(3);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int i = lane + 64 * q;
+            if (i < 100) {
+                s_pv[i] = r_pv[q];
+                s_pv_now[i] = r_pvn[q];
+            }
+            if (i < 102 && s == 1) s_hy[i] = r_hy[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int i = lane + 64 * q;
+            if (i < 150) {
+                s_wd[i] = r_wd[q];
+                s_wd_now[i] = r_wdn[q];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the wave's own LDS rows and records, read back by other lanes of it)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int rows = epb < 64 ? epb : 64;
+        rows = N - env_first < rows ? N - env_first : rows;
+        PipedMid mid{stamp_on};  // #3 (at1: behind the forecourt), #4 (at3: in front of the flush)
+        env_tail<false, MODE_PHILOX, false, true, PipedMid, kEnvBlock, false>(ctx, sa, env, live, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, nullptr, s_out, 0, ta,
+                                                                              s_rec, live ? lane : 0, env_first, rows > 0 ? rows : 0, tin, true, mid);
+        PIPED_STAMP(8);  // (flushed)
     }
 }
+#ifdef CHUB_PIPED_STAMPS
+extern "C" int chub_debug_piped_stamps(unsigned long long *out) {
+    return (int) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_piped_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
 
 // COMPAT only: HySystem.__init__ (HYD:154-158) builds hy_power_speed_list with 101 REAL hy_step()s from the initial tank:
 // each draws the FCEV arrival level and one mk_soc per arrival from the env's two streams (HYD:250-259), serves the
