@@ -65,6 +65,10 @@ constexpr int kPipedMaxBlocks = 256;   // chub_run_steps's spans with the tails 
                                        // one per CU: the slot waves then have nobody else's tails to overlap with.  us per step, tails on their own wave vs on
                                        // the last slot wave: 128 workgroups 4.93 vs 6.13; 192: 4.99 vs 6.12; 256: 5.00 vs 6.18 / 4.85 vs 6.40; 373: 9.40 vs 7.47;
                                        // 384: 9.73 vs 7.25 (two workgroups per CU already run one's tails beside the other's slot phases)
+constexpr int kFusedMaxBlocksTailWave = 768;  // ... as k_step_tailwave (hubs of 8 piles and more: the tails on a wave of their own).  us per step as graph replays,
+                                              // one launch vs two: 373 workgroups 8.15 vs 9.6; 559: 9.32 vs 10.08; 745: 9.57 vs 10.18; 1118: 14.99 vs 11.41 (up to
+                                              // four workgroups of five waves are resident per CU: 1024 in all)
+constexpr int kSpanMaxBlocks = 384;           // chub_run_steps's spans of steps in one launch, up to this many workgroups (745: 12.9 us per step against 11.0)
 constexpr int kFusedMaxBlocks = 384;   // PHILOX lock-step steps of at most this many slot workgroups run as ONE launch (k_step_fused).  Measured, us per step
                                        // as graph replays, one launch vs two: 8.08 vs 8.82 at 128 workgroups (C2), 8.50 vs 9.30 at 256, 9.42 vs 9.79 at 373,
                                        // 10.79 vs 10.61 at 745, 11.71 vs 11.38 at 1024, 17.9 vs 13.1 at 1490

@@ -3481,6 +3481,129 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step_fused(const DevCtx *__restric
     step_fused_body<BLOCK, T, BITS, TAPE>(ctx, sa, pa_in, ta);
 }
 
+// ---- The one-launch step with the tails on a wave of their own (k_step_tailwave; hubs of 8 piles and more: at most 64 envs per workgroup).
+// What k_steps_piped's stamps showed holds inside ONE step too: the tail's first half (the slot's exogenous values, the forecourt, the next
+// slot's exogenous update: ~1 us) looks at nothing the slot phases produce, the next step's draws (~2 us of Philox blocks and dependent table
+// reads on two waves) wait for the admission's queue lengths only, and only the second half of the tail needs the station records.  So a fifth
+// wave starts the tails with the kernel, beside the slot phases; slot waves 0 / 1 pass the fourth barrier right behind the third and make
+// the next step's draws beside everything that follows; slot waves 2 / 3 serve the new cars and end; the tail wave turns the LDS sums into the
+// station records behind the fourth barrier and runs the second half.  Chain: slot phases + new cars + records + second half, instead of slot
+// phases + new cars + draws | first half + records + second half.  Same functions, same Philox counters: bit-identical (tests: every test of
+// the one-launch step runs through it; chub_options.fused_step forced on / off).
+template <int BLOCK, int T, bool BITS>
+struct TailWaveMid {
+    const PackedArgs &pa;
+    int *s_acc;
+    const uint32_t *s_unit;
+    u32x4 *s_rec;
+    __device__ __forceinline__ void at1() { __syncthreads(); }  // #2
+    __device__ __forceinline__ void at2() {}
+    __device__ __forceinline__ void at3() {}
+    __device__ __forceinline__ void operator()() {
+        __syncthreads();  // #3
+        __syncthreads();  // #4: every new car is in its slot and in the LDS sums
+        packed_records<BLOCK, T, false, false, false, true, BITS>(pa, blockIdx.x, s_acc, s_unit, s_rec);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // s_rec was written by other lanes of this wave
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+template <int BLOCK, int T, bool BITS = false>
+__global__ __launch_bounds__(BLOCK + 64, 2) void k_step_tailwave(const DevCtx *__restrict__ ctx, StepArgs sa, PackedArgs pa_in, TailArgs ta) {
+    constexpr int WAVES = BLOCK / 64;
+    static_assert(WAVES == 4, "two waves draw while two serve the new cars");
+    __shared__ uint32_t q_new[BLOCK * T];
+    __shared__ uint32_t q_cnt[2];
+    __shared__ uint64_t s_ball[BLOCK * T / 64 + 2];
+    __shared__ __attribute__((aligned(16))) int s_acc[2 * BLOCK * T * kAccCopies];
+    __shared__ uint32_t s_unit[BLOCK * T / 2];
+    __shared__ uint32_t s_uinfo[BLOCK * T / 2];
+    __shared__ __attribute__((aligned(16))) u32x4 s_rec[BLOCK * T / 2];
+    __shared__ double s_pv[100], s_wd[150], s_pv_now[100], s_wd_now[150], s_hy[102];
+    __shared__ __attribute__((aligned(16))) float s_out[64 * 16];
+    PackedArgs pa = pa_in;
+    asm volatile("" : "+s"(pa.S[0]), "+s"(pa.S[1]), "+s"(pa.type[0]), "+s"(pa.type[1]), "+s"(pa.n_envs), "+s"(pa.epb), "+s"(pa.magic),
+                      "+s"(pa.cls_delta), "+s"(pa.state), "+s"(pa.rec), "+s"(pa.pk), "+s"(pa.actions), "+s"(pa.cls0), "+s"(pa.ttab2));
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int epb = (int) pa.epb, N = (int) pa.n_envs, env_first = (int) blockIdx.x * epb;
+    if (wave < WAVES) {
+        NoHook hook;
+        const int role = slot_body_packed<BLOCK, T, false, false, false, false, true, NoHook, BITS, true>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
+                                                                                                            s_ball + 1, s_acc, s_unit, hook, nullptr, s_uinfo);
+        __syncthreads();  // #4 (waves 0 / 1: right behind the third; waves 2 / 3: behind their new cars)
+        if (role == 1) {
+            for (int i = lane; i < 2 * epb; i += 64) {
+                const int e = i >> 1, k = i & 1, env = env_first + e;
+                if (env >= N) continue;
+                int line;
+                if ((k ? pa.S[1] : pa.S[0]) == 0u) {  // a station without piles: its queue moves on as in the record pass
+                    const int want = dk_want(pa.pk[(uint32_t) (k ? N : 0) + (uint32_t) env]);
+                    line = want < kMaxLine ? want : kMaxLine;
+                } else {
+                    line = pkd_line(s_unit[i]);
+                }
+                level_block<false, false>(ctx, sa, (int64_t) k * N + env, line);
+            }
+        } else if (role == 2) {
+            for (int i = lane; i < epb; i += 64)
+                if (env_first + i < N) level_block<false, false>(ctx, sa, 2 * (int64_t) N + env_first + i);
+        }
+        return;
+    }
+    // ---- the tail wave
+    const int env = env_first + lane;
+    const bool live = lane < epb && env < N;
+    TailIn tin = TailIn();
+    if (live) tail_prefetch(tin, ta, (uint32_t) env, sa.fresh == 0);
+    double r_pv[2], r_pvn[2], r_wd[3], r_wdn[3], r_hy[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int i = lane + 64 * q;
+        r_pv[q] = r_pvn[q] = r_hy[q] = 0.0;
+        if (i < 100) {
+            r_pv[q] = ta.pv_row[i];
+            r_pvn[q] = ta.pv_row_now[i];
+        }
+        if (i < 102) r_hy[q] = ta.hy_table[i];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int i = lane + 64 * q;
+        r_wd[q] = r_wdn[q] = 0.0;
+        if (i < 150) {
+            r_wd[q] = ta.wd_row[i];
+            r_wdn[q] = ta.wd_row_now[i];
+        }
+    }
+    __syncthreads();  // #1
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int i = lane + 64 * q;
+        if (i < 100) {
+            s_pv[i] = r_pv[q];
+            s_pv_now[i] = r_pvn[q];
+        }
+        if (i < 102) s_hy[i] = r_hy[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int i = lane + 64 * q;
+        if (i < 150) {
+            s_wd[i] = r_wd[q];
+            s_wd_now[i] = r_wdn[q];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the wave's own LDS rows, read back by other lanes of it)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int rows = epb < 64 ? epb : 64;
+    rows = N - env_first < rows ? N - env_first : rows;
+    TailWaveMid<BLOCK, T, BITS> mid{pa, s_acc, s_unit, s_rec};  // #2 (at1: behind the forecourt), #3 and #4 + the records (between the halves)
+    env_tail<false, MODE_PHILOX, false, true, TailWaveMid<BLOCK, T, BITS>, kEnvBlock, false>(ctx, sa, env, live, s_pv, s_wd, s_pv_now, s_wd_now, s_hy, nullptr, s_out, 0, ta,
+                                                                                       s_rec, live ? lane : 0, env_first, rows > 0 ? rows : 0, tin, true, mid);
+}
+
 // ---- A SPAN of lock-step steps in ONE launch ("multi-step persistent kernel for the random-policy bench").
 // k_step_fused gives every workgroup whole envs -- their slots, their station records, their tails, the next step's draws -- and nothing
 // crosses workgroups (MGR:136-302: the reference's envs are separate objects), so a workgroup can go from one step to the next BY ITSELF:
@@ -4160,11 +4283,17 @@ void launch_step_fused(const HubParams &hp, const DevCtx *ctx, const StepArgs &s
     }
     if (sa.act_bits) {  // one bit per pile: the tails read their two actions from the caller's [N][2] array
         ta.tail_act = (CHUB_G(const float)) sa.act_tail;
-        CHUB_LAUNCH((k_step_fused<kPackedBlock, kSlotsPerLane, true>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa, ta);
+        if (hp.epb <= 64)
+            CHUB_LAUNCH((k_step_tailwave<kPackedBlock, kSlotsPerLane, true>), dim3(nb), dim3(kPackedBlock + 64), stream, ev0, ev1, ctx, sa, pa, ta);
+        else
+            CHUB_LAUNCH((k_step_fused<kPackedBlock, kSlotsPerLane, true>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa, ta);
         return;
     }
     ta.tail_act = nullptr;  // the tails read their two actions from the action rows (the workgroup has just had them in cache)
-    CHUB_LAUNCH((k_step_fused<kPackedBlock, kSlotsPerLane>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa, ta);
+    if (hp.epb <= 64)  // (the tail wave's lanes are the workgroup's envs)
+        CHUB_LAUNCH((k_step_tailwave<kPackedBlock, kSlotsPerLane>), dim3(nb), dim3(kPackedBlock + 64), stream, ev0, ev1, ctx, sa, pa, ta);
+    else
+        CHUB_LAUNCH((k_step_fused<kPackedBlock, kSlotsPerLane>), dim3(nb), dim3(kPackedBlock), stream, ev0, ev1, ctx, sa, pa, ta);
 }
 
 // COMPAT lock-step reset / step of a handle whose envs all fit one workgroup (the caller has checked): one launch

@@ -68,6 +68,7 @@ struct chub_env {
     Tables tb;
     int device;
     bool fused;         // PHILOX lock-step steps of this handle run as ONE launch (k_step_fused): small batches
+    bool span_size_ok = false;   // spans of steps in one launch: few enough workgroups (or the one-launch step forced: the measurements)
     bool span_piped = false;     // ... with the tails on a wave of their own, a step behind (k_steps_piped; chub_options.span_tails)
     int span_steps = 0;          // chub_options.span_steps: chub_run_steps's spans of steps in one launch (0: up to a day's rest; 1: never; n: at most n)
     bool no_walk_ahead = false;  // chub_options.walk_ahead = 1: the split COMPAT step never walks ahead (A/B, parity cross-check)
@@ -743,7 +744,8 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     {   // the whole step as one launch: where the two kernels are launch- and latency-bound and every workgroup finds room at once
         const int64_t nb = (n_envs + hp.epb - 1) / hp.epb;
         const bool can = hp.packed && hp.S[0] <= 64 && hp.S[1] <= 64 && hp.pblock == kPackedBlock;
-        e->fused = can && (opt.fused_step == 2 || (opt.fused_step == 0 && nb <= kFusedMaxBlocks));
+        e->fused = can && (opt.fused_step == 2 || (opt.fused_step == 0 && nb <= (hp.epb <= 64 ? kFusedMaxBlocksTailWave : kFusedMaxBlocks)));
+        e->span_size_ok = nb <= kSpanMaxBlocks || opt.fused_step == 2;
         if (opt.fused_step == 2 && !can)
             return bail(fail(CHUB_ERR_UNSUPPORTED, "fused_step = 2: the single-launch step covers PHILOX handles on the packed slot kernel with "
                                                    "stations of at most 64 piles"));
@@ -1162,7 +1164,7 @@ int chub_step_gather(chub_env *e, chub_comm *comm, const float *d_actions, float
 // (k_steps_fused: the workgroup that owns an env's slots, records and tail goes from step to step by itself).  Not while a tape is loaded,
 // on per-env clocks, with one bit per pile, under the per-kernel profiler or with chub_options.span_steps = 1.
 static bool span_ok(const chub_env *e, int n_batches) {
-    return e->fused && e->span_steps != 1 && e->hp.rng_mode == CHUB_RNG_PHILOX && !e->per_env && !e->prof_on && !e->tape_pk && !e->tape_car &&
+    return e->fused && e->span_size_ok && e->span_steps != 1 && e->hp.rng_mode == CHUB_RNG_PHILOX && !e->per_env && !e->prof_on && !e->tape_pk && !e->tape_car &&
            !e->tape_tail && !e->tape_only && !e->cur_bits && n_batches <= 8 && e->tick != 0 && !e->hp.telemetry;
 }
 
