@@ -3363,6 +3363,79 @@ __global__ __launch_bounds__(kCompatSmallBlock) void k_compat_small(const DevCtx
 //   wave 1:     next step's per-env draws
 // Same functions, same Philox counters, same operations as k_slot_packed + k_env: bit-identical results
 // (tests: chub_options.fused_step forced on / off).  PHILOX, lock-step, stations of up to 64 piles.
+// The next step's draws of a one-launch workgroup (k_step_fused / k_step_tailwave / k_steps_fused / k_steps_piped): role 1 = the station-level draws of
+// its units, decoded against the queue lengths the admission pass left in s_unit; role 2 = its envs' draws; any other role: nothing.
+__device__ __forceinline__ void draw_next_step(const int role, const DevCtx *__restrict__ ctx, const StepArgs &sa, const PackedArgs &pa, const uint32_t *s_unit) {
+    const int lane = threadIdx.x & 63;
+    const int epb = (int) pa.epb, N = (int) pa.n_envs, env_first = (int) blockIdx.x * epb;
+    if (role == 1) {
+        for (int i = lane; i < 2 * epb; i += 64) {
+            const int e = i >> 1, k = i & 1, env = env_first + e;
+            if (env >= N) continue;
+            int line;
+            if ((k ? pa.S[1] : pa.S[0]) == 0u) {  // a station without piles: its queue moves on as in the body's record pass
+                const int want = dk_want(pa.pk[(uint32_t) (k ? N : 0) + (uint32_t) env]);
+                line = want < kMaxLine ? want : kMaxLine;
+            } else {
+                line = pkd_line(s_unit[i]);
+            }
+            level_block<false, false>(ctx, sa, (int64_t) k * N + env, line);
+        }
+    } else if (role == 2) {
+        for (int i = lane; i < epb; i += 64)
+            if (env_first + i < N) level_block<false, false>(ctx, sa, 2 * (int64_t) N + env_first + i);
+    }
+}
+// The table rows a tail WAVE (k_step_tailwave, k_steps_piped) keeps in LDS for its envs: requested with the per-env state, parked behind the
+// wave's first barrier (one wave: two or three elements per lane)
+struct TailWaveRows {
+    double r_pv[2], r_pvn[2], r_wd[3], r_wdn[3], r_hy[2];
+    __device__ __forceinline__ void request(const TailArgs &ta, const bool with_hy) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int i = lane + 64 * q;
+            r_pv[q] = r_pvn[q] = r_hy[q] = 0.0;
+            if (i < 100) {
+                r_pv[q] = ta.pv_row[i];
+                r_pvn[q] = ta.pv_row_now[i];
+            }
+            if (i < 102 && with_hy) r_hy[q] = ta.hy_table[i];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int i = lane + 64 * q;
+            r_wd[q] = r_wdn[q] = 0.0;
+            if (i < 150) {
+                r_wd[q] = ta.wd_row[i];
+                r_wdn[q] = ta.wd_row_now[i];
+            }
+        }
+    }
+    __device__ __forceinline__ void park(double *s_pv, double *s_wd, double *s_pv_now, double *s_wd_now, double *s_hy, const bool with_hy) const {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int i = lane + 64 * q;
+            if (i < 100) {
+                s_pv[i] = r_pv[q];
+                s_pv_now[i] = r_pvn[q];
+            }
+            if (i < 102 && with_hy) s_hy[i] = r_hy[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int i = lane + 64 * q;
+            if (i < 150) {
+                s_wd[i] = r_wd[q];
+                s_wd_now[i] = r_wdn[q];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the wave's own LDS rows, read back by other lanes of it)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
 struct TailPrefetch {
     const TailArgs &ta;
     double *s_pv, *s_wd, *s_pv_now, *s_wd_now, *s_hy;
@@ -3446,23 +3519,8 @@ __device__ __forceinline__ void step_fused_body(const DevCtx *__restrict__ ctx, 
         }
     };
     if (role != WAVES) __syncthreads();
-    if (role == 1) {
-        // next step's station-level draws of this workgroup's units, against the queue lengths the main pass left in s_unit
-        for (int i = lane; i < 2 * epb; i += 64) {
-            const int e = i >> 1, k = i & 1, env = env_first + e;
-            if (env >= N) continue;
-            int line;
-            if ((k ? pa.S[1] : pa.S[0]) == 0u) {  // a station without piles: its queue moves on as in the body's record pass
-                const int want = dk_want(pa.pk[(uint32_t) (k ? N : 0) + (uint32_t) env]);
-                line = want < kMaxLine ? want : kMaxLine;
-            } else {
-                line = pkd_line(s_unit[i]);
-            }
-            level_block<false, false>(ctx, sa, (int64_t) k * N + env, line);
-        }
-    } else if (role == 2) {
-        for (int i = lane; i < epb; i += 64)
-            if (env_first + i < N) level_block<false, false>(ctx, sa, 2 * (int64_t) N + env_first + i);
+    if (role == 1 || role == 2) {
+        draw_next_step(role, ctx, sa, pa, s_unit);
     } else if (role == WAVES) {
         for (int c = 0; c < epb; c += 64) {  // the workgroup's envs, 64 at a time (the wave's own LDS traffic: wave-level synchronisation)
             const int le = c + lane, env = env_first + le;
@@ -3532,23 +3590,7 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void k_step_tailwave(const DevCtx *_
         const int role = slot_body_packed<BLOCK, T, false, false, false, false, true, NoHook, BITS, true>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
                                                                                                             s_ball + 1, s_acc, s_unit, hook, nullptr, s_uinfo);
         __syncthreads();  // #4 (waves 0 / 1: right behind the third; waves 2 / 3: behind their new cars)
-        if (role == 1) {
-            for (int i = lane; i < 2 * epb; i += 64) {
-                const int e = i >> 1, k = i & 1, env = env_first + e;
-                if (env >= N) continue;
-                int line;
-                if ((k ? pa.S[1] : pa.S[0]) == 0u) {  // a station without piles: its queue moves on as in the record pass
-                    const int want = dk_want(pa.pk[(uint32_t) (k ? N : 0) + (uint32_t) env]);
-                    line = want < kMaxLine ? want : kMaxLine;
-                } else {
-                    line = pkd_line(s_unit[i]);
-                }
-                level_block<false, false>(ctx, sa, (int64_t) k * N + env, line);
-            }
-        } else if (role == 2) {
-            for (int i = lane; i < epb; i += 64)
-                if (env_first + i < N) level_block<false, false>(ctx, sa, 2 * (int64_t) N + env_first + i);
-        }
+        draw_next_step(role, ctx, sa, pa, s_unit);
         return;
     }
     // ---- the tail wave
@@ -3556,47 +3598,10 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void k_step_tailwave(const DevCtx *_
     const bool live = lane < epb && env < N;
     TailIn tin = TailIn();
     if (live) tail_prefetch(tin, ta, (uint32_t) env, sa.fresh == 0);
-    double r_pv[2], r_pvn[2], r_wd[3], r_wdn[3], r_hy[2];
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int i = lane + 64 * q;
-        r_pv[q] = r_pvn[q] = r_hy[q] = 0.0;
-        if (i < 100) {
-            r_pv[q] = ta.pv_row[i];
-            r_pvn[q] = ta.pv_row_now[i];
-        }
-        if (i < 102) r_hy[q] = ta.hy_table[i];
-    }
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-        const int i = lane + 64 * q;
-        r_wd[q] = r_wdn[q] = 0.0;
-        if (i < 150) {
-            r_wd[q] = ta.wd_row[i];
-            r_wdn[q] = ta.wd_row_now[i];
-        }
-    }
+    TailWaveRows tr;
+    tr.request(ta, true);
     __syncthreads();  // #1
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int i = lane + 64 * q;
-        if (i < 100) {
-            s_pv[i] = r_pv[q];
-            s_pv_now[i] = r_pvn[q];
-        }
-        if (i < 102) s_hy[i] = r_hy[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-        const int i = lane + 64 * q;
-        if (i < 150) {
-            s_wd[i] = r_wd[q];
-            s_wd_now[i] = r_wdn[q];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the wave's own LDS rows, read back by other lanes of it)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    tr.park(s_pv, s_wd, s_pv_now, s_wd_now, s_hy, true);
     int rows = epb < 64 ? epb : 64;
     rows = N - env_first < rows ? N - env_first : rows;
     TailWaveMid<BLOCK, T, BITS> mid{pa, s_acc, s_unit, s_rec};  // #2 (at1: behind the forecourt), #3 and #4 + the records (between the halves)
@@ -3762,25 +3767,7 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void k_steps_piped(const DevCtx *__r
             uint32_t *const s_unit = s_unit2[s & 1];
             const int role = slot_body_packed<BLOCK, T, false, false, false, false, true, NoHook, false, true>(ctx->hp, sa, pa, ctx->tb, blockIdx.x, q_cnt, q_new,
                                                                                                                 s_ball + 1, s_acc, s_unit, hook, nullptr, s_uinfo);
-            const int lane = threadIdx.x & 63;
-            const int epb = (int) pa.epb, N = (int) pa.n_envs, env_first = (int) blockIdx.x * epb;
-            if (role == 1) {  // (the queue lengths are the admission's: in s_unit since the third barrier)
-                for (int i = lane; i < 2 * epb; i += 64) {
-                    const int e = i >> 1, k = i & 1, env = env_first + e;
-                    if (env >= N) continue;
-                    int line;
-                    if ((k ? pa.S[1] : pa.S[0]) == 0u) {  // a station without piles: its queue moves on as in the record pass
-                        const int want = dk_want(pa.pk[(uint32_t) (k ? N : 0) + (uint32_t) env]);
-                        line = want < kMaxLine ? want : kMaxLine;
-                    } else {
-                        line = pkd_line(s_unit[i]);
-                    }
-                    level_block<false, false>(ctx, sa, (int64_t) k * N + env, line);
-                }
-            } else if (role == 2) {
-                for (int i = lane; i < epb; i += 64)
-                    if (env_first + i < N) level_block<false, false>(ctx, sa, 2 * (int64_t) N + env_first + i);
-            }
+            draw_next_step(role, ctx, sa, pa, s_unit);  // (waves 0 / 1; the queue lengths are the admission's: in s_unit since the third barrier)
             __syncthreads();  // #4
         }
         return;  // (a wave that has ended no longer counts at the workgroup's barrier: the tail wave runs the last step's records and tails by itself)
@@ -3804,26 +3791,8 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void k_steps_piped(const DevCtx *__r
         const bool live = lane < epb && env < N;
         TailIn tin = TailIn();
         if (live) tail_prefetch(tin, ta, (uint32_t) env, sa.fresh == 0);
-        double r_pv[2], r_pvn[2], r_wd[3], r_wdn[3], r_hy[2];
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int i = lane + 64 * q;
-            r_pv[q] = r_pvn[q] = r_hy[q] = 0.0;
-            if (i < 100) {
-                r_pv[q] = ta.pv_row[i];
-                r_pvn[q] = ta.pv_row_now[i];
-            }
-            if (i < 102 && s == 1) r_hy[q] = ta.hy_table[i];  // (the hydrogen table does not change: parked once)
-        }
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            const int i = lane + 64 * q;
-            r_wd[q] = r_wdn[q] = 0.0;
-            if (i < 150) {
-                r_wd[q] = ta.wd_row[i];
-                r_wdn[q] = ta.wd_row_now[i];
-            }
-        }
+        TailWaveRows tr;
+        tr.request(ta, s == 1);  // (the hydrogen table does not change: parked once)
         const bool stamp_on = blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s == n - 2;
         (void) stamp_on;
         PIPED_STAMP(0);
@@ -3834,26 +3803,7 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void k_steps_piped(const DevCtx *__r
         PIPED_STAMP(2);
         __syncthreads();  // #2
         PIPED_STAMP(3);
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int i = lane + 64 * q;
-            if (i < 100) {
-                s_pv[i] = r_pv[q];
-                s_pv_now[i] = r_pvn[q];
-            }
-            if (i < 102 && s == 1) s_hy[i] = r_hy[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            const int i = lane + 64 * q;
-            if (i < 150) {
-                s_wd[i] = r_wd[q];
-                s_wd_now[i] = r_wdn[q];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the wave's own LDS rows and records, read back by other lanes of it)
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        tr.park(s_pv, s_wd, s_pv_now, s_wd_now, s_hy, s == 1);  // (its wave-level fence also covers the records above: read back by other lanes of this wave)
         int rows = epb < 64 ? epb : 64;
         rows = N - env_first < rows ? N - env_first : rows;
         PipedMid mid{stamp_on};  // #3 (at1: behind the forecourt), #4 (at3: in front of the flush)

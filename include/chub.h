@@ -75,7 +75,8 @@ typedef struct chub_options {
                              1 = one kernel per station with the unit's first lane walking (bit-identical; the parity cross-check) */
     int32_t no_arena;     /* 1: one hipMalloc per array instead of one arena (disables chub_get_state / chub_set_state) */
     int32_t fused_step;   /* PHILOX lock-step steps as ONE launch (slot work + per-env tail + next step's draws per workgroup):
-                             0 = for small batches, where the two step kernels are launch-bound (default), 1 = never, 2 = always
+                             0 = for small batches, where the two step kernels are launch-bound (default: up to 768 slot workgroups; hubs of fewer than 8 piles
+                             up to 384), 1 = never, 2 = always
                              (hub shapes the packed slot kernel covers, stations of at most 64 piles).  Results are bit-identical.
                              COMPAT handles whose envs all fit one workgroup (the drop-in class: one env) run reset and step as one
                              launch too -- station 0, station 1, tail back to back -- unless this is 1. */
@@ -133,7 +134,7 @@ int chub_act_dim(const chub_env *env);  /* S + 2 (MGR:108-113) */
 int64_t chub_num_envs(const chub_env *env);
 int chub_clock(const chub_env *env);    /* 0..95: the slot of day, shared by all envs while they run in lock-step (env 0's otherwise) */
 int chub_uses_packed_kernel(const chub_env *env); /* 1: PHILOX steps of this handle run k_slot_packed (the production kernel) */
-int chub_uses_fused_step(const chub_env *env);    /* 1: its lock-step steps run as one launch (k_step_fused / k_compat_small, small batches) */
+int chub_uses_fused_step(const chub_env *env);    /* 1: its lock-step steps run as one launch (k_step_tailwave / k_step_fused / k_compat_small, small batches) */
 int chub_uses_xcd_order(const chub_env *env);     /* 1: its packed kernels' workgroups take their work in XCD-aware order (chub_options.work_order) */
 
 /* ---- hot path ------------------------------------------------------------------------------
@@ -279,7 +280,7 @@ int chub_step_gather(chub_env *env, chub_comm *comm, const float *d_actions, flo
  * chub_step_device_packed, with actions d_action_batches[i % n_batches] and outputs d_packed2[i & 1] / d_gathered2[i & 1].  Exactly
  * the RESULTS of the calls a host loop would make (PHILOX handles); returns after enqueueing.  Without a communicator, on a handle that
  * runs the one-launch step (chub_uses_fused_step: small batches) and with at most 8 action batches, consecutive lock-step steps go out as
- * ONE launch per span (k_steps_fused; chub_options.span_steps) -- a span ends where the call does, at a reset and where the handle's clock
+ * ONE launch per span (k_steps_piped / k_steps_fused; chub_options.span_steps, span_tails) -- a span ends where the call does, at a reset and where the handle's clock
  * wraps; only the span's last two packed blocks exist afterwards, as after the same steps issued one by one.  Not under the per-kernel
  * profiler, with telemetry on, with a tape loaded or on per-env clocks: every step is then a launch of its own. */
 int chub_run_steps(chub_env *env, chub_comm *comm, const float *const *d_action_batches, int n_batches, float *const *d_packed2,
