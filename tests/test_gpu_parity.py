@@ -1493,3 +1493,21 @@ def test_spans_of_steps_in_one_launch_are_bit_identical(label):
         assert len(res[form]) == len(res[FORMS[0]])
         for k, (a, b) in enumerate(zip(res[FORMS[0]], res[form])):
             assert np.array_equal(a, b), (label, "spans", form, "vs every step a launch: array", k)
+
+
+def test_one_launch_forms_on_random_hub_shapes():
+    """tools/experiments/shape_sweep.py on 14 random hub shapes and batch sizes (stations of 0 .. 64 piles of both kinds in both places, hubs of
+    fewer than 8 piles, 37 .. 5000 envs): every step a launch with the one-launch step forced (k_step_tailwave / k_step_fused), spans with the
+    tails on the last slot wave (k_steps_fused), on a wave of their own (k_steps_piped; refused below 8 piles) and of at most 5 steps -- against
+    the two-launch step (k_slot_packed + k_env), every packed block, slot state and station records bit for bit."""
+    import os
+    import runpy
+    import sys
+    argv = sys.argv
+    sys.argv = ["shape_sweep.py", "14", "3"]
+    try:
+        with pytest.raises(SystemExit) as ex:
+            runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "experiments", "shape_sweep.py"), run_name="__main__")
+    finally:
+        sys.argv = argv
+    assert ex.value.code == 0
