@@ -54,6 +54,24 @@ def test_telemetry_columns_and_option_struct_match_the_header():
     assert C.sizeof(_lib.ChubOptions) == 32
 
 
+def test_option_values_are_validated_before_any_device_call():
+    """chub_create_ex refuses out-of-range chub_options with CHUB_ERR_ARG and a message naming the field, GPU or not (the option checks come
+    before the device is looked for)"""
+    m = chub()
+    lib = m.load_library()
+    from charginghub_env_amd import _lib
+    good = m.make_config([20, 25], ["fast", "slow"])
+    data = _lib.DATA_DIR.encode()
+    for field, bad in (("slot_kernel", 3), ("fused_step", -1), ("tile", 3), ("walk_ahead", 2), ("work_order", 2), ("span_steps", 97), ("span_steps", -1),
+                       ("span_tails", 3), ("span_tails", -1)):
+        opt = _lib.ChubOptions()
+        setattr(opt, field, bad)
+        h = C.c_void_p()
+        assert lib.chub_create_ex(C.byref(good), data, 4, 0, 0, 1, _lib.RNG_PHILOX, C.byref(opt), C.byref(h)) == -1, field
+        assert ("chub_options." + field).encode() in lib.chub_last_error(), (field, lib.chub_last_error())
+        assert not h.value
+
+
 def test_create_fails_loudly_without_gpu_and_validates_arguments():
     m = chub()
     lib = m.load_library()
