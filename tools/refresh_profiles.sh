@@ -128,5 +128,10 @@ echo "kernel trace done"
 rocprofv3 --kernel-trace --stats -d $OUT/kt5 --output-format csv -- python3 bench.py --config c5 --no-cpu-baseline > $OUT/${ROUND}_${TAG}_bench_c5_under_rocprof.json 2> $OUT/kt5.err
 cp $(find $OUT/kt5 -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats_c5.csv
 echo "c5 kernel trace done"
+# (round 6) C2, the small batch: every step a launch (k_step_tailwave) and spans of steps in one launch (k_steps_piped: one launch = up to 96 steps)
+rocprofv3 --kernel-trace --stats -d $OUT/kt2 --output-format csv -- python3 tools/span_rate.py --config c2 --days 6 > $OUT/${ROUND}_${TAG}_span_rate_c2_under_rocprof.txt 2> $OUT/kt2.err
+cp $(find $OUT/kt2 -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats_c2.csv
+rm -rf $OUT/kt2
+echo "c2 kernel trace done"
 rm -rf $OUT/kt $OUT/kt5 $OUT/ktc $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_tcc $OUT/pmc_tcp $OUT/pmc_fetch_c5 $OUT/pmc_write_c5 $OUT/pmc_fetch_compat $OUT/pmc_write_compat $OUT/pmc_sq_compat
 ls $OUT
