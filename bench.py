@@ -65,6 +65,8 @@ N_ACTION_BATCHES = 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 GRAPH_EPISODES = 2     # episodes per captured graph: 2 resets + 192 steps = an even number of launches (double-buffered draws)
 DAY_AVG_DAYS = 10      # whole days behind `value_day_avg` (the same launch form as the timed region, after it)
+SUSTAIN_SECONDS = 2.0  # ... and, where that form is a captured graph, this long of the same replays behind `sustained`: a stretch of GPU time long
+                       # enough for an outside clock or a busy-percentage sampler to see (the timed region and the ten days are milliseconds)
 SPAN_GRAPH_MAX = 1920  # a timed region of up to this many steps is captured as ONE graph of exactly those steps
 
 
@@ -598,6 +600,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the untimed profiled day (no `roofline` block)")
     ap.add_argument("--no-day-avg", action="store_true", help="skip the untimed ten days behind value_day_avg / ms_per_step_day_avg")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the two seconds of graph replays behind `sustained` (counter and trace passes: "
+                                                                  "every replayed kernel is a record)")
     ap.add_argument("--no-c5", action="store_true", help="skip the secondary roofline_c5 block")
     ap.add_argument("--no-bits", action="store_true", help="skip the secondary packed_actions block (one bit per pile as the action input)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the secondary dropin_single_env block (the reference-shaped class at one env, COMPAT mode as a batch)")
@@ -807,6 +811,7 @@ def main():
     # the driver's short form (--steps 20 --warmup 5) times slots 5..24 of a day, a night-time window in which few cars arrive and the
     # slot kernel runs 3 % under its day average; this figure does not depend on where a window falls
     day_avg = None
+    sustained = None
     if not args.no_day_avg:
         span(i, (-i) % 96)
         i += (-i) % 96
@@ -832,6 +837,18 @@ def main():
         if comm is not None:
             dt_days = comm.max(dt_days, stream.ptr)
         day_avg = (dt_days / (96 * DAY_AVG_DAYS), "hipGraph replays of %d episodes" % GRAPH_EPISODES if g_days is not None else "every step a call (issued from C)")
+        if g_days is not None and not args.no_sustained and not args.no_events:
+            reps = max(1, int(round(SUSTAIN_SECONDS / (dt_days / (DAY_AVG_DAYS // GRAPH_EPISODES)))))
+            fence()
+            t2 = time.perf_counter()
+            for _ in range(reps):
+                v.graph_launch(g_days, stream.ptr)
+            fence()
+            dt_sus = time.perf_counter() - t2
+            if comm is not None:
+                dt_sus = comm.max(dt_sus, stream.ptr)
+            i += per_graph * reps
+            sustained = (dt_sus, per_graph * reps)
         if g_days is not None and g_days is not episode_graph:
             v.graph_destroy(g_days)
     # ---- with a communicator: the step taken apart per rank, so that a measured point explains itself -- this rank's kernels (the
@@ -924,6 +941,11 @@ def main():
                                       "not depend on which slots of the day a short timed window covers" % (DAY_AVG_DAYS, 96 * DAY_AVG_DAYS),
                               "days": DAY_AVG_DAYS, "launch": day_avg[1],
                               "roofline_step_frac": (slot_b + env_b) * per / day_avg[0] / 1e9 / HBM_PEAK_GBS}
+        if sustained is not None:
+            out["sustained"] = {"what": "the same graph replayed back to back for about %.0f s after everything else (untimed by the contract): whole days, resets "
+                                        "included -- GPU time an outside clock can see" % SUSTAIN_SECONDS,
+                                "seconds": sustained[0], "steps": sustained[1], "value": total * sustained[1] / sustained[0],
+                                "ms_per_step": sustained[0] / sustained[1] * 1e3}
         if phases is not None:
             # what the builder expects of this configuration, from its own parts: a step cannot be shorter than the slowest rank's
             # kernels + one gather (GPU side) nor than the slowest rank's host issue time (call by call, the host issues two kernel

@@ -81,6 +81,7 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(r["frac_of_traffic"] - r["traffic"] / (r["avg_launch_us"] * 1e-6) / 8e12) < 1e-12 and r["frac_of_layout"] < r["frac_of_traffic"] < r["frac"]
     assert d["day_avg"]["days"] == 10 and abs(d["value_day_avg"] - 65536 / (d["ms_per_step_day_avg"] * 1e-3)) < 1e-6 * d["value_day_avg"]
     assert abs(d["value_day_avg"] / d["value"] - 1) < 0.05
+    assert d["sustained"]["seconds"] > 1.0 and abs(d["sustained"]["value"] / d["value_day_avg"] - 1) < 0.03
     assert rc["traffic_source"] == os.path.basename(lines[-1]).replace("_bench.json", "_pmc_compat.json") and 1.0 < rc["traffic_over_algorithmic"] < 2.5
     assert len(rc["end_state_digest"]) == 32 and rc["days_stepped"] == 8
     assert "COMPAT" in d["cpu_baseline"]["sample"]

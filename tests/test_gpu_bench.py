@@ -47,6 +47,10 @@ def test_bench_short_form_prints_the_contract_line():
     assert d["day_avg"]["days"] == 10 and d["day_avg"]["launch"].startswith("hipGraph replays")
     assert abs(d["value_day_avg"] - 65536 / (d["ms_per_step_day_avg"] * 1e-3)) < 1e-6 * d["value_day_avg"]
     assert 0.8 * d["value"] < d["value_day_avg"] < 1.1 * d["value"] and d["value_day_avg"] > 5e8
+    # ... and about two seconds of the same graph replays: GPU time an outside clock can see, at the ten days' rate
+    su = d["sustained"]
+    assert 1.0 < su["seconds"] < 5.0 and su["steps"] % 192 == 0 and abs(su["value"] - 65536 * su["steps"] / su["seconds"]) < 1e-6 * su["value"]
+    assert abs(su["value"] / d["value_day_avg"] - 1) < 0.05
 
 
 def test_bench_compat_block_carries_the_end_state_of_the_reference_exact_run():

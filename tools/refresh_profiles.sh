@@ -9,7 +9,7 @@ ROUND=${ROUND:-round6}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 192 --warmup 96 --no-cpu-baseline --no-events"
+ARGS="--steps 192 --warmup 96 --no-cpu-baseline --no-events --no-sustained"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch --output-format csv -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write --output-format csv -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_write.err
@@ -120,12 +120,12 @@ PY
 cp $OUT/${ROUND}_${TAG}_pmc_traffic.json $OUT/${ROUND}_${TAG}_pmc_traffic_c5.json $OUT/${ROUND}_${TAG}_pmc_compat.json profiles/
 python3 bench.py > $OUT/${ROUND}_${TAG}_bench.json 2> $OUT/bench.err
 echo "bench done"; tail -c 400 $OUT/${ROUND}_${TAG}_bench.json; echo
-rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 > $OUT/${ROUND}_${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 --no-sustained > $OUT/${ROUND}_${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats.csv
 echo "kernel trace done"
 # ---- round 5: the two workloads whose fractions the bench line quotes without a rocprof summary so far
 # (1) C5 as the bench's own workload (262 144 envs x [32, 32]): kernel-trace stats, to check roofline_c5.avg_launch_us against
-rocprofv3 --kernel-trace --stats -d $OUT/kt5 --output-format csv -- python3 bench.py --config c5 --no-cpu-baseline > $OUT/${ROUND}_${TAG}_bench_c5_under_rocprof.json 2> $OUT/kt5.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt5 --output-format csv -- python3 bench.py --config c5 --no-cpu-baseline --no-sustained > $OUT/${ROUND}_${TAG}_bench_c5_under_rocprof.json 2> $OUT/kt5.err
 cp $(find $OUT/kt5 -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_${TAG}_kernel_stats_c5.csv
 echo "c5 kernel trace done"
 # (round 6) C2, the small batch: every step a launch (k_step_tailwave) and spans of steps in one launch (k_steps_piped: one launch = up to 96 steps)
