@@ -26,7 +26,8 @@ namespace chub {
 
 constexpr int kMaxLine = 10;     // Station::max_line, CHS.hpp:197
 constexpr int kLevels = 1000;    // RandomUtil::uniform_rand has 1000 levels k/999, CHS.hpp:35-44
-constexpr int kBalkTab = 512;
+constexpr int kBalkTab = 1024;   // balk thresholds by queue place, expf(-0.01 m) against the 1000 levels: 0 from m = 691 on, so the last entry stands for every m beyond
+constexpr int kMaxPiles = 4096;  // piles per station (k_slot_unit_any: a unit of more than 256 piles is walked in chunks; its scalar-load control ranks the whole unit in LDS)
 constexpr int kSocLevels = 2048;   // PHILOX: equiprobable classes of the EV arrival SoC (top 11 bits of a Philox word): the class
                                    // tables of both stations (768 KB) stay resident in every XCD's L2 next to the streamed state
 constexpr int kSocLevelShift = 21;

@@ -1438,6 +1438,380 @@ __global__ __launch_bounds__(256) void k_slot_unit(const DevCtx *__restrict__ ct
     }
 }
 
+// ---------------------------------------------------------------------------------------- k_slot_unit_any: a unit of any size
+// Stations of more than 256 piles (the reference's constructors take any count, CHS.hpp:1148, 1458).  One (env, station) unit = ONE
+// workgroup of 256 lanes that goes over the unit's piles in chunks of 256, in slot order, in two passes with the slot records
+// themselves (global memory; every lane re-reads only what it wrote) as the state between them:
+//   pass 1  per chunk: on / off, car_step, departures, the record written back; the unit's empty slots counted
+//   lane 0  arrivals / renege / balk / how many are admitted (receive_car; COMPAT: the env's streams in the reference's order)
+//   pass 2  per chunk: admission by rank (COMPAT: lane 0 draws the chunk's new cars' variates, in rank order, as it gets there),
+//           add_car, then calculate_output: lane 0 adds the chunk's slot powers to the running sums IN SLOT ORDER (COMPAT: the
+//           reference's sequential f32 sums; PHILOX: 64-bit integers)
+// The scalar-load control (evs_step(float)) ranks every pile of the unit by urgency first: three arrays over the whole unit in
+// LDS, hence kMaxPiles.  A parity instrument like k_slot_unit (same phases, same arithmetic), not a fast path.
+template <bool RESET, int MODE>
+__global__ __launch_bounds__(256) void k_slot_unit_any(const DevCtx *__restrict__ ctx, StepArgs sa, int k) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const HubParams &hp = ctx->hp;
+    const SlotArrays &sl = ctx->sl;
+    const StationArrays &st = ctx->st;
+    const Tables &tb = ctx->tb;
+    __shared__ float s_a[256], s_b[256], s_c[256];  // the chunk's min / charge / max power per slot (COMPAT)
+    __shared__ uint32_t s_u[256], s_v[256], s_w[256];  // ... as integers (PHILOX); COMPAT: s_v / s_w = level, late time by admission rank
+    __shared__ float s_soc[256];                    // COMPAT: arrival SoC by admission rank within the chunk
+    __shared__ uint64_t s_ball[8];
+    __shared__ int s_hdr[4];
+    __shared__ int s_cnt;
+    __shared__ float s_em[kMaxPiles], s_pw[kMaxPiles];    // load mode: emergency by slot; power by urgency rank -> running sum
+    __shared__ uint16_t s_cb[kMaxPiles], s_rk[kMaxPiles]; // ... cars by urgency rank -> cars before the rank; urgency rank by slot
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int env = (int) blockIdx.x;
+    const int64_t N = hp.n_envs;
+    if (!in_group(sa, env)) return;  // the whole workgroup: nothing of an env that is not served is touched
+    const int S = hp.S[k], chunks = (S + 255) >> 8;
+    const bool fast = hp.type[k] == 0, cp = hp.constant_charging != 0;
+    const int hub0 = k ? hp.S[0] : 0;
+    const uint32_t idx0 = MODE == MODE_PHILOX ? (uint32_t) env * (uint32_t) (hp.S[0] + hp.S[1]) + (uint32_t) hub0
+                                              : (uint32_t) hp.base[k] + (uint32_t) env * (uint32_t) S;
+    const uint32_t sidx = (uint32_t) k * (uint32_t) N + (uint32_t) env;
+    CHUB_G(const float) cls = tb.cls[k];
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+
+    // ---- scalar-load control (assign_on_off, CHS.hpp:1318-1362 / 1629-1674): the piles in urgency order (std::multimap keyed by
+    // -emergency: ties in slot order), switched on until the target is met
+    float load = 0.0f;
+    if (!RESET && sa.load_mode) {
+        for (int slot = tid; slot < S; slot += 256) {
+            const uint32_t idx = idx0 + (uint32_t) slot;
+            float t_target = 0.0f, t_soc = 0.0f;
+            int tl;
+            if (MODE == MODE_COMPAT) {
+                const u32x4 hot = ((CHUB_G(u32x4)) sl.hot)[idx];
+                t_soc = __uint_as_float(hot.z);
+                tl = (int) (hot.w & 127u);
+                if (tl > 0) t_target = tb.ttab[k][hot_level(hot.w)];
+            } else {
+                const uint32_t w0 = sl.hot[idx];
+                tl = ps_tl(w0);
+                if (tl > 0) {
+                    t_soc = (*(CHUB_G(const f32x2)) ((CHUB_G(const char)) cls + ((size_t) ps_cls(w0) * (kClsRow * 8u) + ps_n(w0) * 8u))).y;
+                    t_target = tb.ttab[k][ps_lev(w0)];
+                }
+            }
+            s_em[slot] = tl > 0 ? emergency_of(t_target, t_soc, tl) : 0.0f;
+        }
+        __syncthreads();
+        for (int slot = tid; slot < S; slot += 256) {
+            const uint32_t idx = idx0 + (uint32_t) slot;
+            float power = 0.0f;
+            bool car;
+            if (MODE == MODE_COMPAT) {
+                const u32x4 hot = ((CHUB_G(u32x4)) sl.hot)[idx];
+                car = (hot.w & 127u) != 0u;
+                power = __uint_as_float(hot.x);
+            } else {
+                const uint32_t w0 = sl.hot[idx];
+                car = ps_tl(w0) > 0;
+                if (car) power = (*(CHUB_G(const f32x2)) ((CHUB_G(const char)) cls + ((size_t) ps_cls(w0) * (kClsRow * 8u) + ps_n(w0) * 8u))).x;
+            }
+            const float em0 = s_em[slot];
+            int rk = 0;
+            for (int j = 0; j < S; j++) {
+                const float ej = s_em[j];
+                rk += (ej > em0 || (ej == em0 && j < slot)) ? 1 : 0;
+            }
+            s_rk[slot] = (uint16_t) rk;
+            s_pw[rk] = car ? power : 0.0f;
+            s_cb[rk] = car ? 1 : 0;
+        }
+        __syncthreads();
+        // catch_load (CHS.hpp:358-366) against the previous calculate_output; rank_power_add (CHS.hpp:1375-1402): sequential f32
+        const StationRec pr = rec_load(st.rec, sidx);
+        load = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) hub0];
+        if (load > pr.mx) load = pr.mx;
+        else if (load < pr.mn) load = pr.mn;
+        if (tid == 0) {
+            float cum = 0.0f;
+            int cars_before = 0;
+            for (int q = 0; q < S; q++) {
+                const int c = (int) s_cb[q];
+                cum = __fadd_rn(cum, s_pw[q]);
+                s_pw[q] = cum;                        // the running sum up to and including rank q
+                s_cb[q] = (uint16_t) cars_before;     // cars of a higher urgency
+                cars_before += c;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- pass 1: the slots as the previous step left them -> on / off, car_step, departures
+    for (int c = 0; c < chunks; c++) {
+        const int slot = (c << 8) + tid;
+        const bool valid = slot < S;
+        const uint32_t idx = idx0 + (uint32_t) slot;
+        float power = 0.0f, t_target = 0.0f, t_soc = 0.0f, arr_soc = 0.0f, a = 0.0f;
+        int tl = 0, meta = 0;
+        uint32_t w0 = 0u;
+        if (!RESET && valid) {
+            a = sa.actions[(uint32_t) env * (uint32_t) hp.act_dim + (uint32_t) (hub0 + slot)];
+            if (MODE == MODE_COMPAT) {
+                const u32x4 hot = ((CHUB_G(u32x4)) sl.hot)[idx];
+                power = __uint_as_float(hot.x); arr_soc = __uint_as_float(hot.y); t_soc = __uint_as_float(hot.z);
+                tl = (int) (hot.w & 127u);
+                meta = (int) (hot.w >> 8);
+                if (tl > 0) t_target = tb.ttab[k][hot_level(hot.w)];
+            } else {
+                w0 = sl.hot[idx];
+                tl = ps_tl(w0);
+                if (tl > 0) {  // (the state word says the rest: a car_step is one more entry along the class row)
+                    t_soc = (*(CHUB_G(const f32x2)) ((CHUB_G(const char)) cls + ((size_t) ps_cls(w0) * (kClsRow * 8u) + ps_n(w0) * 8u))).y;
+                    t_target = tb.ttab[k][ps_lev(w0)];
+                }
+            }
+        }
+        bool car = tl > 0;
+        bool on;
+        if (!RESET && sa.load_mode) {
+            on = false;
+            if (car) {
+                const int rk = (int) s_rk[slot];
+                if (cp) {
+                    const float constant_power = fast ? (float) 36.44764034125146 : (float) 5.254973139368931;
+                    const int n_on = (int) roundf(__fdiv_rn(load, constant_power));
+                    on = (int) s_cb[rk] < n_on;
+                } else {
+                    on = (double) load + 0.0001 >= (double) s_pw[rk];
+                }
+            }
+        } else {
+            on = car && (a >= kActOnThreshold || must_charge(t_target, t_soc, tl));
+        }
+        // car_step (CHS.hpp:900-905 / 1065-1070), remove_car (CHS.hpp:912-923 / 1077-1088)
+        if (MODE == MODE_COMPAT) {
+            if (on) {
+                meta += 1 << 17;
+                float soc_new;
+                const float tt = __fadd_rn(t_soc, 1.0f);
+                if (fast) {
+                    car_step_curves<0>(tt, cp, hp.cc, soc_new, power);
+                    t_soc = soc_to_time<0>(soc_new, cp);
+                } else {
+                    car_step_curves<1>(tt, cp, hp.cc, soc_new, power);
+                    t_soc = soc_to_time<1>(soc_new, cp);
+                }
+            }
+            if (car) {
+                tl -= 1;
+                if (tl <= 0) {
+                    car = false; tl = 0;
+                    power = t_soc = arr_soc = 0.0f;
+                    meta = 0;
+                }
+            }
+            if (RESET) meta = 0;
+        } else {
+            if (on && tl > 1) w0 += kPsStep;  // a car that leaves this step is wiped right after its car_step (CHS.hpp:1196-1201)
+            w0 &= ~kPsChg;
+            if (car) {
+                tl -= 1;
+                w0 -= 1u;
+                if (tl <= 0) { car = false; w0 = 0u; }
+            }
+            if (RESET) w0 = 0u;
+        }
+        const bool charge = on && car;
+        if (valid) {
+            if (MODE == MODE_COMPAT) {
+                u32x4 h2;
+                h2.x = __float_as_uint(power); h2.y = __float_as_uint(arr_soc); h2.z = __float_as_uint(t_soc);
+                h2.w = (uint32_t) tl | (charge ? 128u : 0u) | ((uint32_t) meta << 8);
+                ((CHUB_G(u32x4)) sl.hot)[idx] = h2;
+            } else {
+                sl.hot[idx] = charge ? (w0 | kPsChg) : w0;
+            }
+        }
+        const uint64_t be = __ballot(valid && !car);
+        if (lane == 0 && be) atomicAdd(&s_cnt, __popcll(be));
+    }
+    __syncthreads();
+    const int empties = s_cnt;
+
+    // ---- receive_car (CHS.hpp:1272-1316 / 1583-1627): lane 0 decides how many cars the unit admits
+    CompatStream rs;
+    if (tid == 0) {
+        int line = (RESET || MODE == MODE_PHILOX) ? 0 : pkd_line(st.rec[4u * sidx + 3u]);
+        int flow, assign;
+        if (MODE == MODE_COMPAT) {
+            rs.load(ctx->cr, sa.rng_cur, env);
+            const int mu = S / 2;  // round(charge_number / 2) on ints, CHS.hpp:1276
+            int n_in;
+            if (RESET) {
+                int temp = (int) roundf(rs.normal_f((float) mu, 1.0f));
+                n_in = temp > mu + 3 ? mu + 3 : (temp < mu - 3 ? mu - 3 : temp);
+            } else {
+                const int t_env = sa.env_clk ? clk_t(env_clk(sa, N, env)) : sa.t;
+                n_in = (int) tb.cnt[k][t_env * kLevels + rs.level()];
+            }
+            int tline = 0;
+            for (int w = 0; w < line; w++) tline += (rs.level() >= (int) tb.thr_renege[w]) ? 1 : 0;
+            line = tline;
+            int true_in = 0;
+            for (int j = 0; j < n_in; j++) {
+                const int m = line + j;
+                const int thr = (int) tb.thr_balk[m < kBalkTab ? m : kBalkTab - 1];
+                true_in += (rs.level() <= thr && j <= S) ? 1 : 0;
+            }
+            flow = fast ? n_in : true_in;  // CHS.hpp:1617 / 1306
+            assign = (line + flow) < empties ? (line + flow) : empties;
+            line = line + flow - assign;
+            line = line < kMaxLine ? line : kMaxLine;
+        } else {
+            const uint32_t pk = st.pk[sa.tick & 1u][sidx];
+            int want;
+            if (RESET) {
+                flow = fast ? (int) (int16_t) (pk & 0xFFFFu) : (int) ((pk >> 16) & 0xFFFFu);
+                want = flow;
+            } else {
+                want = dk_want(pk);
+                flow = dk_flow(pk);
+            }
+            assign = want < empties ? want : empties;
+            line = want - assign;
+            line = line < kMaxLine ? line : kMaxLine;
+        }
+        s_hdr[0] = assign; s_hdr[1] = flow; s_hdr[2] = line;
+    }
+    __syncthreads();
+    const int assign = s_hdr[0];
+
+    // ---- pass 2: admission by rank, add_car (CHS.hpp:864-877 / 1029-1042), calculate_output (CHS.hpp:1233-1261 / 1544-1572)
+    int base = 0, cars = 0;                     // empties / cars of the chunks in front (the same number in every lane)
+    float r_min = 0.0f, r_chg = 0.0f, r_max = 0.0f;   // lane 0: the running sums
+    long long i_min = 0, i_chg = 0, i_max = 0;
+    for (int c = 0; c < chunks; c++) {
+        const int slot = (c << 8) + tid;
+        const bool valid = slot < S;
+        const uint32_t idx = idx0 + (uint32_t) slot;
+        float power = 0.0f, t_target = 0.0f, t_soc = 0.0f;
+        int tl = 0;
+        bool charge = false;
+        if (valid) {  // what pass 1 left (this lane's own stores)
+            if (MODE == MODE_COMPAT) {
+                const u32x4 hot = ((CHUB_G(u32x4)) sl.hot)[idx];
+                power = __uint_as_float(hot.x); t_soc = __uint_as_float(hot.z);
+                tl = (int) (hot.w & 127u);
+                charge = (hot.w & 128u) != 0u;
+                if (tl > 0) t_target = tb.ttab[k][hot_level(hot.w)];
+            } else {
+                const uint32_t w0 = sl.hot[idx];
+                tl = ps_tl(w0);
+                charge = (w0 & kPsChg) != 0u;
+                if (tl > 0) {
+                    const f32x2 row = *(CHUB_G(const f32x2)) ((CHUB_G(const char)) cls + ((size_t) ps_cls(w0) * (kClsRow * 8u) + ps_n(w0) * 8u));
+                    power = row.x; t_soc = row.y;
+                    t_target = tb.ttab[k][ps_lev(w0)];
+                }
+            }
+        }
+        bool car = tl > 0;
+        const bool empty = valid && !car;
+        const uint64_t be = __ballot(empty);
+        if (lane == 0) s_ball[wave] = be;
+        __syncthreads();
+        int chunk_empties = 0, rank = base + prefix_count(be);
+        for (int w = 0; w < 4; w++) {
+            const int n = __popcll(s_ball[w]);
+            chunk_empties += n;
+            rank += w < wave ? n : 0;
+        }
+        if (MODE == MODE_COMPAT) {
+            if (tid == 0) {  // the chunk's new cars, ascending slot order == ascending rank
+                int n_new = assign - base;
+                n_new = n_new < 0 ? 0 : (n_new > chunk_empties ? chunk_empties : n_new);
+                for (int rr = 0; rr < n_new; rr++) {
+                    s_soc[rr] = arrive_soc_from(rs.normal_d(7.0, 3.0));
+                    s_v[rr] = (uint32_t) rs.level();
+                    const int late = (int) roundf(rs.normal_f(2.0f, 2.0f));  // mk_late_time("slow"), CHS.hpp:816-830
+                    s_w[rr] = (uint32_t) (late < 0 ? 0 : late);
+                }
+            }
+            __syncthreads();
+        }
+        if (empty && rank < assign) {
+            if (MODE == MODE_COMPAT) {
+                const int r = rank - base;
+                const int lev = (int) s_v[r];
+                const float target = uniform_level(lev, 80.0f, 100.0f);
+                const NewCar nc = fast ? make_car<0>(s_soc[r], lev, soc_to_time<0>(target, cp), (int) s_w[r], cp)
+                                       : make_car<1>(s_soc[r], lev, soc_to_time<1>(target, cp), (int) s_w[r], cp);
+                t_target = nc.t_target; t_soc = nc.t_soc; tl = nc.stay; power = nc.power;
+                car = tl > 0;
+                u32x4 h2;
+                h2.x = __float_as_uint(power); h2.y = __float_as_uint(nc.soc); h2.z = __float_as_uint(t_soc);
+                h2.w = (uint32_t) tl | ((uint32_t) (nc.stay | (nc.lev << 7)) << 8);
+                ((CHUB_G(u32x4)) sl.hot)[idx] = h2;
+            } else {
+                PhiloxCtx px{hp.key[0], hp.key[1], CHUB_TICK(hp, sa.tick), (uint32_t) (hp.env_id0 + env)};
+                const U4 o = px.block(SITE_SOC, (uint32_t) (hub0 + slot), 0);
+                const uint32_t cl = o.v[0] >> kSocLevelShift, lev = o.v[1] % 1000u;
+                const f32x2 e0 = *(CHUB_G(const f32x2)) ((CHUB_G(const char)) cls + (size_t) cl * (kClsRow * 8u));
+                t_target = tb.ttab[k][lev];
+                const int late = late_from_word(tb.late_thr, o.v[2]);
+                int stay = (int) ceilf(__fsub_rn(t_target, e0.y)) + late;
+                stay = stay > kMaxStay ? kMaxStay : stay;
+                power = e0.x; t_soc = e0.y; tl = stay;
+                car = tl > 0;
+                sl.hot[idx] = car ? ps_make(stay, cl, lev) : 0u;
+                sl.stay8[idx] = (uint8_t) stay;
+            }
+        }
+        const bool urgent = car && must_charge(t_target, t_soc, tl);
+        const uint64_t bc = __ballot(car);
+        if (lane == 0) s_ball[4 + wave] = bc;
+        if (MODE == MODE_COMPAT) {
+            s_a[tid] = urgent ? power : 0.0f;
+            s_b[tid] = charge ? power : 0.0f;
+            s_c[tid] = car ? power : 0.0f;
+        } else {
+            const int q = kw_to_fixed(power);
+            s_u[tid] = (uint32_t) (urgent ? q : 0);
+            s_v[tid] = (uint32_t) (charge ? q : 0);
+            s_w[tid] = (uint32_t) (car ? q : 0);
+        }
+        __syncthreads();
+        cars += __popcll(s_ball[4]) + __popcll(s_ball[5]) + __popcll(s_ball[6]) + __popcll(s_ball[7]);
+        if (tid == 0) {
+            const int n = S - (c << 8) < 256 ? S - (c << 8) : 256;
+            if (MODE == MODE_COMPAT) {  // the reference adds the slot powers sequentially in f32 (CHS.hpp:1244-1255)
+                for (int i = 0; i < n; i++) {
+                    r_max = __fadd_rn(r_max, s_c[i]);
+                    r_min = __fadd_rn(r_min, s_a[i]);
+                    r_chg = __fadd_rn(r_chg, s_b[i]);
+                }
+            } else {  // order-independent: 64-bit sums of the slot powers in units of 2^-19 kW, one rounding to f32
+                for (int i = 0; i < n; i++) {
+                    i_min += (long long) (int) s_u[i];
+                    i_chg += (long long) (int) s_v[i];
+                    i_max += (long long) (int) s_w[i];
+                }
+            }
+        }
+        base += chunk_empties;
+        __syncthreads();  // the chunk's LDS areas are free again
+    }
+    if (tid == 0) {
+        if (MODE == MODE_COMPAT) {
+            rs.store(ctx->cr, sa.rng_cur, env);
+        } else {
+            r_min = (float) i_min * (1.0f / 524288.0f);
+            r_chg = (float) i_chg * (1.0f / 524288.0f);
+            r_max = (float) i_max * (1.0f / 524288.0f);
+        }
+        rec_store(st.rec, sidx, r_min, r_chg, r_max, pkd_make(s_hdr[2], s_hdr[1], cars));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // k_slot_packed: the PHILOX step (production).  PHILOX slot state is laid out hub-major, [env][hub slot] (station 0's piles,
 // then station 1's), like the action rows: the workgroup's BLOCK * T virtual lanes map onto epb = BLOCK * T / (S0 + S1) whole
@@ -4100,7 +4474,8 @@ static void launch_slot_t(const HubParams &hp, const DevCtx *ctx, const StepArgs
             StepArgs s2 = sa;
             s2.station_filter = k;
             hipEvent_t e0 = k == 0 ? ev0 : nullptr, e1 = k == 1 ? ev1 : nullptr;
-            if (hp.S[k] > 64) CHUB_LAUNCH((k_slot_unit<RESET, MODE>), dim3((unsigned) hp.n_envs), dim3(256), stream, e0, e1, ctx, s2, k);
+            if (hp.S[k] > 256) CHUB_LAUNCH((k_slot_unit_any<RESET, MODE>), dim3((unsigned) hp.n_envs), dim3(256), stream, e0, e1, ctx, s2, k);
+            else if (hp.S[k] > 64) CHUB_LAUNCH((k_slot_unit<RESET, MODE>), dim3((unsigned) hp.n_envs), dim3(256), stream, e0, e1, ctx, s2, k);
             else CHUB_LAUNCH((k_slot<RESET, MODE, BLOCK>), dim3((unsigned) (k ? nb1 : nb0)), dim3(BLOCK), stream, e0, e1, ctx, s2, nb0);
         }
     }

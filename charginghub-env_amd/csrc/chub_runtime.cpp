@@ -406,9 +406,10 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     if (rng_mode != CHUB_RNG_COMPAT && rng_mode != CHUB_RNG_PHILOX) return fail(CHUB_ERR_ARG, "unknown rng_mode");
     for (int k = 0; k < 2; k++) {
         if (cfg->station_list[k] < 0) return fail(CHUB_ERR_ARG, "station_list entries must be >= 0");
-        // the production (PHILOX) kernel lays whole envs over a workgroup's 512 virtual lanes and counts car_number in 16 bits;
-        // the wave-local kernels keep a unit of up to 64 piles inside a wave and give a larger one a workgroup of 256 lanes
-        if (cfg->station_list[k] > 256) return fail(CHUB_ERR_UNSUPPORTED, "more than 256 piles per station is not supported");
+        // the production (PHILOX) kernel lays whole envs over a workgroup's 512 (2048) virtual lanes; the wave-local kernels keep a unit
+        // of up to 64 piles inside a wave, give a larger one a workgroup of 256 lanes (k_slot_unit) and walk a unit of more than 256
+        // piles in chunks (k_slot_unit_any, whose scalar-load control ranks the whole unit in LDS: kMaxPiles)
+        if (cfg->station_list[k] > kMaxPiles) return fail(CHUB_ERR_UNSUPPORTED, "more than 4096 piles per station is not supported");
         if (cfg->station_type_list[k] != CHUB_FAST && cfg->station_type_list[k] != CHUB_SLOW)
             return fail(CHUB_ERR_ARG, "EVS type must be fast or slow");  // AGG:196
     }

@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define ORC_MAX_PILES 256
+#ifndef ORC_MAX_PILES
+#define ORC_MAX_PILES 256 /* piles per station the plain arrays below hold; liboracle_big.so is the same source with -DORC_MAX_PILES=4096 (stations of more than 256 piles: tests/test_gpu_big_stations.py, the env_big_300_270 fixture) */
+#endif
 #define ORC_CDF_ROWS 96
 #define ORC_CDF_COLS 301
 #define ORC_SOC_LEVELS 2048 /* PHILOX mode: equiprobable levels of the EV arrival SoC */

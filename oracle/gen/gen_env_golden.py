@@ -306,6 +306,11 @@ def main():
     out = run("env_tank_floor", base_kwargs(init_soc=0.1, fcev_permeate=0.03, hydro_store_vlt=5), 1, 96, "random", (4141, 4242), py_seed=21)
     assert out["telem"][:, 7].max() > 0, "no unmet demand in this fixture"
     run("env_tank_brim", base_kwargs(init_soc=1.0, hydro_store_vlt=5, station_list=[6, 9]), 1, 96, "random", (4343, 4444), py_seed=22)
+    # ---- round 6 (appended: the fixtures above come out as before) ----
+    # stations of more than 256 piles (the reference takes any count, CHS:1148, 1458): 300 fast + 270 slow -- a unit is walked in chunks of
+    # 256 piles (k_slot_unit_any); evs_reset admits ~ S / 2 cars at once, the arrival SoCs' and stays' draws run across the chunks
+    run("env_big_300_270", base_kwargs(station_list=[300, 270], hydro_prod_rate=2000, hydro_store_vlt=5000, init_soc=0.5,
+                                       fcev_permeate=0.02), 2, 30, "random", (4545, 4646), py_seed=23)
 
 
 if __name__ == "__main__":

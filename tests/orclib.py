@@ -1,13 +1,15 @@
 """ctypes bindings for the test-side libraries (TEST INFRASTRUCTURE).
 
-* ``orc``  -> oracle/liboracle.so   : the CPU restatement (plain C)
+* ``orc``  -> oracle/liboracle.so   : the CPU restatement (plain C); ``big_oracle()`` -> liboracle_big.so
 * ``ref()`` -> oracle/_ref/libchs_ref.so : the real reference C++ core compiled from
   /root/reference (present only where it was built; its static initialiser reads
   ``car_flow_possibility_list_save.csv`` from the CWD, CHS.hpp:175, so we chdir for the load).
 """
+import contextlib
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -47,16 +49,16 @@ def make_config(piles=(20, 25), types=("fast", "slow"), constant_charging=False,
     return c
 
 
-def _build_oracle():
-    so = os.path.join(ORACLE_DIR, "liboracle.so")
-    src = os.path.join(ORACLE_DIR, "chub_oracle.c")
-    if (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+def _build_oracle(name="liboracle.so"):
+    so = os.path.join(ORACLE_DIR, name)
+    srcs = [os.path.join(ORACLE_DIR, "chub_oracle.c"), os.path.join(ORACLE_DIR, "chub_oracle.h")]
+    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, name], stdout=subprocess.DEVNULL)
     return so
 
 
-def _load_oracle():
-    lib = C.CDLL(_build_oracle())
+def _load_oracle(name="liboracle.so"):
+    lib = C.CDLL(_build_oracle(name))
     P, I, D, F = C.c_void_p, C.c_int, C.c_double, C.c_float
     sig = {
         "orc_parse_float": (F, [C.c_char_p, I]),
@@ -133,6 +135,26 @@ def _load_oracle():
 
 orc = _load_oracle()
 _tables = None
+_big = None
+
+
+@contextlib.contextmanager
+def big_oracle(*modules):
+    """Stations of more than 256 piles: inside the block `orclib.orc` -- and the name `orc` of every module given -- is
+    liboracle_big.so, the same source compiled with room for 4096 piles per station (ORC_MAX_PILES).  The tables are plain data
+    and shared."""
+    global orc, _big
+    if _big is None:
+        _big = _load_oracle("liboracle_big.so")
+    me = sys.modules[__name__]
+    saved = [(m, m.orc) for m in (me,) + tuple(modules)]
+    try:
+        for m, _ in saved:
+            m.orc = _big
+        yield _big
+    finally:
+        for m, o in saved:
+            m.orc = o
 
 
 def tables():
@@ -287,6 +309,10 @@ GOLDEN_ENV = ["env_c1_envtest", "env_c3_random", "env_c2_random", "env_c5_random
               "env_defaults",
               # the tank at its 10 % floor from the first step on (unmet forecourt demand) and full to the brim (the electrolyser idles)
               "env_tank_floor", "env_tank_brim"]
+
+
+# round 6: stations of more than 256 piles (300 fast + 270 slow) -- the oracle side of these runs on liboracle_big.so (big_oracle())
+GOLDEN_ENV_BIG = ["env_big_300_270"]
 
 
 class OrcEnv:

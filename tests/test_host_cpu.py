@@ -90,9 +90,10 @@ def test_create_fails_loudly_without_gpu_and_validates_arguments():
     bad = m.make_config([0, 0], ["fast", "slow"])
     assert lib.chub_create(C.byref(bad), data, 4, 0, 0, 1, _lib.RNG_PHILOX, C.byref(h)) == -1
     assert b"must have fast pile or slow pile" in lib.chub_last_error()  # MGR:336
-    big = m.make_config([257, 1], ["fast", "slow"])
+    big = m.make_config([4097, 1], ["fast", "slow"])  # stations of up to 4096 piles (the reference: any count, CHS.hpp:1148, 1458)
     assert lib.chub_create(C.byref(big), data, 4, 0, 0, 1, _lib.RNG_PHILOX, C.byref(h)) == -4
-    big = m.make_config([65, 257], ["fast", "slow"])  # COMPAT streams take stations of up to 256 piles too (the reference: any size)
+    assert b"4096 piles" in lib.chub_last_error()
+    big = m.make_config([65, 4097], ["fast", "slow"])  # ... in both RNG modes
     assert lib.chub_create(C.byref(big), data, 4, 0, 0, 1, _lib.RNG_COMPAT, C.byref(h)) == -4
     lowsoc = m.make_config([4, 4], ["fast", "slow"], init_soc=0.05)
     assert lib.chub_create(C.byref(lowsoc), data, 4, 0, 0, 1, _lib.RNG_PHILOX, C.byref(h)) == -1  # HYD:137

@@ -22,6 +22,17 @@ def replay(name, make_env_and_check):
 
 @pytest.mark.parametrize("name", orclib.GOLDEN_ENV)
 def test_env_trajectory_matches_reference(name):
+    _check_trajectory(name)
+
+
+@pytest.mark.parametrize("name", orclib.GOLDEN_ENV_BIG)
+def test_env_trajectory_matches_reference_on_stations_of_more_than_256_piles(name):
+    """The same check on liboracle_big.so (the same source with room for 4096 piles per station)."""
+    with orclib.big_oracle():
+        _check_trajectory(name)
+
+
+def _check_trajectory(name):
     g = orclib.load_golden(name)
     cfg = orclib.golden_config(g)
     steps = int(g["steps_per_episode"])

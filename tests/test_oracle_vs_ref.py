@@ -162,6 +162,20 @@ def test_station_trajectories(typ, piles, kind):
             assert np.array_equal(a.scalars(), b.scalars()), (ep, step, a.scalars(), b.scalars())
 
 
+@pytest.mark.parametrize("typ,piles,kind", [(FAST, 300, "random"), (SLOW, 1000, "random"), (SLOW, 1500, "zeros"), (FAST, 4096, "ones")])
+def test_station_trajectories_beyond_256_piles(typ, piles, kind):
+    """Round 6: liboracle_big.so (the same source, ORC_MAX_PILES = 4096) against the reference on stations of more than 256 piles
+    -- evs_reset then admits more cars than the balk test's exp(-0.01 (line + j)) leaves any level but 0 (j > 690)."""
+    with orclib.big_oracle():
+        test_station_trajectories(typ, piles, kind)
+
+
+@pytest.mark.parametrize("typ,piles,cc", [(FAST, 300, False), (SLOW, 700, True), (FAST, 1100, False)])
+def test_station_scalar_load_mode_beyond_256_piles(typ, piles, cc):
+    with orclib.big_oracle():
+        test_station_scalar_load_mode(typ, piles, cc)
+
+
 @pytest.mark.parametrize("typ,piles", [(FAST, 20), (SLOW, 25), (FAST, 100), (SLOW, 170)])
 @pytest.mark.parametrize("cc", [False, True])
 def test_station_scalar_load_mode(typ, piles, cc):
