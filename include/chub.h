@@ -49,7 +49,8 @@ enum { CHUB_RNG_COMPAT = 0, CHUB_RNG_PHILOX = 1 };
 /* Constructor kwargs of EvcsspManagerEnv_v6 (MGR:25-27), same names and meaning.  use_lagrange is
  * ignored by the reference (MGR:126) and has no field.  seed_rand maps to the seeds given at create. */
 typedef struct chub_config {
-    int32_t station_list[2];      /* piles per station; 0 = station absent from obs but still simulated */
+    int32_t station_list[2];      /* piles per station; 0 = station absent from obs but still simulated.  At most 4096 per station (the reference's
+                                     constructors take any count, CHS.hpp:1148, 1458): CHUB_ERR_UNSUPPORTED beyond -- see INTEGRATION.md */
     int32_t station_type_list[2]; /* CHUB_FAST / CHUB_SLOW */
     int32_t constant_charging;
     int32_t reserved0;

@@ -53,6 +53,66 @@ def test_subset_resets_and_steps_on_stations_of_more_than_256_piles(monkeypatch)
         clocks.test_subset_resets_and_steps_match_the_oracle("huge")
 
 
+def test_step_bits_on_stations_of_more_than_256_piles(monkeypatch):
+    """one bit per pile as the action input (chub_step_bits: ceil(S / 64) words per env) == the f32 action rows, bit for bit"""
+    kw = dict(BIG_KW, station_list=[300, 270], station_type_list=["fast", "slow"])
+    monkeypatch.setattr(parity, "PHILOX_CASES", parity.PHILOX_CASES + [("big_300_270", kw, 6)])
+    parity.test_step_bits_equals_step_on_the_thresholded_actions("big_300_270")
+
+
+def test_graph_replay_and_run_steps_on_stations_of_more_than_256_piles():
+    """the same two days three ways -- calls made one by one, chub_run_steps (issued from C), chub_run_steps inside a hipGraph -- on a hub
+    whose units are walked in chunks: outputs, slot state, station records and clock bit for bit"""
+    import ctypes as C
+    chub = parity.hub()
+    from charginghub_env_amd import multi_gpu
+    from charginghub_env_amd._lib import check
+    kw = dict(BIG_KW, station_list=[260, 513], station_type_list=["fast", "slow"])
+    n = 24
+    res = []
+    for form in ("python", "c", "c_in_graph"):
+        v = chub.VecChargingHub(n, seed=12, rng="philox", **kw)
+        st = multi_gpu.Stream(0)
+        acts = [multi_gpu.DeviceBuffer(n * v.act_dim * 4) for _ in range(3)]
+        for b, a in enumerate(acts):
+            v.random_actions_device(a.ptr, 5, b, st.ptr)
+        packed = [multi_gpu.DeviceBuffer(n * (v.obs_dim + 2) * 4) for _ in range(2)]
+        obs0 = multi_gpu.DeviceBuffer(n * v.obs_dim * 4)
+        c_acts = (C.c_void_p * 3)(*[a.ptr for a in acts])
+        c_packed = (C.c_void_p * 2)(packed[0].ptr, packed[1].ptr)
+
+        def span(first, count):
+            if form == "python":
+                for i in range(first, first + count):
+                    if i % 96 == 0:
+                        v.reset_device(obs0.ptr, stream=st.ptr)
+                    v.step_device_packed(acts[i % 3].ptr, packed[i & 1].ptr, stream=st.ptr)
+            else:
+                check(v._lib.chub_run_steps(v._h, None, c_acts, 3, c_packed, None, obs0.ptr, first, count, st.ptr))
+
+        span(0, 40)
+        trace = [packed[1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr)]
+        if form == "c_in_graph":
+            st.sync()
+            v.graph_begin(st.ptr)
+            span(40, 79)  # ... across a day boundary: 79 steps + 1 reset = an even number of calls
+            g = v.graph_end(st.ptr)
+            v.graph_launch(g, st.ptr)
+            st.sync()
+            v.graph_destroy(g)
+        else:
+            span(40, 79)
+        trace.append(packed[(40 + 79 - 1) & 1].to_host(np.float32, (n, v.obs_dim + 2), st.ptr))
+        trace += [np.concatenate([x.reshape(n, -1) for x in v.slots()], axis=1), v.station_scalars().reshape(n, -1), np.array([v.clock])]
+        res.append(trace)
+        v.close()
+        st.destroy()
+    for k in range(len(res[0])):
+        assert np.array_equal(res[0][k], res[1][k]), ("python vs c", k)
+        assert np.array_equal(res[0][k], res[2][k]), ("python vs c in a graph", k)
+    assert res[0][-1][0] == (40 + 79) % 96
+
+
 def test_more_than_4096_piles_per_station_is_refused():
     chub = parity.hub()
     with pytest.raises(chub.ChubError) as ei:
