@@ -55,6 +55,9 @@ constexpr int kSlotsPerLane = CHUB_SLOTS_PER_LANE;  // packed slot kernel: slots
 #define CHUB_BIG_SLOTS_PER_LANE 4
 #endif
 constexpr int kBigBlock = CHUB_BIG_BLOCK, kBigSlotsPerLane = CHUB_BIG_SLOTS_PER_LANE;
+#ifndef CHUB_XCD_ANY_TILE
+#define CHUB_XCD_ANY_TILE 0  // (tile experiments: 1 = the second tile also takes the XCD-aware order while the streams are cache-resident)
+#endif
 constexpr int64_t kBigTileSlots = (int64_t) 10 << 20;  // handles of at least this many charger slots take the second tile (chub_options.tile overrides)
 constexpr int64_t kXcdOrderSlots = (int64_t) 6 << 20;  // handles of at most this many charger slots (their streams live in the caches) run their
                                                        // step kernels in XCD-aware work order

@@ -731,7 +731,7 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
         hp.pblock = big_tile ? kBigBlock : kPackedBlock;
         hp.pslots = big_tile ? kBigSlotsPerLane : kSlotsPerLane;
         // ... and the work order: XCD-aware while the streams are cache-resident (measured: 4-6 % of the step; HBM-resident sizes lose 1 %)
-        hp.xcd = (opt.work_order == 0 && !big_tile && n_envs * (int64_t) St <= kXcdOrderSlots) ? 1 : 0;
+        hp.xcd = (opt.work_order == 0 && (!big_tile || CHUB_XCD_ANY_TILE) && n_envs * (int64_t) St <= kXcdOrderSlots) ? 1 : 0;
         const int pb = hp.pblock * hp.pslots;
         hp.epb = pb / St > 0 ? pb / St : 1;
         if (hp.epb > pb / 4) hp.epb = pb / 4;  // the workgroup's per-unit LDS areas hold 2 * pb / 4 units: hubs of 1-3 piles leave lanes idle
