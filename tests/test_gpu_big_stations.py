@@ -46,6 +46,57 @@ def test_scalar_load_mode_matches_oracle_on_stations_of_more_than_256_piles(pile
         parity.test_scalar_load_mode_matches_oracle(piles, rng, cc)
 
 
+def compat_parity(piles, types, n, steps, cc=False, seed=99):
+    """COMPAT handles against the oracle on the reference's own streams (per-env glibc rand() + minstd_rand0), the caller's normals and days:
+    per-slot state and station records bit for bit, f64 observation / reward to 1e-9 -- resets at the start and after `steps // 2` steps"""
+    import ctypes as C
+    from orclib import ptr
+    chub = parity.hub()
+    kw = dict(BIG_KW, station_list=list(piles), station_type_list=list(types), constant_charging=cc, renew_fluctuate=0.2, price_fluctuate=0.1,
+              hydro_loss=0.001)
+    with orclib.big_oracle(parity) as orc:
+        v = chub.VecChargingHub(n, seed=seed, rng="compat", **kw)
+        v.set_telemetry(True)
+        cfg = orclib.make_config(piles=kw["station_list"], types=kw["station_type_list"],
+                                 **{k: kw[k] for k in kw if k not in ("station_list", "station_type_list")})
+        h = orc.orc_vec_create(C.byref(cfg), orclib.tables(), n, 0, orclib.COMPAT, seed)
+        rs = np.random.RandomState(piles[0] * 31 + piles[1])
+        o_obs, o_rew, o_done = np.zeros((n, v.obs_dim)), np.zeros(n), np.zeros(n, dtype=np.uint8)
+        for t in range(steps):
+            if t in (0, steps // 2):
+                days = np.stack([rs.randint(0, 100, n), rs.randint(0, 150, n)], axis=1).astype(np.int32)
+                z = rs.normal(size=(n, 3))
+                v.reset(days, z)
+                orc.orc_vec_reset(h, ptr(days), ptr(z), ptr(o_obs))
+                parity.close(v.obs_f64(), o_obs, (piles, "reset obs", t), rtol=parity.TIGHT, atol=parity.TIGHT)
+            act = rs.uniform(-1, 1, size=(n, v.act_dim)).astype(np.float32)
+            if t % 7 == 3:
+                act[:, :sum(piles)] = 1.0
+            z = rs.normal(size=(n, 3))
+            v.step(act, z)
+            orc.orc_vec_step(h, ptr(act), ptr(z), ptr(o_obs), ptr(o_rew), ptr(o_done), 2)
+            sl, sc = v.slots(), v.station_scalars()
+            for e in range(n):
+                env = orc.orc_vec_env(h, e)
+                for k, nk in ((0, piles[0]), (1, piles[1])):
+                    want = np.zeros((9, nk), dtype=np.float32)
+                    orc.orc_station_slots(orc.orc_env_station(env, k), ptr(want))
+                    parity.check_slots(sl[k][e], want, ("compat", piles, t, e, k))
+                    ws = np.zeros(8)
+                    orc.orc_station_scalars(orc.orc_env_station(env, k), ptr(ws))
+                    assert np.array_equal(sc[e, k, :6], ws[:6]), (piles, t, e, k, sc[e, k], ws)  # the sums in the reference's f32 order
+            parity.close(v.obs_f64(), o_obs, (piles, "obs", t), rtol=parity.TIGHT, atol=parity.TIGHT)
+            parity.close(v.reward_f64(), o_rew, (piles, "reward", t), rtol=parity.TIGHT, atol=parity.TIGHT)
+        orc.orc_vec_destroy(h)
+        v.close()
+
+
+@pytest.mark.parametrize("piles,types,n,cc", [((257, 64), ("fast", "slow"), 4, False), ((40, 1030), ("slow", "fast"), 3, False),
+                                              ((600, 300), ("fast", "slow"), 2, True)])
+def test_compat_matches_oracle_on_stations_of_more_than_256_piles(piles, types, n, cc):
+    compat_parity(piles, types, n, 60, cc)
+
+
 def test_subset_resets_and_steps_on_stations_of_more_than_256_piles(monkeypatch):
     """chub_reset_envs / chub_step_envs: the whole workgroup of a unit whose env is not named leaves it alone"""
     monkeypatch.setitem(clocks.SHAPES, "huge", (dict(clocks.KW, station_list=[300, 260]), "auto"))
