@@ -261,3 +261,48 @@ def test_level_and_day_uniforms():
         assert np.abs(counts / TWO32 - 1.0 / m).max() <= 2.0 ** -32
     # the reference's own modulo bias is of the same kind: rand() is uniform on [0, 2^31), 2^31 % 1000 = 648
     assert (2**31 % 1000) / 2.0**31 < 1e-6
+
+
+# ---- hy_power_speed_list: the constructor's 101-step sweep with LIVE forecourt demand (HYD:154-157) against the zero-demand sweep
+SWEEP_SAME = {
+    "c2": dict(piles=(16, 0), hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2, fcev_permeate=0.0),
+    "c3_c4": dict(piles=(20, 25), hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2, fcev_permeate=0.01),
+    "c5": dict(piles=(32, 32), hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2, fcev_permeate=0.01, renew_fluctuate=0.3, price_fluctuate=0.3),
+    "defaults": dict(piles=(20, 25), hydro_prod_rate=430.0, hydro_store_vlt=5000.0, init_soc=0.5, fcev_permeate=0.01),
+    "busy_forecourt": dict(piles=(20, 25), hydro_prod_rate=100.0, hydro_store_vlt=25.0, init_soc=0.2, fcev_permeate=0.1),
+    "big_electrolyser": dict(piles=(100, 70), hydro_prod_rate=2000.0, hydro_store_vlt=5000.0, init_soc=0.5, fcev_permeate=0.02),
+}
+SWEEP_DIFFERENT = {
+    "tank_floor": dict(piles=(20, 25), hydro_prod_rate=100.0, hydro_store_vlt=5.0, init_soc=0.1, fcev_permeate=0.03),
+    "tank_brim": dict(piles=(6, 9), hydro_prod_rate=100.0, hydro_store_vlt=5.0, init_soc=1.0, fcev_permeate=0.01),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SWEEP_SAME))
+def test_live_demand_sweep_equals_the_zero_demand_table_where_no_tank_clamp_binds(name):
+    """The reference builds hy_power_speed_list with 101 real hy_step()s whose forecourt draws cars (HYD:154-157); the production (PHILOX)
+    mode keeps ONE table per handle, swept without demand.  Demand reaches a table entry only through the tank's two clamps
+    (must_charge / upper_charge, HYD:172-176): on every BASELINE.json configuration, the reference's own defaults and a forecourt ten times as
+    busy the two tables are the SAME 102 doubles, bit for bit, for each of 300 constructor seeds -- there the production mode's table IS the
+    reference's."""
+    cfg = orclib.make_config(**SWEEP_SAME[name])
+    zero = orclib.OrcEnv(cfg).hy_table()
+    assert zero.max() > 0
+    for s in range(1, 301):
+        live = orclib.OrcEnv(cfg, ctor_seeds=(s, 7 * s + 1)).hy_table()
+        assert np.array_equal(live, zero), (name, s, np.nonzero(live != zero)[0][:5])
+
+
+@pytest.mark.parametrize("name", sorted(SWEEP_DIFFERENT))
+def test_where_the_zero_demand_table_is_not_the_reference_s(name):
+    """... and where it is not: a SMALL tank that starts AT one of the two ends of its range (5 m^3 at init_soc = 0.1 / 1.0).  In the reference's
+    sweep the forecourt takes out what the electrolyser puts in (the tank stays at its floor / never fills: the upper entries keep the
+    electrolyser's full power), in the sweep without demand the tank fills up within the 101 steps and the upper entries fall to zero.  There
+    the production mode's table is NOT the reference's: handles that need the reference's law for such a hub run COMPAT, whose constructor
+    replay reproduces the table per env bit for bit (tests/test_oracle_golden.py: env_tank_floor, env_tank_brim, env_full_tank).  Written
+    down so that the difference has a test that names it."""
+    cfg = orclib.make_config(**SWEEP_DIFFERENT[name])
+    zero = orclib.OrcEnv(cfg).hy_table()
+    tables = np.array([orclib.OrcEnv(cfg, ctor_seeds=(s, 7 * s + 1)).hy_table() for s in range(1, 41)])
+    assert (np.abs(tables - zero).max(axis=1) > 0).all()   # every seed's table differs from the zero-demand one
+    assert zero[-1] == 0.0 and (tables[:, -1] > 400.0).all()  # ... at the top: zero against the electrolyser's full power
