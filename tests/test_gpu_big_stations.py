@@ -164,6 +164,36 @@ def test_graph_replay_and_run_steps_on_stations_of_more_than_256_piles():
     assert res[0][-1][0] == (40 + 79) % 96
 
 
+def test_many_chunked_units_at_once_are_shard_independent_and_deterministic():
+    """1024 envs x [300, 270]: 2048 workgroups of the chunked unit kernel per step -- the handle as a whole == its two halves created
+    with their global env ids (Philox counters are keyed by the global id), twice the same; occupancy bookkeeping holds (a station's
+    car_number is the number of its occupied piles)"""
+    chub = parity.hub()
+    kw = dict(BIG_KW, station_list=[300, 270], station_type_list=["fast", "slow"])
+    N = 1024
+    whole = chub.VecChargingHub(N, seed=777, rng="philox", **kw)
+    again = chub.VecChargingHub(N, seed=777, rng="philox", **kw)
+    a = chub.VecChargingHub(N // 2, seed=777, rng="philox", env_id0=0, **kw)
+    b = chub.VecChargingHub(N // 2, seed=777, rng="philox", env_id0=N // 2, **kw)
+    rs = np.random.RandomState(3)
+    o = whole.reset()
+    assert np.array_equal(o, again.reset()) and np.array_equal(o, np.concatenate([a.reset(), b.reset()]))
+    for t in range(30):
+        act = rs.uniform(-1, 1, size=(N, whole.act_dim)).astype(np.float32)
+        o, r, d, _ = whole.step(act)
+        o2, r2, _, _ = again.step(act)
+        oa, ra, _, _ = a.step(act[:N // 2])
+        ob, rb, _, _ = b.step(act[N // 2:])
+        assert np.array_equal(o, o2) and np.array_equal(r, r2), t
+        assert np.array_equal(o, np.concatenate([oa, ob])) and np.array_equal(r, np.concatenate([ra, rb])), t
+    sl, sc = whole.slots(), whole.station_scalars()
+    for k in (0, 1):
+        assert np.array_equal((sl[k][:, 0, :] > 0).sum(axis=1), sc[:, k, 3].astype(np.int64)), k  # slot field 0 = car, station scalar 3 = car_number
+    assert all(np.array_equal(x, np.concatenate([y, z])) for x, y, z in zip(sl, a.slots(), b.slots()))
+    for v in (whole, again, a, b):
+        v.close()
+
+
 def test_more_than_4096_piles_per_station_is_refused():
     chub = parity.hub()
     with pytest.raises(chub.ChubError) as ei:
