@@ -194,6 +194,39 @@ def test_many_chunked_units_at_once_are_shard_independent_and_deterministic():
         v.close()
 
 
+def test_the_big_fixture_with_every_env_on_its_own_clock():
+    """env_big_300_270 replayed by four envs of one handle, each a different number of calls behind (some are reset while others step):
+    the masked calls of the chunked unit kernel against the reference's recorded run, bit for bit"""
+    clocks.test_compat_envs_replay_the_reference_fixture_on_their_own_clocks("env_big_300_270", "wave")
+
+
+@pytest.mark.parametrize("rng", ["philox", "compat"])
+def test_snapshot_restore_in_place_on_stations_of_more_than_256_piles(rng):
+    """chub_get_state / chub_set_state on the SAME stepped handle: branching from a snapshot replays the same future bit for bit"""
+    chub = parity.hub()
+    kw = dict(BIG_KW, station_list=[300, 270], station_type_list=["fast", "slow"])
+    n = 12
+    v = chub.VecChargingHub(n, seed=5, rng=rng, **kw)
+    rs = np.random.RandomState(0)
+    days = np.stack([rs.randint(0, 100, n), rs.randint(0, 150, n)], axis=1) if rng == "compat" else None
+    z = (lambda: rs.normal(size=(n, 3))) if rng == "compat" else (lambda: None)
+    v.reset(days, z())
+    acts = [rs.uniform(-1, 1, size=(n, v.act_dim)).astype(np.float32) for _ in range(30)]
+    zs = [z() for _ in range(30)]
+    for t in range(8):
+        v.step(acts[t], zs[t])
+    snap = v.get_state()
+    first = [v.step(acts[t], zs[t]) for t in range(8, 30)]
+    slots_a, sc_a = v.slots(), v.station_scalars()
+    v.set_state(snap)
+    assert v.clock == 8
+    second = [v.step(acts[t], zs[t]) for t in range(8, 30)]
+    for a, b in zip(first, second):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert all(np.array_equal(x, y) for x, y in zip(slots_a, v.slots())) and np.array_equal(sc_a, v.station_scalars())
+    v.close()
+
+
 def test_more_than_4096_piles_per_station_is_refused():
     chub = parity.hub()
     with pytest.raises(chub.ChubError) as ei:
