@@ -727,7 +727,8 @@ int chub_create_ex(const chub_config *cfg, const char *data_dir, int64_t n_envs,
     {
         const int St = hp.S[0] + hp.S[1];
         // the workgroup tile: the small one while state and action rows live in the caches, the large one once they stream from HBM
-        const bool big_tile = opt.tile == 2 || (opt.tile == 0 && n_envs * (int64_t) St >= kBigTileSlots);
+        // (a hub too large for the small tile's 512 virtual lanes -- stations of several hundred piles -- still fits the large one's 2048)
+        const bool big_tile = opt.tile == 2 || (opt.tile == 0 && (n_envs * (int64_t) St >= kBigTileSlots || St > kPackedBlock * kSlotsPerLane));
         hp.pblock = big_tile ? kBigBlock : kPackedBlock;
         hp.pslots = big_tile ? kBigSlotsPerLane : kSlotsPerLane;
         // ... and the work order: XCD-aware while the streams are cache-resident (measured: 4-6 % of the step; HBM-resident sizes lose 1 %)

@@ -81,8 +81,9 @@ typedef struct chub_options {
                              (hub shapes the packed slot kernel covers, stations of at most 64 piles).  Results are bit-identical.
                              COMPAT handles whose envs all fit one workgroup (the drop-in class: one env) run reset and step as one
                              launch too -- station 0, station 1, tail back to back -- unless this is 1. */
-    int32_t tile;         /* workgroup tile of the packed slot kernel: 0 = by working-set size (default), 1 = 256 lanes x 2 slots (state
-                             and action rows live in the caches), 2 = 512 lanes x 4 slots (they stream from HBM).  Results are bit-identical. */
+    int32_t tile;         /* workgroup tile of the packed slot kernel: 0 = by working-set size (default; a hub of more than 512 piles takes the
+                             second tile whatever its batch), 1 = 256 lanes x 2 slots (state and action rows live in the caches), 2 = 512 lanes
+                             x 4 slots (they stream from HBM).  Results are bit-identical. */
     int32_t walk_ahead;   /* COMPAT split step: 0 = lock-step steps of every env walk the streams ahead of their step (default): stations of 8 to 64
                              piles run the slot pass of step i and the stream walks of step i + 1 in ONE launch (the walk two steps ahead of the
                              slots it draws for: it takes the slots that will be empty from the stays alone), other shapes the tails of step i

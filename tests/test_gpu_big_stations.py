@@ -31,10 +31,42 @@ def test_compat_matches_reference_golden_on_stations_of_more_than_256_piles(name
     ("512_1000", [512, 1000], ["fast", "slow"], 2, (30, 10)),    # whole chunks; evs_reset admits ~ 500 cars (balk places beyond 690)
     ("4096_3", [4096, 3], ["slow", "fast"], 1, (12, 6)),         # the largest station the library takes
 ])
-def test_philox_matches_oracle_on_stations_of_more_than_256_piles(label, piles, types, n, plan):
+@pytest.mark.parametrize("slot_kernel", ["auto", "wave"])
+def test_philox_matches_oracle_on_stations_of_more_than_256_piles(label, piles, types, n, plan, slot_kernel):
+    """auto: the packed production kernel wherever the hub fits one of its tiles (512 piles, 2048 on the large tile, which a hub of more
+    than 512 piles takes by itself) and its lanes divide by the hub's size with the 20-bit reciprocal, the chunked unit kernel otherwise;
+    wave: always the wave-local / unit / chunked kernels (chub_options.slot_kernel = 1)"""
     kw = dict(BIG_KW, station_list=piles, station_type_list=types)
     with orclib.big_oracle(parity):
-        parity._philox_parity("big_" + label, kw, n, plan=plan)
+        parity._philox_parity("big_" + label + "_" + slot_kernel, kw, n, plan=plan if slot_kernel == "auto" else plan[:1], slot_kernel=slot_kernel)
+
+
+@pytest.mark.parametrize("piles,packed", [([300, 270], 1), ([257, 257], 1), ([700, 60], 1), ([1000, 1000], 0)])
+def test_philox_on_the_large_tile_with_stations_of_more_than_256_piles(piles, packed, monkeypatch):
+    """Where the whole hub fits the packed production kernel's tile (512 piles; 2048 on the large tile, which handles of 10 M slots and more
+    take by themselves) a station of more than 256 piles is simply a unit that spans more of the workgroup's waves: the packed kernel on
+    the large tile against the oracle.  [1000, 1000] does not divide the tile's lanes by its 20-bit reciprocal: the chunked kernel again."""
+    chub = parity.hub()
+    orig = chub.VecChargingHub
+
+    def on_the_large_tile(*a, **k):
+        k.setdefault("tile", "large")
+        v = orig(*a, **k)
+        assert v._lib.chub_uses_packed_kernel(v._h) == packed
+        return v
+
+    monkeypatch.setattr(chub, "VecChargingHub", on_the_large_tile)
+    kw = dict(BIG_KW, station_list=piles, station_type_list=["fast", "slow"])
+    with orclib.big_oracle(parity):
+        parity._philox_parity("large_tile_%d_%d" % tuple(piles), kw, 3, plan=(60, 12))
+
+
+def test_production_kernel_replays_the_big_fixture_in_tape_mode():
+    """The PRODUCTION (PHILOX) kernels against the reference directly: env_big_300_270's recorded decisions (queue / arrival / admission,
+    per car its arrival SoC, target level and extra stay, the tail's variates) fed through k_slot_packed on the large tile and k_env --
+    per-slot state bit for bit, station sums within the bars derived from the two summation orders (tests/test_gpu_tape.py)"""
+    import test_gpu_tape as tape
+    tape.test_packed_kernel_replays_reference_fixture("env_big_300_270", tile="large")
 
 
 @pytest.mark.parametrize("cc", [False, True])
@@ -166,14 +198,15 @@ def test_graph_replay_and_run_steps_on_stations_of_more_than_256_piles():
 
 def test_many_chunked_units_at_once_are_shard_independent_and_deterministic():
     """1024 envs x [300, 270]: 2048 workgroups of the chunked unit kernel per step -- the handle as a whole == its two halves created
-    with their global env ids (Philox counters are keyed by the global id), twice the same; occupancy bookkeeping holds (a station's
-    car_number is the number of its occupied piles)"""
+    with their global env ids (Philox counters are keyed by the global id) == the same handle on the packed production kernel (large
+    tile), observation and reward bit for bit; occupancy bookkeeping holds (a station's car_number is the number of its occupied piles)"""
     chub = parity.hub()
     kw = dict(BIG_KW, station_list=[300, 270], station_type_list=["fast", "slow"])
     N = 1024
-    whole = chub.VecChargingHub(N, seed=777, rng="philox", **kw)
-    again = chub.VecChargingHub(N, seed=777, rng="philox", **kw)
-    a = chub.VecChargingHub(N // 2, seed=777, rng="philox", env_id0=0, **kw)
+    whole = chub.VecChargingHub(N, seed=777, rng="philox", slot_kernel="wave", **kw)          # the chunked unit kernel ...
+    again = chub.VecChargingHub(N, seed=777, rng="philox", **kw)                              # ... and the packed one on the large tile
+    assert not whole.uses_packed_kernel and again.uses_packed_kernel
+    a = chub.VecChargingHub(N // 2, seed=777, rng="philox", slot_kernel="wave", env_id0=0, **kw)
     b = chub.VecChargingHub(N // 2, seed=777, rng="philox", env_id0=N // 2, **kw)
     rs = np.random.RandomState(3)
     o = whole.reset()
