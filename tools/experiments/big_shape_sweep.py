@@ -21,7 +21,8 @@ for i in range(args.shapes):
     n = int(rs.randint(1, 5))
     kw = dict(big.BIG_KW, station_list=piles, station_type_list=types, constant_charging=bool(rs.randint(4) == 0))
     with orclib.big_oracle(parity):
-        parity._philox_parity("sweep_%d" % i, kw, n, plan=(30, 12))
+        parity._philox_parity("sweep_%d" % i, kw, n, plan=(30, 12))                            # the packed kernel where the hub fits a tile
+        parity._philox_parity("sweep_%d_wave" % i, kw, n, plan=(30,), slot_kernel="wave")      # ... and the unit / chunked kernels
     big.compat_parity(piles, types, n, 40, cc=kw["constant_charging"], seed=100 + i)
     print("shape", i, piles, types, "envs", n, "cc", kw["constant_charging"], "ok", flush=True)
 print("all", args.shapes, "shapes equal")
